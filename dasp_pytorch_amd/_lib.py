@@ -1,0 +1,76 @@
+"""ctypes binding of libdasp_hip.so (C ABI: include/dasp_hip.h).
+
+There is deliberately no CPU or PyTorch fallback: if the HIP library is missing, or a tensor is
+not on a ROCm device, the call raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdasp_hip.so")
+_lib = None
+
+c_f = ctypes.c_void_p   # device pointers are passed as raw addresses
+_i, _l, _d, _p = ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/dasp_hip.h one to one
+SIGNATURES = {
+    "dasp_sos_supported_sections": (_i, [_i]),
+    "dasp_sos_chunk": (_i, []),
+    "dasp_sos_tile": (_i, []),
+    "dasp_sos_bwd_waves": (_i, []),
+    "dasp_sos_table_floats": (_l, [_i]),
+    "dasp_sos_dtab_doubles": (_l, [_i]),
+    "dasp_sos_num_tiles": (_l, [_l]),
+    "dasp_sos_carry_floats": (_l, [_l, _l, _i]),
+    "dasp_sos_partial_floats": (_l, [_l, _i]),
+    "dasp_sos_prepare": (_i, [_p, _i, _i, _p, _p, _p]),
+    "dasp_peq_prepare": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p]),
+    "dasp_sosfilt_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _p]),
+    "dasp_sosfilt_backward": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
+    "dasp_sos_grad_finalize": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
+}
+
+
+class DaspHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdasp_hip.so once. Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DaspHipError(
+                f"{LIB_PATH} not found: build it with `python -m dasp_pytorch_amd.csrc.build` "
+                "(or __graft_entry__.build()). dasp_pytorch_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(status, f"hipError {status}")
+        raise DaspHipError(f"{what} failed: {kind}")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t, name="x"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise DaspHipError(
+            f"{name} is on {t.device}: dasp_pytorch_amd runs on MI355X (ROCm) devices only and has no CPU path")

@@ -1,0 +1,47 @@
+"""Build libdasp_hip.so (gfx950) in-tree with hipcc. No torch dependency: the library is a plain
+C-ABI shared object (include/dasp_hip.h) that the Python side binds with ctypes."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libdasp_hip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objs = []
+    for src in sources():
+        obj = src[:-4] + ".o"
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(src), *[os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".hpp")]):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

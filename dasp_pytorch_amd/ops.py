@@ -1,0 +1,125 @@
+"""torch.autograd.Function wrappers over the C ABI (include/dasp_hip.h).
+
+PyTorch is used for device memory, streams and autograd plumbing only; every number is produced by
+the HIP kernels in csrc/. Nothing here falls back to torch math on a missing library or a CPU tensor.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+FILTER_TYPES = {"peaking": 0, "low_shelf": 1, "high_shelf": 2, "low_pass": 3, "high_pass": 4}
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _pad_sections(S):
+    """Smallest compiled section count >= S (kernels exist for 2/4/6/8 sections)."""
+    for s in (2, 4, 6, 8):
+        if S <= s:
+            return s
+    raise ValueError("more than 8 sections per call: chain calls (see signal.sosfilt_via_fsm)")
+
+
+class _SosWork:
+    """Device work buffers of one filter application (tables, carries, partial sums)."""
+
+    def __init__(self, Bs, S, device):
+        L = _lib.lib()
+        self.Bs, self.S = Bs, S
+        self.tab = torch.empty(Bs * L.dasp_sos_table_floats(S), dtype=torch.float32, device=device)
+        self.dtab = torch.empty(Bs * L.dasp_sos_dtab_doubles(S), dtype=torch.float64, device=device)
+        self.carries = None
+
+    def forward(self, x, need_grad):
+        L = _lib.lib()
+        B, C, N = x.shape
+        y = torch.empty_like(x)
+        if need_grad:
+            self.carries = torch.empty(L.dasp_sos_carry_floats(B * C, N, self.S), dtype=torch.float32, device=x.device)
+        check(L.dasp_sosfilt_forward(ptr(self.tab), self.Bs, ptr(x), ptr(y), ptr(self.carries), B, C, N, self.S, stream()),
+              "dasp_sosfilt_forward")
+        return y
+
+    def backward(self, x, gy, mode):
+        L = _lib.lib()
+        B, C, N = x.shape
+        gx = torch.empty_like(x)
+        partials = torch.empty(L.dasp_sos_partial_floats(B * C, self.S), dtype=torch.float32, device=x.device)
+        check(L.dasp_sosfilt_backward(ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(partials),
+                                      B, C, N, self.S, stream()), "dasp_sosfilt_backward")
+        gout = torch.empty(B, self.S, 6 if mode == 0 else 3, dtype=torch.float32, device=x.device)
+        check(L.dasp_sos_grad_finalize(ptr(self.dtab), self.Bs, ptr(partials), B, C, self.S, mode, ptr(gout), stream()),
+              "dasp_sos_grad_finalize")
+        if self.Bs == 1 and B != 1:
+            gout = gout.sum(0, keepdim=True)
+        return gx, gout
+
+
+class SosFiltFunction(torch.autograd.Function):
+    """y = cascade of S biquads `sos` (Bs,S,6) applied to x (B,C,N); grads for x and sos."""
+
+    @staticmethod
+    def forward(ctx, sos, x):
+        _lib.require_device(x, "x")
+        _lib.require_device(sos, "sos")
+        L = _lib.lib()
+        Bs, S, _ = sos.shape
+        Sp = _pad_sections(S)
+        sos32 = _f32c(sos)
+        if Sp != S:  # identity sections [1 0 0 1 0 0]
+            pad = torch.zeros(Bs, Sp - S, 6, dtype=torch.float32, device=sos.device)
+            pad[..., 0] = 1.0
+            pad[..., 3] = 1.0
+            sos32 = torch.cat([sos32, pad], 1).contiguous()
+        x32 = _f32c(x)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        w = _SosWork(Bs, Sp, x.device)
+        check(L.dasp_sos_prepare(ptr(sos32), Bs, Sp, ptr(w.tab), ptr(w.dtab), stream()), "dasp_sos_prepare")
+        y = w.forward(x32, need)
+        if need:
+            ctx.work, ctx.S = w, S
+            ctx.save_for_backward(x32)
+        ctx.dtypes = (sos.dtype, x.dtype)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x32,) = ctx.saved_tensors
+        gx, gsos = ctx.work.backward(x32, _f32c(gy), 0)
+        return gsos[:, :ctx.S].to(ctx.dtypes[0]), gx.to(ctx.dtypes[1])
+
+
+class ParametricEQFunction(torch.autograd.Function):
+    """Fused RBJ design (fp64, in-kernel) + cascade. params (Bp,S,3) = [gain_db, cutoff_freq, q_factor]."""
+
+    @staticmethod
+    def forward(ctx, x, params, sample_rate, types):
+        _lib.require_device(x, "x")
+        _lib.require_device(params, "params")
+        L = _lib.lib()
+        Bp, S, _ = params.shape
+        if not L.dasp_sos_supported_sections(S):
+            raise ValueError(f"no kernel compiled for {S} sections")
+        x32, p32 = _f32c(x), _f32c(params)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        w = _SosWork(Bp, S, x.device)
+        ctypes_types = (ctypes.c_int * S)(*types)
+        check(L.dasp_peq_prepare(ptr(p32), Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream()),
+              "dasp_peq_prepare")
+        y = w.forward(x32, need)
+        if need:
+            ctx.work = w
+            ctx.save_for_backward(x32)
+        ctx.dtypes = (x.dtype, params.dtype)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x32,) = ctx.saved_tensors
+        gx, gp = ctx.work.backward(x32, _f32c(gy), 1)
+        return gx.to(ctx.dtypes[0]), gp.to(ctx.dtypes[1]), None, None

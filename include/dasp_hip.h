@@ -1,0 +1,68 @@
+/* dasp_hip.h -- C ABI of libdasp_hip.so: the MI355X (gfx950) hot path of dasp_pytorch.functional.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream (hipStream_t passed as
+ * void*; NULL = the null stream). All launches are asynchronous on that stream, out-of-place, and
+ * never allocate: the caller owns every buffer (sizes come from the *_floats / *_doubles queries).
+ * Return value: 0 = success, >0 = hipError_t of the failed launch, <0 = DASP_ERR_*.
+ *
+ * The reference (csteinmetz1/dasp-pytorch v0.0.1) has no FFI layer -- its boundary is the Python
+ * function API. Each group below names the reference callable (file:line) it replaces; the Python
+ * binding that restores the reference signatures is dasp_pytorch_amd/ (see INTEGRATION.md).
+ */
+#ifndef DASP_HIP_H
+#define DASP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DASP_OK 0
+#define DASP_ERR_ARG (-1)          /* null pointer / inconsistent sizes */
+#define DASP_ERR_UNSUPPORTED (-2)  /* e.g. section count without a compiled kernel */
+
+/* ---------------------------------------------------------------------------------------------
+ * Cascaded biquads.  Replaces dasp_pytorch.signal.sosfilt_via_fsm (dasp_pytorch/signal.py:136-166,
+ * with fft_sosfreqz :14-32, fft_freqz :7-11, freqdomain_fir :35-39) and, through
+ * dasp_peq_prepare, the coefficient design dasp_pytorch.signal.biquad (signal.py:242-306) as used
+ * by dasp_pytorch.functional.parametric_eq (dasp_pytorch/functional.py:118-272).
+ *
+ * x, y, gy, gx: (B, C, N) fp32 contiguous; one filter per batch item shared by its C channels
+ * (signal.py:157-158). Bs = number of filter sets: B, or 1 = broadcast over the batch
+ * (functional.py:208-220). S = sections per filter; compiled for S in {2,4,6,8}.
+ * ------------------------------------------------------------------------------------------- */
+int  dasp_sos_supported_sections(int S);          /* 1 if a kernel for S sections is compiled */
+int  dasp_sos_chunk(void);                        /* samples per lane chunk (L) */
+int  dasp_sos_tile(void);                         /* samples per wave tile (64 L) */
+int  dasp_sos_bwd_waves(void);                    /* waves per row in the backward kernel */
+long dasp_sos_table_floats(int S);                /* fp32 table size per filter set */
+long dasp_sos_dtab_doubles(int S);                /* fp64 side-table size per filter set */
+long dasp_sos_num_tiles(long N);
+long dasp_sos_carry_floats(long rows, long N, int S);   /* rows = B*C */
+long dasp_sos_partial_floats(long rows, int S);
+
+/* sos: (Bs, S, 6) fp32, rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Fills tab / dtab. */
+int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, void* stream);
+
+/* params: (Bs, S, 3) fp32 rows [gain_db, cutoff_freq, q_factor]; types[S] (host array):
+ * 0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass (signal.py:261-297). */
+int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, double sample_rate,
+                     float* tab, double* dtab, void* stream);
+
+/* y = cascade(x). carries (may be NULL when no backward follows) receives the per-tile states. */
+int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries,
+                         int B, int C, long N, int S, void* stream);
+
+/* gx = adjoint cascade(gy); partials receives the per-wave coefficient correlations. */
+int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float* gy,
+                          const float* carries, float* gx, float* partials,
+                          int B, int C, long N, int S, void* stream);
+
+/* mode 0: gout (B, S, 6) = dL/dsos;  mode 1: gout (B, S, 3) = dL/d[gain_db, cutoff_freq, q_factor].
+ * With Bs == 1 the caller sums gout over the batch. */
+int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S,
+                           int mode, float* gout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASP_HIP_H */

@@ -1,0 +1,211 @@
+"""fp64 numpy model of the chunked-scan biquad-cascade algorithm the HIP kernels implement.
+
+TEST INFRASTRUCTURE ONLY (see oracle/README.md): nothing in the product package imports this.
+It is *not* a restatement of the reference (that is oracle/dasp_oracle.py); it is an executable
+specification of csrc/sosfilt.hip -- same realisation, same tables, same scans, same gradient
+correlations -- used by the CPU tests to prove the algorithm equals the reference's
+`sosfilt_via_fsm` (dasp_pytorch/signal.py:136-166) and its autograd.
+
+Realisation of one section  H(z) = (b0 + b1 z^-1 + b2 z^-2) / (1 + a1 z^-1 + a2 z^-2):
+    s1' = sg*s1 - kom*s2 + u        (A = [[sg, -kom], [om, sg]], B = [1, 0])
+    s2' = om*s1 + sg*s2
+    y   = g1*s1 + g2*s2 + d*u       (C = [g1, g2], D = d = b0)
+with sg = -a1/2, disc = sg^2 - a2, om = max(sqrt|disc|, OM_MIN), kom = sign(-disc)*om
+(rotation-scaling matrix for complex poles, symmetric matrix for real poles: normal either way),
+g1 = b1 - b0*a1, g2 = ((b2 - b0*a2) + g1*sg)/om.  Then s2[n] = om * w[n-2] where w = u / A(z).
+"""
+import numpy as np
+
+OM_MIN = 1e-5
+WAVE = 64
+
+
+def realize(sos):
+    """sos (S,6) -> dict of per-section arrays (a0-normalised)."""
+    sos = np.asarray(sos, np.float64)
+    a0 = sos[:, 3]
+    b0, b1, b2 = sos[:, 0] / a0, sos[:, 1] / a0, sos[:, 2] / a0
+    a1, a2 = sos[:, 4] / a0, sos[:, 5] / a0
+    sg = -a1 / 2
+    disc = sg * sg - a2
+    om = np.maximum(np.sqrt(np.abs(disc)), OM_MIN)
+    kom = np.where(disc < 0, om, -om)
+    g1 = b1 - b0 * a1
+    g2 = ((b2 - b0 * a2) + g1 * sg) / om
+    return dict(sg=sg, om=om, kom=kom, g1=g1, g2=g2, d=b0, b=np.stack([b0, b1, b2], 1), a=np.stack([a1, a2], 1))
+
+
+def _sections_fwd(r):
+    S = len(r["sg"])
+    return [(np.array([[r["sg"][k], -r["kom"][k]], [r["om"][k], r["sg"][k]]]), np.array([1.0, 0.0]),
+             np.array([r["g1"][k], r["g2"][k]]), r["d"][k]) for k in range(S)]
+
+
+def _sections_adj(r):
+    """Adjoint cascade: sections in reverse order, (A^T, C^T, B^T, d), runs on reversed time."""
+    out = []
+    for (A, B, C, d) in reversed(_sections_fwd(r)):
+        out.append((A.T.copy(), C.copy(), B.copy(), d))
+    return out
+
+
+def cascade_system(secs):
+    """Block lower-triangular transition matrix Phi (2S,2S) and input vector Bx (2S)."""
+    S = len(secs)
+    Phi = np.zeros((2 * S, 2 * S))
+    Bx = np.zeros(2 * S)
+    for k, (A, B, C, d) in enumerate(secs):
+        Phi[2 * k:2 * k + 2, 2 * k:2 * k + 2] = A
+        gain = 1.0  # product of d_i for j < i < k
+        for j in range(k - 1, -1, -1):
+            Cj = secs[j][2]
+            Phi[2 * k:2 * k + 2, 2 * j:2 * j + 2] = np.outer(B, Cj) * gain
+            gain *= secs[j][3]
+        Bx[2 * k:2 * k + 2] = B * gain
+    return Phi, Bx
+
+
+def chunk_tables(secs, L):
+    """G (2S,L): chunk zero-state end state = G @ x_chunk.  M = Phi^L.  P[k][l] = (M_kk)^(2^l)."""
+    S = len(secs)
+    Phi, Bx = cascade_system(secs)
+    G = np.zeros((2 * S, L))
+    v = Bx.copy()
+    for n in range(L - 1, -1, -1):
+        G[:, n] = v
+        v = Phi @ v
+    M = np.linalg.matrix_power(Phi, L)
+    P = np.zeros((S, 6, 2, 2))
+    for k in range(S):
+        Q = M[2 * k:2 * k + 2, 2 * k:2 * k + 2].copy()
+        for l in range(6):
+            P[k, l] = Q
+            Q = Q @ Q
+    return G, M, P
+
+
+def tile_scan(z, M, P, carry):
+    """z (64,2S) chunk zero-state end states; carry (2S,) state at tile start.
+    Returns (start (64,2S) state at each chunk start, carry_out (2S,))."""
+    S = z.shape[1] // 2
+    start = np.zeros_like(z)
+    out = np.zeros(2 * S)
+    lane = np.arange(WAVE)
+    for k in range(S):
+        f = z[:, 2 * k:2 * k + 2].copy()
+        for j in range(k):
+            f += start[:, 2 * j:2 * j + 2] @ M[2 * k:2 * k + 2, 2 * j:2 * j + 2].T
+        f[0] += P[k, 0] @ carry[2 * k:2 * k + 2]
+        E = f
+        for l in range(6):
+            sh = 1 << l
+            t = np.zeros_like(E)
+            t[sh:] = E[:-sh]
+            E = E + np.where((lane >= sh)[:, None], t @ P[k, l].T, 0.0)
+        out[2 * k:2 * k + 2] = E[WAVE - 1]
+        start[1:, 2 * k:2 * k + 2] = E[:-1]
+        start[0, 2 * k:2 * k + 2] = carry[2 * k:2 * k + 2]
+    return start, out
+
+
+def cascade_chunks(secs, X, start, store_s2=False):
+    """Run the cascade over each lane's chunk X (64,L) from start states (64,2S).
+    Returns Y (64,L), end states, and (optionally) S2 (S,64,L+2): s2_k[n] for n in chunk, plus
+    the two states following the chunk (s2 does not depend on the current input)."""
+    S = len(secs)
+    L = X.shape[1]
+    st = start.copy()
+    Y = np.zeros_like(X)
+    S2 = np.zeros((S, WAVE, L + 2)) if store_s2 else None
+    for n in range(L):
+        u = X[:, n].copy()
+        for k, (A, B, C, d) in enumerate(secs):
+            s1, s2 = st[:, 2 * k], st[:, 2 * k + 1]
+            if store_s2:
+                S2[k, :, n] = s2
+            y = C[0] * s1 + C[1] * s2 + d * u
+            n1 = A[0, 0] * s1 + A[0, 1] * s2 + B[0] * u
+            n2 = A[1, 0] * s1 + A[1, 1] * s2 + B[1] * u
+            st[:, 2 * k], st[:, 2 * k + 1] = n1, n2
+            u = y
+        Y[:, n] = u
+    if store_s2:
+        for k, (A, B, C, d) in enumerate(secs):
+            s1, s2 = st[:, 2 * k], st[:, 2 * k + 1]
+            S2[k, :, L] = s2
+            S2[k, :, L + 1] = A[1, 0] * s1 + A[1, 1] * s2
+    return Y, st, S2
+
+
+def forward_row(r, x, L, save_every=None):
+    """Forward filter one row x (N,) with realisation r. Returns y and saved tile carries."""
+    secs = _sections_fwd(r)
+    G, M, P = chunk_tables(secs, L)
+    S = len(secs)
+    TS = WAVE * L
+    N = len(x)
+    nt = (N + TS - 1) // TS
+    xp = np.zeros(nt * TS)
+    xp[:N] = x
+    y = np.zeros(nt * TS)
+    carry = np.zeros(2 * S)
+    carries = np.zeros((nt, 2 * S))
+    for t in range(nt):
+        X = xp[t * TS:(t + 1) * TS].reshape(WAVE, L)
+        carries[t] = carry
+        z = X @ G.T
+        start, carry = tile_scan(z, M, P, carry)
+        Y, _, _ = cascade_chunks(secs, X, start)
+        y[t * TS:(t + 1) * TS] = Y.reshape(-1)
+    return y[:N], carries
+
+
+def backward_row(r, x, gy, carries, L):
+    """Backward for one row: returns gx (N,), and gb (S,3), ga (S,3) -- gradients w.r.t. the
+    a0-normalised coefficients (ga[:,0] is d/da0 from scale invariance)."""
+    fs = _sections_fwd(r)
+    ads = _sections_adj(r)
+    S = len(fs)
+    G, M, P = chunk_tables(fs, L)
+    Ga, Ma, Pa = chunk_tables(ads, L)
+    TS = WAVE * L
+    N = len(x)
+    nt = (N + TS - 1) // TS
+    xp = np.zeros(nt * TS); xp[:N] = x
+    gp = np.zeros(nt * TS); gp[:N] = gy
+    gx = np.zeros(nt * TS)
+    acc_b = np.zeros((S, 3))
+    acc_a = np.zeros((S, 3))   # [:,0] unused (filled from the identity)
+    acarry = np.zeros(2 * S)
+    for t in range(nt - 1, -1, -1):
+        X = xp[t * TS:(t + 1) * TS].reshape(WAVE, L)
+        GY = gp[t * TS:(t + 1) * TS].reshape(WAVE, L)
+        # forward chunk start states from the saved tile carry
+        start, _ = tile_scan(X @ G.T, M, P, carries[t])
+        _, _, S2 = cascade_chunks(fs, X, start, store_s2=True)
+        # adjoint: same machinery on (lane, sample)-reversed data
+        GYr = GY[::-1, ::-1]
+        astart_r, acarry = tile_scan(GYr @ Ga.T, Ma, Pa, acarry)
+        # per-lane adjoint cascade with correlations (natural lane order, descending n)
+        lam = astart_r[::-1].copy()    # adjoint state at each chunk *end*, section order S-1..0
+        GX = np.zeros_like(GY)
+        for n in range(L - 1, -1, -1):
+            g = GY[:, n].copy()
+            for i, (A, B, C, d) in enumerate(ads):
+                k = S - 1 - i
+                l1, l2 = lam[:, 2 * i], lam[:, 2 * i + 1]
+                acc_b[k, 0] += np.dot(g, S2[k, :, n + 2]); acc_b[k, 1] += np.dot(g, S2[k, :, n + 1]); acc_b[k, 2] += np.dot(g, S2[k, :, n])
+                out = C[0] * l1 + C[1] * l2 + d * g
+                n1 = A[0, 0] * l1 + A[0, 1] * l2 + B[0] * g
+                n2 = A[1, 0] * l1 + A[1, 1] * l2 + B[1] * g
+                lam[:, 2 * i], lam[:, 2 * i + 1] = n1, n2
+                acc_a[k, 1] += np.dot(out, S2[k, :, n + 1]); acc_a[k, 2] += np.dot(out, S2[k, :, n])
+                g = out
+            GX[:, n] = g
+        gx[t * TS:(t + 1) * TS] = GX.reshape(-1)
+    om = r["om"]
+    gb = acc_b / om[:, None]
+    ga = -acc_a / om[:, None]
+    # d/da0 at a0 = 1 from scale invariance of B/A:  sum_theta theta * dL/dtheta = 0
+    ga[:, 0] = -(np.sum(gb * r["b"], 1) + np.sum(ga[:, 1:] * r["a"], 1))
+    return gx[:N], gb, ga

@@ -1,0 +1,247 @@
+"""CPU oracle: numpy restatement of the reference algorithms on the hot path.
+
+TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg
+may import this module; nothing under dasp_pytorch_amd/ does (the product has no CPU path).
+
+Each function restates one reference function (csteinmetz1/dasp-pytorch v0.0.1, file:line cited)
+with the *reference's own algorithm* -- e.g. the IIR filters are the frequency-sampling method
+(zero-padded FFT, complex divide, inverse FFT, crop), not a recursion. Gradients are hand-derived
+vector-Jacobian products of those algorithms (the reference gets them from torch autograd).
+
+Pinning: the reference has no tests or golden vectors, so the pins are outputs
+of the reference itself, generated in the build container by tests/golden/make_golden.py (imports
+/root/reference) and committed under tests/golden/*.npz; tests/test_oracle_cpu.py checks this module
+against every one of them (forward values and gradients, fp32 and fp64).
+
+All functions take/return numpy arrays; `dtype` selects the arithmetic (np.float64 or np.float32;
+numpy >= 2 runs float32 FFTs natively, matching the reference's fp32 torch.fft path).
+"""
+import math
+
+import numpy as np
+
+# ------------------------------------------------------------------------------------------------
+# signal.py
+
+
+def _cplx(dtype):
+    return np.complex64 if np.dtype(dtype) == np.float32 else np.complex128
+
+
+def n_fft_for(T):
+    """signal.py:109-110 / :150-151  n_fft = 2 ** ceil(log2(2T - 1))."""
+    return int(2 ** math.ceil(math.log2(T + T - 1)))
+
+
+def fft_freqz(b, a, n_fft):
+    """signal.py:7-11."""
+    return np.fft.rfft(b, n_fft, axis=-1) / np.fft.rfft(a, n_fft, axis=-1)
+
+
+def fft_sosfreqz(sos, n_fft):
+    """signal.py:14-32. sos (bs, S, 6) -> H (bs, n_fft/2+1)."""
+    bs, S, six = sos.shape
+    assert six == 6
+    H = None
+    for s in range(S):
+        Hs = fft_freqz(sos[:, s, :3], sos[:, s, 3:], n_fft)
+        H = Hs if H is None else H * Hs
+    return H
+
+
+def freqdomain_fir(x, H, n_fft):
+    """signal.py:35-39."""
+    X = np.fft.rfft(x, n_fft, axis=-1)
+    return np.fft.irfft(X * H.astype(X.dtype), n_fft, axis=-1)
+
+
+def sosfilt_via_fsm(sos, x, dtype=np.float64):
+    """signal.py:136-166. sos (bs,S,6), x (bs,...,T) -> y (bs,...,T)."""
+    sos = np.asarray(sos, dtype)
+    x = np.asarray(x, dtype)
+    T = x.shape[-1]
+    n_fft = n_fft_for(T)
+    H = fft_sosfreqz(sos, n_fft)
+    for _ in range(x.ndim - 2):
+        H = H[:, None]
+    return freqdomain_fir(x, H, n_fft)[..., :T].astype(dtype)
+
+
+def sosfilt_via_fsm_vjp(sos, x, gy, dtype=np.float64):
+    """VJP of sosfilt_via_fsm: returns (gsos (bs,S,6), gx like x).
+
+    y_full = irfft(rfft(x_pad) * prod_s B_s/A_s) is a circular convolution, so
+      gx      = irfft(rfft(gy_pad) * conj(H))[:T]
+      dL/db_sj =  sum_n gy_pad[n] * q_s[(n-j) mod n_fft],  q_s = irfft(X * H_excl_s / A_s)
+      dL/da_sj = -sum_n gy_pad[n] * r_s[(n-j) mod n_fft],  r_s = irfft(X * H / A_s)
+    (H_excl_s = product of the other sections), summed over every non-batch dim of x."""
+    sos = np.asarray(sos, dtype)
+    x = np.asarray(x, dtype)
+    gy = np.asarray(gy, dtype)
+    bs, S, _ = sos.shape
+    T = x.shape[-1]
+    n_fft = n_fft_for(T)
+    xb = x.reshape(x.shape[0], -1, T)
+    gb = gy.reshape(x.shape[0], -1, T)
+    Hs = [fft_freqz(sos[:, s, :3], sos[:, s, 3:], n_fft) for s in range(S)]       # (bs, bins)
+    As = [np.fft.rfft(sos[:, s, 3:], n_fft, axis=-1) for s in range(S)]
+    H = Hs[0].copy()
+    for s in range(1, S):
+        H = H * Hs[s]
+    X = np.fft.rfft(xb, n_fft, axis=-1)
+    GY = np.fft.rfft(gb, n_fft, axis=-1)
+    gx = np.fft.irfft(GY * np.conj(H)[:, None], n_fft, axis=-1)[..., :T]
+    gpad = np.zeros(gb.shape[:-1] + (n_fft,), dtype)
+    gpad[..., :T] = gb
+    gsos = np.zeros((sos.shape[0], S, 6), np.float64)
+    for s in range(S):
+        Hex = np.ones_like(H)
+        for i in range(S):
+            if i != s:
+                Hex = Hex * Hs[i]
+        q = np.fft.irfft(X * (Hex / As[s])[:, None], n_fft, axis=-1)
+        r = np.fft.irfft(X * (H / As[s])[:, None], n_fft, axis=-1)
+        for j in range(3):
+            gb_j = np.sum(gpad.astype(np.float64) * np.roll(q, j, axis=-1), axis=(1, 2))
+            ga_j = -np.sum(gpad.astype(np.float64) * np.roll(r, j, axis=-1), axis=(1, 2))
+            if sos.shape[0] == 1 and x.shape[0] != 1:
+                gsos[0, s, j] = gb_j.sum()
+                gsos[0, s, 3 + j] = ga_j.sum()
+            else:
+                gsos[:, s, j] = gb_j
+                gsos[:, s, 3 + j] = ga_j
+    return gsos.astype(dtype), gx.reshape(x.shape).astype(dtype)
+
+
+def biquad(gain_db, cutoff_freq, q_factor, sample_rate, filter_type="peaking"):
+    """signal.py:242-306. Inputs (bs,) -> b, a each (bs, 3), a0-normalised. Works for complex
+    inputs too (used for complex-step Jacobians)."""
+    A = 10 ** (gain_db / 40.0)
+    w0 = 2 * math.pi * (cutoff_freq / sample_rate)
+    alpha = np.sin(w0) / (2 * q_factor)
+    cos_w0 = np.cos(w0)
+    sqrt_A = np.sqrt(A)
+    if filter_type == "high_shelf":
+        b0 = A * ((A + 1) + (A - 1) * cos_w0 + 2 * sqrt_A * alpha)
+        b1 = -2 * A * ((A - 1) + (A + 1) * cos_w0)
+        b2 = A * ((A + 1) + (A - 1) * cos_w0 - 2 * sqrt_A * alpha)
+        a0 = (A + 1) - (A - 1) * cos_w0 + 2 * sqrt_A * alpha
+        a1 = 2 * ((A - 1) - (A + 1) * cos_w0)
+        a2 = (A + 1) - (A - 1) * cos_w0 - 2 * sqrt_A * alpha
+    elif filter_type == "low_shelf":
+        b0 = A * ((A + 1) - (A - 1) * cos_w0 + 2 * sqrt_A * alpha)
+        b1 = 2 * A * ((A - 1) - (A + 1) * cos_w0)
+        b2 = A * ((A + 1) - (A - 1) * cos_w0 - 2 * sqrt_A * alpha)
+        a0 = (A + 1) + (A - 1) * cos_w0 + 2 * sqrt_A * alpha
+        a1 = -2 * ((A - 1) + (A + 1) * cos_w0)
+        a2 = (A + 1) + (A - 1) * cos_w0 - 2 * sqrt_A * alpha
+    elif filter_type == "peaking":
+        b0 = 1 + alpha * A
+        b1 = -2 * cos_w0
+        b2 = 1 - alpha * A
+        a0 = 1 + (alpha / A)
+        a1 = -2 * cos_w0
+        a2 = 1 - (alpha / A)
+    elif filter_type == "low_pass":
+        b0 = (1 - cos_w0) / 2
+        b1 = 1 - cos_w0
+        b2 = (1 - cos_w0) / 2
+        a0 = 1 + alpha
+        a1 = -2 * cos_w0
+        a2 = 1 - alpha
+    elif filter_type == "high_pass":
+        b0 = (1 + cos_w0) / 2
+        b1 = -(1 + cos_w0)
+        b2 = (1 + cos_w0) / 2
+        a0 = 1 + alpha
+        a1 = -2 * cos_w0
+        a2 = 1 - alpha
+    else:
+        raise ValueError(f"Invalid filter_type: {filter_type}.")
+    b = np.stack([b0, b1, b2], -1) / a0[..., None]
+    a = np.stack([a0, a1, a2], -1) / a0[..., None]
+    return b, a
+
+
+# ------------------------------------------------------------------------------------------------
+# functional.py
+
+PEQ_SECTIONS = [("low_shelf", "low_shelf"), ("band0", "peaking"), ("band1", "peaking"), ("band2", "peaking"),
+                ("band3", "peaking"), ("high_shelf", "high_shelf")]
+
+
+def peq_sos(params, sample_rate, dtype=np.float64):
+    """functional.py:211-265: params (bs, 18) in the reference's argument order -> sos (bs,6,6)."""
+    params = np.asarray(params)
+    bs = params.shape[0]
+    sos = np.zeros((bs, 6, 6), dtype if not np.iscomplexobj(params) else np.complex128)
+    for k, (_, ftype) in enumerate(PEQ_SECTIONS):
+        p = params[:, 3 * k:3 * k + 3].astype(sos.dtype)
+        b, a = biquad(p[:, 0], p[:, 1], p[:, 2], sample_rate, ftype)
+        sos[:, k, :3] = b
+        sos[:, k, 3:] = a
+    return sos
+
+
+def parametric_eq(x, sample_rate, params, dtype=np.float64):
+    """functional.py:118-272 with the 18 controls stacked as params (bs or 1, 18)."""
+    sos = peq_sos(np.asarray(params, dtype), sample_rate, dtype)
+    if sos.shape[0] == 1 and x.shape[0] != 1:
+        sos = np.repeat(sos, x.shape[0], 0)
+    return sosfilt_via_fsm(sos, x, dtype)
+
+
+def parametric_eq_vjp(x, sample_rate, params, gy, dtype=np.float64):
+    """Returns (gx, gparams (bs or 1, 18)). d(sos)/d(params) by complex-step differentiation of
+    `biquad` (analytic formulas), which is exact to rounding."""
+    params = np.asarray(params, np.float64)
+    bp = params.shape[0]
+    sos = peq_sos(params.astype(dtype), sample_rate, dtype)
+    sos_b = np.repeat(sos, x.shape[0], 0) if (bp == 1 and x.shape[0] != 1) else sos
+    gsos, gx = sosfilt_via_fsm_vjp(sos_b, x, gy, dtype)
+    if bp == 1 and x.shape[0] != 1:
+        gsos = gsos.sum(0, keepdims=True)
+    gparams = np.zeros((bp, 18))
+    h = 1e-30
+    for i in range(18):
+        pc = params.astype(np.complex128)
+        pc[:, i] += 1j * h
+        dsos = peq_sos(pc, sample_rate).imag / h          # (bp, 6, 6)
+        gparams[:, i] = np.sum(gsos.astype(np.float64) * dsos, axis=(1, 2))
+    return gx, gparams.astype(dtype)
+
+
+def gain(x, sample_rate, gain_db, dtype=np.float64):
+    """functional.py:10-29."""
+    x = np.asarray(x, dtype)
+    g = np.asarray(gain_db, dtype).reshape(x.shape[0], 1, 1)
+    return x * (10 ** (np.repeat(g, x.shape[1], 1) / dtype(20.0)))
+
+
+def gain_vjp(x, sample_rate, gain_db, gy, dtype=np.float64):
+    x = np.asarray(x, dtype)
+    gy = np.asarray(gy, dtype)
+    g = np.asarray(gain_db, dtype).reshape(x.shape[0], 1, 1)
+    lin = 10 ** (g / 20.0)
+    gx = gy * lin
+    ggain = np.sum(gy * x * lin, axis=(1, 2)) * (math.log(10.0) / 20.0)
+    return gx.astype(dtype), ggain.astype(dtype)
+
+
+def distortion(x, sample_rate, drive_db, dtype=np.float64):
+    """functional.py:65-78: drive_db.view(bs, chs, -1) -> needs bs*chs drive values."""
+    x = np.asarray(x, dtype)
+    d = np.asarray(drive_db, dtype).reshape(x.shape[0], x.shape[1], -1)
+    return np.tanh(x * (10 ** (d / dtype(20.0))))
+
+
+def distortion_vjp(x, sample_rate, drive_db, gy, dtype=np.float64):
+    x = np.asarray(x, dtype)
+    gy = np.asarray(gy, dtype)
+    d = np.asarray(drive_db, dtype).reshape(x.shape[0], x.shape[1], -1)
+    lin = 10 ** (d / 20.0)
+    y = np.tanh(x * lin)
+    t = gy * (1 - y * y)
+    gx = t * lin
+    gd = np.sum(t * x * lin, axis=2, keepdims=True) * (math.log(10.0) / 20.0)
+    return gx.astype(dtype), gd.reshape(np.asarray(drive_db).shape).astype(dtype)

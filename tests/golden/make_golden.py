@@ -1,0 +1,110 @@
+"""Generate golden vectors by running the *reference itself* (csteinmetz1/dasp-pytorch v0.0.1,
+imported from /root/reference) on CPU. The reference ships no tests or fixtures, so these are the
+pins for oracle/ and for the HIP kernels. Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Outputs are stored as float32 (the fp64-reference results are rounded to fp32 on save; that costs
+6e-8 relative, far below every tolerance used). Seeds are fixed; re-running reproduces the files.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+import dasp_pytorch  # noqa: E402
+import dasp_pytorch.functional as RF  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SR = 44100
+
+
+def f32(t):
+    return t.detach().to(torch.float32).numpy()
+
+
+def denorm(mod, p):
+    return mod.denormalize_param_dict(mod.extract_param_dict(p))
+
+
+def run_eq(x, params18, w, dtype):
+    x = x.to(dtype).clone().requires_grad_(True)
+    cols = [params18[:, i].to(dtype).clone().requires_grad_(True) for i in range(18)]
+    y = RF.parametric_eq(x, SR, *cols)
+    (y * w.to(dtype)).sum().backward()
+    gp = torch.stack([c.grad for c in cols], 1)
+    return y, x.grad, gp
+
+
+def eq_case(name, B, C, N, Bp, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    pn = torch.rand(Bp, 18, generator=g)
+    mod = dasp_pytorch.ParametricEQ(SR)
+    d = denorm(mod, pn)
+    params = torch.stack([d[k] for k in mod.param_ranges.keys()], 1)   # (Bp, 18) physical units
+    w = torch.randn(B, C, N, generator=g)
+    out = dict(x=f32(x), params=f32(params), w=f32(w))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        y, gx, gp = run_eq(x, params, w, dt)
+        out["y" + tag], out["gx" + tag], out["gp" + tag] = f32(y), f32(gx), f32(gp)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def sos_case(name, B, C, N, S, seed):
+    """Direct sosfilt_via_fsm boundary with generic (non-unit a0) stable sections."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    r = 0.3 + 0.69 * torch.rand(B, S, generator=g)
+    th = 3.1 * torch.rand(B, S, generator=g)
+    a0 = 0.5 + torch.rand(B, S, generator=g)
+    a = torch.stack([torch.ones_like(r), -2 * r * torch.cos(th), r * r], -1) * a0[..., None]
+    b = torch.randn(B, S, 3, generator=g)
+    # make some sections have real poles
+    a[:, 0, 1] = -(0.9 + 0.5) * a0[:, 0]
+    a[:, 0, 2] = (0.9 * 0.5) * a0[:, 0]
+    sos = torch.cat([b, a], -1)
+    w = torch.randn(B, C, N, generator=g)
+    out = dict(x=f32(x), sos=f32(sos), w=f32(w))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        ss = sos.to(torch.float32).to(dt).clone().requires_grad_(True)   # both precisions consume the fp32-rounded sos
+        y = dasp_pytorch.signal.sosfilt_via_fsm(ss, xx)
+        (y * w.to(dt)).sum().backward()
+        out["y" + tag], out["gx" + tag], out["gsos" + tag] = f32(y), f32(xx.grad), f32(ss.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def gain_dist_case(name, B, C, N, seed):
+    """BASELINE config 1: distortion() + gain() on random (4,1,16384)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    gain_db = torch.rand(B, generator=g) * 48 - 24
+    drive_db = torch.rand(B * C, generator=g) * 24
+    w = torch.randn(B, C, N, generator=g)
+    out = dict(x=f32(x), gain_db=f32(gain_db), drive_db=f32(drive_db), w=f32(w))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        gd = gain_db.to(dt).clone().requires_grad_(True)
+        y = RF.gain(xx, SR, gd)
+        (y * w.to(dt)).sum().backward()
+        out["gain_y" + tag], out["gain_gx" + tag], out["gain_gp" + tag] = f32(y), f32(xx.grad), f32(gd.grad)
+        xx = x.to(dt).clone().requires_grad_(True)
+        dd = drive_db.to(dt).clone().requires_grad_(True)
+        y = RF.distortion(xx, SR, dd)
+        (y * w.to(dt)).sum().backward()
+        out["dist_y" + tag], out["dist_gx" + tag], out["dist_gp" + tag] = f32(y), f32(xx.grad), f32(dd.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    eq_case("eq_b3c2_n12000", 3, 2, 12000, 3, seed=101)
+    eq_case("eq_bcast_b2c1_n4099", 2, 1, 4099, 1, seed=102)
+    sos_case("sos_b2c2_n6000_s3", 2, 2, 6000, 3, seed=103)
+    gain_dist_case("gain_dist_cfg1", 4, 1, 16384, seed=104)

@@ -1,0 +1,81 @@
+"""Pin the CPU oracle (oracle/dasp_oracle.py) and the fp64 model of the kernel algorithm
+(oracle/chunkscan_model.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py). CPU only."""
+import numpy as np
+import pytest
+
+from oracle import chunkscan_model as cm
+from oracle import dasp_oracle as orc
+from tests.util import linf_peak, load_golden
+
+SR = 44100
+
+
+@pytest.mark.parametrize("name", ["eq_b3c2_n12000", "eq_bcast_b2c1_n4099"])
+def test_oracle_parametric_eq_matches_reference_fp64(name):
+    g = load_golden(name)
+    y = orc.parametric_eq(g["x"], SR, g["params"])
+    assert linf_peak(y, g["y64"]).max() < 2e-6          # golden stored as fp32 of the fp64 reference
+    gx, gp = orc.parametric_eq_vjp(g["x"], SR, g["params"], g["w"])
+    assert linf_peak(gx, g["gx64"]).max() < 2e-6
+    assert linf_peak(gp, g["gp64"]).max() < 2e-5
+
+
+def test_oracle_parametric_eq_fp32_mode_tracks_reference_fp32():
+    # the fp32 restatement cannot be bit-identical (different FFT library) but must sit in the
+    # reference's own fp32 noise: compare both against the fp64 reference
+    g = load_golden("eq_b3c2_n12000")
+    y = orc.parametric_eq(g["x"], SR, g["params"], dtype=np.float32)
+    e_or = linf_peak(y, g["y64"])
+    e_ref = linf_peak(g["y32"], g["y64"])
+    assert np.all(e_or < 10 * e_ref + 1e-5)
+
+
+def test_oracle_sosfilt_matches_reference():
+    g = load_golden("sos_b2c2_n6000_s3")
+    y = orc.sosfilt_via_fsm(g["sos"], g["x"])
+    assert linf_peak(y, g["y64"]).max() < 2e-6
+    gsos, gx = orc.sosfilt_via_fsm_vjp(g["sos"], g["x"], g["w"])
+    assert linf_peak(gx, g["gx64"]).max() < 2e-6
+    assert linf_peak(gsos, g["gsos64"]).max() < 2e-5
+
+
+def test_oracle_gain_distortion_match_reference():
+    g = load_golden("gain_dist_cfg1")
+    y = orc.gain(g["x"], SR, g["gain_db"])
+    assert linf_peak(y, g["gain_y64"]).max() < 1e-6
+    gx, gg = orc.gain_vjp(g["x"], SR, g["gain_db"], g["w"])
+    assert linf_peak(gx, g["gain_gx64"]).max() < 1e-6
+    assert np.allclose(gg, g["gain_gp64"], rtol=1e-5)
+    y = orc.distortion(g["x"], SR, g["drive_db"])
+    assert linf_peak(y, g["dist_y64"]).max() < 1e-6
+    gx, gd = orc.distortion_vjp(g["x"], SR, g["drive_db"], g["w"])
+    assert linf_peak(gx, g["dist_gx64"]).max() < 1e-6
+    assert np.allclose(gd, g["dist_gp64"], rtol=1e-5)
+    # fp32 mode vs the reference's fp32 run
+    y32 = orc.gain(g["x"], SR, g["gain_db"], dtype=np.float32)
+    assert linf_peak(y32, g["gain_y32"]).max() < 1e-6
+
+
+def test_chunkscan_model_equals_reference():
+    """The algorithm the HIP kernels implement (normal-form sections, chunk tables, Kogge-Stone
+    scans, s2-correlation gradients) reproduces the reference forward and autograd in fp64."""
+    g = load_golden("sos_b2c2_n6000_s3")
+    sos = g["sos"].astype(np.float64)
+    for b in range(sos.shape[0]):
+        r = cm.realize(sos[b])
+        gb_sum = 0
+        ga_sum = 0
+        for c in range(g["x"].shape[1]):
+            y, car = cm.forward_row(r, g["x"][b, c].astype(np.float64), 16)
+            assert np.abs(y - g["y64"][b, c]).max() / np.abs(g["y64"][b, c]).max() < 2e-6
+            gx, gb, ga = cm.backward_row(r, g["x"][b, c].astype(np.float64), g["w"][b, c].astype(np.float64), car, 16)
+            assert np.abs(gx - g["gx64"][b, c]).max() / np.abs(g["gx64"][b, c]).max() < 2e-6
+            gb_sum = gb_sum + gb
+            ga_sum = ga_sum + ga
+        # model grads are w.r.t. a0-normalised coefficients; map to raw sos (a0 != 1 here)
+        a0 = sos[b, :, 3:4]
+        gs = np.concatenate([gb_sum / a0, ga_sum / a0], 1)
+        gs[:, 3] = -(np.sum(gb_sum * r["b"], 1) + np.sum(ga_sum[:, 1:] * r["a"], 1)) / a0[:, 0]
+        ref = g["gsos64"][b]
+        assert np.abs(gs - ref).max() / np.abs(ref).max() < 2e-5
