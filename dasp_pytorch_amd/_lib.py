@@ -60,6 +60,43 @@ def check(status, what):
         raise DaspHipError(f"{what} failed: {kind}")
 
 
+class KernelTimers:
+    """Optional per-entry-point HIP event timing (bench.py's roofline leg). Events are recorded on
+    torch's current stream, which is the stream every kernel is launched on (see `stream()`)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pending = {}
+
+    def start(self):
+        self.enabled, self.pending = True, {}
+
+    def stop(self):
+        """Synchronise and return {entry point: [ms per launch, ...]}."""
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in self.pending.items()}
+        self.pending = {}
+        return out
+
+
+timers = KernelTimers()
+
+
+def call(name, *args):
+    """Invoke one C-ABI entry point, raising DaspHipError on a non-zero status."""
+    fn = getattr(lib(), name)
+    if timers.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = fn(*args)
+        e1.record()
+        timers.pending.setdefault(name, []).append((e0, e1))
+    else:
+        status = fn(*args)
+    check(status, name)
+
+
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

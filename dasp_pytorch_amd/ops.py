@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream
+from ._lib import call, ptr, stream
 
 FILTER_TYPES = {"peaking": 0, "low_shelf": 1, "high_shelf": 2, "low_pass": 3, "high_pass": 4}
 
@@ -41,8 +41,7 @@ class _SosWork:
         y = torch.empty_like(x)
         if need_grad:
             self.carries = torch.empty(L.dasp_sos_carry_floats(B * C, N, self.S), dtype=torch.float32, device=x.device)
-        check(L.dasp_sosfilt_forward(ptr(self.tab), self.Bs, ptr(x), ptr(y), ptr(self.carries), B, C, N, self.S, stream()),
-              "dasp_sosfilt_forward")
+        call("dasp_sosfilt_forward", ptr(self.tab), self.Bs, ptr(x), ptr(y), ptr(self.carries), B, C, N, self.S, stream())
         return y
 
     def backward(self, x, gy, mode):
@@ -50,11 +49,10 @@ class _SosWork:
         B, C, N = x.shape
         gx = torch.empty_like(x)
         partials = torch.empty(L.dasp_sos_partial_floats(B * C, self.S), dtype=torch.float32, device=x.device)
-        check(L.dasp_sosfilt_backward(ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(partials),
-                                      B, C, N, self.S, stream()), "dasp_sosfilt_backward")
+        call("dasp_sosfilt_backward", ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(partials),
+                                      B, C, N, self.S, stream())
         gout = torch.empty(B, self.S, 6 if mode == 0 else 3, dtype=torch.float32, device=x.device)
-        check(L.dasp_sos_grad_finalize(ptr(self.dtab), self.Bs, ptr(partials), B, C, self.S, mode, ptr(gout), stream()),
-              "dasp_sos_grad_finalize")
+        call("dasp_sos_grad_finalize", ptr(self.dtab), self.Bs, ptr(partials), B, C, self.S, mode, ptr(gout), stream())
         if self.Bs == 1 and B != 1:
             gout = gout.sum(0, keepdim=True)
         return gx, gout
@@ -79,7 +77,7 @@ class SosFiltFunction(torch.autograd.Function):
         x32 = _f32c(x)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         w = _SosWork(Bs, Sp, x.device)
-        check(L.dasp_sos_prepare(ptr(sos32), Bs, Sp, ptr(w.tab), ptr(w.dtab), stream()), "dasp_sos_prepare")
+        call("dasp_sos_prepare", ptr(sos32), Bs, Sp, ptr(w.tab), ptr(w.dtab), stream())
         y = w.forward(x32, need)
         if need:
             ctx.work, ctx.S = w, S
@@ -109,8 +107,7 @@ class ParametricEQFunction(torch.autograd.Function):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         w = _SosWork(Bp, S, x.device)
         ctypes_types = (ctypes.c_int * S)(*types)
-        check(L.dasp_peq_prepare(ptr(p32), Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream()),
-              "dasp_peq_prepare")
+        call("dasp_peq_prepare", ptr(p32), Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream())
         y = w.forward(x32, need)
         if need:
             ctx.work = w

@@ -1,0 +1,67 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads without a GPU, exports exactly
+the symbols include/dasp_hip.h declares, answers its pure size queries, and the Python product
+layer refuses CPU tensors loudly (there is no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from dasp_pytorch_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    h = open(os.path.join(ROOT, "include", "dasp_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(dasp_\w+)\s*\(", h)))
+
+
+def test_header_and_binding_agree():
+    assert _header_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    for name in _header_symbols():
+        assert hasattr(L, name), name
+
+
+def test_size_queries():
+    L = _lib.lib()
+    assert L.dasp_sos_tile() == 64 * L.dasp_sos_chunk()
+    for S in (2, 4, 6, 8):
+        assert L.dasp_sos_supported_sections(S) == 1
+        assert L.dasp_sos_table_floats(S) > 0
+    assert L.dasp_sos_supported_sections(5) == 0
+    assert L.dasp_sos_table_floats(5) == -1
+    T = L.dasp_sos_tile()
+    assert L.dasp_sos_num_tiles(1) == 1 and L.dasp_sos_num_tiles(T) == 1 and L.dasp_sos_num_tiles(T + 1) == 2
+    assert L.dasp_sos_carry_floats(4, 2 * T, 6) == 4 * 2 * 12
+
+
+def test_argument_errors_without_gpu():
+    """NULL pointers / bad sizes are rejected before any launch (status DASP_ERR_ARG = -1)."""
+    L = _lib.lib()
+    assert L.dasp_sosfilt_forward(None, 1, None, None, None, 1, 1, 16, 6, None) == -1
+    assert L.dasp_sos_prepare(None, 1, 6, None, None, None) == -1
+
+
+def test_product_has_no_cpu_path():
+    import dasp_pytorch_amd as D
+    x = torch.zeros(1, 1, 64)
+    p = [torch.ones(1)] * 18
+    with pytest.raises(_lib.DaspHipError):
+        D.parametric_eq(x, 44100, *p)
+    with pytest.raises(_lib.DaspHipError):
+        D.signal.sosfilt_via_fsm(torch.zeros(1, 2, 6), x)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "dasp_pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
