@@ -41,9 +41,7 @@ def parametric_eq(
         band3_gain_db, band3_cutoff_freq, band3_q_factor,
         high_shelf_gain_db, high_shelf_cutoff_freq, high_shelf_q_factor,
     ]
-    cols = [c.reshape(-1).to(torch.float32) for c in controls]
-    n = cols[0].numel()
-    if any(c.numel() != n for c in cols) or n not in (1, bs):
-        raise RuntimeError(f"parametric_eq controls must each hold {bs} (or 1) values, got {[c.numel() for c in cols]}")
-    params = torch.stack(cols, dim=1).view(n, 6, 3)
-    return ParametricEQFunction.apply(x, params, float(sample_rate), _PEQ_TYPES)
+    n = controls[0].numel()
+    if any(c.numel() != n for c in controls) or n not in (1, bs):
+        raise RuntimeError(f"parametric_eq controls must each hold {bs} (or 1) values, got {[c.numel() for c in controls]}")
+    return ParametricEQFunction.apply(x, float(sample_rate), _PEQ_TYPES, *controls)

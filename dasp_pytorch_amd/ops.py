@@ -93,18 +93,23 @@ class SosFiltFunction(torch.autograd.Function):
 
 
 class ParametricEQFunction(torch.autograd.Function):
-    """Fused RBJ design (fp64, in-kernel) + cascade. params (Bp,S,3) = [gain_db, cutoff_freq, q_factor]."""
+    """Fused RBJ design (fp64, in-kernel) + cascade. `controls` are the 3*S per-item controls in the
+    reference's argument order [gain_db, cutoff_freq, q_factor] per section, each with Bp elements.
+    They enter as separate tensors and their gradients leave as contiguous rows of one (3S, Bp)
+    buffer, so autograd neither builds a stack node nor launches 3S copy kernels."""
 
     @staticmethod
-    def forward(ctx, x, params, sample_rate, types):
+    def forward(ctx, x, sample_rate, types, *controls):
         _lib.require_device(x, "x")
-        _lib.require_device(params, "params")
         L = _lib.lib()
-        Bp, S, _ = params.shape
+        S = len(types)
         if not L.dasp_sos_supported_sections(S):
             raise ValueError(f"no kernel compiled for {S} sections")
-        x32, p32 = _f32c(x), _f32c(params)
-        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        cols = [c.detach().reshape(-1).to(device=x.device, dtype=torch.float32) for c in controls]
+        Bp = cols[0].numel()
+        p32 = torch.stack(cols, dim=1)                      # (Bp, 3S) == (Bp, S, 3) rows
+        x32 = _f32c(x)
+        need = any(ctx.needs_input_grad)
         w = _SosWork(Bp, S, x.device)
         ctypes_types = (ctypes.c_int * S)(*types)
         call("dasp_peq_prepare", ptr(p32), Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream())
@@ -112,11 +117,15 @@ class ParametricEQFunction(torch.autograd.Function):
         if need:
             ctx.work = w
             ctx.save_for_backward(x32)
-        ctx.dtypes = (x.dtype, params.dtype)
+        ctx.x_dtype = x.dtype
+        ctx.ctl = [(c.dtype, c.shape) for c in controls]
         return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
         (x32,) = ctx.saved_tensors
-        gx, gp = ctx.work.backward(x32, _f32c(gy), 1)
-        return gx.to(ctx.dtypes[0]), gp.to(ctx.dtypes[1]), None, None
+        gx, gp = ctx.work.backward(x32, _f32c(gy), 1)        # gp (Bp, S, 3)
+        gpt = gp.reshape(gp.shape[0], -1).t().contiguous()   # (3S, Bp): one small transpose kernel
+        gcols = tuple(gpt[i].reshape(shape).to(dt) if need else None
+                      for i, ((dt, shape), need) in enumerate(zip(ctx.ctl, ctx.needs_input_grad[3:])))
+        return (gx.to(ctx.x_dtype) if ctx.needs_input_grad[0] else None, None, None) + gcols
