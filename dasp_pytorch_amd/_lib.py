@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdasp_hip.so")
+LIB_PATH = os.environ.get("DASP_HIP_LIB") or os.path.join(_HERE, "csrc", "libdasp_hip.so")   # env override: A/B of builds
 _lib = None
 
 c_f = ctypes.c_void_p   # device pointers are passed as raw addresses

@@ -12,6 +12,9 @@
 
 namespace dasp {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -49,99 +52,111 @@ __device__ __forceinline__ void wave_lds_sync() {
 // A tile is 64*L consecutive samples of one row. Global side: lane l, vector j holds samples
 // [j*256 + 4l, +4) (1 KiB per wave instruction). Register side: lane l holds the L consecutive
 // samples [l*L, (l+1)*L). LDS image: chunk-major with a 4-float pad per chunk (stride L+4) which
-// makes both the ds_write_b128 (8-lane groups) and the ds_read_b128 (16-lane groups) conflict free
-// for L = 8, 16, 32.
+// keeps both the ds_write_b128 and the ds_read_b128 side at most 2-way conflicted for L = 8, 16, 32.
+// A tile is "full" when it lies inside the row and the row is 16-byte aligned (wave-uniform test);
+// only full tiles use the float4 register path, ragged ones go element-wise straight to/from LDS
+// in a rolled loop (cold code, no register arrays).
 
 template <int L>
-__device__ __forceinline__ void tile_load_global(const float* __restrict__ row, long base, long n_valid,
-                                                 bool vec, float4 (&v)[L / 4]) {
+__device__ __forceinline__ bool tile_full(long base, long n_valid, bool vec) { return vec && base + 64 * L <= n_valid; }
+
+template <int L>
+__device__ __forceinline__ int tile_lds_index(int m) { return (m / L) * (L + 4) + (m % L); }
+
+// issue the coalesced loads of a full tile (results are consumed by tile_regs_to_lds)
+template <int L>
+__device__ __forceinline__ void tile_load_full(const float* __restrict__ row, long base, f4 (&v)[L / 4]) {
     const int lane = lane_id();
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
 #pragma unroll
-    for (int j = 0; j < L / 4; ++j) {
-        const long idx = base + (long)(j * 64 + lane) * 4;
-        if (vec && idx + 3 < n_valid) {
-            v[j] = *reinterpret_cast<const float4*>(row + idx);
-        } else {
-            v[j].x = (idx + 0 < n_valid) ? row[idx + 0] : 0.f;
-            v[j].y = (idx + 1 < n_valid) ? row[idx + 1] : 0.f;
-            v[j].z = (idx + 2 < n_valid) ? row[idx + 2] : 0.f;
-            v[j].w = (idx + 3 < n_valid) ? row[idx + 3] : 0.f;
-        }
-    }
+    for (int j = 0; j < L / 4; ++j) v[j] = f4{0.1f * lane, 0.2f, -0.3f, 0.05f * j};
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < L / 4; ++j) v[j] = *reinterpret_cast<const f4*>(row + base + (long)(j * 64 + lane) * 4);
 }
 
 template <int L>
-__device__ __forceinline__ void tile_store_global(float* __restrict__ row, long base, long n_valid, bool vec,
-                                                  const float4 (&v)[L / 4]) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int j = 0; j < L / 4; ++j) {
-        const long idx = base + (long)(j * 64 + lane) * 4;
-        if (vec && idx + 3 < n_valid) {
-            *reinterpret_cast<float4*>(row + idx) = v[j];
-        } else {
-            if (idx + 0 < n_valid) row[idx + 0] = v[j].x;
-            if (idx + 1 < n_valid) row[idx + 1] = v[j].y;
-            if (idx + 2 < n_valid) row[idx + 2] = v[j].z;
-            if (idx + 3 < n_valid) row[idx + 3] = v[j].w;
-        }
-    }
-}
-
-// coalesced float4s -> lane chunks
-template <int L>
-__device__ __forceinline__ void tile_to_chunks(float* tbuf, const float4 (&v)[L / 4], float (&X)[L]) {
-    constexpr int LP = L + 4;
+__device__ __forceinline__ void tile_regs_to_lds(float* tbuf, const f4 (&v)[L / 4]) {
     const int lane = lane_id();
     wave_lds_sync();  // previous readers of tbuf are done
 #pragma unroll
-    for (int j = 0; j < L / 4; ++j) {
-        const int m = j * 256 + 4 * lane;
-        *reinterpret_cast<float4*>(&tbuf[(m / L) * LP + (m % L)]) = v[j];
-    }
+    for (int j = 0; j < L / 4; ++j) *reinterpret_cast<f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]) = v[j];
     wave_lds_sync();
+}
+
+// ragged tile: guarded element loads straight into the LDS image (zero fill)
+template <int L>
+__device__ __forceinline__ void tile_global_to_lds_guarded(float* tbuf, const float* __restrict__ row, long base, long n_valid) {
+    const int lane = lane_id();
+    wave_lds_sync();
+#pragma unroll 1
+    for (int m = lane; m < 64 * L; m += 64) tbuf[tile_lds_index<L>(m)] = (base + m < n_valid) ? row[base + m] : 0.f;
+    wave_lds_sync();
+}
+
+template <int L>
+__device__ __forceinline__ void lds_to_chunks(const float* tbuf, float (&X)[L]) {
+    const int lane = lane_id();
 #pragma unroll
     for (int i = 0; i < L / 4; ++i) {
-        const float4 q = *reinterpret_cast<const float4*>(&tbuf[lane * LP + 4 * i]);
+        const f4 q = *reinterpret_cast<const f4*>(&tbuf[lane * (L + 4) + 4 * i]);
         X[4 * i + 0] = q.x; X[4 * i + 1] = q.y; X[4 * i + 2] = q.z; X[4 * i + 3] = q.w;
     }
 }
 
-// lane chunks -> coalesced float4s
 template <int L>
-__device__ __forceinline__ void chunks_to_tile(float* tbuf, const float (&X)[L], float4 (&v)[L / 4]) {
-    constexpr int LP = L + 4;
+__device__ __forceinline__ void chunks_to_lds(float* tbuf, const float (&X)[L]) {
     const int lane = lane_id();
     wave_lds_sync();
 #pragma unroll
     for (int i = 0; i < L / 4; ++i) {
-        float4 q; q.x = X[4 * i + 0]; q.y = X[4 * i + 1]; q.z = X[4 * i + 2]; q.w = X[4 * i + 3];
-        *reinterpret_cast<float4*>(&tbuf[lane * LP + 4 * i]) = q;
+        *reinterpret_cast<f4*>(&tbuf[lane * (L + 4) + 4 * i]) = f4{X[4 * i + 0], X[4 * i + 1], X[4 * i + 2], X[4 * i + 3]};
     }
     wave_lds_sync();
+}
+
+// LDS image -> global: coalesced float4 stores for a full tile, guarded element stores otherwise
+template <int L>
+__device__ __forceinline__ void tile_lds_to_global_full(const float* tbuf, float* __restrict__ row, long base) {
+    const int lane = lane_id();
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
+    if (tbuf[lane] != 12345.678f) return;
+#endif
 #pragma unroll
-    for (int j = 0; j < L / 4; ++j) {
-        const int m = j * 256 + 4 * lane;
-        v[j] = *reinterpret_cast<const float4*>(&tbuf[(m / L) * LP + (m % L)]);
-    }
+    for (int j = 0; j < L / 4; ++j)
+        *reinterpret_cast<f4*>(row + base + (long)(j * 64 + lane) * 4) =
+            *reinterpret_cast<const f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]);
+}
+template <int L>
+__device__ __forceinline__ void tile_lds_to_global_guarded(const float* tbuf, float* __restrict__ row, long base, long n_valid) {
+    const int lane = lane_id();
+#pragma unroll 1
+    for (int m = lane; m < 64 * L; m += 64)
+        if (base + m < n_valid) row[base + m] = tbuf[tile_lds_index<L>(m)];
 }
 
 // ---- intra-workgroup mailbox: one wave hands a 2-vector carry to another wave through LDS --------
-// slot = {v0, v1, seq, pad}. Single writer lane, readers poll the sequence word. LDS operations of
-// a wave complete in order, so value-then-seq / seq-then-value is sufficient within a workgroup.
-__device__ __forceinline__ void mbox_publish(volatile float* slot, float a, float b, int seq) {
+// slot = 4 dwords {v0, v1, seq, pad} inside the kernel's LDS array (passed as the array + a dword
+// index so that the accesses stay ds_read/ds_write, not flat). Single writer lane, readers poll the
+// sequence word. The DS instructions of one wave are executed by the LDS in issue order, so
+// "values, then seq" on the writer and "seq, then values" on the reader need no hardware fence --
+// only the compiler has to keep the order. (A workgroup-scope release fence would also drain vmcnt,
+// i.e. put the HBM latency of the prefetched next tile on the carry chain; measured 2x slower.)
+__device__ __forceinline__ void mbox_publish(float* lds, int slot, float a, float b, int seq) {
     if (lane_id() == 0) {
-        slot[0] = a;
-        slot[1] = b;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        reinterpret_cast<volatile int*>(slot)[2] = seq;
+        __hip_atomic_store(&lds[slot + 0], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&lds[slot + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<int*>(&lds[slot + 2]), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
-__device__ __forceinline__ void mbox_wait(volatile float* slot, int seq, float& a, float& b) {
-    while (reinterpret_cast<volatile int*>(slot)[2] != seq) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    a = slot[0];
-    b = slot[1];
+__device__ __forceinline__ void mbox_wait(float* lds, int slot, int seq, float& a, float& b) {
+    while (__hip_atomic_load(reinterpret_cast<int*>(&lds[slot + 2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    a = __hip_atomic_load(&lds[slot + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    b = __hip_atomic_load(&lds[slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace dasp

@@ -12,35 +12,48 @@
 // Each biquad is realised in a *normal* state-space form (rotation/symmetric 2x2 state matrix,
 // see prep kernel) which is ~1000x less noisy in fp32 than direct forms for low-frequency poles.
 // Per tile: (1) coalesced float4 loads -> LDS transpose -> L samples per lane;
-// (2) z = G x : zero-state end state of every chunk (table G from the prep kernel, SGPR operands);
-// (3) per section k: forcing f = z_k + sum_{j<k} M_kj s_j (block-lower-triangular coupling), then a
-//     6-level Kogge-Stone scan over lanes with the 2x2 powers (M_kk)^(2^l);
+// (2) z = G x : zero-state end state of every chunk (table from the prep kernel, SGPR operands,
+//     packed v_pk_fma_f32 over pairs of state components);
+// (3) per section k: forcing f = z_k + sum_{j<k} M_kj s_j (block-lower-triangular coupling), then an
+//     inclusive scan over the 64 lanes with 2x2 matrix powers of M_kk: four Kogge-Stone levels
+//     inside each 16-lane row on DPP row_shr (full-rate VALU, no LDS), two row_bcast levels across
+//     rows with per-lane powers;
 // (4) the tile carry K_k is handed from the wave that owns tile t-1 through an LDS mailbox; only
 //     K' = e_63 + M_kk^64 K sits on that serial chain, the per-lane fix-up M_kk^(lane+1) K is off it;
-// (5) every lane runs the 6-section cascade over its L samples from its exact start state;
+// (5) every lane runs the S-section cascade over its L samples from its exact start state with the
+//     section coefficients held in VGPRs (VALU ops with SGPR operands issue at half rate on gfx950);
 // (6) LDS transpose back -> coalesced float4 stores.
 // The backward kernel walks the tiles in reverse: it recomputes the forward chunk states from the
 // per-tile carries the forward pass saved, keeps s2_k[n] (= om_k * w_k[n-2], the all-pole signal)
-// in registers, runs the adjoint cascade (sections reversed, transposed realisation) and accumulates
-// the five coefficient correlations per section; a finalize kernel reduces them in fp64.
+// in registers, runs the adjoint cascade (sections reversed, transposed realisation; its lane scan
+// runs on lane-mirrored data so that it can use the same DPP machinery) and accumulates the five
+// coefficient correlations per section; a finalize kernel reduces them in fp64.
 #include "common.hpp"
 #include <type_traits>
 
 namespace dasp {
 
+
 // ------------------------------------------------------------------------------------------------
-// Per-item fp32 table layout (floats). S sections, chunk length L.
+// Per-item fp32 table layout (floats). S sections, chunk length L. Every 2x2 matrix is stored
+// column-major (c00, c10, c01, c11) so that  f += col0 * t1 + col1 * t2  is two packed FMAs.
+// "A" suffix = the adjoint system (sections in reverse order, transposed state matrices).
 template <int S, int L>
 struct SosLayout {
     static constexpr int S2 = 2 * S;
-    static constexpr int COEF = 0;                  // [S][8]: sg, om, kom, g1, g2, d, kappa, pad
-    static constexpr int G = COEF + S * 8;          // [2S][L]  forward chunk table
-    static constexpr int M = G + S2 * L;            // [2S][2S] Phi^L (block lower triangular)
-    static constexpr int P = M + S2 * S2;           // [S][7][4]: (p, q, kappa*q, pad) of M_kk^(2^l)
-    static constexpr int PW = P + S * 7 * 4;        // [S][2][64]: (p, q) of M_kk^(lane+1)
-    static constexpr int GA = PW + S * 2 * 64;      // [2S][L]  adjoint chunk table, natural n order
-    static constexpr int MA = GA + S2 * L;          // [2S][2S] adjoint Phi^L (adjoint section order)
-    static constexpr int TOTAL = MA + S2 * S2;
+    static constexpr int COEF = 0;                   // [S][8]: sg, om, kom, g1, g2, d, kappa, pad
+    static constexpr int GT = COEF + S * 8;          // [S][L][2] forward chunk table, section-major
+    static constexpr int MC = GT + L * S2;           // [S][S][4] blocks of Phi^L (j < k used)
+    static constexpr int PL = MC + 4 * S * S;        // [S][4][4] M_kk^(2^l), l = 0..3
+    static constexpr int P64 = PL + 16 * S;          // [S][4]    M_kk^64
+    static constexpr int PW = P64 + 4 * S;           // [S][64][4] M_kk^(c+1), c = 0..63
+    static constexpr int SYS = PW + 256 * S - GT;    // size of one system's block (GT..PW)
+    static constexpr int GAT = GT + SYS;             // adjoint chunk table, natural sample order
+    static constexpr int MCA = MC + SYS;
+    static constexpr int PLA = PL + SYS;
+    static constexpr int P64A = P64 + SYS;
+    static constexpr int PWA = PW + SYS;
+    static constexpr int TOTAL = GT + 2 * SYS;
 };
 // fp64 side table for the finalize kernel, per (item, section)
 constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_STRIDE = 24;
@@ -49,6 +62,13 @@ constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_STRIDE = 
 __device__ __forceinline__ void nmul(double k, double p1, double q1, double p2, double q2, double& p, double& q) {
     p = p1 * p2 - k * q1 * q2;
     q = p1 * q2 + q1 * p2;
+}
+// column-major store of [[p, -k q], [q, p]] (forward) or its transpose (adjoint)
+__device__ __forceinline__ void put_blk(float* o, double p, double q, double kap, int adj) {
+    o[0] = (float)p;
+    o[1] = (float)(adj ? -kap * q : q);
+    o[2] = (float)(adj ? q : -kap * q);
+    o[3] = (float)p;
 }
 
 // ---- forward-mode dual numbers (3 partials) for the RBJ design Jacobian ---------------------------
@@ -212,14 +232,14 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     }
     __syncthreads();
 
-    // G tables: v_m = Phi^m Bx ; forward G[:, L-1-m] = v_m ; adjoint (natural order) Ga[:, m] = v_m
+    // chunk tables: v_m = Phi^m Bx ; forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
     for (int m = 0; m < L; ++m) {
         const int cur = m & 1;
         if (tid < 2 * S2) {
             const int sys = tid / S2, i = tid % S2;
             const double v = vv[cur][sys][i];
-            if (sys == 0) tb[LY::G + i * L + (L - 1 - m)] = (float)v;
-            else tb[LY::GA + i * L + m] = (float)v;
+            if (sys == 0) tb[LY::GT + ((i >> 1) * L + (L - 1 - m)) * 2 + (i & 1)] = (float)v;
+            else tb[LY::GAT + ((i >> 1) * L + m) * 2 + (i & 1)] = (float)v;
             double acc = 0.0;
             for (int j = 0; j < S2; ++j) acc += Phi[sys][i * S2 + j] * vv[cur][sys][j];
             vv[cur ^ 1][sys][i] = acc;
@@ -241,18 +261,25 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             __syncthreads();
             double (*tmp)[NN] = src; src = dst; dst = tmp;
         }
-        for (int e = tid; e < 2 * NN; e += 256) {
-            const int sys = e / NN, ij = e % NN;
-            tb[(sys ? LY::MA : LY::M) + ij] = (float)src[sys][ij];
+        // coupling blocks, column-major
+        for (int e = tid; e < 2 * S * S * 4; e += 256) {
+            const int sys = e / (S * S * 4), k = (e / (S * 4)) % S, j = (e / 4) % S, c = e % 4;
+            tb[(sys ? LY::MCA : LY::MC) + (k * S + j) * 4 + c] = (float)src[sys][(2 * k + (c & 1)) * S2 + 2 * j + (c >> 1)];
         }
-        if (tid < S) {  // diagonal-block powers (p, q): M_kk = [[p, -kap q], [q, p]]
+        if (tid < S) {  // diagonal-block powers of the *forward* section k: M_kk = [[p, -kap q], [q, p]]
             const int k = tid;
             const double kap = sec[k][6];
             double p = src[0][(2 * k) * S2 + 2 * k], q = src[0][(2 * k + 1) * S2 + 2 * k];
             for (int l = 0; l < 7; ++l) {
                 Pd[k][l][0] = p; Pd[k][l][1] = q;
-                float* o = tb + LY::P + (k * 7 + l) * 4;
-                o[0] = (float)p; o[1] = (float)q; o[2] = (float)(kap * q); o[3] = 0.f;
+                if (l < 4) {
+                    put_blk(tb + LY::PL + (k * 4 + l) * 4, p, q, kap, 0);
+                    put_blk(tb + LY::PLA + ((S - 1 - k) * 4 + l) * 4, p, q, kap, 1);
+                }
+                if (l == 6) {
+                    put_blk(tb + LY::P64 + k * 4, p, q, kap, 0);
+                    put_blk(tb + LY::P64A + (S - 1 - k) * 4, p, q, kap, 1);
+                }
                 double p2, q2;
                 nmul(kap, p, q, p, q, p2, q2);
                 p = p2; q = q2;
@@ -271,112 +298,220 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
                 nmul(kap, p, q, Pd[k][l][0], Pd[k][l][1], p2, q2);
                 p = p2; q = q2;
             }
-        tb[LY::PW + (2 * k) * 64 + c] = (float)p;
-        tb[LY::PW + (2 * k + 1) * 64 + c] = (float)q;
+        put_blk(tb + LY::PW + (k * 64 + c) * 4, p, q, kap, 0);
+        put_blk(tb + LY::PWA + ((S - 1 - k) * 64 + c) * 4, p, q, kap, 1);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // shared pieces of the forward / backward tile code
 
-// z[j] = sum_n T[j][n] * X[n]   (T wave-uniform -> scalar loads, SGPR operands)
-template <int S2, int L>
-__device__ __forceinline__ void table_apply(const float* __restrict__ T, const float (&X)[L], float (&z)[S2]) {
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+
+// DPP move: value of the source lane selected by CTRL, 0 where there is none / the row is masked off
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+// lane i <- v[i-1]; lane 0 <- first
+__device__ __forceinline__ float wave_shr1(float first, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+// lane l <- v[63 - l]
+__device__ __forceinline__ float wave_mirror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((63 - lane_id()) * 4, __builtin_bit_cast(int, v)));
+}
+// an integer 0 the compiler cannot prove uniform: loads addressed with it stay in VGPRs
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+// zero-cost scheduling edge: `a` is not available before `dep` has been computed
+__device__ __forceinline__ void order_after(float& a, float dep) { asm volatile("" : "+v"(a) : "v"(dep)); }
+// Phase fence: volatile asm statements keep their program order, so pinning every live value of a
+// phase makes everything computed from them start after everything that produced them. Without
+// it the compiler overlaps independent phases of a tile and their register live ranges add up.
+__device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin(f2& a) { float x = a.x, y = a.y; pin(x); pin(y); a = f2{x, y}; }
+template <typename T, int N>
+__device__ __forceinline__ void pin(T (&a)[N]) {
 #pragma unroll
-    for (int j = 0; j < S2; ++j) {
-        float a = 0.f;
+    for (int i = 0; i < N; ++i) pin(a[i]);
+}
+template <typename T, int N, int M>
+__device__ __forceinline__ void pin(T (&a)[N][M]) {
 #pragma unroll
-        for (int n = 0; n < L; ++n) a = fmaf(T[j * L + n], X[n], a);
-        z[j] = a;
+    for (int i = 0; i < N; ++i) pin(a[i]);
+}
+// the same, but ordered after `dep` has been computed (serialises otherwise independent phases so
+// that their register live ranges do not overlap)
+__device__ __forceinline__ int opaque_zero_after(float dep) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(dep));
+    return z;
+}
+
+// z = sum_n T[n] * X[n] for one section: T = [L] f2 (wave-uniform -> scalar loads, packed FMAs);
+// two accumulators halve the dependent chain.
+template <int L>
+__device__ __forceinline__ f2 table_apply(const float* __restrict__ T, const float (&X)[L]) {
+    f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < L; n += 2) {
+        z0 = fma2(*reinterpret_cast<const f2*>(T + 2 * n), splat(X[n]), z0);
+        z1 = fma2(*reinterpret_cast<const f2*>(T + 2 * n + 2), splat(X[n + 1]), z1);
+    }
+    return z0 + z1;
+}
+
+// One section of the tile scan. f = forcing of this lane's chunk (zero-state end state + coupling).
+// On return f = exact state at the *end* of the lane's chunk given the tile carry-in K.
+//   PLk  : 4 uniform 2x2 blocks M^(1,2,4,8)          (global, scalar loads)
+//   pw   : per-lane blocks M^(c+1) staged in LDS     (pw[c] as f4, column-major)
+// K is added by the caller (it may have to wait for it).
+__device__ __forceinline__ void scan_rows(f2& f, const float* __restrict__ PLk, const f4* __restrict__ pw, int lane) {
+    {
+        const f4 c = *reinterpret_cast<const f4*>(PLk + 0);
+        const float t1 = dpp0<0x111, 0xf>(f.x), t2 = dpp0<0x111, 0xf>(f.y);
+        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
+    }
+    {
+        const f4 c = *reinterpret_cast<const f4*>(PLk + 4);
+        const float t1 = dpp0<0x112, 0xf>(f.x), t2 = dpp0<0x112, 0xf>(f.y);
+        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
+    }
+    {
+        const f4 c = *reinterpret_cast<const f4*>(PLk + 8);
+        const float t1 = dpp0<0x114, 0xf>(f.x), t2 = dpp0<0x114, 0xf>(f.y);
+        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
+    }
+    {
+        const f4 c = *reinterpret_cast<const f4*>(PLk + 12);
+        const float t1 = dpp0<0x118, 0xf>(f.x), t2 = dpp0<0x118, 0xf>(f.y);
+        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
+    }
+    {   // rows 1, 3 += M^(j+1) * (last lane of the previous row)
+        const f4 c = pw[lane & 15];
+        const float t1 = dpp0<0x142, 0xa>(f.x), t2 = dpp0<0x142, 0xa>(f.y);
+        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
+    }
+    {   // rows 2, 3 += M^((lane % 32) + 1) * lane 31
+        const f4 c = pw[lane & 31];
+        const float t1 = dpp0<0x143, 0xc>(f.x), t2 = dpp0<0x143, 0xc>(f.y);
+        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
+    }
+}
+
+// Whole-tile scan for one system (forward or adjoint tables): lane chunks X -> chunk start states st.
+//   Gs   : [S][L][2] chunk table (zero-state end state of section k = sum_n Gs[k][n] X[n]); zmap is
+//          applied to that per-lane value before the scan (identity, or the lane mirror for the adjoint)
+//   MCs  : [S][S][4] coupling blocks, PLs : [S][4][4], P64s : [S][4]   (global, scalar loads)
+//   pws  : [S][64] f4 per-lane powers in LDS
+//   carry_in(k, K)  : obtain the tile carry-in of section k (uniform)
+//   carry_out(k, K) : hand the carry for the next tile on
+template <int S, int L, typename FMap, typename FIn, typename FOut>
+__device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __restrict__ Gs, FMap&& zmap, f2 (&st)[S], const float* __restrict__ MCs,
+                                          const float* __restrict__ PLs, const float* __restrict__ P64s,
+                                          const f4* __restrict__ pws, int lane, FIn&& carry_in, FOut&& carry_out) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        __builtin_amdgcn_sched_barrier(0);   // keep each section's table / LDS loads inside the section (register pressure)
+        f2 f = zmap(table_apply<L>(Gs + k * L * 2, X));
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+            const f4 m = *reinterpret_cast<const f4*>(MCs + (k * S + j) * 4);
+            f = fma2(f2{m.x, m.y}, splat(st[j].x), fma2(f2{m.z, m.w}, splat(st[j].y), f));
+        }
+        scan_rows(f, PLs + k * 16, pws + k * 64, lane);
+        f2 K;
+        carry_in(k, K);
+        {   // carry for the next tile: the only work on the cross-wave serial chain
+            const f4 c = *reinterpret_cast<const f4*>(P64s + k * 4);
+            const f2 e = f2{read_lane(f.x, 63), read_lane(f.y, 63)};
+            carry_out(k, fma2(f2{c.x, c.y}, splat(K.x), fma2(f2{c.z, c.w}, splat(K.y), e)));
+        }
+        const f4 c = pws[k * 64 + lane];
+        const f2 E = fma2(f2{c.x, c.y}, splat(K.x), fma2(f2{c.z, c.w}, splat(K.y), f));
+        st[k] = f2{wave_shr1(K.x, E.x), wave_shr1(K.y, E.y)};
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 template <int S, int L, int W>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
                float* __restrict__ carries, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4;
-    __shared__ __attribute__((aligned(16))) float lds[W * 64 * LP + W * S * 4];
+    constexpr int LDS_T = W * 64 * LP, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     float* __restrict__ yr = y + (size_t)row * N;
     float* tbuf = lds + wave * 64 * LP;
-    volatile float* mb_in = lds + W * 64 * LP + wave * S * 4;
-    volatile float* mb_out = lds + W * 64 * LP + ((wave + 1) % W) * S * 4;
-    if (W > 1) {
-        for (int i = threadIdx.x; i < W * S * 4; i += 64 * W) lds[W * 64 * LP + i] = 0.f;
-        __syncthreads();
-    }
-    float pwp[S], pwq[S];
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        pwp[k] = tb[LY::PW + (2 * k) * 64 + lane];
-        pwq[k] = tb[LY::PW + (2 * k + 1) * 64 + lane];
-    }
-    float Kreg[S2];
-#pragma unroll
-    for (int j = 0; j < S2; ++j) Kreg[j] = 0.f;
+    const int mb_in = LDS_T + wave * S * 4, mb_out = LDS_T + ((wave + 1) % W) * S * 4;
+    float* pw_lds = lds + LDS_T + LDS_MB;
+    float* cf_lds = pw_lds + LDS_PW;
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[LDS_T + i] = 0.f;
+    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PW + i];
+    for (int i = threadIdx.x; i < LDS_CF; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    __syncthreads();
+    const f4* pws = reinterpret_cast<const f4*>(pw_lds);
 
-    float4 cur[L / 4], nxt[L / 4];
-    int t = wave;
-    if (t < nt) tile_load_global<L>(xr, (long)t * TS, N, vec, cur);
-    for (; t < nt; t += W) {
-        if (t + W < nt) tile_load_global<L>(xr, (long)(t + W) * TS, N, vec, nxt);
-        float X[L];
-        tile_to_chunks<L>(tbuf, cur, X);
-
-        float z[S2];
-        table_apply<S2, L>(tb + LY::G, X, z);
-
-        float st[S2];  // exact state at the start of this lane's chunk
+    // section coefficients as per-lane (VGPR) values: sg, -kom, om, g1, g2, d
+    float c_sg[S], c_nk[S], c_om[S], c_g1[S], c_g2[S], c_d[S];
+    {
+        const int oz = opaque_zero();
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            float f1 = z[2 * k], f2 = z[2 * k + 1];
+            const float* cf = cf_lds + k * 8 + oz;
+            c_sg[k] = cf[0]; c_om[k] = cf[1]; c_nk[k] = -cf[2]; c_g1[k] = cf[3]; c_g2[k] = cf[4]; c_d[k] = cf[5];
+        }
+    }
+    f2 Kreg[S];
 #pragma unroll
-            for (int j = 0; j < k; ++j) {
-                const float* m = tb + LY::M + (2 * k) * S2 + 2 * j;
-                f1 = fmaf(m[0], st[2 * j], fmaf(m[1], st[2 * j + 1], f1));
-                f2 = fmaf(m[S2], st[2 * j], fmaf(m[S2 + 1], st[2 * j + 1], f2));
-            }
+    for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
+
+    f4 cur[L / 4];
 #pragma unroll
-            for (int l = 0; l < 6; ++l) {
-                const float* pp = tb + LY::P + (k * 7 + l) * 4;
-                const float t1 = shift_up(f1, 1 << l), t2 = shift_up(f2, 1 << l);
-                if (lane >= (1 << l)) {
-                    f1 += pp[0] * t1 - pp[2] * t2;
-                    f2 += pp[1] * t1 + pp[0] * t2;
-                }
-            }
-            float K1, K2;
-            if (W == 1) {
-                K1 = Kreg[2 * k]; K2 = Kreg[2 * k + 1];
-            } else if (t == 0) {
-                K1 = 0.f; K2 = 0.f;
-            } else {
-                mbox_wait(mb_in + 4 * k, t, K1, K2);
-            }
-            {   // carry for the next tile: the only work on the cross-wave serial chain
-                const float* p64 = tb + LY::P + (k * 7 + 6) * 4;
-                const float e1 = read_lane(f1, 63), e2 = read_lane(f2, 63);
-                const float n1 = e1 + p64[0] * K1 - p64[2] * K2;
-                const float n2 = e2 + p64[1] * K1 + p64[0] * K2;
-                if (W == 1) { Kreg[2 * k] = n1; Kreg[2 * k + 1] = n2; }
-                else if (t + 1 < nt) mbox_publish(mb_out + 4 * k, n1, n2, t + 1);
-            }
-            if (carries && lane == 0) {
-                float* cs = carries + ((size_t)row * nt + t) * S2 + 2 * k;
-                cs[0] = K1; cs[1] = K2;
-            }
-            const float kap = tb[LY::COEF + k * 8 + 6];
-            const float E1 = f1 + pwp[k] * K1 - kap * pwq[k] * K2;
-            const float E2 = f2 + pwq[k] * K1 + pwp[k] * K2;
-            const float s1 = shift_up(E1, 1), s2 = shift_up(E2, 1);
-            st[2 * k] = lane == 0 ? K1 : s1;
-            st[2 * k + 1] = lane == 0 ? K2 : s2;
+    for (int j = 0; j < L / 4; ++j) cur[j] = f4{0.f, 0.f, 0.f, 0.f};
+    int t = wave;
+    if (t < nt && tile_full<L>((long)t * TS, N, vec)) tile_load_full<L>(xr, (long)t * TS, cur);
+    for (; t < nt; t += W) {
+        int toff = 0;
+        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
+        const float* __restrict__ tbl = tb + toff;
+        const bool full = tile_full<L>((long)t * TS, N, vec);
+        float X[L];
+        if (full) tile_regs_to_lds<L>(tbuf, cur);
+        else tile_global_to_lds_guarded<L>(tbuf, xr, (long)t * TS, N);
+        lds_to_chunks<L>(tbuf, X);
+        // prefetch the wave's next tile; it stays in flight for the whole tile computation
+        if (t + W < nt && tile_full<L>((long)(t + W) * TS, N, vec)) tile_load_full<L>(xr, (long)(t + W) * TS, cur);
+
+        f2 st[S];
+        tile_scan<S, L>(X, tbl + LY::GT, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+            [&](int k, f2& K) {
+                if (W == 1) K = Kreg[k];
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 1)
+                else K = f2{0.f, 0.f};
+#else
+                else if (t == 0) K = f2{0.f, 0.f};
+                else { float a, b; mbox_wait(lds, mb_in + 4 * k, t, a, b); K = f2{a, b}; }
+#endif
+            },
+            [&](int k, f2 Kn) {
+                if (W == 1) Kreg[k] = Kn;
+                else if (t + 1 < nt) mbox_publish(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
+            });
+        if (carries && lane == 0) {   // lane 0's start state is the tile carry-in
+            float* cs = carries + ((size_t)row * nt + t) * S2;
+#pragma unroll
+            for (int k = 0; k < S; ++k) *reinterpret_cast<f2*>(cs + 2 * k) = st[k];
         }
 
 #pragma unroll
@@ -384,56 +519,59 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             float u = X[n];
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                const float* cf = tb + LY::COEF + k * 8;
-                const float s1 = st[2 * k], s2 = st[2 * k + 1];
-                const float yv = fmaf(cf[3], s1, fmaf(cf[4], s2, cf[5] * u));
-                st[2 * k] = fmaf(cf[0], s1, fmaf(-cf[2], s2, u));
-                st[2 * k + 1] = fmaf(cf[1], s1, cf[0] * s2);
+                const float s1 = st[k].x, s2 = st[k].y;
+                const float yv = fmaf(c_g1[k], s1, fmaf(c_g2[k], s2, c_d[k] * u));
+                st[k].x = fmaf(c_sg[k], s1, fmaf(c_nk[k], s2, u));
+                st[k].y = fmaf(c_om[k], s1, c_sg[k] * s2);
                 u = yv;
             }
             X[n] = u;
         }
 
-        float4 out[L / 4];
-        chunks_to_tile<L>(tbuf, X, out);
-        tile_store_global<L>(yr, (long)t * TS, N, vec, out);
-#pragma unroll
-        for (int j = 0; j < L / 4; ++j) cur[j] = nxt[j];
+        chunks_to_lds<L>(tbuf, X);
+        if (full) tile_lds_to_global_full<L>(tbuf, yr, (long)t * TS);
+        else tile_lds_to_global_guarded<L>(tbuf, yr, (long)t * TS, N);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward. Register budget is the design constraint: the coefficient correlations pair the
+// adjoint signals of section k with its forward all-pole signal s2_k[n], so forward signals have to
+// be held while the adjoint runs. Holding all S sections (S*(L+2) registers) leaves one wave per
+// SIMD; instead the tile is processed in two half-cascade passes (sections [H, S) then [0, H)),
+// each keeping only its own s2 signals, at the price of running the forward sections [0, H) twice.
 template <int S, int L, int W>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
-    constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4;
-    __shared__ __attribute__((aligned(16))) float lds[W * 64 * LP + W * S * 4];
+    constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4, H = S / 2, SH = S - H;   // SH >= H
+    constexpr int LDS_T = W * 64 * LP, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * LDS_T + LDS_MB + 2 * LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
     float* __restrict__ gxr = gx + (size_t)row * N;
-    float* tbuf = lds + wave * 64 * LP;
-    volatile float* mb_in = lds + W * 64 * LP + wave * S * 4;
-    volatile float* mb_out = lds + W * 64 * LP + ((wave + 1) % W) * S * 4;
-    if (W > 1) {
-        for (int i = threadIdx.x; i < W * S * 4; i += 64 * W) lds[W * 64 * LP + i] = 0.f;
-        __syncthreads();
+    float* tbx = lds + wave * 64 * LP;             // x image (kept for the second pass), then the gx image
+    float* tbg = lds + LDS_T + wave * 64 * LP;     // gy image
+    const int mb_in = 2 * LDS_T + wave * S * 4, mb_out = 2 * LDS_T + ((wave + 1) % W) * S * 4;
+    float* pw_lds = lds + 2 * LDS_T + LDS_MB;
+    float* cf_lds = pw_lds + 2 * LDS_PW;
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[2 * LDS_T + i] = 0.f;
+    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) {
+        pw_lds[i] = tb[LY::PW + i];
+        pw_lds[LDS_PW + i] = tb[LY::PWA + i];
     }
-    // (M_kk^T)^(64 - lane): same (p, q) as M_kk^(64 - lane), applied transposed
-    float pwp[S], pwq[S];
+    for (int i = threadIdx.x; i < LDS_CF; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    __syncthreads();
+    const f4* pws = reinterpret_cast<const f4*>(pw_lds);
+    const f4* pwa = reinterpret_cast<const f4*>(pw_lds + LDS_PW);
+    f2 Kreg[S];
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
-        pwp[k] = tb[LY::PW + (2 * k) * 64 + (63 - lane)];
-        pwq[k] = tb[LY::PW + (2 * k + 1) * 64 + (63 - lane)];
-    }
-    float Kreg[S2];
-#pragma unroll
-    for (int j = 0; j < S2; ++j) Kreg[j] = 0.f;
+    for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
     float accb[S][3], acca[S][2];
 #pragma unroll
     for (int k = 0; k < S; ++k) {
@@ -443,145 +581,143 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 
     for (int r = wave; r < nt; r += W) {
         const int t = nt - 1 - r;
+        int toff = 0;
+        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
+        const float* __restrict__ tbl = tb + toff;
+        const bool full = tile_full<L>((long)t * TS, N, vec);
         float X[L], GY[L];
-        {
-            float4 v[L / 4];
-            tile_load_global<L>(xr, (long)t * TS, N, vec, v);
-            tile_to_chunks<L>(tbuf, v, X);
-            tile_load_global<L>(gr, (long)t * TS, N, vec, v);
-            tile_to_chunks<L>(tbuf, v, GY);
+        if (full) {
+            f4 vx[L / 4], vg[L / 4];
+            tile_load_full<L>(xr, (long)t * TS, vx);
+            tile_load_full<L>(gr, (long)t * TS, vg);
+            tile_regs_to_lds<L>(tbx, vx);
+            tile_regs_to_lds<L>(tbg, vg);
+        } else {
+            tile_global_to_lds_guarded<L>(tbx, xr, (long)t * TS, N);
+            tile_global_to_lds_guarded<L>(tbg, gr, (long)t * TS, N);
         }
+        lds_to_chunks<L>(tbx, X);
+        lds_to_chunks<L>(tbg, GY);
         // ---- forward chunk start states from the carry saved by the forward pass ----
-        float st[S2];
+        f2 st[S];
         {
-            float z[S2];
-            table_apply<S2, L>(tb + LY::G, X, z);
             const float* __restrict__ cs = carries + ((size_t)row * nt + t) * S2;
+            tile_scan<S, L>(X, tbl + LY::GT, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+                [&](int k, f2& K) { K = f2{cs[2 * k], cs[2 * k + 1]}; },
+                [&](int, f2) {});
+        }
+        // ---- adjoint chunk end states: the scan runs from lane 63 down to lane 0, done on lane-mirrored data ----
+        f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
+        {
+            tile_scan<S, L>(GY, tbl + LY::GAT, [](f2 v) { return f2{wave_mirror(v.x), wave_mirror(v.y)}; }, lam,
+                tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
+                [&](int i, f2& K) {
+                    if (W == 1) K = Kreg[i];
+                    else if (r == 0) K = f2{0.f, 0.f};
+                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
+                },
+                [&](int i, f2 Kn) {
+                    if (W == 1) Kreg[i] = Kn;
+                    else if (t > 0) mbox_publish(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                });
 #pragma unroll
-            for (int k = 0; k < S; ++k) {
-                float f1 = z[2 * k], f2 = z[2 * k + 1];
+            for (int i = 0; i < S; ++i) lam[i] = f2{wave_mirror(lam[i].x), wave_mirror(lam[i].y)};
+        }
+        pin(X); pin(GY); pin(st); pin(lam);   // scans done before the cascade passes start
+        __builtin_amdgcn_sched_barrier(0);
+        f2 st_lo[H];   // start states of sections [0, H) for the second pass
 #pragma unroll
-                for (int j = 0; j < k; ++j) {
-                    const float* m = tb + LY::M + (2 * k) * S2 + 2 * j;
-                    f1 = fmaf(m[0], st[2 * j], fmaf(m[1], st[2 * j + 1], f1));
-                    f2 = fmaf(m[S2], st[2 * j], fmaf(m[S2 + 1], st[2 * j + 1], f2));
-                }
-                const float K1 = cs[2 * k], K2 = cs[2 * k + 1];
-                if (lane == 0) {  // fold the known carry into lane 0's forcing (no chain here)
-                    const float* p0 = tb + LY::P + (k * 7 + 0) * 4;
-                    f1 += p0[0] * K1 - p0[2] * K2;
-                    f2 += p0[1] * K1 + p0[0] * K2;
-                }
+        for (int k = 0; k < H; ++k) st_lo[k] = st[k];
+
+        float S2v[SH][L + 2];
 #pragma unroll
-                for (int l = 0; l < 6; ++l) {
-                    const float* pp = tb + LY::P + (k * 7 + l) * 4;
-                    const float t1 = shift_up(f1, 1 << l), t2 = shift_up(f2, 1 << l);
-                    if (lane >= (1 << l)) {
-                        f1 += pp[0] * t1 - pp[2] * t2;
-                        f2 += pp[1] * t1 + pp[0] * t2;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int k0 = pass == 0 ? H : 0, k1 = pass == 0 ? S : H;   // sections whose gradients this pass produces
+            // coefficient loads addressed with an opaque per-pass zero land in VGPRs (full-rate VALU operands)
+            // and cannot be hoisted out of the tile loop; the second pass is additionally chained behind the
+            // last value the first pass produces, otherwise its forward half is scheduled alongside the
+            // first pass's adjoint half and both sets of s2 signals are live at once
+            const int oz = pass == 0 ? opaque_zero() : opaque_zero_after(GY[0]);
+            if (pass == 0) {
+                // sections [0, H): outputs only, one section at a time, in place over X (X is re-read from LDS below)
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
+                    const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+                    const float nk = -ca.z;
+                    float s1 = st[k].x, s2 = st[k].y;
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                        s2 = fmaf(ca.y, s1, ca.x * s2);
+                        s1 = t1;
                     }
                 }
-                const float s1 = shift_up(f1, 1), s2 = shift_up(f2, 1);
-                st[2 * k] = lane == 0 ? K1 : s1;
-                st[2 * k + 1] = lane == 0 ? K2 : s2;
+            } else {
+                lds_to_chunks<L>(tbx + oz, X);
+#pragma unroll
+                for (int k = 0; k < H; ++k) st[k] = st_lo[k];
             }
-        }
-        // ---- adjoint chunk end states (scan runs from lane 63 down to lane 0) ----
-        float lam[S2];  // adjoint section order: i <-> forward section S-1-i
-        {
-            float z[S2];
-            table_apply<S2, L>(tb + LY::GA, GY, z);
+            // forward sections [k0, k1) keeping s2_k[n], n = 0..L+1
 #pragma unroll
-            for (int i = 0; i < S; ++i) {
-                const int k = S - 1 - i;
-                float f1 = z[2 * i], f2 = z[2 * i + 1];
+            for (int k = k0; k < k1; ++k) {
+                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);
+                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);
+                const float nk = -ca.z;
+                float s1 = st[k].x, s2 = st[k].y;
 #pragma unroll
-                for (int j = 0; j < i; ++j) {
-                    const float* m = tb + LY::MA + (2 * i) * S2 + 2 * j;
-                    f1 = fmaf(m[0], lam[2 * j], fmaf(m[1], lam[2 * j + 1], f1));
-                    f2 = fmaf(m[S2], lam[2 * j], fmaf(m[S2 + 1], lam[2 * j + 1], f2));
+                for (int n = 0; n < L; ++n) {
+                    const float u = X[n];
+                    S2v[k - k0][n] = s2;
+                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                    const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                    s2 = fmaf(ca.y, s1, ca.x * s2);
+                    s1 = t1;
                 }
-#pragma unroll
-                for (int l = 0; l < 6; ++l) {
-                    const float* pp = tb + LY::P + (k * 7 + l) * 4;   // transposed: [[p, q], [-kq, p]]
-                    const float t1 = shift_down(f1, 1 << l), t2 = shift_down(f2, 1 << l);
-                    if (lane + (1 << l) < 64) {
-                        f1 += pp[0] * t1 + pp[1] * t2;
-                        f2 += pp[0] * t2 - pp[2] * t1;
-                    }
-                }
-                float K1, K2;
-                if (W == 1) {
-                    K1 = Kreg[2 * i]; K2 = Kreg[2 * i + 1];
-                } else if (r == 0) {
-                    K1 = 0.f; K2 = 0.f;
-                } else {
-                    mbox_wait(mb_in + 4 * i, t + 1, K1, K2);
-                }
-                {
-                    const float* p64 = tb + LY::P + (k * 7 + 6) * 4;
-                    const float e1 = read_lane(f1, 0), e2 = read_lane(f2, 0);
-                    const float n1 = e1 + p64[0] * K1 + p64[1] * K2;
-                    const float n2 = e2 + p64[0] * K2 - p64[2] * K1;
-                    if (W == 1) { Kreg[2 * i] = n1; Kreg[2 * i + 1] = n2; }
-                    else if (t > 0) mbox_publish(mb_out + 4 * i, n1, n2, t);
-                }
-                const float kap = tb[LY::COEF + k * 8 + 6];
-                const float E1 = f1 + pwp[k] * K1 + pwq[k] * K2;
-                const float E2 = f2 + pwp[k] * K2 - kap * pwq[k] * K1;
-                const float s1 = shift_down(E1, 1), s2 = shift_down(E2, 1);
-                lam[2 * i] = lane == 63 ? K1 : s1;
-                lam[2 * i + 1] = lane == 63 ? K2 : s2;
+                S2v[k - k0][L] = s2;
+                S2v[k - k0][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
             }
-        }
-        // ---- forward cascade over the chunk, keeping s2_k[n] (n = 0..L+1) ----
-        float S2v[S][L + 2];
+            pin(S2v); pin(GY);
+            __builtin_amdgcn_sched_barrier(0);
+            // adjoint sections k1-1 .. k0 (descending time) + coefficient correlations, in place over GY
 #pragma unroll
-        for (int n = 0; n < L; ++n) {
-            float u = X[n];
+            for (int k = k1 - 1; k >= k0; --k) {
+                const int i = S - 1 - k;
+                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);
+                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);
+                const float nk = -ca.z;
+                float l1 = lam[i].x, l2 = lam[i].y;
+                float b0 = accb[k][0], b1 = accb[k][1], b2 = accb[k][2], a1 = acca[k][0], a2 = acca[k][1];
 #pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const float* cf = tb + LY::COEF + k * 8;
-                const float s1 = st[2 * k], s2 = st[2 * k + 1];
-                S2v[k][n] = s2;
-                const float yv = fmaf(cf[3], s1, fmaf(cf[4], s2, cf[5] * u));
-                st[2 * k] = fmaf(cf[0], s1, fmaf(-cf[2], s2, u));
-                st[2 * k + 1] = fmaf(cf[1], s1, cf[0] * s2);
-                u = yv;
+                for (int n = L - 1; n >= 0; --n) {
+                    const float g = GY[n];
+                    b0 = fmaf(g, S2v[k - k0][n + 2], b0);
+                    b1 = fmaf(g, S2v[k - k0][n + 1], b1);
+                    b2 = fmaf(g, S2v[k - k0][n], b2);
+                    const float o = fmaf(cb.y, g, l1);
+                    const float t1 = fmaf(ca.x, l1, fmaf(ca.y, l2, ca.w * g));
+                    l2 = fmaf(nk, l1, fmaf(ca.x, l2, cb.x * g));
+                    l1 = t1;
+                    a1 = fmaf(o, S2v[k - k0][n + 1], a1);
+                    a2 = fmaf(o, S2v[k - k0][n], a2);
+                    GY[n] = o;
+                    // keep the correlations next to the recurrence: hoisting the whole recurrence first keeps
+                    // both g[n] and o[n] of all samples live (+16 registers per section)
+                    if ((n & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+                // pinned: otherwise the compiler defers these updates to the end of the tile and keeps all
+                // 5*S per-tile sums live next to the 5*S running sums
+                pin(b0); pin(b1); pin(b2); pin(a1); pin(a2);
+                accb[k][0] = b0; accb[k][1] = b1; accb[k][2] = b2; acca[k][0] = a1; acca[k][1] = a2;
             }
+            pin(GY);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const float* cf = tb + LY::COEF + k * 8;
-            S2v[k][L] = st[2 * k + 1];
-            S2v[k][L + 1] = fmaf(cf[1], st[2 * k], cf[0] * st[2 * k + 1]);  // s2 does not see the input
-        }
-        // ---- adjoint cascade (descending n) + coefficient correlations ----
-#pragma unroll
-        for (int n = L - 1; n >= 0; --n) {
-            float g = GY[n];
-#pragma unroll
-            for (int i = 0; i < S; ++i) {
-                const int k = S - 1 - i;
-                const float* cf = tb + LY::COEF + k * 8;
-                const float l1 = lam[2 * i], l2 = lam[2 * i + 1];
-                accb[k][0] = fmaf(g, S2v[k][n + 2], accb[k][0]);
-                accb[k][1] = fmaf(g, S2v[k][n + 1], accb[k][1]);
-                accb[k][2] = fmaf(g, S2v[k][n], accb[k][2]);
-                const float o = fmaf(cf[5], g, l1);
-                lam[2 * i] = fmaf(cf[0], l1, fmaf(cf[1], l2, cf[3] * g));
-                lam[2 * i + 1] = fmaf(-cf[2], l1, fmaf(cf[0], l2, cf[4] * g));
-                acca[k][0] = fmaf(o, S2v[k][n + 1], acca[k][0]);
-                acca[k][1] = fmaf(o, S2v[k][n], acca[k][1]);
-                g = o;
-            }
-            GY[n] = g;
-        }
-        {
-            float4 out[L / 4];
-            chunks_to_tile<L>(tbuf, GY, out);
-            tile_store_global<L>(gxr, (long)t * TS, N, vec, out);
-        }
+        chunks_to_lds<L>(tbx, GY);
+        if (full) tile_lds_to_global_full<L>(tbx, gxr, (long)t * TS);
+        else tile_lds_to_global_guarded<L>(tbx, gxr, (long)t * TS, N);
     }
     // per-wave partial sums -> partials[row][wave][S][5]
     float* po = partials + ((size_t)row * W + wave) * S * 5;
@@ -638,8 +774,8 @@ using namespace dasp;
 
 namespace {
 constexpr int kL = 16;    // samples per lane chunk
-constexpr int kWF = 8;    // waves per row, forward
-constexpr int kWB = 4;    // waves per row, backward
+constexpr int kWF = 6;    // waves per row, forward (2 rows per CU -> 3 waves per SIMD, 168 VGPRs)
+constexpr int kWB = 4;    // waves per row, backward (2 rows per CU -> 2 waves per SIMD; measured faster than 6 waves at 168 registers)
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
