@@ -1,3 +1,3 @@
 """dasp_pytorch_amd -- MI355X-native hot path of dasp_pytorch.functional."""
-from .functional import parametric_eq  # noqa: F401
-from . import signal  # noqa: F401
+from . import functional, signal  # noqa: F401
+from .functional import distortion, gain, parametric_eq  # noqa: F401

@@ -1,0 +1,149 @@
+// gain and distortion: fused elementwise forward / backward with in-kernel parameter-gradient
+// reduction. Replaces dasp_pytorch/functional.py:10-29 (gain) and :65-78 (distortion) and their
+// autograd graphs.  HBM-bound: forward 8 B per channel-sample (read x, write y), backward 12 B
+// (read x, read gy, write gx; tanh is recomputed, y is never re-read).
+//
+// Layout: x, y, gy, gx (B, C, N) fp32 contiguous; a row = one (b, c) signal. Control values are
+// indexed  row / cdiv  (gain: cdiv = C, one gain per batch item repeated over channels,
+// functional.py:26-28;  distortion: cdiv = 1, one drive per (b, c) row, functional.py:78).
+// Grid = (segments per row, rows); a segment is SEG consecutive samples handled by one 256-thread
+// workgroup with float4 accesses. Backward writes one partial sum per (row, segment); a finalize
+// kernel reduces them in fp64 (deterministic, no float atomics).
+#include "common.hpp"
+
+namespace dasp {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_SEG = 8192;                 // samples per workgroup: 8 float4 per thread
+constexpr float LN10_OVER_20 = 0.11512925464970228f;
+
+enum { EW_GAIN = 0, EW_DIST = 1 };
+
+template <int OP>
+__device__ __forceinline__ float ew_fwd(float x, float lin) {
+    return OP == EW_GAIN ? x * lin : tanhf(x * lin);
+}
+// returns d(loss)/dx, accumulates d(loss)/d(lin)*lin into acc (chain rule to dB applied in finalize)
+template <int OP>
+__device__ __forceinline__ float ew_bwd(float x, float g, float lin, float& acc) {
+    if (OP == EW_GAIN) {
+        acc = fmaf(g, x, acc);
+        return g * lin;
+    } else {
+        const float y = tanhf(x * lin);
+        const float t = g * (1.f - y * y);
+        acc = fmaf(t, x, acc);
+        return t * lin;
+    }
+}
+
+template <int OP, bool BWD>
+__global__ void __launch_bounds__(EW_THREADS)
+ew_kernel(const float* __restrict__ x, const float* __restrict__ ctl_db, const float* __restrict__ gy,
+          float* __restrict__ out, float* __restrict__ partials, int cdiv, long N, int nseg, int vec) {
+    const int row = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const float lin = exp10f(ctl_db[row / cdiv] * 0.05f);
+    const long base = (long)row * N, s0 = (long)seg * EW_SEG;
+    const long s1 = s0 + EW_SEG < N ? s0 + EW_SEG : N;
+    float acc = 0.f;
+    if (vec && s1 - s0 == EW_SEG) {
+#pragma unroll
+        for (int j = 0; j < EW_SEG / (4 * EW_THREADS); ++j) {
+            const long i = base + s0 + (long)(j * EW_THREADS + tid) * 4;
+            const f4 xv = *reinterpret_cast<const f4*>(x + i);
+            f4 o;
+            if (BWD) {
+                const f4 g = *reinterpret_cast<const f4*>(gy + i);
+                o.x = ew_bwd<OP>(xv.x, g.x, lin, acc); o.y = ew_bwd<OP>(xv.y, g.y, lin, acc);
+                o.z = ew_bwd<OP>(xv.z, g.z, lin, acc); o.w = ew_bwd<OP>(xv.w, g.w, lin, acc);
+            } else {
+                o.x = ew_fwd<OP>(xv.x, lin); o.y = ew_fwd<OP>(xv.y, lin); o.z = ew_fwd<OP>(xv.z, lin); o.w = ew_fwd<OP>(xv.w, lin);
+            }
+            *reinterpret_cast<f4*>(out + i) = o;
+        }
+    } else {
+        for (long n = s0 + tid; n < s1; n += EW_THREADS)
+            out[base + n] = BWD ? ew_bwd<OP>(x[base + n], gy[base + n], lin, acc) : ew_fwd<OP>(x[base + n], lin);
+    }
+    if (BWD) {
+        __shared__ float red[EW_THREADS / 64];
+        const float w = wave_sum(acc);
+        if (lane_id() == 0) red[wave_id()] = w;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < EW_THREADS / 64; ++i) s += red[i];
+            partials[(size_t)row * nseg + seg] = s * lin;
+        }
+    }
+}
+
+// gctl[i] = ln10/20 * sum over the cdiv rows of control i and their segments of partials
+__global__ void ew_finalize_kernel(const float* __restrict__ partials, float* __restrict__ gctl, int nctl, int cdiv, int nseg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nctl) return;
+    double s = 0.0;
+    const float* p = partials + (size_t)i * cdiv * nseg;
+    for (int k = 0; k < cdiv * nseg; ++k) s += (double)p[k];
+    gctl[i] = (float)(s * (double)LN10_OVER_20);
+}
+
+}  // namespace dasp
+
+// ================================================================================================
+// C-ABI (include/dasp_hip.h)
+using namespace dasp;
+
+namespace {
+inline int ew_check() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DASP_OK : (int)e;
+}
+inline bool ew_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int ew_nseg(long N) { return (int)((N + EW_SEG - 1) / EW_SEG); }
+
+template <int OP>
+int ew_forward(const float* x, const float* ctl, float* y, int B, int C, long N, void* stream) {
+    if (!x || !ctl || !y || B <= 0 || C <= 0 || N <= 0) return DASP_ERR_ARG;
+    const long rows = (long)B * C;
+    if (rows > 65535) return DASP_ERR_UNSUPPORTED;
+    const int nseg = ew_nseg(N), vec = (N % 4 == 0) && ew_al16(x) && ew_al16(y);
+    hipLaunchKernelGGL((ew_kernel<OP, false>), dim3(nseg, (unsigned)rows), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ctl, nullptr, y,
+                       nullptr, OP == EW_GAIN ? C : 1, N, nseg, vec);
+    return ew_check();
+}
+template <int OP>
+int ew_backward(const float* x, const float* ctl, const float* gy, float* gx, float* gctl, float* partials, int B, int C, long N,
+                void* stream) {
+    if (!x || !ctl || !gy || !gx || !gctl || !partials || B <= 0 || C <= 0 || N <= 0) return DASP_ERR_ARG;
+    const long rows = (long)B * C;
+    if (rows > 65535) return DASP_ERR_UNSUPPORTED;
+    const int nseg = ew_nseg(N), vec = (N % 4 == 0) && ew_al16(x) && ew_al16(gy) && ew_al16(gx);
+    const int cdiv = OP == EW_GAIN ? C : 1, nctl = (int)(rows / cdiv);
+    hipLaunchKernelGGL((ew_kernel<OP, true>), dim3(nseg, (unsigned)rows), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ctl, gy, gx, partials,
+                       cdiv, N, nseg, vec);
+    int st = ew_check();
+    if (st != DASP_OK) return st;
+    hipLaunchKernelGGL(ew_finalize_kernel, dim3((nctl + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, gctl, nctl, cdiv, nseg);
+    return ew_check();
+}
+}  // namespace
+
+extern "C" {
+long dasp_ew_partial_floats(long rows, long N) { return rows * ew_nseg(N); }
+int dasp_gain_forward(const float* x, const float* gain_db, float* y, int B, int C, long N, void* stream) {
+    return ew_forward<EW_GAIN>(x, gain_db, y, B, C, N, stream);
+}
+int dasp_gain_backward(const float* x, const float* gain_db, const float* gy, float* gx, float* ggain, float* partials, int B, int C,
+                       long N, void* stream) {
+    return ew_backward<EW_GAIN>(x, gain_db, gy, gx, ggain, partials, B, C, N, stream);
+}
+int dasp_distortion_forward(const float* x, const float* drive_db, float* y, int B, int C, long N, void* stream) {
+    return ew_forward<EW_DIST>(x, drive_db, y, B, C, N, stream);
+}
+int dasp_distortion_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive, float* partials, int B,
+                             int C, long N, void* stream) {
+    return ew_backward<EW_DIST>(x, drive_db, gy, gx, gdrive, partials, B, C, N, stream);
+}
+}  // extern "C"

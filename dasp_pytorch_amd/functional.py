@@ -2,9 +2,30 @@
 (dasp_pytorch/functional.py), every effect computed by hand-written HIP kernels (csrc/)."""
 import torch
 
-from .ops import FILTER_TYPES, ParametricEQFunction
+from .ops import FILTER_TYPES, DistortionFunction, GainFunction, ParametricEQFunction
 
 _PEQ_TYPES = [FILTER_TYPES[t] for t in ("low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf")]
+
+
+def gain(x: torch.Tensor, sample_rate: int, gain_db: torch.Tensor):
+    """Apply gain in dB; the same gain is applied to every channel of a batch item
+    (reference: dasp_pytorch/functional.py:10-29). gain_db: bs values (any shape that views to (bs, 1, 1))."""
+    bs, chs, seq_len = x.size()
+    if gain_db.numel() != bs:   # the reference's gain_db.view(bs, 1, 1)
+        raise RuntimeError(f"shape '[{bs}, 1, 1]' is invalid for input of size {gain_db.numel()}")
+    return GainFunction.apply(x, gain_db)
+
+
+def distortion(x: torch.Tensor, sample_rate: int, drive_db: torch.Tensor):
+    """Soft-clipping distortion tanh(x * 10^(drive_db/20)) (reference: dasp_pytorch/functional.py:65-78).
+    As in the reference's drive_db.view(bs, chs, -1), drive_db must hold one value per (batch item,
+    channel) row, i.e. bs*chs values (so a (bs,) drive only works for mono input). The reference would
+    also accept bs*chs*k values broadcastable against seq_len; that per-sample form is not supported."""
+    bs, chs, seq_len = x.size()
+    if drive_db.numel() != bs * chs:
+        raise RuntimeError(f"shape '[{bs}, {chs}, -1]' is invalid for input of size {drive_db.numel()} "
+                           "(dasp_pytorch_amd supports one drive value per (batch, channel) row)")
+    return DistortionFunction.apply(x, drive_db)
 
 
 def parametric_eq(

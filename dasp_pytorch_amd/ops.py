@@ -129,3 +129,60 @@ class ParametricEQFunction(torch.autograd.Function):
         gcols = tuple(gpt[i].reshape(shape).to(dt) if need else None
                       for i, ((dt, shape), need) in enumerate(zip(ctx.ctl, ctx.needs_input_grad[3:])))
         return (gx.to(ctx.x_dtype) if ctx.needs_input_grad[0] else None, None, None) + gcols
+
+
+class _ElementwiseFunction(torch.autograd.Function):
+    """Shared plumbing of gain / distortion: y = f(x, ctl), ctl one dB value per batch item (gain)
+    or per (b, c) row (distortion)."""
+    FWD = BWD = None
+
+    @classmethod
+    def _run(cls, ctx, x, ctl):
+        _lib.require_device(x, "x")
+        L = _lib.lib()
+        B, C, N = x.shape
+        x32 = _f32c(x)
+        c32 = ctl.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+        y = torch.empty_like(x32)
+        call(cls.FWD, ptr(x32), ptr(c32), ptr(y), B, C, N, stream())
+        ctx.save_for_backward(x32, c32)
+        ctx.meta = (x.dtype, ctl.dtype, ctl.shape)
+        return y.to(x.dtype)
+
+    @classmethod
+    def _grad(cls, ctx, gy):
+        L = _lib.lib()
+        x32, c32 = ctx.saved_tensors
+        B, C, N = x32.shape
+        gx = torch.empty_like(x32)
+        gctl = torch.empty_like(c32)
+        partials = torch.empty(L.dasp_ew_partial_floats(B * C, N), dtype=torch.float32, device=x32.device)
+        call(cls.BWD, ptr(x32), ptr(c32), ptr(_f32c(gy)), ptr(gx), ptr(gctl), ptr(partials), B, C, N, stream())
+        xd, cd, cshape = ctx.meta
+        return gx.to(xd), gctl.reshape(cshape).to(cd)
+
+
+class GainFunction(_ElementwiseFunction):
+    """y = x * 10^(gain_db/20); gain_db holds one value per batch item (functional.py:10-29)."""
+    FWD, BWD = "dasp_gain_forward", "dasp_gain_backward"
+
+    @staticmethod
+    def forward(ctx, x, gain_db):
+        return GainFunction._run(ctx, x, gain_db)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return GainFunction._grad(ctx, gy)
+
+
+class DistortionFunction(_ElementwiseFunction):
+    """y = tanh(x * 10^(drive_db/20)); drive_db holds one value per (b, c) row (functional.py:65-78)."""
+    FWD, BWD = "dasp_distortion_forward", "dasp_distortion_backward"
+
+    @staticmethod
+    def forward(ctx, x, drive_db):
+        return DistortionFunction._run(ctx, x, drive_db)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return DistortionFunction._grad(ctx, gy)

@@ -62,6 +62,22 @@ int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float*
 int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S,
                            int mode, float* gout, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * gain / distortion.  Replace dasp_pytorch.functional.gain (dasp_pytorch/functional.py:10-29):
+ * y = x * 10^(gain_db/20), gain_db (B) one value per batch item repeated over channels (:26-28);
+ * and dasp_pytorch.functional.distortion (functional.py:65-78): y = tanh(x * 10^(drive_db/20)),
+ * drive_db (B*C) one value per (b, c) row (the reference's drive_db.view(bs, chs, -1), :78).
+ * Backward: gx = dL/dx, ggain (B) / gdrive (B*C) = dL/d(control in dB); `partials` is scratch of
+ * dasp_ew_partial_floats(B*C, N) floats. Rows (B*C) must be <= 65535.
+ * ------------------------------------------------------------------------------------------- */
+long dasp_ew_partial_floats(long rows, long N);
+int dasp_gain_forward(const float* x, const float* gain_db, float* y, int B, int C, long N, void* stream);
+int dasp_gain_backward(const float* x, const float* gain_db, const float* gy, float* gx, float* ggain,
+                       float* partials, int B, int C, long N, void* stream);
+int dasp_distortion_forward(const float* x, const float* drive_db, float* y, int B, int C, long N, void* stream);
+int dasp_distortion_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive,
+                             float* partials, int B, int C, long N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
