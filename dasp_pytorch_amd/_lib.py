@@ -35,6 +35,11 @@ SIGNATURES = {
     "dasp_gain_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
     "dasp_distortion_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dasp_distortion_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
+    "dasp_dyn_num_tiles": (_l, [_l]),
+    "dasp_dyn_carry_floats": (_l, [_l, _l]),
+    "dasp_dyn_partial_floats": (_l, [_l]),
+    "dasp_dynamics_forward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
+    "dasp_dynamics_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
 }
 
 

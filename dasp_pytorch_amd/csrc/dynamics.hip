@@ -1,0 +1,409 @@
+// Dynamic-range compressor / downward expander: gain computer + one-pole ballistics as a wave-level
+// first-order recurrence scan, forward and hand-derived adjoint, for gfx950.
+//
+// Replaces dasp_pytorch.functional.compressor (dasp_pytorch/functional.py:275-399), whose smoothing
+// filter g[n] = (1-a) g_c[n] + a g[n-1] is evaluated by the reference as a frequency-sampled FFT
+// filter (signal.lfilter_via_fsm, dasp_pytorch/signal.py:95-133), and the autograd graph behind
+// both. `expander` is a stub in the reference (functional.py:402-403); mode 1 implements the
+// textbook downward expander with the same structure (no reference behaviour to match).
+//
+// Work decomposition: batch item -> one workgroup of W waves (the side chain is shared by the
+// item's channels); tile = 1024 consecutive samples -> one wave, tiles round-robin; inside a tile
+// the samples stay in the *coalesced* layout (sub-tile j = 256 samples, lane l holds 4 consecutive
+// samples 256 j + 4 l ..) so there is no LDS transpose: each lane runs its 4 samples, a DPP scan
+// (row_shr 1/2/4/8 + row_bcast 15/31, powers of alpha) joins the 64 lanes, the 4 sub-tiles chain
+// through one FMA each, and the tile carry travels wave -> wave through an LDS mailbox.
+// HBM-bound: forward 8 B per channel-sample (read x, write y), backward 12 B (x, gy, gx).
+#include "common.hpp"
+
+namespace dasp {
+
+constexpr int DY_L = 16, DY_SUB = DY_L / 4, DY_TS = 64 * DY_L;
+constexpr float DB_PER_LOG2 = 6.020599913279624f;      // 20 / log2(10)
+constexpr float LOG2_PER_DB = 0.16609640474436813f;    // log2(10) / 20
+constexpr float LN10_20 = 0.11512925464970228f;        // ln(10) / 20
+constexpr float DB_SLOPE = 8.685889638065037f;         // 20 / ln(10)
+
+struct DynItem {   // per-item constants, wave-uniform
+    float thr, inv_ratio, ratio, knee, makeup, eps;
+    float alpha, beta, a4, a8, a16, a32, a256, a1024;
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ddpp0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float dshr1(float v) {   // lane i <- v[i-1], lane 0 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dmirror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((63 - lane_id()) * 4, __builtin_bit_cast(int, v)));
+}
+
+// inclusive scan E_i = e_i + a4 * E_{i-1} over the 64 lanes
+__device__ __forceinline__ float lane_scan(float e, const DynItem& it, float pw16, float pw32) {
+    e = fmaf(it.a4, ddpp0<0x111, 0xf>(e), e);
+    e = fmaf(it.a8, ddpp0<0x112, 0xf>(e), e);
+    e = fmaf(it.a16, ddpp0<0x114, 0xf>(e), e);
+    e = fmaf(it.a32, ddpp0<0x118, 0xf>(e), e);
+    e = fmaf(pw16, ddpp0<0x142, 0xa>(e), e);
+    e = fmaf(pw32, ddpp0<0x143, 0xc>(e), e);
+    return e;
+}
+
+// static gain computer: level in dB -> gain in dB (g_c = x_sc - x_db) and, if D, its partial derivatives
+template <int MODE, bool D>
+__device__ __forceinline__ float gain_computer(float x_db, const DynItem& it, float& d_x, float& d_t, float& d_r, float& d_w) {
+    const float half = 0.5f * it.knee, lo = it.thr - half, hi = it.thr + half;
+    const bool in_knee = (x_db >= lo) && (x_db <= hi) && (it.knee > 0.f);
+    float g = 0.f;
+    if (D) { d_x = d_t = d_r = d_w = 0.f; }
+    if (MODE == 0) {   // compressor, functional.py:350-369
+        const float sl = it.inv_ratio - 1.f;   // 1/R - 1
+        if (x_db > hi) {
+            g = (x_db - it.thr) * sl;
+            if (D) { d_x = sl; d_t = -sl; d_r = -(x_db - it.thr) * it.inv_ratio * it.inv_ratio; }
+        } else if (in_knee) {
+            const float q = x_db - lo, iw = 1.f / it.knee, h = 0.5f * q * q * iw;
+            g = sl * h;
+            if (D) { d_x = sl * q * iw; d_t = -d_x; d_r = -h * it.inv_ratio * it.inv_ratio; d_w = sl * (0.5f * q * iw - h * iw); }
+        }
+    } else {           // downward expander: x_sc = T + (x_db - T) R below the knee
+        const float sl = 1.f - it.ratio;       // 1 - R
+        if (x_db < lo) {
+            g = -(x_db - it.thr) * sl;
+            if (D) { d_x = -sl; d_t = sl; d_r = x_db - it.thr; }
+        } else if (in_knee) {
+            const float q = x_db - hi, iw = 1.f / it.knee, h = 0.5f * q * q * iw;
+            g = sl * h;
+            if (D) { d_x = sl * q * iw; d_t = -d_x; d_r = -h; d_w = sl * (-0.5f * q * iw - h * iw); }
+        }
+    }
+    return g;
+}
+
+__device__ __forceinline__ DynItem load_item(const float* __restrict__ ctl, int b, double sample_rate, float eps) {
+    // ctl rows: threshold_db, ratio, attack_ms, knee_db, makeup_gain_db
+    const float* c = ctl + (size_t)b * 5;
+    DynItem it;
+    it.thr = c[0]; it.ratio = c[1]; it.inv_ratio = 1.f / c[1]; it.knee = c[3]; it.makeup = c[4]; it.eps = eps;
+    const double nat = sample_rate * ((double)c[2] / 1e3);                    // functional.py:339
+    const double a = exp(-2.1972245773362196 / nat);                          // :341-342, ln 9
+    const double a2 = a * a, a4 = a2 * a2, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16, a64 = a32 * a32, a128 = a64 * a64,
+                 a256 = a128 * a128, a512 = a256 * a256;
+    it.alpha = (float)a; it.beta = (float)(1.0 - a);
+    it.a4 = (float)a4; it.a8 = (float)a8; it.a16 = (float)a16; it.a32 = (float)a32; it.a256 = (float)a256; it.a1024 = (float)(a512 * a512);
+    return it;
+}
+// alpha^(4 m) for a per-lane m, fp64 repeated squaring (m < 128)
+__device__ __forceinline__ float alpha_pow4(float alpha, int m) {
+    double p = 1.0, s = (double)alpha; s = s * s; s = s * s;   // alpha^4
+    for (int bit = 0; bit < 7; ++bit) {
+        if (m & (1 << bit)) p *= s;
+        s *= s;
+    }
+    return (float)p;
+}
+
+// sample index of element i of sub-tile j for this lane, relative to the tile start
+__device__ __forceinline__ int dy_pos(int j, int lane, int i) { return j * 256 + 4 * lane + i; }
+
+template <int CREG>
+struct DynTile { f4 v[CREG > 0 ? CREG : 1][DY_SUB]; };
+
+__device__ __forceinline__ f4 load4(const float* __restrict__ p, long idx, long n_valid, bool fast) {
+    if (fast) return *reinterpret_cast<const f4*>(p + idx);
+    f4 r;
+    r.x = (idx + 0 >= 0 && idx + 0 < n_valid) ? p[idx + 0] : 0.f;
+    r.y = (idx + 1 >= 0 && idx + 1 < n_valid) ? p[idx + 1] : 0.f;
+    r.z = (idx + 2 >= 0 && idx + 2 < n_valid) ? p[idx + 2] : 0.f;
+    r.w = (idx + 3 >= 0 && idx + 3 < n_valid) ? p[idx + 3] : 0.f;
+    return r;
+}
+__device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_valid, bool fast, f4 v) {
+    if (fast) { *reinterpret_cast<f4*>(p + idx) = v; return; }
+    if (idx + 0 < n_valid) p[idx + 0] = v.x;
+    if (idx + 1 < n_valid) p[idx + 1] = v.y;
+    if (idx + 2 < n_valid) p[idx + 2] = v.z;
+    if (idx + 3 < n_valid) p[idx + 3] = v.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward. x, y (B, C, N); carries (B, nt) state entering each tile (may be null); lin_buf (B, N)
+// receives the linear gain when lookahead > 0 (the backward needs it at shifted positions).
+template <int MODE, int W>
+__global__ void __launch_bounds__(64 * W)
+dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y, float* __restrict__ carries,
+               float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps) {
+    __shared__ float lds[W * 4];
+    const int lane = lane_id(), wave = wave_id(), b = blockIdx.x;
+    const DynItem it = load_item(ctl, b, sample_rate, eps);
+    const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
+    const float* __restrict__ xb = x + (size_t)b * C * N;
+    float* __restrict__ yb = y + (size_t)b * C * N;
+    const int mb_in = wave * 4, mb_out = ((wave + 1) % W) * 4;
+    for (int i = threadIdx.x; i < W * 4; i += 64 * W) lds[i] = 0.f;
+    __syncthreads();
+    float Kreg = 0.f;
+    for (int t = wave; t < nt; t += W) {
+        const long base = (long)t * DY_TS;
+        const bool fast = vec && base + DY_TS <= N;
+        // side chain: sum over channels (functional.py:328)
+        f4 s[DY_SUB];
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) s[j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) s[j] += load4(xb + (size_t)c * N, base + dy_pos(j, lane, 0), N, fast);
+        }
+        // gain computer, then the zero-state response of each lane's 4 samples and the lane scan
+        float E[DY_SUB];
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            float d0, d1, d2, d3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x_db = DB_PER_LOG2 * log2f(fmaxf(fabsf(s[j][i]), it.eps));   // :347
+                s[j][i] = gain_computer<MODE, false>(x_db, it, d0, d1, d2, d3);           // s now holds g_c
+            }
+            const float e = it.beta * fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, s[j].x, s[j].y), s[j].z), s[j].w);
+            E[j] = lane_scan(e, it, pw16, pw32);
+        }
+        float K;
+        if (W == 1) K = Kreg;
+        else if (t == 0) K = 0.f;
+        else { float dummy; mbox_wait(lds, mb_in, t, K, dummy); }
+        {   // carry for the next tile: the only work on the cross-wave serial chain
+            float Kn = K;
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) Kn = fmaf(it.a256, Kn, read_lane(E[j], 63));
+            if (W == 1) Kreg = Kn;
+            else if (t + 1 < nt) mbox_publish(lds, mb_out, Kn, 0.f, t + 1);
+        }
+        if (carries && lane == 0) carries[(size_t)b * nt + t] = K;
+        // exact smoothed gain per sample -> linear gain
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            float g = fmaf(pws, K, dshr1(E[j]));                 // state entering this lane's 4 samples
+            K = fmaf(it.a256, K, read_lane(E[j], 63));           // state entering the next sub-tile
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g = fmaf(it.alpha, g, it.beta * s[j][i]);        // :372-380 as a recursion
+                s[j][i] = exp2f((g + it.makeup) * LOG2_PER_DB);   // :388-391
+            }
+            if (lin_buf) store4(lin_buf + (size_t)b * N, base + dy_pos(j, lane, 0), N, fast, s[j]);
+        }
+        // y = x (delayed by `look` samples) * lin, every channel (:383-394)
+        const bool fast_in = fast && look == 0;
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) {
+                const long p = base + dy_pos(j, lane, 0);
+                const f4 xv = load4(xb + (size_t)c * N, p - look, N, fast_in);
+                store4(yb + (size_t)c * N, p, N, fast, xv * s[j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward. Walks the tiles in reverse; recomputes the forward gain from the saved tile carries,
+// runs the adjoint one-pole scan on lane-mirrored data, accumulates the control gradients.
+// partials: (B, W, 5) = d/d threshold, ratio, alpha, knee, makeup (per wave, fp32).
+template <int MODE, int W>
+__global__ void __launch_bounds__(64 * W)
+dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const float* __restrict__ gy,
+               const float* __restrict__ carries, const float* __restrict__ lin_buf, float* __restrict__ gx,
+               float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps) {
+    __shared__ float lds[W * 4];
+    const int lane = lane_id(), wave = wave_id(), b = blockIdx.x;
+    const DynItem it = load_item(ctl, b, sample_rate, eps);
+    const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
+    const float* __restrict__ xb = x + (size_t)b * C * N;
+    const float* __restrict__ gb = gy + (size_t)b * C * N;
+    float* __restrict__ gxb = gx + (size_t)b * C * N;
+    const int mb_in = wave * 4, mb_out = ((wave + 1) % W) * 4;
+    for (int i = threadIdx.x; i < W * 4; i += 64 * W) lds[i] = 0.f;
+    __syncthreads();
+    float Rreg = 0.f;
+    float acc_t = 0.f, acc_r = 0.f, acc_a = 0.f, acc_w = 0.f, acc_m = 0.f;
+    for (int r = wave; r < nt; r += W) {
+        const int t = nt - 1 - r;
+        const long base = (long)t * DY_TS;
+        const bool fast = vec && base + DY_TS <= N, fast_in = fast && look == 0;
+        f4 s[DY_SUB], q[DY_SUB];
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) { s[j] = f4{0.f, 0.f, 0.f, 0.f}; q[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) {
+                const long p = base + dy_pos(j, lane, 0);
+                const f4 xv = load4(xb + (size_t)c * N, p, N, fast);
+                s[j] += xv;
+                const f4 xd = look == 0 ? xv : load4(xb + (size_t)c * N, p - look, N, false);
+                q[j] += load4(gb + (size_t)c * N, p, N, fast) * xd;            // sum_c gy * x_d
+            }
+        }
+        // forward recompute: g_c, lane scan, exact g and lin; keep x_db (in s) and g_c
+        f4 gc[DY_SUB], gs[DY_SUB];   // gc = gain computer output, gs = smoothed gain g[n]
+        float E[DY_SUB];
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            float d0, d1, d2, d3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gc[j][i] = gain_computer<MODE, false>(DB_PER_LOG2 * log2f(fmaxf(fabsf(s[j][i]), it.eps)), it, d0, d1, d2, d3);
+            const float e = it.beta * fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, gc[j].x, gc[j].y), gc[j].z), gc[j].w);
+            E[j] = lane_scan(e, it, pw16, pw32);
+        }
+        float K = carries[(size_t)b * nt + t];
+        float gprev[DY_SUB];          // g[n-1] for the first sample of each lane's group
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            float g = fmaf(pws, K, dshr1(E[j]));
+            gprev[j] = g;
+            K = fmaf(it.a256, K, read_lane(E[j], 63));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g = fmaf(it.alpha, g, it.beta * gc[j][i]);
+                gs[j][i] = g;
+                const float lin = exp2f((g + it.makeup) * LOG2_PER_DB);
+                q[j][i] *= LN10_20 * lin;                       // q = dL/d(g + makeup)
+                acc_m += q[j][i];
+            }
+        }
+        // adjoint one-pole r[n] = q[n] + alpha r[n+1]: mirrored lanes, sub-tiles in reverse
+        float Er[DY_SUB];
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            const float e = fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, q[j].w, q[j].z), q[j].y), q[j].x);   // value leaving towards n-1
+            Er[j] = lane_scan(dmirror(e), it, pw16, pw32);     // mirrored lane m = 63 - l; scan direction = decreasing time
+        }
+        float R;
+        if (W == 1) R = Rreg;
+        else if (r == 0) R = 0.f;
+        else { float dummy; mbox_wait(lds, mb_in, t + 1, R, dummy); }
+        {
+            float Rn = R;
+#pragma unroll
+            for (int j = DY_SUB - 1; j >= 0; --j) Rn = fmaf(it.a256, Rn, read_lane(Er[j], 63));
+            if (W == 1) Rreg = Rn;
+            else if (t > 0) mbox_publish(lds, mb_out, Rn, 0.f, t);
+        }
+#pragma unroll
+        for (int j = DY_SUB - 1; j >= 0; --j) {
+            // r[n+1] for this lane's last sample: in mirrored space, the inclusive scan of the previous mirrored lane
+            float rn = dmirror(fmaf(pws, R, dshr1(Er[j])));
+            R = fmaf(it.a256, R, read_lane(Er[j], 63));
+            f4 gside;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                rn = fmaf(it.alpha, rn, q[j][i]);                                  // r[n]
+                const float glast = i == 0 ? gprev[j] : gs[j][i - 1];
+                acc_a = fmaf(rn, glast - gc[j][i], acc_a);                         // dL/dalpha
+                const float p = it.beta * rn;                                      // dL/dg_c[n]
+                const float mag = fabsf(s[j][i]);
+                const float x_db = DB_PER_LOG2 * log2f(fmaxf(mag, it.eps));
+                float d_x, d_t, d_r, d_w;
+                gain_computer<MODE, true>(x_db, it, d_x, d_t, d_r, d_w);
+                acc_t = fmaf(p, d_t, acc_t); acc_r = fmaf(p, d_r, acc_r); acc_w = fmaf(p, d_w, acc_w);
+                gside[i] = mag >= it.eps ? p * d_x * DB_SLOPE * __builtin_copysignf(1.f, s[j][i]) / mag : 0.f;
+            }
+            q[j] = gside;    // dL/d(side chain sample)
+        }
+        // gx = gy[n + look] * lin[n + look] + dL/ds  (functional.py:383-394 transposed)
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) {
+                const long p = base + dy_pos(j, lane, 0);
+                f4 lin;
+                if (look == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lin[i] = exp2f((gs[j][i] + it.makeup) * LOG2_PER_DB);
+                } else {
+                    lin = load4(lin_buf + (size_t)b * N, p + look, N, false);
+                }
+                const f4 g = load4(gb + (size_t)c * N, p + look, N, fast_in);
+                store4(gxb + (size_t)c * N, p, N, fast, g * lin + q[j]);
+            }
+        }
+    }
+    float* po = partials + ((size_t)b * W + wave) * 5;
+    const float v0 = wave_sum(acc_t), v1 = wave_sum(acc_r), v2 = wave_sum(acc_a), v3 = wave_sum(acc_w), v4 = wave_sum(acc_m);
+    if (lane == 0) { po[0] = v0; po[1] = v1; po[2] = v2; po[3] = v3; po[4] = v4; }
+}
+
+// gctl (B, 5): dL/d threshold_db, ratio, attack_ms, knee_db, makeup_gain_db
+__global__ void dyn_finalize_kernel(const float* __restrict__ partials, const float* __restrict__ ctl, int B, int Wn, double sample_rate,
+                                    float* __restrict__ gctl) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < Wn; ++w)
+        for (int i = 0; i < 5; ++i) a[i] += (double)partials[((size_t)b * Wn + w) * 5 + i];
+    const double atk = (double)ctl[(size_t)b * 5 + 2], nat = sample_rate * (atk / 1e3), alpha = exp(-2.1972245773362196 / nat);
+    float* o = gctl + (size_t)b * 5;
+    o[0] = (float)a[0];
+    o[1] = (float)a[1];
+    o[2] = (float)(a[2] * alpha * 2.1972245773362196 / (nat * nat) * (sample_rate / 1e3));   // d alpha / d attack_ms
+    o[3] = (float)a[3];
+    o[4] = (float)a[4];
+}
+
+}  // namespace dasp
+
+// ================================================================================================
+// C-ABI (include/dasp_hip.h)
+using namespace dasp;
+
+namespace {
+constexpr int kDW = 8;   // waves per batch item
+inline int dy_check() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DASP_OK : (int)e;
+}
+inline bool dy_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+extern "C" {
+
+long dasp_dyn_num_tiles(long N) { return (N + DY_TS - 1) / DY_TS; }
+long dasp_dyn_carry_floats(long B, long N) { return B * dasp_dyn_num_tiles(N); }
+long dasp_dyn_partial_floats(long B) { return B * kDW * 5; }
+
+int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, int B, int C, long N,
+                          double sample_rate, float eps, int lookahead, void* stream) {
+    if (!x || !ctl || !y || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1)) return DASP_ERR_ARG;
+    if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
+    if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_dyn_num_tiles(N), vec = (N % 4 == 0) && dy_al16(x) && dy_al16(y) && (!lin_buf || dy_al16(lin_buf));
+    if (mode == 0)
+        hipLaunchKernelGGL((dyn_fwd_kernel<0, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, y, carries,
+                           lookahead > 0 ? lin_buf : nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps);
+    else
+        hipLaunchKernelGGL((dyn_fwd_kernel<1, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, y, carries,
+                           lookahead > 0 ? lin_buf : nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps);
+    return dy_check();
+}
+
+int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
+                           float* gx, float* gctl, float* partials, int B, int C, long N, double sample_rate, float eps, int lookahead,
+                           void* stream) {
+    if (!x || !ctl || !gy || !carries || !gx || !gctl || !partials || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
+        (mode != 0 && mode != 1))
+        return DASP_ERR_ARG;
+    if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
+    if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_dyn_num_tiles(N), vec = (N % 4 == 0) && dy_al16(x) && dy_al16(gy) && dy_al16(gx);
+    if (mode == 0)
+        hipLaunchKernelGGL((dyn_bwd_kernel<0, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, gy, carries, lin_buf, gx,
+                           partials, C, (int)N, nt, vec, lookahead, sample_rate, eps);
+    else
+        hipLaunchKernelGGL((dyn_bwd_kernel<1, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, gy, carries, lin_buf, gx,
+                           partials, C, (int)N, nt, vec, lookahead, sample_rate, eps);
+    int st = dy_check();
+    if (st != DASP_OK) return st;
+    hipLaunchKernelGGL(dyn_finalize_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, ctl, B, kDW, sample_rate, gctl);
+    return dy_check();
+}
+
+}  // extern "C"

@@ -2,7 +2,7 @@
 (dasp_pytorch/functional.py), every effect computed by hand-written HIP kernels (csrc/)."""
 import torch
 
-from .ops import FILTER_TYPES, DistortionFunction, GainFunction, ParametricEQFunction
+from .ops import FILTER_TYPES, DistortionFunction, DynamicsFunction, GainFunction, ParametricEQFunction
 
 _PEQ_TYPES = [FILTER_TYPES[t] for t in ("low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf")]
 
@@ -66,3 +66,51 @@ def parametric_eq(
     if any(c.numel() != n for c in controls) or n not in (1, bs):
         raise RuntimeError(f"parametric_eq controls must each hold {bs} (or 1) values, got {[c.numel() for c in controls]}")
     return ParametricEQFunction.apply(x, float(sample_rate), _PEQ_TYPES, *controls)
+
+
+def _dynamics(mode, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples):
+    bs, chs, seq_len = x.size()
+    ctls = (threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db)
+    for c in ctls:   # the reference's .view(-1, 1, 1) against a (bs, 1, seq_len) side chain: no parameter broadcasting
+        if c.numel() != bs:
+            raise RuntimeError(f"The size of tensor a ({c.numel()}) must match the size of tensor b ({bs}) at non-singleton dimension 0")
+    return DynamicsFunction.apply(x, mode, float(sample_rate), float(eps), int(lookahead_samples), *ctls)
+
+
+def compressor(
+    x: torch.Tensor,
+    sample_rate: float,
+    threshold_db: torch.Tensor,
+    ratio: torch.Tensor,
+    attack_ms: torch.Tensor,
+    release_ms: torch.Tensor,
+    knee_db: torch.Tensor,
+    makeup_gain_db: torch.Tensor,
+    eps: float = 1e-8,
+    lookahead_samples: int = 0,
+):
+    """Feed-forward dynamic range compressor (reference: dasp_pytorch/functional.py:275-399): summed side
+    chain, soft-knee gain computer in dB, one-pole smoothing with the attack time constant (release_ms is
+    accepted and ignored, exactly like the reference), optional look-ahead delay of the signal path, make-up
+    gain. The smoothing filter is evaluated as an exact recurrence (chunked scan) instead of the reference's
+    frequency-sampling FFT filter. Deviation: knee_db == 0 gives finite gradients (the reference's are NaN)."""
+    return _dynamics(0, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples)
+
+
+def expander(
+    x: torch.Tensor,
+    sample_rate: float,
+    threshold_db: torch.Tensor,
+    ratio: torch.Tensor,
+    attack_ms: torch.Tensor,
+    release_ms: torch.Tensor,
+    knee_db: torch.Tensor,
+    makeup_gain_db: torch.Tensor,
+    eps: float = 1e-8,
+    lookahead_samples: int = 0,
+):
+    """Downward expander with the compressor's structure and signature. The reference's `expander()` raises
+    NotImplementedError (dasp_pytorch/functional.py:402-403), so there is no reference behaviour: below
+    threshold - knee/2 the level is mapped to T + (x_db - T) * ratio, with the standard quadratic soft knee
+    (Giannoulis, Massberg & Reiss 2012), above the knee the signal is untouched."""
+    return _dynamics(1, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples)

@@ -186,3 +186,53 @@ class DistortionFunction(_ElementwiseFunction):
     @staticmethod
     def backward(ctx, gy):
         return DistortionFunction._grad(ctx, gy)
+
+
+class DynamicsFunction(torch.autograd.Function):
+    """Compressor (mode 0) / expander (mode 1). Controls enter as separate tensors with bs elements
+    each, in the reference's order: threshold_db, ratio, attack_ms, release_ms, knee_db,
+    makeup_gain_db (functional.py:275-286); release_ms is unused, as in the reference."""
+
+    @staticmethod
+    def forward(ctx, x, mode, sample_rate, eps, lookahead, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db):
+        _lib.require_device(x, "x")
+        L = _lib.lib()
+        B, C, N = x.shape
+        ctls = (threshold_db, ratio, attack_ms, knee_db, makeup_gain_db)
+        ctl = torch.stack([c.detach().reshape(-1).to(device=x.device, dtype=torch.float32) for c in ctls], dim=1).contiguous()
+        x32 = _f32c(x)
+        y = torch.empty_like(x32)
+        need = any(ctx.needs_input_grad)
+        carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
+        lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
+        call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
+             float(eps), int(lookahead), stream())
+        if need:
+            ctx.save_for_backward(x32, ctl, carries, lin if lin is not None else torch.empty(0, device=x.device))
+            ctx.cfg = (mode, float(sample_rate), float(eps), int(lookahead))
+            ctx.meta = (x.dtype, [(c.dtype, c.shape) for c in (threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db)])
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x32, ctl, carries, lin = ctx.saved_tensors
+        mode, sr, eps, look = ctx.cfg
+        B, C, N = x32.shape
+        gx = torch.empty_like(x32)
+        gctl = torch.empty(B, 5, dtype=torch.float32, device=x32.device)
+        partials = torch.empty(L.dasp_dyn_partial_floats(B), dtype=torch.float32, device=x32.device)
+        call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
+             ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
+        xd, cm = ctx.meta
+        g = gctl.t().contiguous()      # rows: threshold, ratio, attack, knee, makeup
+        rows = {0: g[0], 1: g[1], 2: g[2], 4: g[3], 5: g[4]}
+        outs = []
+        for i, ((dt, shape), need) in enumerate(zip(cm, ctx.needs_input_grad[5:])):
+            if not need:
+                outs.append(None)
+            elif i == 3:               # release_ms: no path to the output (functional.py:340,343-344)
+                outs.append(torch.zeros(shape, dtype=dt, device=x32.device))
+            else:
+                outs.append(rows[i].reshape(shape).to(dt))
+        return (gx.to(xd) if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(outs)

@@ -78,6 +78,30 @@ int dasp_distortion_forward(const float* x, const float* drive_db, float* y, int
 int dasp_distortion_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive,
                              float* partials, int B, int C, long N, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dynamics: compressor / expander.  mode 0 replaces dasp_pytorch.functional.compressor
+ * (dasp_pytorch/functional.py:275-399: side-chain sum :328, level in dB :347, soft-knee gain
+ * computer :350-369, one-pole smoothing :372-380 which the reference evaluates through
+ * signal.lfilter_via_fsm, dasp_pytorch/signal.py:95-133, look-ahead delay :383-385, make-up and
+ * dB->linear :388-394). mode 1 is a downward expander of the same structure; the reference's
+ * expander is a stub (functional.py:402-403), so it has no reference behaviour.
+ *
+ * x, y, gy, gx: (B, C, N) fp32 contiguous. ctl: (B, 5) fp32 rows [threshold_db, ratio, attack_ms,
+ * knee_db, makeup_gain_db] (release_ms is unused by the reference, :340,343-344, and has no entry).
+ * carries: dasp_dyn_carry_floats(B, N) floats written by forward, read by backward (may be NULL in
+ * forward when no backward follows). lin_buf: (B, N) floats, required only when lookahead > 0
+ * (forward writes the linear gain, backward reads it at shifted positions). gctl: (B, 5) = dL/dctl.
+ * partials: scratch of dasp_dyn_partial_floats(B) floats.
+ * ------------------------------------------------------------------------------------------- */
+long dasp_dyn_num_tiles(long N);
+long dasp_dyn_carry_floats(long B, long N);
+long dasp_dyn_partial_floats(long B);
+int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf,
+                          int B, int C, long N, double sample_rate, float eps, int lookahead, void* stream);
+int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
+                           const float* lin_buf, float* gx, float* gctl, float* partials, int B, int C, long N,
+                           double sample_rate, float eps, int lookahead, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,3 +245,136 @@ def distortion_vjp(x, sample_rate, drive_db, gy, dtype=np.float64):
     gx = t * lin
     gd = np.sum(t * x * lin, axis=2, keepdims=True) * (math.log(10.0) / 20.0)
     return gx.astype(dtype), gd.reshape(np.asarray(drive_db).shape).astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# compressor  (functional.py:275-399, smoothing filter through signal.py:95-133)
+
+
+def lfilter_via_fsm(x, b, a, dtype=np.float64):
+    """signal.py:95-133. x (bs,1,T), b, a (bs,K) -> y (bs,1,T)."""
+    x = np.asarray(x, dtype)
+    T = x.shape[-1]
+    n_fft = n_fft_for(T)
+    H = fft_freqz(np.asarray(b, dtype), np.asarray(a, dtype), n_fft)
+    return freqdomain_fir(x, H[:, None], n_fft)[..., :T].astype(dtype)
+
+
+def _compressor_core(x, sample_rate, threshold_db, ratio, attack_ms, knee_db, makeup_gain_db, eps, lookahead, dtype):
+    x = np.asarray(x, dtype)
+    bs, chs, T = x.shape
+    col = lambda v: np.asarray(v, dtype).reshape(bs, 1, 1)
+    thr, rat, atk, knee, mk = col(threshold_db), col(ratio), col(attack_ms), col(knee_db), col(makeup_gain_db)
+    x_side = x.sum(1, keepdims=True)                                     # :328
+    nat = sample_rate * (atk / dtype(1e3))                               # :339
+    alpha = np.exp(-np.log(dtype(9.0)) / nat)                            # :341-342
+    mag = np.maximum(np.abs(x_side), dtype(eps))
+    x_db = 20 * np.log10(mag)                                            # :347
+    lo, hi = thr - knee / 2, thr + knee / 2
+    in_knee = (x_db >= lo) & (x_db <= hi)                                # :355-357
+    above = x_db > hi                                                    # :364
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x_sc_knee = x_db + ((1 / rat) - 1) * ((x_db - thr + knee / 2) ** 2) / (2 * knee)   # :358-360
+    x_sc = np.where(in_knee, x_sc_knee, x_db)
+    x_sc = np.where(above, thr + (x_db - thr) / rat, x_sc)               # :365-366
+    g_c = x_sc - x_db                                                    # :369
+    b = np.concatenate([1 - alpha, np.zeros_like(alpha)], -1)[:, 0]      # :372-375
+    a = np.concatenate([np.ones_like(alpha), -alpha], -1)[:, 0]          # :376-379
+    g = lfilter_via_fsm(g_c, b, a, dtype)                                # :380
+    x_d = x
+    if lookahead > 0:                                                    # :383-385
+        x_d = np.roll(x, lookahead, axis=-1)
+        x_d[:, :, :lookahead] = 0
+    lin = 10 ** ((g + mk) / dtype(20.0))                                 # :388-391
+    return dict(x=x, x_side=x_side, x_db=x_db, mag=mag, in_knee=in_knee, above=above, g_c=g_c, g=g, lin=lin, x_d=x_d,
+                thr=thr, rat=rat, atk=atk, knee=knee, mk=mk, alpha=alpha, nat=nat, b=b, a=a)
+
+
+def compressor(x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps=1e-8,
+               lookahead_samples=0, dtype=np.float64):
+    """functional.py:275-399. release_ms is accepted and unused, exactly like the reference (:340,343-344)."""
+    c = _compressor_core(x, sample_rate, threshold_db, ratio, attack_ms, knee_db, makeup_gain_db, eps, lookahead_samples, dtype)
+    return (c["x_d"] * c["lin"]).astype(dtype)                            # :394
+
+
+def compressor_vjp(x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, gy, eps=1e-8,
+                   lookahead_samples=0, dtype=np.float64):
+    """Hand-derived VJP of `compressor` (the reference uses autograd through the FFT filter).
+    Returns (gx, dict of control grads: threshold_db, ratio, attack_ms, release_ms (zeros), knee_db, makeup_gain_db)."""
+    c = _compressor_core(x, sample_rate, threshold_db, ratio, attack_ms, knee_db, makeup_gain_db, eps, lookahead_samples, dtype)
+    gy = np.asarray(gy, dtype)
+    bs, chs, T = c["x"].shape
+    k = lookahead_samples
+    lin, x_d = c["lin"], c["x_d"]
+    gxd = gy * lin                                                        # d/dx_d
+    gx = gxd.copy()
+    if k > 0:
+        gx = np.zeros_like(gxd)
+        gx[:, :, :T - k] = gxd[:, :, k:]
+    ggs = np.sum(gy * x_d, 1, keepdims=True) * lin * (math.log(10.0) / 20.0)    # dL/d(g + makeup)
+    g_mk = ggs.sum((1, 2))
+    # adjoint of the FSM filter (circular convolution on n_fft points) wrt its input and coefficients
+    n_fft = n_fft_for(T)
+    b, a = c["b"], c["a"]
+    Bf, Af = np.fft.rfft(b, n_fft, axis=-1), np.fft.rfft(a, n_fft, axis=-1)
+    H = Bf / Af
+    G = np.fft.rfft(ggs, n_fft, axis=-1)
+    g_gc = np.fft.irfft(G * np.conj(H)[:, None], n_fft, axis=-1)[..., :T]
+    X = np.fft.rfft(c["g_c"], n_fft, axis=-1)
+    gpad = np.zeros((bs, 1, n_fft), np.float64)
+    gpad[..., :T] = ggs
+    q = np.fft.irfft(X / Af[:, None], n_fft, axis=-1)
+    r = np.fft.irfft(X * (H / Af)[:, None], n_fft, axis=-1)
+    g_b0 = np.sum(gpad * q, (1, 2))
+    g_a1 = -np.sum(gpad * np.roll(r, 1, -1), (1, 2))
+    g_alpha = -g_b0 - g_a1                                                # b0 = 1 - alpha, a1 = -alpha
+    alpha, nat, atk = c["alpha"][:, 0, 0], c["nat"][:, 0, 0], c["atk"][:, 0, 0]
+    g_atk = g_alpha * alpha * math.log(9.0) / (nat * nat) * (sample_rate / 1e3)
+    # gain computer
+    thr, rat, knee, x_db = c["thr"], c["rat"], c["knee"], c["x_db"]
+    qk = x_db - thr + knee / 2
+    ik, ab = c["in_knee"], c["above"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d_xdb = np.where(ab, 1 / rat - 1, np.where(ik, (1 / rat - 1) * qk / knee, 0.0))
+        d_thr = np.where(ab, 1 - 1 / rat, np.where(ik, -(1 / rat - 1) * qk / knee, 0.0))
+        d_rat = np.where(ab, -(x_db - thr) / rat ** 2, np.where(ik, -(qk ** 2) / (2 * knee) / rat ** 2, 0.0))
+        d_knee = np.where(ik, (1 / rat - 1) * (qk / (2 * knee) - qk ** 2 / (2 * knee ** 2)), 0.0)
+    g_thr = np.sum(g_gc * d_thr, (1, 2))
+    g_rat = np.sum(g_gc * d_rat, (1, 2))
+    g_knee = np.sum(g_gc * d_knee, (1, 2))
+    g_xdb = g_gc * d_xdb
+    s = c["x_side"]
+    g_side = np.where(np.abs(s) >= eps, g_xdb * (20.0 / math.log(10.0)) * np.sign(s) / c["mag"], 0.0)   # clamp passes grad at >= eps
+    gx = gx + g_side                                                      # x_side = x.sum(1)
+    shp = np.asarray(threshold_db).shape
+    grads = dict(threshold_db=g_thr, ratio=g_rat, attack_ms=g_atk, release_ms=np.zeros(bs), knee_db=g_knee, makeup_gain_db=g_mk)
+    return gx.astype(dtype), {k_: v.reshape(shp).astype(dtype) for k_, v in grads.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# expander -- PARITY UNPINNED: the reference's expander() is a stub (functional.py:402-403), so this
+# is a statement of the design the HIP kernel implements (mode 1 of csrc/dynamics.hip), not of any
+# reference behaviour. Same structure as compressor(); only the static curve differs.
+
+
+def expander(x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps=1e-8,
+             lookahead_samples=0, dtype=np.float64):
+    x = np.asarray(x, dtype)
+    bs, chs, T = x.shape
+    col = lambda v: np.asarray(v, dtype).reshape(bs, 1, 1)
+    thr, rat, atk, knee, mk = col(threshold_db), col(ratio), col(attack_ms), col(knee_db), col(makeup_gain_db)
+    x_side = x.sum(1, keepdims=True)
+    alpha = np.exp(-np.log(dtype(9.0)) / (sample_rate * (atk / dtype(1e3))))
+    x_db = 20 * np.log10(np.maximum(np.abs(x_side), dtype(eps)))
+    lo, hi = thr - knee / 2, thr + knee / 2
+    in_knee = (x_db >= lo) & (x_db <= hi) & (knee > 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x_sc = np.where(x_db < lo, thr + (x_db - thr) * rat, np.where(in_knee, x_db + (1 - rat) * (x_db - hi) ** 2 / (2 * knee), x_db))
+    g_c = x_sc - x_db
+    from scipy.signal import lfilter
+    g = np.stack([lfilter([1 - alpha[b, 0, 0]], [1.0, -alpha[b, 0, 0]], g_c[b], axis=-1) for b in range(bs)])
+    x_d = x
+    if lookahead_samples > 0:
+        x_d = np.roll(x, lookahead_samples, axis=-1)
+        x_d[:, :, :lookahead_samples] = 0
+    return (x_d * 10 ** ((g + mk) / dtype(20.0))).astype(dtype)

@@ -102,9 +102,40 @@ def gain_dist_case(name, B, C, N, seed):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+COMP_KEYS = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
+
+
+def comp_case(name, B, C, N, seed, lookahead=0, speechlike=False):
+    """compressor fwd + all gradients (BASELINE config 3 at a size the CPU reference runs in seconds).
+    knee is kept >= 1e-3 (the reference's backward is NaN at knee_db == 0)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    if speechlike:   # slow random envelope spanning -60..0 dBFS so that all three knee regions are exercised
+        env_db = torch.nn.functional.interpolate(torch.rand(B, 1, N // 500 + 2, generator=g) * 60 - 60, size=N, mode="linear")
+        x = x * 10 ** (env_db / 20)
+    pn = torch.rand(B, 6, generator=g)
+    pn[:, 4] = pn[:, 4].clamp_min(1e-3 / 12)
+    mod = dasp_pytorch.Compressor(SR)
+    d = denorm(mod, pn)
+    params = torch.stack([d[k] for k in COMP_KEYS], 1)
+    w = torch.randn(B, C, N, generator=g)
+    out = dict(x=f32(x), params=f32(params), w=f32(w), lookahead=np.int64(lookahead))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        cols = [params[:, i].to(dt).clone().requires_grad_(True) for i in range(6)]
+        y = RF.compressor(xx, SR, *cols, lookahead_samples=lookahead)
+        (y * w.to(dt)).sum().backward()
+        gp = torch.stack([c.grad if c.grad is not None else torch.zeros_like(c) for c in cols], 1)
+        out["y" + tag], out["gx" + tag], out["gp" + tag] = f32(y), f32(xx.grad), f32(gp)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     eq_case("eq_b3c2_n12000", 3, 2, 12000, 3, seed=101)
     eq_case("eq_bcast_b2c1_n4099", 2, 1, 4099, 1, seed=102)
     sos_case("sos_b2c2_n6000_s3", 2, 2, 6000, 3, seed=103)
     gain_dist_case("gain_dist_cfg1", 4, 1, 16384, seed=104)
+    comp_case("comp_b3c2_n12000", 3, 2, 12000, seed=105, speechlike=True)
+    comp_case("comp_b2c1_n20011_look7", 2, 1, 20011, seed=106, lookahead=7, speechlike=True)

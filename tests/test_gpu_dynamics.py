@@ -1,0 +1,170 @@
+"""GPU parity of compressor (vs reference-generated goldens and the numpy oracle) and expander
+(reference stub -> parity unpinned: checked against the fp64 design model and finite differences).
+
+Tolerances (L-inf / peak per batch item): y and grad_x 2e-5 (north_star bar 1e-4; the dB->linear
+map amplifies fp32 log2/exp2 rounding by ~ln10/20*|gain dB|, the reference's own fp32 run sits at
+1e-5..3e-5); control gradients 2e-4 of the column maximum."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dasp_oracle as orc
+from tests.util import linf_peak, load_golden
+
+pytestmark = pytest.mark.gpu
+SR = 44100
+KEYS = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
+RANGES = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]       # modules.py:179-186, knee kept > 0
+
+
+@pytest.fixture(scope="module")
+def D():
+    assert torch.cuda.is_available()
+    import dasp_pytorch_amd as D
+    return D
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def run(fn, x, p, w, look=0):
+    xt = dev(x).requires_grad_(True)
+    cols = [dev(p[:, i]).requires_grad_(True) for i in range(6)]
+    y = fn(xt, SR, *cols, lookahead_samples=look)
+    (y * dev(w)).sum().backward()
+    torch.cuda.synchronize()
+    gp = torch.stack([c.grad for c in cols], 1).cpu().numpy()
+    return y.detach().cpu().numpy(), xt.grad.cpu().numpy(), gp
+
+
+def speechlike(rng, B, C, N):
+    x = (rng.random((B, C, N)) * 2 - 1)
+    knots = rng.random((B, 1, N // 500 + 2)) * 60 - 60
+    env = np.stack([np.interp(np.linspace(0, knots.shape[-1] - 1, N), np.arange(knots.shape[-1]), knots[b, 0]) for b in range(B)])[:, None]
+    return (x * 10 ** (env / 20)).astype(np.float32)
+
+
+def rand_params(rng, B):
+    u = rng.random((B, 6))
+    return np.stack([u[:, i] * (hi - lo) + lo for i, (lo, hi) in enumerate(RANGES)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["comp_b3c2_n12000", "comp_b2c1_n20011_look7"])
+def test_compressor_golden(D, name):
+    g = load_golden(name)
+    y, gx, gp = run(D.compressor, g["x"], g["params"], g["w"], int(g["lookahead"]))
+    ey, egx = linf_peak(y, g["y64"]), linf_peak(gx, g["gx64"])
+    assert ey.max() < 2e-5 and egx.max() < 2e-5, (ey, egx)
+    for j in range(6):
+        ref = g["gp64"][:, j]
+        assert np.abs(gp[:, j] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), (KEYS[j], gp[:, j], ref)
+    assert np.all(gp[:, 3] == 0)                                  # release_ms has no path to the output
+    assert linf_peak(y, g["y32"]).max() < 1e-4                    # literal north_star bar vs the reference's fp32 output
+    assert np.all(ey <= linf_peak(g["y32"], g["y64"]) + 5e-6)     # not worse than the reference's own fp32 noise
+
+
+@pytest.mark.parametrize("B,C,N,look", [(1, 1, 1, 0), (2, 1, 7, 0), (1, 2, 255, 0), (2, 2, 1024, 0), (1, 3, 1025, 3), (2, 2, 9000, 0),
+                                        (3, 1, 8192 + 5, 64), (4, 2, 262144, 0)])
+def test_compressor_shapes_vs_oracle(D, B, C, N, look):
+    rng = np.random.default_rng(N + 17 * B)
+    x = speechlike(rng, B, C, N) if N >= 1000 else (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, C, N)).astype(np.float32)
+    p = rand_params(rng, B)
+    y, gx, gp = run(D.compressor, x, p, w, look)
+    pd = p.astype(np.float64)
+    if N >= 8192:   # long signals: the reference's circular FFT filter is alias-free -> compare with the oracle of the reference
+        yo = orc.compressor(x, SR, *[pd[:, i] for i in range(6)], lookahead_samples=look)
+        gxo, gco = orc.compressor_vjp(x, SR, *[pd[:, i] for i in range(6)], w, lookahead_samples=look)
+        assert linf_peak(y, yo).max() < 2e-5
+        assert linf_peak(gx, gxo).max() < 5e-5
+        gpo = np.stack([gco[k] for k in KEYS], 1)
+        for j in range(6):
+            assert np.abs(gp[:, j] - gpo[:, j]).max() <= 5e-4 * max(np.abs(gpo[:, j]).max(), 1e-30), (KEYS[j], gp[:, j], gpo[:, j])
+    else:           # short signals: exact recursion (one_pole) is the ground truth
+        from oracle.recursion import one_pole_ref
+        c = orc._compressor_core(x, SR, pd[:, 0], pd[:, 1], pd[:, 2], pd[:, 4], pd[:, 5], 1e-8, look, np.float64)
+        g = one_pole_ref(c["g_c"][:, 0], c["alpha"][:, 0, 0])[:, None]
+        yo = c["x_d"] * 10 ** ((g + c["mk"]) / 20)
+        assert np.abs(y - yo).max() < 2e-5 * max(1.0, np.abs(yo).max())
+    assert np.isfinite(y).all() and np.isfinite(gx).all() and np.isfinite(gp).all()
+
+
+def test_compressor_semantics(D):
+    B, C, N = 2, 2, 5000
+    x = torch.rand(B, C, N, device="cuda:0") * 2 - 1
+    x0 = x.clone()
+    one = lambda v: torch.full((B,), float(v), device="cuda:0")
+    # ratio 1 and no make-up: identity; inputs never mutated; fp64 follows x
+    y = D.compressor(x, SR, one(-20), one(1), one(10), one(50), one(6), one(0))
+    assert (y - x).abs().max().item() < 1e-6 and torch.equal(x, x0)
+    assert D.compressor(x.double(), SR, one(-20), one(4), one(10), one(50), one(6), one(0)).dtype == torch.float64
+    # knee_db == 0 (allowed by modules.py:171): forward finite and gradients finite (reference: NaN)
+    xt = x.clone().requires_grad_(True)
+    k0 = one(0).requires_grad_(True)
+    y = D.compressor(xt, SR, one(-20), one(4), one(10), one(50), k0, one(3))
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(xt.grad).all() and torch.isfinite(k0.grad).all()
+    # look-ahead: the signal is delayed, the gain curve is not (functional.py:383-385)
+    y0 = D.compressor(x, SR, one(-20), one(4), one(10), one(50), one(6), one(0))
+    y5 = D.compressor(x, SR, one(-20), one(4), one(10), one(50), one(6), one(0), lookahead_samples=5)
+    g0 = y0 / x
+    assert (y5[..., :5] == 0).all() and torch.allclose(y5[..., 5:], x[..., :-5] * g0[..., 5:], rtol=1e-5, atol=1e-7)
+    # no parameter broadcasting (the reference raises RuntimeError)
+    with pytest.raises(RuntimeError):
+        D.compressor(x, SR, torch.zeros(1, device="cuda:0"), one(4), one(10), one(50), one(6), one(0))
+
+
+def test_expander_design_model_and_gradcheck(D):
+    """expander has no reference: forward vs the fp64 design model, gradients vs central differences of it."""
+    rng = np.random.default_rng(5)
+    B, C, N = 2, 2, 6000
+    x = speechlike(rng, B, C, N)
+    w = rng.standard_normal((B, C, N)).astype(np.float32)
+    p = np.array([[-35.0, 2.0, 12.0, 50.0, 6.0, 2.0], [-20.0, 3.5, 40.0, 50.0, 10.0, 0.0]], np.float32)
+    y, gx, gp = run(D.expander, x, p, w)
+    pd = p.astype(np.float64)
+    f = lambda xx, pp: orc.expander(xx, SR, *[pp[:, i] for i in range(6)])
+    yo = f(x, pd)
+    assert linf_peak(y, yo).max() < 2e-5
+    for j in (0, 1, 2, 4, 5):
+        h = 1e-4 * max(1.0, abs(pd[0, j]))
+        pp, pm = pd.copy(), pd.copy(); pp[:, j] += h; pm[:, j] -= h
+        fd = ((f(x, pp) - f(x, pm)) * w).sum((1, 2)) / (2 * h)
+        assert np.abs(gp[:, j] - fd).max() <= 2e-3 * np.abs(fd).max() + 1e-6, (KEYS[j], gp[:, j], fd)
+    assert np.all(gp[:, 3] == 0)
+    # grad_x by directional derivative, on a signal whose side chain stays away from zero (d log|s| / ds = 1/s makes
+    # finite differences meaningless next to zero crossings, and the expander is active exactly at low levels)
+    sign = rng.choice([-1.0, 1.0], size=(B, 1, N))
+    xs = (sign * (0.02 + 0.3 * rng.random((B, C, N))) * 10 ** (-rng.random((B, 1, 1)) * 1.5)).astype(np.float32)
+    _, gxs, _ = run(D.expander, xs, p, w)
+    v = rng.standard_normal(xs.shape)
+    h = 1e-5
+    fd = ((f(xs.astype(np.float64) + h * v, pd) - f(xs.astype(np.float64) - h * v, pd)) * w).sum() / (2 * h)
+    assert abs((gxs.astype(np.float64) * v).sum() - fd) < 2e-3 * abs(fd), ((gxs * v).sum(), fd)
+
+
+def test_config3_full_size_properties(D):
+    """BASELINE config 3 (256,2,262144): finite, gain bounded by the static curve, batch rows independent,
+    homogeneity of the adjoint (doubling the upstream gradient doubles every gradient)."""
+    B, C, N = 256, 2, 262144
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    x = (torch.rand(B, C, N, device="cuda:0", generator=gen) * 2 - 1) * 10 ** (-(torch.rand(B, 1, 1, device="cuda:0", generator=gen) * 40) / 20)
+    rng = np.random.default_rng(9)
+    p = rand_params(rng, B)
+    cols = [dev(p[:, i]).requires_grad_(True) for i in range(6)]
+    xt = x.clone().requires_grad_(True)
+    y = D.compressor(xt, SR, *cols)
+    w = torch.randn(B, C, N, device="cuda:0", generator=gen)
+    y.backward(w)
+    assert torch.isfinite(y).all() and torch.isfinite(xt.grad).all() and all(torch.isfinite(c.grad).all() for c in cols)
+    # |y| <= |x| * 10^(makeup/20): a compressor never adds gain beyond the make-up
+    bound = x.abs() * (10 ** (dev(p[:, 5]) / 20)).view(B, 1, 1) * (1 + 1e-5) + 1e-12
+    assert (y.detach().abs() <= bound).all()
+    ys = D.compressor(x[100:103], SR, *[c.detach()[100:103] for c in cols])
+    assert torch.equal(ys, y.detach()[100:103])
+    g1 = [c.grad.clone() for c in cols]; gx1 = xt.grad.clone()
+    xt.grad = None
+    for c in cols: c.grad = None
+    y2 = D.compressor(xt, SR, *cols); y2.backward(2 * w)
+    assert torch.allclose(xt.grad, 2 * gx1, rtol=1e-6, atol=0) and all(torch.allclose(c.grad, 2 * g, rtol=1e-5, atol=1e-12) for c, g in zip(cols, g1))

@@ -79,3 +79,27 @@ def test_chunkscan_model_equals_reference():
         gs[:, 3] = -(np.sum(gb_sum * r["b"], 1) + np.sum(ga_sum[:, 1:] * r["a"], 1)) / a0[:, 0]
         ref = g["gsos64"][b]
         assert np.abs(gs - ref).max() / np.abs(ref).max() < 2e-5
+
+
+COMP_KEYS = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
+
+
+@pytest.mark.parametrize("name", ["comp_b3c2_n12000", "comp_b2c1_n20011_look7"])
+def test_oracle_compressor_matches_reference(name):
+    g = load_golden(name)
+    p = g["params"].astype(np.float64)
+    k = int(g["lookahead"])
+    y = orc.compressor(g["x"], SR, *[p[:, i] for i in range(6)], lookahead_samples=k)
+    assert linf_peak(y, g["y64"]).max() < 2e-6
+    gx, gc = orc.compressor_vjp(g["x"], SR, *[p[:, i] for i in range(6)], g["w"], lookahead_samples=k)
+    assert linf_peak(gx, g["gx64"]).max() < 5e-6
+    gp = np.stack([gc[key] for key in COMP_KEYS], 1)
+    # per control column (they differ by orders of magnitude); release_ms has no path to the output
+    for j in range(6):
+        ref = g["gp64"][:, j]
+        assert np.abs(gp[:, j] - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-30), (COMP_KEYS[j], gp[:, j], ref)
+    assert np.all(g["gp64"][:, 3] == 0)
+    # the golden inputs exercise all three regions of the gain computer
+    c = orc._compressor_core(g["x"], SR, p[:, 0], p[:, 1], p[:, 2], p[:, 4], p[:, 5], 1e-8, k, np.float64)
+    if name == "comp_b3c2_n12000":
+        assert c["in_knee"].any() and c["above"].any() and (~c["in_knee"] & ~c["above"]).any()
