@@ -2,7 +2,8 @@
 (dasp_pytorch/functional.py), every effect computed by hand-written HIP kernels (csrc/)."""
 import torch
 
-from .ops import FILTER_TYPES, DistortionFunction, DynamicsFunction, GainFunction, ParametricEQFunction
+from . import signal as _signal
+from .ops import FILTER_TYPES, DistortionFunction, DynamicsFunction, GainFunction, ParametricEQFunction, ReverbFunction
 
 _PEQ_TYPES = [FILTER_TYPES[t] for t in ("low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf")]
 
@@ -114,3 +115,61 @@ def expander(
     threshold - knee/2 the level is mapped to T + (x_db - T) * ratio, with the standard quadratic soft knee
     (Giannoulis, Massberg & Reiss 2012), above the knee the signal is untouched."""
     return _dynamics(1, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples)
+
+
+def noise_shaped_reverberation(
+    x: torch.Tensor,
+    sample_rate: float,
+    band0_gain: torch.Tensor,
+    band1_gain: torch.Tensor,
+    band2_gain: torch.Tensor,
+    band3_gain: torch.Tensor,
+    band4_gain: torch.Tensor,
+    band5_gain: torch.Tensor,
+    band6_gain: torch.Tensor,
+    band7_gain: torch.Tensor,
+    band8_gain: torch.Tensor,
+    band9_gain: torch.Tensor,
+    band10_gain: torch.Tensor,
+    band11_gain: torch.Tensor,
+    band0_decay: torch.Tensor,
+    band1_decay: torch.Tensor,
+    band2_decay: torch.Tensor,
+    band3_decay: torch.Tensor,
+    band4_decay: torch.Tensor,
+    band5_decay: torch.Tensor,
+    band6_decay: torch.Tensor,
+    band7_decay: torch.Tensor,
+    band8_decay: torch.Tensor,
+    band9_decay: torch.Tensor,
+    band10_decay: torch.Tensor,
+    band11_decay: torch.Tensor,
+    mix: torch.Tensor,
+    num_samples: int = 65536,
+    num_bandpass_taps: int = 1023,
+    noise: torch.Tensor = None,
+    device_noise: bool = False,
+):
+    """Artificial reverberation from frequency-band noise shaping (reference: dasp_pytorch/functional.py:406-577).
+    Mono input is duplicated to stereo and the output always has 2 channels, as in the reference.
+
+    White noise: by default it is drawn exactly like the reference does -- torch.randn(bs*2, 12, num_samples +
+    num_bandpass_taps - 1) from the global *CPU* generator (functional.py:548) and copied to x's device -- so the same
+    torch.manual_seed gives the same impulse responses as the reference. `device_noise=True` draws it on x's device
+    instead (no host->device copy; a different random stream); `noise=` supplies it explicitly. Both keywords are
+    additions; Processor.process_normalized passes only the named parameters above."""
+    assert num_bandpass_taps % 2 == 1, "num_bandpass_taps must be odd"
+    bs, chs, seq_len = x.size()
+    assert chs <= 2, "only mono/stereo signals are supported"
+    if chs == 1:   # if mono copy to stereo (autograd sums the two channel gradients)
+        x = x.repeat(1, 2, 1)
+    band_gains = torch.stack([band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,
+                              band8_gain, band9_gain, band10_gain, band11_gain], dim=1).view(bs, 12)
+    band_decays = torch.stack([band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
+                               band7_decay, band8_decay, band9_decay, band10_decay, band11_decay], dim=1).view(bs, 12)
+    mix = mix.view(bs)
+    filters = _signal.octave_band_filterbank(num_bandpass_taps, sample_rate).squeeze(1).to(x.device)
+    if noise is None:
+        shape = (bs * 2, 12, num_samples + num_bandpass_taps - 1)
+        noise = torch.randn(*shape, device=x.device) if device_noise else torch.randn(*shape).to(x.device)
+    return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples))

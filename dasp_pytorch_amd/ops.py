@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import call, ptr, stream
+from ._lib import call, check, ptr, stream
 
 FILTER_TYPES = {"peaking": 0, "low_shelf": 1, "high_shelf": 2, "low_pass": 3, "high_pass": 4}
 
@@ -236,3 +236,64 @@ class DynamicsFunction(torch.autograd.Function):
             else:
                 outs.append(rows[i].reshape(shape).to(dt))
         return (gx.to(xd) if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(outs)
+
+
+def _cbuf(n, device):
+    """n complex64 elements as a float32 buffer (the C ABI takes void*)."""
+    return torch.empty(2 * n, dtype=torch.float32, device=device)
+
+
+class ReverbFunction(torch.autograd.Function):
+    """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1), filters (nb,taps), gains/decays (B,nb), mix (B)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir):
+        _lib.require_device(x, "x")
+        _lib.ensure_fft()
+        Lb = _lib.lib()
+        B, C, N = x.shape
+        nb, taps = filters.shape
+        dev = x.device
+        sizes = (ctypes.c_long * 12)()
+        check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
+        n1 = sizes[1]
+        x32, n32 = _f32c(x), _f32c(noise)
+        g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
+        f32_ = _f32c(filters)
+        fpad = torch.empty(nb * n1, dtype=torch.float32, device=dev)
+        Fspec = _cbuf(nb * sizes[2], dev)
+        call("dasp_reverb_filter_spectrum", ptr(f32_), nb, taps, n1, ptr(fpad), ptr(Fspec), stream())
+        y = torch.empty_like(x32)
+        wf = torch.empty(sizes[4], dtype=torch.float32, device=dev)
+        Xf, H = _cbuf(sizes[7], dev), _cbuf(sizes[9], dev)
+        z = torch.empty(sizes[6], dtype=torch.float32, device=dev)
+        nspec, yspec = _cbuf(sizes[5], dev), _cbuf(sizes[7], dev)
+        ir_pad = torch.empty(sizes[8], dtype=torch.float32, device=dev)
+        call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(wf), ptr(Xf), ptr(H),
+             ptr(z), ptr(nspec), ptr(yspec), ptr(ir_pad), B, N, L_ir, taps, nb, stream())
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x32, g32, d32, m32, wf, Xf, H, z)
+            ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
+            ctx.meta = (x.dtype, gains.dtype, gains.shape, decays.dtype, decays.shape, mix.dtype, mix.shape)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x32, g32, d32, m32, wf, Xf, H, z = ctx.saved_tensors
+        B, N, L_ir, taps, nb, sizes = ctx.cfg
+        dev = x32.device
+        gx = torch.empty_like(x32)
+        ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
+        gdecay = torch.empty(B, nb, dtype=torch.float32, device=dev)
+        gmix = torch.empty(B, dtype=torch.float32, device=dev)
+        gpad = torch.empty(sizes[6], dtype=torch.float32, device=dev)
+        Gf, cspec = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
+        PQ = _cbuf(2 * sizes[9], dev)
+        pq = torch.empty(2 * sizes[8], dtype=torch.float32, device=dev)
+        part = torch.empty(2 * B * sizes[11] * nb * 2, dtype=torch.float32, device=dev)
+        mix_part = torch.empty(2 * B * sizes[10], dtype=torch.float32, device=dev)
+        call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(g32), ptr(d32), ptr(m32), ptr(wf), ptr(Xf), ptr(H), ptr(z), ptr(gx),
+             ptr(ggain), ptr(gdecay), ptr(gmix), ptr(gpad), ptr(Gf), ptr(cspec), ptr(PQ), ptr(pq), ptr(part), ptr(mix_part),
+             B, N, L_ir, taps, nb, stream())
+        xd, gd, gs, dd, ds, md, ms = ctx.meta
+        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None

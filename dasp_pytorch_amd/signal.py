@@ -5,8 +5,11 @@ recurrence (chunked parallel scan, csrc/sosfilt.hip) instead of the reference's 
 approximation; the two agree to <= 1e-13 in fp64 for stable filters whose impulse response has
 decayed within the signal length.
 """
+import functools
 import math
 
+import numpy as np
+import scipy.signal
 import torch
 
 from .ops import SosFiltFunction
@@ -84,3 +87,25 @@ def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
     for s0 in range(0, n_sections, 8):
         xx = SosFiltFunction.apply(sos[:, s0:s0 + 8], xx)
     return xx.reshape(shape)
+
+
+OCTAVE_BANDS = (31.5, 63, 125, 250, 500, 1000, 2000, 4000, 8000, 16000)
+
+
+@functools.lru_cache(maxsize=16)
+def _octave_band_taps(num_taps: int, sample_rate: float):
+    """SciPy window-method design of the 12 filters, exactly the reference's calls (signal.py:60-87); host-side and
+    parameter-free, so it is designed once per (num_taps, sample_rate) and cached (the reference redesigns per call)."""
+    filts = [scipy.signal.firwin(num_taps, 12, fs=sample_rate)]
+    for fc in OCTAVE_BANDS:
+        f_min = fc / np.sqrt(2)
+        f_max = np.clip(fc * np.sqrt(2), a_min=0, a_max=(sample_rate / 2) * 0.999)
+        filts.append(scipy.signal.firwin(num_taps, [f_min, f_max], fs=sample_rate, pass_zero=False))
+    filts.append(scipy.signal.firwin(num_taps, 18000, fs=sample_rate, pass_zero=False))
+    return np.stack([f.astype("float32")[::-1] for f in filts], 0).copy()   # the reference's torch.flip (a no-op: symmetric)
+
+
+def octave_band_filterbank(num_taps: int, sample_rate: float):
+    """Octave-spaced linear-phase FIR bank, shape (12, 1, num_taps) float32 on the CPU, as the reference
+    (dasp_pytorch/signal.py:42-92): lowpass 12 Hz, ten octave bandpasses 31.5 Hz .. 16 kHz, highpass 18 kHz."""
+    return torch.from_numpy(_octave_band_taps(int(num_taps), float(sample_rate))).unsqueeze(1)

@@ -102,6 +102,33 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
                            const float* lin_buf, float* gx, float* gctl, float* partials, int B, int C, long N,
                            double sample_rate, float eps, int lookahead, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Noise-shaped reverberation.  Replaces dasp_pytorch.functional.noise_shaped_reverberation
+ * (dasp_pytorch/functional.py:406-577): grouped FIR filter bank over white noise (:548-558),
+ * per-band exponential envelope x gain and mean over bands (:561-567), causal convolution of the
+ * input with the resulting 2-channel impulse response truncated to N (:570-572), wet/dry mix (:575).
+ * The filter design (dasp_pytorch.signal.octave_band_filterbank, dasp_pytorch/signal.py:42-92,
+ * SciPy firwin on the host) stays on the host; its taps are passed in.
+ *
+ * FFTs come from hipFFT, bound at run time: call dasp_fft_init once with the path of the libhipfft.so
+ * the process should use (NULL = dlopen("libhipfft.so")). FFT plans are created on first use per
+ * (length, batch) and cached for the life of the process (hipFFT allocates their work areas).
+ *
+ * x, y, gy, gx: (B, 2, N) fp32.  noise: (2B, nb, L + taps - 1).  gains, decays: (B, nb).  mix: (B).
+ * nb <= 16 bands, L = IR length, taps = FIR length.  All buffer sizes come from dasp_reverb_sizes.
+ * ------------------------------------------------------------------------------------------- */
+int dasp_fft_init(const char* libhipfft_path);
+int dasp_fft_ready(void);
+int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [12], see reverb.hip */);
+int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, int n1, float* fpad, void* Fspec, void* stream);
+int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays,
+                        const float* mix, float* y, float* wf, void* Xf, void* H, float* z, void* nspec, void* yspec,
+                        float* ir_pad, int B, long N, int L, int taps, int nb, void* stream);
+int dasp_reverb_backward(const float* x, const float* gy, const float* gains, const float* decays, const float* mix,
+                         const float* wf, const void* Xf, const void* H, const float* z, float* gx, float* ggain,
+                         float* gdecay, float* gmix, float* gpad, void* Gf, void* cspec, void* PQ, float* pq, float* part,
+                         float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

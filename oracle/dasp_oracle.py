@@ -378,3 +378,75 @@ def expander(x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db
         x_d = np.roll(x, lookahead_samples, axis=-1)
         x_d[:, :, :lookahead_samples] = 0
     return (x_d * 10 ** ((g + mk) / dtype(20.0))).astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# noise_shaped_reverberation  (functional.py:406-577, filterbank signal.py:42-92)
+# The reference evaluates both convolutions directly (conv1d); the restatement uses SciPy's fp64
+# FFT convolution, which computes the same linear convolutions to rounding.
+
+OCTAVE_BANDS = [31.5, 63, 125, 250, 500, 1000, 2000, 4000, 8000, 16000]
+
+
+def octave_band_filterbank(num_taps, sample_rate):
+    """signal.py:42-92 -> (12, num_taps) float32 (the reference flips each symmetric filter: a no-op)."""
+    from scipy.signal import firwin
+    filts = [firwin(num_taps, 12, fs=sample_rate)]                                    # :60-64
+    for fc in OCTAVE_BANDS:                                                          # :69-80
+        f_min, f_max = fc / np.sqrt(2), np.clip(fc * np.sqrt(2), 0, (sample_rate / 2) * 0.999)
+        filts.append(firwin(num_taps, [f_min, f_max], fs=sample_rate, pass_zero=False))
+    filts.append(firwin(num_taps, 18000, fs=sample_rate, pass_zero=False))            # :84
+    return np.stack([f.astype(np.float32)[::-1] for f in filts], 0)
+
+
+def _reverb_core(x, sample_rate, gains, decays, mix, noise, num_samples, num_bandpass_taps, dtype):
+    from scipy.signal import fftconvolve
+    x = np.asarray(x, dtype)
+    bs, chs, T = x.shape
+    assert chs <= 2 and num_bandpass_taps % 2 == 1                                    # :487,490
+    if chs == 1:
+        x = np.repeat(x, 2, 1)                                                        # :493-495
+    L = num_samples
+    filt = octave_band_filterbank(num_bandpass_taps, sample_rate).astype(dtype)       # :537-538
+    nb = filt.shape[0]
+    g = np.asarray(gains, dtype).reshape(bs, 1, nb, 1)
+    d = np.asarray(decays, dtype).reshape(bs, 1, nb, 1) * 10.0 + 1.0                  # :562
+    m = np.asarray(mix, dtype).reshape(bs, 1, 1)
+    wn = np.asarray(noise, dtype)                                                     # (2 bs, nb, L + taps - 1), :548
+    # conv1d = cross-correlation with the stored filter, "valid" (:551-556)
+    wf = fftconvolve(wn, filt[None, :, ::-1], mode="valid", axes=-1).reshape(bs, 2, nb, L)
+    t = np.linspace(0, 1, L).astype(dtype)                                            # :561
+    env = np.exp(-d * t.reshape(1, 1, 1, -1))                                         # :563
+    ir = (wf * env * g).mean(2)                                                       # :564-567  (bs, 2, L)
+    y_wet = fftconvolve(x, ir, mode="full", axes=-1)[..., :T]                         # :570-572 causal, truncated
+    return dict(x=x, wf=wf, env=env, g=g, d=d, m=m, t=t, ir=ir, y_wet=y_wet, nb=nb, L=L, T=T, chs=chs)
+
+
+def noise_shaped_reverberation(x, sample_rate, gains, decays, mix, noise, num_samples=65536, num_bandpass_taps=1023, dtype=np.float64):
+    """functional.py:406-577 with band gains/decays stacked as (bs, 12) and the white noise passed in explicitly
+    (the reference draws torch.randn(bs*2, 12, num_samples + taps - 1) from the global CPU generator, :548)."""
+    c = _reverb_core(x, sample_rate, gains, decays, mix, noise, num_samples, num_bandpass_taps, dtype)
+    return ((1 - c["m"]) * c["x"] + c["m"] * c["y_wet"]).astype(dtype)                # :575
+
+
+def noise_shaped_reverberation_vjp(x, sample_rate, gains, decays, mix, noise, gy, num_samples=65536, num_bandpass_taps=1023,
+                                   dtype=np.float64):
+    """Returns gx (shape of x), ggains (bs,12), gdecays (bs,12), gmix (bs,)."""
+    from scipy.signal import fftconvolve
+    c = _reverb_core(x, sample_rate, gains, decays, mix, noise, num_samples, num_bandpass_taps, dtype)
+    gy = np.asarray(gy, dtype)
+    T, L = c["T"], c["L"]
+    gwet = c["m"] * gy
+    # y_wet[n] = sum_j ir[j] x[n-j]  ->  gx[m] = sum_j ir[j] gwet[m+j] ;  gir[j] = sum_n gwet[n] x[n-j]
+    gx = (1 - c["m"]) * gy + fftconvolve(gwet, c["ir"][..., ::-1], mode="full", axes=-1)[..., L - 1:L - 1 + T]
+    full = fftconvolve(gwet, c["x"][..., ::-1], mode="full", axes=-1)                  # lag j at index T-1+j
+    gir = np.zeros_like(c["ir"])
+    nlag = min(L, T)
+    gir[..., :nlag] = full[..., T - 1:T - 1 + nlag]
+    gmix = np.sum(gy * (c["y_wet"] - c["x"]), (1, 2))
+    w = gir[:, :, None, :] * c["wf"] * c["env"] / c["nb"]                             # (bs, 2, nb, L)
+    ggain = w.sum((1, 3))
+    gdec = (w * c["g"] * (-10.0 * c["t"].reshape(1, 1, 1, -1))).sum((1, 3))
+    if c["chs"] == 1:
+        gx = gx.sum(1, keepdims=True)
+    return gx.astype(dtype), ggain.astype(dtype), gdec.astype(dtype), gmix.astype(dtype)

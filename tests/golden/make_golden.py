@@ -131,6 +131,33 @@ def comp_case(name, B, C, N, seed, lookahead=0, speechlike=False):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def reverb_case(name, B, C, N, L, taps, seed, store_noise):
+    """noise_shaped_reverberation fwd + all gradients. The reference draws its noise from the global CPU generator
+    (functional.py:548): the golden records the seed set immediately before each call, plus either the noise itself
+    (small cases) or a checksum of it."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    p = torch.rand(B, 25, generator=g)           # gains 12, decays 12, mix  (modules.py:204-230 ranges are all [0, 1])
+    w = torch.randn(B, 2, N, generator=g)
+    nseed = 4321 + seed
+    torch.manual_seed(nseed)
+    noise = torch.randn(B * 2, 12, L + taps - 1)
+    out = dict(x=f32(x), params=f32(p), w=f32(w), L=np.int64(L), taps=np.int64(taps), noise_seed=np.int64(nseed),
+               noise_sum=np.float64(noise.double().sum().item()), noise_head=f32(noise[0, 0, :8]))
+    if store_noise:
+        out["noise"] = f32(noise)
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        cols = [p[:, i].to(dt).clone().requires_grad_(True) for i in range(25)]
+        torch.manual_seed(nseed)
+        y = RF.noise_shaped_reverberation(xx, SR, *cols, num_samples=L, num_bandpass_taps=taps)
+        (y * w.to(dt)).sum().backward()
+        out["y" + tag], out["gx" + tag] = f32(y), f32(xx.grad)
+        out["gp" + tag] = f32(torch.stack([c.grad for c in cols], 1))
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     eq_case("eq_b3c2_n12000", 3, 2, 12000, 3, seed=101)
@@ -139,3 +166,6 @@ if __name__ == "__main__":
     gain_dist_case("gain_dist_cfg1", 4, 1, 16384, seed=104)
     comp_case("comp_b3c2_n12000", 3, 2, 12000, seed=105, speechlike=True)
     comp_case("comp_b2c1_n20011_look7", 2, 1, 20011, seed=106, lookahead=7, speechlike=True)
+    reverb_case("rev_b2c2_n6000_l2048_t127", 2, 2, 6000, 2048, 127, seed=107, store_noise=True)
+    reverb_case("rev_b1c1_n5000_l1000_t63", 1, 1, 5000, 1000, 63, seed=108, store_noise=True)
+    reverb_case("rev_b1c2_n20000_default", 1, 2, 20000, 65536, 1023, seed=109, store_noise=False)

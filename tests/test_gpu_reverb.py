@@ -1,0 +1,99 @@
+"""GPU parity of noise_shaped_reverberation against reference-generated goldens (same noise) and the numpy oracle.
+Tolerance: 2e-5 L-inf/peak for y / grad_x (fp32 FFTs of length 2^12..2^17; SURVEY measured 4.9e-6 for an fp32 FFT
+restatement), 1e-4 of the largest entry for the 25 control gradients."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dasp_oracle as orc
+from tests.test_oracle_cpu import _reverb_noise
+from tests.util import linf_peak, load_golden
+
+pytestmark = pytest.mark.gpu
+SR = 44100
+
+
+@pytest.fixture(scope="module")
+def D():
+    assert torch.cuda.is_available()
+    import dasp_pytorch_amd as D
+    return D
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def run(D, x, p, w, noise, L, taps):
+    xt = dev(x).requires_grad_(True)
+    cols = [dev(p[:, i]).requires_grad_(True) for i in range(25)]
+    y = D.noise_shaped_reverberation(xt, SR, *cols, num_samples=L, num_bandpass_taps=taps, noise=None if noise is None else dev(noise))
+    (y * dev(w)).sum().backward()
+    torch.cuda.synchronize()
+    return y.detach().cpu().numpy(), xt.grad.cpu().numpy(), torch.stack([c.grad for c in cols], 1).cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["rev_b2c2_n6000_l2048_t127", "rev_b1c1_n5000_l1000_t63", "rev_b1c2_n20000_default"])
+def test_reverb_golden(D, name):
+    g = load_golden(name)
+    noise = _reverb_noise(g)
+    y, gx, gp = run(D, g["x"], g["params"], g["w"], noise, int(g["L"]), int(g["taps"]))
+    assert y.shape == g["y64"].shape and gx.shape == g["gx64"].shape          # mono in -> stereo out, grad_x mono
+    assert linf_peak(y, g["y64"]).max() < 2e-5
+    assert linf_peak(gx, g["gx64"]).max() < 2e-5
+    assert linf_peak(gp, g["gp64"]).max() < 1e-4
+    assert linf_peak(y, g["y32"]).max() < 1e-4                                # literal north_star bar vs the reference's fp32 run
+
+
+def test_reverb_seed_reproduces_reference_noise_stream(D):
+    """Default noise path = the reference's: global CPU generator, same call (functional.py:548)."""
+    g = load_golden("rev_b2c2_n6000_l2048_t127")
+    torch.manual_seed(int(g["noise_seed"]))
+    x = dev(g["x"]); cols = [dev(g["params"][:, i]) for i in range(25)]
+    y = D.noise_shaped_reverberation(x, SR, *cols, num_samples=int(g["L"]), num_bandpass_taps=int(g["taps"]))
+    e = linf_peak(y.cpu().numpy(), g["y64"]).max()
+    if e > 1e-3:
+        pytest.skip("this torch build's CPU generator does not reproduce the golden's noise stream")
+    assert e < 2e-5
+
+
+@pytest.mark.parametrize("B,C,N,L,taps", [(1, 2, 1, 64, 15), (2, 1, 100, 256, 31), (1, 2, 5000, 300, 63), (3, 2, 70000, 65536, 1023), (2, 2, 262144, 65536, 1023)])
+def test_reverb_shapes_vs_oracle(D, B, C, N, L, taps):
+    rng = np.random.default_rng(N + L)
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 2, N)).astype(np.float32)
+    p = rng.random((B, 25)).astype(np.float32)
+    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+    y, gx, gp = run(D, x, p, w, noise, L, taps)
+    pd = p.astype(np.float64)
+    yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
+    gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, w, L, taps)
+    assert np.abs(y - yo).max() < 3e-5 * max(np.abs(yo).max(), 1e-6)
+    assert np.abs(gx - gxo).max() < 3e-5 * max(np.abs(gxo).max(), 1e-6)
+    gpo = np.concatenate([gg, gd, gm[:, None]], 1)
+    assert np.abs(gp - gpo).max() < 2e-4 * np.abs(gpo).max()
+
+
+def test_reverb_semantics(D):
+    B, N = 2, 3000
+    x = torch.rand(B, 2, N, device="cuda:0") * 2 - 1
+    x0 = x.clone()
+    cols = [torch.rand(B, device="cuda:0") for _ in range(24)]
+    zero, one = torch.zeros(B, device="cuda:0"), torch.ones(B, device="cuda:0")
+    # mix = 0 -> dry signal, input not mutated; device_noise path runs; asserts as the reference
+    y = D.noise_shaped_reverberation(x, SR, *cols, zero, num_samples=512, num_bandpass_taps=31)
+    assert torch.equal(y, x) and torch.equal(x, x0)
+    yd = D.noise_shaped_reverberation(x, SR, *cols, one, num_samples=512, num_bandpass_taps=31, device_noise=True)
+    assert yd.shape == (B, 2, N) and torch.isfinite(yd).all()
+    with pytest.raises(AssertionError):
+        D.noise_shaped_reverberation(x, SR, *cols, one, num_bandpass_taps=32)
+    with pytest.raises(AssertionError):
+        D.noise_shaped_reverberation(torch.zeros(1, 3, 100, device="cuda:0"), SR, *[c[:1] for c in cols], one[:1])
+    # wet path is causal and linear in x: an impulse at n0 reproduces mix * ir delayed by n0
+    imp = torch.zeros(1, 2, 2000, device="cuda:0"); imp[:, :, 100] = 1.0
+    nz = torch.randn(2, 12, 512 + 30, device="cuda:0")
+    c1 = [c[:1] for c in cols]
+    y1 = D.noise_shaped_reverberation(imp, SR, *c1, one[:1], num_samples=512, num_bandpass_taps=31, noise=nz)
+    assert y1[..., :100].abs().max().item() < 1e-6 and y1[..., 100 + 512:].abs().max().item() < 1e-6
+    y2 = D.noise_shaped_reverberation(2.5 * imp, SR, *c1, one[:1], num_samples=512, num_bandpass_taps=31, noise=nz)
+    assert torch.allclose(y2, 2.5 * y1, rtol=1e-4, atol=1e-6)

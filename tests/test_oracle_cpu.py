@@ -103,3 +103,39 @@ def test_oracle_compressor_matches_reference(name):
     c = orc._compressor_core(g["x"], SR, p[:, 0], p[:, 1], p[:, 2], p[:, 4], p[:, 5], 1e-8, k, np.float64)
     if name == "comp_b3c2_n12000":
         assert c["in_knee"].any() and c["above"].any() and (~c["in_knee"] & ~c["above"]).any()
+
+
+def _reverb_noise(g):
+    """The white noise the reference drew for a golden: stored, or regenerated from the recorded seed
+    (torch CPU generator) and verified against the recorded checksum."""
+    if "noise" in g:
+        return g["noise"]
+    import torch
+    torch.manual_seed(int(g["noise_seed"]))
+    n = torch.randn(g["x"].shape[0] * 2, 12, int(g["L"]) + int(g["taps"]) - 1)
+    if not np.allclose(n[0, 0, :8].numpy(), g["noise_head"]) or abs(n.double().sum().item() - float(g["noise_sum"])) > 1e-6:
+        pytest.skip("this torch build's CPU generator does not reproduce the golden's noise stream")
+    return n.numpy()
+
+
+@pytest.mark.parametrize("name", ["rev_b2c2_n6000_l2048_t127", "rev_b1c1_n5000_l1000_t63", "rev_b1c2_n20000_default"])
+def test_oracle_reverb_matches_reference(name):
+    g = load_golden(name)
+    noise = _reverb_noise(g)
+    p = g["params"].astype(np.float64)
+    L, taps = int(g["L"]), int(g["taps"])
+    y = orc.noise_shaped_reverberation(g["x"], SR, p[:, :12], p[:, 12:24], p[:, 24], noise, L, taps)
+    assert linf_peak(y, g["y64"]).max() < 2e-6
+    gx, gg, gd, gm = orc.noise_shaped_reverberation_vjp(g["x"], SR, p[:, :12], p[:, 12:24], p[:, 24], noise, g["w"], L, taps)
+    assert linf_peak(gx, g["gx64"]).max() < 2e-6
+    gp = np.concatenate([gg, gd, gm[:, None]], 1)
+    assert linf_peak(gp, g["gp64"]).max() < 2e-5
+
+
+def test_oracle_filterbank_matches_reference_design():
+    # golden-free pin: 12 symmetric linear-phase filters, unit DC gain for the lowpass (signal.py:42-92); the filters
+    # themselves are pinned through the reverb goldens above (any design difference changes every output sample)
+    f = orc.octave_band_filterbank(1023, SR)
+    assert f.shape == (12, 1023) and f.dtype == np.float32
+    assert np.allclose(f, f[:, ::-1], atol=1e-9)
+    assert abs(f[0].sum() - 1) < 1e-4
