@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 import dasp_pytorch_amd as D  # noqa: E402
 from dasp_pytorch_amd import _lib  # noqa: E402
+from dasp_pytorch_amd import distributed as dd  # noqa: E402
 
 SR = 44100
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -71,6 +72,53 @@ def cpu_baseline(seconds_budget=15.0):
                       "numpy pocketfft single thread"}
 
 
+def _time_steps(fn, steps=5, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary(dev):
+    """Short fwd+bwd timings of the other hot-path ops at their BASELINE.json configs (1 GPU, not the headline)."""
+    res = {}
+    g = torch.Generator(device=dev).manual_seed(7)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+
+    def bench_op(name, B, C, N, make, bytes_per_cs, note=None):
+        x = (rnd(B, C, N) * 2 - 1).requires_grad_(True)
+        ctl, call = make(B)
+        w = torch.randn(B, 2 if name == "noise_shaped_reverberation" else C, N, device=dev, generator=g)
+
+        def step():
+            x.grad = None
+            for c in ctl:
+                c.grad = None
+            call(x, ctl).backward(w)
+        t = _time_steps(step)
+        cs = B * C * N
+        res[name] = {"shape": [B, C, N], "ms_fwd_bwd": round(t * 1e3, 3), "channel_samples_per_s": cs / t,
+                     "algorithmic_GBps": round(bytes_per_cs * cs / t / 1e9, 1), "frac_of_8TBps": round(bytes_per_cs * cs / t / 1e9 / HBM_PEAK_GBS, 4)}
+        if note:
+            res[name]["note"] = note
+        del x, w
+
+    ctl1 = lambda lo, hi: (lambda B: (rnd(B) * (hi - lo) + lo).requires_grad_(True))
+    bench_op("gain", 256, 2, 131072, lambda B: ([ctl1(-24, 24)(B)], lambda x, c: D.gain(x, SR, c[0])), 20)
+    bench_op("distortion", 256, 2, 131072, lambda B: ([ctl1(0, 24)(B * 2)], lambda x, c: D.distortion(x, SR, c[0])), 20)
+    rng = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]
+    bench_op("compressor", 256, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20)
+    bench_op("noise_shaped_reverberation", 128, 2, 262144,
+             lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
+             2 * 1.354e9 / (128 * 2 * 262144),
+             "device-generated noise; bytes = SURVEY 8(d) compulsory traffic with noise as an input (2 x 1.354 GB)")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,11 +128,10 @@ def main():
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other hot-path ops")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local, world = dd.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in dasp_pytorch_amd)")
     torch.cuda.set_device(local)
@@ -92,8 +139,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dd.init("nccl", dev)
 
     B, C, N = args.batch, args.channels, args.samples
     x, params, w = make_batch(B, C, N, 1234 + rank, dev)
@@ -123,10 +169,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ktimes = _lib.timers.stop()
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dd.max_over_ranks(dt, dev)
     finite = bool(torch.isfinite(x.grad).all().item()) and all(bool(torch.isfinite(c.grad).all().item()) for c in cols)
 
     if rank == 0:
@@ -157,6 +200,8 @@ def main():
             "small_kernels_ms": round(t_small * 1e3, 4),
             "finite": finite,
         }
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

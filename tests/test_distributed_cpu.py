@@ -1,0 +1,89 @@
+"""world_size-2 gloo tests of the multi-GPU plumbing (runs on CPU, no GPU needed): batch sharding covers the
+batch exactly once, timing is the max over ranks, bucketed gradient all-reduce equals the mean of the ranks'
+gradients, and bench.py's argument/launch contract parses."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+from dasp_pytorch_amd import distributed as dd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition():
+    for n in (1, 2, 7, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [dd.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert dd.max_over_ranks(1.5) == 1.5 and dd.allreduce_gradients([torch.nn.Parameter(torch.ones(2))]) == 0
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from dasp_pytorch_amd import distributed as dd
+    rank, world = dd.init(backend="gloo")
+    assert world == 2 and dist.get_backend() == "gloo"
+    # batch shards: disjoint, ordered, complete
+    x = torch.arange(7 * 3, dtype=torch.float32).view(7, 3)
+    mine = dd.shard_batch(x, world, rank)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([mine.shape[0]]))
+    assert sum(int(s) for s in sizes) == 7
+    tot = mine.sum().clone(); dist.all_reduce(tot)
+    assert float(tot) == float(x.sum())
+    # timing: max over ranks
+    assert dd.max_over_ranks(1.0 + rank) == 2.0
+    # bucketed gradient all-reduce: mean over ranks, several buckets, a None grad on one rank only
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    inp = torch.full((5, 16), float(rank + 1))
+    net(inp).square().mean().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    extra = torch.nn.Parameter(torch.ones(3))
+    if rank == 0:
+        extra.grad = torch.full((3,), 4.0)
+    params = list(net.parameters()) + [extra]
+    nb = dd.allreduce_gradients(params, bucket_bytes=1024)
+    assert nb >= 2
+    for p, g in zip(net.parameters(), ref):
+        other = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(other, g)
+        assert torch.allclose(p.grad, sum(other) / world, atol=1e-6)
+    assert torch.allclose(extra.grad, torch.full((3,), 2.0))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("worker", rank, "ok")
+""")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.timeout(180)
+def test_world2_gloo():
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=150)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"worker {rank} ok" in o, o
+
+
+def test_bench_refuses_without_gpu_and_parses_contract():
+    """bench.py must not silently fall back to a CPU path (there is none)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
