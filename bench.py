@@ -180,10 +180,21 @@ def main():
         t_bwd = float(np.mean(ktimes["dasp_sosfilt_backward"])) * 1e-3
         t_small = sum(float(np.mean(v)) for k, v in ktimes.items() if k not in ("dasp_sosfilt_forward", "dasp_sosfilt_backward")) * 1e-3
 
-        def roof(bytes_per_sample, t):
+        # HBM traffic per launch from the PMC counters: collected off-line (rocprofv3 --pmc passes cannot run inside
+        # this process) on the same shape and stored under profiles/; null when the shape differs
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")))
+            if tj["shape"] == [B, C, N]:
+                traffic = {"fwd": tj["sos_fwd_kernel"]["hbm_bytes"], "bwd": tj["sos_bwd_kernel"]["hbm_bytes"]}
+                traffic["both"] = traffic["fwd"] + traffic["bwd"]
+        except (OSError, KeyError, ValueError):
+            pass
+
+        def roof(bytes_per_sample, t, which=None):
             a = bytes_per_sample * units / t / 1e9
             return {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-                    "traffic": None}
+                    "traffic": traffic.get(which)}
 
         out = {
             "metric": "audio-samples/sec fwd+bwd, 6-band parametric_eq @ (256,2,131072)",
@@ -193,10 +204,10 @@ def main():
             "config": {"workload": f"parametric_eq fwd+bwd (grad x + 18 controls) on ({B},{C},{N}) fp32 per GPU, sr 44100, "
                                    "controls ~ U(ParametricEQ ranges)", "global_batch": B * world,
                        "parallelism": f"batch-shard x{world}, no collective"},
-            "roofline": dict(roof(12, t_bwd), kernel="sos_bwd_kernel<6>", ms=round(t_bwd * 1e3, 4),
+            "roofline": dict(roof(12, t_bwd, "bwd"), kernel="sos_bwd_kernel<6>", ms=round(t_bwd * 1e3, 4),
                              algorithmic_bytes=12 * units),
-            "roofline_fwd": dict(roof(8, t_fwd), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),
-            "roofline_fwd_bwd": dict(roof(20, t_fwd + t_bwd), ms=round((t_fwd + t_bwd) * 1e3, 4), algorithmic_bytes=20 * units),
+            "roofline_fwd": dict(roof(8, t_fwd, "fwd"), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),
+            "roofline_fwd_bwd": dict(roof(20, t_fwd + t_bwd, "both"), ms=round((t_fwd + t_bwd) * 1e3, 4), algorithmic_bytes=20 * units),
             "small_kernels_ms": round(t_small * 1e3, 4),
             "finite": finite,
         }
