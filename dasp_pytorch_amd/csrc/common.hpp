@@ -151,6 +151,19 @@ __device__ __forceinline__ void mbox_publish(float* lds, int slot, float a, floa
         __hip_atomic_store(reinterpret_cast<int*>(&lds[slot + 2]), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
+// Non-blocking read of a slot, sequence word first (the DS unit keeps a wave's reads in order, so if the
+// sequence matches, the values read after it are the published ones). Issue it early and test it later
+// with mbox_ready: in steady state the producer is ahead and the LDS round trip hides behind the
+// section's own work; otherwise fall back to mbox_wait.
+struct MboxPeek { int seq; float a, b; };
+__device__ __forceinline__ MboxPeek mbox_peek(float* lds, int slot) {
+    MboxPeek p;
+    p.seq = __hip_atomic_load(reinterpret_cast<int*>(&lds[slot + 2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    p.a = __hip_atomic_load(&lds[slot + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    p.b = __hip_atomic_load(&lds[slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return p;
+}
 __device__ __forceinline__ void mbox_wait(float* lds, int slot, int seq, float& a, float& b) {
     while (__hip_atomic_load(reinterpret_cast<int*>(&lds[slot + 2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
         __builtin_amdgcn_s_sleep(1);

@@ -33,6 +33,15 @@
 
 namespace dasp {
 
+#ifdef DASP_TRACE   // developer builds only: cycle stamps of one wave's phases (tools/sosbench prints them)
+__device__ long long g_trace[64];
+#define TRACE(i) do { if (blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W) g_trace[i] = clock64(); } while (0)
+#define TRACE2(i) do { if (trace_on && k == 3) g_trace[i] = clock64(); } while (0)
+#else
+#define TRACE(i)
+#define TRACE2(i)
+#endif
+
 
 // ------------------------------------------------------------------------------------------------
 // Per-item fp32 table layout (floats). S sections, chunk length L. Every 2x2 matrix is stored
@@ -355,86 +364,96 @@ __device__ __forceinline__ int opaque_zero_after(float dep) {
 
 // z = sum_n T[n] * X[n] for one section: T = [L] f2 (wave-uniform -> scalar loads, packed FMAs);
 // two accumulators halve the dependent chain.
-template <int L>
-__device__ __forceinline__ f2 table_apply(const float* __restrict__ T, const float (&X)[L]) {
-    f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < L; n += 2) {
-        z0 = fma2(*reinterpret_cast<const f2*>(T + 2 * n), splat(X[n]), z0);
-        z1 = fma2(*reinterpret_cast<const f2*>(T + 2 * n + 2), splat(X[n + 1]), z1);
-    }
-    return z0 + z1;
-}
+#define TLD2(p) (*reinterpret_cast<const f2*>(p))
+#define TLD4(p) (*reinterpret_cast<const f4*>(p))
 
-// One section of the tile scan. f = forcing of this lane's chunk (zero-state end state + coupling).
-// On return f = exact state at the *end* of the lane's chunk given the tile carry-in K.
-//   PLk  : 4 uniform 2x2 blocks M^(1,2,4,8)          (global, scalar loads)
-//   pw   : per-lane blocks M^(c+1) staged in LDS     (pw[c] as f4, column-major)
-// K is added by the caller (it may have to wait for it).
-__device__ __forceinline__ void scan_rows(f2& f, const float* __restrict__ PLk, const f4* __restrict__ pw, int lane) {
-    {
-        const f4 c = *reinterpret_cast<const f4*>(PLk + 0);
-        const float t1 = dpp0<0x111, 0xf>(f.x), t2 = dpp0<0x111, 0xf>(f.y);
-        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
-    }
-    {
-        const f4 c = *reinterpret_cast<const f4*>(PLk + 4);
-        const float t1 = dpp0<0x112, 0xf>(f.x), t2 = dpp0<0x112, 0xf>(f.y);
-        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
-    }
-    {
-        const f4 c = *reinterpret_cast<const f4*>(PLk + 8);
-        const float t1 = dpp0<0x114, 0xf>(f.x), t2 = dpp0<0x114, 0xf>(f.y);
-        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
-    }
-    {
-        const f4 c = *reinterpret_cast<const f4*>(PLk + 12);
-        const float t1 = dpp0<0x118, 0xf>(f.x), t2 = dpp0<0x118, 0xf>(f.y);
-        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
-    }
-    {   // rows 1, 3 += M^(j+1) * (last lane of the previous row)
-        const f4 c = pw[lane & 15];
-        const float t1 = dpp0<0x142, 0xa>(f.x), t2 = dpp0<0x142, 0xa>(f.y);
-        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
-    }
-    {   // rows 2, 3 += M^((lane % 32) + 1) * lane 31
-        const f4 c = pw[lane & 31];
-        const float t1 = dpp0<0x143, 0xc>(f.x), t2 = dpp0<0x143, 0xc>(f.y);
-        f = fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
-    }
+// f += [c.x c.z; c.y c.w] * (t1, t2)   (column-major 2x2 block, packed FMAs)
+__device__ __forceinline__ f2 blk_apply(f4 c, float t1, float t2, f2 f) {
+    return fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
 }
 
 // Whole-tile scan for one system (forward or adjoint tables): lane chunks X -> chunk start states st.
 //   Gs   : [S][L][2] chunk table (zero-state end state of section k = sum_n Gs[k][n] X[n]); zmap is
 //          applied to that per-lane value before the scan (identity, or the lane mirror for the adjoint)
-//   MCs  : [S][S][4] coupling blocks, PLs : [S][4][4], P64s : [S][4]   (global, scalar loads)
-//   pws  : [S][64] f4 per-lane powers in LDS
+//   MCs  : [S][S][4] coupling blocks, PLs : [S][4][4] M^(1,2,4,8), P64s : [S][4] M^64  (global, scalar loads)
+//   pws  : [S][64] f4 per-lane powers M^(c+1) in LDS
 //   carry_in(k, K)  : obtain the tile carry-in of section k (uniform)
 //   carry_out(k, K) : hand the carry for the next tile on
-template <int S, int L, typename FMap, typename FIn, typename FOut>
-__device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __restrict__ Gs, FMap&& zmap, f2 (&st)[S], const float* __restrict__ MCs,
-                                          const float* __restrict__ PLs, const float* __restrict__ P64s,
-                                          const f4* __restrict__ pws, int lane, FIn&& carry_in, FOut&& carry_out) {
+// Per section: f = z_k + sum_{j<k} M_kj st_j; inclusive scan of f over the 64 lanes (four Kogge-Stone
+// levels inside each 16-lane row on DPP row_shr, then row_bcast:15 / row_bcast:31 with per-lane
+// powers); E = f + M^(lane+1) K; st = E shifted by one lane.
+// The wave-uniform tables go through SGPRs. Scalar loads return after hundreds of cycles and a wave
+// has nothing else to issue meanwhile, so they are software-pipelined by hand: each table buffer is
+// refilled for section k+1 right after its last use in section k (the scheduling barriers pin the
+// issue points), which keeps at most one section's worth (~72 SGPRs) live.
+template <int S, int L, typename FMap, typename FPre, typename FIn, typename FOut>
+__device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __restrict__ Gs, FMap&& zmap, f2 (&st)[S],
+                                          const float* __restrict__ MCs, const float* __restrict__ PLs,
+                                          const float* __restrict__ P64s, const f4* __restrict__ pws, int lane,
+                                          FPre&& carry_prefetch, FIn&& carry_in, FOut&& carry_out, bool trace_on = false) {
+    f2 G[L];
+    f4 MC[S], PL[4], P64[2];
+#pragma unroll
+    for (int n = 0; n < L; ++n) G[n] = TLD2(Gs + 2 * n);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) PL[l] = TLD4(PLs + 4 * l);
+    P64[0] = TLD4(P64s);
+    if (S > 1) P64[1] = TLD4(P64s + 4);
 #pragma unroll
     for (int k = 0; k < S; ++k) {
-        __builtin_amdgcn_sched_barrier(0);   // keep each section's table / LDS loads inside the section (register pressure)
-        f2 f = zmap(table_apply<L>(Gs + k * L * 2, X));
+        __builtin_amdgcn_sched_barrier(0);
+        // LDS reads of the section (per-lane powers, carry mailbox) are issued first and *waited for* right after the
+        // table product, before any scalar refill is in flight: LDS and SMEM share lgkmcnt and SMEM returns out of
+        // order, so a later LDS wait would be an lgkmcnt(0) that also waits for the refills just issued.
+        TRACE2(8);
+        f4 pw16 = pws[k * 64 + (lane & 15)], pw32 = pws[k * 64 + (lane & 31)], pw64 = pws[k * 64 + lane];
+        carry_prefetch(k);
+        f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < k; ++j) {
-            const f4 m = *reinterpret_cast<const f4*>(MCs + (k * S + j) * 4);
-            f = fma2(f2{m.x, m.y}, splat(st[j].x), fma2(f2{m.z, m.w}, splat(st[j].y), f));
+        for (int n = 0; n < L; n += 2) {
+            z0 = fma2(G[n], splat(X[n]), z0);
+            z1 = fma2(G[n + 1], splat(X[n + 1]), z1);
         }
-        scan_rows(f, PLs + k * 16, pws + k * 64, lane);
+        f2 f = zmap(z0 + z1);
+        { float a = pw16.x, b = pw32.x, c = pw64.x; pin(a); pin(b); pin(c); pw16.x = a; pw32.x = b; pw64.x = c; }
+        TRACE2(9);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < S) {
+#pragma unroll
+            for (int n = 0; n < L; ++n) G[n] = TLD2(Gs + ((k + 1) * L + n) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < k; ++j) f = blk_apply(MC[j], st[j].x, st[j].y, f);
+        pin(f); TRACE2(10);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < S) {
+#pragma unroll
+            for (int j = 0; j <= k; ++j) MC[j] = TLD4(MCs + ((k + 1) * S + j) * 4);
+        }
+        f = blk_apply(PL[0], dpp0<0x111, 0xf>(f.x), dpp0<0x111, 0xf>(f.y), f);
+        f = blk_apply(PL[1], dpp0<0x112, 0xf>(f.x), dpp0<0x112, 0xf>(f.y), f);
+        f = blk_apply(PL[2], dpp0<0x114, 0xf>(f.x), dpp0<0x114, 0xf>(f.y), f);
+        f = blk_apply(PL[3], dpp0<0x118, 0xf>(f.x), dpp0<0x118, 0xf>(f.y), f);
+        pin(f); TRACE2(11);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < S) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) PL[l] = TLD4(PLs + (k + 1) * 16 + 4 * l);
+        }
+        // rows 1, 3 += M^(j+1) * (last lane of the previous row); rows 2, 3 += M^((lane % 32) + 1) * lane 31
+        f = blk_apply(pw16, dpp0<0x142, 0xa>(f.x), dpp0<0x142, 0xa>(f.y), f);
+        f = blk_apply(pw32, dpp0<0x143, 0xc>(f.x), dpp0<0x143, 0xc>(f.y), f);
+        pin(f); TRACE2(12);
         f2 K;
         carry_in(k, K);
-        {   // carry for the next tile: the only work on the cross-wave serial chain
-            const f4 c = *reinterpret_cast<const f4*>(P64s + k * 4);
-            const f2 e = f2{read_lane(f.x, 63), read_lane(f.y, 63)};
-            carry_out(k, fma2(f2{c.x, c.y}, splat(K.x), fma2(f2{c.z, c.w}, splat(K.y), e)));
-        }
-        const f4 c = pws[k * 64 + lane];
-        const f2 E = fma2(f2{c.x, c.y}, splat(K.x), fma2(f2{c.z, c.w}, splat(K.y), f));
+        pin(K); TRACE2(13);
+        // carry for the next tile: the only work on the cross-wave serial chain
+        carry_out(k, blk_apply(P64[k & 1], K.x, K.y, f2{read_lane(f.x, 63), read_lane(f.y, 63)}));
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 2 < S) P64[k & 1] = TLD4(P64s + (k + 2) * 4);
+        const f2 E = blk_apply(pw64, K.x, K.y, f);
         st[k] = f2{wave_shr1(K.x, E.x), wave_shr1(K.y, E.y)};
+        pin(st[k]); TRACE2(14);
     }
 }
 
@@ -462,75 +481,87 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     __syncthreads();
     const f4* pws = reinterpret_cast<const f4*>(pw_lds);
 
-    // section coefficients as per-lane (VGPR) values: sg, -kom, om, g1, g2, d
-    float c_sg[S], c_nk[S], c_om[S], c_g1[S], c_g2[S], c_d[S];
-    {
-        const int oz = opaque_zero();
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const float* cf = cf_lds + k * 8 + oz;
-            c_sg[k] = cf[0]; c_om[k] = cf[1]; c_nk[k] = -cf[2]; c_g1[k] = cf[3]; c_g2[k] = cf[4]; c_d[k] = cf[5];
-        }
-    }
     f2 Kreg[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
 
-    f4 cur[L / 4];
-#pragma unroll
-    for (int j = 0; j < L / 4; ++j) cur[j] = f4{0.f, 0.f, 0.f, 0.f};
-    int t = wave;
-    if (t < nt && tile_full<L>((long)t * TS, N, vec)) tile_load_full<L>(xr, (long)t * TS, cur);
-    for (; t < nt; t += W) {
+    for (int t = wave; t < nt; t += W) {
         int toff = 0;
         asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
         const float* __restrict__ tbl = tb + toff;
         const bool full = tile_full<L>((long)t * TS, N, vec);
         float X[L];
-        if (full) tile_regs_to_lds<L>(tbuf, cur);
-        else tile_global_to_lds_guarded<L>(tbuf, xr, (long)t * TS, N);
+        TRACE(0);
+        // no register prefetch of the next tile: at <= 80 VGPRs six waves per SIMD hide the HBM latency instead
+        if (full) {
+            f4 cur[L / 4];
+            tile_load_full<L>(xr, (long)t * TS, cur);
+            tile_regs_to_lds<L>(tbuf, cur);
+        } else {
+            tile_global_to_lds_guarded<L>(tbuf, xr, (long)t * TS, N);
+        }
         lds_to_chunks<L>(tbuf, X);
-        // prefetch the wave's next tile; it stays in flight for the whole tile computation
-        if (t + W < nt && tile_full<L>((long)(t + W) * TS, N, vec)) tile_load_full<L>(xr, (long)(t + W) * TS, cur);
+        TRACE(1);
 
         f2 st[S];
+        MboxPeek pk;
         tile_scan<S, L>(X, tbl + LY::GT, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+            [&](int k) { if (W > 1 && t > 0) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
             [&](int k, f2& K) {
                 if (W == 1) K = Kreg[k];
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 1)
                 else K = f2{0.f, 0.f};
 #else
                 else if (t == 0) K = f2{0.f, 0.f};
+                else if (pk.seq == t) K = f2{pk.a, pk.b};
                 else { float a, b; mbox_wait(lds, mb_in + 4 * k, t, a, b); K = f2{a, b}; }
 #endif
             },
             [&](int k, f2 Kn) {
                 if (W == 1) Kreg[k] = Kn;
                 else if (t + 1 < nt) mbox_publish(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
-            });
+            }
+#ifdef DASP_TRACE
+            , blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W
+#endif
+            );
+        TRACE(2);
         if (carries && lane == 0) {   // lane 0's start state is the tile carry-in
             float* cs = carries + ((size_t)row * nt + t) * S2;
 #pragma unroll
             for (int k = 0; k < S; ++k) *reinterpret_cast<f2*>(cs + 2 * k) = st[k];
         }
 
-#pragma unroll
-        for (int n = 0; n < L; ++n) {
-            float u = X[n];
+        // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
+        // wave-uniform but are loaded into VGPRs (opaque lane-dependent address): VALU ops with SGPR operands issue at
+        // half rate on gfx950. Only one section's coefficients are live, which keeps the kernel at <= 80 VGPRs so that
+        // six waves per SIMD hide the dependent-issue latency of the lane scans.
+        {
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                const float s1 = st[k].x, s2 = st[k].y;
-                const float yv = fmaf(c_g1[k], s1, fmaf(c_g2[k], s2, c_d[k] * u));
-                st[k].x = fmaf(c_sg[k], s1, fmaf(c_nk[k], s2, u));
-                st[k].y = fmaf(c_om[k], s1, c_sg[k] * s2);
-                u = yv;
+                // chained behind the previous section's first output so that the six coefficient loads are not all
+                // hoisted to the top (48 live registers)
+                const int oz = opaque_zero_after(X[0]);
+                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
+                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+                const float nk = -ca.z;
+                float s1 = st[k].x, s2 = st[k].y;
+#pragma unroll
+                for (int n = 0; n < L; ++n) {
+                    const float u = X[n];
+                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                    const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                    s2 = fmaf(ca.y, s1, ca.x * s2);
+                    s1 = t1;
+                }
             }
-            X[n] = u;
         }
+        TRACE(3);
 
         chunks_to_lds<L>(tbuf, X);
         if (full) tile_lds_to_global_full<L>(tbuf, yr, (long)t * TS);
         else tile_lds_to_global_guarded<L>(tbuf, yr, (long)t * TS, N);
+        TRACE(4);
     }
 }
 
@@ -603,17 +634,21 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         {
             const float* __restrict__ cs = carries + ((size_t)row * nt + t) * S2;
             tile_scan<S, L>(X, tbl + LY::GT, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+                [](int) {},
                 [&](int k, f2& K) { K = f2{cs[2 * k], cs[2 * k + 1]}; },
                 [&](int, f2) {});
         }
         // ---- adjoint chunk end states: the scan runs from lane 63 down to lane 0, done on lane-mirrored data ----
         f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
         {
+            MboxPeek pk;
             tile_scan<S, L>(GY, tbl + LY::GAT, [](f2 v) { return f2{wave_mirror(v.x), wave_mirror(v.y)}; }, lam,
                 tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
+                [&](int i) { if (W > 1 && r > 0) pk = mbox_peek(lds, mb_in + 4 * i); },
                 [&](int i, f2& K) {
                     if (W == 1) K = Kreg[i];
                     else if (r == 0) K = f2{0.f, 0.f};
+                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};
                     else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
                 },
                 [&](int i, f2 Kn) {
@@ -774,8 +809,14 @@ using namespace dasp;
 
 namespace {
 constexpr int kL = 16;    // samples per lane chunk
-constexpr int kWF = 6;    // waves per row, forward (2 rows per CU -> 3 waves per SIMD, 168 VGPRs)
-constexpr int kWB = 4;    // waves per row, backward (2 rows per CU -> 2 waves per SIMD; measured faster than 6 waves at 168 registers)
+#ifndef DASP_FWD_W
+#define DASP_FWD_W 8
+#endif
+constexpr int kWF = DASP_FWD_W;    // waves per row, forward (2 rows per CU -> 4 waves per SIMD, <= 128 VGPRs; measured best)
+#ifndef DASP_BWD_W
+#define DASP_BWD_W 4
+#endif
+constexpr int kWB = DASP_BWD_W;    // waves per row, backward (2 rows per CU -> 2 waves per SIMD; measured faster than 6 waves at 168 registers)
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
@@ -796,6 +837,10 @@ int dispatch_S(int S, F&& f) {
 }  // namespace
 
 extern "C" {
+
+#ifdef DASP_TRACE
+int dasp_debug_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasp::g_trace), sizeof(long long) * 64); }
+#endif
 
 int dasp_sos_chunk(void) { return kL; }
 int dasp_sos_tile(void) { return 64 * kL; }

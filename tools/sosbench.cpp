@@ -8,6 +8,7 @@
 #include <random>
 #include <vector>
 #include "../include/dasp_hip.h"
+#include <dlfcn.h>
 
 #define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(err_), __FILE__, __LINE__); exit(1); } } while (0)
 #define DK(x) do { int s = (x); if (s != 0) { printf("dasp status %d at %s:%d\n", s, __FILE__, __LINE__); exit(1); } } while (0)
@@ -77,6 +78,19 @@ int main(int argc, char** argv) {
            B, C, N, S, tp, tf, 8 * units / tf / 1e6, 8 * units / tf / 1e6 / 80, tb, 12 * units / tb / 1e6, 12 * units / tb / 1e6 / 80,
            tf + tb, units / ((tf + tb) * 1e-3), 20 * units / (tf + tb) / 1e6 / 80);
 
+    if (getenv("DASP_TRACE")) {
+
+        typedef int (*trace_fn)(long long*);
+        trace_fn dasp_debug_trace_p = (trace_fn)dlsym(RTLD_DEFAULT, "dasp_debug_trace");
+        if (dasp_debug_trace_p) {
+            long long tr[64];
+            dasp_debug_trace_p(tr);
+            printf("trace (cycles): load+transpose %lld  scan %lld  cascade %lld  store %lld  | tile total %lld\n", tr[1] - tr[0], tr[2] - tr[1],
+                   tr[3] - tr[2], tr[4] - tr[3], tr[4] - tr[0]);
+            printf("section 3: lds-issue+table+zmap+wait %lld  coupling %lld  in-row %lld  bcast %lld  carry-in %lld  carry-out+apply+shift %lld\n",
+                   tr[9] - tr[8], tr[10] - tr[9], tr[11] - tr[10], tr[12] - tr[11], tr[13] - tr[12], tr[14] - tr[13]);
+        }
+    }
     // correctness spot-check on a few rows (first, a middle one, last)
     std::vector<float> y(n), gx(n);
     CK(hipMemcpy(y.data(), dy, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gx.data(), dgx, n * 4, hipMemcpyDeviceToHost));
