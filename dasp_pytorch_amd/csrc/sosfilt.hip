@@ -526,10 +526,10 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #endif
             );
         TRACE(2);
-        if (carries && lane == 0) {   // lane 0's start state is the tile carry-in
-            float* cs = carries + ((size_t)row * nt + t) * S2;
+        if (carries) {   // chunk start states for the backward pass: [row][tile][section][lane] f2, 512 B per wave store
+            f2* cs = reinterpret_cast<f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < S; ++k) *reinterpret_cast<f2*>(cs + 2 * k) = st[k];
+            for (int k = 0; k < S; ++k) cs[k * 64] = st[k];
         }
 
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
@@ -617,6 +617,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         const float* __restrict__ tbl = tb + toff;
         const bool full = tile_full<L>((long)t * TS, N, vec);
         float X[L], GY[L];
+        TRACE(16);
         if (full) {
             f4 vx[L / 4], vg[L / 4];
             tile_load_full<L>(xr, (long)t * TS, vx);
@@ -629,15 +630,16 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         }
         lds_to_chunks<L>(tbx, X);
         lds_to_chunks<L>(tbg, GY);
-        // ---- forward chunk start states from the carry saved by the forward pass ----
+        pin(X); pin(GY); TRACE(17);
+        // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
+        //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
         f2 st[S];
         {
-            const float* __restrict__ cs = carries + ((size_t)row * nt + t) * S2;
-            tile_scan<S, L>(X, tbl + LY::GT, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
-                [](int) {},
-                [&](int k, f2& K) { K = f2{cs[2 * k], cs[2 * k + 1]}; },
-                [&](int, f2) {});
+            const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < S; ++k) st[k] = cs[k * 64];
         }
+        pin(st); TRACE(18);
         // ---- adjoint chunk end states: the scan runs from lane 63 down to lane 0, done on lane-mirrored data ----
         f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
         {
@@ -659,6 +661,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             for (int i = 0; i < S; ++i) lam[i] = f2{wave_mirror(lam[i].x), wave_mirror(lam[i].y)};
         }
         pin(X); pin(GY); pin(st); pin(lam);   // scans done before the cascade passes start
+        TRACE(19);
         __builtin_amdgcn_sched_barrier(0);
         f2 st_lo[H];   // start states of sections [0, H) for the second pass
 #pragma unroll
@@ -715,6 +718,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 S2v[k - k0][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
             }
             pin(S2v); pin(GY);
+            TRACE(20 + 2 * pass);
             __builtin_amdgcn_sched_barrier(0);
             // adjoint sections k1-1 .. k0 (descending time) + coefficient correlations, in place over GY
 #pragma unroll
@@ -740,7 +744,9 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                     GY[n] = o;
                     // keep the correlations next to the recurrence: hoisting the whole recurrence first keeps
                     // both g[n] and o[n] of all samples live (+16 registers per section)
+#ifdef DASP_BWD_INLOOP_BARRIER
                     if ((n & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 // pinned: otherwise the compiler defers these updates to the end of the tile and keeps all
                 // 5*S per-tile sums live next to the 5*S running sums
@@ -748,11 +754,13 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 accb[k][0] = b0; accb[k][1] = b1; accb[k][2] = b2; acca[k][0] = a1; acca[k][1] = a2;
             }
             pin(GY);
+            TRACE(21 + 2 * pass);
             __builtin_amdgcn_sched_barrier(0);
         }
         chunks_to_lds<L>(tbx, GY);
         if (full) tile_lds_to_global_full<L>(tbx, gxr, (long)t * TS);
         else tile_lds_to_global_guarded<L>(tbx, gxr, (long)t * TS, N);
+        TRACE(24);
     }
     // per-wave partial sums -> partials[row][wave][S][5]
     float* po = partials + ((size_t)row * W + wave) * S * 5;
@@ -854,7 +862,7 @@ long dasp_sos_table_floats(int S) {
 }
 long dasp_sos_dtab_doubles(int S) { return (long)S * DT_STRIDE; }
 long dasp_sos_num_tiles(long N) { return (N + 64 * kL - 1) / (64 * kL); }
-long dasp_sos_carry_floats(long rows, long N, int S) { return rows * dasp_sos_num_tiles(N) * 2 * S; }
+long dasp_sos_carry_floats(long rows, long N, int S) { return rows * dasp_sos_num_tiles(N) * 2 * S * 64; }
 long dasp_sos_partial_floats(long rows, int S) { return rows * kWB * S * 5; }
 
 // sos: (Bs, S, 6) fp32 rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Builds tables for Bs items.

@@ -48,7 +48,9 @@ int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, 
 int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, double sample_rate,
                      float* tab, double* dtab, void* stream);
 
-/* y = cascade(x). carries (may be NULL when no backward follows) receives the per-tile states. */
+/* y = cascade(x). carries (may be NULL when no backward follows) receives the state of every lane chunk
+ * (dasp_sos_carry_floats(rows, N, S) floats = 2*S per dasp_sos_chunk() samples); the backward pass reads it
+ * instead of re-scanning the forward recurrence. */
 int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries,
                          int B, int C, long N, int S, void* stream);
 

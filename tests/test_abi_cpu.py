@@ -38,7 +38,7 @@ def test_size_queries():
     assert L.dasp_sos_table_floats(5) == -1
     T = L.dasp_sos_tile()
     assert L.dasp_sos_num_tiles(1) == 1 and L.dasp_sos_num_tiles(T) == 1 and L.dasp_sos_num_tiles(T + 1) == 2
-    assert L.dasp_sos_carry_floats(4, 2 * T, 6) == 4 * 2 * 12
+    assert L.dasp_sos_carry_floats(4, 2 * T, 6) == 4 * 2 * 12 * 64
 
 
 def test_argument_errors_without_gpu():
