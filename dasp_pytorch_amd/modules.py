@@ -1,0 +1,158 @@
+"""Processor wrappers: the normalised-parameter API of dasp_pytorch.modules on top of the MI355X
+functional layer (reference: dasp_pytorch/modules.py:21-231).
+
+Same class names, constructor arguments, `param_ranges` (name -> (min, max), in the order of the
+columns of the parameter tensor), `num_params`, `process`, `process_normalized`,
+`extract_param_dict` and `denormalize_param_dict`. Differences, all deliberate:
+
+* the range check of `process_normalized` is one fused reduction over the whole (bs, P) tensor and
+  one host sync, instead of the reference's two syncs per parameter (modules.py:83: 50 syncs for
+  an EQ -> compressor -> reverb -> gain chain, each a GPU pipeline drain); the ValueError still
+  names the offending parameter;
+* de-normalisation is one affine op on the (bs, P) tensor, then column views;
+* `Distortion` works: the reference's has no `sample_rate` attribute and names its parameter
+  `gain_db` although `functional.distortion` takes `drive_db`, so `process_normalized` raises
+  there (modules.py:110-121). Here the parameter is `drive_db`;
+* `Expander` exists (the reference's functional.expander is a stub).
+"""
+from typing import Dict
+
+import torch
+
+from . import functional as F
+
+
+def denormalize(norm_val, max_val, min_val):
+    return (norm_val * (max_val - min_val)) + min_val
+
+
+def normalize(val, min_val, max_val):
+    return (val - min_val) / (max_val - min_val)
+
+
+class Processor:
+    sample_rate = None
+    process_fn = None
+    param_ranges: Dict[str, tuple] = {}
+
+    def _finish(self):
+        self.num_params = len(self.param_ranges)
+        self._lo = torch.tensor([r[0] for r in self.param_ranges.values()], dtype=torch.float32)
+        self._span = torch.tensor([r[1] - r[0] for r in self.param_ranges.values()], dtype=torch.float32)
+        self._cache = {}
+
+    def _affine(self, ref: torch.Tensor):
+        key = (ref.device, ref.dtype)
+        if key not in self._cache:
+            self._cache[key] = (self._lo.to(device=ref.device, dtype=ref.dtype), self._span.to(device=ref.device, dtype=ref.dtype))
+        return self._cache[key]
+
+    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
+        """Run the processor with parameters normalised to [0, 1], one row per batch item, columns in the
+        order of `param_ranges` (reference: modules.py:25-51)."""
+        if param_tensor.shape[1] != len(self.param_ranges):
+            raise ValueError(
+                f"Parameter tensor has {param_tensor.shape[1]} parameters, but processor has {len(self.param_ranges)} parameters.")
+        self._check_range(param_tensor)
+        lo, span = self._affine(param_tensor)
+        denorm = param_tensor * span + lo                      # one op for all parameters
+        kwargs = {name: denorm[:, i] for i, name in enumerate(self.param_ranges)}
+        return self.process_fn(x, self.sample_rate, **kwargs)
+
+    def process(self, x: torch.Tensor, *args):
+        return self.process_fn(x, *args)
+
+    def _check_range(self, param_tensor: torch.Tensor):
+        p = param_tensor.detach()
+        bad = ((p < 0) | (p > 1)).any(dim=0)                   # one reduction ...
+        if bool(bad.any()):                                    # ... one sync
+            name = list(self.param_ranges)[int(torch.nonzero(bad)[0])]
+            raise ValueError(f"Parameter {name} of is out of range.")
+
+    def extract_param_dict(self, param_tensor: torch.Tensor):
+        if param_tensor.shape[1] != len(self.param_ranges):
+            raise ValueError(
+                f"Parameter tensor has {param_tensor.shape[1]} parameters, but processor has {len(self.param_ranges)} parameters.")
+        return {name: param_tensor[:, i] for i, name in enumerate(self.param_ranges)}
+
+    def denormalize_param_dict(self, param_dict: dict):
+        """Parameters on [0, 1] -> the processor's physical ranges (reference: modules.py:70-91)."""
+        out = {}
+        for name, t in param_dict.items():
+            if t.min() < 0 or t.max() > 1:
+                raise ValueError(f"Parameter {name} of is out of range.")
+            lo, hi = self.param_ranges[name]
+            out[name] = denormalize(t, hi, lo)
+        return out
+
+
+class Gain(Processor):
+    def __init__(self, sample_rate: int, min_gain_db: float = -24.0, max_gain_db: float = 24.0):
+        self.sample_rate = sample_rate
+        self.process_fn = F.gain
+        self.param_ranges = {"gain_db": (min_gain_db, max_gain_db)}
+        self._finish()
+
+
+class Distortion(Processor):
+    def __init__(self, sample_rate: int = None, min_gain_db: float = 0.0, max_gain_db: float = 24.0):
+        self.sample_rate = sample_rate
+        self.process_fn = F.distortion
+        self.param_ranges = {"drive_db": (min_gain_db, max_gain_db)}
+        self._finish()
+
+
+def _eq_ranges(sample_rate, g, q):
+    top = (sample_rate // 2) - 1000
+    cut = {"low_shelf": (20, 2000), "band0": (80, 2000), "band1": (2000, 8000), "band2": (8000, 12000), "band3": (12000, top),
+           "high_shelf": (4000, top)}
+    ranges = {}
+    for band, c in cut.items():
+        ranges[f"{band}_gain_db"] = g
+        ranges[f"{band}_cutoff_freq"] = c
+        ranges[f"{band}_q_factor"] = q
+    return ranges
+
+
+class ParametricEQ(Processor):
+    def __init__(self, sample_rate: int, min_gain_db: float = -20.0, max_gain_db: float = 20.0, min_q_factor: float = 0.1,
+                 max_q_factor: float = 6.0):
+        self.sample_rate = sample_rate
+        self.process_fn = F.parametric_eq
+        self.param_ranges = _eq_ranges(sample_rate, (min_gain_db, max_gain_db), (min_q_factor, max_q_factor))
+        self._finish()
+
+
+class _Dynamics(Processor):
+    def __init__(self, fn, sample_rate: int, min_threshold_db: float = -60.0, max_threshold_db: float = 0.0, min_ratio: float = 1.0,
+                 max_ratio: float = 20.0, min_attack_ms: float = 5.0, max_attack_ms: float = 100.0, min_release_ms: float = 5.0,
+                 max_release_ms: float = 100.0, min_knee_db: float = 0.0, max_knee_db: float = 12.0, min_makeup_gain_db: float = 0.0,
+                 max_makeup_gain_db: float = 12.0):
+        self.sample_rate = sample_rate
+        self.process_fn = fn
+        self.param_ranges = {
+            "threshold_db": (min_threshold_db, max_threshold_db), "ratio": (min_ratio, max_ratio),
+            "attack_ms": (min_attack_ms, max_attack_ms), "release_ms": (min_release_ms, max_release_ms),
+            "knee_db": (min_knee_db, max_knee_db), "makeup_gain_db": (min_makeup_gain_db, max_makeup_gain_db)}
+        self._finish()
+
+
+class Compressor(_Dynamics):
+    def __init__(self, sample_rate: int, **ranges):
+        super().__init__(F.compressor, sample_rate, **ranges)
+
+
+class Expander(_Dynamics):
+    def __init__(self, sample_rate: int, **ranges):
+        super().__init__(F.expander, sample_rate, **ranges)
+
+
+class NoiseShapedReverb(Processor):
+    def __init__(self, sample_rate, min_band_gain: float = 0.0, max_band_gain: float = 1.0, min_band_decay: float = 0.0,
+                 max_band_decay: float = 1.0, min_mix: float = 0.0, max_mix: float = 1.0):
+        self.sample_rate = sample_rate
+        self.process_fn = F.noise_shaped_reverberation
+        self.param_ranges = {f"band{i}_gain": (min_band_gain, max_band_gain) for i in range(12)}
+        self.param_ranges.update({f"band{i}_decay": (min_band_decay, max_band_decay) for i in range(12)})
+        self.param_ranges["mix"] = (min_mix, max_mix)
+        self._finish()

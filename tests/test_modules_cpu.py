@@ -1,0 +1,63 @@
+"""Processor wrappers (dasp_pytorch_amd.modules) against the reference's tables and semantics
+(dasp_pytorch/modules.py). The expected ranges below are the reference's defaults, restated."""
+import pytest
+import torch
+
+import dasp_pytorch_amd as D
+
+SR = 44100
+EXPECTED = {
+    "Gain": [("gain_db", -24.0, 24.0)],
+    "Compressor": [("threshold_db", -60.0, 0.0), ("ratio", 1.0, 20.0), ("attack_ms", 5.0, 100.0), ("release_ms", 5.0, 100.0),
+                   ("knee_db", 0.0, 12.0), ("makeup_gain_db", 0.0, 12.0)],
+}
+
+
+def test_param_tables_match_reference():
+    assert list(D.Gain(SR).param_ranges.items()) == [(n, (lo, hi)) for n, lo, hi in EXPECTED["Gain"]]
+    assert list(D.Compressor(SR).param_ranges.items()) == [(n, (lo, hi)) for n, lo, hi in EXPECTED["Compressor"]]
+    eq = D.ParametricEQ(SR)
+    names = list(eq.param_ranges)
+    assert eq.num_params == 18 and names[0] == "low_shelf_gain_db" and names[-1] == "high_shelf_q_factor"
+    assert names[3:6] == ["band0_gain_db", "band0_cutoff_freq", "band0_q_factor"]
+    assert eq.param_ranges["band3_cutoff_freq"] == (12000, 21050) and eq.param_ranges["high_shelf_cutoff_freq"] == (4000, 21050)
+    assert eq.param_ranges["low_shelf_cutoff_freq"] == (20, 2000) and eq.param_ranges["band1_cutoff_freq"] == (2000, 8000)
+    assert eq.param_ranges["band2_q_factor"] == (0.1, 6.0) and eq.param_ranges["band0_gain_db"] == (-20.0, 20.0)
+    rv = D.NoiseShapedReverb(SR)
+    assert rv.num_params == 25 and list(rv.param_ranges)[12] == "band0_decay" and list(rv.param_ranges)[-1] == "mix"
+    # argument names line up with the functional signatures (process_normalized passes them by keyword)
+    import inspect
+    for mod in (D.Gain(SR), eq, D.Compressor(SR), D.Expander(SR), rv, D.Distortion()):
+        sig = list(inspect.signature(mod.process_fn).parameters)
+        assert sig[2:2 + mod.num_params] == list(mod.param_ranges), type(mod).__name__
+
+
+def test_extract_denormalize_and_errors():
+    eq = D.ParametricEQ(SR)
+    p = torch.rand(3, 18)
+    d = eq.denormalize_param_dict(eq.extract_param_dict(p))
+    assert torch.allclose(d["band1_cutoff_freq"], p[:, 7] * 6000 + 2000)
+    with pytest.raises(ValueError):
+        eq.extract_param_dict(torch.rand(3, 17))
+    bad = p.clone(); bad[1, 4] = 1.5
+    with pytest.raises(ValueError, match="band0_cutoff_freq"):
+        eq.denormalize_param_dict(eq.extract_param_dict(bad))
+    with pytest.raises(ValueError, match="band0_cutoff_freq"):
+        eq._check_range(bad)
+    with pytest.raises(ValueError):
+        eq.process_normalized(torch.zeros(3, 1, 8), torch.rand(3, 5))
+
+
+def test_process_normalized_routes_by_keyword_without_gpu(monkeypatch):
+    """The chain of calls, with the kernels stubbed (there is no CPU path to run them)."""
+    seen = {}
+
+    def fake(x, sample_rate, **kw):
+        seen.update(kw, sample_rate=sample_rate)
+        return x
+    comp = D.Compressor(SR)
+    comp.process_fn = fake
+    p = torch.rand(4, 6)
+    comp.process_normalized(torch.zeros(4, 2, 16), p)
+    assert seen["sample_rate"] == SR and list(seen)[:6] == list(comp.param_ranges)
+    assert torch.allclose(seen["ratio"], p[:, 1] * 19 + 1) and torch.allclose(seen["threshold_db"], p[:, 0] * 60 - 60)
