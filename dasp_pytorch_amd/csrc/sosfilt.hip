@@ -569,8 +569,10 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 // Backward. Register budget is the design constraint: the coefficient correlations pair the
 // adjoint signals of section k with its forward all-pole signal s2_k[n], so forward signals have to
 // be held while the adjoint runs. Holding all S sections (S*(L+2) registers) leaves one wave per
-// SIMD; instead the tile is processed in two half-cascade passes (sections [H, S) then [0, H)),
-// each keeping only its own s2 signals, at the price of running the forward sections [0, H) twice.
+// SIMD; instead the forward cascade is run once, the s2 signals of the lower half [0, H) are
+// parked in the wave's LDS region (the transposition buffers are idle at that point), the upper
+// half [H, S) keeps its own in registers, and the adjoint runs as two half-cascade passes
+// (sections S-1..H, then H-1..0 with the parked signals read back).
 template <int S, int L, int W>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
@@ -578,20 +580,22 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                float* __restrict__ partials, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4, H = S / 2, SH = S - H;   // SH >= H
-    constexpr int LDS_T = W * 64 * LP, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
-    __shared__ __attribute__((aligned(16))) float lds[2 * LDS_T + LDS_MB + 2 * LDS_PW + LDS_CF];
+    constexpr int NSTASH4 = (H * (L + 2) + 3) / 4;                 // float4 per lane of parked s2 signals
+    constexpr int REGION = (2 * 64 * LP > 64 * 4 * NSTASH4) ? 2 * 64 * LP : 64 * 4 * NSTASH4;   // floats per wave
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + 2 * LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
     float* __restrict__ gxr = gx + (size_t)row * N;
-    float* tbx = lds + wave * 64 * LP;             // x image (kept for the second pass), then the gx image
-    float* tbg = lds + LDS_T + wave * 64 * LP;     // gy image
-    const int mb_in = 2 * LDS_T + wave * S * 4, mb_out = 2 * LDS_T + ((wave + 1) % W) * S * 4;
-    float* pw_lds = lds + 2 * LDS_T + LDS_MB;
+    float* tbx = lds + wave * REGION;              // x image, later the parked s2 signals, finally the gx image
+    float* tbg = tbx + 64 * LP;                    // gy image
+    const int mb_in = LDS_T + wave * S * 4, mb_out = LDS_T + ((wave + 1) % W) * S * 4;
+    float* pw_lds = lds + LDS_T + LDS_MB;
     float* cf_lds = pw_lds + 2 * LDS_PW;
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[2 * LDS_T + i] = 0.f;
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[LDS_T + i] = 0.f;
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) {
         pw_lds[i] = tb[LY::PW + i];
         pw_lds[LDS_PW + i] = tb[LY::PWA + i];
@@ -610,6 +614,25 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         acca[k][0] = acca[k][1] = 0.f;
     }
 
+    // Register prefetch of the next tile (x, gy and the saved chunk states): issued at the start of the last adjoint
+    // half, when the upper half's s2 registers are dead, and consumed at the top of the next iteration. Without it a
+    // wave has ~11 KB in flight for ~2 us out of every ~10 us and the kernel is bound by memory latency
+    // (bytes in flight / latency), not by bandwidth or issue.
+    f4 vx[L / 4], vg[L / 4];
+    f2 vst[S];
+#pragma unroll
+    for (int j = 0; j < L / 4; ++j) { vx[j] = f4{0.f, 0.f, 0.f, 0.f}; vg[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < S; ++k) vst[k] = f2{0.f, 0.f};
+    auto issue_loads = [&](int tt) {
+        tile_load_full<L>(xr, (long)tt * TS, vx);
+        tile_load_full<L>(gr, (long)tt * TS, vg);
+        const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + tt) * S * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < S; ++k) vst[k] = cs[k * 64];
+    };
+    if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_loads(nt - 1 - wave);
+
     for (int r = wave; r < nt; r += W) {
         const int t = nt - 1 - r;
         int toff = 0;
@@ -619,9 +642,6 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         float X[L], GY[L];
         TRACE(16);
         if (full) {
-            f4 vx[L / 4], vg[L / 4];
-            tile_load_full<L>(xr, (long)t * TS, vx);
-            tile_load_full<L>(gr, (long)t * TS, vg);
             tile_regs_to_lds<L>(tbx, vx);
             tile_regs_to_lds<L>(tbg, vg);
         } else {
@@ -634,7 +654,10 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
         //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
         f2 st[S];
-        {
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) st[k] = vst[k];
+        } else {
             const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
 #pragma unroll
             for (int k = 0; k < S; ++k) st[k] = cs[k * 64];
@@ -663,100 +686,104 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         pin(X); pin(GY); pin(st); pin(lam);   // scans done before the cascade passes start
         TRACE(19);
         __builtin_amdgcn_sched_barrier(0);
-        f2 st_lo[H];   // start states of sections [0, H) for the second pass
-#pragma unroll
-        for (int k = 0; k < H; ++k) st_lo[k] = st[k];
-
         float S2v[SH][L + 2];
+        // forward section k over the chunk, in place over X, keeping s2_k[n], n = 0..L+1 in S2v[slot]
+        auto forward_keep = [&](int k, int slot, int oz) {
+            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
+            const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+            const float nk = -ca.z;
+            float s1 = st[k].x, s2 = st[k].y;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int k0 = pass == 0 ? H : 0, k1 = pass == 0 ? S : H;   // sections whose gradients this pass produces
-            // coefficient loads addressed with an opaque per-pass zero land in VGPRs (full-rate VALU operands)
-            // and cannot be hoisted out of the tile loop; the second pass is additionally chained behind the
-            // last value the first pass produces, otherwise its forward half is scheduled alongside the
-            // first pass's adjoint half and both sets of s2 signals are live at once
-            const int oz = pass == 0 ? opaque_zero() : opaque_zero_after(GY[0]);
-            if (pass == 0) {
-                // sections [0, H): outputs only, one section at a time, in place over X (X is re-read from LDS below)
-#pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
-                    const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
-                    const float nk = -ca.z;
-                    float s1 = st[k].x, s2 = st[k].y;
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                        s2 = fmaf(ca.y, s1, ca.x * s2);
-                        s1 = t1;
-                    }
-                }
-            } else {
-                lds_to_chunks<L>(tbx + oz, X);
-#pragma unroll
-                for (int k = 0; k < H; ++k) st[k] = st_lo[k];
+            for (int n = 0; n < L; ++n) {
+                const float u = X[n];
+                S2v[slot][n] = s2;
+                X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                s2 = fmaf(ca.y, s1, ca.x * s2);
+                s1 = t1;
             }
-            // forward sections [k0, k1) keeping s2_k[n], n = 0..L+1
+            S2v[slot][L] = s2;
+            S2v[slot][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
+        };
+        // adjoint section k (descending time) + coefficient correlations, in place over GY
+        auto adjoint = [&](int k, int slot, int oz) {
+            const int i = S - 1 - k;
+            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);
+            const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);
+            const float nk = -ca.z;
+            float l1 = lam[i].x, l2 = lam[i].y;
+            float b0 = accb[k][0], b1 = accb[k][1], b2 = accb[k][2], a1 = acca[k][0], a2 = acca[k][1];
 #pragma unroll
-            for (int k = k0; k < k1; ++k) {
-                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);
-                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);
-                const float nk = -ca.z;
-                float s1 = st[k].x, s2 = st[k].y;
-#pragma unroll
-                for (int n = 0; n < L; ++n) {
-                    const float u = X[n];
-                    S2v[k - k0][n] = s2;
-                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                    const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                    s2 = fmaf(ca.y, s1, ca.x * s2);
-                    s1 = t1;
-                }
-                S2v[k - k0][L] = s2;
-                S2v[k - k0][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
+            for (int n = L - 1; n >= 0; --n) {
+                const float g = GY[n];
+                b0 = fmaf(g, S2v[slot][n + 2], b0);
+                b1 = fmaf(g, S2v[slot][n + 1], b1);
+                b2 = fmaf(g, S2v[slot][n], b2);
+                const float o = fmaf(cb.y, g, l1);
+                const float t1 = fmaf(ca.x, l1, fmaf(ca.y, l2, ca.w * g));
+                l2 = fmaf(nk, l1, fmaf(ca.x, l2, cb.x * g));
+                l1 = t1;
+                a1 = fmaf(o, S2v[slot][n + 1], a1);
+                a2 = fmaf(o, S2v[slot][n], a2);
+                GY[n] = o;
             }
-            pin(S2v); pin(GY);
-            TRACE(20 + 2 * pass);
-            __builtin_amdgcn_sched_barrier(0);
-            // adjoint sections k1-1 .. k0 (descending time) + coefficient correlations, in place over GY
+            // pinned: otherwise the compiler defers these updates to the end of the tile and keeps all
+            // 5*S per-tile sums live next to the 5*S running sums
+            pin(b0); pin(b1); pin(b2); pin(a1); pin(a2);
+            accb[k][0] = b0; accb[k][1] = b1; accb[k][2] = b2; acca[k][0] = a1; acca[k][1] = a2;
+        };
+        // coefficient loads addressed with an opaque zero land in VGPRs (full-rate VALU operands) and cannot be
+        // hoisted out of the tile loop
+        {   // lower half forward, s2 signals parked in LDS ([j][lane] float4: conflict-free 1 KiB wave accesses)
+            const int oz = opaque_zero();
 #pragma unroll
-            for (int k = k1 - 1; k >= k0; --k) {
-                const int i = S - 1 - k;
-                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);
-                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);
-                const float nk = -ca.z;
-                float l1 = lam[i].x, l2 = lam[i].y;
-                float b0 = accb[k][0], b1 = accb[k][1], b2 = accb[k][2], a1 = acca[k][0], a2 = acca[k][1];
+            for (int k = 0; k < H; ++k) forward_keep(k, k, oz);
+            wave_lds_sync();
+            f4* stash = reinterpret_cast<f4*>(tbx) + lane;
 #pragma unroll
-                for (int n = L - 1; n >= 0; --n) {
-                    const float g = GY[n];
-                    b0 = fmaf(g, S2v[k - k0][n + 2], b0);
-                    b1 = fmaf(g, S2v[k - k0][n + 1], b1);
-                    b2 = fmaf(g, S2v[k - k0][n], b2);
-                    const float o = fmaf(cb.y, g, l1);
-                    const float t1 = fmaf(ca.x, l1, fmaf(ca.y, l2, ca.w * g));
-                    l2 = fmaf(nk, l1, fmaf(ca.x, l2, cb.x * g));
-                    l1 = t1;
-                    a1 = fmaf(o, S2v[k - k0][n + 1], a1);
-                    a2 = fmaf(o, S2v[k - k0][n], a2);
-                    GY[n] = o;
-                    // keep the correlations next to the recurrence: hoisting the whole recurrence first keeps
-                    // both g[n] and o[n] of all samples live (+16 registers per section)
-#ifdef DASP_BWD_INLOOP_BARRIER
-                    if ((n & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
+            for (int j = 0; j < NSTASH4; ++j) {
+                f4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = 4 * j + c;
+                    v[c] = e < H * (L + 2) ? S2v[e / (L + 2)][e % (L + 2)] : 0.f;
                 }
-                // pinned: otherwise the compiler defers these updates to the end of the tile and keeps all
-                // 5*S per-tile sums live next to the 5*S running sums
-                pin(b0); pin(b1); pin(b2); pin(a1); pin(a2);
-                accb[k][0] = b0; accb[k][1] = b1; accb[k][2] = b2; acca[k][0] = a1; acca[k][1] = a2;
+                stash[j * 64] = v;
             }
-            pin(GY);
-            TRACE(21 + 2 * pass);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // upper half: forward keeping its s2 signals in registers, then its adjoint
+            const int oz = opaque_zero_after(X[0]);
+#pragma unroll
+            for (int k = H; k < S; ++k) forward_keep(k, k - H, oz);
+            pin(S2v); pin(GY);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = S - 1; k >= H; --k) adjoint(k, k - H, oz);
+        }
+        pin(GY);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // lower half adjoint with the parked signals (chained behind the upper half so that the two sets of
+            // s2 registers are not live at once)
+            const int oz = opaque_zero_after(GY[0]);
+            if (r + W < nt) issue_loads(t - W);   // tiles below the row's last one are always full when this one is
+            __builtin_amdgcn_sched_barrier(0);
+            const f4* stash = reinterpret_cast<const f4*>(tbx + oz) + lane;
+#pragma unroll
+            for (int j = 0; j < NSTASH4; ++j) {
+                const f4 v = stash[j * 64];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = 4 * j + c;
+                    if (e < H * (L + 2)) S2v[e / (L + 2)][e % (L + 2)] = v[c];
+                }
+            }
+#pragma unroll
+            for (int k = H - 1; k >= 0; --k) adjoint(k, k, oz);
+        }
+        pin(GY);
+        TRACE(23);
+        __builtin_amdgcn_sched_barrier(0);
         chunks_to_lds<L>(tbx, GY);
         if (full) tile_lds_to_global_full<L>(tbx, gxr, (long)t * TS);
         else tile_lds_to_global_guarded<L>(tbx, gxr, (long)t * TS, N);
