@@ -6,7 +6,7 @@
 // Layout: x, y, gy, gx (B, C, N) fp32 contiguous; a row = one (b, c) signal. Control values are
 // indexed  row / cdiv  (gain: cdiv = C, one gain per batch item repeated over channels,
 // functional.py:26-28;  distortion: cdiv = 1, one drive per (b, c) row, functional.py:78).
-// Grid = (segments per row, rows); a segment is SEG consecutive samples handled by one 256-thread
+// Grid = rows x segments per row (1-D); a segment is SEG consecutive samples handled by one 256-thread
 // workgroup with float4 accesses. Backward writes one partial sum per (row, segment); a finalize
 // kernel reduces them in fp64 (deterministic, no float atomics).
 #include "common.hpp"
@@ -41,7 +41,7 @@ template <int OP, bool BWD>
 __global__ void __launch_bounds__(EW_THREADS)
 ew_kernel(const float* __restrict__ x, const float* __restrict__ ctl_db, const float* __restrict__ gy,
           float* __restrict__ out, float* __restrict__ partials, int cdiv, long N, int nseg, int vec) {
-    const int row = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const int row = blockIdx.x / nseg, seg = blockIdx.x % nseg, tid = threadIdx.x;   // 1-D grid: no 65535-row limit
     const float lin = exp10f(ctl_db[row / cdiv] * 0.05f);
     const long base = (long)row * N, s0 = (long)seg * EW_SEG;
     const long s1 = s0 + EW_SEG < N ? s0 + EW_SEG : N;
@@ -107,9 +107,9 @@ template <int OP>
 int ew_forward(const float* x, const float* ctl, float* y, int B, int C, long N, void* stream) {
     if (!x || !ctl || !y || B <= 0 || C <= 0 || N <= 0) return DASP_ERR_ARG;
     const long rows = (long)B * C;
-    if (rows > 65535) return DASP_ERR_UNSUPPORTED;
     const int nseg = ew_nseg(N), vec = (N % 4 == 0) && ew_al16(x) && ew_al16(y);
-    hipLaunchKernelGGL((ew_kernel<OP, false>), dim3(nseg, (unsigned)rows), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ctl, nullptr, y,
+    if (rows * nseg > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((ew_kernel<OP, false>), dim3((unsigned)(rows * nseg)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ctl, nullptr, y,
                        nullptr, OP == EW_GAIN ? C : 1, N, nseg, vec);
     return ew_check();
 }
@@ -118,10 +118,10 @@ int ew_backward(const float* x, const float* ctl, const float* gy, float* gx, fl
                 void* stream) {
     if (!x || !ctl || !gy || !gx || !gctl || !partials || B <= 0 || C <= 0 || N <= 0) return DASP_ERR_ARG;
     const long rows = (long)B * C;
-    if (rows > 65535) return DASP_ERR_UNSUPPORTED;
     const int nseg = ew_nseg(N), vec = (N % 4 == 0) && ew_al16(x) && ew_al16(gy) && ew_al16(gx);
+    if (rows * nseg > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int cdiv = OP == EW_GAIN ? C : 1, nctl = (int)(rows / cdiv);
-    hipLaunchKernelGGL((ew_kernel<OP, true>), dim3(nseg, (unsigned)rows), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ctl, gy, gx, partials,
+    hipLaunchKernelGGL((ew_kernel<OP, true>), dim3((unsigned)(rows * nseg)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ctl, gy, gx, partials,
                        cdiv, N, nseg, vec);
     int st = ew_check();
     if (st != DASP_OK) return st;

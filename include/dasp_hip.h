@@ -70,7 +70,7 @@ int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, in
  * and dasp_pytorch.functional.distortion (functional.py:65-78): y = tanh(x * 10^(drive_db/20)),
  * drive_db (B*C) one value per (b, c) row (the reference's drive_db.view(bs, chs, -1), :78).
  * Backward: gx = dL/dx, ggain (B) / gdrive (B*C) = dL/d(control in dB); `partials` is scratch of
- * dasp_ew_partial_floats(B*C, N) floats. Rows (B*C) must be <= 65535.
+ * dasp_ew_partial_floats(B*C, N) floats.
  * ------------------------------------------------------------------------------------------- */
 long dasp_ew_partial_floats(long rows, long N);
 int dasp_gain_forward(const float* x, const float* gain_db, float* y, int B, int C, long N, void* stream);

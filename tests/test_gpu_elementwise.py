@@ -38,7 +38,7 @@ def test_config1_golden(D):
         assert linf_peak(y.detach().cpu().numpy(), g[name + "_y32"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("B,C,N", [(1, 1, 1), (2, 3, 5), (3, 2, 8191), (2, 2, 8192), (1, 2, 8193), (4, 2, 100000), (256, 2, 131072)])
+@pytest.mark.parametrize("B,C,N", [(1, 1, 1), (2, 3, 5), (3, 2, 8191), (2, 2, 8192), (1, 2, 8193), (4, 2, 100000), (70000, 1, 64), (256, 2, 131072)])
 def test_shapes_vs_oracle(D, B, C, N):
     rng = np.random.default_rng(N + B)
     x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)

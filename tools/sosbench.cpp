@@ -57,11 +57,29 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dsos, sos.data(), sos.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dgy, gy.data(), n * 4, hipMemcpyHostToDevice));
 
+    // optional: time the fused RBJ design path (parametric_eq) instead of raw sos
+    const bool peq = getenv("DASP_PEQ") != nullptr;
+    const int types[6] = {1, 0, 0, 0, 0, 2};
+    float* dpar = nullptr;
+    if (peq) {
+        std::vector<float> par((size_t)B * S * 3);
+        const float lo[6] = {20, 80, 2000, 8000, 12000, 4000}, hi[6] = {2000, 2000, 8000, 12000, 21050, 21050};
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < S; ++k) {
+                par[((size_t)b * S + k) * 3 + 0] = -20.f + 40.f * U(rng);
+                par[((size_t)b * S + k) * 3 + 1] = lo[k] + (hi[k] - lo[k]) * U(rng);
+                par[((size_t)b * S + k) * 3 + 2] = 0.1f + 5.9f * U(rng);
+            }
+        CK(hipMalloc(&dpar, par.size() * 4));
+        CK(hipMemcpy(dpar, par.data(), par.size() * 4, hipMemcpyHostToDevice));
+    }
     hipEvent_t e[4]; for (auto& ev : e) CK(hipEventCreate(&ev));
     double tp = 0, tf = 0, tb = 0;
     for (int it = -2; it < iters; ++it) {
+        if (getenv("DASP_PREP2")) { if (peq) DK(dasp_peq_prepare(dpar, B, S, types, 44100.0, dtab, ddtab, nullptr)); else DK(dasp_sos_prepare(dsos, B, S, dtab, ddtab, nullptr)); }
         CK(hipEventRecord(e[0]));
-        DK(dasp_sos_prepare(dsos, B, S, dtab, ddtab, nullptr));
+        if (peq) DK(dasp_peq_prepare(dpar, B, S, types, 44100.0, dtab, ddtab, nullptr));
+        else DK(dasp_sos_prepare(dsos, B, S, dtab, ddtab, nullptr));
         CK(hipEventRecord(e[1]));
         DK(dasp_sosfilt_forward(dtab, B, dx, dy, dcar, B, C, N, S, nullptr));
         CK(hipEventRecord(e[2]));
