@@ -356,7 +356,13 @@ __global__ void dyn_finalize_kernel(const float* __restrict__ partials, const fl
 using namespace dasp;
 
 namespace {
-constexpr int kDW = 8;   // waves per batch item
+#ifndef DASP_DYN_WF
+#define DASP_DYN_WF 16
+#endif
+#ifndef DASP_DYN_WB
+#define DASP_DYN_WB 8
+#endif
+constexpr int kDWF = DASP_DYN_WF, kDW = DASP_DYN_WB;   // waves per batch item (forward, backward)
 inline int dy_check() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
@@ -377,10 +383,10 @@ int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, 
     if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_dyn_num_tiles(N), vec = (N % 4 == 0) && dy_al16(x) && dy_al16(y) && (!lin_buf || dy_al16(lin_buf));
     if (mode == 0)
-        hipLaunchKernelGGL((dyn_fwd_kernel<0, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, y, carries,
+        hipLaunchKernelGGL((dyn_fwd_kernel<0, kDWF>), dim3(B), dim3(64 * kDWF), 0, (hipStream_t)stream, x, ctl, y, carries,
                            lookahead > 0 ? lin_buf : nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps);
     else
-        hipLaunchKernelGGL((dyn_fwd_kernel<1, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, y, carries,
+        hipLaunchKernelGGL((dyn_fwd_kernel<1, kDWF>), dim3(B), dim3(64 * kDWF), 0, (hipStream_t)stream, x, ctl, y, carries,
                            lookahead > 0 ? lin_buf : nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps);
     return dy_check();
 }
