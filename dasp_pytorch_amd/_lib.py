@@ -92,9 +92,11 @@ class KernelTimers:
     def __init__(self):
         self.enabled = False
         self.pending = {}
+        self.every = 1        # record every n-th call of each entry point (events cost ~2 us each on the stream)
+        self.count = {}
 
-    def start(self):
-        self.enabled, self.pending = True, {}
+    def start(self, every=1):
+        self.enabled, self.pending, self.every, self.count = True, {}, max(1, int(every)), {}
 
     def stop(self):
         """Synchronise and return {entry point: [ms per launch, ...]}."""
@@ -111,7 +113,12 @@ timers = KernelTimers()
 def call(name, *args):
     """Invoke one C-ABI entry point, raising DaspHipError on a non-zero status."""
     fn = getattr(lib(), name)
+    sample = False
     if timers.enabled:
+        n = timers.count.get(name, 0)
+        timers.count[name] = n + 1
+        sample = n % timers.every == 0
+    if sample:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         status = fn(*args)
