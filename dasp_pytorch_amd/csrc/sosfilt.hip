@@ -80,30 +80,28 @@ __device__ __forceinline__ void put_blk(float* o, double p, double q, double kap
     o[3] = (float)p;
 }
 
-// ---- forward-mode dual numbers (3 partials) for the RBJ design Jacobian ---------------------------
-struct D3 {
-    double v, d[3];
+// ---- forward-mode dual numbers for the RBJ design Jacobian ------------------------------------------
+// One partial per thread (thread = (section, control)): three short dependent fp64 chains side by side
+// instead of one thread dragging three partials through every operation.
+struct D1 {
+    double v, d;
 };
-__device__ __forceinline__ D3 dconst(double c) { return {c, {0, 0, 0}}; }
-__device__ __forceinline__ D3 dvar(double c, int i) { D3 r = {c, {0, 0, 0}}; r.d[i] = 1; return r; }
-__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
-__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
-__device__ __forceinline__ D3 operator*(D3 a, D3 b) {
-    return {a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
-}
-__device__ __forceinline__ D3 operator/(D3 a, D3 b) {
+__device__ __forceinline__ D1 dconst(double c) { return {c, 0.0}; }
+__device__ __forceinline__ D1 operator+(D1 a, D1 b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ D1 operator-(D1 a, D1 b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ D1 operator*(D1 a, D1 b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ D1 operator/(D1 a, D1 b) {
     const double iv = 1.0 / b.v, q = a.v * iv;
-    return {q, {(a.d[0] - q * b.d[0]) * iv, (a.d[1] - q * b.d[1]) * iv, (a.d[2] - q * b.d[2]) * iv}};
+    return {q, (a.d - q * b.d) * iv};
 }
-__device__ __forceinline__ D3 operator*(double c, D3 a) { return {c * a.v, {c * a.d[0], c * a.d[1], c * a.d[2]}}; }
-__device__ __forceinline__ D3 operator+(double c, D3 a) { return {c + a.v, {a.d[0], a.d[1], a.d[2]}}; }
-__device__ __forceinline__ D3 operator-(double c, D3 a) { return {c - a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
-__device__ __forceinline__ D3 operator-(D3 a) { return {-a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
-__device__ __forceinline__ D3 dchain(D3 a, double f, double fp) { return {f, {fp * a.d[0], fp * a.d[1], fp * a.d[2]}}; }
-__device__ __forceinline__ D3 dsin(D3 a) { return dchain(a, sin(a.v), cos(a.v)); }
-__device__ __forceinline__ D3 dcos(D3 a) { return dchain(a, cos(a.v), -sin(a.v)); }
-__device__ __forceinline__ D3 dsqrt(D3 a) { const double s = sqrt(a.v); return dchain(a, s, 0.5 / s); }
-__device__ __forceinline__ D3 dexp(D3 a) { const double e = exp(a.v); return dchain(a, e, e); }
+__device__ __forceinline__ D1 operator*(double c, D1 a) { return {c * a.v, c * a.d}; }
+__device__ __forceinline__ D1 operator+(double c, D1 a) { return {c + a.v, a.d}; }
+__device__ __forceinline__ D1 operator-(double c, D1 a) { return {c - a.v, -a.d}; }
+__device__ __forceinline__ D1 operator-(D1 a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ D1 dsin(D1 a) { return {sin(a.v), cos(a.v) * a.d}; }
+__device__ __forceinline__ D1 dcos(D1 a) { return {cos(a.v), -sin(a.v) * a.d}; }
+__device__ __forceinline__ D1 dsqrt(D1 a) { const double r = sqrt(a.v); return {r, 0.5 / r * a.d}; }
+__device__ __forceinline__ D1 dexp(D1 a) { const double e = exp(a.v); return {e, e * a.d}; }
 
 struct PeqSpec {
     int types[8];        // 0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass
@@ -112,14 +110,15 @@ struct PeqSpec {
 
 // RBJ cookbook design, same formulas as dasp_pytorch/signal.py:255-304, in fp64 with the Jacobian
 // d(b0,b1,b2,a1,a2 normalised)/d(gain_db, cutoff_freq, q_factor).
-__device__ void rbj_design(int type, double sample_rate, double gain_db, double fc, double qf, double* c5, double* J /*[5][3]*/) {
-    const D3 g = dvar(gain_db, 0), f = dvar(fc, 1), q = dvar(qf, 2);
-    const D3 A = dexp((2.302585092994045684 / 40.0) * g);
-    const D3 w0 = (2.0 * 3.14159265358979323846 / sample_rate) * f;
-    const D3 alpha = dsin(w0) / (2.0 * q);
-    const D3 cw = dcos(w0);
-    const D3 sA = dsqrt(A);
-    D3 b0, b1, b2, a0, a1, a2;
+// c5 = normalised (b0, b1, b2, a1, a2); dc5 = their derivative w.r.t. control `dir` (0 gain_db, 1 cutoff_freq, 2 q_factor)
+__device__ void rbj_design(int type, double sample_rate, double gain_db, double fc, double qf, int dir, double* c5, double* dc5) {
+    const D1 g = {gain_db, dir == 0 ? 1.0 : 0.0}, f = {fc, dir == 1 ? 1.0 : 0.0}, q = {qf, dir == 2 ? 1.0 : 0.0};
+    const D1 A = dexp((2.302585092994045684 / 40.0) * g);
+    const D1 w0 = (2.0 * 3.14159265358979323846 / sample_rate) * f;
+    const D1 alpha = dsin(w0) / (2.0 * q);
+    const D1 cw = dcos(w0);
+    const D1 sA = dsqrt(A);
+    D1 b0, b1, b2, a0, a1, a2;
     if (type == 2) {  // high_shelf
         b0 = A * ((A + dconst(1)) + (A - dconst(1)) * cw + 2.0 * (sA * alpha));
         b1 = -2.0 * (A * ((A - dconst(1)) + (A + dconst(1)) * cw));
@@ -156,10 +155,10 @@ __device__ void rbj_design(int type, double sample_rate, double gain_db, double 
         a1 = -2.0 * cw;
         a2 = 1.0 - alpha;
     }
-    const D3 n[5] = {b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0};
+    const D1 n[5] = {b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0};
     for (int c = 0; c < 5; ++c) {
         c5[c] = n[c].v;
-        for (int i = 0; i < 3; ++i) J[c * 3 + i] = n[c].d[i];
+        dc5[c] = n[c].d;
     }
 }
 
@@ -176,39 +175,41 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     __shared__ double sec[S][8];        // sg, om, kom, g1, g2, d, kappa
     __shared__ double Phi[2][NN], T1[2][NN], T2[2][NN];
     __shared__ double vv[2][2][S2];
+    __shared__ float Gsh[2][L][S2];     // chunk-table columns v_m, written out after the recursion (no global stores inside it)
     __shared__ double Pd[S][7][2];
     const int tid = threadIdx.x, item = blockIdx.x;
     float* tb = tab + (size_t)item * LY::TOTAL;
     double* dt = dtab + (size_t)item * S * DT_STRIDE;
 
-    if (tid < S) {
-        const int k = tid;
-        double c5[5], a0 = 1.0, J[15];
-        for (int i = 0; i < 15; ++i) J[i] = 0.0;
+    if (tid < 3 * S) {   // thread = (section k, control dir): values + one Jacobian column each
+        const int k = tid / 3, dir = tid % 3;
+        double c5[5], dc5[5] = {0, 0, 0, 0, 0}, a0 = 1.0;
         if (params) {
             const float* p = params + ((size_t)item * S + k) * 3;
-            rbj_design(spec.types[k], spec.sample_rate, (double)p[0], (double)p[1], (double)p[2], c5, J);
+            rbj_design(spec.types[k], spec.sample_rate, (double)p[0], (double)p[1], (double)p[2], dir, c5, dc5);
         } else {
             const float* s = sos + ((size_t)item * S + k) * 6;
             a0 = (double)s[3];
             c5[0] = s[0] / a0; c5[1] = s[1] / a0; c5[2] = s[2] / a0; c5[3] = s[4] / a0; c5[4] = s[5] / a0;
         }
-        const double b0 = c5[0], b1 = c5[1], b2 = c5[2], a1 = c5[3], a2 = c5[4];
-        const double sg = -0.5 * a1, disc = sg * sg - a2;
-        const double kap = disc < 0 ? 1.0 : -1.0;
-        double om = sqrt(fabs(disc));
-        om = om < OM_MIN ? OM_MIN : om;
-        const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
-        sec[k][0] = sg; sec[k][1] = om; sec[k][2] = kap * om; sec[k][3] = g1; sec[k][4] = g2; sec[k][5] = b0; sec[k][6] = kap;
-        float* cf = tb + LY::COEF + k * 8;
-        cf[0] = (float)sg; cf[1] = (float)om; cf[2] = (float)(kap * om); cf[3] = (float)g1; cf[4] = (float)g2;
-        cf[5] = (float)b0; cf[6] = (float)kap; cf[7] = 0.f;
         double* d = dt + k * DT_STRIDE;
-        d[DT_OM] = om;
-        for (int c = 0; c < 5; ++c) d[DT_B0 + c] = c5[c];
-        d[DT_A0] = a0; d[7] = kap;
-        for (int i = 0; i < 15; ++i) d[DT_J + i] = J[i];
-        d[23] = 0.0;
+        for (int c = 0; c < 5; ++c) d[DT_J + c * 3 + dir] = dc5[c];
+        if (dir == 0) {
+            const double b0 = c5[0], b1 = c5[1], b2 = c5[2], a1 = c5[3], a2 = c5[4];
+            const double sg = -0.5 * a1, disc = sg * sg - a2;
+            const double kap = disc < 0 ? 1.0 : -1.0;
+            double om = sqrt(fabs(disc));
+            om = om < OM_MIN ? OM_MIN : om;
+            const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
+            sec[k][0] = sg; sec[k][1] = om; sec[k][2] = kap * om; sec[k][3] = g1; sec[k][4] = g2; sec[k][5] = b0; sec[k][6] = kap;
+            float* cf = tb + LY::COEF + k * 8;
+            cf[0] = (float)sg; cf[1] = (float)om; cf[2] = (float)(kap * om); cf[3] = (float)g1; cf[4] = (float)g2;
+            cf[5] = (float)b0; cf[6] = (float)kap; cf[7] = 0.f;
+            d[DT_OM] = om;
+            for (int c = 0; c < 5; ++c) d[DT_B0 + c] = c5[c];
+            d[DT_A0] = a0; d[7] = kap;
+            d[23] = 0.0;
+        }
     }
     __syncthreads();
 
@@ -242,50 +243,52 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     __syncthreads();
 
     // chunk tables: v_m = Phi^m Bx ; forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
-    for (int m = 0; m < L; ++m) {
-        const int cur = m & 1;
-        if (tid < 2 * S2) {
-            const int sys = tid / S2, i = tid % S2;
-            const double v = vv[cur][sys][i];
-            if (sys == 0) tb[LY::GT + ((i >> 1) * L + (L - 1 - m)) * 2 + (i & 1)] = (float)v;
-            else tb[LY::GAT + ((i >> 1) * L + m) * 2 + (i & 1)] = (float)v;
-            double acc = 0.0;
-            for (int j = 0; j < S2; ++j) acc += Phi[sys][i * S2 + j] * vv[cur][sys][j];
-            vv[cur ^ 1][sys][i] = acc;
+    // Two independent dependent chains run side by side in different waves with wave-level synchronisation only
+    // (block barriers cost more than the arithmetic here): wave 0 the 16-step chunk-table recursion, wave 1 the
+    // log2(L) squarings to M = Phi^L with the coupling blocks and diagonal-block powers that follow from it.
+    if (tid < 64) {
+        for (int m = 0; m < L; ++m) {
+            const int cur = m & 1;
+            if (tid < 2 * S2) {
+                const int sys = tid / S2, i = tid % S2;
+                const double v = vv[cur][sys][i];
+                Gsh[sys][m][i] = (float)v;
+                double acc = 0.0;
+                for (int j = 0; j < S2; ++j) acc += Phi[sys][i * S2 + j] * vv[cur][sys][j];
+                vv[cur ^ 1][sys][i] = acc;
+            }
+            wave_lds_sync();
         }
-        __syncthreads();
-    }
-
-    // M = Phi^L by repeated squaring (L is a power of two)
-    {
+    } else if (tid < 128) {
+        const int l = tid - 64;
         double (*src)[NN] = T1;
         double (*dst)[NN] = T2;
         for (int step = 1; step < L; step <<= 1) {
-            for (int e = tid; e < 2 * NN; e += 256) {
+            for (int e = l; e < 2 * NN; e += 64) {
                 const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
                 double acc = 0.0;
                 for (int m = 0; m < S2; ++m) acc += src[sys][i * S2 + m] * src[sys][m * S2 + j];
                 dst[sys][i * S2 + j] = acc;
             }
-            __syncthreads();
+            wave_lds_sync();
             double (*tmp)[NN] = src; src = dst; dst = tmp;
         }
         // coupling blocks, column-major
-        for (int e = tid; e < 2 * S * S * 4; e += 256) {
+        for (int e = l; e < 2 * S * S * 4; e += 64) {
             const int sys = e / (S * S * 4), k = (e / (S * 4)) % S, j = (e / 4) % S, c = e % 4;
             tb[(sys ? LY::MCA : LY::MC) + (k * S + j) * 4 + c] = (float)src[sys][(2 * k + (c & 1)) * S2 + 2 * j + (c >> 1)];
         }
-        if (tid < S) {  // diagonal-block powers of the *forward* section k: M_kk = [[p, -kap q], [q, p]]
-            const int k = tid;
+        if (l < S) {  // diagonal-block powers of the *forward* section k: M_kk = [[p, -kap q], [q, p]]
+            const int k = l;
             const double kap = sec[k][6];
             double p = src[0][(2 * k) * S2 + 2 * k], q = src[0][(2 * k + 1) * S2 + 2 * k];
-            for (int l = 0; l < 7; ++l) {
-                Pd[k][l][0] = p; Pd[k][l][1] = q;
-                if (l < 4) {
-                    put_blk(tb + LY::PL + (k * 4 + l) * 4, p, q, kap, 0);
-                    put_blk(tb + LY::PLA + ((S - 1 - k) * 4 + l) * 4, p, q, kap, 1);
+            for (int lv = 0; lv < 7; ++lv) {
+                Pd[k][lv][0] = p; Pd[k][lv][1] = q;
+                if (lv < 4) {
+                    put_blk(tb + LY::PL + (k * 4 + lv) * 4, p, q, kap, 0);
+                    put_blk(tb + LY::PLA + ((S - 1 - k) * 4 + lv) * 4, p, q, kap, 1);
                 }
-                if (l == 6) {
+                if (lv == 6) {
                     put_blk(tb + LY::P64 + k * 4, p, q, kap, 0);
                     put_blk(tb + LY::P64A + (S - 1 - k) * 4, p, q, kap, 1);
                 }
@@ -296,6 +299,12 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         }
     }
     __syncthreads();
+    // chunk tables: forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
+    for (int e = tid; e < 2 * L * S2; e += 256) {
+        const int sys = e / (L * S2), m = (e / S2) % L, i = e % S2;
+        if (sys == 0) tb[LY::GT + ((i >> 1) * L + (L - 1 - m)) * 2 + (i & 1)] = Gsh[0][m][i];
+        else tb[LY::GAT + ((i >> 1) * L + m) * 2 + (i & 1)] = Gsh[1][m][i];
+    }
     // per-lane powers M_kk^(c+1), c = 0..63
     for (int e = tid; e < S * 64; e += 256) {
         const int k = e / 64, c = e % 64, m = c + 1;
