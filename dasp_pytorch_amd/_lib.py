@@ -43,9 +43,9 @@ SIGNATURES = {
     "dasp_fft_init": (_i, [ctypes.c_char_p]),
     "dasp_fft_ready": (_i, []),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
-    "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _i, _p, _p, _p]),
-    "dasp_reverb_forward": (_i, [_p] * 14 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_backward": (_i, [_p] * 20 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
+    "dasp_reverb_forward": (_i, [_p] * 12 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_backward": (_i, [_p] * 21 + [_i, _l, _i, _i, _i, _p]),
 }
 
 

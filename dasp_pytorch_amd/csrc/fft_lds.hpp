@@ -1,0 +1,129 @@
+// Workgroup-level complex FFT of 4096 points held in registers + LDS (gfx950): 512 threads, 8 elements per thread,
+// four radix-8 Stockham passes with three LDS exchanges. Element `idx = j + 512 q` lives in register q of thread j
+// both before and after a transform (natural order in, natural order out), so a forward transform, a pointwise
+// product and the inverse transform chain through registers without touching LDS in between.
+//
+// Used by the reverb's filter bank (reverb.hip), where it replaces three batched rocFFT passes over 2B*12 noise
+// rows (dasp_pytorch/functional.py:548-558) with one fused kernel.
+#pragma once
+#include "common.hpp"
+
+namespace dasp {
+
+constexpr int FFT_N = 4096;          // transform length
+constexpr int FFT_T = 512;           // threads per transform
+constexpr int FFT_LDS = FFT_N + FFT_N / 8;   // float2 elements of the padded exchange buffer (36,864 B)
+
+// one pad slot per 8 elements: makes the stride-8 and stride-64 scatter of the first two passes conflict-free
+__device__ __forceinline__ int fft_pad(int i) { return i + (i >> 3); }
+
+// z * (-i) for DIR < 0, z * (+i) for DIR > 0
+template <int DIR> __device__ __forceinline__ void rot90(float& re, float& im) {
+    const float t = re;
+    if (DIR < 0) { re = im; im = -t; } else { re = -im; im = t; }
+}
+
+// 4-point DFT of (c0..c3) in place, outputs in natural order
+template <int DIR>
+__device__ __forceinline__ void dft4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3, float& i3) {
+    const float s0r = r0 + r2, s0i = i0 + i2, d0r = r0 - r2, d0i = i0 - i2;
+    const float s1r = r1 + r3, s1i = i1 + i3;
+    float d1r = r1 - r3, d1i = i1 - i3;
+    rot90<DIR>(d1r, d1i);
+    r0 = s0r + s1r; i0 = s0i + s1i;
+    r2 = s0r - s1r; i2 = s0i - s1i;
+    r1 = d0r + d1r; i1 = d0i + d1i;
+    r3 = d0r - d1r; i3 = d0i - d1i;
+}
+
+// 8-point DFT, X[q] = sum_r x[r] exp(DIR 2 pi i q r / 8), natural order in and out
+template <int DIR> __device__ __forceinline__ void radix8(float (&r)[8], float (&i)[8]) {
+    constexpr float H = 0.70710678118654752440f;
+    float ar[8], ai[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ar[k] = r[k] + r[k + 4]; ai[k] = i[k] + i[k + 4];
+        ar[k + 4] = r[k] - r[k + 4]; ai[k + 4] = i[k] - i[k + 4];
+    }
+    // odd half: a[4 + k] *= w8^k
+    {
+        const float p = ar[5], q = ai[5];
+        if (DIR < 0) { ar[5] = (p + q) * H; ai[5] = (q - p) * H; } else { ar[5] = (p - q) * H; ai[5] = (p + q) * H; }
+    }
+    rot90<DIR>(ar[6], ai[6]);
+    {
+        const float p = ar[7], q = ai[7];
+        if (DIR < 0) { ar[7] = (q - p) * H; ai[7] = -(p + q) * H; } else { ar[7] = -(p + q) * H; ai[7] = (p - q) * H; }
+    }
+    dft4<DIR>(ar[0], ai[0], ar[1], ai[1], ar[2], ai[2], ar[3], ai[3]);
+    dft4<DIR>(ar[4], ai[4], ar[5], ai[5], ar[6], ai[6], ar[7], ai[7]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[2 * k] = ar[k]; i[2 * k] = ai[k];
+        r[2 * k + 1] = ar[4 + k]; i[2 * k + 1] = ai[4 + k];
+    }
+}
+
+// w^1..w^7 of one pass's twiddle (forward sign), powers by repeated products (each within ~2 ulp)
+struct Tw8 { float r[7], i[7]; };
+__device__ __forceinline__ Tw8 tw_powers(f2 w) {
+    Tw8 t;
+    t.r[0] = w.x; t.i[0] = w.y;
+    t.r[1] = w.x * w.x - w.y * w.y;            t.i[1] = 2.f * w.x * w.y;
+    t.r[2] = t.r[1] * w.x - t.i[1] * w.y;      t.i[2] = t.r[1] * w.y + t.i[1] * w.x;
+    t.r[3] = t.r[1] * t.r[1] - t.i[1] * t.i[1]; t.i[3] = 2.f * t.r[1] * t.i[1];
+    t.r[4] = t.r[3] * w.x - t.i[3] * w.y;      t.i[4] = t.r[3] * w.y + t.i[3] * w.x;
+    t.r[5] = t.r[2] * t.r[2] - t.i[2] * t.i[2]; t.i[5] = 2.f * t.r[2] * t.i[2];
+    t.r[6] = t.r[3] * t.r[2] - t.i[3] * t.i[2]; t.i[6] = t.r[3] * t.i[2] + t.i[3] * t.r[2];
+    return t;
+}
+// the three twiddle sets of a thread (they depend on the thread index only: compute once, reuse for every transform)
+struct FftTw { Tw8 s1, s2, s3; };
+__device__ __forceinline__ FftTw fft_twiddles(int j, const f2* __restrict__ tw) {
+    FftTw t;
+    t.s1 = tw_powers(tw[(j & 7) * 64]);      // Ns = 8
+    t.s2 = tw_powers(tw[(j & 63) * 8]);      // Ns = 64
+    t.s3 = tw_powers(tw[j]);                 // Ns = 512
+    return t;
+}
+// x[k] *= w^k (DIR < 0) or conj(w)^k (DIR > 0), k = 1..7
+template <int DIR> __device__ __forceinline__ void twiddle8(float (&r)[8], float (&i)[8], const Tw8& w) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const float wr = w.r[k - 1], wi = w.i[k - 1];
+        float t;
+        if (DIR < 0) { t = r[k] * wr - i[k] * wi; i[k] = r[k] * wi + i[k] * wr; }
+        else { t = r[k] * wr + i[k] * wi; i[k] = i[k] * wr - r[k] * wi; }
+        r[k] = t;
+    }
+}
+
+// registers -> LDS at wbase + q * wstride, barrier, LDS -> registers at element j + 512 q. All indices are already padded
+// (fft_pad is linear over each of these progressions, so every access is one base register + an immediate offset).
+__device__ __forceinline__ void fft_exchange(float (&r)[8], float (&i)[8], f2* lds, int wbase, int wstride, int rbase) {
+    __syncthreads();                 // every thread has finished reading the previous contents
+    f2* wp = lds + wbase;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wp[q * wstride] = f2{r[q], i[q]};
+    __syncthreads();
+    const f2* rp = lds + rbase;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f2 v = rp[q * (FFT_N / 8 + FFT_N / 64)]; r[q] = v.x; i[q] = v.y; }
+}
+
+template <int DIR>
+__device__ __forceinline__ void fft4096(float (&r)[8], float (&i)[8], int j, const FftTw& tw, f2* lds) {
+    const int rb = j + (j >> 3);                                            // fft_pad(j); fft_pad(j + 512 q) = rb + 576 q
+    radix8<DIR>(r, i);                                                     // Ns = 1: scatter to 8 j + q
+    fft_exchange(r, i, lds, 9 * j, 1, rb);
+    twiddle8<DIR>(r, i, tw.s1);                                            // Ns = 8: scatter to (j / 8) 64 + j % 8 + 8 q
+    radix8<DIR>(r, i);
+    fft_exchange(r, i, lds, (j >> 3) * 72 + (j & 7), 9, rb);
+    twiddle8<DIR>(r, i, tw.s2);                                            // Ns = 64: scatter to (j / 64) 512 + j % 64 + 64 q
+    radix8<DIR>(r, i);
+    fft_exchange(r, i, lds, (j >> 6) * 576 + (j & 63) + ((j & 63) >> 3), 72, rb);
+    twiddle8<DIR>(r, i, tw.s3);                                            // Ns = 512
+    radix8<DIR>(r, i);
+}
+
+}  // namespace dasp

@@ -7,12 +7,17 @@
 //   y_wet   = causal convolution of x with ir, truncated to N        (:570-572, direct conv1d, 65536 taps)
 //   y       = (1 - mix) x + mix y_wet                                (:575)
 // The reference's direct convolutions are 99.6 % of its time. Here both are
-// frequency-domain products: the filterbank as one batched FFT correlation (n1-point), the 65536-tap
-// convolution as overlap-add over blocks of Lb samples with n1 = 2 Lb point FFTs.
+// frequency-domain products. The filter bank (short filters, 2B*12 independent noise rows) is ONE fused kernel:
+// overlap-save windows of 4096 samples, the left/right rows of an item packed as one complex signal, forward FFT,
+// product with the band's spectrum and inverse FFT inside the workgroup (fft_lds.hpp), envelope / gain / band mean
+// applied to the result in registers - the filtered noise never exists in HBM (the backward pass re-runs the same
+// kernel with the impulse-response gradient as a weight instead of saving it). The 65536-tap convolution is
+// overlap-add over blocks of Lb samples with n1 = 2 Lb point FFTs (hipFFT/rocFFT).
 //
 // The FFT library is bound at run time (dasp_fft_init dlopens the libhipfft the host process
 // already uses, so a process never holds two copies); plans are cached per (length, batch).
 #include "common.hpp"
+#include "fft_lds.hpp"
 #include <dlfcn.h>
 #include <hipfft/hipfft.h>
 #include <map>
@@ -55,23 +60,121 @@ __global__ void cmul_rows_kernel(const cpx* __restrict__ A, const cpx* __restric
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nfreq; f += gridDim.x * blockDim.x) o[f] = conjB ? cmulc(a[f], b[f]) : cmul(a[f], b[f]);
 }
 
-// ir_pad[r][n] = n < L ? mean_band(wf[r][band][n] * exp(-(10 decay + 1) t_n) * gain) / fft_scale : 0,  r = b*2 + c
-// wf rows are the un-normalised inverse FFTs (stride n1), hence the 1/n1.
-__global__ void ir_shape_kernel(const float* __restrict__ wf, const float* __restrict__ gains, const float* __restrict__ decays,
-                                float* __restrict__ ir_pad, int nb, int L, int n1) {
-    const int r = blockIdx.y, b = r >> 1;
-    __shared__ float g[RV_BANDS_MAX], d[RV_BANDS_MAX];
-    if (threadIdx.x < nb) { g[threadIdx.x] = gains[b * nb + threadIdx.x]; d[threadIdx.x] = 10.f * decays[b * nb + threadIdx.x] + 1.f; }
-    __syncthreads();
-    const float inv = 1.f / ((float)nb * (float)n1), tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f;
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n1; n += gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        if (n < L) {
-            const float t = (float)n * tstep;      // torch.linspace(0, 1, L)
-            for (int k = 0; k < nb; ++k) acc = fmaf(wf[((long)r * nb + k) * n1 + n] * __expf(-d[k] * t), g[k], acc);
-        }
-        ir_pad[(long)r * n1 + n] = acc * inv;
+// ---- fused filter bank ---------------------------------------------------------------------------------------------
+// spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096.
+__global__ void fb_twiddle_kernel(f2* __restrict__ spec) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < FFT_N) {
+        double sn, cs;
+        sincospi(2.0 * (double)e / (double)FFT_N, &sn, &cs);
+        spec[e] = f2{(float)cs, (float)-sn};
     }
+}
+__global__ __launch_bounds__(FFT_T) void fb_spectrum_kernel(const float* __restrict__ filters, f2* __restrict__ spec, int taps) {
+    __shared__ f2 lds[FFT_LDS];
+    const int j = threadIdx.x, band = blockIdx.x;
+    float r[8], i[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int idx = j + 512 * q; r[q] = idx < taps ? filters[(long)band * taps + idx] : 0.f; i[q] = 0.f; }
+    const FftTw tw = fft_twiddles(j, spec);
+    fft4096<-1>(r, i, j, tw, lds);
+    constexpr float inv = 1.f / (float)FFT_N;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) spec[FFT_N + (long)band * FFT_N + j + 512 * q] = f2{r[q] * inv, -i[q] * inv};
+}
+
+// One workgroup = one (batch item b, window w): output samples n = w V + idx, idx < V = 512 VQ <= 4096 - (taps - 1).
+//   z_band[idx] = noise[b,0,band][n0 + idx] + i noise[b,1,band][n0 + idx]          (functional.py:548; both rows share the band filter)
+//   o_band     = IFFT(FFT(z_band) conj(F_band))  -> valid cross-correlations for idx < V   (:551-558)
+//   MODE 0:  ir[b,c][n] = 1/nb sum_band gain env_band(t_n) o_band                   (:561-567)
+//   MODE 1:  part[(b, w), band] = (sum_n gir o env / nb,  sum_n gir o env gain (-10 t_n) / nb),  gir = (p[n] + q[n + Lb]) * pq_scale
+template <int MODE>
+__global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const float* __restrict__ gains,
+                                                         const float* __restrict__ decays, float* __restrict__ ir_pad, const float* __restrict__ p,
+                                                         const float* __restrict__ qq, float* __restrict__ part, int nb, int L, int taps, int n1,
+                                                         int Lb, int VQ, float pq_scale) {
+    __shared__ f2 lds[FFT_LDS];
+    __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
+    const int j = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
+    const int V = VQ * 512, n0 = w * V, row_len = L + taps - 1;
+    const float tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f, inv_nb = 1.f / (float)nb;
+    const FftTw tw = fft_twiddles(j, spec);
+    const float t0 = (float)(n0 + j) * tstep, t512 = 512.f * tstep;      // t_n = n / (L - 1), torch.linspace(0, 1, L)
+    float accr[8], acci[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int n = n0 + j + 512 * q;
+        accr[q] = 0.f; acci[q] = 0.f;
+        if (MODE == 1 && q < VQ && n < L) {          // weights: gradient w.r.t. the two impulse responses of this item
+            accr[q] = (p[(long)(2 * b) * n1 + n] + qq[(long)(2 * b) * n1 + n + Lb]) * pq_scale;
+            acci[q] = (p[(long)(2 * b + 1) * n1 + n] + qq[(long)(2 * b + 1) * n1 + n + Lb]) * pq_scale;
+        }
+    }
+    for (int band = 0; band < nb; ++band) {
+        float r[8], i[8];
+        {
+            const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
+            const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = n0 + j + 512 * q;
+                r[q] = idx < row_len ? rl[idx] : 0.f;
+                i[q] = idx < row_len ? rr[idx] : 0.f;
+            }
+        }
+        fft4096<-1>(r, i, j, tw, lds);
+        const f2* F = spec + FFT_N + (long)band * FFT_N;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f2 f = F[j + 512 * q];
+            const float t = r[q] * f.x - i[q] * f.y;
+            i[q] = r[q] * f.y + i[q] * f.x;
+            r[q] = t;
+        }
+        fft4096<1>(r, i, j, tw, lds);
+        const float g = gains[b * nb + band], d = 10.f * decays[b * nb + band] + 1.f;
+        if (MODE == 0) {
+            const float gs = g * inv_nb;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float e = __expf(-d * fmaf((float)q, t512, t0)) * gs;
+                accr[q] = fmaf(e, r[q], accr[q]);
+                acci[q] = fmaf(e, i[q], acci[q]);
+            }
+        } else {
+            float sg = 0.f, sd = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float tq = fmaf((float)q, t512, t0);
+                const float e = (accr[q] * r[q] + acci[q] * i[q]) * __expf(-d * tq) * inv_nb;     // weights are zero outside the valid range
+                sg += e;
+                sd = fmaf(e, -10.f * tq * g, sd);
+            }
+            sg = wave_sum(sg); sd = wave_sum(sd);
+            if (lane_id() == 0) { red[wave_id()][band][0] = sg; red[wave_id()][band][1] = sd; }
+        }
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = n0 + j + 512 * q;
+            if (q < VQ && n < L) { ir_pad[(long)(2 * b) * n1 + n] = accr[q]; ir_pad[(long)(2 * b + 1) * n1 + n] = acci[q]; }
+        }
+    } else {
+        __syncthreads();
+        if (j < nb * 2) {
+            const int band = j >> 1, k = j & 1;
+            float a = 0.f;
+            for (int v = 0; v < FFT_T / 64; ++v) a += red[v][band][k];
+            part[(((long)b * gridDim.x + w) * nb + band) * 2 + k] = a;
+        }
+    }
+}
+
+// zero the tail [L, n1) of every impulse-response row (the head is written by fb_fused_kernel<0>)
+__global__ void zero_tail_kernel(float* __restrict__ ir_pad, int L, int n1) {
+    float* d = ir_pad + (long)blockIdx.y * n1;
+    for (int n = L + blockIdx.x * blockDim.x + threadIdx.x; n < n1; n += gridDim.x * blockDim.x) d[n] = 0.f;
 }
 
 // y[b,c,n] = (1 - mix) x + mix * (z[k][r] + z[k-1][r + Lb]) / n1      n = k Lb + r
@@ -127,42 +230,6 @@ __global__ void ir_grad_spec_kernel(const cpx* __restrict__ G, const cpx* __rest
     }
 }
 
-// g_ir[n] = (p[n] + q[n + Lb]) / n1 (adjoint of mix * conv, mix already folded into G); partial sums for gains / decays:
-// part[(r, chunk)][band][0] = sum_n g_ir wf env / nb ;  [1] = sum_n g_ir wf env gain (-10 t) / nb
-__global__ void gain_decay_grad_kernel(const float* __restrict__ p, const float* __restrict__ q, const float* __restrict__ wf,
-                                       const float* __restrict__ gains, const float* __restrict__ decays, float* __restrict__ part, int nb, int L,
-                                       int Lb, int n1) {
-    const int r = blockIdx.y, b = r >> 1;
-    __shared__ float g[RV_BANDS_MAX], d[RV_BANDS_MAX];
-    __shared__ float red[4][RV_BANDS_MAX][2];
-    if (threadIdx.x < nb) { g[threadIdx.x] = gains[b * nb + threadIdx.x]; d[threadIdx.x] = 10.f * decays[b * nb + threadIdx.x] + 1.f; }
-    __syncthreads();
-    float ag[RV_BANDS_MAX], ad[RV_BANDS_MAX];
-    for (int k = 0; k < RV_BANDS_MAX; ++k) { ag[k] = 0.f; ad[k] = 0.f; }
-    const float inv = 1.f / ((float)n1 * (float)n1 * (float)nb), tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f;
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < L; n += gridDim.x * blockDim.x) {
-        const float gir = (p[(long)r * n1 + n] + q[(long)r * n1 + n + Lb]) * inv;
-        const float t = (float)n * tstep;
-#pragma unroll
-        for (int k = 0; k < RV_BANDS_MAX; ++k) {
-            if (k < nb) {
-                const float e = gir * wf[((long)r * nb + k) * n1 + n] * __expf(-d[k] * t);
-                ag[k] += e;
-                ad[k] = fmaf(e, -10.f * t * g[k], ad[k]);
-            }
-        }
-    }
-    for (int k = 0; k < nb; ++k) {
-        const float a = wave_sum(ag[k]), c = wave_sum(ad[k]);
-        if (lane_id() == 0) { red[wave_id()][k][0] = a; red[wave_id()][k][1] = c; }
-    }
-    __syncthreads();
-    if (threadIdx.x < nb * 2) {
-        const int k = threadIdx.x >> 1, w = threadIdx.x & 1;
-        part[(((long)r * gridDim.x + blockIdx.x) * nb + k) * 2 + w] = red[0][k][w] + red[1][k][w] + red[2][k][w] + red[3][k][w];
-    }
-}
-
 // ggain, gdecay (B, nb) and gmix (B) from the per-block partial sums, in fp64
 __global__ void reverb_finalize_kernel(const float* __restrict__ part, const float* __restrict__ mix_part, float* __restrict__ ggain,
                                        float* __restrict__ gdecay, float* __restrict__ gmix, int B, int nb, int chunks, int mix_chunks) {
@@ -170,11 +237,10 @@ __global__ void reverb_finalize_kernel(const float* __restrict__ part, const flo
     if (i < B * nb) {
         const int b = i / nb, k = i % nb;
         double a = 0.0, c = 0.0;
-        for (int ch = 0; ch < 2; ++ch)
-            for (int j = 0; j < chunks; ++j) {
-                const float* p = part + ((((long)(b * 2 + ch)) * chunks + j) * nb + k) * 2;
-                a += (double)p[0]; c += (double)p[1];
-            }
+        for (int j = 0; j < chunks; ++j) {
+            const float* p = part + (((long)b * chunks + j) * nb + k) * 2;
+            a += (double)p[0]; c += (double)p[1];
+        }
         ggain[i] = (float)a; gdecay[i] = (float)c;
     }
     if (i < B) {
@@ -237,7 +303,7 @@ inline int rv_check() {
     return e == hipSuccess ? DASP_OK : (int)e;
 }
 inline long next_pow2(long v) { long p = 1; while (p < v) p <<= 1; return p; }
-struct RvDims { int Lb, n1, nfreq, nblk; long R; };
+struct RvDims { int Lb, n1, nfreq, nblk, VQ, nwin; long R; };
 inline RvDims rv_dims(int B, long N, int L, int taps) {
     RvDims d;
     d.Lb = (int)next_pow2(L > taps ? L : taps);
@@ -245,6 +311,9 @@ inline RvDims rv_dims(int B, long N, int L, int taps) {
     d.nfreq = d.n1 / 2 + 1;
     d.nblk = (int)((N + d.Lb - 1) / d.Lb);
     d.R = 2L * B;
+    d.VQ = (FFT_N - (taps - 1)) / 512;          // valid outputs per filter-bank window = 512 VQ (0: filters too long for the window)
+    if (d.VQ < 0) d.VQ = 0;
+    d.nwin = d.VQ ? (L + 512 * d.VQ - 1) / (512 * d.VQ) : 0;
     return d;
 }
 constexpr int RV_T = 256;
@@ -275,53 +344,48 @@ int dasp_fft_init(const char* libhipfft_path) {
 int dasp_fft_ready(void) { return g_fft.handle != nullptr; }
 
 /* sizes[0] = Lb (block length), [1] = n1 (FFT length), [2] = nfreq, [3] = nblk,
- * [4] = floats of wf (noise filter bank output, 2B*nb rows of n1), [5] = complex elements of the noise spectrum scratch,
+ * [4] = complex elements of Fspec (twiddles + band spectra of the filter bank), [5] = filter-bank windows per batch item,
  * [6] = floats of z / xpad (2B*nblk rows of n1), [7] = complex elements of Xf (2B*nblk rows of nfreq),
  * [8] = floats of ir_pad (2B rows of n1), [9] = complex elements of H (2B rows of nfreq),
- * [10] = mix partial chunks per signal, [11] = gain/decay partial chunks per signal */
+ * [10] = mix partial chunks per signal, [11] = floats of the gain/decay partial sums */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!sizes || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX) return DASP_ERR_ARG;
     const RvDims d = rv_dims(B, N, L, taps);
+    if (d.VQ < 1) return DASP_ERR_UNSUPPORTED;      // filters longer than 3585 taps do not fit the 4096-point window
     sizes[0] = d.Lb; sizes[1] = d.n1; sizes[2] = d.nfreq; sizes[3] = d.nblk;
-    sizes[4] = d.R * nb * d.n1; sizes[5] = d.R * nb * d.nfreq;
+    sizes[4] = (long)(nb + 1) * FFT_N; sizes[5] = d.nwin;
     sizes[6] = d.R * d.nblk * d.n1; sizes[7] = d.R * d.nblk * d.nfreq;
     sizes[8] = d.R * d.n1; sizes[9] = d.R * d.nfreq;
-    sizes[10] = 64; sizes[11] = 16;
+    sizes[10] = 64; sizes[11] = (long)B * d.nwin * nb * 2;
     return DASP_OK;
 }
 
-/* filters (nb, taps) fp32 -> Fspec (nb, nfreq) complex spectra of the zero-padded filters; fpad scratch (nb, n1) floats */
-int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, int n1, float* fpad, void* Fspec, void* stream) {
-    if (!filters || !fpad || !Fspec || nb <= 0 || taps <= 0 || n1 < taps) return DASP_ERR_ARG;
-    hipLaunchKernelGGL(pad_rows_kernel, rv_grid(n1, nb), dim3(RV_T), 0, (hipStream_t)stream, filters, fpad, (long)nb, n1, 0, (long)taps, taps, 0L, 0, 1,
-                       (const float*)nullptr);
-    RV_TRY(rv_check());
-    return fft_r2c(n1, nb, fpad, (cpx*)Fspec, (hipStream_t)stream);
+/* filters (nb, taps) fp32 -> Fspec (sizes[4] complex): the 4096-point twiddle table followed by conj(FFT(filter)) / 4096 per band */
+int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream) {
+    if (!filters || !Fspec || nb <= 0 || nb > RV_BANDS_MAX || taps <= 0) return DASP_ERR_ARG;
+    if (taps - 1 > FFT_N - 512) return DASP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fb_twiddle_kernel, dim3(FFT_N / 256), dim3(256), 0, (hipStream_t)stream, (f2*)Fspec);
+    hipLaunchKernelGGL(fb_spectrum_kernel, dim3(nb), dim3(FFT_T), 0, (hipStream_t)stream, filters, (f2*)Fspec, taps);
+    return rv_check();
 }
 
-/* Forward.  x (B,2,N); noise (2B, nb, L+taps-1); Fspec (nb, nfreq); gains, decays (B, nb); mix (B); y (B,2,N).
- * Saved for backward: wf (sizes[4] floats), Xf (sizes[7] complex), H (sizes[9] complex), z (sizes[6] floats).
- * Scratch: nspec (sizes[5] complex), yspec (sizes[7] complex), ir_pad (sizes[8] floats). */
+/* Forward.  x (B,2,N); noise (2B, nb, L+taps-1); Fspec (sizes[4] complex); gains, decays (B, nb); mix (B); y (B,2,N).
+ * Saved for backward: Xf (sizes[7] complex), H (sizes[9] complex), z (sizes[6] floats) (and the caller's noise, Fspec).
+ * Scratch: yspec (sizes[7] complex), ir_pad (sizes[8] floats). */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays, const float* mix,
-                        float* y, float* wf, void* Xf, void* H, float* z, void* nspec, void* yspec, float* ir_pad, int B, long N, int L,
-                        int taps, int nb, void* stream) {
-    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || !wf || !Xf || !H || !z || !nspec || !yspec || !ir_pad || B <= 0 ||
-        N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
+                        float* y, void* Xf, void* H, float* z, void* yspec, float* ir_pad, int B, long N, int L, int taps, int nb,
+                        void* stream) {
+    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || !Xf || !H || !z || !yspec || !ir_pad || B <= 0 || N <= 0 || L <= 0 ||
+        taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     const RvDims d = rv_dims(B, N, L, taps);
     hipStream_t st = (hipStream_t)stream;
-    const long nrows = d.R * nb, xrows = d.R * d.nblk;
-    if (nrows > 65535 || xrows > 65535) return DASP_ERR_UNSUPPORTED;
-    // 1. filter bank: correlation of every noise row with its band filter (functional.py:551-558)
-    hipLaunchKernelGGL(pad_rows_kernel, rv_grid(d.n1, nrows), dim3(RV_T), 0, st, noise, wf, nrows, d.n1, 0, (long)(L + taps - 1), L + taps - 1, 0L, 0, 1,
-                       (const float*)nullptr);
-    RV_TRY(rv_check());
-    RV_TRY(fft_r2c(d.n1, nrows, wf, (cpx*)nspec, st));
-    hipLaunchKernelGGL(cmul_rows_kernel, rv_grid(d.nfreq, nrows), dim3(RV_T), 0, st, (const cpx*)nspec, (const cpx*)Fspec, (cpx*)nspec, d.nfreq, 1, nb, 1);
-    RV_TRY(rv_check());
-    RV_TRY(fft_c2r(d.n1, nrows, (cpx*)nspec, wf, st));
-    // 2. envelope, gains, mean over bands -> zero-padded impulse responses (:561-567) and their spectra
-    hipLaunchKernelGGL(ir_shape_kernel, rv_grid(d.n1, d.R), dim3(RV_T), 0, st, wf, gains, decays, ir_pad, nb, L, d.n1);
+    const long xrows = d.R * d.nblk;
+    if (d.VQ < 1 || B > 65535 || xrows > 65535) return DASP_ERR_UNSUPPORTED;
+    // 1 + 2. filter bank, envelope, gains, mean over bands -> zero-padded impulse responses (functional.py:551-567), then their spectra
+    hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, (const f2*)Fspec, gains, decays, ir_pad,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, nb, L, taps, d.n1, d.Lb, d.VQ, 0.f);
+    hipLaunchKernelGGL(zero_tail_kernel, rv_grid(d.n1 - L, d.R), dim3(RV_T), 0, st, ir_pad, L, d.n1);
     RV_TRY(rv_check());
     RV_TRY(fft_r2c(d.n1, d.R, ir_pad, (cpx*)H, st));
     // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
@@ -337,18 +401,18 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
 
 /* Backward.  gx (B,2,N); ggain, gdecay (B, nb); gmix (B).
  * Scratch: gpad / cc (sizes[6] floats), Gf (sizes[7] complex), cspec (sizes[7] complex), PQ (2 * sizes[9] complex),
- * pq (2 * sizes[8] floats), part (2B * sizes[11] * nb * 2 floats), mix_part (2B * sizes[10] floats). */
-int dasp_reverb_backward(const float* x, const float* gy, const float* gains, const float* decays, const float* mix, const float* wf,
-                         const void* Xf, const void* H, const float* z, float* gx, float* ggain, float* gdecay, float* gmix, float* gpad,
-                         void* Gf, void* cspec, void* PQ, float* pq, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
-                         void* stream) {
-    if (!x || !gy || !gains || !decays || !mix || !wf || !Xf || !H || !z || !gx || !ggain || !gdecay || !gmix || !gpad || !Gf || !cspec ||
-        !PQ || !pq || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
+ * pq (2 * sizes[8] floats), part (sizes[11] floats), mix_part (2B * sizes[10] floats). */
+int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
+                         const float* mix, const void* Xf, const void* H, const float* z, float* gx, float* ggain, float* gdecay, float* gmix,
+                         float* gpad, void* Gf, void* cspec, void* PQ, float* pq, float* part, float* mix_part, int B, long N, int L, int taps,
+                         int nb, void* stream) {
+    if (!x || !gy || !noise || !Fspec || !gains || !decays || !mix || !Xf || !H || !z || !gx || !ggain || !gdecay || !gmix || !gpad || !Gf ||
+        !cspec || !PQ || !pq || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     const RvDims d = rv_dims(B, N, L, taps);
     hipStream_t st = (hipStream_t)stream;
     const long xrows = d.R * d.nblk;
-    if (xrows > 65535) return DASP_ERR_UNSUPPORTED;
+    if (d.VQ < 1 || B > 65535 || xrows > 65535) return DASP_ERR_UNSUPPORTED;
     // blocks of mix * gy and their spectra
     hipLaunchKernelGGL(pad_rows_kernel, rv_grid(d.n1, xrows), dim3(RV_T), 0, st, gy, gpad, xrows, d.n1, 1, 0L, 0, N, d.Lb, d.nblk, mix);
     RV_TRY(rv_check());
@@ -358,7 +422,9 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* gains, co
     hipLaunchKernelGGL(ir_grad_spec_kernel, rv_grid(d.nfreq, d.R), dim3(RV_T), 0, st, (const cpx*)Gf, (const cpx*)Xf, P, Q, d.nfreq, d.nblk);
     RV_TRY(rv_check());
     RV_TRY(fft_c2r(d.n1, 2 * d.R, P, pq, st));
-    hipLaunchKernelGGL(gain_decay_grad_kernel, dim3(16, (unsigned)d.R), dim3(RV_T), 0, st, pq, pq + d.R * d.n1, wf, gains, decays, part, nb, L, d.Lb, d.n1);
+    // d/dgain, d/ddecay: the filter bank again, weighted by g_ir = (p[n] + q[n + Lb]) / n1 (mix is already folded into G)
+    hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, (const f2*)Fspec, gains, decays,
+                       (float*)nullptr, pq, pq + d.R * d.n1, part, nb, L, taps, d.n1, d.Lb, d.VQ, 1.f / (float)d.n1);
     RV_TRY(rv_check());
     // d/dx: correlation with the impulse response
     hipLaunchKernelGGL(cmul_rows_kernel, rv_grid(d.nfreq, xrows), dim3(RV_T), 0, st, (const cpx*)Gf, (const cpx*)H, (cpx*)cspec, d.nfreq, d.nblk, (int)d.R, 1);
@@ -367,7 +433,7 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* gains, co
     hipLaunchKernelGGL(bwd_combine_kernel, dim3(64, (unsigned)d.R), dim3(RV_T), 0, st, x, gy, z, gpad, mix, gx, mix_part, N, d.Lb, d.nblk, d.n1);
     RV_TRY(rv_check());
     const int nfin = B * nb > B ? B * nb : B;
-    hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, 16, 64);
+    hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin, 64);
     return rv_check();
 }
 

@@ -256,30 +256,26 @@ class ReverbFunction(torch.autograd.Function):
         dev = x.device
         sizes = (ctypes.c_long * 12)()
         check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
-        n1 = sizes[1]
         x32, n32 = _f32c(x), _f32c(noise)
         g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
-        f32_ = _f32c(filters)
-        fpad = torch.empty(nb * n1, dtype=torch.float32, device=dev)
-        Fspec = _cbuf(nb * sizes[2], dev)
-        call("dasp_reverb_filter_spectrum", ptr(f32_), nb, taps, n1, ptr(fpad), ptr(Fspec), stream())
+        Fspec = _cbuf(sizes[4], dev)
+        call("dasp_reverb_filter_spectrum", ptr(_f32c(filters)), nb, taps, ptr(Fspec), stream())
         y = torch.empty_like(x32)
-        wf = torch.empty(sizes[4], dtype=torch.float32, device=dev)
         Xf, H = _cbuf(sizes[7], dev), _cbuf(sizes[9], dev)
         z = torch.empty(sizes[6], dtype=torch.float32, device=dev)
-        nspec, yspec = _cbuf(sizes[5], dev), _cbuf(sizes[7], dev)
+        yspec = _cbuf(sizes[7], dev)
         ir_pad = torch.empty(sizes[8], dtype=torch.float32, device=dev)
-        call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(wf), ptr(Xf), ptr(H),
-             ptr(z), ptr(nspec), ptr(yspec), ptr(ir_pad), B, N, L_ir, taps, nb, stream())
+        call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(Xf), ptr(H),
+             ptr(z), ptr(yspec), ptr(ir_pad), B, N, L_ir, taps, nb, stream())
         if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x32, g32, d32, m32, wf, Xf, H, z)
+            ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, Xf, H, z)
             ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
             ctx.meta = (x.dtype, gains.dtype, gains.shape, decays.dtype, decays.shape, mix.dtype, mix.shape)
         return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
-        x32, g32, d32, m32, wf, Xf, H, z = ctx.saved_tensors
+        x32, n32, Fspec, g32, d32, m32, Xf, H, z = ctx.saved_tensors
         B, N, L_ir, taps, nb, sizes = ctx.cfg
         dev = x32.device
         gx = torch.empty_like(x32)
@@ -290,10 +286,10 @@ class ReverbFunction(torch.autograd.Function):
         Gf, cspec = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
         PQ = _cbuf(2 * sizes[9], dev)
         pq = torch.empty(2 * sizes[8], dtype=torch.float32, device=dev)
-        part = torch.empty(2 * B * sizes[11] * nb * 2, dtype=torch.float32, device=dev)
+        part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
         mix_part = torch.empty(2 * B * sizes[10], dtype=torch.float32, device=dev)
-        call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(g32), ptr(d32), ptr(m32), ptr(wf), ptr(Xf), ptr(H), ptr(z), ptr(gx),
-             ptr(ggain), ptr(gdecay), ptr(gmix), ptr(gpad), ptr(Gf), ptr(cspec), ptr(PQ), ptr(pq), ptr(part), ptr(mix_part),
+        call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(Xf), ptr(H), ptr(z),
+             ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(gpad), ptr(Gf), ptr(cspec), ptr(PQ), ptr(pq), ptr(part), ptr(mix_part),
              B, N, L_ir, taps, nb, stream())
         xd, gd, gs, dd, ds, md, ms = ctx.meta
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None
