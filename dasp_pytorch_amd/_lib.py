@@ -40,12 +40,10 @@ SIGNATURES = {
     "dasp_dyn_partial_floats": (_l, [_l]),
     "dasp_dynamics_forward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
     "dasp_dynamics_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
-    "dasp_fft_init": (_i, [ctypes.c_char_p]),
-    "dasp_fft_ready": (_i, []),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
-    "dasp_reverb_forward": (_i, [_p] * 12 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_backward": (_i, [_p] * 21 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_backward": (_i, [_p] * 20 + [_i, _l, _i, _i, _i, _p]),
 }
 
 
@@ -69,14 +67,6 @@ def lib():
         _lib = L
     return _lib
 
-
-def ensure_fft():
-    """Bind hipFFT inside libdasp_hip.so to the copy torch ships (one FFT library per process)."""
-    L = lib()
-    if not L.dasp_fft_ready():
-        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libhipfft.so")
-        path = cand if os.path.exists(cand) else "libhipfft.so"
-        check(L.dasp_fft_init(path.encode()), f"dasp_fft_init({path})")
 
 
 def check(status, what):

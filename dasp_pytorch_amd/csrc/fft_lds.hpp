@@ -1,10 +1,11 @@
-// Workgroup-level complex FFT of 4096 points held in registers + LDS (gfx950): 512 threads, 8 elements per thread,
-// four radix-8 Stockham passes with three LDS exchanges. Element `idx = j + 512 q` lives in register q of thread j
-// both before and after a transform (natural order in, natural order out), so a forward transform, a pointwise
-// product and the inverse transform chain through registers without touching LDS in between.
-//
-// Used by the reverb's filter bank (reverb.hip), where it replaces three batched rocFFT passes over 2B*12 noise
-// rows (dasp_pytorch/functional.py:548-558) with one fused kernel.
+// Complex FFTs held in registers + LDS (gfx950), 8 elements per thread, radix-8 Stockham passes with LDS exchanges in
+// between. Element `idx = j + T q` (T = length / 8) lives in register q of thread j both before and after a transform
+// (natural order in, natural order out), so a forward transform, a pointwise product and the inverse transform chain
+// through registers without touching LDS in between. Three shapes, all used by reverb.hip:
+//   fft4096      one 4096-point transform per 512-thread workgroup            (filter bank, functional.py:548-558)
+//   fft512_wave  one 512-point transform per wave, no workgroup barriers      (row pass of the four-step long FFT)
+//   col_fft      4096 / P transforms of P = 8..4096 points side by side in a 512-thread workgroup, radix-8 passes plus
+//                one radix-2/4 pass                                           (column pass of the four-step long FFT)
 #pragma once
 #include "common.hpp"
 
@@ -124,6 +125,109 @@ __device__ __forceinline__ void fft4096(float (&r)[8], float (&i)[8], int j, con
     fft_exchange(r, i, lds, (j >> 6) * 576 + (j & 63) + ((j & 63) >> 3), 72, rb);
     twiddle8<DIR>(r, i, tw.s3);                                            // Ns = 512
     radix8<DIR>(r, i);
+}
+
+// ---- 512-point transform held by one wave --------------------------------------------------------------------------
+constexpr int FFT512_LDS = 512 + 64;          // padded float2 elements per wave
+struct Fft512Tw { Tw8 s1, s2; };
+__device__ __forceinline__ Fft512Tw fft512_twiddles(int j, const f2* __restrict__ tw) {      // j = lane, tw = 4096-entry table
+    Fft512Tw t;
+    t.s1 = tw_powers(tw[(j & 7) * 64]);       // Ns = 8: w_512^(8 (j % 8))
+    t.s2 = tw_powers(tw[j * 8]);              // Ns = 64: w_512^j
+    return t;
+}
+__device__ __forceinline__ void wave_exchange(float (&r)[8], float (&i)[8], f2* lds, int wbase, int wstride, int rbase) {
+    wave_lds_sync();
+    f2* wp = lds + wbase;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wp[q * wstride] = f2{r[q], i[q]};
+    wave_lds_sync();
+    const f2* rp = lds + rbase;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f2 v = rp[q * 72]; r[q] = v.x; i[q] = v.y; }
+}
+template <int DIR>
+__device__ __forceinline__ void fft512_wave(float (&r)[8], float (&i)[8], int j, const Fft512Tw& tw, f2* lds) {
+    const int rb = j + (j >> 3);              // fft_pad(j + 64 q) = rb + 72 q
+    radix8<DIR>(r, i);
+    wave_exchange(r, i, lds, 9 * j, 1, rb);
+    twiddle8<DIR>(r, i, tw.s1);
+    radix8<DIR>(r, i);
+    wave_exchange(r, i, lds, (j >> 3) * 72 + (j & 7), 9, rb);
+    twiddle8<DIR>(r, i, tw.s2);
+    radix8<DIR>(r, i);
+}
+
+// ---- TC = 4096 / P transforms of P points side by side (batch index fastest in LDS and across lanes) ---------------
+struct ColCfg { int P, logP, T, TC, j, c; };      // thread (j, c): transform c, elements j + T q
+__device__ __forceinline__ ColCfg col_config(int logP, int t) {
+    ColCfg g;
+    g.logP = logP; g.P = 1 << logP; g.T = g.P >> 3; g.TC = FFT_N >> logP;
+    g.c = t & (g.TC - 1); g.j = t >> (12 - logP);
+    return g;
+}
+struct ColTw { Tw8 p1, p2, p3; float fr[6], fi[6]; };
+__device__ __forceinline__ ColTw col_twiddles(const ColCfg& g, const f2* __restrict__ tw) {
+    ColTw t;
+    const int mul = FFT_N >> g.logP;               // w_P^e = tw[e * mul]
+    t.p1 = tw_powers(tw[g.P >= 64 ? ((g.j & 7) * (g.P >> 6)) * mul : 0]);
+    t.p2 = tw_powers(tw[g.P >= 512 ? ((g.j & 63) * (g.P >> 9)) * mul : 0]);
+    t.p3 = tw_powers(tw[g.P >= 4096 ? (g.j & 511) * mul : 0]);
+    const int a = g.logP / 3, R = g.P >> (3 * a);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int e = 0;
+        if (R == 4) e = ((g.j + g.T * (k / 3)) * (k % 3 + 1)) & (g.P - 1);      // butterfly m = k / 3, input r = k % 3 + 1
+        else if (R == 2 && k < 4) e = g.j + g.T * k;                              // butterfly m = k, input r = 1
+        const f2 w = tw[e * mul];
+        t.fr[k] = w.x; t.fi[k] = w.y;
+    }
+    return t;
+}
+__device__ __forceinline__ void col_exchange(float (&r)[8], float (&i)[8], f2* lds, const ColCfg& g, int wbase, int Ns) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds[fft_pad(wbase + q * Ns) * g.TC + g.c] = f2{r[q], i[q]};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f2 v = lds[fft_pad(g.j + q * g.T) * g.TC + g.c]; r[q] = v.x; i[q] = v.y; }
+}
+template <int DIR> __device__ __forceinline__ void cmul_dir(float& re, float& im, float wr, float wi) {
+    const float t = DIR < 0 ? re * wr - im * wi : re * wr + im * wi;
+    im = DIR < 0 ? re * wi + im * wr : im * wr - re * wi;
+    re = t;
+}
+template <int DIR>
+__device__ __forceinline__ void col_fft(float (&r)[8], float (&i)[8], const ColCfg& g, const ColTw& tw, f2* lds) {
+    const int a = g.logP / 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < a) {                                   // workgroup-uniform
+            if (k == 1) twiddle8<DIR>(r, i, tw.p1);
+            if (k == 2) twiddle8<DIR>(r, i, tw.p2);
+            if (k == 3) twiddle8<DIR>(r, i, tw.p3);
+            radix8<DIR>(r, i);
+            const int Ns = 1 << (3 * k);
+            if (Ns * 8 < g.P) col_exchange(r, i, lds, g, ((g.j >> (3 * k)) << (3 * k + 3)) + (g.j & (Ns - 1)), Ns);
+        }
+    }
+    const int R = g.P >> (3 * a);
+    if (R == 4) {                                      // two radix-4 butterflies on registers (m, m+2, m+4, m+6)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) cmul_dir<DIR>(r[m + 2 * k], i[m + 2 * k], tw.fr[m * 3 + k - 1], tw.fi[m * 3 + k - 1]);
+            dft4<DIR>(r[m], i[m], r[m + 2], i[m + 2], r[m + 4], i[m + 4], r[m + 6], i[m + 6]);
+        }
+    } else if (R == 2) {                               // four radix-2 butterflies on registers (m, m+4)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cmul_dir<DIR>(r[m + 4], i[m + 4], tw.fr[m], tw.fi[m]);
+            const float ar = r[m], ai = i[m];
+            r[m] = ar + r[m + 4]; i[m] = ai + i[m + 4];
+            r[m + 4] = ar - r[m + 4]; i[m + 4] = ai - i[m + 4];
+        }
+    }
 }
 
 }  // namespace dasp

@@ -1,64 +1,38 @@
-// Noise-shaped reverberation: shaped-noise impulse response + long convolution, forward and adjoint,
-// as batched real FFTs (hipFFT/rocFFT) with fused spectral-multiply, overlap-add and reduction kernels.
+// Noise-shaped reverberation: shaped-noise impulse response + long convolution, forward and adjoint, entirely on the
+// library's own register/LDS FFTs (fft_lds.hpp) - no FFT library, no real-to-complex post-processing passes.
 //
 // Replaces dasp_pytorch.functional.noise_shaped_reverberation (dasp_pytorch/functional.py:406-577):
 //   wn_filt = grouped 1023-tap FIR of white noise, 12 bands          (:548-558, direct conv1d)
 //   ir      = mean_band(wn_filt * exp(-(10 decay + 1) t) * gain)     (:561-567)
 //   y_wet   = causal convolution of x with ir, truncated to N        (:570-572, direct conv1d, 65536 taps)
 //   y       = (1 - mix) x + mix y_wet                                (:575)
-// The reference's direct convolutions are 99.6 % of its time. Here both are
-// frequency-domain products. The filter bank (short filters, 2B*12 independent noise rows) is ONE fused kernel:
-// overlap-save windows of 4096 samples, the left/right rows of an item packed as one complex signal, forward FFT,
-// product with the band's spectrum and inverse FFT inside the workgroup (fft_lds.hpp), envelope / gain / band mean
-// applied to the result in registers - the filtered noise never exists in HBM (the backward pass re-runs the same
-// kernel with the impulse-response gradient as a weight instead of saving it). The 65536-tap convolution is
-// overlap-add over blocks of Lb samples with n1 = 2 Lb point FFTs (hipFFT/rocFFT).
+// The reference's direct convolutions are 99.6 % of its time. Here both are frequency-domain products.
 //
-// The FFT library is bound at run time (dasp_fft_init dlopens the libhipfft the host process
-// already uses, so a process never holds two copies); plans are cached per (length, batch).
+// Filter bank (short filters, 2B*12 independent noise rows): ONE fused kernel - overlap-save windows of 4096 samples,
+// the left/right rows of an item packed as one complex signal, forward FFT, product with the band's spectrum and
+// inverse FFT inside the workgroup, envelope / gain / band mean applied in registers. The filtered noise never exists
+// in HBM; the backward pass re-runs the kernel with d loss / d ir as a weight instead of saving it.
+//
+// Long convolution (L taps, L up to 2^20): overlap-add over blocks of Lb = nextpow2(L) samples, n1 = 2 Lb-point complex
+// transforms of PAIRS of consecutive blocks of one signal (block 2p real, block 2p+1 imaginary; both meet the same real
+// impulse response, so one complex product serves both and no Hermitian split is ever needed). Each transform is a
+// four-step FFT n1 = NA x 512 (time index = ja * 512 + jb, frequency index = ka + NA * kb) in three kernels:
+//   conv_load_kernel   column transforms over ja (col_fft), input gathered from the signal        -> A[ka][jb]
+//   conv_rows_kernel   per row ka (one wave each): twiddle, 512-point transform, product with the stored spectrum,
+//                      inverse transform, conjugate twiddle - spectra stay in the permuted [ka][kb] order, which
+//                      pointwise products do not care about, so there is no transpose anywhere
+//   conv_cols_kernel   inverse column transforms, fused with overlap-add + wet/dry mix (forward; the workgroup walks
+//                      the pairs of its signal and carries the overlap in registers), or with the gx / mix-gradient
+//                      epilogue, or with the extraction of d loss / d ir (backward)
+// Backward uses overlapped (not zero-padded) windows of mix * gy: gx_k = first half of IFFT(GW_k conj(H)) and
+// d ir = first half of IFFT(sum_k GW_k conj(X_k)), with X_k recomputed from the saved column transforms A.
 #include "common.hpp"
 #include "fft_lds.hpp"
-#include <dlfcn.h>
-#include <hipfft/hipfft.h>
-#include <map>
-#include <mutex>
 
 namespace dasp {
 
 constexpr int RV_BANDS_MAX = 16;
-typedef float2 cpx;
-
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cpx cmulc(cpx a, cpx b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
-
-// dst[row][i] = i < len(row) ? scale(row) * src[off(row) + i] : 0     rows of n1 floats
-//   mode 0: plain rows           off = row * src_stride, len = src_len
-//   mode 1: signal blocks        row = (sig * nblk + k): off = sig * N + k * Lb, len = min(Lb, N - k Lb); scale = sc[sig / 2] or 1
-__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int n1, int mode, long src_stride,
-                                int src_len, long N, int Lb, int nblk, const float* __restrict__ sc) {
-    const long row = blockIdx.y;
-    long off; int len; float s = 1.f;
-    if (mode == 0) { off = row * src_stride; len = src_len; }
-    else {
-        const long sig = row / nblk; const int k = (int)(row % nblk);
-        off = sig * N + (long)k * Lb;
-        const long rem = N - (long)k * Lb;
-        len = rem < Lb ? (int)(rem > 0 ? rem : 0) : Lb;
-        if (sc) s = sc[sig / 2];
-    }
-    float* d = dst + row * (long)n1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) d[i] = i < len ? s * src[off + i] : 0.f;
-}
-
-// out[row][f] = A[row][f] * (conj?) Bs[(row / div) % mod][f]
-__global__ void cmul_rows_kernel(const cpx* __restrict__ A, const cpx* __restrict__ Bs, cpx* __restrict__ out, int nfreq, int div, int mod,
-                                 int conjB) {
-    const long row = blockIdx.y;
-    const cpx* a = A + row * (long)nfreq;
-    const cpx* b = Bs + ((row / div) % mod) * (long)nfreq;
-    cpx* o = out + row * (long)nfreq;
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nfreq; f += gridDim.x * blockDim.x) o[f] = conjB ? cmulc(a[f], b[f]) : cmul(a[f], b[f]);
-}
+constexpr int CV_NB = 512;                // row length of the four-step split
 
 // ---- fused filter bank ---------------------------------------------------------------------------------------------
 // spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096.
@@ -87,12 +61,11 @@ __global__ __launch_bounds__(FFT_T) void fb_spectrum_kernel(const float* __restr
 //   z_band[idx] = noise[b,0,band][n0 + idx] + i noise[b,1,band][n0 + idx]          (functional.py:548; both rows share the band filter)
 //   o_band     = IFFT(FFT(z_band) conj(F_band))  -> valid cross-correlations for idx < V   (:551-558)
 //   MODE 0:  ir[b,c][n] = 1/nb sum_band gain env_band(t_n) o_band                   (:561-567)
-//   MODE 1:  part[(b, w), band] = (sum_n gir o env / nb,  sum_n gir o env gain (-10 t_n) / nb),  gir = (p[n] + q[n + Lb]) * pq_scale
+//   MODE 1:  part[(b, w), band] = (sum_n gir o env / nb,  sum_n gir o env gain (-10 t_n) / nb),  gir (2B, L) = d loss / d ir
 template <int MODE>
 __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const float* __restrict__ gains,
-                                                         const float* __restrict__ decays, float* __restrict__ ir_pad, const float* __restrict__ p,
-                                                         const float* __restrict__ qq, float* __restrict__ part, int nb, int L, int taps, int n1,
-                                                         int Lb, int VQ, float pq_scale) {
+                                                         const float* __restrict__ decays, float* __restrict__ ir, const float* __restrict__ gir,
+                                                         float* __restrict__ part, int nb, int L, int taps, int VQ) {
     __shared__ f2 lds[FFT_LDS];
     __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
     const int j = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
@@ -106,8 +79,8 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
         const int n = n0 + j + 512 * q;
         accr[q] = 0.f; acci[q] = 0.f;
         if (MODE == 1 && q < VQ && n < L) {          // weights: gradient w.r.t. the two impulse responses of this item
-            accr[q] = (p[(long)(2 * b) * n1 + n] + qq[(long)(2 * b) * n1 + n + Lb]) * pq_scale;
-            acci[q] = (p[(long)(2 * b + 1) * n1 + n] + qq[(long)(2 * b + 1) * n1 + n + Lb]) * pq_scale;
+            accr[q] = gir[(long)(2 * b) * L + n];
+            acci[q] = gir[(long)(2 * b + 1) * L + n];
         }
     }
     for (int band = 0; band < nb; ++band) {
@@ -158,7 +131,7 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = n0 + j + 512 * q;
-            if (q < VQ && n < L) { ir_pad[(long)(2 * b) * n1 + n] = accr[q]; ir_pad[(long)(2 * b + 1) * n1 + n] = acci[q]; }
+            if (q < VQ && n < L) { ir[(long)(2 * b) * L + n] = accr[q]; ir[(long)(2 * b + 1) * L + n] = acci[q]; }
         }
     } else {
         __syncthreads();
@@ -171,64 +144,184 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
     }
 }
 
-// zero the tail [L, n1) of every impulse-response row (the head is written by fb_fused_kernel<0>)
-__global__ void zero_tail_kernel(float* __restrict__ ir_pad, int L, int n1) {
-    float* d = ir_pad + (long)blockIdx.y * n1;
-    for (int n = L + blockIdx.x * blockDim.x + threadIdx.x; n < n1; n += gridDim.x * blockDim.x) d[n] = 0.f;
+// ---- long convolution ----------------------------------------------------------------------------------------------
+struct ConvDims { int logNA, NA, n1, Lb, npairs; long N; };
+
+// forward twiddle w_n1^(ka (j + 64 q)), q = 0..7, as a chain from two accurate sincospi evaluations
+__device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (&wr)[8], float (&wi)[8]) {
+    const float inv = 2.f / (float)n1;        // exact: n1 is a power of two and the reduced exponents are below 2^24
+    float s0, c0, s1, c1;
+    sincospif(-(float)((ka * j) & (n1 - 1)) * inv, &s0, &c0);
+    sincospif(-(float)((ka * 64) & (n1 - 1)) * inv, &s1, &c1);
+    wr[0] = c0; wi[0] = s0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { wr[q] = wr[q - 1] * c1 - wi[q - 1] * s1; wi[q] = wr[q - 1] * s1 + wi[q - 1] * c1; }
 }
 
-// y[b,c,n] = (1 - mix) x + mix * (z[k][r] + z[k-1][r + Lb]) / n1      n = k Lb + r
-__global__ void ola_mix_kernel(const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ mix, float* __restrict__ y,
-                               long N, int Lb, int nblk, int n1) {
-    const long sig = blockIdx.y;
-    const float m = mix[sig >> 1], inv = 1.f / (float)n1;
-    for (long n = blockIdx.x * (long)blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(n / Lb), r = (int)(n - (long)k * Lb);
-        float wet = z[(sig * nblk + k) * (long)n1 + r];
-        if (k > 0) wet += z[(sig * nblk + k - 1) * (long)n1 + r + Lb];
-        const float xv = x[sig * N + n];
-        y[sig * N + n] = fmaf(m, wet * inv - xv, xv);
-    }
-}
-
-// gx[b,c,n] = (1 - mix) gy + (c_k[r] + c_{k+1}[r + Lb]) / n1 ;  also partial sums of gy * (y_wet - x) for d/dmix
-__global__ void bwd_combine_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ z, const float* __restrict__ cc,
-                                   const float* __restrict__ mix, float* __restrict__ gx, float* __restrict__ mix_part, long N, int Lb, int nblk,
-                                   int n1) {
-    const long sig = blockIdx.y;
-    const float m = mix[sig >> 1], inv = 1.f / (float)n1;
-    float acc = 0.f;
-    for (long n = blockIdx.x * (long)blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(n / Lb), r = (int)(n - (long)k * Lb);
-        float wet = z[(sig * nblk + k) * (long)n1 + r];
-        if (k > 0) wet += z[(sig * nblk + k - 1) * (long)n1 + r + Lb];
-        float c = cc[(sig * nblk + k) * (long)n1 + r];
-        if (k + 1 < nblk) c += cc[(sig * nblk + k + 1) * (long)n1 + r + Lb];
-        const float g = gy[sig * N + n], xv = x[sig * N + n];
-        gx[sig * N + n] = fmaf(1.f - m, g, c * inv);     // cc already carries the factor mix (it is the adjoint of mix * gy)
-        acc = fmaf(g, wet * inv - xv, acc);
-    }
-    __shared__ float red[4];
-    const float w = wave_sum(acc);
-    if (lane_id() == 0) red[wave_id()] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) mix_part[sig * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// P[sig][f] = sum_k G[k][f] conj(X[k][f]) ;  Q[sig][f] = sum_{k>=1} G[k][f] conj(X[k-1][f])
-__global__ void ir_grad_spec_kernel(const cpx* __restrict__ G, const cpx* __restrict__ X, cpx* __restrict__ P, cpx* __restrict__ Q, int nfreq, int nblk) {
-    const long sig = blockIdx.y;
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nfreq; f += gridDim.x * blockDim.x) {
-        cpx p = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
-        for (int k = 0; k < nblk; ++k) {
-            const cpx g = G[(sig * nblk + k) * (long)nfreq + f];
-            const cpx a = cmulc(g, X[(sig * nblk + k) * (long)nfreq + f]);
-            p.x += a.x; p.y += a.y;
-            if (k > 0) { const cpx c = cmulc(g, X[(sig * nblk + k - 1) * (long)nfreq + f]); q.x += c.x; q.y += c.y; }
+// Column pass, time -> A[ka][jb]. grid (NA / 8 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
+// elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
+//                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of mix * gy, k = 2p, 2p+1
+//                                 MODE 2: zero-padded impulse responses (L samples per row), imaginary part 0
+template <int MODE>
+__global__ __launch_bounds__(FFT_T) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
+                                                          f2* __restrict__ A, ConvDims d, int L) {
+    __shared__ f2 lds[FFT_LDS];
+    const ColCfg g = col_config(d.logNA, threadIdx.x);
+    const ColTw ct = col_twiddles(g, tw);
+    const int p = blockIdx.y;
+    const long sig = blockIdx.z;
+    const int jb = blockIdx.x * g.TC + g.c;
+    const float scale = MODE == 1 ? mix[sig >> 1] : 1.f;
+    float r[8], i[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int tt = (g.j + g.T * q) * CV_NB + jb;          // time index inside the n1-point frame
+        r[q] = 0.f; i[q] = 0.f;
+        if (MODE == 2) {
+            if (tt < L) r[q] = src[sig * L + tt];
+        } else if (MODE == 1 || q < 4) {                        // MODE 0: the upper half of the frame is padding
+            const long n0 = (long)(2 * p) * d.Lb + tt, n1i = n0 + d.Lb;
+            if (n0 < d.N) r[q] = scale * src[sig * d.N + n0];
+            if (n1i < d.N) i[q] = scale * src[sig * d.N + n1i];
         }
-        P[sig * (long)nfreq + f] = p; Q[sig * (long)nfreq + f] = q;
+    }
+    col_fft<-1>(r, i, g, ct, lds);
+    f2* out = A + (sig * d.npairs + p) * (long)d.n1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[(long)(g.j + g.T * q) * CV_NB + jb] = f2{r[q], i[q]};
+}
+
+// Row pass. grid (NA / 8, signals), 512 threads = 8 waves, wave = row ka, lane j holds columns j + 64 q.
+//   MODE 0  forward:   Wout[p] = rowIFFT(rowFFT(A[p] tw) H) conj(tw)                        for every pair p of the signal
+//   MODE 1  backward:  Wout[p] = rowIFFT(rowFFT(Ag[p] tw) conj(H)) conj(tw);  Pout = rowIFFT(sum_p rowFFT(Ag[p] tw) conj(rowFFT(Ax[p] tw))) conj(tw)
+//   MODE 2  spectrum:  H = rowFFT(A tw)   (pairs = 1)
+template <int MODE>
+__global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__ A, const f2* __restrict__ Ax, const f2* __restrict__ tw,
+                                                          f2* __restrict__ H, f2* __restrict__ Wout, f2* __restrict__ Pout, ConvDims d) {
+    __shared__ f2 lds_all[FFT_T / 64][FFT512_LDS];
+    const int j = lane_id(), ka = blockIdx.x * 8 + wave_id();
+    const long sig = blockIdx.y;
+    f2* lds = lds_all[wave_id()];
+    const Fft512Tw t5 = fft512_twiddles(j, tw);
+    float wr[8], wi[8];
+    fourstep_twiddles(ka, j, d.n1, wr, wi);
+    const long rowoff = (long)ka * CV_NB + j;
+    float hr[8], hi[8], pr[8], pi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        pr[q] = 0.f; pi[q] = 0.f; hr[q] = 0.f; hi[q] = 0.f;
+        if (MODE != 2) { const f2 h = H[sig * d.n1 + rowoff + 64 * q]; hr[q] = h.x; hi[q] = MODE == 1 ? -h.y : h.y; }
+    }
+    auto load_spec = [&](const f2* base, float (&r)[8], float (&i)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f2 v = base[rowoff + 64 * q];
+            r[q] = v.x * wr[q] - v.y * wi[q];
+            i[q] = v.x * wi[q] + v.y * wr[q];
+        }
+        fft512_wave<-1>(r, i, j, t5, lds);
+    };
+    auto store_time = [&](f2* base, float (&r)[8], float (&i)[8]) {
+        fft512_wave<1>(r, i, j, t5, lds);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) base[rowoff + 64 * q] = f2{r[q] * wr[q] + i[q] * wi[q], i[q] * wr[q] - r[q] * wi[q]};
+    };
+    for (int p = 0; p < d.npairs; ++p) {
+        const long off = (sig * d.npairs + p) * (long)d.n1;
+        float r[8], i[8];
+        load_spec(A + off, r, i);
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) H[sig * d.n1 + rowoff + 64 * q] = f2{r[q], i[q]};
+        } else {
+            if (MODE == 1) {
+                float xr[8], xi[8];
+                load_spec(Ax + off, xr, xi);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {          // G conj(X)
+                    pr[q] += r[q] * xr[q] + i[q] * xi[q];
+                    pi[q] += i[q] * xr[q] - r[q] * xi[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float t = r[q] * hr[q] - i[q] * hi[q];
+                i[q] = r[q] * hi[q] + i[q] * hr[q];
+                r[q] = t;
+            }
+            store_time(Wout + off, r, i);
+        }
+    }
+    if (MODE == 1) store_time(Pout + sig * (long)d.n1, pr, pi);
+}
+
+// Inverse column pass + epilogue. 512 threads; thread (j, c) as in conv_load_kernel; registers q < 4 are the lower half of the frame
+// (r = (j + T q) 512 + jb < Lb), q >= 4 the upper half (r + Lb).
+//   MODE 0  grid (tiles, signals): for p = 0..: y[2p Lb + r] = Re lo + carry, y[(2p+1) Lb + r] = Im lo + Re hi, carry = Im hi;
+//           then y = x + mix (wet - x) (:575); wet saved for the mix gradient when `wet` is not null
+//   MODE 1  grid (tiles, pairs, signals): gx[2p Lb + r] = (1 - mix) gy + Re lo, gx[(2p+1) Lb + r] = (1 - mix) gy + Im lo;
+//           mix_part[sig][p * tiles + tile] = sum gy (wet - x)
+//   MODE 2  grid (tiles, signals): gir[sig][r] = Re lo, r < L
+template <int MODE>
+__global__ __launch_bounds__(FFT_T) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
+                                                          const float* __restrict__ gy, const float* __restrict__ mix, float* __restrict__ wet,
+                                                          float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L) {
+    __shared__ f2 lds[FFT_LDS];
+    __shared__ float red[FFT_T / 64];
+    const ColCfg g = col_config(d.logNA, threadIdx.x);
+    const ColTw ct = col_twiddles(g, tw);
+    const long sig = MODE == 1 ? blockIdx.z : blockIdx.y;
+    const int jb = blockIdx.x * g.TC + g.c;
+    const float inv = 1.f / (float)d.n1;
+    const float m = MODE == 2 ? 0.f : mix[sig >> 1];
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float macc = 0.f;
+    const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
+    for (int p = p_lo; p < p_hi; ++p) {
+        const f2* in = W + (sig * d.npairs + p) * (long)d.n1;
+        float r[8], i[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f2 v = in[(long)(g.j + g.T * q) * CV_NB + jb]; r[q] = v.x; i[q] = v.y; }
+        col_fft<1>(r, i, g, ct, lds);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = (g.j + g.T * q) * CV_NB + jb;          // < Lb
+            if (MODE == 2) {
+                if (rr < L) out[sig * L + rr] = r[q] * inv;
+            } else {
+                const long na = (long)(2 * p) * d.Lb + rr, nbk = na + d.Lb;
+                if (MODE == 0) {
+                    const float wa = fmaf(r[q], inv, carry[q]), wb = (i[q] + r[q + 4]) * inv;
+                    carry[q] = i[q + 4] * inv;
+                    if (na < d.N) { const float xv = x[sig * d.N + na]; out[sig * d.N + na] = fmaf(m, wa - xv, xv); if (wet) wet[sig * d.N + na] = wa; }
+                    if (nbk < d.N) { const float xv = x[sig * d.N + nbk]; out[sig * d.N + nbk] = fmaf(m, wb - xv, xv); if (wet) wet[sig * d.N + nbk] = wb; }
+                } else {
+                    if (na < d.N) {
+                        const float gv = gy[sig * d.N + na];
+                        out[sig * d.N + na] = fmaf(1.f - m, gv, r[q] * inv);      // the windows already carry the factor mix
+                        macc = fmaf(gv, wet[sig * d.N + na] - x[sig * d.N + na], macc);
+                    }
+                    if (nbk < d.N) {
+                        const float gv = gy[sig * d.N + nbk];
+                        out[sig * d.N + nbk] = fmaf(1.f - m, gv, i[q] * inv);
+                        macc = fmaf(gv, wet[sig * d.N + nbk] - x[sig * d.N + nbk], macc);
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        const float s = wave_sum(macc);
+        if (lane_id() == 0) red[wave_id()] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f;
+            for (int v = 0; v < FFT_T / 64; ++v) a += red[v];
+            mix_part[(sig * d.npairs + blockIdx.y) * gridDim.x + blockIdx.x] = a;
+        }
     }
 }
+
 
 // ggain, gdecay (B, nb) and gmix (B) from the per-block partial sums, in fp64
 __global__ void reverb_finalize_kernel(const float* __restrict__ part, const float* __restrict__ mix_part, float* __restrict__ ggain,
@@ -245,50 +338,9 @@ __global__ void reverb_finalize_kernel(const float* __restrict__ part, const flo
     }
     if (i < B) {
         double m = 0.0;
-        for (int j = 0; j < 2 * mix_chunks; ++j) m += (double)mix_part[(long)i * 2 * mix_chunks + j];
+        for (long j = 0; j < 2L * mix_chunks; ++j) m += (double)mix_part[(long)i * 2 * mix_chunks + j];
         gmix[i] = (float)m;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// run-time binding of hipFFT
-struct FftApi {
-    void* handle = nullptr;
-    hipfftResult (*Plan1d)(hipfftHandle*, int, hipfftType, int) = nullptr;
-    hipfftResult (*SetStream)(hipfftHandle, hipStream_t) = nullptr;
-    hipfftResult (*ExecR2C)(hipfftHandle, hipfftReal*, hipfftComplex*) = nullptr;
-    hipfftResult (*ExecC2R)(hipfftHandle, hipfftComplex*, hipfftReal*) = nullptr;
-    std::map<std::tuple<int, int, int>, hipfftHandle> plans;
-    std::mutex mu;
-};
-static FftApi g_fft;
-
-static int fft_plan(int n, int type, int batch, hipfftHandle* out) {
-    std::lock_guard<std::mutex> lk(g_fft.mu);
-    if (!g_fft.handle) return DASP_ERR_UNSUPPORTED;
-    auto key = std::make_tuple(n, type, batch);
-    auto it = g_fft.plans.find(key);
-    if (it == g_fft.plans.end()) {
-        hipfftHandle h;
-        if (g_fft.Plan1d(&h, n, (hipfftType)type, batch) != HIPFFT_SUCCESS) return DASP_ERR_UNSUPPORTED;
-        it = g_fft.plans.emplace(key, h).first;
-    }
-    *out = it->second;
-    return DASP_OK;
-}
-static int fft_r2c(int n, long batch, float* in, cpx* out, hipStream_t st) {
-    hipfftHandle h;
-    int s = fft_plan(n, HIPFFT_R2C, (int)batch, &h);
-    if (s) return s;
-    if (g_fft.SetStream(h, st) != HIPFFT_SUCCESS) return DASP_ERR_UNSUPPORTED;
-    return g_fft.ExecR2C(h, in, reinterpret_cast<hipfftComplex*>(out)) == HIPFFT_SUCCESS ? DASP_OK : DASP_ERR_UNSUPPORTED;
-}
-static int fft_c2r(int n, long batch, cpx* in, float* out, hipStream_t st) {
-    hipfftHandle h;
-    int s = fft_plan(n, HIPFFT_C2R, (int)batch, &h);
-    if (s) return s;
-    if (g_fft.SetStream(h, st) != HIPFFT_SUCCESS) return DASP_ERR_UNSUPPORTED;
-    return g_fft.ExecC2R(h, reinterpret_cast<hipfftComplex*>(in), out) == HIPFFT_SUCCESS ? DASP_OK : DASP_ERR_UNSUPPORTED;
 }
 
 }  // namespace dasp
@@ -302,61 +354,44 @@ inline int rv_check() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
 }
-inline long next_pow2(long v) { long p = 1; while (p < v) p <<= 1; return p; }
-struct RvDims { int Lb, n1, nfreq, nblk, VQ, nwin; long R; };
-inline RvDims rv_dims(int B, long N, int L, int taps) {
+struct RvDims { ConvDims c; int nblk, VQ, nwin, tiles; long R; };
+inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     RvDims d;
-    d.Lb = (int)next_pow2(L > taps ? L : taps);
-    d.n1 = 2 * d.Lb;
-    d.nfreq = d.n1 / 2 + 1;
-    d.nblk = (int)((N + d.Lb - 1) / d.Lb);
+    long Lb = 2048;                                  // n1 >= 4096 keeps every workgroup of the four-step kernels full
+    while (Lb < L) Lb <<= 1;
+    if (Lb > (1L << 20)) return false;               // NA = n1 / 512 <= 4096
+    d.c.Lb = (int)Lb; d.c.n1 = 2 * d.c.Lb; d.c.NA = d.c.n1 / CV_NB;
+    d.c.logNA = 0; while ((1 << d.c.logNA) < d.c.NA) ++d.c.logNA;
+    d.c.N = N;
+    d.nblk = (int)((N + Lb - 1) / Lb);
+    d.c.npairs = (d.nblk + 1) / 2;
+    d.tiles = d.c.NA / 8;
     d.R = 2L * B;
-    d.VQ = (FFT_N - (taps - 1)) / 512;          // valid outputs per filter-bank window = 512 VQ (0: filters too long for the window)
-    if (d.VQ < 0) d.VQ = 0;
-    d.nwin = d.VQ ? (L + 512 * d.VQ - 1) / (512 * d.VQ) : 0;
-    return d;
+    d.VQ = (FFT_N - (taps - 1)) / 512;              // valid outputs per filter-bank window = 512 VQ
+    if (d.VQ < 1) return false;                      // filters longer than 3585 taps do not fit the 4096-point window
+    d.nwin = (L + 512 * d.VQ - 1) / (512 * d.VQ);
+    if (d.R > 65535 || d.c.npairs > 65535 || B > 65535) return false;
+    *o = d;
+    return true;
 }
-constexpr int RV_T = 256;
-inline dim3 rv_grid(long n, long rows, int cap = 64) {
-    long bx = (n + RV_T - 1) / RV_T;
-    if (bx > cap) bx = cap;
-    if (bx < 1) bx = 1;
-    return dim3((unsigned)bx, (unsigned)rows);
-}
-#define RV_TRY(expr) do { int s_ = (expr); if (s_ != DASP_OK) return s_; } while (0)
 }  // namespace
 
 extern "C" {
 
-int dasp_fft_init(const char* libhipfft_path) {
-    std::lock_guard<std::mutex> lk(g_fft.mu);
-    if (g_fft.handle) return DASP_OK;
-    void* h = dlopen(libhipfft_path ? libhipfft_path : "libhipfft.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return DASP_ERR_UNSUPPORTED;
-    g_fft.Plan1d = reinterpret_cast<decltype(g_fft.Plan1d)>(dlsym(h, "hipfftPlan1d"));
-    g_fft.SetStream = reinterpret_cast<decltype(g_fft.SetStream)>(dlsym(h, "hipfftSetStream"));
-    g_fft.ExecR2C = reinterpret_cast<decltype(g_fft.ExecR2C)>(dlsym(h, "hipfftExecR2C"));
-    g_fft.ExecC2R = reinterpret_cast<decltype(g_fft.ExecC2R)>(dlsym(h, "hipfftExecC2R"));
-    if (!g_fft.Plan1d || !g_fft.SetStream || !g_fft.ExecR2C || !g_fft.ExecC2R) return DASP_ERR_UNSUPPORTED;
-    g_fft.handle = h;
-    return DASP_OK;
-}
-int dasp_fft_ready(void) { return g_fft.handle != nullptr; }
-
-/* sizes[0] = Lb (block length), [1] = n1 (FFT length), [2] = nfreq, [3] = nblk,
- * [4] = complex elements of Fspec (twiddles + band spectra of the filter bank), [5] = filter-bank windows per batch item,
- * [6] = floats of z / xpad (2B*nblk rows of n1), [7] = complex elements of Xf (2B*nblk rows of nfreq),
- * [8] = floats of ir_pad (2B rows of n1), [9] = complex elements of H (2B rows of nfreq),
- * [10] = mix partial chunks per signal, [11] = floats of the gain/decay partial sums */
+/* sizes[0] = Lb (block length), [1] = n1 (transform length), [2] = pairs of blocks per signal, [3] = blocks per signal,
+ * [4] = complex elements of Fspec (twiddle table + band spectra of the filter bank), [5] = filter-bank windows per batch item,
+ * [6] = complex elements of A / W / Ag (2B * pairs * n1), [7] = complex elements of H / Ah / P (2B * n1),
+ * [8] = floats of ir / gir (2B * L), [9] = floats of wet (2B * N),
+ * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!sizes || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX) return DASP_ERR_ARG;
-    const RvDims d = rv_dims(B, N, L, taps);
-    if (d.VQ < 1) return DASP_ERR_UNSUPPORTED;      // filters longer than 3585 taps do not fit the 4096-point window
-    sizes[0] = d.Lb; sizes[1] = d.n1; sizes[2] = d.nfreq; sizes[3] = d.nblk;
+    RvDims d;
+    if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
+    sizes[0] = d.c.Lb; sizes[1] = d.c.n1; sizes[2] = d.c.npairs; sizes[3] = d.nblk;
     sizes[4] = (long)(nb + 1) * FFT_N; sizes[5] = d.nwin;
-    sizes[6] = d.R * d.nblk * d.n1; sizes[7] = d.R * d.nblk * d.nfreq;
-    sizes[8] = d.R * d.n1; sizes[9] = d.R * d.nfreq;
-    sizes[10] = 64; sizes[11] = (long)B * d.nwin * nb * 2;
+    sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = d.R * d.c.n1;
+    sizes[8] = d.R * L; sizes[9] = d.R * N;
+    sizes[10] = d.R * d.c.npairs * d.tiles; sizes[11] = (long)B * d.nwin * nb * 2;
     return DASP_OK;
 }
 
@@ -370,70 +405,66 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
 }
 
 /* Forward.  x (B,2,N); noise (2B, nb, L+taps-1); Fspec (sizes[4] complex); gains, decays (B, nb); mix (B); y (B,2,N).
- * Saved for backward: Xf (sizes[7] complex), H (sizes[9] complex), z (sizes[6] floats) (and the caller's noise, Fspec).
- * Scratch: yspec (sizes[7] complex), ir_pad (sizes[8] floats). */
+ * Saved for backward: A (sizes[6] complex), H (sizes[7] complex), wet (sizes[9] floats, may be NULL when no gradient is needed).
+ * Scratch: W (sizes[6] complex), Ah (sizes[7] complex), ir (sizes[8] floats). */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays, const float* mix,
-                        float* y, void* Xf, void* H, float* z, void* yspec, float* ir_pad, int B, long N, int L, int taps, int nb,
+                        float* y, void* A, void* H, float* wet, void* W, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
                         void* stream) {
-    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || !Xf || !H || !z || !yspec || !ir_pad || B <= 0 || N <= 0 || L <= 0 ||
-        taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
+    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || !A || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
+        nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
-    const RvDims d = rv_dims(B, N, L, taps);
+    RvDims d;
+    if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const long xrows = d.R * d.nblk;
-    if (d.VQ < 1 || B > 65535 || xrows > 65535) return DASP_ERR_UNSUPPORTED;
-    // 1 + 2. filter bank, envelope, gains, mean over bands -> zero-padded impulse responses (functional.py:551-567), then their spectra
-    hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, (const f2*)Fspec, gains, decays, ir_pad,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, nb, L, taps, d.n1, d.Lb, d.VQ, 0.f);
-    hipLaunchKernelGGL(zero_tail_kernel, rv_grid(d.n1 - L, d.R), dim3(RV_T), 0, st, ir_pad, L, d.n1);
-    RV_TRY(rv_check());
-    RV_TRY(fft_r2c(d.n1, d.R, ir_pad, (cpx*)H, st));
+    const f2* tw = (const f2*)Fspec;
+    // 1. filter bank, envelope, gains, mean over bands -> impulse responses (functional.py:551-567)
+    hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, ir, (const float*)nullptr,
+                       (float*)nullptr, nb, L, taps, d.VQ);
+    // 2. their spectra, in the permuted four-step order
+    hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.tiles, 1, (unsigned)d.R), dim3(FFT_T), 0, st, (const float*)ir, (const float*)nullptr, tw,
+                       (f2*)Ah, ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N}, L);
+    hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, (f2*)H,
+                       (f2*)nullptr, (f2*)nullptr, ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N});
     // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
-    hipLaunchKernelGGL(pad_rows_kernel, rv_grid(d.n1, xrows), dim3(RV_T), 0, st, x, z, xrows, d.n1, 1, 0L, 0, N, d.Lb, d.nblk, (const float*)nullptr);
-    RV_TRY(rv_check());
-    RV_TRY(fft_r2c(d.n1, xrows, z, (cpx*)Xf, st));
-    hipLaunchKernelGGL(cmul_rows_kernel, rv_grid(d.nfreq, xrows), dim3(RV_T), 0, st, (const cpx*)Xf, (const cpx*)H, (cpx*)yspec, d.nfreq, d.nblk, (int)d.R, 0);
-    RV_TRY(rv_check());
-    RV_TRY(fft_c2r(d.n1, xrows, (cpx*)yspec, z, st));
-    hipLaunchKernelGGL(ola_mix_kernel, rv_grid(N, d.R, 256), dim3(RV_T), 0, st, x, z, mix, y, N, d.Lb, d.nblk, d.n1);
+    hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.tiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(FFT_T), 0, st, x, (const float*)nullptr,
+                       tw, (f2*)A, d.c, L);
+    hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)A, (const f2*)nullptr, tw, (f2*)H,
+                       (f2*)W, (f2*)nullptr, d.c);
+    hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)W, tw, x, (const float*)nullptr, mix,
+                       wet, y, (float*)nullptr, d.c, L);
     return rv_check();
 }
 
 /* Backward.  gx (B,2,N); ggain, gdecay (B, nb); gmix (B).
- * Scratch: gpad / cc (sizes[6] floats), Gf (sizes[7] complex), cspec (sizes[7] complex), PQ (2 * sizes[9] complex),
- * pq (2 * sizes[8] floats), part (sizes[11] floats), mix_part (2B * sizes[10] floats). */
+ * Scratch: Ag (sizes[6] complex), W (sizes[6] complex), P (sizes[7] complex), gir (sizes[8] floats), part (sizes[11] floats),
+ * mix_part (sizes[10] floats). */
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
-                         const float* mix, const void* Xf, const void* H, const float* z, float* gx, float* ggain, float* gdecay, float* gmix,
-                         float* gpad, void* Gf, void* cspec, void* PQ, float* pq, float* part, float* mix_part, int B, long N, int L, int taps,
-                         int nb, void* stream) {
-    if (!x || !gy || !noise || !Fspec || !gains || !decays || !mix || !Xf || !H || !z || !gx || !ggain || !gdecay || !gmix || !gpad || !Gf ||
-        !cspec || !PQ || !pq || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
+                         const float* mix, const void* A, const void* H, const float* wet, float* gx, float* ggain, float* gdecay, float* gmix,
+                         void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
+                         void* stream) {
+    if (!x || !gy || !noise || !Fspec || !gains || !decays || !mix || !A || !H || !wet || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
+        !gir || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
-    const RvDims d = rv_dims(B, N, L, taps);
+    RvDims d;
+    if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const long xrows = d.R * d.nblk;
-    if (d.VQ < 1 || B > 65535 || xrows > 65535) return DASP_ERR_UNSUPPORTED;
-    // blocks of mix * gy and their spectra
-    hipLaunchKernelGGL(pad_rows_kernel, rv_grid(d.n1, xrows), dim3(RV_T), 0, st, gy, gpad, xrows, d.n1, 1, 0L, 0, N, d.Lb, d.nblk, mix);
-    RV_TRY(rv_check());
-    RV_TRY(fft_r2c(d.n1, xrows, gpad, (cpx*)Gf, st));
-    // d/dir: cross-correlations with the input blocks (same block and previous block)
-    cpx* P = (cpx*)PQ; cpx* Q = P + d.R * d.nfreq;
-    hipLaunchKernelGGL(ir_grad_spec_kernel, rv_grid(d.nfreq, d.R), dim3(RV_T), 0, st, (const cpx*)Gf, (const cpx*)Xf, P, Q, d.nfreq, d.nblk);
-    RV_TRY(rv_check());
-    RV_TRY(fft_c2r(d.n1, 2 * d.R, P, pq, st));
-    // d/dgain, d/ddecay: the filter bank again, weighted by g_ir = (p[n] + q[n + Lb]) / n1 (mix is already folded into G)
-    hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, (const f2*)Fspec, gains, decays,
-                       (float*)nullptr, pq, pq + d.R * d.n1, part, nb, L, taps, d.n1, d.Lb, d.VQ, 1.f / (float)d.n1);
-    RV_TRY(rv_check());
-    // d/dx: correlation with the impulse response
-    hipLaunchKernelGGL(cmul_rows_kernel, rv_grid(d.nfreq, xrows), dim3(RV_T), 0, st, (const cpx*)Gf, (const cpx*)H, (cpx*)cspec, d.nfreq, d.nblk, (int)d.R, 1);
-    RV_TRY(rv_check());
-    RV_TRY(fft_c2r(d.n1, xrows, (cpx*)cspec, gpad, st));
-    hipLaunchKernelGGL(bwd_combine_kernel, dim3(64, (unsigned)d.R), dim3(RV_T), 0, st, x, gy, z, gpad, mix, gx, mix_part, N, d.Lb, d.nblk, d.n1);
-    RV_TRY(rv_check());
+    const f2* tw = (const f2*)Fspec;
+    // overlapped windows of mix * gy -> column transforms
+    hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.tiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(FFT_T), 0, st, gy, mix, tw, (f2*)Ag, d.c, L);
+    // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
+    hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A, tw, (f2*)H, (f2*)W,
+                       (f2*)P, d.c);
+    hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.tiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)W, tw, x, gy, mix,
+                       (float*)wet, gx, mix_part, d.c, L);
+    hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)P, tw, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, gir, (float*)nullptr,
+                       ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N}, L);
+    // d/dgain, d/ddecay: the filter bank again, weighted by gir
+    hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, (float*)nullptr,
+                       (const float*)gir, part, nb, L, taps, d.VQ);
     const int nfin = B * nb > B ? B * nb : B;
-    hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin, 64);
+    hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
+                       d.c.npairs * d.tiles);
     return rv_check();
 }
 

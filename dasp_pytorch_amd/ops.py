@@ -249,7 +249,6 @@ class ReverbFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, noise, filters, gains, decays, mix, L_ir):
         _lib.require_device(x, "x")
-        _lib.ensure_fft()
         Lb = _lib.lib()
         B, C, N = x.shape
         nb, taps = filters.shape
@@ -261,35 +260,35 @@ class ReverbFunction(torch.autograd.Function):
         Fspec = _cbuf(sizes[4], dev)
         call("dasp_reverb_filter_spectrum", ptr(_f32c(filters)), nb, taps, ptr(Fspec), stream())
         y = torch.empty_like(x32)
-        Xf, H = _cbuf(sizes[7], dev), _cbuf(sizes[9], dev)
-        z = torch.empty(sizes[6], dtype=torch.float32, device=dev)
-        yspec = _cbuf(sizes[7], dev)
-        ir_pad = torch.empty(sizes[8], dtype=torch.float32, device=dev)
-        call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(Xf), ptr(H),
-             ptr(z), ptr(yspec), ptr(ir_pad), B, N, L_ir, taps, nb, stream())
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, Xf, H, z)
+        need_grad = any(ctx.needs_input_grad)
+        A, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
+        H, Ah = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
+        ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
+        wet = torch.empty(sizes[9], dtype=torch.float32, device=dev) if need_grad else None
+        call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
+             ptr(wet) if need_grad else None, ptr(W), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+        if need_grad:
+            ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, A, H, wet)
             ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
             ctx.meta = (x.dtype, gains.dtype, gains.shape, decays.dtype, decays.shape, mix.dtype, mix.shape)
         return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
-        x32, n32, Fspec, g32, d32, m32, Xf, H, z = ctx.saved_tensors
+        x32, n32, Fspec, g32, d32, m32, A, H, wet = ctx.saved_tensors
         B, N, L_ir, taps, nb, sizes = ctx.cfg
         dev = x32.device
         gx = torch.empty_like(x32)
         ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
         gdecay = torch.empty(B, nb, dtype=torch.float32, device=dev)
         gmix = torch.empty(B, dtype=torch.float32, device=dev)
-        gpad = torch.empty(sizes[6], dtype=torch.float32, device=dev)
-        Gf, cspec = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
-        PQ = _cbuf(2 * sizes[9], dev)
-        pq = torch.empty(2 * sizes[8], dtype=torch.float32, device=dev)
+        Ag, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
+        P = _cbuf(sizes[7], dev)
+        gir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
         part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
-        mix_part = torch.empty(2 * B * sizes[10], dtype=torch.float32, device=dev)
-        call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(Xf), ptr(H), ptr(z),
-             ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(gpad), ptr(Gf), ptr(cspec), ptr(PQ), ptr(pq), ptr(part), ptr(mix_part),
+        mix_part = torch.empty(sizes[10], dtype=torch.float32, device=dev)
+        call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(wet),
+             ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P), ptr(gir), ptr(part), ptr(mix_part),
              B, N, L_ir, taps, nb, stream())
         xd, gd, gs, dd, ds, md, ms = ctx.meta
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None

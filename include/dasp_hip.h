@@ -112,26 +112,22 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
  * The filter design (dasp_pytorch.signal.octave_band_filterbank, dasp_pytorch/signal.py:42-92,
  * SciPy firwin on the host) stays on the host; its taps are passed in.
  *
- * The filter bank (taps <= 3585) runs as one fused kernel on the library's own in-LDS 4096-point FFT and is
- * recomputed in the backward pass (noise and Fspec are inputs of both). The FFTs of the long convolution
- * come from hipFFT, bound at run time: call dasp_fft_init once with the path of the libhipfft.so
- * the process should use (NULL = dlopen("libhipfft.so")). FFT plans are created on first use per
- * (length, batch) and cached for the life of the process (hipFFT allocates their work areas).
+ * Both convolutions run on the library's own register/LDS FFTs (no FFT library is linked or loaded): the filter
+ * bank (taps <= 3585) as one fused kernel that is re-run in the backward pass instead of saving its output, the
+ * long convolution (L <= 2^20) as overlap-add with four-step transforms of pairs of blocks (reverb.hip).
  *
  * x, y, gy, gx: (B, 2, N) fp32.  noise: (2B, nb, L + taps - 1).  gains, decays: (B, nb).  mix: (B).
  * nb <= 16 bands, L = IR length, taps = FIR length.  All buffer sizes come from dasp_reverb_sizes.
  * ------------------------------------------------------------------------------------------- */
-int dasp_fft_init(const char* libhipfft_path);
-int dasp_fft_ready(void);
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [12], see reverb.hip */);
 int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream);
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays,
-                        const float* mix, float* y, void* Xf, void* H, float* z, void* yspec, float* ir_pad, int B, long N,
-                        int L, int taps, int nb, void* stream);
+                        const float* mix, float* y, void* A, void* H, float* wet, void* W, void* Ah, float* ir, int B,
+                        long N, int L, int taps, int nb, void* stream);
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains,
-                         const float* decays, const float* mix, const void* Xf, const void* H, const float* z, float* gx,
-                         float* ggain, float* gdecay, float* gmix, float* gpad, void* Gf, void* cspec, void* PQ, float* pq,
-                         float* part, float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
+                         const float* decays, const float* mix, const void* A, const void* H, const float* wet, float* gx,
+                         float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
+                         float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
 
 #ifdef __cplusplus
 }
