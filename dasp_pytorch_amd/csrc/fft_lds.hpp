@@ -166,24 +166,6 @@ __device__ __forceinline__ ColCfg col_config(int logP, int t) {
     g.c = t & (g.TC - 1); g.j = t >> (12 - logP);
     return g;
 }
-struct ColTw { Tw8 p1, p2, p3; float fr[6], fi[6]; };
-__device__ __forceinline__ ColTw col_twiddles(const ColCfg& g, const f2* __restrict__ tw) {
-    ColTw t;
-    const int mul = FFT_N >> g.logP;               // w_P^e = tw[e * mul]
-    t.p1 = tw_powers(tw[g.P >= 64 ? ((g.j & 7) * (g.P >> 6)) * mul : 0]);
-    t.p2 = tw_powers(tw[g.P >= 512 ? ((g.j & 63) * (g.P >> 9)) * mul : 0]);
-    t.p3 = tw_powers(tw[g.P >= 4096 ? (g.j & 511) * mul : 0]);
-    const int a = g.logP / 3, R = g.P >> (3 * a);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        int e = 0;
-        if (R == 4) e = ((g.j + g.T * (k / 3)) * (k % 3 + 1)) & (g.P - 1);      // butterfly m = k / 3, input r = k % 3 + 1
-        else if (R == 2 && k < 4) e = g.j + g.T * k;                              // butterfly m = k, input r = 1
-        const f2 w = tw[e * mul];
-        t.fr[k] = w.x; t.fi[k] = w.y;
-    }
-    return t;
-}
 __device__ __forceinline__ void col_exchange(float (&r)[8], float (&i)[8], f2* lds, const ColCfg& g, int wbase, int Ns) {
     __syncthreads();
 #pragma unroll
@@ -197,32 +179,36 @@ template <int DIR> __device__ __forceinline__ void cmul_dir(float& re, float& im
     im = DIR < 0 ? re * wi + im * wr : im * wr - re * wi;
     re = t;
 }
+// tw = the 4096-entry forward table; the twiddles of a pass are formed right before it (workgroups that run one transform per
+// thread have nothing to amortise them over, and keeping all of them live costs ~50 VGPRs)
 template <int DIR>
-__device__ __forceinline__ void col_fft(float (&r)[8], float (&i)[8], const ColCfg& g, const ColTw& tw, f2* lds) {
-    const int a = g.logP / 3;
+__device__ __forceinline__ void col_fft(float (&r)[8], float (&i)[8], const ColCfg& g, const f2* __restrict__ tw, f2* lds) {
+    const int a = g.logP / 3, mul = FFT_N >> g.logP;          // w_P^e = tw[e * mul]
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < a) {                                   // workgroup-uniform
-            if (k == 1) twiddle8<DIR>(r, i, tw.p1);
-            if (k == 2) twiddle8<DIR>(r, i, tw.p2);
-            if (k == 3) twiddle8<DIR>(r, i, tw.p3);
-            radix8<DIR>(r, i);
             const int Ns = 1 << (3 * k);
+            if (k > 0) twiddle8<DIR>(r, i, tw_powers(tw[((g.j & (Ns - 1)) * (g.P >> (3 * k + 3))) * mul]));
+            radix8<DIR>(r, i);
             if (Ns * 8 < g.P) col_exchange(r, i, lds, g, ((g.j >> (3 * k)) << (3 * k + 3)) + (g.j & (Ns - 1)), Ns);
         }
     }
     const int R = g.P >> (3 * a);
-    if (R == 4) {                                      // two radix-4 butterflies on registers (m, m+2, m+4, m+6)
+    if (R == 4) {                                      // two radix-4 butterflies on registers (m, m+2, m+4, m+6), u = j + T m
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int k = 1; k < 4; ++k) cmul_dir<DIR>(r[m + 2 * k], i[m + 2 * k], tw.fr[m * 3 + k - 1], tw.fi[m * 3 + k - 1]);
+            for (int k = 1; k < 4; ++k) {
+                const f2 w = tw[(((g.j + g.T * m) * k) & (g.P - 1)) * mul];
+                cmul_dir<DIR>(r[m + 2 * k], i[m + 2 * k], w.x, w.y);
+            }
             dft4<DIR>(r[m], i[m], r[m + 2], i[m + 2], r[m + 4], i[m + 4], r[m + 6], i[m + 6]);
         }
-    } else if (R == 2) {                               // four radix-2 butterflies on registers (m, m+4)
+    } else if (R == 2) {                               // four radix-2 butterflies on registers (m, m+4), u = j + T m
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            cmul_dir<DIR>(r[m + 4], i[m + 4], tw.fr[m], tw.fi[m]);
+            const f2 w = tw[(g.j + g.T * m) * mul];
+            cmul_dir<DIR>(r[m + 4], i[m + 4], w.x, w.y);
             const float ar = r[m], ai = i[m];
             r[m] = ar + r[m + 4]; i[m] = ai + i[m + 4];
             r[m + 4] = ar - r[m + 4]; i[m + 4] = ai - i[m + 4];

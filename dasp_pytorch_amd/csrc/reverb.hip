@@ -158,6 +158,11 @@ __device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (
     for (int q = 1; q < 8; ++q) { wr[q] = wr[q - 1] * c1 - wi[q - 1] * s1; wi[q] = wr[q - 1] * s1 + wi[q - 1] * c1; }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs in launch order. A column tile is only 16 floats (64 B) wide on the signal side, so the
+// two halves of every 128-byte line belong to neighbouring tiles: give each XCD a contiguous run of tiles, so that both halves meet in
+// the same L2 instead of being fetched from HBM twice.
+__device__ __forceinline__ int xcd_tile(int bx, int nx) { return (nx & 7) ? bx : (bx & 7) * (nx >> 3) + (bx >> 3); }
+
 // Column pass, time -> A[ka][jb]. grid (NA / 8 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
 //                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of mix * gy, k = 2p, 2p+1
@@ -167,10 +172,9 @@ __global__ __launch_bounds__(FFT_T) void conv_load_kernel(const float* __restric
                                                           f2* __restrict__ A, ConvDims d, int L) {
     __shared__ f2 lds[FFT_LDS];
     const ColCfg g = col_config(d.logNA, threadIdx.x);
-    const ColTw ct = col_twiddles(g, tw);
     const int p = blockIdx.y;
     const long sig = blockIdx.z;
-    const int jb = blockIdx.x * g.TC + g.c;
+    const int jb = xcd_tile(blockIdx.x, gridDim.x) * g.TC + g.c;
     const float scale = MODE == 1 ? mix[sig >> 1] : 1.f;
     float r[8], i[8];
 #pragma unroll
@@ -181,11 +185,15 @@ __global__ __launch_bounds__(FFT_T) void conv_load_kernel(const float* __restric
             if (tt < L) r[q] = src[sig * L + tt];
         } else if (MODE == 1 || q < 4) {                        // MODE 0: the upper half of the frame is padding
             const long n0 = (long)(2 * p) * d.Lb + tt, n1i = n0 + d.Lb;
-            if (n0 < d.N) r[q] = scale * src[sig * d.N + n0];
+            if (n0 < d.N && !(MODE == 1 && q >= 4)) r[q] = scale * src[sig * d.N + n0];      // MODE 1, q >= 4: same sample as i[q - 4]
             if (n1i < d.N) i[q] = scale * src[sig * d.N + n1i];
         }
     }
-    col_fft<-1>(r, i, g, ct, lds);
+    if (MODE == 1) {
+#pragma unroll
+        for (int q = 4; q < 8; ++q) r[q] = i[q - 4];
+    }
+    col_fft<-1>(r, i, g, tw, lds);
     f2* out = A + (sig * d.npairs + p) * (long)d.n1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) out[(long)(g.j + g.T * q) * CV_NB + jb] = f2{r[q], i[q]};
@@ -269,23 +277,27 @@ __global__ __launch_bounds__(FFT_T) void conv_cols_kernel(const f2* __restrict__
     __shared__ f2 lds[FFT_LDS];
     __shared__ float red[FFT_T / 64];
     const ColCfg g = col_config(d.logNA, threadIdx.x);
-    const ColTw ct = col_twiddles(g, tw);
     const long sig = MODE == 1 ? blockIdx.z : blockIdx.y;
-    const int jb = blockIdx.x * g.TC + g.c;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const float inv = 1.f / (float)d.n1;
     const float m = MODE == 2 ? 0.f : mix[sig >> 1];
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
     float macc = 0.f;
     const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
     for (int p = p_lo; p < p_hi; ++p) {
+        // the thread coordinates pass through an opaque move once per pair: without it every LDS / global address of the loop body is
+        // hoisted out of the loop and the kernel needs 208 VGPRs (one workgroup per CU) instead of ~100
+        ColCfg gl = g;
+        if (MODE == 0) { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); gl.j += z; }
+        const int jbl = tile * gl.TC + gl.c;
         const f2* in = W + (sig * d.npairs + p) * (long)d.n1;
         float r[8], i[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const f2 v = in[(long)(g.j + g.T * q) * CV_NB + jb]; r[q] = v.x; i[q] = v.y; }
-        col_fft<1>(r, i, g, ct, lds);
+        for (int q = 0; q < 8; ++q) { const f2 v = in[(long)(gl.j + gl.T * q) * CV_NB + jbl]; r[q] = v.x; i[q] = v.y; }
+        col_fft<1>(r, i, gl, tw, lds);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int rr = (g.j + g.T * q) * CV_NB + jb;          // < Lb
+            const int rr = (gl.j + gl.T * q) * CV_NB + jbl;          // < Lb
             if (MODE == 2) {
                 if (rr < L) out[sig * L + rr] = r[q] * inv;
             } else {
