@@ -40,6 +40,20 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sum over the 64 lanes on DPP row shifts / row broadcasts (six VALU instructions, no LDS); wave-uniform result.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_or_zero(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v += dpp_or_zero<0x111, 0xf>(v);       // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);       // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);       // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);       // row_shr:8      lane 15 of each row = row total
+    v += dpp_or_zero<0x142, 0xa>(v);       // row_bcast:15   rows 1, 3 += previous row
+    v += dpp_or_zero<0x143, 0xc>(v);       // row_bcast:31   rows 2, 3 += rows 0..1
+    return read_lane(v, 63);
+}
+
 // LDS accesses of one wave are executed in issue order; this only stops the compiler from moving
 // them across the point where lanes exchange data through a wave-private LDS region.
 __device__ __forceinline__ void wave_lds_sync() {

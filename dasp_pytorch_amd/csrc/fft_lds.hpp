@@ -2,8 +2,9 @@
 // between. Element `idx = j + T q` (T = length / 8) lives in register q of thread j both before and after a transform
 // (natural order in, natural order out), so a forward transform, a pointwise product and the inverse transform chain
 // through registers without touching LDS in between. Three shapes, all used by reverb.hip:
-//   fft4096      one 4096-point transform per 512-thread workgroup            (filter bank, functional.py:548-558)
 //   fft512_wave  one 512-point transform per wave, no workgroup barriers      (row pass of the four-step long FFT)
+//   fft4096_split_fwd / _inv  one 4096-point transform per 512-thread workgroup as radix-8 x 512 with a single
+//                workgroup barrier                                             (filter bank, functional.py:548-558)
 //   col_fft      4096 / P transforms of P = 8..4096 points side by side in a 512-thread workgroup, radix-8 passes plus
 //                one radix-2/4 pass                                           (column pass of the four-step long FFT)
 #pragma once
@@ -13,9 +14,10 @@ namespace dasp {
 
 constexpr int FFT_N = 4096;          // transform length
 constexpr int FFT_T = 512;           // threads per transform
-constexpr int FFT_LDS = FFT_N + FFT_N / 8;   // float2 elements of the padded exchange buffer (36,864 B)
+constexpr int FFT512_LDS = 512 + 64;          // padded float2 elements of one 512-point transform
+constexpr int FFT_LDS = FFT_N + FFT_N / 8;   // float2 elements of one padded exchange buffer (36,864 B)
 
-// one pad slot per 8 elements: makes the stride-8 and stride-64 scatter of the first two passes conflict-free
+// one pad slot per 8 elements: spreads the stride-8 and stride-64 scatters of the Stockham passes over the LDS banks
 __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 3); }
 
 // z * (-i) for DIR < 0, z * (+i) for DIR > 0
@@ -78,15 +80,6 @@ __device__ __forceinline__ Tw8 tw_powers(f2 w) {
     t.r[6] = t.r[3] * t.r[2] - t.i[3] * t.i[2]; t.i[6] = t.r[3] * t.i[2] + t.i[3] * t.r[2];
     return t;
 }
-// the three twiddle sets of a thread (they depend on the thread index only: compute once, reuse for every transform)
-struct FftTw { Tw8 s1, s2, s3; };
-__device__ __forceinline__ FftTw fft_twiddles(int j, const f2* __restrict__ tw) {
-    FftTw t;
-    t.s1 = tw_powers(tw[(j & 7) * 64]);      // Ns = 8
-    t.s2 = tw_powers(tw[(j & 63) * 8]);      // Ns = 64
-    t.s3 = tw_powers(tw[j]);                 // Ns = 512
-    return t;
-}
 // x[k] *= w^k (DIR < 0) or conj(w)^k (DIR > 0), k = 1..7
 template <int DIR> __device__ __forceinline__ void twiddle8(float (&r)[8], float (&i)[8], const Tw8& w) {
 #pragma unroll
@@ -99,36 +92,7 @@ template <int DIR> __device__ __forceinline__ void twiddle8(float (&r)[8], float
     }
 }
 
-// registers -> LDS at wbase + q * wstride, barrier, LDS -> registers at element j + 512 q. All indices are already padded
-// (fft_pad is linear over each of these progressions, so every access is one base register + an immediate offset).
-__device__ __forceinline__ void fft_exchange(float (&r)[8], float (&i)[8], f2* lds, int wbase, int wstride, int rbase) {
-    __syncthreads();                 // every thread has finished reading the previous contents
-    f2* wp = lds + wbase;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) wp[q * wstride] = f2{r[q], i[q]};
-    __syncthreads();
-    const f2* rp = lds + rbase;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const f2 v = rp[q * (FFT_N / 8 + FFT_N / 64)]; r[q] = v.x; i[q] = v.y; }
-}
-
-template <int DIR>
-__device__ __forceinline__ void fft4096(float (&r)[8], float (&i)[8], int j, const FftTw& tw, f2* lds) {
-    const int rb = j + (j >> 3);                                            // fft_pad(j); fft_pad(j + 512 q) = rb + 576 q
-    radix8<DIR>(r, i);                                                     // Ns = 1: scatter to 8 j + q
-    fft_exchange(r, i, lds, 9 * j, 1, rb);
-    twiddle8<DIR>(r, i, tw.s1);                                            // Ns = 8: scatter to (j / 8) 64 + j % 8 + 8 q
-    radix8<DIR>(r, i);
-    fft_exchange(r, i, lds, (j >> 3) * 72 + (j & 7), 9, rb);
-    twiddle8<DIR>(r, i, tw.s2);                                            // Ns = 64: scatter to (j / 64) 512 + j % 64 + 64 q
-    radix8<DIR>(r, i);
-    fft_exchange(r, i, lds, (j >> 6) * 576 + (j & 63) + ((j & 63) >> 3), 72, rb);
-    twiddle8<DIR>(r, i, tw.s3);                                            // Ns = 512
-    radix8<DIR>(r, i);
-}
-
 // ---- 512-point transform held by one wave --------------------------------------------------------------------------
-constexpr int FFT512_LDS = 512 + 64;          // padded float2 elements per wave
 struct Fft512Tw { Tw8 s1, s2; };
 __device__ __forceinline__ Fft512Tw fft512_twiddles(int j, const f2* __restrict__ tw) {      // j = lane, tw = 4096-entry table
     Fft512Tw t;
@@ -156,6 +120,47 @@ __device__ __forceinline__ void fft512_wave(float (&r)[8], float (&i)[8], int j,
     wave_exchange(r, i, lds, (j >> 3) * 72 + (j & 7), 9, rb);
     twiddle8<DIR>(r, i, tw.s2);
     radix8<DIR>(r, i);
+}
+
+// ---- 4096 = 8 x 512 split: one workgroup barrier per transform ------------------------------------------------------
+// forward:  radix-8 over r of x[j + 512 r] in registers, twiddle w_4096^(j k1), transpose through LDS so that wave k1 owns all j,
+//           512-point transform inside the wave. Output: wave k1, lane l, register s = X[k1 + 8 (l + 64 s)] ("split order").
+// inverse:  the mirror image, from split order back to thread j, register r = N x[j + 512 r].
+// A pointwise product between the two only needs the other factor in split order. Each direction uses one buffer of FFT_LDS
+// elements (8 rows of 576): the workgroup-wide transpose, then each wave's private exchanges inside its own row; with the forward
+// transform on one buffer and the inverse on the other, one barrier per transform is enough: a buffer is written again only by threads that have passed the other
+// buffer's barrier, which every thread reaches after executing (LDS is in order per wave) its reads of the first.
+struct SplitTw { Tw8 outer; Fft512Tw inner; };
+__device__ __forceinline__ SplitTw split_twiddles(int j, const f2* __restrict__ tw) {
+    SplitTw t;
+    t.outer = tw_powers(tw[j]);
+    t.inner = fft512_twiddles(j & 63, tw);
+    return t;
+}
+__device__ __forceinline__ void fft4096_split_fwd(float (&r)[8], float (&i)[8], int j, const SplitTw& tw, f2* buf) {
+    radix8<-1>(r, i);
+    twiddle8<-1>(r, i, tw.outer);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) buf[q * FFT512_LDS + j] = f2{r[q], i[q]};
+    __syncthreads();
+    f2* row = buf + (j >> 6) * FFT512_LDS;
+    const int l = j & 63;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f2 v = row[l + 64 * q]; r[q] = v.x; i[q] = v.y; }
+    fft512_wave<-1>(r, i, l, tw.inner, row);
+}
+__device__ __forceinline__ void fft4096_split_inv(float (&r)[8], float (&i)[8], int j, const SplitTw& tw, f2* buf) {
+    f2* row = buf + (j >> 6) * FFT512_LDS;
+    const int l = j & 63;
+    fft512_wave<1>(r, i, l, tw.inner, row);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) row[l + 64 * q] = f2{r[q], i[q]};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f2 v = buf[q * FFT512_LDS + j]; r[q] = v.x; i[q] = v.y; }
+    twiddle8<1>(r, i, tw.outer);
+    radix8<1>(r, i);
 }
 
 // ---- TC = 4096 / P transforms of P points side by side (batch index fastest in LDS and across lanes) ---------------

@@ -35,7 +35,8 @@ constexpr int RV_BANDS_MAX = 16;
 constexpr int CV_NB = 512;                // row length of the four-step split
 
 // ---- fused filter bank ---------------------------------------------------------------------------------------------
-// spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096.
+// spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096
+// in the split order of fft4096_split_fwd.
 __global__ void fb_twiddle_kernel(f2* __restrict__ spec) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < FFT_N) {
@@ -45,16 +46,17 @@ __global__ void fb_twiddle_kernel(f2* __restrict__ spec) {
     }
 }
 __global__ __launch_bounds__(FFT_T) void fb_spectrum_kernel(const float* __restrict__ filters, f2* __restrict__ spec, int taps) {
-    __shared__ f2 lds[FFT_LDS];
+    __shared__ f2 lds[2 * FFT_LDS];
     const int j = threadIdx.x, band = blockIdx.x;
     float r[8], i[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int idx = j + 512 * q; r[q] = idx < taps ? filters[(long)band * taps + idx] : 0.f; i[q] = 0.f; }
-    const FftTw tw = fft_twiddles(j, spec);
-    fft4096<-1>(r, i, j, tw, lds);
+    const SplitTw tw = split_twiddles(j, spec);
+    fft4096_split_fwd(r, i, j, tw, lds);
     constexpr float inv = 1.f / (float)FFT_N;
+    const int so = (j >> 6) * 512 + (j & 63);          // split order (fft_lds.hpp), the order fb_fused_kernel multiplies in
 #pragma unroll
-    for (int q = 0; q < 8; ++q) spec[FFT_N + (long)band * FFT_N + j + 512 * q] = f2{r[q] * inv, -i[q] * inv};
+    for (int q = 0; q < 8; ++q) spec[FFT_N + (long)band * FFT_N + so + 64 * q] = f2{r[q] * inv, -i[q] * inv};
 }
 
 // One workgroup = one (batch item b, window w): output samples n = w V + idx, idx < V = 512 VQ <= 4096 - (taps - 1).
@@ -66,12 +68,13 @@ template <int MODE>
 __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const float* __restrict__ gains,
                                                          const float* __restrict__ decays, float* __restrict__ ir, const float* __restrict__ gir,
                                                          float* __restrict__ part, int nb, int L, int taps, int VQ) {
-    __shared__ f2 lds[FFT_LDS];
+    __shared__ f2 lds[2 * FFT_LDS];
     __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
     const int j = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
     const int V = VQ * 512, n0 = w * V, row_len = L + taps - 1;
     const float tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f, inv_nb = 1.f / (float)nb;
-    const FftTw tw = fft_twiddles(j, spec);
+    const SplitTw tw = split_twiddles(j, spec);
+    const int so = (j >> 6) * 512 + (j & 63);
     const float t0 = (float)(n0 + j) * tstep, t512 = 512.f * tstep;      // t_n = n / (L - 1), torch.linspace(0, 1, L)
     float accr[8], acci[8];
 #pragma unroll
@@ -95,16 +98,16 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
                 i[q] = idx < row_len ? rr[idx] : 0.f;
             }
         }
-        fft4096<-1>(r, i, j, tw, lds);
-        const f2* F = spec + FFT_N + (long)band * FFT_N;
+        fft4096_split_fwd(r, i, j, tw, lds);
+        const f2* F = spec + FFT_N + (long)band * FFT_N + so;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const f2 f = F[j + 512 * q];
+            const f2 f = F[64 * q];
             const float t = r[q] * f.x - i[q] * f.y;
             i[q] = r[q] * f.y + i[q] * f.x;
             r[q] = t;
         }
-        fft4096<1>(r, i, j, tw, lds);
+        fft4096_split_inv(r, i, j, tw, lds + FFT_LDS);
         const float g = gains[b * nb + band], d = 10.f * decays[b * nb + band] + 1.f;
         if (MODE == 0) {
             const float gs = g * inv_nb;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
                 sg += e;
                 sd = fmaf(e, -10.f * tq * g, sd);
             }
-            sg = wave_sum(sg); sd = wave_sum(sd);
+            sg = wave_sum_uniform(sg); sd = wave_sum_uniform(sd);
             if (lane_id() == 0) { red[wave_id()][band][0] = sg; red[wave_id()][band][1] = sd; }
         }
     }

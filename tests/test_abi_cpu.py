@@ -41,6 +41,22 @@ def test_size_queries():
     assert L.dasp_sos_carry_floats(4, 2 * T, 6) == 4 * 2 * 12 * 64
 
 
+def test_reverb_size_query():
+    """Host-side planning of the reverb (no launch): block length, transform length, pairs; refusals are -2."""
+    import ctypes
+    L = _lib.lib()
+    sizes = (ctypes.c_long * 12)()
+    assert L.dasp_reverb_sizes(128, 262144, 65536, 1023, 12, sizes) == 0
+    Lb, n1, pairs, nblk = sizes[0], sizes[1], sizes[2], sizes[3]
+    assert (Lb, n1, pairs, nblk) == (65536, 131072, 2, 4)
+    assert sizes[4] == 13 * 4096 and sizes[5] == -(-65536 // 3072)            # twiddles + 12 band spectra; 3072 valid samples per window
+    assert sizes[6] == 256 * pairs * n1 and sizes[7] == 256 * n1 and sizes[8] == 256 * 65536 and sizes[9] == 256 * 262144
+    assert L.dasp_reverb_sizes(1, 5000, 1000, 63, 12, sizes) == 0 and (sizes[0], sizes[3], sizes[2]) == (2048, 3, 2)   # odd block count: zero partner
+    assert L.dasp_reverb_sizes(1, 1000, 4096, 3587, 12, sizes) == -2         # filter longer than the filter-bank window
+    assert L.dasp_reverb_sizes(1, 1000, (1 << 20) + 1, 63, 12, sizes) == -2  # impulse response beyond 2^20 samples
+    assert L.dasp_reverb_sizes(1, 1000, 4096, 63, 17, sizes) == -1           # more than 16 bands
+
+
 def test_argument_errors_without_gpu():
     """NULL pointers / bad sizes are rejected before any launch (status DASP_ERR_ARG = -1)."""
     L = _lib.lib()

@@ -57,7 +57,13 @@ def test_reverb_seed_reproduces_reference_noise_stream(D):
     assert e < 2e-5
 
 
-@pytest.mark.parametrize("B,C,N,L,taps", [(1, 2, 1, 64, 15), (2, 1, 100, 256, 31), (1, 2, 5000, 300, 63), (3, 2, 70000, 65536, 1023), (2, 2, 262144, 65536, 1023)])
+# The long convolution runs n1 = 2 nextpow2(L) point four-step transforms with column length NA = n1 / 512: the L values below walk NA
+# through 8, 16, ..., 4096, i.e. every combination of radix-8 passes and radix-2/4 tail of the column transform (fft_lds.hpp col_fft),
+# with odd and even block counts (zero partner in the last pair, overlap carried across pairs).
+@pytest.mark.parametrize("B,C,N,L,taps", [(1, 2, 1, 64, 15), (2, 1, 100, 256, 31), (1, 2, 5000, 300, 63), (3, 2, 70000, 65536, 1023), (2, 2, 262144, 65536, 1023),
+                                          (1, 2, 9000, 3000, 63), (2, 2, 21000, 5000, 255), (1, 1, 50000, 10000, 1023), (1, 2, 9000, 20000, 127),
+                                          (1, 2, 300000, 100000, 63), (1, 1, 30000, 200000, 255), (1, 2, 40000, 400000, 63), (1, 2, 40000, 1000000, 63),
+                                          (1, 2, 4000, 500, 3585)])
 def test_reverb_shapes_vs_oracle(D, B, C, N, L, taps):
     rng = np.random.default_rng(N + L)
     x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
@@ -72,6 +78,17 @@ def test_reverb_shapes_vs_oracle(D, B, C, N, L, taps):
     assert np.abs(gx - gxo).max() < 3e-5 * max(np.abs(gxo).max(), 1e-6)
     gpo = np.concatenate([gg, gd, gm[:, None]], 1)
     assert np.abs(gp - gpo).max() < 2e-4 * np.abs(gpo).max()
+
+
+def test_reverb_unsupported_sizes_raise(D):
+    """Filters longer than the 4096-point filter-bank window and impulse responses beyond 2^20 samples are refused, not approximated."""
+    from dasp_pytorch_amd._lib import DaspHipError
+    x = torch.rand(1, 2, 1000, device="cuda:0")
+    cols = [torch.rand(1, device="cuda:0") for _ in range(25)]
+    with pytest.raises(DaspHipError):
+        D.noise_shaped_reverberation(x, SR, *cols, num_samples=4096, num_bandpass_taps=3587)
+    with pytest.raises(DaspHipError):
+        D.noise_shaped_reverberation(x, SR, *cols, num_samples=(1 << 20) + 1, num_bandpass_taps=63, noise=torch.zeros(2, 12, 8, device="cuda:0"))
 
 
 def test_reverb_semantics(D):
