@@ -18,7 +18,16 @@
 
 namespace dasp {
 
-constexpr int DY_L = 16, DY_SUB = DY_L / 4, DY_TS = 64 * DY_L;
+#ifdef DASP_TRACE   // developer builds only: time stamps of one wave's phases over four consecutive tiles (scripts/dyn_trace.py)
+__device__ long long g_dtrace[64];
+#define DTRACE(i) do { if (blockIdx.x == 7 && threadIdx.x == 192 && r >= 8 * W + wave && r < 12 * W + wave) g_dtrace[((r / W) & 3) * 8 + (i)] = clock64(); } while (0)
+#else
+#define DTRACE(i)
+#endif
+
+constexpr int DY_L = 8, DY_SUB = DY_L / 4, DY_TS = 64 * DY_L;          // tile = 512 samples = 2 sub-tiles of 256
+constexpr int DY_SLOT = 4 * DY_TS + 4;      // floats per slot of the backward kernel's LDS ring: (x, gy) x 2 channels x tile, + the tile carry
+constexpr int DY_RING = 2 * DY_SLOT;        // two slots per wave
 constexpr float DB_PER_LOG2 = 6.020599913279624f;      // 20 / log2(10)
 constexpr float LOG2_PER_DB = 0.16609640474436813f;    // log2(10) / 20
 constexpr float LN10_20 = 0.11512925464970228f;        // ln(10) / 20
@@ -206,16 +215,41 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
     }
 }
 
+// LDS-DMA: 16 (4) bytes per active lane straight from global memory into LDS at (wave-uniform dst) + 16 (4) * lane, no staging
+// registers; completion is counted by vmcnt. Issued as inline asm on purpose: hipcc answers the builtin form with a vmcnt(0) in front
+// of every later LDS read, which would serialise the prefetch it is meant to overlap; here the waits are placed by hand
+// (M0 = LDS destination base, saved and restored inside the statement because the compiler owns it).
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+__device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward. Walks the tiles in reverse; recomputes the forward gain from the saved tile carries,
 // runs the adjoint one-pole scan on lane-mirrored data, accumulates the control gradients.
 // partials: (B, W, 5) = d/d threshold, ratio, alpha, knee, makeup (per wave, fp32).
-template <int MODE, int W>
+//
+// DMA = true (no look-ahead, <= 2 channels, 16-byte aligned rows): a workgroup is limited to ~11 B/cycle of fetch bandwidth and the
+// register-staged version spent 70 % of every tile waiting for its own load burst and its re-read of gy. Here every wave owns a two-slot
+// LDS ring; the x / gy samples of its NEXT tile are in flight (global_load_lds, no staging registers) while it works on the current
+// one, gy is read from the slot a second time for the output stage instead of from memory, and the loop-top wait lets the previous
+// tile's stores stay outstanding (vmcnt is in-order on gfx9).
+template <int MODE, int W, bool DMA>
 __global__ void __launch_bounds__(64 * W)
 dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const float* __restrict__ gy,
                const float* __restrict__ carries, const float* __restrict__ lin_buf, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps) {
     __shared__ float lds[W * 4];
+    __shared__ float ring[DMA ? W * DY_RING : 1];
     const int lane = lane_id(), wave = wave_id(), b = blockIdx.x;
     const DynItem it = load_item(ctl, b, sample_rate, eps);
     const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
@@ -227,23 +261,69 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
     __syncthreads();
     float Rreg = 0.f;
     float acc_t = 0.f, acc_r = 0.f, acc_a = 0.f, acc_w = 0.f, acc_m = 0.f;
-    for (int r = wave; r < nt; r += W) {
-        const int t = nt - 1 - r;
-        const long base = (long)t * DY_TS;
-        const bool fast = vec && base + DY_TS <= N, fast_in = fast && look == 0;
-        f4 s[DY_SUB], q[DY_SUB];
-#pragma unroll
-        for (int j = 0; j < DY_SUB; ++j) { s[j] = f4{0.f, 0.f, 0.f, 0.f}; q[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+    // DMA path: slot layout [x c0 | x c1 | gy c0 | gy c1], each DY_TS floats in tile order, then the carry entering the tile.
+    // Nothing on this path is an ordinary global load: the compiler would answer one in flight next to the DMA with vmcnt(0) waits.
+    const int lk = DMA ? 0 : look;
+    float* const myring = ring + (DMA ? wave * DY_RING : 0);
+    auto prefetch = [&](int tt, int slot) {
+        const long pbase = (long)tt * DY_TS;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(myring + slot * DY_SLOT));       // byte address
+        if (lane == 0) glds4(carries + (size_t)b * nt + tt, dst + 16 * DY_TS);
         for (int c = 0; c < C; ++c) {
 #pragma unroll
             for (int j = 0; j < DY_SUB; ++j) {
-                const long p = base + dy_pos(j, lane, 0);
-                const f4 xv = load4(xb + (size_t)c * N, p, N, fast);
-                s[j] += xv;
-                const f4 xd = look == 0 ? xv : load4(xb + (size_t)c * N, p - look, N, false);
-                q[j] += load4(gb + (size_t)c * N, p, N, fast) * xd;            // sum_c gy * x_d
+                const long p = pbase + dy_pos(j, lane, 0);
+                if (p < N) {                                  // N % 4 == 0 on this path: a lane's 16 bytes are inside or outside as a whole
+                    glds16(xb + (size_t)c * N + p, dst + 4 * (c * DY_TS + j * 256));
+                    glds16(gb + (size_t)c * N + p, dst + 4 * ((2 + c) * DY_TS + j * 256));
+                }
             }
         }
+    };
+    int pending_stores = 0;
+    if (DMA && wave < nt) prefetch(nt - 1 - wave, 0);
+    int slot = 0;
+    for (int r = wave; r < nt; r += W, slot ^= 1) {
+        const int t = nt - 1 - r;
+        const long base = (long)t * DY_TS;
+        const bool fast = vec && base + DY_TS <= N, fast_in = fast && lk == 0;
+        DTRACE(0);
+        f4 s[DY_SUB], q[DY_SUB];
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) { s[j] = f4{0.f, 0.f, 0.f, 0.f}; q[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+        float Kcur = 0.f;
+        const float* cur = myring + slot * DY_SLOT;
+        if (DMA) {
+            // this tile's samples and carry have landed; the previous tile's stores (issued after them) may still be in flight
+            if (pending_stores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (pending_stores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            Kcur = cur[4 * DY_TS];
+            if (r + W < nt) prefetch(t - W, slot ^ 1);
+            for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int j = 0; j < DY_SUB; ++j) {
+                    const bool in = base + dy_pos(j, lane, 0) < N;
+                    const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+                    const f4 xv = in ? *reinterpret_cast<const f4*>(cur + c * DY_TS + dy_pos(j, lane, 0)) : z;
+                    const f4 gv = in ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : z;
+                    s[j] += xv;
+                    q[j] += gv * xv;
+                }
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int j = 0; j < DY_SUB; ++j) {
+                    const long p = base + dy_pos(j, lane, 0);
+                    const f4 xv = load4(xb + (size_t)c * N, p, N, fast);
+                    s[j] += xv;
+                    const f4 xd = lk == 0 ? xv : load4(xb + (size_t)c * N, p - lk, N, false);
+                    q[j] += load4(gb + (size_t)c * N, p, N, fast) * xd;            // sum_c gy * x_d
+                }
+            }
+        }
+        DTRACE(1);
         // forward recompute: g_c, lane scan, exact g and lin; keep x_db (in s) and g_c
         f4 gc[DY_SUB], gs[DY_SUB];   // gc = gain computer output, gs = smoothed gain g[n]
         float E[DY_SUB];
@@ -255,7 +335,8 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             const float e = it.beta * fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, gc[j].x, gc[j].y), gc[j].z), gc[j].w);
             E[j] = lane_scan(e, it, pw16, pw32);
         }
-        float K = carries[(size_t)b * nt + t];
+        DTRACE(2);
+        float K = DMA ? Kcur : carries[(size_t)b * nt + t];
         float gprev[DY_SUB];          // g[n-1] for the first sample of each lane's group
 #pragma unroll
         for (int j = 0; j < DY_SUB; ++j) {
@@ -278,10 +359,12 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             const float e = fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, q[j].w, q[j].z), q[j].y), q[j].x);   // value leaving towards n-1
             Er[j] = lane_scan(dmirror(e), it, pw16, pw32);     // mirrored lane m = 63 - l; scan direction = decreasing time
         }
+        DTRACE(3);
         float R;
         if (W == 1) R = Rreg;
         else if (r == 0) R = 0.f;
         else { float dummy; mbox_wait(lds, mb_in, t + 1, R, dummy); }
+        DTRACE(4);
         {
             float Rn = R;
 #pragma unroll
@@ -289,6 +372,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             if (W == 1) Rreg = Rn;
             else if (t > 0) mbox_publish(lds, mb_out, Rn, 0.f, t);
         }
+        DTRACE(5);
 #pragma unroll
         for (int j = DY_SUB - 1; j >= 0; --j) {
             // r[n+1] for this lane's last sample: in mirrored space, the inclusive scan of the previous mirrored lane
@@ -310,22 +394,25 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             }
             q[j] = gside;    // dL/d(side chain sample)
         }
+        DTRACE(6);
         // gx = gy[n + look] * lin[n + look] + dL/ds  (functional.py:383-394 transposed)
         for (int c = 0; c < C; ++c) {
 #pragma unroll
             for (int j = 0; j < DY_SUB; ++j) {
                 const long p = base + dy_pos(j, lane, 0);
                 f4 lin;
-                if (look == 0) {
+                if (lk == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lin[i] = exp2f((gs[j][i] + it.makeup) * LOG2_PER_DB);
                 } else {
-                    lin = load4(lin_buf + (size_t)b * N, p + look, N, false);
+                    lin = load4(lin_buf + (size_t)b * N, p + lk, N, false);
                 }
-                const f4 g = load4(gb + (size_t)c * N, p + look, N, fast_in);
+                const f4 g = DMA ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : load4(gb + (size_t)c * N, p + lk, N, fast_in);
                 store4(gxb + (size_t)c * N, p, N, fast, g * lin + q[j]);
             }
         }
+        pending_stores = fast ? C * DY_SUB : 0;       // a full tile issues exactly C * DY_SUB wave-wide stores; anything else: wait for all
+        DTRACE(7);
     }
     float* po = partials + ((size_t)b * W + wave) * 5;
     const float v0 = wave_sum(acc_t), v1 = wave_sum(acc_r), v2 = wave_sum(acc_a), v3 = wave_sum(acc_w), v4 = wave_sum(acc_m);
@@ -372,6 +459,10 @@ inline bool dy_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15
 
 extern "C" {
 
+#ifdef DASP_TRACE
+int dasp_debug_dyn_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasp::g_dtrace), sizeof(long long) * 64); }
+#endif
+
 long dasp_dyn_num_tiles(long N) { return (N + DY_TS - 1) / DY_TS; }
 long dasp_dyn_carry_floats(long B, long N) { return B * dasp_dyn_num_tiles(N); }
 long dasp_dyn_partial_floats(long B) { return B * kDW * 5; }
@@ -400,12 +491,13 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
     if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
     if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_dyn_num_tiles(N), vec = (N % 4 == 0) && dy_al16(x) && dy_al16(gy) && dy_al16(gx);
-    if (mode == 0)
-        hipLaunchKernelGGL((dyn_bwd_kernel<0, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, gy, carries, lin_buf, gx,
-                           partials, C, (int)N, nt, vec, lookahead, sample_rate, eps);
-    else
-        hipLaunchKernelGGL((dyn_bwd_kernel<1, kDW>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, gy, carries, lin_buf, gx,
-                           partials, C, (int)N, nt, vec, lookahead, sample_rate, eps);
+    const bool dma = vec && lookahead == 0 && C <= 2;
+#define DASP_DYN_BWD(MODE_, DMA_)                                                                                                              \
+    hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_>), dim3(B), dim3(64 * kDW), 0, (hipStream_t)stream, x, ctl, gy, carries, lin_buf, gx, \
+                       partials, C, (int)N, nt, vec, lookahead, sample_rate, eps)
+    if (mode == 0) { if (dma) DASP_DYN_BWD(0, true); else DASP_DYN_BWD(0, false); }
+    else { if (dma) DASP_DYN_BWD(1, true); else DASP_DYN_BWD(1, false); }
+#undef DASP_DYN_BWD
     int st = dy_check();
     if (st != DASP_OK) return st;
     hipLaunchKernelGGL(dyn_finalize_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, ctl, B, kDW, sample_rate, gctl);

@@ -65,7 +65,8 @@ def test_compressor_golden(D, name):
 
 
 @pytest.mark.parametrize("B,C,N,look", [(1, 1, 1, 0), (2, 1, 7, 0), (1, 2, 255, 0), (2, 2, 1024, 0), (1, 3, 1025, 3), (2, 2, 9000, 0),
-                                        (3, 1, 8192 + 5, 64), (4, 2, 262144, 0)])
+                                        (3, 1, 8192 + 5, 64), (4, 2, 262144, 0),
+                                        (2, 1, 16384, 0), (2, 2, 8200, 0), (9, 2, 12288, 0)])   # LDS-DMA backward: mono, ragged last tile, more tiles than waves
 def test_compressor_shapes_vs_oracle(D, B, C, N, look):
     rng = np.random.default_rng(N + 17 * B)
     x = speechlike(rng, B, C, N) if N >= 1000 else (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
