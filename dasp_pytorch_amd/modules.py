@@ -17,6 +17,8 @@ columns of the parameter tensor), `num_params`, `process`, `process_normalized`,
 """
 from typing import Dict
 
+import functools
+
 import torch
 
 from . import functional as F
@@ -149,9 +151,13 @@ class Expander(_Dynamics):
 
 class NoiseShapedReverb(Processor):
     def __init__(self, sample_rate, min_band_gain: float = 0.0, max_band_gain: float = 1.0, min_band_decay: float = 0.0,
-                 max_band_decay: float = 1.0, min_mix: float = 0.0, max_mix: float = 1.0):
+                 max_band_decay: float = 1.0, min_mix: float = 0.0, max_mix: float = 1.0, num_samples: int = 65536,
+                 num_bandpass_taps: int = 1023, device_noise: bool = False):
+        """The last three arguments are additions to the reference's constructor (defaults = the reference's behaviour):
+        impulse-response length, filter-bank taps, and drawing the noise on the GPU instead of from the global CPU generator."""
         self.sample_rate = sample_rate
-        self.process_fn = F.noise_shaped_reverberation
+        self.process_fn = functools.partial(F.noise_shaped_reverberation, num_samples=num_samples, num_bandpass_taps=num_bandpass_taps,
+                                            device_noise=device_noise)
         self.param_ranges = {f"band{i}_gain": (min_band_gain, max_band_gain) for i in range(12)}
         self.param_ranges.update({f"band{i}_decay": (min_band_decay, max_band_decay) for i in range(12)})
         self.param_ranges["mix"] = (min_mix, max_mix)

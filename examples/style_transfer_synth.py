@@ -1,0 +1,137 @@
+"""BASELINE config 5 on synthetic data: the reference's style-transfer use case (examples/style_transfer.py in the reference:
+a network looks at an input clip and a reference clip and predicts the controls of an EQ -> compressor -> reverb chain, trained
+through the differentiable effects) as a data-parallel training step on MI355X.
+
+One process per GPU (python -m torch.distributed.run --nproc-per-node N examples/style_transfer_synth.py ...): every rank owns its
+own batch shard, the effect chain runs on the hand-written HIP kernels of dasp_pytorch_amd with no data-path collective, and the only
+exchange is the bucketed all-reduce of the predictor's gradients (dasp_pytorch_amd.distributed.allreduce_gradients, RCCL over xGMI).
+The predictor and the loss are ordinary PyTorch modules: they are the user's code around the hot path, not part of it.
+
+Prints one JSON line (rank 0): steps/s, clips/s, channel-samples/s through the chain, the loss trajectory.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dasp_pytorch_amd as D                      # noqa: E402
+from dasp_pytorch_amd import distributed as dd    # noqa: E402
+
+
+class ControlPredictor(torch.nn.Module):
+    """Strided 1-D conv encoder over (input, reference) -> one vector of normalised controls in (0, 1) per effect."""
+
+    def __init__(self, num_controls, width=32):
+        super().__init__()
+        chans = [2, width, width, 2 * width, 2 * width, 4 * width]
+        self.encoder = torch.nn.Sequential(*[
+            layer for i in range(5)
+            for layer in (torch.nn.Conv1d(chans[i], chans[i + 1], 31, stride=8, padding=15), torch.nn.PReLU(chans[i + 1]))])
+        self.head = torch.nn.Sequential(torch.nn.Linear(8 * width, 4 * width), torch.nn.PReLU(), torch.nn.Linear(4 * width, num_controls))
+
+    def forward(self, inp_mono, ref_mono):
+        h = self.encoder(torch.cat([inp_mono, ref_mono], 1))
+        h = torch.cat([h.mean(-1), h.amax(-1)], 1)
+        return torch.sigmoid(self.head(h))
+
+
+class EffectChain:
+    """EQ -> compressor -> reverb, controls normalised to (0, 1) (the reference's StyleTransferModel wiring)."""
+
+    def __init__(self, sample_rate, ir_samples=65536):
+        self.eq = D.ParametricEQ(sample_rate)
+        self.comp = D.Compressor(sample_rate)
+        self.verb = D.NoiseShapedReverb(sample_rate, num_samples=ir_samples, device_noise=True)
+        self.sizes = (self.eq.num_params, self.comp.num_params, self.verb.num_params)
+
+    @property
+    def num_controls(self):
+        return sum(self.sizes)
+
+    def __call__(self, x, controls):
+        pe, pc, pv = torch.split(controls, self.sizes, dim=1)
+        y = self.eq.process_normalized(x, pe)
+        y = self.comp.process_normalized(y, pc)
+        return self.verb.process_normalized(y, pv)
+
+
+def mrstft_loss(a, b, ffts=(512, 2048, 8192)):
+    """Spectral convergence + log-magnitude L1 at three resolutions (what auraloss.freq.MultiResolutionSTFTLoss measures)."""
+    a = a.reshape(-1, a.shape[-1]); b = b.reshape(-1, b.shape[-1])
+    total = 0.0
+    for n in ffts:
+        w = torch.hann_window(n, device=a.device)
+        A = torch.stft(a, n, n // 4, window=w, return_complex=True).abs().clamp_min(1e-7)
+        Bm = torch.stft(b, n, n // 4, window=w, return_complex=True).abs().clamp_min(1e-7)
+        total = total + torch.linalg.norm(Bm - A) / torch.linalg.norm(Bm) + (A.log() - Bm.log()).abs().mean()
+    return total / len(ffts)
+
+
+def synth_clips(batch, n, gen, device):
+    """Speech-like stand-in for the reference's vocal clips: pitched pulse train with a syllable envelope plus noise, peak 0.5."""
+    t = torch.arange(n, device=device) / 44100.0
+    f0 = 90 + 160 * torch.rand(batch, 1, device=device, generator=gen)
+    vib = 1 + 0.02 * torch.sin(2 * torch.pi * 5.5 * t)[None]
+    phase = 2 * torch.pi * torch.cumsum(f0 * vib / 44100.0, -1)
+    voiced = sum(torch.sin(k * phase) / k for k in range(1, 12))
+    env = (0.55 + 0.45 * torch.sin(2 * torch.pi * (2 + 3 * torch.rand(batch, 1, device=device, generator=gen)) * t[None])).clamp_min(0) ** 2
+    x = env * (voiced + 0.05 * torch.randn(batch, n, device=device, generator=gen))
+    x = 0.5 * x / x.abs().amax(-1, keepdim=True)
+    return x[:, None, :].repeat(1, 2, 1).contiguous()
+
+
+def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-3, width=32, seed=0, quiet=False):
+    rank, local, world = dd.env_world()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dd.init("nccl", dev)
+    torch.manual_seed(seed)                                   # identical predictor weights on every rank
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # different data per rank
+    chain = EffectChain(sample_rate, ir_samples)
+    model = ControlPredictor(chain.num_controls, width).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses, t0 = [], None
+    for step in range(steps + 1):                             # step 0 warms the caches / clocks and is not timed
+        if step == 1:
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            t0 = time.perf_counter()
+        x = synth_clips(batch, n, gen, dev)
+        with torch.no_grad():                                 # the "style": the same chain with hidden random controls
+            target = chain(x, torch.rand(batch, chain.num_controls, device=dev, generator=gen))
+        controls = model(x.mean(1, keepdim=True), target.mean(1, keepdim=True))
+        y = chain(x, controls)
+        loss = mrstft_loss(y, target)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        dd.allreduce_gradients(model.parameters())            # the one collective of the job
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = dd.max_over_ranks(time.perf_counter() - t0, dev) / max(steps, 1)
+    out = {"workload": "style-transfer chain EQ->compressor->reverb, predictor + MR-STFT loss, data parallel", "n_gpus": world,
+           "clip": [batch, 2, n], "ir_samples": ir_samples, "steps": steps, "s_per_step": dt, "clips_per_s": world * batch / dt,
+           "channel_samples_per_s": world * batch * 2 * n / dt, "loss_first": losses[0], "loss_last": losses[-1],
+           "finite": bool(all(map(lambda v: v == v and abs(v) != float("inf"), losses)))}
+    if rank == 0 and not quiet:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return out, model
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--samples", type=int, default=131072)
+    ap.add_argument("--ir-samples", type=int, default=65536)
+    a = ap.parse_args()
+    run(a.steps, a.batch, a.samples, ir_samples=a.ir_samples)
