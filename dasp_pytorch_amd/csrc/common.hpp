@@ -15,6 +15,26 @@ namespace dasp {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Streaming accesses to the big signal tensors (read once / written once per kernel): the non-temporal hint keeps them from
+// displacing each other in L2 / MALL. Measured on gain backward (2 read streams + 1 write stream, 805 MB): 0.160 -> 0.132 ms.
+#ifndef DASP_NT
+#define DASP_NT 1
+#endif
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) {
+#if DASP_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
+#if DASP_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -87,7 +107,7 @@ __device__ __forceinline__ void tile_load_full(const float* __restrict__ row, lo
     return;
 #endif
 #pragma unroll
-    for (int j = 0; j < L / 4; ++j) v[j] = *reinterpret_cast<const f4*>(row + base + (long)(j * 64 + lane) * 4);
+    for (int j = 0; j < L / 4; ++j) v[j] = ld_stream(reinterpret_cast<const f4*>(row + base + (long)(j * 64 + lane) * 4));
 }
 
 template <int L>
@@ -139,8 +159,8 @@ __device__ __forceinline__ void tile_lds_to_global_full(const float* tbuf, float
 #endif
 #pragma unroll
     for (int j = 0; j < L / 4; ++j)
-        *reinterpret_cast<f4*>(row + base + (long)(j * 64 + lane) * 4) =
-            *reinterpret_cast<const f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]);
+        st_stream(reinterpret_cast<f4*>(row + base + (long)(j * 64 + lane) * 4),
+                  *reinterpret_cast<const f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]));
 }
 template <int L>
 __device__ __forceinline__ void tile_lds_to_global_guarded(const float* tbuf, float* __restrict__ row, long base, long n_valid) {

@@ -120,8 +120,10 @@ __device__ __forceinline__ int dy_pos(int j, int lane, int i) { return j * 256 +
 template <int CREG>
 struct DynTile { f4 v[CREG > 0 ? CREG : 1][DY_SUB]; };
 
+// STREAM: last use of the data in this kernel (non-temporal hint); the first of two reads stays a plain load so that the second hits
+template <bool STREAM = false>
 __device__ __forceinline__ f4 load4(const float* __restrict__ p, long idx, long n_valid, bool fast) {
-    if (fast) return *reinterpret_cast<const f4*>(p + idx);
+    if (fast) return STREAM ? ld_stream(reinterpret_cast<const f4*>(p + idx)) : *reinterpret_cast<const f4*>(p + idx);
     f4 r;
     r.x = (idx + 0 >= 0 && idx + 0 < n_valid) ? p[idx + 0] : 0.f;
     r.y = (idx + 1 >= 0 && idx + 1 < n_valid) ? p[idx + 1] : 0.f;
@@ -130,7 +132,7 @@ __device__ __forceinline__ f4 load4(const float* __restrict__ p, long idx, long 
     return r;
 }
 __device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_valid, bool fast, f4 v) {
-    if (fast) { *reinterpret_cast<f4*>(p + idx) = v; return; }
+    if (fast) { st_stream(reinterpret_cast<f4*>(p + idx), v); return; }
     if (idx + 0 < n_valid) p[idx + 0] = v.x;
     if (idx + 1 < n_valid) p[idx + 1] = v.y;
     if (idx + 2 < n_valid) p[idx + 2] = v.z;
@@ -208,7 +210,7 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
 #pragma unroll
             for (int j = 0; j < DY_SUB; ++j) {
                 const long p = base + dy_pos(j, lane, 0);
-                const f4 xv = load4(xb + (size_t)c * N, p - look, N, fast_in);
+                const f4 xv = load4<true>(xb + (size_t)c * N, p - look, N, fast_in);
                 store4(yb + (size_t)c * N, p, N, fast, xv * s[j]);
             }
         }
@@ -222,9 +224,14 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
+#if DASP_NT
+#define DASP_GLDS_POLICY " nt"
+#else
+#define DASP_GLDS_POLICY ""
+#endif
 __device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
 }
 __device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
@@ -407,7 +414,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                 } else {
                     lin = load4(lin_buf + (size_t)b * N, p + lk, N, false);
                 }
-                const f4 g = DMA ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : load4(gb + (size_t)c * N, p + lk, N, fast_in);
+                const f4 g = DMA ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : load4<true>(gb + (size_t)c * N, p + lk, N, fast_in);
                 store4(gxb + (size_t)c * N, p, N, fast, g * lin + q[j]);
             }
         }

@@ -50,16 +50,17 @@ ew_kernel(const float* __restrict__ x, const float* __restrict__ ctl_db, const f
 #pragma unroll
         for (int j = 0; j < EW_SEG / (4 * EW_THREADS); ++j) {
             const long i = base + s0 + (long)(j * EW_THREADS + tid) * 4;
-            const f4 xv = *reinterpret_cast<const f4*>(x + i);
+            // backward: two read streams + one write stream -> streaming hints (0.160 -> 0.132 ms); forward is as fast without them
+            const f4 xv = BWD ? ld_stream(reinterpret_cast<const f4*>(x + i)) : *reinterpret_cast<const f4*>(x + i);
             f4 o;
             if (BWD) {
-                const f4 g = *reinterpret_cast<const f4*>(gy + i);
+                const f4 g = ld_stream(reinterpret_cast<const f4*>(gy + i));
                 o.x = ew_bwd<OP>(xv.x, g.x, lin, acc); o.y = ew_bwd<OP>(xv.y, g.y, lin, acc);
                 o.z = ew_bwd<OP>(xv.z, g.z, lin, acc); o.w = ew_bwd<OP>(xv.w, g.w, lin, acc);
             } else {
                 o.x = ew_fwd<OP>(xv.x, lin); o.y = ew_fwd<OP>(xv.y, lin); o.z = ew_fwd<OP>(xv.z, lin); o.w = ew_fwd<OP>(xv.w, lin);
             }
-            *reinterpret_cast<f4*>(out + i) = o;
+            if (BWD) st_stream(reinterpret_cast<f4*>(out + i), o); else *reinterpret_cast<f4*>(out + i) = o;
         }
     } else {
         for (long n = s0 + tid; n < s1; n += EW_THREADS)

@@ -538,7 +538,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         if (carries) {   // chunk start states for the backward pass: [row][tile][section][lane] f2, 512 B per wave store
             f2* cs = reinterpret_cast<f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < S; ++k) cs[k * 64] = st[k];
+            for (int k = 0; k < S; ++k) st_stream(cs + k * 64, st[k]);
         }
 
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
@@ -638,7 +638,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         tile_load_full<L>(gr, (long)tt * TS, vg);
         const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + tt) * S * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < S; ++k) vst[k] = cs[k * 64];
+        for (int k = 0; k < S; ++k) vst[k] = ld_stream(cs + k * 64);
     };
     if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_loads(nt - 1 - wave);
 
