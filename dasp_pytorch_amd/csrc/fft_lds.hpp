@@ -5,7 +5,7 @@
 //   fft512_wave  one 512-point transform per wave, no workgroup barriers      (row pass of the four-step long FFT)
 //   fft4096_split_fwd / _inv  one 4096-point transform per 512-thread workgroup as radix-8 x 512 with a single
 //                workgroup barrier                                             (filter bank, functional.py:548-558)
-//   col_fft      4096 / P transforms of P = 8..4096 points side by side in a 512-thread workgroup, radix-8 passes plus
+//   col_fft      4096 / P or 8192 / P transforms of P = 8..4096 points side by side in a 512- / 1024-thread workgroup, radix-8 passes plus
 //                one radix-2/4 pass                                           (column pass of the four-step long FFT)
 #pragma once
 #include "common.hpp"
@@ -163,12 +163,15 @@ __device__ __forceinline__ void fft4096_split_inv(float (&r)[8], float (&i)[8], 
     radix8<1>(r, i);
 }
 
-// ---- TC = 4096 / P transforms of P points side by side (batch index fastest in LDS and across lanes) ---------------
+// ---- TC = 2^LOGN / P transforms of P points side by side (batch index fastest in LDS and across lanes) ------------
+// A workgroup of 2^LOGN / 8 threads holds 2^LOGN elements. LOGN = 12: 512 threads; LOGN = 13: 1024 threads, at P = 256 a tile is then 32
+// columns wide, i.e. whole 128-byte lines of a float signal (pays in the epilogue kernels that read and write several float streams).
+template <int LOGN> struct ColGeom { static constexpr int N = 1 << LOGN, T = N / 8, LDS = N + N / 8; };
 struct ColCfg { int P, logP, T, TC, j, c; };      // thread (j, c): transform c, elements j + T q
-__device__ __forceinline__ ColCfg col_config(int logP, int t) {
+template <int LOGN> __device__ __forceinline__ ColCfg col_config(int logP, int t) {
     ColCfg g;
-    g.logP = logP; g.P = 1 << logP; g.T = g.P >> 3; g.TC = FFT_N >> logP;
-    g.c = t & (g.TC - 1); g.j = t >> (12 - logP);
+    g.logP = logP; g.P = 1 << logP; g.T = g.P >> 3; g.TC = (1 << LOGN) >> logP;
+    g.c = t & (g.TC - 1); g.j = t >> (LOGN - logP);
     return g;
 }
 __device__ __forceinline__ void col_exchange(float (&r)[8], float (&i)[8], f2* lds, const ColCfg& g, int wbase, int Ns) {

@@ -33,6 +33,9 @@ namespace dasp {
 
 constexpr int RV_BANDS_MAX = 16;
 constexpr int CV_NB = 512;                // row length of the four-step split
+constexpr int LOAD_LOG = 12, COLS_LOG = 13;   // workgroup size (log2 elements) of the forward / inverse column kernels: measured per kernel
+typedef ColGeom<LOAD_LOG> LoadGeom;
+typedef ColGeom<COLS_LOG> ColsGeom;
 
 // ---- fused filter bank ---------------------------------------------------------------------------------------------
 // spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096
@@ -161,20 +164,19 @@ __device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (
     for (int q = 1; q < 8; ++q) { wr[q] = wr[q - 1] * c1 - wi[q - 1] * s1; wi[q] = wr[q - 1] * s1 + wi[q - 1] * c1; }
 }
 
-// Workgroups are dealt round-robin to the 8 XCDs in launch order. A column tile is only 16 floats (64 B) wide on the signal side, so the
-// two halves of every 128-byte line belong to neighbouring tiles: give each XCD a contiguous run of tiles, so that both halves meet in
-// the same L2 instead of being fetched from HBM twice.
+// Workgroups are dealt round-robin to the 8 XCDs in launch order; neighbouring column tiles touch neighbouring (at small NA: the same)
+// 128-byte lines of the signal, so each XCD gets a contiguous run of tiles and the shared lines meet in one L2.
 __device__ __forceinline__ int xcd_tile(int bx, int nx) { return (nx & 7) ? bx : (bx & 7) * (nx >> 3) + (bx >> 3); }
 
-// Column pass, time -> A[ka][jb]. grid (NA / 8 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
+// Column pass, time -> A[ka][jb]. grid (NA * 512 / 4096 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
 //                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of mix * gy, k = 2p, 2p+1
 //                                 MODE 2: zero-padded impulse responses (L samples per row), imaginary part 0
 template <int MODE>
-__global__ __launch_bounds__(FFT_T) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
+__global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
                                                           f2* __restrict__ A, ConvDims d, int L) {
-    __shared__ f2 lds[FFT_LDS];
-    const ColCfg g = col_config(d.logNA, threadIdx.x);
+    __shared__ f2 lds[LoadGeom::LDS];
+    const ColCfg g = col_config<LOAD_LOG>(d.logNA, threadIdx.x);
     const int p = blockIdx.y;
     const long sig = blockIdx.z;
     const int jb = xcd_tile(blockIdx.x, gridDim.x) * g.TC + g.c;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
     if (MODE == 1) store_time(Pout + sig * (long)d.n1, pr, pi);
 }
 
-// Inverse column pass + epilogue. 512 threads; thread (j, c) as in conv_load_kernel; registers q < 4 are the lower half of the frame
+// Inverse column pass + epilogue. 1024 threads, 8192-element tiles; thread (j, c) as in conv_load_kernel; registers q < 4 are the lower half of the frame
 // (r = (j + T q) 512 + jb < Lb), q >= 4 the upper half (r + Lb).
 //   MODE 0  grid (tiles, signals): for p = 0..: y[2p Lb + r] = Re lo + carry, y[(2p+1) Lb + r] = Im lo + Re hi, carry = Im hi;
 //           then y = x + mix (wet - x) (:575); wet saved for the mix gradient when `wet` is not null
@@ -277,12 +279,12 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
 //           mix_part[sig][p * tiles + tile] = sum gy (wet - x)
 //   MODE 2  grid (tiles, signals): gir[sig][r] = Re lo, r < L
 template <int MODE>
-__global__ __launch_bounds__(FFT_T) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
+__global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
                                                           const float* __restrict__ gy, const float* __restrict__ mix, float* __restrict__ wet,
                                                           float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L) {
-    __shared__ f2 lds[FFT_LDS];
-    __shared__ float red[FFT_T / 64];
-    const ColCfg g = col_config(d.logNA, threadIdx.x);
+    __shared__ f2 lds[ColsGeom::LDS];
+    __shared__ float red[ColsGeom::T / 64];
+    const ColCfg g = col_config<COLS_LOG>(d.logNA, threadIdx.x);
     const long sig = MODE == 1 ? blockIdx.z : blockIdx.y;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const float inv = 1.f / (float)d.n1;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(FFT_T) void conv_cols_kernel(const f2* __restrict__
         __syncthreads();
         if (threadIdx.x == 0) {
             float a = 0.f;
-            for (int v = 0; v < FFT_T / 64; ++v) a += red[v];
+            for (int v = 0; v < ColsGeom::T / 64; ++v) a += red[v];
             mix_part[(sig * d.npairs + blockIdx.y) * gridDim.x + blockIdx.x] = a;
         }
     }
@@ -380,10 +382,10 @@ inline int rv_check() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
 }
-struct RvDims { ConvDims c; int nblk, VQ, nwin, tiles; long R; };
+struct RvDims { ConvDims c; int nblk, VQ, nwin, ltiles, ctiles, rowgroups; long R; };
 inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     RvDims d;
-    long Lb = 2048;                                  // n1 >= 4096 keeps every workgroup of the four-step kernels full
+    long Lb = ColsGeom::N / 2;                       // n1 >= 8192 keeps every workgroup of the four-step kernels full
     while (Lb < L) Lb <<= 1;
     if (Lb > (1L << 20)) return false;               // NA = n1 / 512 <= 4096
     d.c.Lb = (int)Lb; d.c.n1 = 2 * d.c.Lb; d.c.NA = d.c.n1 / CV_NB;
@@ -391,7 +393,9 @@ inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     d.c.N = N;
     d.nblk = (int)((N + Lb - 1) / Lb);
     d.c.npairs = (d.nblk + 1) / 2;
-    d.tiles = d.c.NA / 8;
+    d.ltiles = (int)((long)d.c.NA * CV_NB / LoadGeom::N);   // column tiles of the forward / inverse column kernels
+    d.ctiles = (int)((long)d.c.NA * CV_NB / ColsGeom::N);
+    d.rowgroups = d.c.NA / 8;                        // 8 rows (waves) per workgroup of the row pass
     d.R = 2L * B;
     d.VQ = (FFT_N - (taps - 1)) / 512;              // valid outputs per filter-bank window = 512 VQ
     if (d.VQ < 1) return false;                      // filters longer than 3585 taps do not fit the 4096-point window
@@ -417,7 +421,7 @@ int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     sizes[4] = (long)(nb + 1) * FFT_N; sizes[5] = d.nwin;
     sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = d.R * d.c.n1;
     sizes[8] = d.R * L; sizes[9] = d.R * N;
-    sizes[10] = d.R * d.c.npairs * d.tiles; sizes[11] = (long)B * d.nwin * nb * 2;
+    sizes[10] = d.R * d.c.npairs * d.ctiles; sizes[11] = (long)B * d.nwin * nb * 2;
     return DASP_OK;
 }
 
@@ -447,16 +451,16 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
     hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, ir, (const float*)nullptr,
                        (float*)nullptr, nb, L, taps, d.VQ);
     // 2. their spectra, in the permuted four-step order
-    hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.tiles, 1, (unsigned)d.R), dim3(FFT_T), 0, st, (const float*)ir, (const float*)nullptr, tw,
+    hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.ltiles, 1, (unsigned)d.R), dim3(LoadGeom::T), 0, st, (const float*)ir, (const float*)nullptr, tw,
                        (f2*)Ah, ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N}, L);
-    hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, (f2*)H,
+    hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, (f2*)H,
                        (f2*)nullptr, (f2*)nullptr, ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N});
     // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
-    hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.tiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(FFT_T), 0, st, x, (const float*)nullptr,
+    hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(LoadGeom::T), 0, st, x, (const float*)nullptr,
                        tw, (f2*)A, d.c, L);
-    hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)A, (const f2*)nullptr, tw, (f2*)H,
+    hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.rowgroups, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)A, (const f2*)nullptr, tw, (f2*)H,
                        (f2*)W, (f2*)nullptr, d.c);
-    hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)W, tw, x, (const float*)nullptr, mix,
+    hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.ctiles, (unsigned)d.R), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x, (const float*)nullptr, mix,
                        wet, y, (float*)nullptr, d.c, L);
     return rv_check();
 }
@@ -476,13 +480,13 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
     hipStream_t st = (hipStream_t)stream;
     const f2* tw = (const f2*)Fspec;
     // overlapped windows of mix * gy -> column transforms
-    hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.tiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(FFT_T), 0, st, gy, mix, tw, (f2*)Ag, d.c, L);
+    hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(LoadGeom::T), 0, st, gy, mix, tw, (f2*)Ag, d.c, L);
     // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
-    hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A, tw, (f2*)H, (f2*)W,
+    hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A, tw, (f2*)H, (f2*)W,
                        (f2*)P, d.c);
-    hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.tiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)W, tw, x, gy, mix,
+    hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x, gy, mix,
                        (float*)wet, gx, mix_part, d.c, L);
-    hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.tiles, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)P, tw, (const float*)nullptr,
+    hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, (unsigned)d.R), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, gir, (float*)nullptr,
                        ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N}, L);
     // d/dgain, d/ddecay: the filter bank again, weighted by gir
@@ -490,7 +494,7 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
                        (const float*)gir, part, nb, L, taps, d.VQ);
     const int nfin = B * nb > B ? B * nb : B;
     hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
-                       d.c.npairs * d.tiles);
+                       d.c.npairs * d.ctiles);
     return rv_check();
 }
 

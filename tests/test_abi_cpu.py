@@ -51,7 +51,7 @@ def test_reverb_size_query():
     assert (Lb, n1, pairs, nblk) == (65536, 131072, 2, 4)
     assert sizes[4] == 13 * 4096 and sizes[5] == -(-65536 // 3072)            # twiddles + 12 band spectra; 3072 valid samples per window
     assert sizes[6] == 256 * pairs * n1 and sizes[7] == 256 * n1 and sizes[8] == 256 * 65536 and sizes[9] == 256 * 262144
-    assert L.dasp_reverb_sizes(1, 5000, 1000, 63, 12, sizes) == 0 and (sizes[0], sizes[3], sizes[2]) == (2048, 3, 2)   # odd block count: zero partner
+    assert L.dasp_reverb_sizes(1, 9000, 1000, 63, 12, sizes) == 0 and (sizes[0], sizes[3], sizes[2]) == (4096, 3, 2)   # minimum block; odd block count: zero partner
     assert L.dasp_reverb_sizes(1, 1000, 4096, 3587, 12, sizes) == -2         # filter longer than the filter-bank window
     assert L.dasp_reverb_sizes(1, 1000, (1 << 20) + 1, 63, 12, sizes) == -2  # impulse response beyond 2^20 samples
     assert L.dasp_reverb_sizes(1, 1000, 4096, 63, 17, sizes) == -1           # more than 16 bands
