@@ -27,6 +27,7 @@ SIGNATURES = {
     "dasp_sos_partial_floats": (_l, [_l, _i]),
     "dasp_sos_prepare": (_i, [_p, _i, _i, _p, _p, _p]),
     "dasp_peq_prepare": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p]),
+    "dasp_peq_prepare_rows": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p]),
     "dasp_sosfilt_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sosfilt_backward": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sos_grad_finalize": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),

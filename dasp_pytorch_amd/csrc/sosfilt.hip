@@ -106,6 +106,7 @@ __device__ __forceinline__ D1 dexp(D1 a) { const double e = exp(a.v); return {e,
 struct PeqSpec {
     int types[8];        // 0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass
     double sample_rate;
+    const float* rows[24];   // optional: the 3 S controls as separate vectors of Bs values ([3 k + dir]); used when `params` is null
 };
 
 // RBJ cookbook design, same formulas as dasp_pytorch/signal.py:255-304, in fp64 with the Jacobian
@@ -187,6 +188,9 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         if (params) {
             const float* p = params + ((size_t)item * S + k) * 3;
             rbj_design(spec.types[k], spec.sample_rate, (double)p[0], (double)p[1], (double)p[2], dir, c5, dc5);
+        } else if (!sos) {
+            rbj_design(spec.types[k], spec.sample_rate, (double)spec.rows[3 * k][item], (double)spec.rows[3 * k + 1][item],
+                       (double)spec.rows[3 * k + 2][item], dir, c5, dc5);
         } else {
             const float* s = sos + ((size_t)item * S + k) * 6;
             a0 = (double)s[3];
@@ -812,7 +816,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // Finalize: one thread per (item, section). mode 0: gradient w.r.t. sos (B,S,6) as given (a0 included);
-// mode 1: gradient w.r.t. (gain_db, cutoff_freq, q_factor) (B,S,3) through the RBJ design Jacobian.
+// mode 1: gradient w.r.t. (gain_db, cutoff_freq, q_factor) (B,S,3) through the RBJ design Jacobian; mode 2: the same as 3 S rows of
+// B values ([3 k + dir][item]: one contiguous gradient vector per control tensor of parametric_eq).
 __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
                                     int B, int C, int S, int Wb, int mode, float* __restrict__ gout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -836,11 +841,11 @@ __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bca
         o[3] = (float)(-dot / a0);
         o[4] = (float)(g5[3] / a0); o[5] = (float)(g5[4] / a0);
     } else {
-        float* o = gout + (size_t)idx * 3;
         for (int i = 0; i < 3; ++i) {
             double s = 0.0;
             for (int c = 0; c < 5; ++c) s += g5[c] * d[DT_J + c * 3 + i];
-            o[i] = (float)s;
+            if (mode == 1) gout[(size_t)idx * 3 + i] = (float)s;
+            else gout[(size_t)(3 * k + i) * B + item] = (float)s;
         }
     }
 }
@@ -929,6 +934,28 @@ int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, doubl
     });
 }
 
+/* The same design from 3 S separate control vectors (host array of device pointers, [3 k + dir] -> Bs values): what
+ * functional.parametric_eq receives (functional.py:118-139), without packing them first. */
+int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
+                          void* stream) {
+    if (!rows || !types || !tab || !dtab || Bs <= 0 || S > 8 || S <= 0) return DASP_ERR_ARG;
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        PeqSpec spec = {};
+        for (int i = 0; i < S; ++i) {
+            if (types[i] < 0 || types[i] > 4) return DASP_ERR_ARG;
+            spec.types[i] = types[i];
+        }
+        for (int i = 0; i < 3 * S; ++i) {
+            if (!rows[i]) return DASP_ERR_ARG;
+            spec.rows[i] = rows[i];
+        }
+        spec.sample_rate = sample_rate;
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bs), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab);
+        return check_launch();
+    });
+}
+
 int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries, int B, int C, long N,
                          int S, void* stream) {
     if (!tab || !x || !y || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B)) return DASP_ERR_ARG;
@@ -961,7 +988,7 @@ int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float*
 // mode 0: gout (B,S,6) = dL/dsos ; mode 1: gout (B,S,3) = dL/d(gain_db, cutoff_freq, q_factor)
 int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S, int mode,
                            float* gout, void* stream) {
-    if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || (mode != 0 && mode != 1))
+    if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2)
         return DASP_ERR_ARG;
     const int n = B * S;
     hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,

@@ -51,10 +51,11 @@ class _SosWork:
         partials = torch.empty(L.dasp_sos_partial_floats(B * C, self.S), dtype=torch.float32, device=x.device)
         call("dasp_sosfilt_backward", ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(partials),
                                       B, C, N, self.S, stream())
-        gout = torch.empty(B, self.S, 6 if mode == 0 else 3, dtype=torch.float32, device=x.device)
+        shape = (B, self.S, 6) if mode == 0 else (B, self.S, 3) if mode == 1 else (3 * self.S, B)
+        gout = torch.empty(shape, dtype=torch.float32, device=x.device)
         call("dasp_sos_grad_finalize", ptr(self.dtab), self.Bs, ptr(partials), B, C, self.S, mode, ptr(gout), stream())
         if self.Bs == 1 and B != 1:
-            gout = gout.sum(0, keepdim=True)
+            gout = gout.sum(1 if mode == 2 else 0, keepdim=True)
         return gx, gout
 
 
@@ -105,14 +106,16 @@ class ParametricEQFunction(torch.autograd.Function):
         S = len(types)
         if not L.dasp_sos_supported_sections(S):
             raise ValueError(f"no kernel compiled for {S} sections")
-        cols = [c.detach().reshape(-1).to(device=x.device, dtype=torch.float32) for c in controls]
+        cols = [c.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous() for c in controls]   # views when already fp32
         Bp = cols[0].numel()
-        p32 = torch.stack(cols, dim=1)                      # (Bp, 3S) == (Bp, S, 3) rows
+        if any(c.numel() != Bp for c in cols):
+            raise ValueError("parametric_eq controls must all have the same number of elements")
         x32 = _f32c(x)
         need = any(ctx.needs_input_grad)
         w = _SosWork(Bp, S, x.device)
         ctypes_types = (ctypes.c_int * S)(*types)
-        call("dasp_peq_prepare", ptr(p32), Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream())
+        rows = (ctypes.c_void_p * (3 * S))(*[c.data_ptr() for c in cols])        # read by the design kernel in place: no packing copy
+        call("dasp_peq_prepare_rows", rows, Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream())
         y = w.forward(x32, need)
         if need:
             ctx.work = w
@@ -124,8 +127,7 @@ class ParametricEQFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (x32,) = ctx.saved_tensors
-        gx, gp = ctx.work.backward(x32, _f32c(gy), 1)        # gp (Bp, S, 3)
-        gpt = gp.reshape(gp.shape[0], -1).t().contiguous()   # (3S, Bp): one small transpose kernel
+        gx, gpt = ctx.work.backward(x32, _f32c(gy), 2)       # (3S, Bp): one contiguous gradient row per control tensor
         gcols = tuple(gpt[i].reshape(shape).to(dt) if need else None
                       for i, ((dt, shape), need) in enumerate(zip(ctx.ctl, ctx.needs_input_grad[3:])))
         return (gx.to(ctx.x_dtype) if ctx.needs_input_grad[0] else None, None, None) + gcols

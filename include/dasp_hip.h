@@ -47,6 +47,10 @@ int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, 
  * 0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass (signal.py:261-297). */
 int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, double sample_rate,
                      float* tab, double* dtab, void* stream);
+/* The same from 3*S separate control vectors: rows = host array of device pointers, rows[3*k + c] -> Bs values of control c
+ * (0 gain_db, 1 cutoff_freq, 2 q_factor) of section k - the tensors functional.parametric_eq receives (functional.py:118-139). */
+int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab,
+                          double* dtab, void* stream);
 
 /* y = cascade(x). carries (may be NULL when no backward follows) receives the state of every lane chunk
  * (dasp_sos_carry_floats(rows, N, S) floats = 2*S per dasp_sos_chunk() samples); the backward pass reads it
