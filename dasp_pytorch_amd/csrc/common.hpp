@@ -82,6 +82,30 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS-DMA: 16 (4) bytes per active lane straight from global memory into LDS at (wave-uniform dst) + 16 (4) * lane, no staging
+// registers; completion is counted by vmcnt. Issued as inline asm on purpose: hipcc answers the builtin form with a vmcnt(0) in front
+// of every later LDS read, which would serialise the prefetch it is meant to overlap; here the waits are placed by hand
+// (M0 = LDS destination base, saved and restored inside the statement because the compiler owns it).
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+#if DASP_NT
+#define DASP_GLDS_POLICY " nt"
+#else
+#define DASP_GLDS_POLICY ""
+#endif
+__device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+}
+
+
 // ---- coalesced tile <-> per-lane chunk transposition through a wave-private LDS buffer ---------
 // A tile is 64*L consecutive samples of one row. Global side: lane l, vector j holds samples
 // [j*256 + 4l, +4) (1 KiB per wave instruction). Register side: lane l holds the L consecutive
@@ -96,6 +120,27 @@ __device__ __forceinline__ bool tile_full(long base, long n_valid, bool vec) { r
 
 template <int L>
 __device__ __forceinline__ int tile_lds_index(int m) { return (m / L) * (L + 4) + (m % L); }
+
+// LDS-DMA of a full tile into the padded chunk layout above: in 16-byte granules a chunk is L/4 data slots + 1 pad slot, so the
+// 64 (L/4 + 1) slots of a tile are L/4 + 1 wave instructions of 64 consecutive slots; a lane whose slot is a pad stays off, the
+// others fetch the granule that belongs there (the source address is per lane, the destination is lane-linear).
+template <int L> struct TileDma { int goff[L / 4 + 1]; bool on[L / 4 + 1]; };
+template <int L> __device__ __forceinline__ TileDma<L> tile_dma_plan(int lane) {
+    constexpr int GPC = L / 4, SLOTS = GPC + 1;
+    TileDma<L> p;
+#pragma unroll
+    for (int m = 0; m < SLOTS; ++m) {
+        const int G = 64 * m + lane, c = G / SLOTS, k = G - c * SLOTS;
+        p.on[m] = k < GPC;
+        p.goff[m] = (c * GPC + k) * 4;        // floats from the tile start
+    }
+    return p;
+}
+template <int L> __device__ __forceinline__ void tile_dma_issue(const float* __restrict__ tile, unsigned lds_bytes, const TileDma<L>& p) {
+#pragma unroll
+    for (int m = 0; m < L / 4 + 1; ++m)
+        if (p.on[m]) glds16(tile + p.goff[m], lds_bytes + 1024 * m);
+}
 
 // issue the coalesced loads of a full tile (results are consumed by tile_regs_to_lds)
 template <int L>
@@ -129,23 +174,22 @@ __device__ __forceinline__ void tile_global_to_lds_guarded(float* tbuf, const fl
     wave_lds_sync();
 }
 
+// `chunk` = which chunk of the tile this lane takes (default: its own lane number; the backward kernel uses 63 - lane)
 template <int L>
-__device__ __forceinline__ void lds_to_chunks(const float* tbuf, float (&X)[L]) {
-    const int lane = lane_id();
+__device__ __forceinline__ void lds_to_chunks(const float* tbuf, float (&X)[L], int chunk = lane_id()) {
 #pragma unroll
     for (int i = 0; i < L / 4; ++i) {
-        const f4 q = *reinterpret_cast<const f4*>(&tbuf[lane * (L + 4) + 4 * i]);
+        const f4 q = *reinterpret_cast<const f4*>(&tbuf[chunk * (L + 4) + 4 * i]);
         X[4 * i + 0] = q.x; X[4 * i + 1] = q.y; X[4 * i + 2] = q.z; X[4 * i + 3] = q.w;
     }
 }
 
 template <int L>
-__device__ __forceinline__ void chunks_to_lds(float* tbuf, const float (&X)[L]) {
-    const int lane = lane_id();
+__device__ __forceinline__ void chunks_to_lds(float* tbuf, const float (&X)[L], int chunk = lane_id()) {
     wave_lds_sync();
 #pragma unroll
     for (int i = 0; i < L / 4; ++i) {
-        *reinterpret_cast<f4*>(&tbuf[lane * (L + 4) + 4 * i]) = f4{X[4 * i + 0], X[4 * i + 1], X[4 * i + 2], X[4 * i + 3]};
+        *reinterpret_cast<f4*>(&tbuf[chunk * (L + 4) + 4 * i]) = f4{X[4 * i + 0], X[4 * i + 1], X[4 * i + 2], X[4 * i + 3]};
     }
     wave_lds_sync();
 }

@@ -217,29 +217,6 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
     }
 }
 
-// LDS-DMA: 16 (4) bytes per active lane straight from global memory into LDS at (wave-uniform dst) + 16 (4) * lane, no staging
-// registers; completion is counted by vmcnt. Issued as inline asm on purpose: hipcc answers the builtin form with a vmcnt(0) in front
-// of every later LDS read, which would serialise the prefetch it is meant to overlap; here the waits are placed by hand
-// (M0 = LDS destination base, saved and restored inside the statement because the compiler owns it).
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
-}
-#if DASP_NT
-#define DASP_GLDS_POLICY " nt"
-#else
-#define DASP_GLDS_POLICY ""
-#endif
-__device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
-}
-__device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
-}
-
 // ------------------------------------------------------------------------------------------------
 // Backward. Walks the tiles in reverse; recomputes the forward gain from the saved tile carries,
 // runs the adjoint one-pole scan on lane-mirrored data, accumulates the control gradients.

@@ -23,11 +23,11 @@
 // (5) every lane runs the S-section cascade over its L samples from its exact start state with the
 //     section coefficients held in VGPRs (VALU ops with SGPR operands issue at half rate on gfx950);
 // (6) LDS transpose back -> coalesced float4 stores.
-// The backward kernel walks the tiles in reverse: it recomputes the forward chunk states from the
-// per-tile carries the forward pass saved, keeps s2_k[n] (= om_k * w_k[n-2], the all-pole signal)
-// in registers, runs the adjoint cascade (sections reversed, transposed realisation; its lane scan
-// runs on lane-mirrored data so that it can use the same DPP machinery) and accumulates the five
-// coefficient correlations per section; a finalize kernel reduces them in fp64.
+// The backward kernel walks the tiles in reverse with lane l on chunk 63 - l (so that the adjoint lane scan, which runs from
+// the last chunk to the first, is an ordinary ascending DPP scan): the next tile's x, gy and the chunk start states the forward
+// pass saved arrive by LDS-DMA while the current tile is processed; it recomputes s2_k[n] (= om_k * w_k[n-2], the all-pole
+// signal) of every section into registers, runs the adjoint cascade (sections reversed, transposed realisation) and accumulates
+// the five coefficient correlations per section; a finalize kernel reduces them in fp64.
 #include "common.hpp"
 #include <type_traits>
 
@@ -592,31 +592,32 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
-    constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4, H = S / 2, SH = S - H;   // SH >= H
+    // S <= 6: the s2 signals of all sections stay in registers (H = 0). S = 8: the lower half is parked in LDS (H = S / 2).
+    constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4, H = S > 6 ? S / 2 : 0, SH = S - H;   // SH >= H
     constexpr int NSTASH4 = (H * (L + 2) + 3) / 4;                 // float4 per lane of parked s2 signals
-    constexpr int REGION = (2 * 64 * LP > 64 * 4 * NSTASH4) ? 2 * 64 * LP : 64 * 4 * NSTASH4;   // floats per wave
+    // per wave: x landing image, gy landing image, gx staging image (padded chunk layout), saved chunk states, parked signals
+    constexpr int IMG = 64 * LP, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
     constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + 2 * LDS_PW + LDS_CF];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
     float* __restrict__ gxr = gx + (size_t)row * N;
-    float* tbx = lds + wave * REGION;              // x image, later the parked s2 signals, finally the gx image
-    float* tbg = tbx + 64 * LP;                    // gy image
+    float* tbx = lds + wave * REGION;              // x image of this tile; receives the next tile's as soon as it has been read
+    float* tbg = tbx + IMG;                        // gy image, likewise
+    float* tbo = tbg + IMG;                        // gx image on its way out
+    float* tst = tbo + IMG;                        // chunk start states [section][lane] f2
+    float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
     const int mb_in = LDS_T + wave * S * 4, mb_out = LDS_T + ((wave + 1) % W) * S * 4;
     float* pw_lds = lds + LDS_T + LDS_MB;
-    float* cf_lds = pw_lds + 2 * LDS_PW;
+    float* cf_lds = pw_lds + LDS_PW;
     for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[LDS_T + i] = 0.f;
-    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) {
-        pw_lds[i] = tb[LY::PW + i];
-        pw_lds[LDS_PW + i] = tb[LY::PWA + i];
-    }
+    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < LDS_CF; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
     __syncthreads();
-    const f4* pws = reinterpret_cast<const f4*>(pw_lds);
-    const f4* pwa = reinterpret_cast<const f4*>(pw_lds + LDS_PW);
+    const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
     f2 Kreg[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
@@ -627,24 +628,22 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         acca[k][0] = acca[k][1] = 0.f;
     }
 
-    // Register prefetch of the next tile (x, gy and the saved chunk states): issued at the start of the last adjoint
-    // half, when the upper half's s2 registers are dead, and consumed at the top of the next iteration. Without it a
-    // wave has ~11 KB in flight for ~2 us out of every ~10 us and the kernel is bound by memory latency
-    // (bytes in flight / latency), not by bandwidth or issue.
-    f4 vx[L / 4], vg[L / 4];
-    f2 vst[S];
+    // LDS-DMA prefetch of the next tile (x, gy and the saved chunk states): issued as soon as this tile's images have been read into
+    // registers, i.e. a whole tile time before it is needed, with no staging registers (the register-staged prefetch this replaces
+    // could only be issued for the last fifth of a tile and left ~2.8k of every ~18k cycles waiting on vmcnt). vmcnt is in order on
+    // gfx9, so the wait at the top of a tile lets the previous tile's L/4 gx stores stay in flight.
+    const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
+                   a_s = __builtin_amdgcn_readfirstlane(lds_addr(tst));
+    auto issue_dma = [&](int tt) {
+        const TileDma<L> plan = tile_dma_plan<L>(lane + opaque_zero());     // recomputed per tile: cheaper than keeping it live
+        tile_dma_issue<L>(xr + (size_t)tt * TS, a_x, plan);
+        tile_dma_issue<L>(gr + (size_t)tt * TS, a_g, plan);
+        const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
 #pragma unroll
-    for (int j = 0; j < L / 4; ++j) { vx[j] = f4{0.f, 0.f, 0.f, 0.f}; vg[j] = f4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int k = 0; k < S; ++k) vst[k] = f2{0.f, 0.f};
-    auto issue_loads = [&](int tt) {
-        tile_load_full<L>(xr, (long)tt * TS, vx);
-        tile_load_full<L>(gr, (long)tt * TS, vg);
-        const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + tt) * S * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < S; ++k) vst[k] = ld_stream(cs + k * 64);
+        for (int m = 0; m < S / 2; ++m) glds16(cs + m * 256, a_s + 1024 * m);
     };
-    if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_loads(nt - 1 - wave);
+    if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_dma(nt - 1 - wave);
+    int stores_in_flight = 0;
 
     for (int r = wave; r < nt; r += W) {
         const int t = nt - 1 - r;
@@ -655,32 +654,37 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         float X[L], GY[L];
         TRACE(16);
         if (full) {
-            tile_regs_to_lds<L>(tbx, vx);
-            tile_regs_to_lds<L>(tbg, vg);
+            if (stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             tile_global_to_lds_guarded<L>(tbx, xr, (long)t * TS, N);
             tile_global_to_lds_guarded<L>(tbg, gr, (long)t * TS, N);
         }
-        lds_to_chunks<L>(tbx, X);
-        lds_to_chunks<L>(tbg, GY);
+        // Lane l works on chunk 63 - l for the whole tile: the adjoint scan runs from the last chunk to the first, and with the
+        // chunks dealt out in that order it is an ordinary ascending lane scan - no lane mirroring (ds_bpermute) of its inputs and
+        // outputs. Everything else in this kernel is per chunk and does not care which lane owns which.
+        const int cl = 63 - lane;
+        lds_to_chunks<L>(tbx, X, cl);
+        lds_to_chunks<L>(tbg, GY, cl);
         pin(X); pin(GY); TRACE(17);
         // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
         //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
         f2 st[S];
         if (full) {
 #pragma unroll
-            for (int k = 0; k < S; ++k) st[k] = vst[k];
+            for (int k = 0; k < S; ++k) st[k] = *reinterpret_cast<const f2*>(tst + (k * 64 + cl) * 2);
         } else {
-            const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
+            const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + t) * S * 64 + cl;
 #pragma unroll
             for (int k = 0; k < S; ++k) st[k] = cs[k * 64];
         }
         pin(st); TRACE(18);
-        // ---- adjoint chunk end states: the scan runs from lane 63 down to lane 0, done on lane-mirrored data ----
+        if (r + W < nt) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full
+        // ---- adjoint chunk end states: the scan runs from the last chunk to the first = ascending lanes (chunk 63 - lane) ----
         f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
         {
             MboxPeek pk;
-            tile_scan<S, L>(GY, tbl + LY::GAT, [](f2 v) { return f2{wave_mirror(v.x), wave_mirror(v.y)}; }, lam,
+            tile_scan<S, L>(GY, tbl + LY::GAT, [](f2 v) { return v; }, lam,
                 tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
                 [&](int i) { if (W > 1 && r > 0) pk = mbox_peek(lds, mb_in + 4 * i); },
                 [&](int i, f2& K) {
@@ -693,8 +697,6 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                     if (W == 1) Kreg[i] = Kn;
                     else if (t > 0) mbox_publish(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
                 });
-#pragma unroll
-            for (int i = 0; i < S; ++i) lam[i] = f2{wave_mirror(lam[i].x), wave_mirror(lam[i].y)};
         }
         pin(X); pin(GY); pin(st); pin(lam);   // scans done before the cascade passes start
         TRACE(19);
@@ -752,7 +754,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #pragma unroll
             for (int k = 0; k < H; ++k) forward_keep(k, k, oz);
             wave_lds_sync();
-            f4* stash = reinterpret_cast<f4*>(tbx) + lane;
+            f4* stash = reinterpret_cast<f4*>(tpk) + lane;
 #pragma unroll
             for (int j = 0; j < NSTASH4; ++j) {
                 f4 v;
@@ -765,23 +767,23 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        {   // upper half: forward keeping its s2 signals in registers, then its adjoint
-            const int oz = opaque_zero_after(X[0]);
+        {   // upper half (all sections when H = 0): forward keeping its s2 signals in registers, then its adjoint. Every section's
+            // coefficient load is chained behind the previous section's result: left free, the scheduler issues all of them up
+            // front and the S coefficient sets (8 registers each) are live on top of the s2 signals.
 #pragma unroll
-            for (int k = H; k < S; ++k) forward_keep(k, k - H, oz);
+            for (int k = H; k < S; ++k) forward_keep(k, k - H, opaque_zero_after(X[0]));
             pin(S2v); pin(GY);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = S - 1; k >= H; --k) adjoint(k, k - H, oz);
+            for (int k = S - 1; k >= H; --k) adjoint(k, k - H, opaque_zero_after(GY[0]));
         }
         pin(GY);
         __builtin_amdgcn_sched_barrier(0);
         {   // lower half adjoint with the parked signals (chained behind the upper half so that the two sets of
             // s2 registers are not live at once)
             const int oz = opaque_zero_after(GY[0]);
-            if (r + W < nt) issue_loads(t - W);   // tiles below the row's last one are always full when this one is
             __builtin_amdgcn_sched_barrier(0);
-            const f4* stash = reinterpret_cast<const f4*>(tbx + oz) + lane;
+            const f4* stash = reinterpret_cast<const f4*>(tpk + oz) + lane;
 #pragma unroll
             for (int j = 0; j < NSTASH4; ++j) {
                 const f4 v = stash[j * 64];
@@ -797,9 +799,10 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         pin(GY);
         TRACE(23);
         __builtin_amdgcn_sched_barrier(0);
-        chunks_to_lds<L>(tbx, GY);
-        if (full) tile_lds_to_global_full<L>(tbx, gxr, (long)t * TS);
-        else tile_lds_to_global_guarded<L>(tbx, gxr, (long)t * TS, N);
+        chunks_to_lds<L>(tbo, GY, cl);
+        if (full) tile_lds_to_global_full<L>(tbo, gxr, (long)t * TS);
+        else tile_lds_to_global_guarded<L>(tbo, gxr, (long)t * TS, N);
+        stores_in_flight = full ? L / 4 : 0;
         TRACE(24);
     }
     // per-wave partial sums -> partials[row][wave][S][5]
