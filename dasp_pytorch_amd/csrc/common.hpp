@@ -144,7 +144,7 @@ template <int L> __device__ __forceinline__ void tile_dma_issue(const float* __r
 
 // issue the coalesced loads of a full tile (results are consumed by tile_regs_to_lds)
 template <int L>
-__device__ __forceinline__ void tile_load_full(const float* __restrict__ row, long base, f4 (&v)[L / 4]) {
+__device__ __forceinline__ void tile_load_full(const float* __restrict__ row, long base, f4 (&v)[L / 4], bool stream = false) {
     const int lane = lane_id();
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
 #pragma unroll
@@ -152,7 +152,10 @@ __device__ __forceinline__ void tile_load_full(const float* __restrict__ row, lo
     return;
 #endif
 #pragma unroll
-    for (int j = 0; j < L / 4; ++j) v[j] = ld_stream(reinterpret_cast<const f4*>(row + base + (long)(j * 64 + lane) * 4));
+    for (int j = 0; j < L / 4; ++j) {
+        const f4* p = reinterpret_cast<const f4*>(row + base + (long)(j * 64 + lane) * 4);
+        v[j] = stream ? ld_stream(p) : *p;
+    }
 }
 
 template <int L>
@@ -196,15 +199,18 @@ __device__ __forceinline__ void chunks_to_lds(float* tbuf, const float (&X)[L], 
 
 // LDS image -> global: coalesced float4 stores for a full tile, guarded element stores otherwise
 template <int L>
-__device__ __forceinline__ void tile_lds_to_global_full(const float* tbuf, float* __restrict__ row, long base) {
+__device__ __forceinline__ void tile_lds_to_global_full(const float* tbuf, float* __restrict__ row, long base, bool stream = false) {
     const int lane = lane_id();
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
     if (tbuf[lane] != 12345.678f) return;
 #endif
 #pragma unroll
     for (int j = 0; j < L / 4; ++j)
-        st_stream(reinterpret_cast<f4*>(row + base + (long)(j * 64 + lane) * 4),
-                  *reinterpret_cast<const f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]));
+    {
+        f4* p = reinterpret_cast<f4*>(row + base + (long)(j * 64 + lane) * 4);
+        const f4 v = *reinterpret_cast<const f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]);
+        if (stream) st_stream(p, v); else *p = v;
+    }
 }
 template <int L>
 __device__ __forceinline__ void tile_lds_to_global_guarded(const float* tbuf, float* __restrict__ row, long base, long n_valid) {

@@ -31,6 +31,13 @@
 #include "common.hpp"
 #include <type_traits>
 
+#ifndef DASP_FWD_NT
+// forward kernel: streaming hints on 1 = x loads, 2 = y stores, 4 = state stores. The kernels run back to back (forward, backward,
+// forward, ...) and share the 256 MB MALL, so only the pair can be judged: same box, fwd + bwd: all 0.484 ms, y stores only 0.490,
+// none in either kernel 0.494, none in forward / all in backward 0.500.
+#define DASP_FWD_NT 7
+#endif
+
 namespace dasp {
 
 #ifdef DASP_TRACE   // developer builds only: cycle stamps of one wave's phases (tools/sosbench prints them)
@@ -330,6 +337,14 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
 
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+// acc += g * (x, x) with x = one half of `xy`, selected by the instruction's op_sel bits: the table product needs every sample
+// broadcast to both halves of a packed operand, and building that operand with two v_mov per sample costs as many issue slots as a
+// sixth of the product itself. g is wave-uniform (SGPR pair).
+template <int HALF> __device__ __forceinline__ f2 fma2_bcast(f2 g, f2 xy, f2 acc) {
+    if (HALF) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(g), "v"(xy));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(g), "v"(xy));
+    return acc;
+}
 
 // DPP move: value of the source lane selected by CTRL, 0 where there is none / the row is masked off
 template <int CTRL, int ROW_MASK>
@@ -424,8 +439,9 @@ __device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __re
         f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
 #pragma unroll
         for (int n = 0; n < L; n += 2) {
-            z0 = fma2(G[n], splat(X[n]), z0);
-            z1 = fma2(G[n + 1], splat(X[n + 1]), z1);
+            const f2 xy = f2{X[n], X[n + 1]};
+            z0 = fma2_bcast<0>(G[n], xy, z0);
+            z1 = fma2_bcast<1>(G[n + 1], xy, z1);
         }
         f2 f = zmap(z0 + z1);
         { float a = pw16.x, b = pw32.x, c = pw64.x; pin(a); pin(b); pin(c); pw16.x = a; pw32.x = b; pw64.x = c; }
@@ -508,7 +524,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // no register prefetch of the next tile: at <= 80 VGPRs six waves per SIMD hide the HBM latency instead
         if (full) {
             f4 cur[L / 4];
-            tile_load_full<L>(xr, (long)t * TS, cur);
+            tile_load_full<L>(xr, (long)t * TS, cur, DASP_FWD_NT & 1);
             tile_regs_to_lds<L>(tbuf, cur);
         } else {
             tile_global_to_lds_guarded<L>(tbuf, xr, (long)t * TS, N);
@@ -542,7 +558,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         if (carries) {   // chunk start states for the backward pass: [row][tile][section][lane] f2, 512 B per wave store
             f2* cs = reinterpret_cast<f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < S; ++k) st_stream(cs + k * 64, st[k]);
+            for (int k = 0; k < S; ++k) { if (DASP_FWD_NT & 4) st_stream(cs + k * 64, st[k]); else cs[k * 64] = st[k]; }
         }
 
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
@@ -572,7 +588,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         TRACE(3);
 
         chunks_to_lds<L>(tbuf, X);
-        if (full) tile_lds_to_global_full<L>(tbuf, yr, (long)t * TS);
+        if (full) tile_lds_to_global_full<L>(tbuf, yr, (long)t * TS, DASP_FWD_NT & 2);
         else tile_lds_to_global_guarded<L>(tbuf, yr, (long)t * TS, N);
         TRACE(4);
     }
@@ -800,7 +816,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         TRACE(23);
         __builtin_amdgcn_sched_barrier(0);
         chunks_to_lds<L>(tbo, GY, cl);
-        if (full) tile_lds_to_global_full<L>(tbo, gxr, (long)t * TS);
+        if (full) tile_lds_to_global_full<L>(tbo, gxr, (long)t * TS, true);
         else tile_lds_to_global_guarded<L>(tbo, gxr, (long)t * TS, N);
         stores_in_flight = full ? L / 4 : 0;
         TRACE(24);
