@@ -44,9 +44,12 @@ namespace dasp {
 __device__ long long g_trace[64];
 #define TRACE(i) do { if (blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W) g_trace[i] = clock64(); } while (0)
 #define TRACE2(i) do { if (trace_on && k == 3) g_trace[i] = clock64(); } while (0)
+#define PTRACE(i, t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                          if (blockIdx.x == 7 && threadIdx.x == (t)) g_trace[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TRACE(i)
 #define TRACE2(i)
+#define PTRACE(i, t)
 #endif
 
 
@@ -186,6 +189,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     __shared__ float Gsh[2][L][S2];     // chunk-table columns v_m, written out after the recursion (no global stores inside it)
     __shared__ double Pd[S][7][2];
     const int tid = threadIdx.x, item = blockIdx.x;
+    PTRACE(40, 0);
     float* tb = tab + (size_t)item * LY::TOTAL;
     double* dt = dtab + (size_t)item * S * DT_STRIDE;
 
@@ -222,6 +226,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             d[23] = 0.0;
         }
     }
+    PTRACE(41, 0);
     __syncthreads();
 
     // Phi for the forward system (sys 0) and the adjoint system (sys 1: sections reversed, A^T, B<->C)
@@ -244,6 +249,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         Phi[sys][i * S2 + j] = v;
         T1[sys][i * S2 + j] = v;
     }
+    PTRACE(46, 0);
     if (tid < 2 * S2) {
         const int sys = tid / S2, i = tid % S2, kk = i / 2, r = i % 2;
         const int fk = sys ? S - 1 - kk : kk;
@@ -251,6 +257,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         for (int m = 0; m < kk; ++m) gain *= sec[sys ? S - 1 - m : m][5];
         vv[0][sys][i] = (sys ? sec[fk][3 + r] : (r == 0 ? 1.0 : 0.0)) * gain;
     }
+    PTRACE(42, 0);
     __syncthreads();
 
     // chunk tables: v_m = Phi^m Bx ; forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
@@ -309,6 +316,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             }
         }
     }
+    PTRACE(43, 0); PTRACE(44, 64);
     __syncthreads();
     // chunk tables: forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
     for (int e = tid; e < 2 * L * S2; e += 256) {
@@ -330,6 +338,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         put_blk(tb + LY::PW + (k * 64 + c) * 4, p, q, kap, 0);
         put_blk(tb + LY::PWA + ((S - 1 - k) * 64 + c) * 4, p, q, kap, 1);
     }
+    PTRACE(45, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
