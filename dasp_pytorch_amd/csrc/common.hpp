@@ -167,6 +167,59 @@ __device__ __forceinline__ void tile_regs_to_lds(float* tbuf, const f4 (&v)[L / 
     wave_lds_sync();
 }
 
+// ---- unpadded tile image with an XOR swizzle (L = 16: 4 granules of 16 bytes per chunk, 4 KiB per tile) ----------------------
+// Granule k of chunk c lives in slot 4 c + (k ^ ((c >> 2) & 3)). Chunk-wise (lane = chunk, ds_read/write_b128) every 16 lanes touch 16
+// different 16-byte columns; row-wise (slot = 64 m + lane) the access is linear, which is what LDS-DMA needs on the LDS side, and the
+// global side stays coalesced because the swizzle only permutes the four granules of a chunk (64 contiguous bytes).
+__device__ __forceinline__ int swz_slot(int c, int k) { return 4 * c + (k ^ ((c >> 2) & 3)); }
+__device__ __forceinline__ int swz_granule_of_slot(int P) { const int c = P >> 2; return 4 * c + ((P & 3) ^ ((c >> 2) & 3)); }   // its own inverse
+template <int L>
+__device__ __forceinline__ void lds_to_chunks_swz(const float* img, float (&X)[L], int chunk) {
+    static_assert(L == 16, "swizzled images are laid out for 16-sample chunks");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f4 q = *reinterpret_cast<const f4*>(img + 4 * swz_slot(chunk, k));
+        X[4 * k + 0] = q.x; X[4 * k + 1] = q.y; X[4 * k + 2] = q.z; X[4 * k + 3] = q.w;
+    }
+}
+template <int L>
+__device__ __forceinline__ void chunks_to_lds_swz(float* img, const float (&X)[L], int chunk) {
+    static_assert(L == 16, "swizzled images are laid out for 16-sample chunks");
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<f4*>(img + 4 * swz_slot(chunk, k)) = f4{X[4 * k + 0], X[4 * k + 1], X[4 * k + 2], X[4 * k + 3]};
+    wave_lds_sync();
+}
+// full tile, global -> image by LDS-DMA (4 wave instructions of 1 KiB, every lane active)
+__device__ __forceinline__ void tile_dma_issue_swz(const float* __restrict__ tile, unsigned lds_bytes, int lane) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) glds16(tile + 4 * swz_granule_of_slot(64 * m + lane), lds_bytes + 1024 * m);
+}
+__device__ __forceinline__ void tile_swz_to_global_full(const float* img, float* __restrict__ row, long base, bool stream, int lane) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int P = 64 * m + lane;
+        f4* p = reinterpret_cast<f4*>(row + base + 4 * swz_granule_of_slot(P));
+        const f4 v = *reinterpret_cast<const f4*>(img + 4 * P);
+        if (stream) st_stream(p, v); else *p = v;
+    }
+}
+__device__ __forceinline__ int swz_index(int m) { return 4 * swz_granule_of_slot(m >> 2) + (m & 3); }   // float index of sample m (slot map is an involution)
+__device__ __forceinline__ void tile_global_to_swz_guarded(float* img, const float* __restrict__ row, long base, long n_valid) {
+    const int lane = lane_id();
+    wave_lds_sync();
+#pragma unroll 1
+    for (int m = lane; m < 1024; m += 64) img[swz_index(m)] = (base + m < n_valid) ? row[base + m] : 0.f;
+    wave_lds_sync();
+}
+__device__ __forceinline__ void tile_swz_to_global_guarded(const float* img, float* __restrict__ row, long base, long n_valid) {
+    const int lane = lane_id();
+#pragma unroll 1
+    for (int m = lane; m < 1024; m += 64)
+        if (base + m < n_valid) row[base + m] = img[swz_index(m)];
+}
+
 // ragged tile: guarded element loads straight into the LDS image (zero fill)
 template <int L>
 __device__ __forceinline__ void tile_global_to_lds_guarded(float* tbuf, const float* __restrict__ row, long base, long n_valid) {
