@@ -106,66 +106,12 @@ __device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
 }
 
 
-// ---- coalesced tile <-> per-lane chunk transposition through a wave-private LDS buffer ---------
-// A tile is 64*L consecutive samples of one row. Global side: lane l, vector j holds samples
-// [j*256 + 4l, +4) (1 KiB per wave instruction). Register side: lane l holds the L consecutive
-// samples [l*L, (l+1)*L). LDS image: chunk-major with a 4-float pad per chunk (stride L+4) which
-// keeps both the ds_write_b128 and the ds_read_b128 side at most 2-way conflicted for L = 8, 16, 32.
-// A tile is "full" when it lies inside the row and the row is 16-byte aligned (wave-uniform test);
-// only full tiles use the float4 register path, ragged ones go element-wise straight to/from LDS
-// in a rolled loop (cold code, no register arrays).
-
+// ---- coalesced tile <-> per-lane chunk transposition through wave-private LDS images -----------------------------------------
+// A tile is 64*L consecutive samples of one row. Global side: 16-byte granules, 1 KiB per wave instruction. Register side: lane l
+// holds the L consecutive samples of one chunk. A tile is "full" when it lies inside the row and the row is 16-byte aligned
+// (wave-uniform test); only full tiles use the vector / LDS-DMA paths, ragged ones go element-wise in a rolled loop (cold code).
 template <int L>
 __device__ __forceinline__ bool tile_full(long base, long n_valid, bool vec) { return vec && base + 64 * L <= n_valid; }
-
-template <int L>
-__device__ __forceinline__ int tile_lds_index(int m) { return (m / L) * (L + 4) + (m % L); }
-
-// LDS-DMA of a full tile into the padded chunk layout above: in 16-byte granules a chunk is L/4 data slots + 1 pad slot, so the
-// 64 (L/4 + 1) slots of a tile are L/4 + 1 wave instructions of 64 consecutive slots; a lane whose slot is a pad stays off, the
-// others fetch the granule that belongs there (the source address is per lane, the destination is lane-linear).
-template <int L> struct TileDma { int goff[L / 4 + 1]; bool on[L / 4 + 1]; };
-template <int L> __device__ __forceinline__ TileDma<L> tile_dma_plan(int lane) {
-    constexpr int GPC = L / 4, SLOTS = GPC + 1;
-    TileDma<L> p;
-#pragma unroll
-    for (int m = 0; m < SLOTS; ++m) {
-        const int G = 64 * m + lane, c = G / SLOTS, k = G - c * SLOTS;
-        p.on[m] = k < GPC;
-        p.goff[m] = (c * GPC + k) * 4;        // floats from the tile start
-    }
-    return p;
-}
-template <int L> __device__ __forceinline__ void tile_dma_issue(const float* __restrict__ tile, unsigned lds_bytes, const TileDma<L>& p) {
-#pragma unroll
-    for (int m = 0; m < L / 4 + 1; ++m)
-        if (p.on[m]) glds16(tile + p.goff[m], lds_bytes + 1024 * m);
-}
-
-// issue the coalesced loads of a full tile (results are consumed by tile_regs_to_lds)
-template <int L>
-__device__ __forceinline__ void tile_load_full(const float* __restrict__ row, long base, f4 (&v)[L / 4], bool stream = false) {
-    const int lane = lane_id();
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
-#pragma unroll
-    for (int j = 0; j < L / 4; ++j) v[j] = f4{0.1f * lane, 0.2f, -0.3f, 0.05f * j};
-    return;
-#endif
-#pragma unroll
-    for (int j = 0; j < L / 4; ++j) {
-        const f4* p = reinterpret_cast<const f4*>(row + base + (long)(j * 64 + lane) * 4);
-        v[j] = stream ? ld_stream(p) : *p;
-    }
-}
-
-template <int L>
-__device__ __forceinline__ void tile_regs_to_lds(float* tbuf, const f4 (&v)[L / 4]) {
-    const int lane = lane_id();
-    wave_lds_sync();  // previous readers of tbuf are done
-#pragma unroll
-    for (int j = 0; j < L / 4; ++j) *reinterpret_cast<f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]) = v[j];
-    wave_lds_sync();
-}
 
 // ---- unpadded tile image with an XOR swizzle (L = 16: 4 granules of 16 bytes per chunk, 4 KiB per tile) ----------------------
 // Granule k of chunk c lives in slot 4 c + (k ^ ((c >> 2) & 3)). Chunk-wise (lane = chunk, ds_read/write_b128) every 16 lanes touch 16
@@ -218,59 +164,6 @@ __device__ __forceinline__ void tile_swz_to_global_guarded(const float* img, flo
 #pragma unroll 1
     for (int m = lane; m < 1024; m += 64)
         if (base + m < n_valid) row[base + m] = img[swz_index(m)];
-}
-
-// ragged tile: guarded element loads straight into the LDS image (zero fill)
-template <int L>
-__device__ __forceinline__ void tile_global_to_lds_guarded(float* tbuf, const float* __restrict__ row, long base, long n_valid) {
-    const int lane = lane_id();
-    wave_lds_sync();
-#pragma unroll 1
-    for (int m = lane; m < 64 * L; m += 64) tbuf[tile_lds_index<L>(m)] = (base + m < n_valid) ? row[base + m] : 0.f;
-    wave_lds_sync();
-}
-
-// `chunk` = which chunk of the tile this lane takes (default: its own lane number; the backward kernel uses 63 - lane)
-template <int L>
-__device__ __forceinline__ void lds_to_chunks(const float* tbuf, float (&X)[L], int chunk = lane_id()) {
-#pragma unroll
-    for (int i = 0; i < L / 4; ++i) {
-        const f4 q = *reinterpret_cast<const f4*>(&tbuf[chunk * (L + 4) + 4 * i]);
-        X[4 * i + 0] = q.x; X[4 * i + 1] = q.y; X[4 * i + 2] = q.z; X[4 * i + 3] = q.w;
-    }
-}
-
-template <int L>
-__device__ __forceinline__ void chunks_to_lds(float* tbuf, const float (&X)[L], int chunk = lane_id()) {
-    wave_lds_sync();
-#pragma unroll
-    for (int i = 0; i < L / 4; ++i) {
-        *reinterpret_cast<f4*>(&tbuf[chunk * (L + 4) + 4 * i]) = f4{X[4 * i + 0], X[4 * i + 1], X[4 * i + 2], X[4 * i + 3]};
-    }
-    wave_lds_sync();
-}
-
-// LDS image -> global: coalesced float4 stores for a full tile, guarded element stores otherwise
-template <int L>
-__device__ __forceinline__ void tile_lds_to_global_full(const float* tbuf, float* __restrict__ row, long base, bool stream = false) {
-    const int lane = lane_id();
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
-    if (tbuf[lane] != 12345.678f) return;
-#endif
-#pragma unroll
-    for (int j = 0; j < L / 4; ++j)
-    {
-        f4* p = reinterpret_cast<f4*>(row + base + (long)(j * 64 + lane) * 4);
-        const f4 v = *reinterpret_cast<const f4*>(&tbuf[tile_lds_index<L>(j * 256 + 4 * lane)]);
-        if (stream) st_stream(p, v); else *p = v;
-    }
-}
-template <int L>
-__device__ __forceinline__ void tile_lds_to_global_guarded(const float* tbuf, float* __restrict__ row, long base, long n_valid) {
-    const int lane = lane_id();
-#pragma unroll 1
-    for (int m = lane; m < 64 * L; m += 64)
-        if (base + m < n_valid) row[base + m] = tbuf[tile_lds_index<L>(m)];
 }
 
 // ---- intra-workgroup mailbox: one wave hands a 2-vector carry to another wave through LDS --------

@@ -634,10 +634,10 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                float* __restrict__ partials, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
     // S <= 6: the s2 signals of all sections stay in registers (H = 0). S = 8: the lower half is parked in LDS (H = S / 2).
-    constexpr int S2 = 2 * S, TS = 64 * L, LP = L + 4, H = S > 6 ? S / 2 : 0, SH = S - H;   // SH >= H
+    constexpr int S2 = 2 * S, TS = 64 * L, H = S > 6 ? S / 2 : 0, SH = S - H;   // SH >= H
     constexpr int NSTASH4 = (H * (L + 2) + 3) / 4;                 // float4 per lane of parked s2 signals
-    // per wave: x landing image, gy landing image, gx staging image (padded chunk layout), saved chunk states, parked signals
-    constexpr int IMG = 64 * LP, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
+    // per wave: x landing image, gy landing image, gx staging image (unpadded, swizzled: common.hpp), saved chunk states, parked signals
+    constexpr int IMG = 64 * L, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
     constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
@@ -676,9 +676,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
                    a_s = __builtin_amdgcn_readfirstlane(lds_addr(tst));
     auto issue_dma = [&](int tt) {
-        const TileDma<L> plan = tile_dma_plan<L>(lane + opaque_zero());     // recomputed per tile: cheaper than keeping it live
-        tile_dma_issue<L>(xr + (size_t)tt * TS, a_x, plan);
-        tile_dma_issue<L>(gr + (size_t)tt * TS, a_g, plan);
+        tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
+        tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
         const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
 #pragma unroll
         for (int m = 0; m < S / 2; ++m) glds16(cs + m * 256, a_s + 1024 * m);
@@ -698,15 +697,15 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             if (stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            tile_global_to_lds_guarded<L>(tbx, xr, (long)t * TS, N);
-            tile_global_to_lds_guarded<L>(tbg, gr, (long)t * TS, N);
+            tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
+            tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
         }
         // Lane l works on chunk 63 - l for the whole tile: the adjoint scan runs from the last chunk to the first, and with the
         // chunks dealt out in that order it is an ordinary ascending lane scan - no lane mirroring (ds_bpermute) of its inputs and
         // outputs. Everything else in this kernel is per chunk and does not care which lane owns which.
         const int cl = 63 - lane;
-        lds_to_chunks<L>(tbx, X, cl);
-        lds_to_chunks<L>(tbg, GY, cl);
+        lds_to_chunks_swz<L>(tbx, X, cl);
+        lds_to_chunks_swz<L>(tbg, GY, cl);
         pin(X); pin(GY); TRACE(17);
         // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
         //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
@@ -840,9 +839,9 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         pin(GY);
         TRACE(23);
         __builtin_amdgcn_sched_barrier(0);
-        chunks_to_lds<L>(tbo, GY, cl);
-        if (full) tile_lds_to_global_full<L>(tbo, gxr, (long)t * TS, true);
-        else tile_lds_to_global_guarded<L>(tbo, gxr, (long)t * TS, N);
+        chunks_to_lds_swz<L>(tbo, GY, cl);
+        if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
+        else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
         stores_in_flight = full ? L / 4 : 0;
         TRACE(24);
     }
