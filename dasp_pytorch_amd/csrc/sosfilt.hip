@@ -354,6 +354,12 @@ template <int HALF> __device__ __forceinline__ f2 fma2_bcast(f2 g, f2 xy, f2 acc
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(g), "v"(xy));
     return acc;
 }
+// the same with a per-lane (VGPR) g
+template <int HALF> __device__ __forceinline__ f2 fma2_bcast_v(f2 g, f2 xy, f2 acc) {
+    if (HALF) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(g), "v"(xy));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g), "v"(xy));
+    return acc;
+}
 
 // DPP move: value of the source lane selected by CTRL, 0 where there is none / the row is masked off
 template <int CTRL, int ROW_MASK>
@@ -417,6 +423,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #define TLD4(p) (*reinterpret_cast<const f4*>(p))
 
 // f += [c.x c.z; c.y c.w] * (t1, t2)   (column-major 2x2 block, packed FMAs)
+// f + [[c.x, c.z], [c.y, c.w]] * t with t.x / t.y broadcast by op_sel: two issue slots per packed FMA and nothing else (the splat
+// form below costs two extra v_mov per application). _s: wave-uniform block (SGPRs), _v: per-lane block.
+__device__ __forceinline__ f2 blk_apply_s(f4 c, f2 t, f2 f) {
+    return fma2_bcast<0>(f2{c.x, c.y}, t, fma2_bcast<1>(f2{c.z, c.w}, t, f));
+}
+__device__ __forceinline__ f2 blk_apply_v(f4 c, f2 t, f2 f) {
+    return fma2_bcast_v<0>(f2{c.x, c.y}, t, fma2_bcast_v<1>(f2{c.z, c.w}, t, f));
+}
 __device__ __forceinline__ f2 blk_apply(f4 c, float t1, float t2, f2 f) {
     return fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
 }
@@ -473,17 +487,17 @@ __device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __re
             for (int n = 0; n < L; ++n) G[n] = TLD2(Gs + ((k + 1) * L + n) * 2);
         }
 #pragma unroll
-        for (int j = 0; j < k; ++j) f = blk_apply(MC[j], st[j].x, st[j].y, f);
+        for (int j = 0; j < k; ++j) f = blk_apply_s(MC[j], st[j], f);
         pin(f); TRACE2(10);
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < S) {
 #pragma unroll
             for (int j = 0; j <= k; ++j) MC[j] = TLD4(MCs + ((k + 1) * S + j) * 4);
         }
-        f = blk_apply(PL[0], dpp0<0x111, 0xf>(f.x), dpp0<0x111, 0xf>(f.y), f);
-        f = blk_apply(PL[1], dpp0<0x112, 0xf>(f.x), dpp0<0x112, 0xf>(f.y), f);
-        f = blk_apply(PL[2], dpp0<0x114, 0xf>(f.x), dpp0<0x114, 0xf>(f.y), f);
-        f = blk_apply(PL[3], dpp0<0x118, 0xf>(f.x), dpp0<0x118, 0xf>(f.y), f);
+        f = blk_apply_s(PL[0], f2{dpp0<0x111, 0xf>(f.x), dpp0<0x111, 0xf>(f.y)}, f);
+        f = blk_apply_s(PL[1], f2{dpp0<0x112, 0xf>(f.x), dpp0<0x112, 0xf>(f.y)}, f);
+        f = blk_apply_s(PL[2], f2{dpp0<0x114, 0xf>(f.x), dpp0<0x114, 0xf>(f.y)}, f);
+        f = blk_apply_s(PL[3], f2{dpp0<0x118, 0xf>(f.x), dpp0<0x118, 0xf>(f.y)}, f);
         pin(f); TRACE2(11);
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < S) {
@@ -491,17 +505,17 @@ __device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __re
             for (int l = 0; l < 4; ++l) PL[l] = TLD4(PLs + (k + 1) * 16 + 4 * l);
         }
         // rows 1, 3 += M^(j+1) * (last lane of the previous row); rows 2, 3 += M^((lane % 32) + 1) * lane 31
-        f = blk_apply(pw16, dpp0<0x142, 0xa>(f.x), dpp0<0x142, 0xa>(f.y), f);
-        f = blk_apply(pw32, dpp0<0x143, 0xc>(f.x), dpp0<0x143, 0xc>(f.y), f);
+        f = blk_apply_v(pw16, f2{dpp0<0x142, 0xa>(f.x), dpp0<0x142, 0xa>(f.y)}, f);
+        f = blk_apply_v(pw32, f2{dpp0<0x143, 0xc>(f.x), dpp0<0x143, 0xc>(f.y)}, f);
         pin(f); TRACE2(12);
         f2 K;
         carry_in(k, K);
         pin(K); TRACE2(13);
         // carry for the next tile: the only work on the cross-wave serial chain
-        carry_out(k, blk_apply(P64[k & 1], K.x, K.y, f2{read_lane(f.x, 63), read_lane(f.y, 63)}));
+        carry_out(k, blk_apply_s(P64[k & 1], K, f2{read_lane(f.x, 63), read_lane(f.y, 63)}));
         __builtin_amdgcn_sched_barrier(0);
         if (k + 2 < S) P64[k & 1] = TLD4(P64s + (k + 2) * 4);
-        const f2 E = blk_apply(pw64, K.x, K.y, f);
+        const f2 E = blk_apply_v(pw64, K, f);
         st[k] = f2{wave_shr1(K.x, E.x), wave_shr1(K.y, E.y)};
         pin(st[k]); TRACE2(14);
     }
