@@ -41,6 +41,13 @@ SIGNATURES = {
     "dasp_dyn_partial_floats": (_l, [_l]),
     "dasp_dynamics_forward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
     "dasp_dynamics_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
+    "dasp_stereo_partial_floats": (_l, [_i, _l, _i, _l]),
+    "dasp_widener_forward": (_i, [_p, _p, _p, _i, _l, _p]),
+    "dasp_widener_backward": (_i, [_p] * 6 + [_i, _l, _p]),
+    "dasp_panner_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
+    "dasp_panner_backward": (_i, [_p] * 6 + [_i, _i, _l, _p]),
+    "dasp_bus_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
+    "dasp_bus_backward": (_i, [_p] * 6 + [_i, _i, _l, _p]),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
     "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),

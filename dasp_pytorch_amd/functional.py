@@ -3,7 +3,8 @@
 import torch
 
 from . import signal as _signal
-from .ops import FILTER_TYPES, DistortionFunction, DynamicsFunction, GainFunction, ParametricEQFunction, ReverbFunction
+from .ops import (FILTER_TYPES, BusFunction, DistortionFunction, DynamicsFunction, GainFunction, PannerFunction, ParametricEQFunction,
+                  ReverbFunction, WidenerFunction)
 
 _PEQ_TYPES = [FILTER_TYPES[t] for t in ("low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf")]
 
@@ -27,6 +28,46 @@ def distortion(x: torch.Tensor, sample_rate: int, drive_db: torch.Tensor):
         raise RuntimeError(f"shape '[{bs}, {chs}, -1]' is invalid for input of size {drive_db.numel()} "
                            "(dasp_pytorch_amd supports one drive value per (batch, channel) row)")
     return DistortionFunction.apply(x, drive_db)
+
+
+def stereo_bus(x: torch.Tensor, sample_rate: int, send_db: torch.Tensor):
+    """Sum stereo tracks (bs, 2, tracks, seq_len) into one stereo bus (bs, 2, seq_len) with send levels in dB, bs*tracks values
+    (reference: dasp_pytorch/functional.py:32-62, send_db.view(bs, 1, tracks, 1)). At most 64 tracks."""
+    bs, chs, tracks, seq_len = x.size()
+    assert chs == 2, "Input tensor must have shape (bs, 2, tracks, seq_len)"
+    if send_db.numel() != bs * tracks:
+        raise RuntimeError(f"shape '[{bs}, 1, {tracks}, 1]' is invalid for input of size {send_db.numel()}")
+    return BusFunction.apply(x, send_db)
+
+
+def advanced_distortion(x, sample_rate, input_gain_db, output_gain_db, tone, dc_offset):
+    """Not implemented in the reference either (dasp_pytorch/functional.py:81-111)."""
+    raise NotImplementedError
+
+
+def graphic_eq(x: torch.Tensor, sample_rate: float):
+    """Not implemented in the reference either (dasp_pytorch/functional.py:114-115)."""
+    raise NotImplementedError
+
+
+def stereo_widener(x: torch.Tensor, sample_rate: float, width: torch.Tensor):
+    """Mid/side stereo widener on (bs, 2, seq_len), width with bs values (the reference needs them shaped (bs, 1)): mid * 2 (1 - width), side * 2 width
+    (reference: dasp_pytorch/functional.py:580-605)."""
+    bs, chs, seq_len = x.size()
+    assert chs == 2, "Input tensor must have shape (bs, 2, seq_len)"
+    if width.numel() != bs:
+        raise RuntimeError(f"The size of tensor a ({bs}) must match the size of tensor b ({width.numel()})")
+    return WidenerFunction.apply(x, width)
+
+
+def stereo_panner(x: torch.Tensor, sample_rate: float, pan: torch.Tensor):
+    """Pan mono tracks (bs, num_tracks, seq_len) across the stereo field; pan in [0, 1] with bs*num_tracks values. Returns
+    (bs, 2, num_tracks, seq_len), the shape the reference's code produces (its docstring says otherwise;
+    dasp_pytorch/functional.py:608-636)."""
+    bs, num_tracks, seq_len = x.size()
+    if pan.numel() != bs * num_tracks:
+        raise RuntimeError(f"shape '[{bs}, 1, {num_tracks}, 1]' is invalid for input of size {pan.numel()}")
+    return PannerFunction.apply(x, pan)
 
 
 def parametric_eq(

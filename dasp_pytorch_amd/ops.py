@@ -245,6 +245,87 @@ def _cbuf(n, device):
     return torch.empty(2 * n, dtype=torch.float32, device=device)
 
 
+class _StereoFunction(torch.autograd.Function):
+    """Shared plumbing of stereo_widener / stereo_panner / stereo_bus: y = f(x, ctl) with a small per-item / per-track control."""
+    OP = None       # 0 widener, 1 panner, 2 bus
+    FWD = BWD = None
+
+    @classmethod
+    def _dims(cls, x):
+        if cls.OP == 0:
+            B, _, N = x.shape
+            return B, 1, N, (B, 2, N)
+        if cls.OP == 1:
+            B, T, N = x.shape
+            return B, T, N, (B, 2, T, N)
+        B, _, T, N = x.shape
+        return B, T, N, (B, 2, N)
+
+    @classmethod
+    def _run(cls, ctx, x, ctl):
+        _lib.require_device(x, "x")
+        B, T, N, oshape = cls._dims(x)
+        x32 = _f32c(x)
+        c32 = ctl.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        dims = (B, N) if cls.OP == 0 else (B, T, N)
+        call(cls.FWD, ptr(x32), ptr(c32), ptr(y), *dims, stream())
+        ctx.save_for_backward(x32, c32)
+        ctx.meta = (x.dtype, ctl.dtype, ctl.shape, B, T, N)
+        return y.to(x.dtype)
+
+    @classmethod
+    def _grad(cls, ctx, gy):
+        L = _lib.lib()
+        x32, c32 = ctx.saved_tensors
+        xd, cd, cshape, B, T, N = ctx.meta
+        gx = torch.empty_like(x32)
+        gctl = torch.empty_like(c32)
+        partials = torch.empty(L.dasp_stereo_partial_floats(cls.OP, B, T, N), dtype=torch.float32, device=x32.device)
+        dims = (B, N) if cls.OP == 0 else (B, T, N)
+        call(cls.BWD, ptr(x32), ptr(c32), ptr(_f32c(gy)), ptr(gx), ptr(gctl), ptr(partials), *dims, stream())
+        return gx.to(xd), gctl.reshape(cshape).to(cd)
+
+
+class WidenerFunction(_StereoFunction):
+    """(L, R) -> (L + k R, k L + R), k = 1 - 2 width (functional.py:580-605)."""
+    OP, FWD, BWD = 0, "dasp_widener_forward", "dasp_widener_backward"
+
+    @staticmethod
+    def forward(ctx, x, width):
+        return WidenerFunction._run(ctx, x, width)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return WidenerFunction._grad(ctx, gy)
+
+
+class PannerFunction(_StereoFunction):
+    """(B, T, N) mono tracks -> (B, 2, T, N) with the pan law of functional.py:608-636."""
+    OP, FWD, BWD = 1, "dasp_panner_forward", "dasp_panner_backward"
+
+    @staticmethod
+    def forward(ctx, x, pan):
+        return PannerFunction._run(ctx, x, pan)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return PannerFunction._grad(ctx, gy)
+
+
+class BusFunction(_StereoFunction):
+    """(B, 2, T, N) -> (B, 2, N): sum of the tracks weighted by 10^(send_db / 20) (functional.py:32-62)."""
+    OP, FWD, BWD = 2, "dasp_bus_forward", "dasp_bus_backward"
+
+    @staticmethod
+    def forward(ctx, x, send_db):
+        return BusFunction._run(ctx, x, send_db)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return BusFunction._grad(ctx, gy)
+
+
 class ReverbFunction(torch.autograd.Function):
     """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1), filters (nb,taps), gains/decays (B,nb), mix (B)."""
 

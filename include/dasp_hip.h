@@ -133,6 +133,25 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
                          float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
                          float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Stereo utilities.  Replace dasp_pytorch.functional.stereo_widener (dasp_pytorch/functional.py:580-605),
+ * stereo_panner (:608-636) and stereo_bus (:32-62).
+ *   widener: x, y (B, 2, N); width (B).            left = L + (1 - 2 width) R, right = (1 - 2 width) L + R
+ *   panner:  x (B, T, N); pan (B * T); y (B, 2, T, N).  y[:, 0] = lg x, y[:, 1] = rg x, constant-power-like gains of pan
+ *   bus:     x (B, 2, T, N); send_db (B * T); y (B, 2, N).  y = sum over tracks of 10^(send_db / 20) x;  T <= 64
+ * partials: dasp_stereo_partial_floats(op, B, T, N) floats (op 0 widener, 1 panner, 2 bus).
+ * ------------------------------------------------------------------------------------------- */
+long dasp_stereo_partial_floats(int op, long B, int T, long N);
+int dasp_widener_forward(const float* x, const float* width, float* y, int B, long N, void* stream);
+int dasp_widener_backward(const float* x, const float* width, const float* gy, float* gx, float* gwidth, float* partials, int B,
+                          long N, void* stream);
+int dasp_panner_forward(const float* x, const float* pan, float* y, int B, int T, long N, void* stream);
+int dasp_panner_backward(const float* x, const float* pan, const float* gy, float* gx, float* gpan, float* partials, int B, int T,
+                         long N, void* stream);
+int dasp_bus_forward(const float* x, const float* send_db, float* y, int B, int T, long N, void* stream);
+int dasp_bus_backward(const float* x, const float* send_db, const float* gy, float* gx, float* gsend, float* partials, int B, int T,
+                      long N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,6 +228,65 @@ def gain_vjp(x, sample_rate, gain_db, gy, dtype=np.float64):
     return gx.astype(dtype), ggain.astype(dtype)
 
 
+def stereo_widener(x, sample_rate, width, dtype=np.float64):
+    """functional.py:580-605: mid/side, mid *= 2 (1 - width), side *= 2 width, back to left/right. x (bs, 2, N), width (bs)."""
+    x = np.asarray(x, dtype)
+    w = np.asarray(width, dtype).reshape(-1, 1)
+    sqrt2 = dtype(np.sqrt(2.0))
+    mid = (x[:, 0] + x[:, 1]) / sqrt2 * (2 * (1 - w))
+    side = (x[:, 0] - x[:, 1]) / sqrt2 * (2 * w)
+    return np.stack(((mid + side) / sqrt2, (mid - side) / sqrt2), 1)
+
+
+def stereo_widener_vjp(x, sample_rate, width, gy, dtype=np.float64):
+    x = np.asarray(x, dtype)
+    gy = np.asarray(gy, dtype)
+    k = 1 - 2 * np.asarray(width, dtype).reshape(-1, 1)          # left = L + k R, right = k L + R
+    gx = np.stack((gy[:, 0] + k * gy[:, 1], k * gy[:, 0] + gy[:, 1]), 1)
+    gw = -2 * np.sum(x[:, 1] * gy[:, 0] + x[:, 0] * gy[:, 1], axis=1)
+    return gx.astype(dtype), gw.reshape(np.asarray(width).shape).astype(dtype)
+
+
+def _pan_gains(pan, dtype):
+    """functional.py:621-626."""
+    theta = np.asarray(pan, dtype) * (np.pi / 2)
+    return np.sqrt(((np.pi / 2) - theta) * (2 / np.pi) * np.cos(theta)), np.sqrt(theta * (2 / np.pi) * np.sin(theta)), theta
+
+
+def stereo_panner(x, sample_rate, pan, dtype=np.float64):
+    """functional.py:608-636: x (bs, T, N), pan (bs, T) -> (bs, 2, T, N) (what the code returns; the docstring says (bs, T, 2, N))."""
+    x = np.asarray(x, dtype)
+    lg, rg, _ = _pan_gains(np.asarray(pan).reshape(x.shape[0], x.shape[1]), dtype)
+    return np.stack((x * lg[..., None], x * rg[..., None]), 1)
+
+
+def stereo_panner_vjp(x, sample_rate, pan, gy, dtype=np.float64):
+    x = np.asarray(x, dtype)
+    gy = np.asarray(gy, dtype)
+    lg, rg, th = _pan_gains(np.asarray(pan).reshape(x.shape[0], x.shape[1]), dtype)
+    gx = gy[:, 0] * lg[..., None] + gy[:, 1] * rg[..., None]
+    dlg = 0.5 / lg * (2 / np.pi) * (-np.cos(th) - (np.pi / 2 - th) * np.sin(th)) * (np.pi / 2)
+    drg = 0.5 / rg * (2 / np.pi) * (np.sin(th) + th * np.cos(th)) * (np.pi / 2)
+    gp = dlg * np.sum(gy[:, 0] * x, -1) + drg * np.sum(gy[:, 1] * x, -1)
+    return gx.astype(dtype), gp.reshape(np.asarray(pan).shape).astype(dtype)
+
+
+def stereo_bus(x, sample_rate, send_db, dtype=np.float64):
+    """functional.py:32-62: x (bs, 2, T, N), send_db (bs, T, 1) -> (bs, 2, N)."""
+    x = np.asarray(x, dtype)
+    s = 10 ** (np.asarray(send_db, dtype).reshape(x.shape[0], 1, x.shape[2], 1) / dtype(20.0))
+    return np.sum(x * s, axis=2)
+
+
+def stereo_bus_vjp(x, sample_rate, send_db, gy, dtype=np.float64):
+    x = np.asarray(x, dtype)
+    gy = np.asarray(gy, dtype)
+    s = 10 ** (np.asarray(send_db, dtype).reshape(x.shape[0], 1, x.shape[2], 1) / 20.0)
+    gx = gy[:, :, None, :] * s
+    gs = np.sum(gy[:, :, None, :] * x, axis=(1, 3)) * s[:, 0, :, 0] * (math.log(10.0) / 20.0)
+    return gx.astype(dtype), gs.reshape(np.asarray(send_db).shape).astype(dtype)
+
+
 def distortion(x, sample_rate, drive_db, dtype=np.float64):
     """functional.py:65-78: drive_db.view(bs, chs, -1) -> needs bs*chs drive values."""
     x = np.asarray(x, dtype)

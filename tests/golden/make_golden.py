@@ -102,6 +102,29 @@ def gain_dist_case(name, B, C, N, seed):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def stereo_case(name, B, T, N, seed):
+    """stereo_widener (B,2,N), stereo_panner (B,T,N) -> (B,2,T,N), stereo_bus (B,2,T,N) -> (B,2,N): forward and all gradients."""
+    g = torch.Generator().manual_seed(seed)
+    xw = torch.rand(B, 2, N, generator=g) * 2 - 1
+    width = torch.rand(B, 1, generator=g)                      # the reference's broadcast needs (bs, 1), its docstring says (bs)
+    xp = torch.rand(B, T, N, generator=g) * 2 - 1
+    pan = torch.rand(B, T, generator=g) * 0.9 + 0.05          # away from 0 / 1, where the reference's sqrt has an infinite slope
+    xb = torch.rand(B, 2, T, N, generator=g) * 2 - 1
+    send = torch.rand(B, T, 1, generator=g) * 36 - 24
+    ww, wp, wb = torch.randn(B, 2, N, generator=g), torch.randn(B, 2, T, N, generator=g), torch.randn(B, 2, N, generator=g)
+    out = dict(xw=f32(xw), width=f32(width), xp=f32(xp), pan=f32(pan), xb=f32(xb), send=f32(send), ww=f32(ww), wp=f32(wp), wb=f32(wb))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        for key, fn, x, c, w in (("wid", RF.stereo_widener, xw, width, ww), ("pan", RF.stereo_panner, xp, pan, wp),
+                                 ("bus", RF.stereo_bus, xb, send, wb)):
+            xx = x.to(dt).clone().requires_grad_(True)
+            cc = c.to(dt).clone().requires_grad_(True)
+            y = fn(xx, SR, cc)
+            (y * w.to(dt)).sum().backward()
+            out[key + "_y" + tag], out[key + "_gx" + tag], out[key + "_gc" + tag] = f32(y), f32(xx.grad), f32(cc.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
 COMP_KEYS = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
 
 
@@ -164,6 +187,7 @@ if __name__ == "__main__":
     eq_case("eq_bcast_b2c1_n4099", 2, 1, 4099, 1, seed=102)
     sos_case("sos_b2c2_n6000_s3", 2, 2, 6000, 3, seed=103)
     gain_dist_case("gain_dist_cfg1", 4, 1, 16384, seed=104)
+    stereo_case("stereo_b2t3_n1501", 2, 3, 1501, seed=110)
     comp_case("comp_b3c2_n12000", 3, 2, 12000, seed=105, speechlike=True)
     comp_case("comp_b2c1_n20011_look7", 2, 1, 20011, seed=106, lookahead=7, speechlike=True)
     reverb_case("rev_b2c2_n6000_l2048_t127", 2, 2, 6000, 2048, 127, seed=107, store_noise=True)

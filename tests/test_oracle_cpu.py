@@ -57,6 +57,20 @@ def test_oracle_gain_distortion_match_reference():
     assert linf_peak(y32, g["gain_y32"]).max() < 1e-6
 
 
+def test_oracle_stereo_utilities_match_reference():
+    """stereo_widener / stereo_panner / stereo_bus restatements and their hand VJPs vs the reference's forward and autograd."""
+    g = load_golden("stereo_b2t3_n1501")
+    for key, f, fv, x, c, w in (("wid", orc.stereo_widener, orc.stereo_widener_vjp, "xw", "width", "ww"),
+                                ("pan", orc.stereo_panner, orc.stereo_panner_vjp, "xp", "pan", "wp"),
+                                ("bus", orc.stereo_bus, orc.stereo_bus_vjp, "xb", "send", "wb")):
+        y = f(g[x], SR, g[c])
+        assert y.shape == g[key + "_y64"].shape
+        assert linf_peak(y, g[key + "_y64"]).max() < 1e-6
+        gx, gc = fv(g[x], SR, g[c], g[w])
+        assert linf_peak(gx, g[key + "_gx64"]).max() < 1e-6
+        assert gc.shape == g[key + "_gc64"].shape and np.allclose(gc, g[key + "_gc64"], rtol=1e-5, atol=1e-6 * np.abs(g[key + "_gc64"]).max())
+
+
 def test_chunkscan_model_equals_reference():
     """The algorithm the HIP kernels implement (normal-form sections, chunk tables, Kogge-Stone
     scans, s2-correlation gradients) reproduces the reference forward and autograd in fp64."""
