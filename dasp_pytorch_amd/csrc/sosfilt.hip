@@ -72,7 +72,8 @@ struct SosLayout {
     static constexpr int PLA = PL + SYS;
     static constexpr int P64A = P64 + SYS;
     static constexpr int PWA = PW + SYS;
-    static constexpr int TOTAL = GT + 2 * SYS;
+    static constexpr int DF = GT + 2 * SYS;          // [S][4]: b1, b2, -a1, -a2 (normalised): transposed direct form II of the adjoint sections
+    static constexpr int TOTAL = DF + 4 * S;
 };
 // fp64 side table for the finalize kernel, per (item, section)
 constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_STRIDE = 24;
@@ -217,6 +218,8 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             om = om < OM_MIN ? OM_MIN : om;
             const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
             sec[k][0] = sg; sec[k][1] = om; sec[k][2] = kap * om; sec[k][3] = g1; sec[k][4] = g2; sec[k][5] = b0; sec[k][6] = kap;
+            float* df = tb + LY::DF + k * 4;
+            df[0] = (float)b1; df[1] = (float)b2; df[2] = (float)-a1; df[3] = (float)-a2;
             float* cf = tb + LY::COEF + k * 8;
             cf[0] = (float)sg; cf[1] = (float)om; cf[2] = (float)(kap * om); cf[3] = (float)g1; cf[4] = (float)g2;
             cf[5] = (float)b0; cf[6] = (float)kap; cf[7] = 0.f;
@@ -652,7 +655,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     constexpr int NSTASH4 = (H * (L + 2) + 3) / 4;                 // float4 per lane of parked s2 signals
     // per wave: x landing image, gy landing image, gx staging image (unpadded, swizzled: common.hpp), saved chunk states, parked signals
     constexpr int IMG = 64 * L, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
-    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 12;   // COEF rows, then DF rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
@@ -670,7 +673,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* cf_lds = pw_lds + LDS_PW;
     for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[LDS_T + i] = 0.f;
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
-    for (int i = threadIdx.x; i < LDS_CF; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    for (int i = threadIdx.x; i < S * 4; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
     __syncthreads();
     const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
     f2 Kreg[S];
@@ -774,13 +778,16 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             S2v[slot][L] = s2;
             S2v[slot][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
         };
-        // adjoint section k (descending time) + coefficient correlations, in place over GY
+        // adjoint section k (descending time) + coefficient correlations, in place over GY. The section itself runs in transposed
+        // direct form II (o = b0 g + z1; z1 = b1 g - a1 o + z2; z2 = b2 g - a2 o: 5 ops against 7 in normal form). Direct forms lose
+        // digits over long horizons, not over the 16 samples between two exact restarts: the chunk's entry costate comes from the
+        // normal-form lane scan and is mapped once per chunk, z1 = l1, z2 = -sg l1 + om l2 (same zero-input response).
         auto adjoint = [&](int k, int slot, int oz) {
             const int i = S - 1 - k;
-            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);
-            const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);
-            const float nk = -ca.z;
-            float l1 = lam[i].x, l2 = lam[i].y;
+            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);           // sg, om, kom, g1
+            const float d = cf_lds[k * 8 + 5 + oz];                                     // b0
+            const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 4 + oz);   // b1, b2, -a1, -a2
+            float z1 = lam[i].x, z2 = fmaf(ca.y, lam[i].y, -ca.x * lam[i].x);
             float b0 = accb[k][0], b1 = accb[k][1], b2 = accb[k][2], a1 = acca[k][0], a2 = acca[k][1];
 #pragma unroll
             for (int n = L - 1; n >= 0; --n) {
@@ -788,10 +795,9 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 b0 = fmaf(g, S2v[slot][n + 2], b0);
                 b1 = fmaf(g, S2v[slot][n + 1], b1);
                 b2 = fmaf(g, S2v[slot][n], b2);
-                const float o = fmaf(cb.y, g, l1);
-                const float t1 = fmaf(ca.x, l1, fmaf(ca.y, l2, ca.w * g));
-                l2 = fmaf(nk, l1, fmaf(ca.x, l2, cb.x * g));
-                l1 = t1;
+                const float o = fmaf(d, g, z1);
+                z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                z2 = fmaf(cd.y, g, cd.w * o);
                 a1 = fmaf(o, S2v[slot][n + 1], a1);
                 a2 = fmaf(o, S2v[slot][n], a2);
                 GY[n] = o;
