@@ -13,6 +13,8 @@ Realisation of one section  H(z) = (b0 + b1 z^-1 + b2 z^-2) / (1 + a1 z^-1 + a2 
 with sg = -a1/2, disc = sg^2 - a2, om = max(sqrt|disc|, OM_MIN), kom = sign(-disc)*om
 (rotation-scaling matrix for complex poles, symmetric matrix for real poles: normal either way),
 g1 = b1 - b0*a1, g2 = ((b2 - b0*a2) + g1*sg)/om.  Then s2[n] = om * w[n-2] where w = u / A(z).
+The lane scans (forward and adjoint) and the forward cascade use this realisation; the adjoint cascade inside a chunk runs each
+section in transposed direct form II (backward_row).
 """
 import numpy as np
 
@@ -186,19 +188,26 @@ def backward_row(r, x, gy, carries, L):
         # adjoint: same machinery on (lane, sample)-reversed data
         GYr = GY[::-1, ::-1]
         astart_r, acarry = tile_scan(GYr @ Ga.T, Ma, Pa, acarry)
-        # per-lane adjoint cascade with correlations (natural lane order, descending n)
+        # per-lane adjoint cascade with correlations (natural lane order, descending n). As in the kernel, each adjoint section
+        # runs in transposed direct form II from the chunk's entry costate (normal-form coordinates, from the scan), mapped once
+        # per chunk: z1 = l1, z2 = -sg*l1 + om*l2 (same zero-input response, same transfer function H(1/z)).
         lam = astart_r[::-1].copy()    # adjoint state at each chunk *end*, section order S-1..0
+        z = np.empty_like(lam)
+        for i in range(S):
+            k = S - 1 - i
+            z[:, 2 * i] = lam[:, 2 * i]
+            z[:, 2 * i + 1] = -r["sg"][k] * lam[:, 2 * i] + r["om"][k] * lam[:, 2 * i + 1]
         GX = np.zeros_like(GY)
         for n in range(L - 1, -1, -1):
             g = GY[:, n].copy()
-            for i, (A, B, C, d) in enumerate(ads):
+            for i in range(S):
                 k = S - 1 - i
-                l1, l2 = lam[:, 2 * i], lam[:, 2 * i + 1]
+                b0, b1, b2 = r["b"][k]
+                a1, a2 = r["a"][k]
                 acc_b[k, 0] += np.dot(g, S2[k, :, n + 2]); acc_b[k, 1] += np.dot(g, S2[k, :, n + 1]); acc_b[k, 2] += np.dot(g, S2[k, :, n])
-                out = C[0] * l1 + C[1] * l2 + d * g
-                n1 = A[0, 0] * l1 + A[0, 1] * l2 + B[0] * g
-                n2 = A[1, 0] * l1 + A[1, 1] * l2 + B[1] * g
-                lam[:, 2 * i], lam[:, 2 * i + 1] = n1, n2
+                out = b0 * g + z[:, 2 * i]
+                z[:, 2 * i] = b1 * g - a1 * out + z[:, 2 * i + 1]
+                z[:, 2 * i + 1] = b2 * g - a2 * out
                 acc_a[k, 1] += np.dot(out, S2[k, :, n + 1]); acc_a[k, 2] += np.dot(out, S2[k, :, n])
                 g = out
             GX[:, n] = g
