@@ -1,0 +1,93 @@
+"""Developer tool: randomized shape sweep of every op against the numpy oracle (forward and all gradients) on small problems.
+Catches layout / tail / alignment slips in the tile paths that the fixed-shape tests might miss."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dasp_pytorch_amd as D
+from oracle import dasp_oracle as orc
+from oracle.recursion import sosfilt_ref, sosfilt_vjp_ref
+SR = 44100
+dev = "cuda:0"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+PEQ = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
+       (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
+lo = np.array([r[0] for r in PEQ]); hi = np.array([r[1] for r in PEQ])
+worst = {}
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+def note(op, key, v, tol, cfg):
+    worst[(op, key)] = max(worst.get((op, key), 0.0), v)
+    if not (v <= tol):
+        print("FAIL", op, key, v, "tol", tol, cfg, flush=True)
+def randN():
+    return int(rng.choice([1, 3, 4, 63, 64, 1000, 1023, 1024, 1025, 2047, 4096, 4100, 8191, 8192, 9000, 16385, 20000, int(rng.integers(1, 40000))]))
+t0 = time.time()
+n_cfg = 0
+while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
+    n_cfg += 1
+    B, C, N = int(rng.integers(1, 5)), int(rng.integers(1, 4)), randN()
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32); w = rng.standard_normal((B, C, N)).astype(np.float32)
+    cfg = (B, C, N)
+    # parametric_eq (N >= 8192 against the oracle of the reference; shorter: against the exact recursion through signal.biquad)
+    p = (rng.random((B, 18)) * (hi - lo) + lo).astype(np.float32)
+    xt = T(x).requires_grad_(True); cols = [T(p[:, i]).requires_grad_(True) for i in range(18)]
+    y = D.parametric_eq(xt, SR, *cols); (y * T(w)).sum().backward()
+    sos = orc.peq_sos(p.astype(np.float64), SR)
+    yo = sosfilt_ref(sos, x)
+    gxo = sosfilt_vjp_ref(sos, w)
+    note("eq", "y", rel(y.detach().cpu().numpy(), yo), 2e-5, cfg); note("eq", "gx", rel(xt.grad.cpu().numpy(), gxo), 3e-5, cfg)
+    if N >= 8192:
+        _, gpo = orc.parametric_eq_vjp(x, SR, p.astype(np.float64), w)
+        gp = torch.stack([c.grad for c in cols], 1).cpu().numpy()
+        note("eq", "gparams", float(np.abs(gp - gpo).max() / np.abs(gpo).max()), 2e-3, cfg)
+    # gain / distortion
+    for name, fn, f, fv, shape in (("gain", D.gain, orc.gain, orc.gain_vjp, (B,)), ("dist", D.distortion, orc.distortion, orc.distortion_vjp, (B * C,))):
+        c = (rng.random(shape) * 24).astype(np.float32)
+        xt = T(x).requires_grad_(True); ct = T(c).requires_grad_(True)
+        y = fn(xt, SR, ct); (y * T(w)).sum().backward()
+        gxo, gco = fv(x, SR, c, w)
+        note(name, "y", rel(y.detach().cpu().numpy(), f(x, SR, c)), 2e-6, cfg); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo), 2e-6, cfg)
+        note(name, "gc", rel(ct.grad.cpu().numpy(), gco), 1e-4, cfg)
+    # compressor (signals bounded away from silence so that the gain computer's kinks are not sampled exactly)
+    if N >= 8192 or True:
+        pc = np.stack([rng.random(B) * 60 - 60, rng.random(B) * 19 + 1, rng.random(B) * 95 + 5, rng.random(B) * 95 + 5, rng.random(B) * 12 + 1e-3, rng.random(B) * 12], 1).astype(np.float32)
+        look = int(rng.choice([0, 0, 0, 5]))
+        xt = T(x).requires_grad_(True); cc = [T(pc[:, i]).requires_grad_(True) for i in range(6)]
+        y = D.compressor(xt, SR, *cc, lookahead_samples=look); (y * T(w)).sum().backward()
+        pd = pc.astype(np.float64)
+        from oracle.recursion import one_pole_ref
+        c = orc._compressor_core(x, SR, pd[:, 0], pd[:, 1], pd[:, 2], pd[:, 4], pd[:, 5], 1e-8, look, np.float64)
+        g = one_pole_ref(c["g_c"][:, 0], c["alpha"][:, 0, 0])[:, None]
+        yo = c["x_d"] * 10 ** ((g + c["mk"]) / 20)
+        note("comp", "y", rel(y.detach().cpu().numpy(), yo), 3e-5, cfg + (look,))
+        assert torch.isfinite(xt.grad).all() and all(torch.isfinite(q.grad).all() for q in cc)
+    # stereo utilities
+    Tn = int(rng.integers(1, 6))
+    xw = (rng.random((B, 2, N)) * 2 - 1).astype(np.float32); wd = rng.random((B, 1)).astype(np.float32)
+    xp = (rng.random((B, Tn, N)) * 2 - 1).astype(np.float32); pan = (rng.random((B, Tn)) * 0.9 + 0.05).astype(np.float32)
+    xb = (rng.random((B, 2, Tn, N)) * 2 - 1).astype(np.float32); send = (rng.random((B, Tn, 1)) * 36 - 24).astype(np.float32)
+    for name, fn, f, fv, xx, c, osh in (("wid", D.stereo_widener, orc.stereo_widener, orc.stereo_widener_vjp, xw, wd, (B, 2, N)),
+                                       ("pan", D.stereo_panner, orc.stereo_panner, orc.stereo_panner_vjp, xp, pan, (B, 2, Tn, N)),
+                                       ("bus", D.stereo_bus, orc.stereo_bus, orc.stereo_bus_vjp, xb, send, (B, 2, N))):
+        ww = rng.standard_normal(osh).astype(np.float32)
+        xt = T(xx).requires_grad_(True); ct = T(c).requires_grad_(True)
+        y = fn(xt, SR, ct); (y * T(ww)).sum().backward()
+        gxo, gco = fv(xx, SR, c, ww)
+        note(name, "y", rel(y.detach().cpu().numpy(), f(xx, SR, c)), 3e-6, cfg + (Tn,)); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo), 3e-6, cfg + (Tn,))
+        note(name, "gc", rel(ct.grad.cpu().numpy(), gco), 2e-4, cfg + (Tn,))
+    # reverb (small impulse responses, odd shapes)
+    if n_cfg % 3 == 0:
+        L = int(rng.choice([64, 300, 1000, 2048, 3000, 5000, 9000])); taps = int(rng.choice([15, 63, 127, 1023]))
+        Cr = int(rng.integers(1, 3)); xr = (rng.random((B, Cr, N)) * 2 - 1).astype(np.float32); wr = rng.standard_normal((B, 2, N)).astype(np.float32)
+        pr = rng.random((B, 25)).astype(np.float32); noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+        xt = T(xr).requires_grad_(True); cr = [T(pr[:, i]).requires_grad_(True) for i in range(25)]
+        y = D.noise_shaped_reverberation(xt, SR, *cr, num_samples=L, num_bandpass_taps=taps, noise=T(noise)); (y * T(wr)).sum().backward()
+        pd = pr.astype(np.float64)
+        yo = orc.noise_shaped_reverberation(xr, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
+        gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(xr, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, wr, L, taps)
+        note("rev", "y", rel(y.detach().cpu().numpy(), yo), 5e-5, cfg + (Cr, L, taps)); note("rev", "gx", rel(xt.grad.cpu().numpy(), gxo), 5e-5, cfg + (Cr, L, taps))
+        gp = torch.stack([q.grad for q in cr], 1).cpu().numpy(); gpo = np.concatenate([gg, gd, gm[:, None]], 1)
+        note("rev", "gp", float(np.abs(gp - gpo).max() / np.abs(gpo).max()), 5e-4, cfg + (Cr, L, taps))
+print("configs", n_cfg)
+for k in sorted(worst): print(k, "%.2e" % worst[k])
