@@ -1,0 +1,44 @@
+"""The effect chain of the reference's style-transfer model with its last stage folded away.
+
+The reference runs `equalizer -> compressor -> reverb -> gain`, four passes over (bs, chs, seq_len) forward and four backward
+(examples/style_transfer.py:150-154). The noise-shaped reverb is linear and time-invariant per batch item, so a per-item gain
+commutes with it:  gain * reverb(c) = reverb(gain * c);  and a gain applied to the compressor's output is what its make-up gain
+already does:  gain_db just adds to makeup_gain_db. The chain below therefore runs three kernels' worth of passes, not four, with
+bit-for-bit the same mathematics (up to fp32 rounding of one multiply) and the gradient of gain_db falling out of the make-up gain's.
+"""
+import torch
+
+from . import modules as _modules
+
+
+class StyleTransferChain:
+    """EQ -> compressor -> reverb -> gain on normalised parameters, the gain folded into the compressor's make-up gain.
+
+    Same constructor idea and `process_normalized` contract as the four `Processor`s it replaces (`dasp_pytorch/modules.py`):
+    `process_normalized(x, eq_params (bs, 18), comp_params (bs, 6), reverb_params (bs, 25), gain_params (bs, 1))`, every entry in
+    [0, 1]; mono or stereo `x`, stereo output (the reverb's)."""
+
+    def __init__(self, sample_rate, **reverb_kwargs):
+        self.sample_rate = sample_rate
+        self.equalizer = _modules.ParametricEQ(sample_rate)
+        self.compressor = _modules.Compressor(sample_rate)
+        self.reverb = _modules.NoiseShapedReverb(sample_rate, **reverb_kwargs)
+        self.gain = _modules.Gain(sample_rate)
+        self.num_params = (self.equalizer.num_params, self.compressor.num_params, self.reverb.num_params, self.gain.num_params)
+
+    def process_normalized(self, x: torch.Tensor, eq_params, comp_params, reverb_params, gain_params):
+        for proc, p in ((self.equalizer, eq_params), (self.compressor, comp_params), (self.reverb, reverb_params), (self.gain, gain_params)):
+            if p.shape[1] != proc.num_params:
+                raise ValueError(f"Parameter tensor has {p.shape[1]} parameters, but processor has {proc.num_params} parameters.")
+        self.gain._check_range(gain_params)
+        self.compressor._check_range(comp_params)
+        lo, span = self.gain._affine(gain_params)
+        gain_db = gain_params * span + lo                                   # (bs, 1), differentiable
+        clo, cspan = self.compressor._affine(comp_params)
+        comp = comp_params * cspan + clo                                    # denormalised compressor controls, columns in param_ranges order
+        names = list(self.compressor.param_ranges)
+        kwargs = {n: comp[:, i] for i, n in enumerate(names)}
+        kwargs["makeup_gain_db"] = kwargs["makeup_gain_db"] + gain_db[:, 0]   # the fold
+        y = self.equalizer.process_normalized(x, eq_params)
+        y = self.compressor.process_fn(y, self.sample_rate, **kwargs)
+        return self.reverb.process_normalized(y, reverb_params)

@@ -40,23 +40,19 @@ class ControlPredictor(torch.nn.Module):
 
 
 class EffectChain:
-    """EQ -> compressor -> reverb, controls normalised to (0, 1) (the reference's StyleTransferModel wiring)."""
+    """EQ -> compressor -> reverb -> gain, controls normalised to (0, 1): the reference's StyleTransferModel wiring
+    (examples/style_transfer.py:150-154) on dasp_pytorch_amd.chain.StyleTransferChain, which folds the gain into the compressor."""
 
     def __init__(self, sample_rate, ir_samples=65536):
-        self.eq = D.ParametricEQ(sample_rate)
-        self.comp = D.Compressor(sample_rate)
-        self.verb = D.NoiseShapedReverb(sample_rate, num_samples=ir_samples, device_noise=True)
-        self.sizes = (self.eq.num_params, self.comp.num_params, self.verb.num_params)
+        self.chain = D.chain.StyleTransferChain(sample_rate, num_samples=ir_samples, device_noise=True)
+        self.sizes = self.chain.num_params
 
     @property
     def num_controls(self):
         return sum(self.sizes)
 
     def __call__(self, x, controls):
-        pe, pc, pv = torch.split(controls, self.sizes, dim=1)
-        y = self.eq.process_normalized(x, pe)
-        y = self.comp.process_normalized(y, pc)
-        return self.verb.process_normalized(y, pv)
+        return self.chain.process_normalized(x, *torch.split(controls, self.sizes, dim=1))
 
 
 def mrstft_loss(a, b, ffts=(512, 2048, 8192)):

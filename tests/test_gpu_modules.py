@@ -63,3 +63,35 @@ def test_style_transfer_chain_example_runs():
     assert out["finite"] and out["steps"] == 3
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert any(float(p.grad.abs().max()) > 0 for p in model.parameters())
+
+
+def test_style_transfer_chain_folds_the_gain(D):
+    """dasp_pytorch_amd.chain.StyleTransferChain (gain folded into the compressor's make-up gain) equals the four processors run in
+    sequence, forward and for every parameter gradient: the reverb is linear per item, so the per-item gain commutes with it."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    B, N = 3, 24576
+    x = torch.rand(B, 2, N, device="cuda:0", generator=g) * 2 - 1
+    chain = StyleTransferChain(SR, num_samples=4096)
+    ps = [torch.rand(B, n, device="cuda:0", generator=g).clamp(0.02, 0.98) for n in chain.num_params]
+    w = torch.randn(B, 2, N, device="cuda:0", generator=g)
+    outs = []
+    for fused in (True, False):
+        pp = [p.clone().requires_grad_(True) for p in ps]
+        xx = x.clone().requires_grad_(True)
+        torch.manual_seed(11)                      # same reverb noise for both runs (drawn from the CPU generator)
+        if fused:
+            y = chain.process_normalized(xx, *pp)
+        else:
+            y = chain.equalizer.process_normalized(xx, pp[0])
+            y = chain.compressor.process_normalized(y, pp[1])
+            y = chain.reverb.process_normalized(y, pp[2])
+            y = chain.gain.process_normalized(y, pp[3])
+        (y * w).sum().backward()
+        outs.append((y.detach(), xx.grad, [p.grad for p in pp]))
+    (y1, gx1, gp1), (y2, gx2, gp2) = outs
+    peak = float(y2.abs().max())
+    assert float((y1 - y2).abs().max()) < 2e-5 * peak
+    assert float((gx1 - gx2).abs().max()) < 5e-5 * float(gx2.abs().max())
+    for a, b in zip(gp1, gp2):
+        assert float((a - b).abs().max()) < 2e-3 * max(float(b.abs().max()), 1e-12)
