@@ -48,6 +48,10 @@ SIGNATURES = {
     "dasp_panner_backward": (_i, [_p] * 6 + [_i, _i, _l, _p]),
     "dasp_bus_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dasp_bus_backward": (_i, [_p] * 6 + [_i, _i, _l, _p]),
+    "dasp_mrstft_partial_floats": (_l, [_l, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "dasp_mrstft_table": (_i, [_p, _p]),
+    "dasp_mrstft_forward": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
+    "dasp_mrstft_backward": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
     "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),

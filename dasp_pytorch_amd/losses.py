@@ -1,0 +1,79 @@
+"""Multi-resolution STFT loss on the HIP kernels of csrc/stftloss.hip: the loss the reference's training loops put directly after
+the effect chain (auraloss.freq.MultiResolutionSTFTLoss(), examples/style_transfer.py:341,363). Same defaults and call convention as
+auraloss 0.4.0: `loss_fn(input, target)` with (bs, chs, seq_len) tensors, spectral convergence + log-magnitude L1 per resolution,
+mean over the resolutions. Only `input` receives a gradient (the target is the reference signal at every call site)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+class _MRSTFTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, target, res, eps):
+        _lib.require_device(inp, "input")
+        _lib.require_device(target, "target")
+        if inp.shape != target.shape:
+            raise RuntimeError(f"input {tuple(inp.shape)} and target {tuple(target.shape)} must have the same shape")
+        L = _lib.lib()
+        N = inp.shape[-1]
+        p32 = inp.detach().reshape(-1, N).to(torch.float32).contiguous()
+        t32 = target.detach().reshape(-1, N).to(torch.float32).contiguous()
+        rows = p32.shape[0]
+        nres = len(res)
+        arr = [(ctypes.c_int * nres)(*[int(r[i]) for r in res]) for i in range(3)]
+        nfl = L.dasp_mrstft_partial_floats(rows, N, nres, *arr)
+        if nfl < 0:
+            raise _lib.DaspHipError("unsupported STFT resolutions (fft a power of two in 8..4096, win <= fft, fft / 2 < seq_len, <= 8 of them)")
+        dev = inp.device
+        tw = _twiddles(dev)
+        partials = torch.empty(nfl, dtype=torch.float32, device=dev)
+        stats = torch.empty(4 * nres, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        call("dasp_mrstft_forward", ptr(p32), ptr(t32), ptr(tw), ptr(partials), ptr(stats), ptr(loss), rows, N, nres, *arr, float(eps), stream())
+        ctx.save_for_backward(p32, t32, stats)
+        ctx.cfg = (rows, N, nres, arr, float(eps), inp.shape, inp.dtype)
+        return loss.to(inp.dtype)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        p32, t32, stats = ctx.saved_tensors
+        rows, N, nres, arr, eps, shape, dtype = ctx.cfg
+        g = torch.empty_like(p32)
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        call("dasp_mrstft_backward", ptr(p32), ptr(t32), ptr(_twiddles(p32.device)), ptr(stats), ptr(gl), ptr(g), rows, N, nres, *arr, eps, stream())
+        return g.reshape(shape).to(dtype), None, None, None
+
+
+_TW = {}
+
+
+def _twiddles(device):
+    key = (device.type, device.index)
+    if key not in _TW:
+        tw = torch.empty(2 * 4096, dtype=torch.float32, device=device)
+        call("dasp_mrstft_table", ptr(tw), stream())
+        _TW[key] = tw
+    return _TW[key]
+
+
+class MultiResolutionSTFTLoss(torch.nn.Module):
+    """auraloss.freq.MultiResolutionSTFTLoss with its default weights (w_sc = w_log_mag = 1, w_lin_mag = w_phs = 0, hann window,
+    L1 magnitude distance, mean reduction)."""
+
+    def __init__(self, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240), eps: float = 1e-8):
+        super().__init__()
+        if not (len(fft_sizes) == len(hop_sizes) == len(win_lengths)):
+            raise ValueError("fft_sizes, hop_sizes and win_lengths must have the same length")
+        self.resolutions = tuple(zip(fft_sizes, hop_sizes, win_lengths))
+        self.eps = eps
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor):
+        return _MRSTFTFunction.apply(input, target, self.resolutions, self.eps)
+
+
+def mrstft_loss(input: torch.Tensor, target: torch.Tensor, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240),
+                eps: float = 1e-8):
+    return _MRSTFTFunction.apply(input, target, tuple(zip(fft_sizes, hop_sizes, win_lengths)), eps)

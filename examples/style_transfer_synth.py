@@ -5,7 +5,8 @@ through the differentiable effects) as a data-parallel training step on MI355X.
 One process per GPU (python -m torch.distributed.run --nproc-per-node N examples/style_transfer_synth.py ...): every rank owns its
 own batch shard, the effect chain runs on the hand-written HIP kernels of dasp_pytorch_amd with no data-path collective, and the only
 exchange is the bucketed all-reduce of the predictor's gradients (dasp_pytorch_amd.distributed.allreduce_gradients, RCCL over xGMI).
-The predictor and the loss are ordinary PyTorch modules: they are the user's code around the hot path, not part of it.
+The predictor is an ordinary PyTorch module (the user's code around the hot path); the loss is dasp_pytorch_amd.losses'
+multi-resolution STFT loss, the fused-kernel counterpart of the auraloss loss the reference trains with.
 
 Prints one JSON line (rank 0): steps/s, clips/s, channel-samples/s through the chain, the loss trajectory.
 """
@@ -55,18 +56,6 @@ class EffectChain:
         return self.chain.process_normalized(x, *torch.split(controls, self.sizes, dim=1))
 
 
-def mrstft_loss(a, b, ffts=(512, 2048, 8192)):
-    """Spectral convergence + log-magnitude L1 at three resolutions (what auraloss.freq.MultiResolutionSTFTLoss measures)."""
-    a = a.reshape(-1, a.shape[-1]); b = b.reshape(-1, b.shape[-1])
-    total = 0.0
-    for n in ffts:
-        w = torch.hann_window(n, device=a.device)
-        A = torch.stft(a, n, n // 4, window=w, return_complex=True).abs().clamp_min(1e-7)
-        Bm = torch.stft(b, n, n // 4, window=w, return_complex=True).abs().clamp_min(1e-7)
-        total = total + torch.linalg.norm(Bm - A) / torch.linalg.norm(Bm) + (A.log() - Bm.log()).abs().mean()
-    return total / len(ffts)
-
-
 def synth_clips(batch, n, gen, device):
     """Speech-like stand-in for the reference's vocal clips: pitched pulse train with a syllable envelope plus noise, peak 0.5."""
     t = torch.arange(n, device=device) / 44100.0
@@ -90,6 +79,7 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
     chain = EffectChain(sample_rate, ir_samples)
     model = ControlPredictor(chain.num_controls, width).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=lr)
+    loss_fn = D.losses.MultiResolutionSTFTLoss()              # auraloss' default resolutions, fused HIP kernels
     losses, t0 = [], None
     for step in range(steps + 1):                             # step 0 warms the caches / clocks and is not timed
         if step == 1:
@@ -102,7 +92,7 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
             target = chain(x, torch.rand(batch, chain.num_controls, device=dev, generator=gen))
         controls = model(x.mean(1, keepdim=True), target.mean(1, keepdim=True))
         y = chain(x, controls)
-        loss = mrstft_loss(y, target)
+        loss = loss_fn(y, target)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         dd.allreduce_gradients(model.parameters())            # the one collective of the job

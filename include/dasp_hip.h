@@ -152,6 +152,22 @@ int dasp_bus_forward(const float* x, const float* send_db, float* y, int B, int 
 int dasp_bus_backward(const float* x, const float* send_db, const float* gy, float* gx, float* gsend, float* partials, int B, int T,
                       long N, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-resolution STFT loss, the op downstream of the effect chain in the reference's training loops
+ * (auraloss.freq.MultiResolutionSTFTLoss(): examples/style_transfer.py:341,363, auto_eq.py:252, virtual_analog.py:288; auraloss is
+ * not vendored by the reference - its published algorithm is restated in oracle/dasp_oracle.py:mrstft_loss).
+ * pred, target: (rows, N) fp32.  Resolutions: nres <= 8 triples (fft, hop, win); fft a power of two in 8..4096, win <= fft, fft/2 < N.
+ * tw: 4096 complex twiddles from dasp_mrstft_table.  partials: dasp_mrstft_partial_floats floats.  stats: 4*nres floats
+ * (forward -> backward).  loss, gloss: device scalars.  gpred = gloss * d loss / d pred (float atomics: summation order only
+ * is not deterministic).
+ * ------------------------------------------------------------------------------------------- */
+long dasp_mrstft_partial_floats(long rows, int N, int nres, const int* fft, const int* hop, const int* win);
+int dasp_mrstft_table(void* tw, void* stream);
+int dasp_mrstft_forward(const float* pred, const float* target, const void* tw, float* partials, float* stats, float* loss, int rows,
+                        int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
+int dasp_mrstft_backward(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss, float* gpred,
+                         int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

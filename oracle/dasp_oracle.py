@@ -509,3 +509,70 @@ def noise_shaped_reverberation_vjp(x, sample_rate, gains, decays, mix, noise, gy
     if c["chs"] == 1:
         gx = gx.sum(1, keepdims=True)
     return gx.astype(dtype), ggain.astype(dtype), gdec.astype(dtype), gmix.astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-resolution STFT loss: the op downstream of the hot path in the reference's training loops
+# (auraloss.freq.MultiResolutionSTFTLoss(), call sites examples/style_transfer.py:341,363, auto_eq.py:252, virtual_analog.py:288).
+# auraloss is a third-party dependency that is NOT vendored in /root/reference and not pinned by it (no version in setup.py /
+# pyproject.toml): PARITY UNPINNED. This restates the published algorithm of auraloss 0.4.0 with its default arguments:
+#   for (n_fft, hop, win) in ((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)):
+#       X = torch.stft(x, n_fft, hop, win, hann_window(win), return_complex=True)        # center=True, reflect padding, onesided
+#       mag = sqrt(clamp(re^2 + im^2, min=eps)), eps = 1e-8
+#       sc = ||mag_target - mag_input||_F / ||mag_target||_F;  lm = mean |log mag_input - log mag_target|
+#   loss = mean over resolutions of (sc + lm)
+MRSTFT_DEFAULT = ((1024, 120, 600), (2048, 240, 1200), (512, 50, 240))
+
+
+def _stft_mag(x, n_fft, hop, win, eps, dtype):
+    """x (rows, N) -> magnitudes (rows, n_fft/2+1, frames), torch.stft conventions (center, reflect, periodic hann zero-padded to n_fft)."""
+    x = np.asarray(x, dtype)
+    rows, N = x.shape
+    xp = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+    w = np.zeros(n_fft, dtype)
+    lp = (n_fft - win) // 2
+    w[lp:lp + win] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win) / win)
+    frames = 1 + N // hop
+    idx = np.arange(frames)[:, None] * hop + np.arange(n_fft)[None, :]
+    seg = xp[:, idx] * w                                   # (rows, frames, n_fft)
+    X = np.fft.rfft(seg, axis=-1)
+    return np.sqrt(np.maximum(X.real ** 2 + X.imag ** 2, eps)).transpose(0, 2, 1), seg, w, idx
+
+
+def mrstft_loss(inp, target, resolutions=MRSTFT_DEFAULT, eps=1e-8, dtype=np.float64):
+    """inp, target (bs, chs, N) -> scalar loss."""
+    a = np.asarray(inp, dtype).reshape(-1, np.shape(inp)[-1]); b = np.asarray(target, dtype).reshape(-1, np.shape(target)[-1])
+    total = 0.0
+    for n_fft, hop, win in resolutions:
+        A, _, _, _ = _stft_mag(a, n_fft, hop, win, eps, dtype)
+        B, _, _, _ = _stft_mag(b, n_fft, hop, win, eps, dtype)
+        total += np.linalg.norm(B - A) / np.linalg.norm(B) + np.mean(np.abs(np.log(A) - np.log(B)))
+    return total / len(resolutions)
+
+
+def mrstft_loss_vjp(inp, target, resolutions=MRSTFT_DEFAULT, eps=1e-8, dtype=np.float64):
+    """d loss / d inp (same shape as inp); the target is treated as a constant (it is the reference signal at every call site)."""
+    shape = np.shape(inp)
+    a = np.asarray(inp, dtype).reshape(-1, shape[-1]); b = np.asarray(target, dtype).reshape(-1, shape[-1])
+    rows, N = a.shape
+    g = np.zeros_like(a)
+    for n_fft, hop, win in resolutions:
+        B, _, _, _ = _stft_mag(b, n_fft, hop, win, eps, dtype)
+        A, seg, w, idx = _stft_mag(a, n_fft, hop, win, eps, dtype)
+        X = np.fft.rfft(seg, axis=-1).transpose(0, 2, 1)                  # (rows, bins, frames)
+        s1, s2 = np.linalg.norm(B - A), np.linalg.norm(B)
+        gA = (A - B) / (s1 * s2) - np.sign(np.log(B) - np.log(A)) / (A * A.size)
+        gA = np.where(X.real ** 2 + X.imag ** 2 > eps, gA, 0.0) / len(resolutions)     # clamp has zero slope
+        G = (gA * X / A).transpose(0, 2, 1)                                # gradient w.r.t. (Re, Im) of the one-sided bins, as complex
+        full = np.zeros((rows, G.shape[1], n_fft), np.complex128)
+        full[:, :, :n_fft // 2 + 1] = G
+        gseg = np.real(np.fft.ifft(full, axis=-1) * n_fft) * w             # sum_k G[k] e^{+i theta}
+        gp = np.zeros((rows, N + 2 * (n_fft // 2)), dtype)
+        np.add.at(gp, (np.arange(rows)[:, None, None], idx[None, :, :]), gseg)
+        # adjoint of the reflect padding
+        p = n_fft // 2
+        core = gp[:, p:p + N].copy()
+        core[:, 1:p + 1] += gp[:, :p][:, ::-1]
+        core[:, N - 1 - p:N - 1] += gp[:, p + N:][:, ::-1]
+        g += core
+    return g.reshape(shape)
