@@ -116,6 +116,19 @@ def secondary(dev):
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
              2 * 1.354e9 / (128 * 2 * 262144),
              "device-generated noise; bytes = SURVEY 8(d) compulsory traffic with noise as an input (2 x 1.354 GB)")
+    # widening rows: stereo utilities and the multi-resolution STFT loss
+    bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
+    xs = (rnd(16, 2, 131072) * 0.6 - 0.3).requires_grad_(True)
+    ys = rnd(16, 2, 131072) * 0.6 - 0.3
+    loss_fn = D.losses.MultiResolutionSTFTLoss()
+
+    def loss_step():
+        xs.grad = None
+        loss_fn(xs, ys).backward()
+    t = _time_steps(loss_step)
+    res["mrstft_loss"] = {"shape": [16, 2, 131072], "ms_fwd_bwd": round(t * 1e3, 3), "channel_samples_per_s": 16 * 2 * 131072 / t,
+                          "note": "3 resolutions (1024/120/600, 2048/240/1200, 512/50/240); compute-bound (7.4 transforms per input sample "
+                                  "and direction), HBM traffic is the two signals and the gradient"}
     return res
 
 
