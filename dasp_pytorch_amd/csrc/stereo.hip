@@ -12,12 +12,13 @@ namespace dasp {
 constexpr int ST_THREADS = 256;
 constexpr int ST_SEG = 4096;     // samples per workgroup: 4 float4 per thread
 
-__device__ __forceinline__ f4 ld4(const float* p, long i, long n, bool vec) {
-    if (vec) return *reinterpret_cast<const f4*>(p + i);
+// STREAM: non-temporal hint, used by the backward kernels (several read streams + a write stream; elementwise.hip: 0.160 -> 0.132 ms)
+template <bool STREAM = false> __device__ __forceinline__ f4 ld4(const float* p, long i, long n, bool vec) {
+    if (vec) return STREAM ? ld_stream(reinterpret_cast<const f4*>(p + i)) : *reinterpret_cast<const f4*>(p + i);
     return f4{i < n ? p[i] : 0.f, i + 1 < n ? p[i + 1] : 0.f, i + 2 < n ? p[i + 2] : 0.f, i + 3 < n ? p[i + 3] : 0.f};
 }
-__device__ __forceinline__ void st4(float* p, long i, long n, bool vec, f4 v) {
-    if (vec) { *reinterpret_cast<f4*>(p + i) = v; return; }
+template <bool STREAM = false> __device__ __forceinline__ void st4(float* p, long i, long n, bool vec, f4 v) {
+    if (vec) { if (STREAM) st_stream(reinterpret_cast<f4*>(p + i), v); else *reinterpret_cast<f4*>(p + i) = v; return; }
     if (i < n) p[i] = v.x;
     if (i + 1 < n) p[i + 1] = v.y;
     if (i + 2 < n) p[i + 2] = v.z;
@@ -58,10 +59,10 @@ widener_kernel(const float* __restrict__ x, const float* __restrict__ width, con
     for (int j = 0; j < ST_SEG / (4 * ST_THREADS); ++j) {
         const long i = (long)seg * ST_SEG + (long)(j * ST_THREADS + threadIdx.x) * 4;
         if (i >= N) break;
-        const f4 l = ld4(src_l, i, N, vec), r = ld4(src_r, i, N, vec);
-        st4(ol, i, N, vec, l + k * r);
-        st4(orr, i, N, vec, k * l + r);
-        if (BWD) acc += dot4(ld4(xr, i, N, vec), l) + dot4(ld4(xl, i, N, vec), r);     // R gL + L gR
+        const f4 l = ld4<BWD>(src_l, i, N, vec), r = ld4<BWD>(src_r, i, N, vec);
+        st4<BWD>(ol, i, N, vec, l + k * r);
+        st4<BWD>(orr, i, N, vec, k * l + r);
+        if (BWD) acc += dot4(ld4<true>(xr, i, N, vec), l) + dot4(ld4<true>(xl, i, N, vec), r);     // R gL + L gR
     }
     if (BWD) block_sum_to(-2.f * acc, partials + (size_t)b * nseg + seg);
 }
@@ -93,8 +94,8 @@ panner_kernel(const float* __restrict__ x, const float* __restrict__ pan, const 
             st4(out + y0, i, N, vec, lg * xv);
             st4(out + y1, i, N, vec, rg * xv);
         } else {
-            const f4 g0 = ld4(gy + y0, i, N, vec), g1 = ld4(gy + y1, i, N, vec);
-            st4(out + (size_t)row * N, i, N, vec, lg * g0 + rg * g1);
+            const f4 g0 = ld4<true>(gy + y0, i, N, vec), g1 = ld4<true>(gy + y1, i, N, vec);
+            st4<true>(out + (size_t)row * N, i, N, vec, lg * g0 + rg * g1);
             al += dot4(xv, g0); ar += dot4(xv, g1);
         }
     }
@@ -139,8 +140,8 @@ bus_kernel(const float* __restrict__ x, const float* __restrict__ send_db, const
             for (int j = 0; j < ST_SEG / (4 * ST_THREADS); ++j) {
                 const long i = (long)seg * ST_SEG + (long)(j * ST_THREADS + threadIdx.x) * 4;
                 if (i >= N) break;
-                acc += dot4(ld4(xr + (size_t)t * N, i, N, vec), g[j]);
-                st4(out + ((size_t)row * T + t) * N, i, N, vec, s_lin[t] * g[j]);
+                acc += dot4(ld4<true>(xr + (size_t)t * N, i, N, vec), g[j]);
+                st4<true>(out + ((size_t)row * T + t) * N, i, N, vec, s_lin[t] * g[j]);
             }
             block_sum_to(acc, partials + ((size_t)row * nseg + seg) * T + t);
         }
