@@ -231,24 +231,27 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     }
     PTRACE(41, 0);
     __syncthreads();
+    PTRACE(47, 0);
 
-    // Phi for the forward system (sys 0) and the adjoint system (sys 1: sections reversed, A^T, B<->C)
+    // Phi for the forward system (sys 0) and the adjoint system (sys 1: sections reversed, A^T, B<->C). Written without branches on
+    // purpose: a kernel starts with a cold instruction cache, and in its divergent if / else form this loop's ~50 taken branches
+    // each paid an instruction fetch miss (measured 25-50k cycles for ~350 instructions; straight-line code streams through).
     for (int e = tid; e < 2 * NN; e += 256) {
         const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
         const int kk = i / 2, r = i % 2, jj = j / 2, c = j % 2;
         const int fk = sys ? S - 1 - kk : kk, fj = sys ? S - 1 - jj : jj;  // forward section ids
-        double v = 0.0;
-        if (jj == kk) {
-            const double sg = sec[fk][0], om = sec[fk][1], kom = sec[fk][2];
-            const double A[2][2] = {{sg, -kom}, {om, sg}};
-            v = sys ? A[c][r] : A[r][c];
-        } else if (jj < kk) {
-            const double Bk = sys ? sec[fk][3 + r] : (r == 0 ? 1.0 : 0.0);   // B of section at position kk
-            const double Cj = sys ? (c == 0 ? 1.0 : 0.0) : sec[fj][3 + c];   // C of section at position jj
-            double gain = 1.0;
-            for (int m = jj + 1; m < kk; ++m) gain *= sec[sys ? S - 1 - m : m][5];
-            v = Bk * gain * Cj;
+        const double sg = sec[fk][0], om = sec[fk][1], kom = sec[fk][2];
+        const int rr = sys ? c : r, cc = sys ? r : c;                      // A^T for the adjoint system
+        const double a_el = rr == cc ? sg : (rr == 0 ? -kom : om);        // A = [[sg, -kom], [om, sg]]
+        const double Bk = sys ? sec[fk][3 + r] : (r == 0 ? 1.0 : 0.0);   // B of the section at position kk
+        const double Cj = sys ? (c == 0 ? 1.0 : 0.0) : sec[fj][3 + c];   // C of the section at position jj
+        double gain = 1.0;                                                 // feed-through of the sections strictly between jj and kk
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+            const double dm = sec[sys ? S - 1 - m : m][5];
+            gain *= (m > jj && m < kk) ? dm : 1.0;
         }
+        const double v = jj == kk ? a_el : (jj < kk ? Bk * gain * Cj : 0.0);
         Phi[sys][i * S2 + j] = v;
         T1[sys][i * S2 + j] = v;
     }
