@@ -1,5 +1,7 @@
 """Drop-in for dasp_pytorch.functional on MI355X: same names, argument order and keyword names
 (dasp_pytorch/functional.py), every effect computed by hand-written HIP kernels (csrc/)."""
+import functools
+
 import torch
 
 from . import signal as _signal
@@ -158,6 +160,13 @@ def expander(
     return _dynamics(1, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples)
 
 
+@functools.lru_cache(maxsize=8)
+def _device_filterbank(num_taps: int, sample_rate: float, device: torch.device):
+    """One device-resident copy of the octave filterbank per (taps, sample_rate, device): the taps are constants, so the
+    host->device copy and their spectra (ops._filter_spectrum) are paid once, not per call."""
+    return _signal.octave_band_filterbank(num_taps, sample_rate).squeeze(1).to(device).contiguous()
+
+
 def noise_shaped_reverberation(
     x: torch.Tensor,
     sample_rate: float,
@@ -209,7 +218,7 @@ def noise_shaped_reverberation(
     band_decays = torch.stack([band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
                                band7_decay, band8_decay, band9_decay, band10_decay, band11_decay], dim=1).view(bs, 12)
     mix = mix.view(bs)
-    filters = _signal.octave_band_filterbank(num_bandpass_taps, sample_rate).squeeze(1).to(x.device)
+    filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
     if noise is None:
         shape = (bs * 2, 12, num_samples + num_bandpass_taps - 1)
         noise = torch.randn(*shape, device=x.device) if device_noise else torch.randn(*shape).to(x.device)

@@ -326,6 +326,26 @@ class BusFunction(_StereoFunction):
         return BusFunction._grad(ctx, gy)
 
 
+_FSPEC_CACHE = {}
+
+
+def _filter_spectrum(filters, nb, taps, n_complex, dev):
+    """Spectra of the filterbank taps (dasp_reverb_filter_spectrum). They depend only on the taps, so the result is kept
+    for as long as the caller keeps passing the same (unmodified) filters tensor on the same stream -- functional.py
+    holds one device copy of the bank per (taps, sample_rate, device)."""
+    key = (id(filters), filters._version, int(n_complex), int(torch.cuda.current_stream().cuda_stream))
+    hit = _FSPEC_CACHE.get(key)
+    if hit is not None and hit[0] is filters:
+        return hit[1]
+    Fspec = _cbuf(n_complex, dev)
+    call("dasp_reverb_filter_spectrum", ptr(_f32c(filters)), nb, taps, ptr(Fspec), stream())
+    if filters.is_cuda and filters.dtype == torch.float32 and filters.is_contiguous() and not filters.requires_grad:
+        if len(_FSPEC_CACHE) >= 8:
+            _FSPEC_CACHE.clear()
+        _FSPEC_CACHE[key] = (filters, Fspec)
+    return Fspec
+
+
 class ReverbFunction(torch.autograd.Function):
     """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1), filters (nb,taps), gains/decays (B,nb), mix (B)."""
 
@@ -340,8 +360,7 @@ class ReverbFunction(torch.autograd.Function):
         check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
         x32, n32 = _f32c(x), _f32c(noise)
         g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
-        Fspec = _cbuf(sizes[4], dev)
-        call("dasp_reverb_filter_spectrum", ptr(_f32c(filters)), nb, taps, ptr(Fspec), stream())
+        Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
         y = torch.empty_like(x32)
         need_grad = any(ctx.needs_input_grad)
         A, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
