@@ -60,7 +60,7 @@ __device__ long long g_trace[64];
 template <int S, int L>
 struct SosLayout {
     static constexpr int S2 = 2 * S;
-    static constexpr int COEF = 0;                   // [S][8]: sg, om, kom, g1, g2, d, kappa, pad
+    static constexpr int COEF = 0;                   // [S][8]: sg, om, kom, g1, g2, d, kappa, direct-form flag (0 / 1)
     static constexpr int GT = COEF + S * 8;          // [S][L][2] forward chunk table, section-major
     static constexpr int MC = GT + L * S2;           // [S][S][4] blocks of Phi^L (j < k used)
     static constexpr int PL = MC + 4 * S * S;        // [S][4][4] M_kk^(2^l), l = 0..3
@@ -72,8 +72,8 @@ struct SosLayout {
     static constexpr int PLA = PL + SYS;
     static constexpr int P64A = P64 + SYS;
     static constexpr int PWA = PW + SYS;
-    static constexpr int DF = GT + 2 * SYS;          // [S][4]: b1, b2, -a1, -a2 (normalised): transposed direct form II of the adjoint sections
-    static constexpr int TOTAL = DF + 4 * S;
+    static constexpr int DF = GT + 2 * SYS;          // [S][8]: b1, b2, -a1, -a2 (normalised), zc1, zc2, 1/om, sg/om: direct-form sections
+    static constexpr int TOTAL = DF + 8 * S;
 };
 // fp64 side table for the finalize kernel, per (item, section)
 constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_STRIDE = 24;
@@ -177,6 +177,12 @@ __device__ void rbj_design(int type, double sample_rate, double gain_db, double 
 // ------------------------------------------------------------------------------------------------
 // Prep kernel: one workgroup per batch item. Builds the realisation and all chunk tables in fp64.
 constexpr double OM_MIN = 1e-5;
+// A section whose poles are complex and at least this far (imaginary part) from the real axis runs in direct form between the exact
+// chunk restarts (5 ops per sample against 7 in normal form): the internal signals of a direct form exceed the normal form's by
+// 1 / (2 sin(pole angle)), which is what costs digits near z = +-1 and nothing in the middle of the band.
+#ifndef DASP_DF_OM_MIN
+#define DASP_DF_OM_MIN 0.125
+#endif
 
 template <int S, int L>
 __global__ void __launch_bounds__(256)
@@ -218,12 +224,16 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             om = om < OM_MIN ? OM_MIN : om;
             const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
             sec[k][0] = sg; sec[k][1] = om; sec[k][2] = kap * om; sec[k][3] = g1; sec[k][4] = g2; sec[k][5] = b0; sec[k][6] = kap;
-            float* df = tb + LY::DF + k * 4;
+            const bool direct = disc < 0 && om >= DASP_DF_OM_MIN;
+            float* df = tb + LY::DF + k * 8;
             df[0] = (float)b1; df[1] = (float)b2; df[2] = (float)-a1; df[3] = (float)-a2;
+            // entry states of the direct forms from the normal-form chunk start state (s1, s2): transposed form II z1 = g1 s1 + g2 s2,
+            // z2 = zc1 s1 + zc2 s2 (= C (A + a1 I) s); form II w[-2] = s2 / om, w[-1] = s1 + (sg / om) s2
+            df[4] = (float)(-g1 * sg + g2 * om); df[5] = (float)(-g1 * kap * om - g2 * sg); df[6] = (float)(1.0 / om); df[7] = (float)(sg / om);
             float* cf = tb + LY::COEF + k * 8;
             cf[0] = (float)sg; cf[1] = (float)om; cf[2] = (float)(kap * om); cf[3] = (float)g1; cf[4] = (float)g2;
-            cf[5] = (float)b0; cf[6] = (float)kap; cf[7] = 0.f;
-            d[DT_OM] = om;
+            cf[5] = (float)b0; cf[6] = (float)kap; cf[7] = direct ? 1.f : 0.f;
+            d[DT_OM] = direct ? 1.0 : om;   // the correlations of a direct-form section are taken with w itself, not with om w
             for (int c = 0; c < 5; ++c) d[DT_B0 + c] = c5[c];
             d[DT_A0] = a0; d[7] = kap;
             d[23] = 0.0;
@@ -393,6 +403,7 @@ __device__ __forceinline__ void order_after(float& a, float dep) { asm volatile(
 // it the compiler overlaps independent phases of a tile and their register live ranges add up.
 __device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(f2& a) { float x = a.x, y = a.y; pin(x); pin(y); a = f2{x, y}; }
+__device__ __forceinline__ void pin(f4& a) { asm volatile("" : "+v"(a)); }
 template <typename T, int N>
 __device__ __forceinline__ void pin(T (&a)[N]) {
 #pragma unroll
@@ -441,6 +452,53 @@ __device__ __forceinline__ f2 blk_apply(f4 c, float t1, float t2, f2 f) {
     return fma2(f2{c.x, c.y}, splat(t1), fma2(f2{c.z, c.w}, splat(t2), f));
 }
 
+// bit k set: section k runs in direct form (prep kernel's decision, COEF[k][7]); wave-uniform
+template <int S>
+__device__ __forceinline__ unsigned direct_form_mask(const float* __restrict__ coef) {
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) m |= (coef[k * 8 + 7] != 0.f ? 1u : 0u) << k;
+    return __builtin_amdgcn_readfirstlane(m);
+}
+
+// Zero-state chunk end states of all sections for the whole tile, on the matrix cores: z[2S x 64 chunks] = G[2S x L] * X[L x 64] is
+// a small dense product whose left factor is the same for every tile of a row. As packed VALU FMAs it was L issue-slot pairs per
+// section and tile (19 % of the forward kernel's VALU work, 10 % of the backward's); as 16 v_mfma_f32_16x16x4_f32 it runs beside
+// the VALU. Operand layouts (16x16x4 f32): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[i][j] in lane 16 (i / 4) + j,
+// register i % 4. With contraction slot (q, k) <-> sample 4 k + q, lane l's B operands of column block c are one granule of the
+// swizzled tile image (chunk 16 c + l % 16, granule l / 16) and its D registers are one granule (rows 4 (l / 16) ..) of a [chunk][16
+// rows] image with the same geometry, so both sides use the tile-image helpers.
+//   chunk_table_operands: A registers, once per kernel. Row 2 k + comp of G is Gs[(k L + n) 2 + comp]; rows >= 2 S are zero.
+//   chunk_products_load / _issue / _collect: img = this tile's swizzled input image (the operands are in registers after _load, so
+//   the image can be handed to the next DMA), scratch = a free image of the wave; Z[2 k + comp] for chunk `chunk`.
+template <int S, int L>
+__device__ __forceinline__ void chunk_table_operands(const float* __restrict__ Gs, float (&A)[4], int lane) {
+    static_assert(L == 16 && 2 * S <= 16, "one 16x16x4 block row");
+    const int i = lane & 15, k = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[q] = i < 2 * S ? Gs[((i >> 1) * L + 4 * k + q) * 2 + (i & 1)] : 0.f;
+}
+__device__ __forceinline__ void chunk_products_load(const float* img, f4 (&Bv)[4], int lane) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Bv[c] = *reinterpret_cast<const f4*>(img + 4 * swz_slot(16 * c + (lane & 15), lane >> 4));
+}
+__device__ __forceinline__ void chunk_products_issue(const f4 (&Bv)[4], const float (&A)[4], f4 (&acc)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q], Bv[c][q], acc[c], 0, 0, 0);
+}
+template <int L>
+__device__ __forceinline__ void chunk_products_collect(float* scratch, const f4 (&acc)[4], float (&Z)[L], int lane, int chunk) {
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(scratch + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = acc[c];
+    wave_lds_sync();
+    lds_to_chunks_swz<L>(scratch, Z, chunk);
+}
+
 // Whole-tile scan for one system (forward or adjoint tables): lane chunks X -> chunk start states st.
 //   Gs   : [S][L][2] chunk table (zero-state end state of section k = sum_n Gs[k][n] X[n]); zmap is
 //          applied to that per-lane value before the scan (identity, or the lane mirror for the adjoint)
@@ -456,14 +514,11 @@ __device__ __forceinline__ f2 blk_apply(f4 c, float t1, float t2, f2 f) {
 // refilled for section k+1 right after its last use in section k (the scheduling barriers pin the
 // issue points), which keeps at most one section's worth (~72 SGPRs) live.
 template <int S, int L, typename FMap, typename FPre, typename FIn, typename FOut>
-__device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __restrict__ Gs, FMap&& zmap, f2 (&st)[S],
+__device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (&st)[S],
                                           const float* __restrict__ MCs, const float* __restrict__ PLs,
                                           const float* __restrict__ P64s, const f4* __restrict__ pws, int lane,
                                           FPre&& carry_prefetch, FIn&& carry_in, FOut&& carry_out, bool trace_on = false) {
-    f2 G[L];
     f4 MC[S], PL[4], P64[2];
-#pragma unroll
-    for (int n = 0; n < L; ++n) G[n] = TLD2(Gs + 2 * n);
 #pragma unroll
     for (int l = 0; l < 4; ++l) PL[l] = TLD4(PLs + 4 * l);
     P64[0] = TLD4(P64s);
@@ -477,21 +532,10 @@ __device__ __forceinline__ void tile_scan(const float (&X)[L], const float* __re
         TRACE2(8);
         f4 pw16 = pws[k * 64 + (lane & 15)], pw32 = pws[k * 64 + (lane & 31)], pw64 = pws[k * 64 + lane];
         carry_prefetch(k);
-        f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < L; n += 2) {
-            const f2 xy = f2{X[n], X[n + 1]};
-            z0 = fma2_bcast<0>(G[n], xy, z0);
-            z1 = fma2_bcast<1>(G[n + 1], xy, z1);
-        }
-        f2 f = zmap(z0 + z1);
+        f2 f = zmap(f2{Z[2 * k], Z[2 * k + 1]});
         { float a = pw16.x, b = pw32.x, c = pw64.x; pin(a); pin(b); pin(c); pw16.x = a; pw32.x = b; pw64.x = c; }
         TRACE2(9);
         __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < S) {
-#pragma unroll
-            for (int n = 0; n < L; ++n) G[n] = TLD2(Gs + ((k + 1) * L + n) * 2);
-        }
 #pragma unroll
         for (int j = 0; j < k; ++j) f = blk_apply_s(MC[j], st[j], f);
         pin(f); TRACE2(10);
@@ -534,21 +578,24 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                float* __restrict__ carries, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L;        // unpadded, swizzled tile images (common.hpp)
-    constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8;
+    constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     float* __restrict__ yr = y + (size_t)row * N;
-    float* tbx = lds + wave * 2 * IMG;         // x image: this tile's, then (by LDS-DMA, as soon as it has been read) the next one's
-    float* tby = tbx + IMG;                    // y image on its way out
-    const int mb_in = LDS_T + wave * S * 4, mb_out = LDS_T + ((wave + 1) % W) * S * 4;
-    float* pw_lds = lds + LDS_T + LDS_MB;
-    float* cf_lds = pw_lds + LDS_PW;
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[LDS_T + i] = 0.f;
+    // mailboxes, coefficients and per-lane powers first: below 64 KiB their addresses fold into the 16-bit DS offset field (behind
+    // the tile images every slot needed an address register of its own, ~14 VGPRs that ended up spilled on the carry chain)
+    const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;
+    float* cf_lds = lds + LDS_MB;
+    float* pw_lds = cf_lds + LDS_CF;
+    float* tbx = pw_lds + LDS_PW + wave * 2 * IMG;   // x image: this tile's, then (by LDS-DMA, as soon as it has been read) the next one's
+    float* tby = tbx + IMG;                          // y image on its way out
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = 0.f;
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PW + i];
-    for (int i = threadIdx.x; i < LDS_CF; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
     __syncthreads();
     const f4* pws = reinterpret_cast<const f4*>(pw_lds);
 
@@ -558,6 +605,9 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx));
     if (wave < nt && tile_full<L>((long)wave * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)wave * TS, a_x, lane);
     int stores_in_flight = 0;
+    float Aop[4];
+    chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
+    const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
 
     for (int t = wave; t < nt; t += W) {
         int toff = 0;
@@ -572,13 +622,23 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         if (full) wait_vmcnt(stores_in_flight);
         else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
         lds_to_chunks_swz<L>(tbx, X, lane);
-        pin(X);
+        f4 Bop[4], zacc[4];
+        chunk_products_load(tbx, Bop, lane);
+        pin(X); pin(Bop);
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 16)
+        if (t + W < nt && t < W) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
+#else
         if (t + W < nt && tile_full<L>((long)(t + W) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
+#endif
         TRACE(1);
+        float Z[L];
+        chunk_products_issue(Bop, Aop, zacc);
+        chunk_products_collect<L>(tby, zacc, Z, lane, lane);   // the y image is idle until the end of the tile
+        pin(Z); TRACE(5);
 
         f2 st[S];
         MboxPeek pk;
-        tile_scan<S, L>(X, tbl + LY::GT, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+        tile_scan<S, L>(Z, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
             [&](int k) { if (W > 1 && t > 0) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
             [&](int k, f2& K) {
                 if (W == 1) K = Kreg[k];
@@ -599,7 +659,11 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #endif
             );
         TRACE(2);
-        if (carries) {   // chunk start states for the backward pass: [row][tile][section][lane] f2, 512 B per wave store
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 8)
+        if (false) {
+#else
+        if (carries) {   // chunk start states for the backward pass
+#endif: [row][tile][section][lane] f2, 512 B per wave store
             f2* cs = reinterpret_cast<f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
 #pragma unroll
             for (int k = 0; k < S; ++k) { if (DASP_FWD_NT & 4) st_stream(cs + k * 64, st[k]); else cs[k * 64] = st[k]; }
@@ -617,24 +681,44 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 const int oz = opaque_zero_after(X[0]);
                 const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
                 const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
-                const float nk = -ca.z;
                 float s1 = st[k].x, s2 = st[k].y;
+                if ((direct >> k) & 1) {   // wave-uniform. Transposed direct form II from the exact chunk start state: y = b0 u + z1;
+                                           // z1 = b1 u - a1 y + z2; z2 = b2 u - a2 y
+                    const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
+                    const f2 cz = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 4 + oz);   // zc1, zc2
+                    float z1 = fmaf(ca.w, s1, cb.x * s2), z2 = fmaf(cz.x, s1, cz.y * s2);
 #pragma unroll
-                for (int n = 0; n < L; ++n) {
-                    const float u = X[n];
-                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                    const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                    s2 = fmaf(ca.y, s1, ca.x * s2);
-                    s1 = t1;
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        const float o = fmaf(cb.y, u, z1);
+                        z1 = fmaf(cd.x, u, fmaf(cd.z, o, z2));
+                        z2 = fmaf(cd.y, u, cd.w * o);
+                        X[n] = o;
+                    }
+                } else {
+                    const float nk = -ca.z;
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                        s2 = fmaf(ca.y, s1, ca.x * s2);
+                        s1 = t1;
+                    }
                 }
             }
         }
         TRACE(3);
 
         chunks_to_lds_swz<L>(tby, X, lane);
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 4)
+        if (X[0] == 123.456f) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
+        stores_in_flight = -1;
+#else
         if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
         else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
-        stores_in_flight = full ? (carries ? S : 0) + L / 4 : -1;      // -1: a ragged tile issues a data-dependent number of stores
+        stores_in_flight = full ? (carries ? S : 0) + L / 4 : -1;
+#endif      // -1: a ragged tile issues a data-dependent number of stores
         TRACE(4);
     }
 }
@@ -658,7 +742,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     constexpr int NSTASH4 = (H * (L + 2) + 3) / 4;                 // float4 per lane of parked s2 signals
     // per wave: x landing image, gy landing image, gx staging image (unpadded, swizzled: common.hpp), saved chunk states, parked signals
     constexpr int IMG = 64 * L, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
-    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 12;   // COEF rows, then DF rows
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = blockIdx.x;
@@ -666,18 +750,18 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
     float* __restrict__ gxr = gx + (size_t)row * N;
-    float* tbx = lds + wave * REGION;              // x image of this tile; receives the next tile's as soon as it has been read
+    const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;   // small regions first (16-bit DS offsets), as in the forward kernel
+    float* cf_lds = lds + LDS_MB;
+    float* pw_lds = cf_lds + LDS_CF;
+    float* tbx = pw_lds + LDS_PW + wave * REGION;  // x image of this tile; receives the next tile's as soon as it has been read
     float* tbg = tbx + IMG;                        // gy image, likewise
     float* tbo = tbg + IMG;                        // gx image on its way out
     float* tst = tbo + IMG;                        // chunk start states [section][lane] f2
     float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
-    const int mb_in = LDS_T + wave * S * 4, mb_out = LDS_T + ((wave + 1) % W) * S * 4;
-    float* pw_lds = lds + LDS_T + LDS_MB;
-    float* cf_lds = pw_lds + LDS_PW;
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[LDS_T + i] = 0.f;
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = 0.f;
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
-    for (int i = threadIdx.x; i < S * 4; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
     __syncthreads();
     const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
     f2 Kreg[S];
@@ -705,6 +789,9 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     };
     if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_dma(nt - 1 - wave);
     int stores_in_flight = 0;
+    float Aop[4];
+    chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
+    const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
 
     for (int r = wave; r < nt; r += W) {
         const int t = nt - 1 - r;
@@ -727,7 +814,9 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         const int cl = 63 - lane;
         lds_to_chunks_swz<L>(tbx, X, cl);
         lds_to_chunks_swz<L>(tbg, GY, cl);
-        pin(X); pin(GY); TRACE(17);
+        f4 Bop[4], zacc[4];
+        chunk_products_load(tbg, Bop, lane);
+        pin(X); pin(GY); pin(Bop); TRACE(17);
         // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
         //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
         f2 st[S];
@@ -741,18 +830,26 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         }
         pin(st); TRACE(18);
         if (r + W < nt) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full
+        float Z[L];
+        chunk_products_issue(Bop, Aop, zacc);
+        chunk_products_collect<L>(tbo, zacc, Z, lane, cl);   // the gx image is idle until the end of the tile
+        pin(Z); TRACE(25);
         // ---- adjoint chunk end states: the scan runs from the last chunk to the first = ascending lanes (chunk 63 - lane) ----
         f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
         {
             MboxPeek pk;
-            tile_scan<S, L>(GY, tbl + LY::GAT, [](f2 v) { return v; }, lam,
+            tile_scan<S, L>(Z, [](f2 v) { return v; }, lam,
                 tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
                 [&](int i) { if (W > 1 && r > 0) pk = mbox_peek(lds, mb_in + 4 * i); },
                 [&](int i, f2& K) {
                     if (W == 1) K = Kreg[i];
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
+                    else K = f2{0.f, 0.f};
+#else
                     else if (r == 0) K = f2{0.f, 0.f};
                     else if (pk.seq == t + 1) K = f2{pk.a, pk.b};
                     else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
+#endif
                 },
                 [&](int i, f2 Kn) {
                     if (W == 1) Kreg[i] = Kn;
@@ -765,21 +862,40 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         float S2v[SH][L + 2];
         // forward section k over the chunk, in place over X, keeping s2_k[n], n = 0..L+1 in S2v[slot]
         auto forward_keep = [&](int k, int slot, int oz) {
-            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
-            const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
-            const float nk = -ca.z;
             float s1 = st[k].x, s2 = st[k].y;
+            if ((direct >> k) & 1) {   // wave-uniform. Direct form II from the exact chunk start state; the kept signal is w[n - 2] itself
+                                       // (s2 = om w: the finalize kernel's 1 / om is 1 for these sections)
+                const float d = cf_lds[k * 8 + 5 + oz];                                         // b0
+                const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
+                const f2 cw = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 6 + oz);   // 1 / om, sg / om
+                float w2 = cw.x * s2, w1 = fmaf(cw.y, s2, s1);
 #pragma unroll
-            for (int n = 0; n < L; ++n) {
-                const float u = X[n];
-                S2v[slot][n] = s2;
-                X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                s2 = fmaf(ca.y, s1, ca.x * s2);
-                s1 = t1;
+                for (int n = 0; n < L; ++n) {
+                    const float u = X[n];
+                    S2v[slot][n] = w2;
+                    const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
+                    X[n] = fmaf(d, w, fmaf(cd.x, w1, cd.y * w2));
+                    w2 = w1;
+                    w1 = w;
+                }
+                S2v[slot][L] = w2;
+                S2v[slot][L + 1] = w1;
+            } else {
+                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
+                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+                const float nk = -ca.z;
+#pragma unroll
+                for (int n = 0; n < L; ++n) {
+                    const float u = X[n];
+                    S2v[slot][n] = s2;
+                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                    const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                    s2 = fmaf(ca.y, s1, ca.x * s2);
+                    s1 = t1;
+                }
+                S2v[slot][L] = s2;
+                S2v[slot][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
             }
-            S2v[slot][L] = s2;
-            S2v[slot][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
         };
         // adjoint section k (descending time) + coefficient correlations, in place over GY. The section itself runs in transposed
         // direct form II (o = b0 g + z1; z1 = b1 g - a1 o + z2; z2 = b2 g - a2 o: 5 ops against 7 in normal form). Direct forms lose
@@ -789,7 +905,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             const int i = S - 1 - k;
             const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);           // sg, om, kom, g1
             const float d = cf_lds[k * 8 + 5 + oz];                                     // b0
-            const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 4 + oz);   // b1, b2, -a1, -a2
+            const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);   // b1, b2, -a1, -a2
             float z1 = lam[i].x, z2 = fmaf(ca.y, lam[i].y, -ca.x * lam[i].x);
             float b0 = accb[k][0], b1 = accb[k][1], b2 = accb[k][2], a1 = acca[k][0], a2 = acca[k][1];
 #pragma unroll

@@ -13,12 +13,18 @@ Realisation of one section  H(z) = (b0 + b1 z^-1 + b2 z^-2) / (1 + a1 z^-1 + a2 
 with sg = -a1/2, disc = sg^2 - a2, om = max(sqrt|disc|, OM_MIN), kom = sign(-disc)*om
 (rotation-scaling matrix for complex poles, symmetric matrix for real poles: normal either way),
 g1 = b1 - b0*a1, g2 = ((b2 - b0*a2) + g1*sg)/om.  Then s2[n] = om * w[n-2] where w = u / A(z).
-The lane scans (forward and adjoint) and the forward cascade use this realisation; the adjoint cascade inside a chunk runs each
-section in transposed direct form II (backward_row).
+The lane scans (forward and adjoint) use this realisation; the adjoint cascade inside a chunk runs each section in transposed
+direct form II (backward_row). The forward cascade inside a chunk uses it for sections whose poles are real or closer than
+DF_OM_MIN (imaginary part) to the real axis; the others ("direct" sections) run in a direct form from the chunk's exact start state
+(s1, s2), mapped once per chunk:
+    forward kernel, transposed form II:  z1 = g1 s1 + g2 s2,  z2 = zc1 s1 + zc2 s2  with (zc1, zc2) = C (A + a1 I)
+    backward kernel's recomputation, form II:  w[-2] = s2 / om,  w[-1] = s1 + (sg / om) s2; the kept signal is w itself, so the
+    coefficient correlations of a direct section are not divided by om.
 """
 import numpy as np
 
 OM_MIN = 1e-5
+DF_OM_MIN = 0.125      # csrc/sosfilt.hip DASP_DF_OM_MIN
 WAVE = 64
 
 
@@ -34,7 +40,9 @@ def realize(sos):
     kom = np.where(disc < 0, om, -om)
     g1 = b1 - b0 * a1
     g2 = ((b2 - b0 * a2) + g1 * sg) / om
-    return dict(sg=sg, om=om, kom=kom, g1=g1, g2=g2, d=b0, b=np.stack([b0, b1, b2], 1), a=np.stack([a1, a2], 1))
+    direct = (disc < 0) & (om >= DF_OM_MIN)
+    return dict(sg=sg, om=om, kom=kom, g1=g1, g2=g2, d=b0, b=np.stack([b0, b1, b2], 1), a=np.stack([a1, a2], 1), direct=direct,
+                zc1=-g1 * sg + g2 * om, zc2=-g1 * kom - g2 * sg)
 
 
 def _sections_fwd(r):
@@ -110,33 +118,53 @@ def tile_scan(z, M, P, carry):
     return start, out
 
 
-def cascade_chunks(secs, X, start, store_s2=False):
-    """Run the cascade over each lane's chunk X (64,L) from start states (64,2S).
-    Returns Y (64,L), end states, and (optionally) S2 (S,64,L+2): s2_k[n] for n in chunk, plus
-    the two states following the chunk (s2 does not depend on the current input)."""
+def cascade_chunks(secs, X, start, store_s2=False, r=None):
+    """Run the cascade over each lane's chunk X (64,L) from start states (64,2S), one section at a time over the chunk as the
+    kernels do. Returns Y (64,L) and (optionally) S2 (S,64,L+2): for a normal-form section s2_k[n] for n in chunk plus the two
+    states following the chunk (s2 does not depend on the current input); for a direct section (r["direct"], when r is given)
+    w_k[n-2] instead (= s2_k[n] / om)."""
     S = len(secs)
     L = X.shape[1]
-    st = start.copy()
-    Y = np.zeros_like(X)
+    U = X.copy()
     S2 = np.zeros((S, WAVE, L + 2)) if store_s2 else None
-    for n in range(L):
-        u = X[:, n].copy()
-        for k, (A, B, C, d) in enumerate(secs):
-            s1, s2 = st[:, 2 * k], st[:, 2 * k + 1]
+    for k, (A, B, C, d) in enumerate(secs):
+        s1, s2 = start[:, 2 * k].copy(), start[:, 2 * k + 1].copy()
+        direct = r is not None and bool(r["direct"][k])
+        if direct and not store_s2:      # forward kernel: transposed direct form II
+            b0, b1, b2 = r["b"][k]
+            a1, a2 = r["a"][k]
+            z1 = r["g1"][k] * s1 + r["g2"][k] * s2
+            z2 = r["zc1"][k] * s1 + r["zc2"][k] * s2
+            for n in range(L):
+                u = U[:, n]
+                o = b0 * u + z1
+                z1 = b1 * u - a1 * o + z2
+                z2 = b2 * u - a2 * o
+                U[:, n] = o
+        elif direct:                     # backward kernel: direct form II, keeping w
+            b0, b1, b2 = r["b"][k]
+            a1, a2 = r["a"][k]
+            w2 = s2 / r["om"][k]
+            w1 = s1 + (r["sg"][k] / r["om"][k]) * s2
+            for n in range(L):
+                u = U[:, n]
+                S2[k, :, n] = w2
+                w = u - a1 * w1 - a2 * w2
+                U[:, n] = b0 * w + b1 * w1 + b2 * w2
+                w2, w1 = w1, w
+            S2[k, :, L] = w2
+            S2[k, :, L + 1] = w1
+        else:
+            for n in range(L):
+                u = U[:, n].copy()
+                if store_s2:
+                    S2[k, :, n] = s2
+                U[:, n] = C[0] * s1 + C[1] * s2 + d * u
+                s1, s2 = A[0, 0] * s1 + A[0, 1] * s2 + B[0] * u, A[1, 0] * s1 + A[1, 1] * s2 + B[1] * u
             if store_s2:
-                S2[k, :, n] = s2
-            y = C[0] * s1 + C[1] * s2 + d * u
-            n1 = A[0, 0] * s1 + A[0, 1] * s2 + B[0] * u
-            n2 = A[1, 0] * s1 + A[1, 1] * s2 + B[1] * u
-            st[:, 2 * k], st[:, 2 * k + 1] = n1, n2
-            u = y
-        Y[:, n] = u
-    if store_s2:
-        for k, (A, B, C, d) in enumerate(secs):
-            s1, s2 = st[:, 2 * k], st[:, 2 * k + 1]
-            S2[k, :, L] = s2
-            S2[k, :, L + 1] = A[1, 0] * s1 + A[1, 1] * s2
-    return Y, st, S2
+                S2[k, :, L] = s2
+                S2[k, :, L + 1] = A[1, 0] * s1 + A[1, 1] * s2
+    return U, None, S2
 
 
 def forward_row(r, x, L, save_every=None):
@@ -157,7 +185,7 @@ def forward_row(r, x, L, save_every=None):
         carries[t] = carry
         z = X @ G.T
         start, carry = tile_scan(z, M, P, carry)
-        Y, _, _ = cascade_chunks(secs, X, start)
+        Y, _, _ = cascade_chunks(secs, X, start, r=r)
         y[t * TS:(t + 1) * TS] = Y.reshape(-1)
     return y[:N], carries
 
@@ -184,7 +212,7 @@ def backward_row(r, x, gy, carries, L):
         GY = gp[t * TS:(t + 1) * TS].reshape(WAVE, L)
         # forward chunk start states from the saved tile carry
         start, _ = tile_scan(X @ G.T, M, P, carries[t])
-        _, _, S2 = cascade_chunks(fs, X, start, store_s2=True)
+        _, _, S2 = cascade_chunks(fs, X, start, store_s2=True, r=r)
         # adjoint: same machinery on (lane, sample)-reversed data
         GYr = GY[::-1, ::-1]
         astart_r, acarry = tile_scan(GYr @ Ga.T, Ma, Pa, acarry)
@@ -212,7 +240,7 @@ def backward_row(r, x, gy, carries, L):
                 g = out
             GX[:, n] = g
         gx[t * TS:(t + 1) * TS] = GX.reshape(-1)
-    om = r["om"]
+    om = np.where(r["direct"], 1.0, r["om"])
     gb = acc_b / om[:, None]
     ga = -acc_a / om[:, None]
     # d/da0 at a0 = 1 from scale invariance of B/A:  sum_theta theta * dL/dtheta = 0

@@ -95,11 +95,13 @@ def test_oracle_mrstft_loss_matches_torch_stft():
 
 def test_chunkscan_model_equals_reference():
     """The algorithm the HIP kernels implement (normal-form sections, chunk tables, Kogge-Stone
-    scans, s2-correlation gradients) reproduces the reference forward and autograd in fp64."""
+    scans, direct-form sections between chunk restarts where the poles allow it, s2 / w-correlation
+    gradients) reproduces the reference forward and autograd in fp64."""
     g = load_golden("sos_b2c2_n6000_s3")
     sos = g["sos"].astype(np.float64)
     for b in range(sos.shape[0]):
         r = cm.realize(sos[b])
+        assert r["direct"].any() and not r["direct"].all()   # both section kinds are exercised
         gb_sum = 0
         ga_sum = 0
         for c in range(g["x"].shape[1]):

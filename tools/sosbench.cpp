@@ -103,13 +103,13 @@ int main(int argc, char** argv) {
         if (dasp_debug_trace_p) {
             long long tr[64];
             dasp_debug_trace_p(tr);
-            printf("trace (cycles): load+transpose %lld  scan %lld  cascade %lld  store %lld  | tile total %lld\n", tr[1] - tr[0], tr[2] - tr[1],
-                   tr[3] - tr[2], tr[4] - tr[3], tr[4] - tr[0]);
+            printf("trace (cycles): load+transpose %lld  chunk products %lld  scan %lld  cascade %lld  store %lld  | tile total %lld\n", tr[1] - tr[0],
+                   tr[5] - tr[1], tr[2] - tr[5], tr[3] - tr[2], tr[4] - tr[3], tr[4] - tr[0]);
             printf("prep phases (cycles): design %lld  phi %lld  G-loop (wave 0) %lld  squarings+diag (wave 1) %lld  tables + lane powers %lld | total %lld\n",
                    tr[41] - tr[40], tr[42] - tr[41], tr[43] - tr[42], tr[44] - tr[42], tr[45] - (tr[43] > tr[44] ? tr[43] : tr[44]), tr[45] - tr[40]);
             printf("  phi: barrier wait %lld, element loop %lld, vv init %lld\n", tr[47] - tr[41], tr[46] - tr[47], tr[42] - tr[46]);
-            printf("bwd tile: load+transpose %lld  fwd-scan %lld  adj-scan %lld  pass0 fwd %lld adj %lld  pass1 fwd %lld adj %lld  store %lld | total %lld\n",
-                   tr[17] - tr[16], tr[18] - tr[17], tr[19] - tr[18], tr[20] - tr[19], tr[21] - tr[20], tr[22] - tr[21], tr[23] - tr[22], tr[24] - tr[23], tr[24] - tr[16]);
+            printf("bwd tile: load+transpose %lld  states %lld  chunk products %lld  adj-scan %lld  cascade fwd+adj %lld  store %lld | total %lld\n",
+                   tr[17] - tr[16], tr[18] - tr[17], tr[25] - tr[18], tr[19] - tr[25], tr[23] - tr[19], tr[24] - tr[23], tr[24] - tr[16]);
             printf("section 3: lds-issue+table+zmap+wait %lld  coupling %lld  in-row %lld  bcast %lld  carry-in %lld  carry-out+apply+shift %lld\n",
                    tr[9] - tr[8], tr[10] - tr[9], tr[11] - tr[10], tr[12] - tr[11], tr[13] - tr[12], tr[14] - tr[13]);
         }
