@@ -224,7 +224,8 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             om = om < OM_MIN ? OM_MIN : om;
             const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
             sec[k][0] = sg; sec[k][1] = om; sec[k][2] = kap * om; sec[k][3] = g1; sec[k][4] = g2; sec[k][5] = b0; sec[k][6] = kap;
-            const bool direct = disc < 0 && om >= DASP_DF_OM_MIN;
+            // (a section that is exactly the identity, e.g. a band at 0 dB, stays in normal form: there g1 = g2 = 0 and it is exact)
+            const bool direct = disc < 0 && om >= DASP_DF_OM_MIN && !(b0 == 1.0 && b1 == a1 && b2 == a2);
             float* df = tb + LY::DF + k * 8;
             df[0] = (float)b1; df[1] = (float)b2; df[2] = (float)-a1; df[3] = (float)-a2;
             // entry states of the direct forms from the normal-form chunk start state (s1, s2): transposed form II z1 = g1 s1 + g2 s2,

@@ -40,7 +40,7 @@ def realize(sos):
     kom = np.where(disc < 0, om, -om)
     g1 = b1 - b0 * a1
     g2 = ((b2 - b0 * a2) + g1 * sg) / om
-    direct = (disc < 0) & (om >= DF_OM_MIN)
+    direct = (disc < 0) & (om >= DF_OM_MIN) & ~((b0 == 1.0) & (b1 == a1) & (b2 == a2))   # identity sections stay in normal form (exact)
     return dict(sg=sg, om=om, kom=kom, g1=g1, g2=g2, d=b0, b=np.stack([b0, b1, b2], 1), a=np.stack([a1, a2], 1), direct=direct,
                 zc1=-g1 * sg + g2 * om, zc2=-g1 * kom - g2 * sg)
 

@@ -18,6 +18,8 @@ p = (rng.random((B, 18)) * (hi - lo) + lo).astype(np.float32)
 for b in range(4):            # corner items: min cut-off, max Q, gains at +-20 dB
     p[b, 1::3] = lo[1::3]; p[b, 2::3] = hi[2::3]; p[b, 0::3] = 20.0 if b % 2 else -20.0
 p[2, 2::3] = lo[2::3]; p[3, 2::3] = lo[2::3]   # two of them with the lowest Q instead
+for b in (4, 5):              # and the opposite corner: max cut-off (poles nearest z = -1), max / min Q
+    p[b, 1::3] = hi[1::3]; p[b, 2::3] = hi[2::3] if b == 4 else lo[2::3]; p[b, 0::3] = 20.0 if b % 2 else -20.0
 xt = torch.from_numpy(x).cuda().requires_grad_(True)
 cols = [torch.from_numpy(p[:, i].copy()).cuda().requires_grad_(True) for i in range(18)]
 y = D.parametric_eq(xt, SR, *cols)
