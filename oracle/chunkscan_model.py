@@ -15,9 +15,10 @@ with sg = -a1/2, disc = sg^2 - a2, om = max(sqrt|disc|, OM_MIN), kom = sign(-dis
 g1 = b1 - b0*a1, g2 = ((b2 - b0*a2) + g1*sg)/om.  Then s2[n] = om * w[n-2] where w = u / A(z).
 The lane scans (forward and adjoint) use this realisation; the adjoint cascade inside a chunk runs each section in transposed
 direct form II (backward_row). The forward cascade inside a chunk uses it for sections whose poles are real or closer than
-DF_OM_MIN (imaginary part) to the real axis; the others ("direct" sections) run in a direct form from the chunk's exact start state
-(s1, s2), mapped once per chunk:
-    forward kernel, transposed form II:  z1 = g1 s1 + g2 s2,  z2 = zc1 s1 + zc2 s2  with (zc1, zc2) = C (A + a1 I)
+DF_OM_MIN (imaginary part) to the real axis; the others ("direct" sections) can run in a direct form from the chunk's exact start
+state (s1, s2), mapped once per chunk:
+    forward kernel (only when built with DASP_FWD_DIRECT; FWD_DIRECT here), transposed form II:
+        z1 = g1 s1 + g2 s2,  z2 = zc1 s1 + zc2 s2  with (zc1, zc2) = C (A + a1 I)
     backward kernel's recomputation, form II:  w[-2] = s2 / om,  w[-1] = s1 + (sg / om) s2; the kept signal is w itself, so the
     coefficient correlations of a direct section are not divided by om.
 """
@@ -25,6 +26,7 @@ import numpy as np
 
 OM_MIN = 1e-5
 DF_OM_MIN = 0.125      # csrc/sosfilt.hip DASP_DF_OM_MIN
+FWD_DIRECT = False     # csrc/sosfilt.hip DASP_FWD_DIRECT: the forward kernel keeps every section in normal form by default
 WAVE = 64
 
 
@@ -185,7 +187,7 @@ def forward_row(r, x, L, save_every=None):
         carries[t] = carry
         z = X @ G.T
         start, carry = tile_scan(z, M, P, carry)
-        Y, _, _ = cascade_chunks(secs, X, start, r=r)
+        Y, _, _ = cascade_chunks(secs, X, start, r=r if FWD_DIRECT else None)
         y[t * TS:(t + 1) * TS] = Y.reshape(-1)
     return y[:N], carries
 
