@@ -16,6 +16,13 @@
 // HBM-bound: forward 8 B per channel-sample (read x, write y), backward 12 B (x, gy, gx).
 #include "common.hpp"
 
+// s_setprio of a wave from the top of its tile until its carry has been handed on (loads, gain computer, lane scans, mailbox):
+// see the same switch in sosfilt.hip
+#ifndef DASP_DYN_PRIO
+#define DASP_DYN_PRIO 1     // compressor backward -2 %, forward unchanged
+#endif
+#define DYN_PRIO(p) do { if (DASP_DYN_PRIO) __builtin_amdgcn_s_setprio(p); } while (0)
+
 namespace dasp {
 
 #ifdef DASP_TRACE   // developer builds only: time stamps of one wave's phases over four consecutive tiles (scripts/dyn_trace.py)
@@ -159,6 +166,7 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
     for (int t = wave; t < nt; t += W) {
         const long base = (long)t * DY_TS;
         const bool fast = vec && base + DY_TS <= N;
+        DYN_PRIO(1);
         // side chain: sum over channels (functional.py:328)
         f4 s[DY_SUB];
 #pragma unroll
@@ -192,6 +200,7 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
             else if (t + 1 < nt) mbox_publish(lds, mb_out, Kn, 0.f, t + 1);
         }
         if (carries && lane == 0) carries[(size_t)b * nt + t] = K;
+        DYN_PRIO(0);
         // exact smoothed gain per sample -> linear gain
 #pragma unroll
         for (int j = 0; j < DY_SUB; ++j) {
@@ -271,6 +280,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
         const int t = nt - 1 - r;
         const long base = (long)t * DY_TS;
         const bool fast = vec && base + DY_TS <= N, fast_in = fast && lk == 0;
+        DYN_PRIO(1);
         DTRACE(0);
         f4 s[DY_SUB], q[DY_SUB];
 #pragma unroll
@@ -356,6 +366,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             if (W == 1) Rreg = Rn;
             else if (t > 0) mbox_publish(lds, mb_out, Rn, 0.f, t);
         }
+        DYN_PRIO(0);
         DTRACE(5);
 #pragma unroll
         for (int j = DY_SUB - 1; j >= 0; --j) {
