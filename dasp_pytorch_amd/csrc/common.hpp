@@ -173,8 +173,9 @@ __device__ __forceinline__ void tile_swz_to_global_guarded(const float* img, flo
 // "values, then seq" on the writer and "seq, then values" on the reader need no hardware fence --
 // only the compiler has to keep the order. (A workgroup-scope release fence would also drain vmcnt,
 // i.e. put the HBM latency of the prefetched next tile on the carry chain; measured 2x slower.)
+template <int LANE = 0>   // the lane whose (a, b) is published
 __device__ __forceinline__ void mbox_publish(float* lds, int slot, float a, float b, int seq) {
-    if (lane_id() == 0) {
+    if (lane_id() == LANE) {
         __hip_atomic_store(&lds[slot + 0], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&lds[slot + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");

@@ -402,6 +402,11 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp0(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
 }
+// the same, rows outside ROW_MASK keep `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
 // lane i <- v[i-1]; lane 0 <- first
 __device__ __forceinline__ float wave_shr1(float first, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -538,11 +543,13 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
                                           const float* __restrict__ MCs, const float* __restrict__ PLs,
                                           const float* __restrict__ P64s, const f4* __restrict__ pws, int lane,
                                           FPre&& carry_prefetch, FIn&& carry_in, FOut&& carry_out, bool trace_on = false) {
-    f4 MC[S], PL[4], P64[2];
+    (void)P64s;   // M^64 is lane 63's per-lane power
+    f4 MC[S], PL[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) PL[l] = TLD4(PLs + 4 * l);
-    P64[0] = TLD4(P64s);
-    if (S > 1) P64[1] = TLD4(P64s + 4);
+    // destinations of the two row-broadcast moves: their masked-off rows are never written and stay 0, so one zeroing per tile serves
+    // all sections (a fresh zero "old" value per move cost four v_mov per section)
+    float b16x = 0.f, b16y = 0.f, b32x = 0.f, b32y = 0.f;
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         __builtin_amdgcn_sched_barrier(0);
@@ -575,17 +582,18 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
             for (int l = 0; l < 4; ++l) PL[l] = TLD4(PLs + (k + 1) * 16 + 4 * l);
         }
         // rows 1, 3 += M^(j+1) * (last lane of the previous row); rows 2, 3 += M^((lane % 32) + 1) * lane 31
-        f = blk_apply_v(pw16, f2{dpp0<0x142, 0xa>(f.x), dpp0<0x142, 0xa>(f.y)}, f);
-        f = blk_apply_v(pw32, f2{dpp0<0x143, 0xc>(f.x), dpp0<0x143, 0xc>(f.y)}, f);
+        b16x = dpp_keep<0x142, 0xa>(b16x, f.x); b16y = dpp_keep<0x142, 0xa>(b16y, f.y);
+        f = blk_apply_v(pw16, f2{b16x, b16y}, f);
+        b32x = dpp_keep<0x143, 0xc>(b32x, f.x); b32y = dpp_keep<0x143, 0xc>(b32y, f.y);
+        f = blk_apply_v(pw32, f2{b32x, b32y}, f);
         pin(f); TRACE2(12);
         f2 K;
         carry_in(k, K);
         pin(K); TRACE2(13);
-        // carry for the next tile: the only work on the cross-wave serial chain
-        carry_out(k, blk_apply_s(P64[k & 1], K, f2{read_lane(f.x, 63), read_lane(f.y, 63)}));
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < S) P64[k & 1] = TLD4(P64s + (k + 2) * 4);
+        // E = f + M^(lane+1) K: the chunk end states; lane 63's is the carry for the next tile and that lane hands it on (the only
+        // work on the cross-wave serial chain; no readlane / SGPR round trip, no separate M^64 product)
         const f2 E = blk_apply_v(pw64, K, f);
+        carry_out(k, E);
         st[k] = f2{wave_shr1(K.x, E.x), wave_shr1(K.y, E.y)};
         pin(st[k]); TRACE2(14);
     }
@@ -661,20 +669,19 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         MboxPeek pk;
         SCAN_PRIO(DASP_SCAN_PRIO);
         tile_scan<S, L>(Z, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
-            [&](int k) { if (W > 1 && t > 0) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
+            [&](int k) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
             [&](int k, f2& K) {
                 if (W == 1) K = Kreg[k];
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 1)
                 else K = f2{0.f, 0.f};
 #else
-                else if (t == 0) K = f2{0.f, 0.f};
-                else if (pk.seq == t) K = f2{pk.a, pk.b};
+                else if (pk.seq == t) K = f2{pk.a, pk.b};   // tile 0 finds the zero-initialised inbox: sequence 0, carry 0
                 else { float a, b; mbox_wait(lds, mb_in + 4 * k, t, a, b); K = f2{a, b}; }
 #endif
             },
             [&](int k, f2 Kn) {
-                if (W == 1) Kreg[k] = Kn;
-                else if (t + 1 < nt) mbox_publish(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
+                if (W == 1) Kreg[k] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
+                else if (t + 1 < nt) mbox_publish<63>(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
             }
 #ifdef DASP_TRACE
             , blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W
@@ -782,7 +789,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* tbo = tbg + IMG;                        // gx image on its way out
     float* tst = tbo + IMG;                        // chunk start states [section][lane] f2
     float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = 0.f;
+    // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (the row's last, nt - 1) waits for, with a zero carry
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
@@ -866,20 +874,19 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             SCAN_PRIO(DASP_SCAN_PRIO);
             tile_scan<S, L>(Z, [](f2 v) { return v; }, lam,
                 tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
-                [&](int i) { if (W > 1 && r > 0) pk = mbox_peek(lds, mb_in + 4 * i); },
+                [&](int i) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * i); },
                 [&](int i, f2& K) {
                     if (W == 1) K = Kreg[i];
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
                     else K = f2{0.f, 0.f};
 #else
-                    else if (r == 0) K = f2{0.f, 0.f};
-                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};
+                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
                     else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
 #endif
                 },
                 [&](int i, f2 Kn) {
-                    if (W == 1) Kreg[i] = Kn;
-                    else if (t > 0) mbox_publish(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                    if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
+                    else if (t > 0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
                 });
         }
         SCAN_PRIO(0);
