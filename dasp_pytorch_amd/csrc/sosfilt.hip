@@ -140,8 +140,10 @@ __device__ void rbj_design(int type, double sample_rate, double gain_db, double 
     const D1 g = {gain_db, dir == 0 ? 1.0 : 0.0}, f = {fc, dir == 1 ? 1.0 : 0.0}, q = {qf, dir == 2 ? 1.0 : 0.0};
     const D1 A = dexp((2.302585092994045684 / 40.0) * g);
     const D1 w0 = (2.0 * 3.14159265358979323846 / sample_rate) * f;
-    const D1 alpha = dsin(w0) / (2.0 * q);
-    const D1 cw = dcos(w0);
+    double sn, cs;
+    sincos(w0.v, &sn, &cs);                       // one evaluation serves sin, cos and both derivatives
+    const D1 sw = {sn, cs * w0.d}, cw = {cs, -sn * w0.d};
+    const D1 alpha = sw / (2.0 * q);
     const D1 sA = dsqrt(A);
     D1 b0, b1, b2, a0, a1, a2;
     if (type == 2) {  // high_shelf
@@ -284,6 +286,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         const double v = jj == kk ? a_el : (jj < kk ? Bk * gain * Cj : 0.0);
         Phi[sys][i * S2 + j] = v;
         T1[sys][i * S2 + j] = v;
+        T2[sys][i * S2 + j] = 0.0;
     }
     PTRACE(46, 0);
     if (tid < 2 * S2) {
@@ -318,9 +321,17 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         double (*src)[NN] = T1;
         double (*dst)[NN] = T2;
         for (int step = 1; step < L; step <<= 1) {
-            for (int e = l; e < 2 * NN; e += 64) {
-                const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
+            // Phi and its powers are block lower triangular: only the S (S + 1) / 2 blocks on and below the diagonal are computed
+            // (the others stay zero from the initialisation). The inner product keeps its fixed, unrolled length: a data-dependent
+            // trip count runs into the cold instruction cache (measured: 2.7x slower).
+            constexpr int NTRI = S * (S + 1) / 2 * 4;
+            for (int e = l; e < 2 * NTRI; e += 64) {
+                const int sys = e / NTRI, q = e % NTRI, blk = q >> 2;
+                const int kk = (blk >= 1) + (blk >= 3) + (blk >= 6) + (blk >= 10) + (blk >= 15) + (blk >= 21) + (blk >= 28);
+                const int jj = blk - kk * (kk + 1) / 2;
+                const int i = 2 * kk + ((q >> 1) & 1), j = 2 * jj + (q & 1);
                 double acc = 0.0;
+#pragma unroll
                 for (int m = 0; m < S2; ++m) acc += src[sys][i * S2 + m] * src[sys][m * S2 + j];
                 dst[sys][i * S2 + j] = acc;
             }
