@@ -31,6 +31,7 @@ SIGNATURES = {
     "dasp_sosfilt_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sosfilt_backward": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sos_grad_finalize": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
+    "dasp_sosfilt_backward_grads": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _p]),
     "dasp_ew_partial_floats": (_l, [_l, _l]),
     "dasp_gain_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dasp_gain_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),

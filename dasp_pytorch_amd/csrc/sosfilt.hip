@@ -86,7 +86,9 @@ struct SosLayout {
     static constexpr int P64A = P64 + SYS;
     static constexpr int PWA = PW + SYS;
     static constexpr int DF = GT + 2 * SYS;          // [S][8]: b1, b2, -a1, -a2 (normalised), zc1, zc2, 1/om, sg/om: direct-form sections
-    static constexpr int TOTAL = DF + 8 * S;
+    static constexpr int CNT = DF + 8 * S;           // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
+                                                     //      prep kernel, reset by the workgroup that finalizes the item)
+    static constexpr int TOTAL = CNT + 4;
 };
 // fp64 side table for the finalize kernel, per (item, section)
 constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_STRIDE = 24;
@@ -221,6 +223,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     float* tb = tab + (size_t)item * LY::TOTAL;
     double* dt = dtab + (size_t)item * S * DT_STRIDE;
 
+    if (tid < 4) tb[LY::CNT + tid] = 0.f;
     if (tid < 3 * S) {   // thread = (section k, control dir): values + one Jacobian column each
         const int k = tid / 3, dir = tid % 3;
         double c5[5], dc5[5] = {0, 0, 0, 0, 0}, a0 = 1.0;
@@ -766,6 +769,43 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Finalize, one (item, section) per call: sums the per-wave partial correlations of the item's rows in fp64 and maps them to
+// mode 0: gradient w.r.t. sos (B,S,6) as given (a0 included); mode 1: gradient w.r.t. (gain_db, cutoff_freq, q_factor) (B,S,3)
+// through the RBJ design Jacobian; mode 2: the same as 3 S rows of B values ([3 k + dir][item]: one contiguous gradient vector per
+// control tensor of parametric_eq).
+template <bool COHERENT>   // COHERENT: the partial sums were written by other workgroups of the running kernel (device-scope loads)
+__device__ __forceinline__ void finalize_section(const double* __restrict__ dtab, int tab_bcast, const float* partials,
+                                                 int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int item, int k) {
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int c = 0; c < C; ++c)
+        for (int w = 0; w < Wb; ++w) {
+            const float* p = partials + (((size_t)(item * C + c) * Wb + w) * S + k) * 5;
+            for (int i = 0; i < 5; ++i)
+                acc[i] += (double)(COHERENT ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i]);
+        }
+    const double* d = dtab + ((size_t)(tab_bcast ? 0 : item) * S + k) * DT_STRIDE;
+    const double iom = 1.0 / d[DT_OM];
+    const double g5[5] = {acc[0] * iom, acc[1] * iom, acc[2] * iom, -acc[3] * iom, -acc[4] * iom};
+    const int idx = item * S + k;
+    if (mode == 0) {
+        const double a0 = d[DT_A0];
+        double dot = 0.0;
+        for (int i = 0; i < 5; ++i) dot += g5[i] * d[DT_B0 + i];
+        float* o = gout + (size_t)idx * 6;
+        o[0] = (float)(g5[0] / a0); o[1] = (float)(g5[1] / a0); o[2] = (float)(g5[2] / a0);
+        o[3] = (float)(-dot / a0);
+        o[4] = (float)(g5[3] / a0); o[5] = (float)(g5[4] / a0);
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            double v = 0.0;
+            for (int c = 0; c < 5; ++c) v += g5[c] * d[DT_J + c * 3 + i];
+            if (mode == 1) gout[(size_t)idx * 3 + i] = (float)v;
+            else gout[(size_t)(3 * k + i) * B + item] = (float)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward. Register budget is the design constraint: the coefficient correlations pair the
 // adjoint signals of section k with its forward all-pole signal s2_k[n], so forward signals have to
 // be held while the adjoint runs. Holding all S sections (S*(L+2) registers) leaves one wave per
@@ -777,7 +817,8 @@ template <int S, int L, int W>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
-               float* __restrict__ partials, int C, int N, int nt, int vec) {
+               float* __restrict__ partials, int C, int N, int nt, int vec,
+               float* __restrict__ cnt_tab, const double* __restrict__ dtab, int mode, float* __restrict__ gout, int B) {
     using LY = SosLayout<S, L>;
     // S <= 6: the s2 signals of all sections stay in registers (H = 0). S = 8: the lower half is parked in LDS (H = S / 2).
     constexpr int S2 = 2 * S, TS = 64 * L, H = S > 6 ? S / 2 : 0, SH = S - H;   // SH >= H
@@ -1037,45 +1078,44 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         const float v0 = wave_sum(accb[k][0]), v1 = wave_sum(accb[k][1]), v2 = wave_sum(accb[k][2]);
         const float v3 = wave_sum(acca[k][0]), v4 = wave_sum(acca[k][1]);
         if (lane == 0) {
-            po[k * 5 + 0] = v0; po[k * 5 + 1] = v1; po[k * 5 + 2] = v2; po[k * 5 + 3] = v3; po[k * 5 + 4] = v4;
+            const float v[5] = {v0, v1, v2, v3, v4};
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (cnt_tab) __hip_atomic_store(po + k * 5 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else po[k * 5 + i] = v[i];
+            }
         }
+    }
+    // Fused finalize (cnt_tab != null: every item has its own table). The workgroup of an item's last row to finish maps the item's
+    // partial sums to the requested gradients - no separate launch (5.5 us + a launch gap per step at the north-star shape).
+    // The rows of an item run on different XCDs, whose L2s are not coherent with each other: a release fence here would write back
+    // this XCD's whole dirty L2 (the gx tiles: measured +65 us). Instead the few values that cross workgroups travel as device-scope
+    // relaxed atomics (write-through stores, L2-bypassing loads): each wave waits for its own stores to be acknowledged (vmcnt), the
+    // barrier orders that before thread 0's counter increment, and the workgroup that sees the count complete reads the sums.
+    if (cnt_tab) {
+        __shared__ int last_row;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int item = row / C;
+        int* cnt = reinterpret_cast<int*>(cnt_tab + (size_t)item * LY::TOTAL + LY::CNT);
+        if (threadIdx.x == 0) {
+            const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_row = done == C - 1;
+            if (last_row) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the table can serve another backward pass
+        }
+        __syncthreads();
+        if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Finalize: one thread per (item, section). mode 0: gradient w.r.t. sos (B,S,6) as given (a0 included);
-// mode 1: gradient w.r.t. (gain_db, cutoff_freq, q_factor) (B,S,3) through the RBJ design Jacobian; mode 2: the same as 3 S rows of
-// B values ([3 k + dir][item]: one contiguous gradient vector per control tensor of parametric_eq).
+// Stand-alone finalize (one thread per (item, section)): used when the table is shared by all items (tab_bcast) or when the caller
+// asks for the two steps separately; otherwise the backward kernel finalizes an item as soon as its last row is done.
 __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
                                     int B, int C, int S, int Wb, int mode, float* __restrict__ gout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * S) return;
-    const int item = idx / S, k = idx % S;
-    double acc[5] = {0, 0, 0, 0, 0};
-    for (int c = 0; c < C; ++c)
-        for (int w = 0; w < Wb; ++w) {
-            const float* p = partials + (((size_t)(item * C + c) * Wb + w) * S + k) * 5;
-            for (int i = 0; i < 5; ++i) acc[i] += (double)p[i];
-        }
-    const double* d = dtab + ((size_t)(tab_bcast ? 0 : item) * S + k) * DT_STRIDE;
-    const double iom = 1.0 / d[DT_OM];
-    const double g5[5] = {acc[0] * iom, acc[1] * iom, acc[2] * iom, -acc[3] * iom, -acc[4] * iom};
-    if (mode == 0) {
-        const double a0 = d[DT_A0];
-        double dot = 0.0;
-        for (int i = 0; i < 5; ++i) dot += g5[i] * d[DT_B0 + i];
-        float* o = gout + (size_t)idx * 6;
-        o[0] = (float)(g5[0] / a0); o[1] = (float)(g5[1] / a0); o[2] = (float)(g5[2] / a0);
-        o[3] = (float)(-dot / a0);
-        o[4] = (float)(g5[3] / a0); o[5] = (float)(g5[4] / a0);
-    } else {
-        for (int i = 0; i < 3; ++i) {
-            double s = 0.0;
-            for (int c = 0; c < 5; ++c) s += g5[c] * d[DT_J + c * 3 + i];
-            if (mode == 1) gout[(size_t)idx * 3 + i] = (float)s;
-            else gout[(size_t)(3 * k + i) * B + item] = (float)s;
-        }
-    }
+    finalize_section<false>(dtab, tab_bcast, partials, B, C, S, Wb, mode, gout, idx / S, idx % S);
 }
 
 }  // namespace dasp
@@ -1208,7 +1248,8 @@ int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float*
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB>), dim3(B * C), dim3(64 * kWB), 0, (hipStream_t)stream, tab,
-                           Bs == 1 && B != 1, x, gy, carries, gx, partials, C, (int)N, nt, vec);
+                           Bs == 1 && B != 1, x, gy, carries, gx, partials, C, (int)N, nt, vec,
+                           (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B);
         return check_launch();
     });
 }
@@ -1222,6 +1263,34 @@ int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, in
     hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
                        Bs == 1 && B != 1, partials, B, C, S, kWB, mode, gout);
     return check_launch();
+}
+
+// dasp_sosfilt_backward followed by dasp_sos_grad_finalize (same mode / gout) as one call. Built with -DDASP_FUSED_FINALIZE=1 and
+// given one table per item (Bs == B) it is also one launch: the backward kernel finalizes every item as its last row completes, using
+// the completion counter in the item's table (hence the non-const tab). Measured at the north-star shape: 2-3 us of 425 per step
+// (the finalize work becomes a tail of the big kernel); left off by default - the gain does not pay for a cross-XCD hand-off that
+// only the hardware's memory model keeps correct. Otherwise, and with a shared table (Bs == 1 < B), it launches the two kernels.
+#ifndef DASP_FUSED_FINALIZE
+#define DASP_FUSED_FINALIZE 0
+#endif
+int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
+                                float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, void* stream) {
+    if (!tab || !dtab || !x || !gy || !carries || !gx || !partials || !gout || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) ||
+        mode < 0 || mode > 2)
+        return DASP_ERR_ARG;
+    if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    if (!DASP_FUSED_FINALIZE || (Bs == 1 && B != 1)) {
+        const int rc = dasp_sosfilt_backward(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, stream);
+        return rc != DASP_OK ? rc : dasp_sos_grad_finalize(dtab, Bs, partials, B, C, S, mode, gout, stream);
+    }
+    const int nt = (int)dasp_sos_num_tiles(N);
+    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB>), dim3(B * C), dim3(64 * kWB), 0, (hipStream_t)stream, tab, 0, x, gy, carries,
+                           gx, partials, C, (int)N, nt, vec, tab, dtab, mode, gout, B);
+        return check_launch();
+    });
 }
 
 }  // extern "C"

@@ -68,6 +68,15 @@ int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float*
 int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S,
                            int mode, float* gout, void* stream);
 
+/* dasp_sosfilt_backward followed by dasp_sos_grad_finalize (same mode / gout) as one call - the autograd of
+ * signal.sosfilt_via_fsm (dasp_pytorch/signal.py:136-166) / functional.parametric_eq (functional.py:118-272) in one step.
+ * A library built with -DDASP_FUSED_FINALIZE=1 also makes it one launch when every item has its own table (Bs == B): the
+ * backward kernel then finalizes an item when its last row completes, counting rows in the item's table (hence the non-const
+ * tab; the count is left at zero). */
+int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy,
+                                const float* carries, float* gx, float* partials, int mode, float* gout,
+                                int B, int C, long N, int S, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * gain / distortion.  Replace dasp_pytorch.functional.gain (dasp_pytorch/functional.py:10-29):
  * y = x * 10^(gain_db/20), gain_db (B) one value per batch item repeated over channels (:26-28);

@@ -239,3 +239,39 @@ def test_full_size_properties(D):
     ys = D.parametric_eq(x1[40:44], SR, *[c[40:44] for c in cols])
     assert torch.equal(ys, y1[40:44].detach())
     assert torch.isfinite(y1).all() and torch.isfinite(xa.grad).all()
+
+
+@pytest.mark.parametrize("Bs_shared", [False, True])
+def test_backward_grads_entry_equals_two_calls(D, Bs_shared):
+    """dasp_sosfilt_backward_grads == dasp_sosfilt_backward followed by dasp_sos_grad_finalize, bit for bit (gx and all three
+    gradient layouts), with one table per item and with a table shared by the batch; the item counters it may use are left at zero
+    so the same table serves repeated backward passes."""
+    import ctypes
+    from dasp_pytorch_amd import _lib
+    from dasp_pytorch_amd._lib import call, ptr, stream
+    L = _lib.lib()
+    B, C, N, S = 3, 2, 5000, 6
+    Bs = 1 if Bs_shared else B
+    rng = np.random.default_rng(7)
+    lo = np.array([r[0] for r in PEQ_RANGES]); hi = np.array([r[1] for r in PEQ_RANGES])
+    p = dev((rng.random((Bs, S, 3)) * (hi - lo).reshape(S, 3) + lo.reshape(S, 3)).astype(np.float32))
+    x = dev((rng.random((B, C, N)) * 2 - 1).astype(np.float32)); gy = dev(rng.standard_normal((B, C, N)).astype(np.float32))
+    tab = torch.empty(Bs * L.dasp_sos_table_floats(S), dtype=torch.float32, device="cuda:0")
+    dtab = torch.empty(Bs * L.dasp_sos_dtab_doubles(S), dtype=torch.float64, device="cuda:0")
+    types = (ctypes.c_int * S)(1, 0, 0, 0, 0, 2)
+    call("dasp_peq_prepare", ptr(p), Bs, S, types, float(SR), ptr(tab), ptr(dtab), stream())
+    y = torch.empty_like(x)
+    car = torch.empty(L.dasp_sos_carry_floats(B * C, N, S), dtype=torch.float32, device="cuda:0")
+    call("dasp_sosfilt_forward", ptr(tab), Bs, ptr(x), ptr(y), ptr(car), B, C, N, S, stream())
+    for mode, shape in ((1, (B, S, 3)), (2, (3 * S, B)), (0, (B, S, 6))):
+        part = torch.empty(L.dasp_sos_partial_floats(B * C, S), dtype=torch.float32, device="cuda:0")
+        gx1, gx2 = torch.empty_like(x), torch.empty_like(x)
+        g1, g2 = torch.zeros(shape, device="cuda:0"), torch.zeros(shape, device="cuda:0")
+        call("dasp_sosfilt_backward", ptr(tab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx1), ptr(part), B, C, N, S, stream())
+        call("dasp_sos_grad_finalize", ptr(dtab), Bs, ptr(part), B, C, S, mode, ptr(g1), stream())
+        for _ in range(2):   # twice: the table must come back ready for another pass
+            part.fill_(float("nan"))
+            g2.zero_()
+            call("dasp_sosfilt_backward_grads", ptr(tab), ptr(dtab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx2), ptr(part), mode, ptr(g2),
+                 B, C, N, S, stream())
+            assert torch.equal(gx1, gx2) and torch.equal(g1, g2) and torch.isfinite(g2).all()

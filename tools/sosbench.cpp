@@ -83,8 +83,12 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e[1]));
         DK(dasp_sosfilt_forward(dtab, B, dx, dy, dcar, B, C, N, S, nullptr));
         CK(hipEventRecord(e[2]));
-        DK(dasp_sosfilt_backward(dtab, B, dx, dgy, dcar, dgx, dpart, B, C, N, S, nullptr));
-        DK(dasp_sos_grad_finalize(ddtab, B, dpart, B, C, S, 0, dgout, nullptr));
+        if (getenv("DASP_SPLIT_FINALIZE")) {
+            DK(dasp_sosfilt_backward(dtab, B, dx, dgy, dcar, dgx, dpart, B, C, N, S, nullptr));
+            DK(dasp_sos_grad_finalize(ddtab, B, dpart, B, C, S, 0, dgout, nullptr));
+        } else {
+            DK(dasp_sosfilt_backward_grads(dtab, ddtab, B, dx, dgy, dcar, dgx, dpart, 0, dgout, B, C, N, S, nullptr));
+        }
         CK(hipEventRecord(e[3]));
         CK(hipEventSynchronize(e[3]));
         float a, b, c; CK(hipEventElapsedTime(&a, e[0], e[1])); CK(hipEventElapsedTime(&b, e[1], e[2])); CK(hipEventElapsedTime(&c, e[2], e[3]));
