@@ -89,8 +89,8 @@ def secondary(dev):
     g = torch.Generator(device=dev).manual_seed(7)
     rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
 
-    def bench_op(name, B, C, N, make, bytes_per_cs, note=None):
-        x = (rnd(B, C, N) * 2 - 1).requires_grad_(True)
+    def bench_op(name, B, C, N, make, bytes_per_cs, note=None, xmake=None):
+        x = (xmake(B, C, N) if xmake else rnd(B, C, N) * 2 - 1).requires_grad_(True)
         ctl, call = make(B)
         w = torch.randn(B, 2 if name == "noise_shaped_reverberation" else C, N, device=dev, generator=g)
 
@@ -112,6 +112,14 @@ def secondary(dev):
     bench_op("distortion", 256, 2, 131072, lambda B: ([ctl1(0, 24)(B * 2)], lambda x, c: D.distortion(x, SR, c[0])), 20)
     rng = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]
     bench_op("compressor", 256, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20)
+
+
+    def speechlike(B, C, N):   # white noise x a slow random envelope spanning -60 .. 0 dBFS (all three knee regions)
+        knots = rnd(B, 1, N // 4096 + 2) * -60.0
+        env_db = torch.nn.functional.interpolate(knots, size=N, mode="linear", align_corners=True)
+        return (rnd(B, C, N) * 2 - 1) * torch.pow(10.0, env_db / 20.0)
+    bench_op("compressor_speechlike", 256, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20,
+             "same op on white noise x slow random envelope, -60 .. 0 dBFS", xmake=speechlike)
     bench_op("noise_shaped_reverberation", 128, 2, 262144,
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
              2 * 1.354e9 / (128 * 2 * 262144),
