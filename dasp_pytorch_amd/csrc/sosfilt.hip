@@ -465,7 +465,9 @@ __device__ __forceinline__ int opaque_zero_after(float dep) {
 __device__ __forceinline__ void wait_vmcnt(int n) {
     switch (n) {
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
@@ -706,11 +708,15 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 8)
         if (false) {
 #else
-        if (carries) {   // chunk start states for the backward pass: [row][tile][section][lane] f2, 512 B per wave store
+        if (carries) {   // chunk start states for the backward pass: [row][tile][section pair][lane] f4, 1 KiB per wave store
 #endif
-            f2* cs = reinterpret_cast<f2*>(carries) + ((size_t)row * nt + t) * S * 64 + lane;
+            static_assert(S % 2 == 0, "states are stored in section pairs");
+            f4* cs = reinterpret_cast<f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < S; ++k) { if (DASP_FWD_NT & 4) st_stream(cs + k * 64, st[k]); else cs[k * 64] = st[k]; }
+            for (int m = 0; m < S / 2; ++m) {
+                const f4 v = f4{st[2 * m].x, st[2 * m].y, st[2 * m + 1].x, st[2 * m + 1].y};
+                if (DASP_FWD_NT & 4) st_stream(cs + m * 64, v); else cs[m * 64] = v;
+            }
         }
 
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
@@ -762,7 +768,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #else
         if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
         else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
-        stores_in_flight = full ? (carries ? S : 0) + L / 4 : -1;
+        stores_in_flight = full ? (carries ? S / 2 : 0) + L / 4 : -1;
 #endif      // -1: a ragged tile issues a data-dependent number of stores
         TRACE(4);
     }
@@ -839,7 +845,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* tbx = pw_lds + LDS_PW + wave * REGION;  // x image of this tile; receives the next tile's as soon as it has been read
     float* tbg = tbx + IMG;                        // gy image, likewise
     float* tbo = tbg + IMG;                        // gx image on its way out
-    float* tst = tbo + IMG;                        // chunk start states [section][lane] f2
+    float* tst = tbo + IMG;                        // chunk start states [section pair][lane] f4
     float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
     // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (the row's last, nt - 1) waits for, with a zero carry
     for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
@@ -905,13 +911,12 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
         //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
         f2 st[S];
-        if (full) {
 #pragma unroll
-            for (int k = 0; k < S; ++k) st[k] = *reinterpret_cast<const f2*>(tst + (k * 64 + cl) * 2);
-        } else {
-            const f2* cs = reinterpret_cast<const f2*>(carries) + ((size_t)row * nt + t) * S * 64 + cl;
-#pragma unroll
-            for (int k = 0; k < S; ++k) st[k] = cs[k * 64];
+        for (int m = 0; m < S / 2; ++m) {   // [section pair][chunk] f4, as the forward kernel stored them
+            const f4 q = full ? *reinterpret_cast<const f4*>(tst + (m * 64 + cl) * 4)
+                              : (reinterpret_cast<const f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + cl)[m * 64];
+            st[2 * m] = f2{q.x, q.y};
+            st[2 * m + 1] = f2{q.z, q.w};
         }
         pin(st); TRACE(18);
         if (r + W < nt) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full

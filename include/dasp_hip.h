@@ -53,7 +53,7 @@ int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* ty
                           double* dtab, void* stream);
 
 /* y = cascade(x). carries (may be NULL when no backward follows) receives the state of every lane chunk
- * (dasp_sos_carry_floats(rows, N, S) floats = 2*S per dasp_sos_chunk() samples); the backward pass reads it
+ * (dasp_sos_carry_floats(rows, N, S) floats = 2*S per dasp_sos_chunk() samples, in the kernels' own order); the backward pass reads it
  * instead of re-scanning the forward recurrence. */
 int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries,
                          int B, int C, long N, int S, void* stream);
