@@ -94,10 +94,15 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 #else
 #define DASP_GLDS_POLICY ""
 #endif
+template <bool STREAM = true>   // STREAM: the data is touched once (non-temporal); false: leave it to the caches' normal policy
 __device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+    if (STREAM)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
 }
 __device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
     unsigned keep;

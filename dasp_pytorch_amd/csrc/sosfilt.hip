@@ -33,9 +33,11 @@
 
 #ifndef DASP_FWD_NT
 // forward kernel: streaming hints on 1 = x loads, 2 = y stores, 4 = state stores. The kernels run back to back (forward, backward,
-// forward, ...) and share the 256 MB MALL, so only the pair can be judged: same box, fwd + bwd: all 0.484 ms, y stores only 0.490,
-// none in either kernel 0.494, none in forward / all in backward 0.500.
-#define DASP_FWD_NT 7
+// forward, ...) and share the 256 MB MALL, so only the pair can be judged. The signals (x, y: touched once per kernel) stream; the
+// 201 MB of chunk states do not, on either side (DASP_STATES_CACHED: the backward kernel reads them with the normal policy too):
+// they are read back last-written-first by the backward pass and overwritten in place by the next step's forward pass, and keeping
+// them cache-resident took the forward kernel from 0.156 to 0.143 ms (same box; either half of the change alone: nothing).
+#define DASP_FWD_NT 3
 #endif
 
 // Issue priority (s_setprio) of a wave while it is in a latency-bound phase of its tile - the lane scan (dependent DPP chains, few
@@ -203,6 +205,9 @@ constexpr double OM_MIN = 1e-5;
 // The backward kernel's recomputation uses the direct form (its signals only enter the coefficient correlations: parameter
 // gradients unchanged to their digits, -4.6 % kernel time). The forward kernel does not by default: there it bought 2 % and moved the
 // worst y error over 2.6k random configurations from 1.5e-6 to 8.9e-6 (scripts/fuzz_gpu.py).
+#ifndef DASP_STATES_CACHED
+#define DASP_STATES_CACHED 1   // the backward kernel reads the saved chunk states with the caches' normal policy (not streaming)
+#endif
 #ifndef DASP_FWD_DIRECT
 #define DASP_FWD_DIRECT 0
 #endif
@@ -875,7 +880,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
         const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
 #pragma unroll
-        for (int m = 0; m < S / 2; ++m) glds16(cs + m * 256, a_s + 1024 * m);
+        for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
     };
     if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_dma(nt - 1 - wave);
     int stores_in_flight = 0;
