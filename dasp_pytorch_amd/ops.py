@@ -333,13 +333,14 @@ def _filter_spectrum(filters, nb, taps, n_complex, dev):
     """Spectra of the filterbank taps (dasp_reverb_filter_spectrum). They depend only on the taps, so the result is kept
     for as long as the caller keeps passing the same (unmodified) filters tensor on the same stream -- functional.py
     holds one device copy of the bank per (taps, sample_rate, device)."""
+    capturing = torch.cuda.is_current_stream_capturing()   # memory allocated inside a HIP-graph capture belongs to that graph
     key = (id(filters), filters._version, int(n_complex), int(torch.cuda.current_stream().cuda_stream))
-    hit = _FSPEC_CACHE.get(key)
+    hit = None if capturing else _FSPEC_CACHE.get(key)
     if hit is not None and hit[0] is filters:
         return hit[1]
     Fspec = _cbuf(n_complex, dev)
     call("dasp_reverb_filter_spectrum", ptr(_f32c(filters)), nb, taps, ptr(Fspec), stream())
-    if filters.is_cuda and filters.dtype == torch.float32 and filters.is_contiguous() and not filters.requires_grad:
+    if not capturing and filters.is_cuda and filters.dtype == torch.float32 and filters.is_contiguous() and not filters.requires_grad:
         if len(_FSPEC_CACHE) >= 8:
             _FSPEC_CACHE.clear()
         _FSPEC_CACHE[key] = (filters, Fspec)

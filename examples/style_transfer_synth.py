@@ -69,7 +69,7 @@ def synth_clips(batch, n, gen, device):
     return x[:, None, :].repeat(1, 2, 1).contiguous()
 
 
-def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-3, width=32, seed=0, quiet=False):
+def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-3, width=32, seed=0, quiet=False, graph=False):
     rank, local, world = dd.env_world()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -81,6 +81,33 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     loss_fn = D.losses.MultiResolutionSTFTLoss()              # auraloss' default resolutions, fused HIP kernels
     losses, t0 = [], None
+
+    def fwd_bwd(x, target):
+        controls = model(x.mean(1, keepdim=True), target.mean(1, keepdim=True))
+        loss = loss_fn(chain(x, controls), target)
+        loss.backward()
+        return loss
+
+    # --graph: predictor forward, effect chain, loss and the whole backward pass are captured once into a HIP graph and replayed
+    # per step (one launch instead of a few hundred; at 8 clips per GPU the step is launch-bound otherwise). The hand-written
+    # kernels are plain stream launches on torch's current stream, so they are captured like any torch op; data generation, the
+    # gradient all-reduce and the optimizer step stay eager.
+    g, static = None, {}
+    if graph:
+        static["x"] = synth_clips(batch, n, gen, dev)
+        static["target"] = torch.zeros_like(static["x"])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # warm-up off the capture stream (allocator, lazy tables)
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                fwd_bwd(static["x"], static["target"])
+        torch.cuda.current_stream().wait_stream(side)
+        opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static["loss"] = fwd_bwd(static["x"], static["target"])
+
     for step in range(steps + 1):                             # step 0 warms the caches / clocks and is not timed
         if step == 1:
             torch.cuda.synchronize()
@@ -90,11 +117,14 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
         x = synth_clips(batch, n, gen, dev)
         with torch.no_grad():                                 # the "style": the same chain with hidden random controls
             target = chain(x, torch.rand(batch, chain.num_controls, device=dev, generator=gen))
-        controls = model(x.mean(1, keepdim=True), target.mean(1, keepdim=True))
-        y = chain(x, controls)
-        loss = loss_fn(y, target)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
+        if g is None:
+            opt.zero_grad(set_to_none=True)
+            loss = fwd_bwd(x, target)
+        else:
+            static["x"].copy_(x)
+            static["target"].copy_(target)
+            g.replay()                                        # gradients land in the .grad tensors the capture allocated
+            loss = static["loss"]
         dd.allreduce_gradients(model.parameters())            # the one collective of the job
         opt.step()
         losses.append(float(loss.detach()))
@@ -104,7 +134,7 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
     dt = dd.max_over_ranks(time.perf_counter() - t0, dev) / max(steps, 1)
     out = {"workload": "style-transfer chain EQ->compressor->reverb, predictor + MR-STFT loss, data parallel", "n_gpus": world,
            "clip": [batch, 2, n], "ir_samples": ir_samples, "steps": steps, "s_per_step": dt, "clips_per_s": world * batch / dt,
-           "channel_samples_per_s": world * batch * 2 * n / dt, "loss_first": losses[0], "loss_last": losses[-1],
+           "channel_samples_per_s": world * batch * 2 * n / dt, "hip_graph": bool(graph), "loss_first": losses[0], "loss_last": losses[-1],
            "finite": bool(all(map(lambda v: v == v and abs(v) != float("inf"), losses)))}
     if rank == 0 and not quiet:
         print(json.dumps(out))
@@ -119,5 +149,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--ir-samples", type=int, default=65536)
+    ap.add_argument("--graph", action="store_true", help="capture forward + backward of the step into a HIP graph and replay it")
     a = ap.parse_args()
-    run(a.steps, a.batch, a.samples, ir_samples=a.ir_samples)
+    run(a.steps, a.batch, a.samples, ir_samples=a.ir_samples, graph=a.graph)

@@ -95,3 +95,53 @@ def test_style_transfer_chain_folds_the_gain(D):
     assert float((gx1 - gx2).abs().max()) < 5e-5 * float(gx2.abs().max())
     for a, b in zip(gp1, gp2):
         assert float((a - b).abs().max()) < 2e-3 * max(float(b.abs().max()), 1e-12)
+
+
+def test_hip_graph_capture_replays_the_eager_step(D):
+    """The ops are plain stream launches, so a training step through them can be captured into a HIP graph (torch.cuda.CUDAGraph)
+    and replayed on new data: EQ -> compressor -> gain on normalised controls plus the multi-resolution STFT loss, forward and
+    backward, gives the eager step's outputs and loss bit for bit and its gradients to the last few bits."""
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    B, N = 4, 16384
+    eq, comp, gain = D.ParametricEQ(SR), D.Compressor(SR), D.Gain(SR)
+    loss_fn = D.losses.MultiResolutionSTFTLoss()
+    sizes = [eq.num_params, comp.num_params, gain.num_params]
+
+    def step(x, target, p):
+        pe, pc, pg = torch.split(p, sizes, dim=1)
+        y = gain.process_normalized(comp.process_normalized(eq.process_normalized(x, pe), pc), pg)
+        loss = loss_fn(y, target)
+        loss.backward()
+        return y, loss
+
+    def data():
+        x = torch.rand(B, 2, N, device="cuda:0", generator=g) * 2 - 1
+        t = torch.rand(B, 2, N, device="cuda:0", generator=g) - 0.5
+        p = torch.rand(B, sum(sizes), device="cuda:0", generator=g).clamp(0.02, 0.98)
+        return x, t, p
+
+    sx, st, sp = data()
+    sx.requires_grad_(True); sp.requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            sx.grad = sp.grad = None
+            step(sx, st, sp)
+    torch.cuda.current_stream().wait_stream(side)
+    sx.grad = sp.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sy, sloss = step(sx, st, sp)
+    for _ in range(2):                                    # replay on fresh data, compare with the eager step on the same data
+        x, t, p = data()
+        with torch.no_grad():
+            sx.copy_(x); st.copy_(t); sp.copy_(p)
+        graph.replay()
+        xe, pe = x.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        ye, le = step(xe, t, pe)
+        assert torch.equal(sy, ye) and torch.equal(sloss, le)
+        # (the loss' backward kernel accumulates overlapping frames with atomics: summation order, hence the last bits, vary run to run)
+        for a, b in ((sx.grad, xe.grad), (sp.grad, pe.grad)):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+        assert torch.isfinite(sp.grad).all() and sp.grad.abs().sum() > 0
