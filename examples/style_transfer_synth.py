@@ -78,7 +78,8 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # different data per rank
     chain = EffectChain(sample_rate, ir_samples)
     model = ControlPredictor(chain.num_controls, width).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    whole = graph and world == 1                              # one GPU: the optimizer step is captured too (no collective in between)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=whole)
     loss_fn = D.losses.MultiResolutionSTFTLoss()              # auraloss' default resolutions, fused HIP kernels
     losses, t0 = [], None
 
@@ -88,25 +89,37 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
         loss.backward()
         return loss
 
+    def make_target(x):                                       # the "style": the same chain with hidden random controls
+        with torch.no_grad():
+            return chain(x, torch.rand(batch, chain.num_controls, device=dev))
+
     # --graph: predictor forward, effect chain, loss and the whole backward pass are captured once into a HIP graph and replayed
     # per step (one launch instead of a few hundred; at 8 clips per GPU the step is launch-bound otherwise). The hand-written
-    # kernels are plain stream launches on torch's current stream, so they are captured like any torch op; data generation, the
-    # gradient all-reduce and the optimizer step stay eager.
+    # kernels are plain stream launches on torch's current stream, so they are captured like any torch op. On one GPU the target
+    # chain and the optimizer step are part of the graph as well; with several, the gradient all-reduce and the optimizer stay eager.
     g, static = None, {}
     if graph:
         static["x"] = synth_clips(batch, n, gen, dev)
         static["target"] = torch.zeros_like(static["x"])
+
+        def captured():
+            if whole:
+                static["target"] = make_target(static["x"])
+            loss = fwd_bwd(static["x"], static["target"])
+            if whole:
+                opt.step()
+            return loss
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                         # warm-up off the capture stream (allocator, lazy tables)
-            for _ in range(2):
+        with torch.cuda.stream(side):                         # warm-up off the capture stream (allocator, lazy tables, Adam state)
+            for _ in range(3):
                 opt.zero_grad(set_to_none=True)
-                fwd_bwd(static["x"], static["target"])
+                captured()
         torch.cuda.current_stream().wait_stream(side)
         opt.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            static["loss"] = fwd_bwd(static["x"], static["target"])
+            static["loss"] = captured()
 
     for step in range(steps + 1):                             # step 0 warms the caches / clocks and is not timed
         if step == 1:
@@ -115,18 +128,19 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
                 torch.distributed.barrier()
             t0 = time.perf_counter()
         x = synth_clips(batch, n, gen, dev)
-        with torch.no_grad():                                 # the "style": the same chain with hidden random controls
-            target = chain(x, torch.rand(batch, chain.num_controls, device=dev, generator=gen))
         if g is None:
+            target = make_target(x)
             opt.zero_grad(set_to_none=True)
             loss = fwd_bwd(x, target)
         else:
             static["x"].copy_(x)
-            static["target"].copy_(target)
+            if not whole:
+                static["target"].copy_(make_target(x))
             g.replay()                                        # gradients land in the .grad tensors the capture allocated
             loss = static["loss"]
-        dd.allreduce_gradients(model.parameters())            # the one collective of the job
-        opt.step()
+        if not whole:
+            dd.allreduce_gradients(model.parameters())        # the one collective of the job
+            opt.step()
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     if world > 1:
