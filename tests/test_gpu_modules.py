@@ -52,14 +52,16 @@ def test_style_transfer_chain(D):
     assert ps[1].grad[:, 3].abs().max() == 0          # release_ms: no path to the output
 
 
-def test_style_transfer_chain_example_runs():
+@pytest.mark.parametrize("graph", [False, True])
+def test_style_transfer_chain_example_runs(graph):
     """BASELINE config 5 on synthetic clips (examples/style_transfer_synth.py): predictor -> EQ -> compressor -> reverb -> MR-STFT loss,
-    backward through all three effects into every predictor parameter, optimizer steps with finite losses."""
+    backward through all three effects into every predictor parameter, optimizer steps with finite losses; eagerly and as a replayed
+    HIP graph (--graph)."""
     import importlib.util, os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "style_transfer_synth.py")
     spec = importlib.util.spec_from_file_location("style_transfer_synth", path)
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    out, model = mod.run(steps=3, batch=2, n=32768, ir_samples=8192, width=8, quiet=True)
+    out, model = mod.run(steps=3, batch=2, n=32768, ir_samples=8192, width=8, quiet=True, graph=graph)
     assert out["finite"] and out["steps"] == 3
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert any(float(p.grad.abs().max()) > 0 for p in model.parameters())
