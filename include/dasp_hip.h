@@ -132,8 +132,15 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
  * x, y, gy, gx: (B, 2, N) fp32.  noise: (2B, nb, L + taps - 1).  gains, decays: (B, nb).  mix: (B).
  * nb <= 16 bands, L = IR length, taps = FIR length.  All buffer sizes come from dasp_reverb_sizes.
  * ------------------------------------------------------------------------------------------- */
-int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [12], see reverb.hip */);
+/* sizes[0] = block length Lb, [1] = transform length n1, [2] = pairs of blocks per signal, [3] = blocks per signal,
+ * [4] = complex (2 x fp32) elements of Fspec, [5] = filter-bank windows per batch item,
+ * [6] = complex elements of each of A / W / Ag, [7] = complex elements of each of H / Ah / P,
+ * [8] = floats of each of ir / gir, [9] = floats of wet, [10] = floats of mix_part, [11] = floats of part. */
+int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [12] */);
+/* filters (nb, taps) fp32, the host-designed bank -> Fspec: transform twiddles followed by the band spectra. */
 int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream);
+/* forward: A, H and wet (wet may be NULL when no gradient is needed) are kept for the backward pass; W, Ah, ir are scratch.
+ * backward: gx, ggain (B, nb), gdecay (B, nb), gmix (B) are the results; Ag, W, P, gir, part, mix_part are scratch. */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays,
                         const float* mix, float* y, void* A, void* H, float* wet, void* W, void* Ah, float* ir, int B,
                         long N, int L, int taps, int nb, void* stream);
