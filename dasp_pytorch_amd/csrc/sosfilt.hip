@@ -11,23 +11,25 @@
 //   chunk = L consecutive samples of a tile                         -> one lane
 // Each biquad is realised in a *normal* state-space form (rotation/symmetric 2x2 state matrix,
 // see prep kernel) which is ~1000x less noisy in fp32 than direct forms for low-frequency poles.
-// Per tile: (1) coalesced float4 loads -> LDS transpose -> L samples per lane;
-// (2) z = G x : zero-state end state of every chunk (table from the prep kernel, SGPR operands,
-//     packed v_pk_fma_f32 over pairs of state components);
+// Per tile: (1) the tile arrives by LDS-DMA (requested a tile ahead) in a swizzled 4 KiB image -> L samples per lane;
+// (2) z = G x : zero-state end state of every chunk, a [2S x L] x [L x 64] product on the matrix cores
+//     (16 v_mfma_f32_16x16x4_f32 per tile; its left factor comes from the prep kernel);
 // (3) per section k: forcing f = z_k + sum_{j<k} M_kj s_j (block-lower-triangular coupling), then an
 //     inclusive scan over the 64 lanes with 2x2 matrix powers of M_kk: four Kogge-Stone levels
 //     inside each 16-lane row on DPP row_shr (full-rate VALU, no LDS), two row_bcast levels across
 //     rows with per-lane powers;
 // (4) the tile carry K_k is handed from the wave that owns tile t-1 through an LDS mailbox; only
-//     K' = e_63 + M_kk^64 K sits on that serial chain, the per-lane fix-up M_kk^(lane+1) K is off it;
+//     K' = e_63 + M_kk^64 K sits on that serial chain (it is lane 63's end state and that lane writes the mailbox),
+//     the per-lane fix-up M_kk^(lane+1) K is off it;
 // (5) every lane runs the S-section cascade over its L samples from its exact start state with the
-//     section coefficients held in VGPRs (VALU ops with SGPR operands issue at half rate on gfx950);
+//     section coefficients held in VGPRs (VALU ops with SGPR operands issue at 2/3 rate on gfx950);
 // (6) LDS transpose back -> coalesced float4 stores.
 // The backward kernel walks the tiles in reverse with lane l on chunk 63 - l (so that the adjoint lane scan, which runs from
 // the last chunk to the first, is an ordinary ascending DPP scan): the next tile's x, gy and the chunk start states the forward
 // pass saved arrive by LDS-DMA while the current tile is processed; it recomputes s2_k[n] (= om_k * w_k[n-2], the all-pole
-// signal) of every section into registers, runs the adjoint cascade (sections reversed, transposed realisation) and accumulates
-// the five coefficient correlations per section; a finalize kernel reduces them in fp64.
+// signal; w_k itself where a section may run in direct form) of every section into registers, runs the adjoint cascade (sections
+// reversed, each in transposed direct form II from the exact chunk costate) and accumulates the five coefficient correlations per
+// section; a finalize kernel reduces them in fp64.
 #include "common.hpp"
 #include <type_traits>
 
