@@ -169,8 +169,10 @@ def cascade_chunks(secs, X, start, store_s2=False, r=None):
     return U, None, S2
 
 
-def forward_row(r, x, L, save_every=None):
-    """Forward filter one row x (N,) with realisation r. Returns y and saved tile carries."""
+def forward_row(r, x, L, save_every=None, tiles=None, carry0=None, scan_only=False):
+    """Forward filter one row x (N,) with realisation r. Returns y and saved tile carries.
+    tiles = (t0, t1) restricts the pass to that tile range starting from the cascade state carry0 (the segmented scheme below);
+    scan_only skips the cascade (no output) and returns the state after tile t1 - 1 instead of y."""
     secs = _sections_fwd(r)
     G, M, P = chunk_tables(secs, L)
     S = len(secs)
@@ -180,21 +182,29 @@ def forward_row(r, x, L, save_every=None):
     xp = np.zeros(nt * TS)
     xp[:N] = x
     y = np.zeros(nt * TS)
-    carry = np.zeros(2 * S)
+    t0, t1 = tiles if tiles is not None else (0, nt)
+    carry = np.zeros(2 * S) if carry0 is None else np.asarray(carry0, np.float64).copy()
     carries = np.zeros((nt, 2 * S))
-    for t in range(nt):
+    for t in range(t0, t1):
         X = xp[t * TS:(t + 1) * TS].reshape(WAVE, L)
         carries[t] = carry
         z = X @ G.T
         start, carry = tile_scan(z, M, P, carry)
+        if scan_only:
+            continue
         Y, _, _ = cascade_chunks(secs, X, start, r=r if FWD_DIRECT else None)
         y[t * TS:(t + 1) * TS] = Y.reshape(-1)
-    return y[:N], carries
+    if scan_only:
+        return carry, carries
+    return (y if tiles is not None else y[:N]), carries
 
 
-def backward_row(r, x, gy, carries, L):
+def backward_row(r, x, gy, carries, L, tiles=None, acarry0=None, scan_only=False, raw=False):
     """Backward for one row: returns gx (N,), and gb (S,3), ga (S,3) -- gradients w.r.t. the
-    a0-normalised coefficients (ga[:,0] is d/da0 from scale invariance)."""
+    a0-normalised coefficients (ga[:,0] is d/da0 from scale invariance).
+    tiles = (t0, t1) restricts the pass to tiles t1 - 1 .. t0 starting from the adjoint cascade state acarry0; scan_only runs only the
+    adjoint lane scans and returns the adjoint state below tile t0; raw returns (gx padded, acc_b, acc_a) un-normalised so that
+    segments can be summed (the segmented scheme below)."""
     fs = _sections_fwd(r)
     ads = _sections_adj(r)
     S = len(fs)
@@ -208,16 +218,19 @@ def backward_row(r, x, gy, carries, L):
     gx = np.zeros(nt * TS)
     acc_b = np.zeros((S, 3))
     acc_a = np.zeros((S, 3))   # [:,0] unused (filled from the identity)
-    acarry = np.zeros(2 * S)
-    for t in range(nt - 1, -1, -1):
+    t0, t1 = tiles if tiles is not None else (0, nt)
+    acarry = np.zeros(2 * S) if acarry0 is None else np.asarray(acarry0, np.float64).copy()
+    for t in range(t1 - 1, t0 - 1, -1):
         X = xp[t * TS:(t + 1) * TS].reshape(WAVE, L)
         GY = gp[t * TS:(t + 1) * TS].reshape(WAVE, L)
-        # forward chunk start states from the saved tile carry
-        start, _ = tile_scan(X @ G.T, M, P, carries[t])
-        _, _, S2 = cascade_chunks(fs, X, start, store_s2=True, r=r)
         # adjoint: same machinery on (lane, sample)-reversed data
         GYr = GY[::-1, ::-1]
         astart_r, acarry = tile_scan(GYr @ Ga.T, Ma, Pa, acarry)
+        if scan_only:
+            continue
+        # forward chunk start states from the saved tile carry
+        start, _ = tile_scan(X @ G.T, M, P, carries[t])
+        _, _, S2 = cascade_chunks(fs, X, start, store_s2=True, r=r)
         # per-lane adjoint cascade with correlations (natural lane order, descending n). As in the kernel, each adjoint section
         # runs in transposed direct form II from the chunk's entry costate (normal-form coordinates, from the scan), mapped once
         # per chunk: z1 = l1, z2 = -sg*l1 + om*l2 (same zero-input response, same transfer function H(1/z)).
@@ -242,9 +255,72 @@ def backward_row(r, x, gy, carries, L):
                 g = out
             GX[:, n] = g
         gx[t * TS:(t + 1) * TS] = GX.reshape(-1)
+    if scan_only:
+        return acarry
+    if raw:
+        return gx, acc_b, acc_a
+    return (gx if tiles is not None else gx[:N],) + _normalise_grads(r, acc_b, acc_a)
+
+
+def _normalise_grads(r, acc_b, acc_a):
     om = np.where(r["direct"], 1.0, r["om"])
     gb = acc_b / om[:, None]
     ga = -acc_a / om[:, None]
     # d/da0 at a0 = 1 from scale invariance of B/A:  sum_theta theta * dL/dtheta = 0
     ga[:, 0] = -(np.sum(gb * r["b"], 1) + np.sum(ga[:, 1:] * r["a"], 1))
-    return gx[:N], gb, ga
+    return gb, ga
+
+
+# ---- segmented scheme for few rows (a row is one workgroup, so B*C < 512 rows leave CUs idle) --------------------
+# Every row is cut into `segments` runs of tiles that are processed independently:
+#   1. a scan-only pass over each segment from a zero state gives z(g), the cascade state its input alone leaves behind;
+#   2. start(g + 1) = Phi_seg start(g) + z(g) with Phi_seg = Phi^(samples per segment) chains the segments (a 2S-vector recursion);
+#   3. the ordinary pass runs per segment from start(g).
+# The backward pass is the mirror image on the adjoint system, walking the segments downwards.
+def segment_transitions(r, L, tiles_per_segment):
+    n = WAVE * L * tiles_per_segment
+    Phi, _ = cascade_system(_sections_fwd(r))
+    Phia, _ = cascade_system(_sections_adj(r))
+    return np.linalg.matrix_power(Phi, n), np.linalg.matrix_power(Phia, n)
+
+
+def forward_row_segmented(r, x, L, segments):
+    TS = WAVE * L
+    N = len(x)
+    nt = (N + TS - 1) // TS
+    assert nt % segments == 0, "the model takes whole segments"
+    T = nt // segments
+    Phi_seg, _ = segment_transitions(r, L, T)
+    z = [forward_row(r, x, L, tiles=(g * T, (g + 1) * T), scan_only=True)[0] for g in range(segments)]          # step 1
+    start = [np.zeros_like(z[0])]
+    for g in range(segments - 1):                                                                                # step 2
+        start.append(Phi_seg @ start[g] + z[g])
+    y = np.zeros(nt * TS)
+    carries = np.zeros((nt, len(z[0])))
+    for g in range(segments):                                                                                    # step 3
+        yg, cg = forward_row(r, x, L, tiles=(g * T, (g + 1) * T), carry0=start[g])
+        y[g * T * TS:(g + 1) * T * TS] = yg[g * T * TS:(g + 1) * T * TS]
+        carries[g * T:(g + 1) * T] = cg[g * T:(g + 1) * T]
+    return y[:N], carries
+
+
+def backward_row_segmented(r, x, gy, carries, L, segments):
+    TS = WAVE * L
+    N = len(x)
+    nt = (N + TS - 1) // TS
+    assert nt % segments == 0
+    T = nt // segments
+    _, Phia_seg = segment_transitions(r, L, T)
+    za = [backward_row(r, x, gy, carries, L, tiles=(g * T, (g + 1) * T), scan_only=True) for g in range(segments)]
+    aend = [None] * segments                         # adjoint state entering segment g from above
+    aend[segments - 1] = np.zeros_like(za[0])
+    for g in range(segments - 1, 0, -1):
+        aend[g - 1] = Phia_seg @ aend[g] + za[g]
+    gx = np.zeros(nt * TS)
+    acc_b = acc_a = 0
+    for g in range(segments):
+        gxg, b, a = backward_row(r, x, gy, carries, L, tiles=(g * T, (g + 1) * T), acarry0=aend[g], raw=True)
+        gx[g * T * TS:(g + 1) * T * TS] = gxg[g * T * TS:(g + 1) * T * TS]
+        acc_b = acc_b + b
+        acc_a = acc_a + a
+    return (gx[:N],) + _normalise_grads(r, acc_b, acc_a)
