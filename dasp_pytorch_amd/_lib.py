@@ -32,6 +32,14 @@ SIGNATURES = {
     "dasp_sosfilt_backward": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sos_grad_finalize": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "dasp_sosfilt_backward_grads": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _p]),
+    "dasp_sos_segment_tiles": (_l, [_l, _l]),
+    "dasp_sos_segments": (_l, [_l, _l]),
+    "dasp_sos_segtab_doubles": (_l, [_i]),
+    "dasp_sos_seg_floats": (_l, [_l, _l, _i, _l]),
+    "dasp_sos_segment_prepare": (_i, [_p, _i, _i, _l, _p, _p]),
+    "dasp_sosfilt_forward_seg": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _l, _i, _l, _p]),
+    "dasp_sosfilt_backward_seg": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _p]),
+    "dasp_sos_grad_finalize_seg": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p]),
     "dasp_ew_partial_floats": (_l, [_l, _l]),
     "dasp_gain_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dasp_gain_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),

@@ -623,16 +623,21 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int S, int L, int W>
+// SEG 0: one workgroup per row. SEG 1 / 2: the segmented scheme for few rows (oracle/chunkscan_model.py forward_row_segmented): one
+// workgroup per (row, segment of Tseg tiles); 2 = the scan-only pre-pass from a zero state, which leaves the segment's end state in
+// zseg[row][segment][2S]; 1 = the ordinary pass from the segment's start state segstart[row][segment][2S].
+template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
-               float* __restrict__ carries, int C, int N, int nt, int vec) {
+               float* __restrict__ carries, int C, int N, int nt, int vec,
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L;        // unpadded, swizzled tile images (common.hpp)
     constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
-    const int row = blockIdx.x;
+    const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt;   // this workgroup's tiles
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     float* __restrict__ yr = y + (size_t)row * N;
@@ -643,7 +648,16 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* pw_lds = cf_lds + LDS_CF;
     float* tbx = pw_lds + LDS_PW + wave * 2 * IMG;   // x image: this tile's, then (by LDS-DMA, as soon as it has been read) the next one's
     float* tby = tbx + IMG;                          // y image on its way out
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = 0.f;
+    // mailboxes zeroed; wave 0's inbox holds what its first tile t0 waits for: sequence number t0 and the state the segment starts from
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
+        float v = 0.f;
+        if (SEG && i < S * 4) {
+            const int comp = i & 3;
+            if (comp == 2) v = __builtin_bit_cast(float, t0);
+            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
+        }
+        lds[i] = v;
+    }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PW + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
@@ -654,13 +668,13 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #pragma unroll
     for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
     const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx));
-    if (wave < nt && tile_full<L>((long)wave * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)wave * TS, a_x, lane);
+    if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
     int stores_in_flight = 0;
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
     const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
 
-    for (int t = wave; t < nt; t += W) {
+    for (int t = t0 + wave; t < t1; t += W) {
         int toff = 0;
         asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
         const float* __restrict__ tbl = tb + toff;
@@ -678,9 +692,9 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         chunk_products_load(tbx, Bop, lane);
         pin(X); pin(Bop);
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 16)
-        if (t + W < nt && t < W) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
+        if (t + W < t1 && t < W) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
 #else
-        if (t + W < nt && tile_full<L>((long)(t + W) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
+        if (t + W < t1 && tile_full<L>((long)(t + W) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
 #endif
         TRACE(1);
         float Z[L];
@@ -704,7 +718,8 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             },
             [&](int k, f2 Kn) {
                 if (W == 1) Kreg[k] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
-                else if (t + 1 < nt) mbox_publish<63>(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
+                else if (t + 1 < t1) mbox_publish<63>(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
+                else if (SEG == 2 && lane == 63) *reinterpret_cast<f2*>(zseg + ((size_t)row * G + seg) * S2 + 2 * k) = Kn;   // the segment's end state
             }
 #ifdef DASP_TRACE
             , blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W
@@ -712,6 +727,10 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             );
         SCAN_PRIO(0);
         TRACE(2);
+        if (SEG == 2) {          // scan-only pre-pass: the carries are all this pass is for; nothing was stored
+            stores_in_flight = 0;
+            continue;
+        }
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 8)
         if (false) {
 #else
@@ -837,12 +856,16 @@ __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab
 // parked in the wave's LDS region (the transposition buffers are idle at that point), the upper
 // half [H, S) keeps its own in registers, and the adjoint runs as two half-cascade passes
 // (sections S-1..H, then H-1..0 with the parked signals read back).
-template <int S, int L, int W>
+// SEG as in the forward kernel (oracle/chunkscan_model.py backward_row_segmented): 2 = adjoint scan-only pre-pass from a zero adjoint
+// state, leaving the state below the segment in zseg[row][segment][2S]; 1 = the ordinary pass from segstart[row][segment][2S], the
+// adjoint state entering the segment from above; partial sums per (row, segment, wave).
+template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec,
-               float* __restrict__ cnt_tab, const double* __restrict__ dtab, int mode, float* __restrict__ gout, int B) {
+               float* __restrict__ cnt_tab, const double* __restrict__ dtab, int mode, float* __restrict__ gout, int B,
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
     using LY = SosLayout<S, L>;
     // S <= 6: the s2 signals of all sections stay in registers (H = 0). S = 8: the lower half is parked in LDS (H = S / 2).
     constexpr int S2 = 2 * S, TS = 64 * L, H = S > 6 ? S / 2 : 0, SH = S - H;   // SH >= H
@@ -852,7 +875,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
-    const int row = blockIdx.x;
+    const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // this workgroup's tiles, walked t1 - 1 .. t0
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
@@ -865,8 +889,17 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* tbo = tbg + IMG;                        // gx image on its way out
     float* tst = tbo + IMG;                        // chunk start states [section pair][lane] f4
     float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
-    // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (the row's last, nt - 1) waits for, with a zero carry
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
+    // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (t1 - 1: the row's or the segment's last) waits for,
+    // with the adjoint state that enters from above (zero at the end of the row)
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
+        float v = 0.f;
+        if (i < S * 4) {
+            const int comp = i & 3;
+            if (comp == 2) v = __builtin_bit_cast(float, t1);
+            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
+        }
+        lds[i] = v;
+    }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
@@ -895,14 +928,14 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #pragma unroll
         for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
     };
-    if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) issue_dma(nt - 1 - wave);
+    if (wave < nr && tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec)) issue_dma(t1 - 1 - wave);
     int stores_in_flight = 0;
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
     const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
 
-    for (int r = wave; r < nt; r += W) {
-        const int t = nt - 1 - r;
+    for (int r = wave; r < nr; r += W) {
+        const int t = t1 - 1 - r;
         int toff = 0;
         asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
         const float* __restrict__ tbl = tb + toff;
@@ -937,7 +970,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             st[2 * m + 1] = f2{q.z, q.w};
         }
         pin(st); TRACE(18);
-        if (r + W < nt) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full
+        if (r + W < nr) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full
         float Z[L];
         chunk_products_issue(Bop, Aop, zacc);
         chunk_products_collect<L>(tbo, zacc, Z, lane, cl);   // the gx image is idle until the end of the tile
@@ -961,10 +994,15 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 },
                 [&](int i, f2 Kn) {
                     if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
-                    else if (t > 0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                    else if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                    else if (SEG == 2 && lane == 63) *reinterpret_cast<f2*>(zseg + ((size_t)row * G + seg) * S2 + 2 * i) = Kn;   // state below the segment
                 });
         }
         SCAN_PRIO(0);
+        if (SEG == 2) {          // adjoint scan-only pre-pass
+            stores_in_flight = 0;
+            continue;
+        }
         pin(X); pin(GY); pin(st); pin(lam);   // scans done before the cascade passes start
         TRACE(19);
         __builtin_amdgcn_sched_barrier(0);
@@ -1095,7 +1133,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         TRACE(24);
     }
     // per-wave partial sums -> partials[row][wave][S][5]
-    float* po = partials + ((size_t)row * W + wave) * S * 5;
+    if (SEG == 2) return;
+    float* po = partials + (((size_t)row * G + seg) * W + wave) * S * 5;
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const float v0 = wave_sum(accb[k][0]), v1 = wave_sum(accb[k][1]), v2 = wave_sum(accb[k][2]);
@@ -1128,6 +1167,93 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         }
         __syncthreads();
         if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented rows (few rows: B*C workgroups do not fill the chip). Per item: Phi^(samples per segment) of the forward and the adjoint
+// cascade, in fp64 from the fp64 design in dtab (same realisation and Phi as the prep kernel), by repeated squaring. One wave per item.
+template <int S>
+__global__ void __launch_bounds__(64)
+sos_segprep_kernel(const double* __restrict__ dtab, int nsq, double* __restrict__ segtab) {
+    constexpr int S2 = 2 * S, NN = S2 * S2;
+    __shared__ double sec[S][8];
+    __shared__ double T1[2][NN], T2[2][NN];
+    const int l = threadIdx.x, item = blockIdx.x;
+    if (l < S) {
+        const double* d = dtab + ((size_t)item * S + l) * DT_STRIDE;
+        const double b0 = d[DT_B0], b1 = d[DT_B0 + 1], b2 = d[DT_B0 + 2], a1 = d[DT_B0 + 3], a2 = d[DT_B0 + 4];
+        const double sg = -0.5 * a1, disc = sg * sg - a2, kap = disc < 0 ? 1.0 : -1.0;
+        double om = sqrt(fabs(disc));
+        om = om < OM_MIN ? OM_MIN : om;
+        const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
+        sec[l][0] = sg; sec[l][1] = om; sec[l][2] = kap * om; sec[l][3] = g1; sec[l][4] = g2; sec[l][5] = b0;
+    }
+    wave_lds_sync();
+    for (int e = l; e < 2 * NN; e += 64) {   // as in sos_prep_kernel
+        const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
+        const int kk = i / 2, r = i % 2, jj = j / 2, c = j % 2;
+        const int fk = sys ? S - 1 - kk : kk, fj = sys ? S - 1 - jj : jj;
+        const double sg = sec[fk][0], om = sec[fk][1], kom = sec[fk][2];
+        const int rr = sys ? c : r, cc = sys ? r : c;
+        const double a_el = rr == cc ? sg : (rr == 0 ? -kom : om);
+        const double Bk = sys ? sec[fk][3 + r] : (r == 0 ? 1.0 : 0.0);
+        const double Cj = sys ? (c == 0 ? 1.0 : 0.0) : sec[fj][3 + c];
+        double gain = 1.0;
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+            const double dm = sec[sys ? S - 1 - m : m][5];
+            gain *= (m > jj && m < kk) ? dm : 1.0;
+        }
+        T1[sys][i * S2 + j] = jj == kk ? a_el : (jj < kk ? Bk * gain * Cj : 0.0);
+    }
+    wave_lds_sync();
+    double (*src)[NN] = T1;
+    double (*dst)[NN] = T2;
+    for (int step = 0; step < nsq; ++step) {
+        for (int e = l; e < 2 * NN; e += 64) {
+            const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < S2; ++m) acc += src[sys][i * S2 + m] * src[sys][m * S2 + j];
+            dst[sys][i * S2 + j] = acc;
+        }
+        wave_lds_sync();
+        double (*tmp)[NN] = src; src = dst; dst = tmp;
+    }
+    for (int e = l; e < 2 * NN; e += 64) segtab[(size_t)item * 2 * NN + e] = src[e / NN][e % NN];
+}
+
+// Chains the segments of a row: start(g + 1) = Phi_seg start(g) + z(g) upwards for the forward system (adjoint = 0), downwards
+// aend(g - 1) = Phia_seg aend(g) + za(g) for the adjoint system (adjoint = 1). z and the result are [row][G][2S] fp32; one wave per row.
+template <int S>
+__global__ void __launch_bounds__(64)
+sos_chain_kernel(const double* __restrict__ segtab, int tab_bcast, int C, const float* __restrict__ z, float* __restrict__ start, int G,
+                 int adjoint) {
+    constexpr int S2 = 2 * S, NN = S2 * S2;
+    __shared__ double st[2][S2];
+    const int l = threadIdx.x, row = blockIdx.x;
+    const double* Phi = segtab + ((size_t)(tab_bcast ? 0 : row / C) * 2 + (adjoint ? 1 : 0)) * NN;
+    double prow[S2];
+#pragma unroll
+    for (int j = 0; j < S2; ++j) prow[j] = l < S2 ? Phi[l * S2 + j] : 0.0;
+    const int first = adjoint ? G - 1 : 0, step = adjoint ? -1 : 1;
+    if (l < S2) {
+        st[0][l] = 0.0;
+        start[((size_t)row * G + first) * S2 + l] = 0.f;
+    }
+    wave_lds_sync();
+    int cur = 0;
+    for (int n = 0, g = first; n < G - 1; ++n, g += step) {
+        if (l < S2) {
+            double acc = (double)z[((size_t)row * G + g) * S2 + l];
+#pragma unroll
+            for (int j = 0; j < S2; ++j) acc += prow[j] * st[cur][j];
+            st[cur ^ 1][l] = acc;
+            start[((size_t)row * G + g + step) * S2 + l] = (float)acc;
+        }
+        wave_lds_sync();
+        cur ^= 1;
     }
 }
 
@@ -1315,5 +1441,88 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
         return check_launch();
     });
 }
+
+// ---- segmented rows -------------------------------------------------------------------------------------------------------------
+// For few rows (a row is one workgroup) every row can be cut into segments of Tseg tiles that run as independent workgroups:
+// dasp_sos_segment_tiles proposes Tseg (a power of two; 0 = do not segment), dasp_sos_segment_prepare builds the per-item segment
+// transition matrices from dtab, and the *_seg entry points run scan-only pre-pass, chain kernel and the ordinary pass. segbuf:
+// dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch; partials: dasp_sos_partial_floats(rows * segments, S).
+long dasp_sos_segment_tiles(long rows, long N) {
+    const long nt = dasp_sos_num_tiles(N);
+    if (rows <= 0 || rows >= 128 || nt < 16) return 0;
+    long T = 8;                                        // at least one tile per forward wave
+    while (rows * ((nt + T - 1) / T) > 1024 && T < nt) T *= 2;
+    return (nt + T - 1) / T > 1 ? T : 0;
+}
+long dasp_sos_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_sos_num_tiles(N) + Tseg - 1) / Tseg : 1; }
+long dasp_sos_segtab_doubles(int S) { return 2L * (2 * S) * (2 * S); }
+long dasp_sos_seg_floats(long rows, long N, int S, long Tseg) { return 2 * rows * dasp_sos_segments(N, Tseg) * 2 * S; }
+
+int dasp_sos_segment_prepare(const double* dtab, int Bs, int S, long Tseg, double* segtab, void* stream) {
+    if (!dtab || !segtab || Bs <= 0 || Tseg <= 0 || (Tseg & (Tseg - 1))) return DASP_ERR_ARG;
+    int nsq = 0;
+    for (long n = 64L * kL * Tseg; n > 1; n >>= 1) ++nsq;   // Phi^(64 L Tseg): log2 squarings
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        hipLaunchKernelGGL((sos_segprep_kernel<SS>), dim3(Bs), dim3(64), 0, (hipStream_t)stream, dtab, nsq, segtab);
+        return check_launch();
+    });
+}
+
+int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, const float* x, float* y, float* carries, float* segbuf,
+                             int B, int C, long N, int S, long Tseg, void* stream) {
+    if (!tab || !segtab || !x || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0) return DASP_ERR_ARG;
+    if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_sos_num_tiles(N), G = (int)dasp_sos_segments(N, Tseg), bc = Bs == 1 && B != 1;
+    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(y);
+    float* z = segbuf;
+    float* start = segbuf + (size_t)B * C * G * 2 * S;
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 2>), dim3(B * C * G), dim3(64 * kWF), 0, st, tab, bc, x, (float*)nullptr,
+                           (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg, (const float*)nullptr, z);
+        hipLaunchKernelGGL((sos_chain_kernel<SS>), dim3(B * C), dim3(64), 0, st, segtab, bc, C, (const float*)z, start, G, 0);
+        hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 1>), dim3(B * C * G), dim3(64 * kWF), 0, st, tab, bc, x, y, carries, C, (int)N, nt,
+                           vec, G, (int)Tseg, (const float*)start, (float*)nullptr);
+        return check_launch();
+    });
+}
+
+int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
+                              float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, void* stream) {
+    if (!tab || !segtab || !x || !gy || !carries || !gx || !partials || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) ||
+        Tseg <= 0)
+        return DASP_ERR_ARG;
+    if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_sos_num_tiles(N), G = (int)dasp_sos_segments(N, Tseg), bc = Bs == 1 && B != 1;
+    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
+    float* z = segbuf;
+    float* start = segbuf + (size_t)B * C * G * 2 * S;
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 2>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, (float*)nullptr,
+                           (float*)nullptr, C, (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg,
+                           (const float*)nullptr, z);
+        hipLaunchKernelGGL((sos_chain_kernel<SS>), dim3(B * C), dim3(64), 0, st, segtab, bc, C, (const float*)z, start, G, 1);
+        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 1>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, gx, partials, C,
+                           (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg, (const float*)start,
+                           (float*)nullptr);
+        return check_launch();
+    });
+}
+
+// dasp_sos_grad_finalize for partial sums produced by dasp_sosfilt_backward_seg with `segments` segments per row
+int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
+                               float* gout, void* stream) {
+    if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
+        return DASP_ERR_ARG;
+    const int n = B * S;
+    hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab, Bs == 1 && B != 1, partials, B, C, S,
+                       kWB * segments, mode, gout);
+    return check_launch();
+}
+
 
 }  // extern "C"

@@ -77,6 +77,27 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
                                 const float* carries, float* gx, float* partials, int mode, float* gout,
                                 int B, int C, long N, int S, void* stream);
 
+/* Few rows (B*C < 128): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
+ * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, a
+ * small kernel chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab), then the ordinary pass runs per
+ * segment from its start state; same results (oracle/chunkscan_model.py forward_row_segmented / backward_row_segmented).
+ *   Tseg   = dasp_sos_segment_tiles(rows, N): proposed tiles per segment (a power of two), 0 = use the plain calls
+ *   segtab = dasp_sos_segtab_doubles(S) doubles per item (Bs items);  segbuf = dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch
+ *   partials of the backward pass: dasp_sos_partial_floats(rows * dasp_sos_segments(N, Tseg), S) floats, finalized by
+ *   dasp_sos_grad_finalize_seg(..., segments = dasp_sos_segments(N, Tseg), ...). */
+long dasp_sos_segment_tiles(long rows, long N);
+long dasp_sos_segments(long N, long Tseg);
+long dasp_sos_segtab_doubles(int S);
+long dasp_sos_seg_floats(long rows, long N, int S, long Tseg);
+int dasp_sos_segment_prepare(const double* dtab, int Bs, int S, long Tseg, double* segtab, void* stream);
+int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, const float* x, float* y, float* carries,
+                             float* segbuf, int B, int C, long N, int S, long Tseg, void* stream);
+int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy,
+                              const float* carries, float* gx, float* partials, float* segbuf,
+                              int B, int C, long N, int S, long Tseg, void* stream);
+int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments,
+                               int mode, float* gout, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * gain / distortion.  Replace dasp_pytorch.functional.gain (dasp_pytorch/functional.py:10-29):
  * y = x * 10^(gain_db/20), gain_db (B) one value per batch item repeated over channels (:26-28);

@@ -275,3 +275,34 @@ def test_backward_grads_entry_equals_two_calls(D, Bs_shared):
             call("dasp_sosfilt_backward_grads", ptr(tab), ptr(dtab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx2), ptr(part), mode, ptr(g2),
                  B, C, N, S, stream())
             assert torch.equal(gx1, gx2) and torch.equal(g1, g2) and torch.isfinite(g2).all()
+
+
+@pytest.mark.parametrize("B,C,N,bcast,tiles", [(2, 2, 40000, False, None), (3, 1, 65536, False, 16), (1, 2, 131072, False, None),
+                                               (4, 2, 33333, True, 8), (2, 1, 16385, False, 8)])
+def test_segmented_rows_equal_plain_rows(D, monkeypatch, B, C, N, bcast, tiles):
+    """Few rows: the segmented-row kernels (scan-only pre-pass, chained segment start states, per-segment pass; dasp_hip.h) give what
+    one workgroup per row gives - outputs and input gradients to the last bits, parameter gradients to summation order - on full and
+    ragged lengths, a shared parameter set, and a last segment shorter than the others; and both agree with the oracle."""
+    rng = np.random.default_rng(B * 1000 + N)
+    lo = np.array([r[0] for r in PEQ_RANGES]); hi = np.array([r[1] for r in PEQ_RANGES])
+    Bp = 1 if bcast else B
+    p = (rng.random((Bp, 18)) * (hi - lo) + lo).astype(np.float32)
+    p[0, 1] = 25.0; p[0, 2] = 5.0                                   # a slowly decaying low shelf: the segment chain must carry real state
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32); w = rng.standard_normal((B, C, N)).astype(np.float32)
+
+    def run(mode):
+        monkeypatch.setenv("DASP_SOS_SEGMENT", mode)
+        if tiles:
+            monkeypatch.setenv("DASP_SOS_SEGMENT_TILES", str(tiles))
+        xt = dev(x).requires_grad_(True)
+        cols = [dev(p[:, i]).requires_grad_(True) for i in range(18)]
+        y = D.parametric_eq(xt, SR, *cols)
+        (y * dev(w)).sum().backward()
+        return y.detach().cpu().numpy(), xt.grad.cpu().numpy(), torch.stack([c.grad for c in cols], 1).cpu().numpy()
+    yp, gxp, gpp = run("0")
+    ys, gxs, gps = run("1")
+    assert np.abs(ys - yp).max() <= 2e-6 * np.abs(yp).max()
+    assert np.abs(gxs - gxp).max() <= 2e-6 * np.abs(gxp).max()
+    assert np.abs(gps - gpp).max() <= 2e-4 * np.abs(gpp).max()
+    yo = orc.parametric_eq(x, SR, np.broadcast_to(p, (B, 18)).astype(np.float64))
+    assert linf_peak(ys, yo).max() < TOL_SIG
