@@ -649,14 +649,18 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* tbx = pw_lds + LDS_PW + wave * 2 * IMG;   // x image: this tile's, then (by LDS-DMA, as soon as it has been read) the next one's
     float* tby = tbx + IMG;                          // y image on its way out
     // mailboxes zeroed; wave 0's inbox holds what its first tile t0 waits for: sequence number t0 and the state the segment starts from
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
-        float v = 0.f;
-        if (SEG && i < S * 4) {
-            const int comp = i & 3;
-            if (comp == 2) v = __builtin_bit_cast(float, t0);
-            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
+    if (SEG) {
+        for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
+            float v = 0.f;
+            if (i < S * 4) {
+                const int comp = i & 3;
+                if (comp == 2) v = __builtin_bit_cast(float, t0);
+                else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
+            }
+            lds[i] = v;
         }
-        lds[i] = v;
+    } else {
+        for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = 0.f;
     }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PW + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
@@ -891,14 +895,18 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
     // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (t1 - 1: the row's or the segment's last) waits for,
     // with the adjoint state that enters from above (zero at the end of the row)
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
-        float v = 0.f;
-        if (i < S * 4) {
-            const int comp = i & 3;
-            if (comp == 2) v = __builtin_bit_cast(float, t1);
-            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
+    if (SEG) {
+        for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
+            float v = 0.f;
+            if (i < S * 4) {
+                const int comp = i & 3;
+                if (comp == 2) v = __builtin_bit_cast(float, t1);
+                else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
+            }
+            lds[i] = v;
         }
-        lds[i] = v;
+    } else {
+        for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
     }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
@@ -1134,7 +1142,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     }
     // per-wave partial sums -> partials[row][wave][S][5]
     if (SEG == 2) return;
-    float* po = partials + (((size_t)row * G + seg) * W + wave) * S * 5;
+    float* po = partials + ((SEG ? (size_t)row * G + seg : (size_t)row) * W + wave) * S * 5;
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const float v0 = wave_sum(accb[k][0]), v1 = wave_sum(accb[k][1]), v2 = wave_sum(accb[k][2]);
