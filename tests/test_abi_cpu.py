@@ -41,6 +41,24 @@ def test_size_queries():
     assert L.dasp_sos_carry_floats(4, 2 * T, 6) == 4 * 2 * 12 * 64
 
 
+def test_segment_planning():
+    """Host-side planning of the segmented-row path (no launch): few rows of a long signal are cut into power-of-two runs of at least
+    eight tiles so that rows * segments fills the chip; many rows or short signals keep one workgroup per row."""
+    L = _lib.lib()
+    T = L.dasp_sos_tile()
+    N = 128 * T
+    assert L.dasp_sos_segment_tiles(512, N) == 0 and L.dasp_sos_segment_tiles(128, N) == 0      # enough rows
+    assert L.dasp_sos_segment_tiles(8, 15 * T) == 0                                             # too short to cut
+    for rows in (1, 2, 16, 32, 100):
+        t = L.dasp_sos_segment_tiles(rows, N)
+        g = L.dasp_sos_segments(N, t)
+        assert t >= 8 and t & (t - 1) == 0 and g == -(-128 // t) and g > 1 and rows * g <= 1024
+        assert L.dasp_sos_seg_floats(rows, N, 6, t) == 2 * rows * g * 12
+    assert L.dasp_sos_segments(N + 1, 8) == 17 and L.dasp_sos_segments(N, 0) == 1                # ragged last segment; 0 = not segmented
+    assert L.dasp_sos_segtab_doubles(6) == 2 * 12 * 12
+    assert L.dasp_sos_partial_floats(4 * L.dasp_sos_segments(N, 8), 6) == 16 * L.dasp_sos_partial_floats(4, 6)
+
+
 def test_reverb_size_query():
     """Host-side planning of the reverb (no launch): block length, transform length, pairs; refusals are -2."""
     import ctypes
