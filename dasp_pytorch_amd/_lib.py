@@ -32,6 +32,12 @@ SIGNATURES = {
     "dasp_sosfilt_backward": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sos_grad_finalize": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "dasp_sosfilt_backward_grads": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _p]),
+    "dasp_sosfilt_backward_ex": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p]),
+    "dasp_sos_grad_finalize_ex": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasp_sosfilt_backward_grads_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _i, _p]),
+    "dasp_peq_forward": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
+    "dasp_peq_backward": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _l, _p, _p, _p]),
+    "dasp_sosfilt_backward_seg_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _i, _p]),
     "dasp_sos_segment_tiles": (_l, [_l, _l]),
     "dasp_sos_segments": (_l, [_l, _l]),
     "dasp_sos_segtab_doubles": (_l, [_i]),
@@ -146,6 +152,13 @@ def ptr(t):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_same_device(x, **others):
+    """Every tensor of a call lives on x's device (the kernels get raw pointers: a pointer of another GPU is a memory fault)."""
+    for name, t in others.items():
+        if isinstance(t, torch.Tensor) and t.device != x.device:
+            raise DaspHipError(f"{name} is on {t.device} but x is on {x.device}: all tensors of a call must share one device")
 
 
 def require_device(t, name="x"):

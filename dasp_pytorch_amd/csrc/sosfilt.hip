@@ -90,12 +90,17 @@ struct SosLayout {
     static constexpr int P64A = P64 + SYS;
     static constexpr int PWA = PW + SYS;
     static constexpr int DF = GT + 2 * SYS;          // [S][8]: b1, b2, -a1, -a2 (normalised), zc1, zc2, 1/om, sg/om: direct-form sections
-    static constexpr int CNT = DF + 8 * S;           // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
+    static constexpr int MN = DF + 8 * S;            // [S][8]: b1/b0, b2/b0, g1/d, g2/d, q, q/om, q sg/om, 0 with q = 1 / (b0 of the sections before k): the
+                                                     //      backward kernel's recomputation of a designed cascade runs every section with feed-through 1
+    static constexpr int CNT = MN + 8 * S;           // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
                                                      //      prep kernel, reset by the workgroup that finalizes the item)
     static constexpr int TOTAL = CNT + 4;
 };
 // fp64 side table for the finalize kernel, per (item, section)
-constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_STRIDE = 24;
+// [DT_OM] om (1 for a direct-form section: its correlations are taken with w itself), [DT_B0..+4] b0 b1 b2 a1 a2 (normalised), [DT_A0] a0 as
+// given, [7] kappa, [DT_J..+14] design Jacobian, [DT_SG32] sg as the kernels hold it (fp32), [DT_PK] product of the b0 of the sections before
+// this one (scale of its signals in the monic recomputation), [DT_NF] 1 = the section's kept signal is om w (normal form), 0 = w (direct form)
+constexpr int DT_OM = 0, DT_B0 = 1, DT_A1 = 4, DT_A0 = 6, DT_J = 8, DT_SG32 = 24, DT_PK = 25, DT_NF = 26, DT_STRIDE = 28;
 
 // (p, q) x (p', q') for matrices [[p, -k q], [q, p]] (closed under multiplication for fixed k)
 __device__ __forceinline__ void nmul(double k, double p1, double q1, double p2, double q2, double& p, double& q) {
@@ -220,7 +225,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
                 float* __restrict__ tab, double* __restrict__ dtab) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, NN = S2 * S2;
-    __shared__ double sec[S][8];        // sg, om, kom, g1, g2, d, kappa
+    __shared__ double sec[S][10];       // sg, om, kom, g1, g2, d, kappa, b1, b2
     __shared__ double Phi[2][NN], T1[2][NN], T2[2][NN];
     __shared__ double vv[2][2][S2];
     __shared__ float Gsh[2][L][S2];     // chunk-table columns v_m, written out after the recursion (no global stores inside it)
@@ -255,6 +260,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             om = om < OM_MIN ? OM_MIN : om;
             const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
             sec[k][0] = sg; sec[k][1] = om; sec[k][2] = kap * om; sec[k][3] = g1; sec[k][4] = g2; sec[k][5] = b0; sec[k][6] = kap;
+            sec[k][7] = b1; sec[k][8] = b2;
             // (a section that is exactly the identity, e.g. a band at 0 dB, stays in normal form: there g1 = g2 = 0 and it is exact)
             const bool direct = disc < 0 && om >= DASP_DF_OM_MIN && !(b0 == 1.0 && b1 == a1 && b2 == a2);
             float* df = tb + LY::DF + k * 8;
@@ -269,11 +275,24 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             for (int c = 0; c < 5; ++c) d[DT_B0 + c] = c5[c];
             d[DT_A0] = a0; d[7] = kap;
             d[23] = 0.0;
+            d[DT_SG32] = (double)(float)sg; d[DT_NF] = direct ? 0.0 : 1.0; d[27] = 0.0;
         }
     }
     PTRACE(41, 0);
     __syncthreads();
     PTRACE(47, 0);
+    if (tid < S) {   // monic rows (sos_bwd_kernel, FAST): feed-through 1 per section, the inputs of section k scaled by q = 1 / prod_{j<k} b0_j
+        const int k = tid;
+        double pk = 1.0;
+        for (int m = 0; m < k; ++m) pk *= sec[m][5];
+        const double b0 = sec[k][5], om = sec[k][1], sg = sec[k][0];
+        const double ib0 = b0 != 0.0 ? 1.0 / b0 : 0.0, q = pk != 0.0 ? 1.0 / pk : 0.0;   // (a cascade with a zero b0 never takes the FAST kernels)
+        float* mn = tb + LY::MN + k * 8;
+        mn[0] = (float)(sec[k][7] * ib0); mn[1] = (float)(sec[k][8] * ib0);
+        mn[2] = (float)(sec[k][3] * ib0); mn[3] = (float)(sec[k][4] * ib0);
+        mn[4] = (float)q; mn[5] = (float)(q / om); mn[6] = (float)(q * sg / om); mn[7] = 0.f;
+        dt[k * DT_STRIDE + DT_PK] = pk;
+    }
 
     // Phi for the forward system (sys 0) and the adjoint system (sys 1: sections reversed, A^T, B<->C). Written without branches on
     // purpose: a kernel starts with a cold instruction cache, and in its divergent if / else form this loop's ~50 taken branches
@@ -811,7 +830,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 // control tensor of parametric_eq).
 template <bool COHERENT>   // COHERENT: the partial sums were written by other workgroups of the running kernel (device-scope loads)
 __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab, int tab_bcast, const float* partials,
-                                                 int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int item, int k) {
+                                                 int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int item, int k, int fast) {
     double acc[5] = {0, 0, 0, 0, 0};
     // the item's C * Wb rows of sums are contiguous; they are fetched eight rows (40 independent loads) at a time: one rolled loop with
     // a dependent add per load paid the L2 latency C * Wb times (5.4 us for this kernel, most of it waiting)
@@ -830,9 +849,36 @@ __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab
 #pragma unroll
             for (int i = 0; i < 5; ++i) acc[i] += r0 + j < R ? (double)v[j][i] : 0.0;
     }
-    const double* d = dtab + ((size_t)(tab_bcast ? 0 : item) * S + k) * DT_STRIDE;
+    const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
+    const double* d = d0 + k * DT_STRIDE;
+    // What the backward kernel summed (sos_bwd_kernel, `adjoint`): with K[n] the kept signal of the section (w[n - 2] itself for a
+    // direct-form section, om w[n - 2] for a normal-form one), g the section's adjoint input and o its adjoint output,
+    //   direct form:  [0] sum g K[n+2]   [1] sum g K[n+1]   [2] sum g K[n]   [3] sum o K[n+1]   [4] sum o K[n]
+    //   normal form:  [0] sum g D[n+1]   [1] sum g D[n]     [2] sum g K[n]   [3] sum o D[n]     [4] sum o K[n]     D[n] = K[n+1] - sg K[n]
+    // (near z = 1 the three lags of K are equal to five digits and the coefficient gradients are differences of their correlations;
+    // summed as they are, the fp32 rounding of the running sums is what is left of those differences. D is the small quantity itself.)
+    // FAST kernels leave [0] out and put T = sum (adjoint output of the last section) x (its input) there instead: for every section
+    // sum_i b_i (sum g w[n - i]) = <g, y> = T, because <adjoint input, output> is the same number at every section of a cascade.
+    const double sg = d[DT_SG32];
+    const bool nf = d[DT_NF] != 0.0;
+    double lag[5];      // sum g K[n+2], sum g K[n+1], sum g K[n], sum o K[n+1], sum o K[n]
+    lag[2] = acc[2];
+    lag[1] = nf ? acc[1] + sg * acc[2] : acc[1];
+    lag[4] = acc[4];
+    lag[3] = nf ? acc[3] + sg * acc[4] : acc[3];
+    if (fast) {
+        // the recomputed signals of section k are scaled by 1 / pk (pk = product of the b0 of the sections before it), T by 1 / pk of
+        // the last section:  b0 lag0 + b1 lag1 + b2 lag2 = T om' pk_last / pk   in the scaled units
+        const double pk = d[DT_PK], pk_last = d0[(S - 1) * DT_STRIDE + DT_PK];
+        const double rhs = acc[0] * d[DT_OM] * pk_last / pk;
+        lag[0] = (rhs - d[DT_B0 + 1] * lag[1] - d[DT_B0 + 2] * lag[2]) / d[DT_B0];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) lag[i] *= pk;
+    } else {
+        lag[0] = nf ? acc[0] + sg * lag[1] : acc[0];    // K[n+2] = D[n+1] + sg K[n+1]
+    }
     const double iom = 1.0 / d[DT_OM];
-    const double g5[5] = {acc[0] * iom, acc[1] * iom, acc[2] * iom, -acc[3] * iom, -acc[4] * iom};
+    const double g5[5] = {lag[0] * iom, lag[1] * iom, lag[2] * iom, -lag[3] * iom, -lag[4] * iom};
     const int idx = item * S + k;
     if (mode == 0) {
         const double a0 = d[DT_A0];
@@ -863,7 +909,21 @@ __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab
 // SEG as in the forward kernel (oracle/chunkscan_model.py backward_row_segmented): 2 = adjoint scan-only pre-pass from a zero adjoint
 // state, leaving the state below the segment in zseg[row][segment][2S]; 1 = the ordinary pass from segstart[row][segment][2S], the
 // adjoint state entering the segment from above; partial sums per (row, segment, wave).
-template <int S, int L, int W, int SEG = 0>
+// FLAGS: what the caller asked for and what the cascade is.
+//   BWD_FAST  the cascade comes from the RBJ design (every b0 > 0): the recomputation runs each section in monic form (feed-through 1, its
+//             signals scaled by 1 / product of the earlier b0: one operation per section-sample less), the last section computes no
+//             output, and the lag-0 correlation of every section is left out - the finalize step gets it from T = <adjoint output, input>
+//             of the last section (finalize_section). Executable specification of the arithmetic: scripts/bwd_fp32_model.py.
+//   BWD_NOGX  no gradient for x is wanted (the EQ is the first effect of the reference's chain: examples/style_transfer.py:150):
+//             the adjoint output is not transposed back and not stored.
+//   BWD_NOGC  no coefficient gradients (a fixed filter): no x, no saved states, no recomputation - the adjoint cascade only.
+// Sections kept in normal form (poles on or near the real axis) take their correlations with K[n] and D[n] = K[n+1] - sg K[n] instead
+// of the three nearly equal lags of K (finalize_section undoes it in fp64): at the low-frequency corner of the EQ's ranges the lag
+// correlations agree to five digits, the control gradients are their differences, and what the running fp32 sums rounded away was
+// most of them (measured 1.5e-4 .. 1e-3 of the gradient there before; 1e-5 .. 5e-5, the level of the fp32 signals themselves, after).
+constexpr int BWD_FAST = 1, BWD_NOGX = 2, BWD_NOGC = 4;
+
+template <int S, int L, int W, int SEG = 0, int FLAGS = 0>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
@@ -871,12 +931,15 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                float* __restrict__ cnt_tab, const double* __restrict__ dtab, int mode, float* __restrict__ gout, int B,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
     using LY = SosLayout<S, L>;
+    constexpr bool GC = SEG != 2 && !(FLAGS & BWD_NOGC), GX = SEG != 2 && !(FLAGS & BWD_NOGX), FAST = GC && (FLAGS & BWD_FAST);
+    constexpr int NACC = FAST ? 4 : 5;            // running correlation sums per section
+    constexpr int KEEP = FAST ? L + 1 : L + 2;    // kept samples of a section's signal per chunk
     // S <= 6: the s2 signals of all sections stay in registers (H = 0). S = 8: the lower half is parked in LDS (H = S / 2).
-    constexpr int S2 = 2 * S, TS = 64 * L, H = S > 6 ? S / 2 : 0, SH = S - H;   // SH >= H
-    constexpr int NSTASH4 = (H * (L + 2) + 3) / 4;                 // float4 per lane of parked s2 signals
+    constexpr int S2 = 2 * S, TS = 64 * L, H = (GC && S > 6) ? S / 2 : 0, SH = S - H;   // SH >= H
+    constexpr int NSTASH4 = (H * KEEP + 3) / 4;                 // float4 per lane of parked s2 signals
     // per wave: x landing image, gy landing image, gx staging image (unpadded, swizzled: common.hpp), saved chunk states, parked signals
     constexpr int IMG = 64 * L, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
-    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 24;   // COEF rows, DF rows, MN rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
@@ -911,17 +974,17 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 16 + i] = tb[LY::MN + i];
     __syncthreads();
     const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
     f2 Kreg[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
-    float accb[S][3], acca[S][2];
+    float acc[S][NACC], Tacc = 0.f;     // FAST: sum g K1, sum g K0, sum o K1, sum o K0 (K1 = D for a normal-form section); else lag 0 first
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
-        accb[k][0] = accb[k][1] = accb[k][2] = 0.f;
-        acca[k][0] = acca[k][1] = 0.f;
-    }
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[k][i] = 0.f;
 
     // LDS-DMA prefetch of the next tile (x, gy and the saved chunk states): issued as soon as this tile's images have been read into
     // registers, i.e. a whole tile time before it is needed, with no staging registers (the register-staged prefetch this replaces
@@ -930,11 +993,13 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
                    a_s = __builtin_amdgcn_readfirstlane(lds_addr(tst));
     auto issue_dma = [&](int tt) {
-        tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
+        if (GC) tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
         tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
-        const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
+        if (GC) {
+            const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
 #pragma unroll
-        for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
+            for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
+        }
     };
     if (wave < nr && tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec)) issue_dma(t1 - 1 - wave);
     int stores_in_flight = 0;
@@ -952,32 +1017,36 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         WIDE_PRIO(DASP_SCAN_PRIO);
         TRACE(16);
         if (full) {
-            if (stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
+            if (GX && stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
+            if (GC) tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
             tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
         }
         // Lane l works on chunk 63 - l for the whole tile: the adjoint scan runs from the last chunk to the first, and with the
         // chunks dealt out in that order it is an ordinary ascending lane scan - no lane mirroring (ds_bpermute) of its inputs and
         // outputs. Everything else in this kernel is per chunk and does not care which lane owns which.
         const int cl = 63 - lane;
-        lds_to_chunks_swz<L>(tbx, X, cl);
+        if (GC) lds_to_chunks_swz<L>(tbx, X, cl);
         lds_to_chunks_swz<L>(tbg, GY, cl);
         f4 Bop[4], zacc[4];
         chunk_products_load(tbg, Bop, lane);
-        pin(X); pin(GY); pin(Bop); TRACE(17);
+        if (GC) pin(X);
+        pin(GY); pin(Bop); TRACE(17);
         // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
         //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
         f2 st[S];
+        if (GC) {
 #pragma unroll
-        for (int m = 0; m < S / 2; ++m) {   // [section pair][chunk] f4, as the forward kernel stored them
-            const f4 q = full ? *reinterpret_cast<const f4*>(tst + (m * 64 + cl) * 4)
-                              : (reinterpret_cast<const f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + cl)[m * 64];
-            st[2 * m] = f2{q.x, q.y};
-            st[2 * m + 1] = f2{q.z, q.w};
+            for (int m = 0; m < S / 2; ++m) {   // [section pair][chunk] f4, as the forward kernel stored them
+                const f4 q = full ? *reinterpret_cast<const f4*>(tst + (m * 64 + cl) * 4)
+                                  : (reinterpret_cast<const f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + cl)[m * 64];
+                st[2 * m] = f2{q.x, q.y};
+                st[2 * m + 1] = f2{q.z, q.w};
+            }
+            pin(st);
         }
-        pin(st); TRACE(18);
+        TRACE(18);
         if (r + W < nr) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full
         float Z[L];
         chunk_products_issue(Bop, Aop, zacc);
@@ -1011,45 +1080,81 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             stores_in_flight = 0;
             continue;
         }
-        pin(X); pin(GY); pin(st); pin(lam);   // scans done before the cascade passes start
+        if (GC) { pin(X); pin(st); }
+        pin(GY); pin(lam);   // scans done before the cascade passes start
         TRACE(19);
         __builtin_amdgcn_sched_barrier(0);
-        float S2v[SH][L + 2];
-        // forward section k over the chunk, in place over X, keeping s2_k[n], n = 0..L+1 in S2v[slot]
+        float S2v[GC ? SH : 1][KEEP];
+        // forward section k over the chunk, in place over X, keeping K_k[n] = s2_k[n] (normal form) or w_k[n - 2] (direct form) for
+        // n = 0..KEEP-1 in S2v[slot]. FAST: monic recomputation (see the kernel header); the last section computes no output, so X
+        // still holds that section's input afterwards (T is taken from it).
         auto forward_keep = [&](int k, int slot, int oz) {
             float s1 = st[k].x, s2 = st[k].y;
+            const bool last = FAST && k == S - 1;
             if ((direct >> k) & 1) {   // wave-uniform. Direct form II from the exact chunk start state; the kept signal is w[n - 2] itself
                                        // (s2 = om w: the finalize kernel's 1 / om is 1 for these sections)
-                const float d = cf_lds[k * 8 + 5 + oz];                                         // b0
                 const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
-                const f2 cw = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 6 + oz);   // 1 / om, sg / om
-                float w2 = cw.x * s2, w1 = fmaf(cw.y, s2, s1);
+                if (FAST) {
+                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + oz);       // b1 / b0, b2 / b0
+                    const f4 cq = *reinterpret_cast<const f4*>(cf_lds + S * 16 + k * 8 + 4 + oz);   // q, q / om, q sg / om
+                    float w2 = cq.y * s2, w1 = fmaf(cq.z, s2, cq.x * s1);
 #pragma unroll
-                for (int n = 0; n < L; ++n) {
-                    const float u = X[n];
-                    S2v[slot][n] = w2;
-                    const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
-                    X[n] = fmaf(d, w, fmaf(cd.x, w1, cd.y * w2));
-                    w2 = w1;
-                    w1 = w;
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        S2v[slot][n] = w2;
+                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
+                        if (!last) X[n] = fmaf(cm.x, w1, fmaf(cm.y, w2, w));
+                        w2 = w1;
+                        w1 = w;
+                    }
+                    S2v[slot][L] = w2;
+                } else {
+                    const float d = cf_lds[k * 8 + 5 + oz];                                         // b0
+                    const f2 cw = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 6 + oz);   // 1 / om, sg / om
+                    float w2 = cw.x * s2, w1 = fmaf(cw.y, s2, s1);
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        S2v[slot][n] = w2;
+                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
+                        X[n] = fmaf(d, w, fmaf(cd.x, w1, cd.y * w2));
+                        w2 = w1;
+                        w1 = w;
+                    }
+                    S2v[slot][L] = w2;
+                    S2v[slot][KEEP - 1] = w1;
                 }
-                S2v[slot][L] = w2;
-                S2v[slot][L + 1] = w1;
             } else {
                 const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
-                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
                 const float nk = -ca.z;
+                if (FAST) {
+                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + 2 + oz);   // g1 / d, g2 / d
+                    const float q = cf_lds[S * 16 + k * 8 + 4 + oz];
+                    s1 *= q; s2 *= q;
 #pragma unroll
-                for (int n = 0; n < L; ++n) {
-                    const float u = X[n];
-                    S2v[slot][n] = s2;
-                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                    const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                    s2 = fmaf(ca.y, s1, ca.x * s2);
-                    s1 = t1;
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        S2v[slot][n] = s2;
+                        if (!last) X[n] = fmaf(cm.x, s1, fmaf(cm.y, s2, u));
+                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                        s2 = fmaf(ca.y, s1, ca.x * s2);
+                        s1 = t1;
+                    }
+                    S2v[slot][L] = s2;
+                } else {
+                    const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        S2v[slot][n] = s2;
+                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                        s2 = fmaf(ca.y, s1, ca.x * s2);
+                        s1 = t1;
+                    }
+                    S2v[slot][L] = s2;
+                    S2v[slot][KEEP - 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
                 }
-                S2v[slot][L] = s2;
-                S2v[slot][L + 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
             }
         };
         // adjoint section k (descending time) + coefficient correlations, in place over GY. The section itself runs in transposed
@@ -1062,93 +1167,144 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             const float d = cf_lds[k * 8 + 5 + oz];                                     // b0
             const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);   // b1, b2, -a1, -a2
             float z1 = lam[i].x, z2 = fmaf(ca.y, lam[i].y, -ca.x * lam[i].x);
-            float b0 = accb[k][0], b1 = accb[k][1], b2 = accb[k][2], a1 = acca[k][0], a2 = acca[k][1];
+            if (!GC) {
 #pragma unroll
-            for (int n = L - 1; n >= 0; --n) {
-                const float g = GY[n];
-                b0 = fmaf(g, S2v[slot][n + 2], b0);
-                b1 = fmaf(g, S2v[slot][n + 1], b1);
-                b2 = fmaf(g, S2v[slot][n], b2);
-                const float o = fmaf(d, g, z1);
-                z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
-                z2 = fmaf(cd.y, g, cd.w * o);
-                a1 = fmaf(o, S2v[slot][n + 1], a1);
-                a2 = fmaf(o, S2v[slot][n], a2);
-                GY[n] = o;
+                for (int n = L - 1; n >= 0; --n) {
+                    const float g = GY[n];
+                    const float o = fmaf(d, g, z1);
+                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                    z2 = fmaf(cd.y, g, cd.w * o);
+                    GY[n] = o;
+                }
+                return;
+            }
+            float c[NACC];
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) c[j] = acc[k][j];
+            if ((direct >> k) & 1) {        // the three lags of w as they are
+#pragma unroll
+                for (int n = L - 1; n >= 0; --n) {
+                    const float g = GY[n];
+                    if (!FAST) c[0] = fmaf(g, S2v[slot][KEEP - 1 - (L - 1 - n)], c[0]);      // K[n + 2]
+                    c[NACC - 4] = fmaf(g, S2v[slot][n + 1], c[NACC - 4]);
+                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
+                    const float o = fmaf(d, g, z1);
+                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                    z2 = fmaf(cd.y, g, cd.w * o);
+                    c[NACC - 2] = fmaf(o, S2v[slot][n + 1], c[NACC - 2]);
+                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
+                    GY[n] = o;
+                }
+            } else {                        // K[n] and D[n] = K[n+1] - sg K[n] (finalize_section undoes it in fp64)
+                const float nsg = -ca.x;
+#pragma unroll
+                for (int n = L - 1; n >= 0; --n) {
+                    const float g = GY[n];
+                    const float dlo = fmaf(nsg, S2v[slot][n], S2v[slot][n + 1]);              // D[n]
+                    // (D[n + 1] is computed again rather than carried from the previous step: the carried copy was the register
+                    // that made this variant spill)
+                    if (!FAST) c[0] = fmaf(g, fmaf(nsg, S2v[slot][n + 1], S2v[slot][KEEP - 1 - (L - 1 - n)]), c[0]);
+                    c[NACC - 4] = fmaf(g, dlo, c[NACC - 4]);
+                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
+                    const float o = fmaf(d, g, z1);
+                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                    z2 = fmaf(cd.y, g, cd.w * o);
+                    c[NACC - 2] = fmaf(o, dlo, c[NACC - 2]);
+                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
+                    GY[n] = o;
+                }
             }
             // pinned: otherwise the compiler defers these updates to the end of the tile and keeps all
-            // 5*S per-tile sums live next to the 5*S running sums
-            pin(b0); pin(b1); pin(b2); pin(a1); pin(a2);
-            accb[k][0] = b0; accb[k][1] = b1; accb[k][2] = b2; acca[k][0] = a1; acca[k][1] = a2;
+            // the per-tile sums live next to the running sums
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) { pin(c[j]); acc[k][j] = c[j]; }
+            if (FAST && k == S - 1) {       // T = <adjoint output of the last section, its (scaled) input>: X was left untouched by forward_keep
+                float tt = Tacc;
+#pragma unroll
+                for (int n = 0; n < L; ++n) tt = fmaf(X[n], GY[n], tt);
+                pin(tt);
+                Tacc = tt;
+            }
         };
         // coefficient loads addressed with an opaque zero land in VGPRs (full-rate VALU operands) and cannot be
         // hoisted out of the tile loop
-        {   // lower half forward, s2 signals parked in LDS ([j][lane] float4: conflict-free 1 KiB wave accesses)
-            const int oz = opaque_zero();
+        if (GC) {
+            {   // lower half forward, s2 signals parked in LDS ([j][lane] float4: conflict-free 1 KiB wave accesses)
+                const int oz = opaque_zero();
 #pragma unroll
-            for (int k = 0; k < H; ++k) forward_keep(k, k, oz);
-            wave_lds_sync();
-            f4* stash = reinterpret_cast<f4*>(tpk) + lane;
+                for (int k = 0; k < H; ++k) forward_keep(k, k, oz);
+                if (H > 0) {
+                    wave_lds_sync();
+                    f4* stash = reinterpret_cast<f4*>(tpk) + lane;
 #pragma unroll
-            for (int j = 0; j < NSTASH4; ++j) {
-                f4 v;
+                    for (int j = 0; j < NSTASH4; ++j) {
+                        f4 v;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int e = 4 * j + c;
-                    v[c] = e < H * (L + 2) ? S2v[e / (L + 2)][e % (L + 2)] : 0.f;
-                }
-                stash[j * 64] = v;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {   // upper half (all sections when H = 0): forward keeping its s2 signals in registers, then its adjoint. Every section's
-            // coefficient load is chained behind the previous section's result: left free, the scheduler issues all of them up
-            // front and the S coefficient sets (8 registers each) are live on top of the s2 signals.
-#pragma unroll
-            for (int k = H; k < S; ++k) forward_keep(k, k - H, opaque_zero_after(X[0]));
-            pin(S2v); pin(GY);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = S - 1; k >= H; --k) adjoint(k, k - H, opaque_zero_after(GY[0]));
-        }
-        pin(GY);
-        __builtin_amdgcn_sched_barrier(0);
-        {   // lower half adjoint with the parked signals (chained behind the upper half so that the two sets of
-            // s2 registers are not live at once)
-            const int oz = opaque_zero_after(GY[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            const f4* stash = reinterpret_cast<const f4*>(tpk + oz) + lane;
-#pragma unroll
-            for (int j = 0; j < NSTASH4; ++j) {
-                const f4 v = stash[j * 64];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int e = 4 * j + c;
-                    if (e < H * (L + 2)) S2v[e / (L + 2)][e % (L + 2)] = v[c];
+                        for (int c = 0; c < 4; ++c) {
+                            const int e = 4 * j + c;
+                            v[c] = e < H * KEEP ? S2v[e / KEEP][e % KEEP] : 0.f;
+                        }
+                        stash[j * 64] = v;
+                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // upper half (all sections when H = 0): forward keeping its s2 signals in registers, then its adjoint. Every section's
+                // coefficient load is chained behind the previous section's result: left free, the scheduler issues all of them up
+                // front and the S coefficient sets (8 registers each) are live on top of the s2 signals.
 #pragma unroll
-            for (int k = H - 1; k >= 0; --k) adjoint(k, k, oz);
+                for (int k = H; k < S; ++k) forward_keep(k, k - H, opaque_zero_after(X[0]));
+                pin(S2v); pin(GY);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = S - 1; k >= H; --k) adjoint(k, k - H, opaque_zero_after(GY[0]));
+            }
+            pin(GY);
+            __builtin_amdgcn_sched_barrier(0);
+            if (H > 0) {   // lower half adjoint with the parked signals (chained behind the upper half so that the two sets of
+                // s2 registers are not live at once)
+                const int oz = opaque_zero_after(GY[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f4* stash = reinterpret_cast<const f4*>(tpk + oz) + lane;
+#pragma unroll
+                for (int j = 0; j < NSTASH4; ++j) {
+                    const f4 v = stash[j * 64];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int e = 4 * j + c;
+                        if (e < H * KEEP) S2v[e / KEEP][e % KEEP] = v[c];
+                    }
+                }
+#pragma unroll
+                for (int k = H - 1; k >= 0; --k) adjoint(k, k, oz);
+            }
+        } else {
+#pragma unroll
+            for (int k = S - 1; k >= 0; --k) adjoint(k, 0, opaque_zero_after(GY[0]));
         }
         pin(GY);
         TRACE(23);
         WIDE_PRIO(DASP_SCAN_PRIO);
         __builtin_amdgcn_sched_barrier(0);
-        chunks_to_lds_swz<L>(tbo, GY, cl);
-        if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
-        else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
-        stores_in_flight = full ? L / 4 : 0;
+        if (GX) {
+            chunks_to_lds_swz<L>(tbo, GY, cl);
+            if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
+            else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+            stores_in_flight = full ? L / 4 : 0;
+        }
         TRACE(24);
     }
     // per-wave partial sums -> partials[row][wave][S][5]
-    if (SEG == 2) return;
+    if (!GC) return;
     float* po = partials + ((SEG ? (size_t)row * G + seg : (size_t)row) * W + wave) * S * 5;
+    const float vT = FAST ? wave_sum(Tacc) : 0.f;
 #pragma unroll
     for (int k = 0; k < S; ++k) {
-        const float v0 = wave_sum(accb[k][0]), v1 = wave_sum(accb[k][1]), v2 = wave_sum(accb[k][2]);
-        const float v3 = wave_sum(acca[k][0]), v4 = wave_sum(acca[k][1]);
+        float v[5];
+        v[0] = FAST ? vT : wave_sum(acc[k][0]);
+#pragma unroll
+        for (int i = 1; i < 5; ++i) v[i] = wave_sum(acc[k][NACC - 5 + i]);
         if (lane == 0) {
-            const float v[5] = {v0, v1, v2, v3, v4};
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 if (cnt_tab) __hip_atomic_store(po + k * 5 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1174,7 +1330,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             if (last_row) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the table can serve another backward pass
         }
         __syncthreads();
-        if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x);
+        if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x, FAST ? 1 : 0);
     }
 }
 
@@ -1269,10 +1425,10 @@ sos_chain_kernel(const double* __restrict__ segtab, int tab_bcast, int C, const 
 // Stand-alone finalize (one thread per (item, section)): used when the table is shared by all items (tab_bcast) or when the caller
 // asks for the two steps separately; otherwise the backward kernel finalizes an item as soon as its last row is done.
 __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
-                                    int B, int C, int S, int Wb, int mode, float* __restrict__ gout) {
+                                    int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int fast) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * S) return;
-    finalize_section<false>(dtab, tab_bcast, partials, B, C, S, Wb, mode, gout, idx / S, idx % S);
+    finalize_section<false>(dtab, tab_bcast, partials, B, C, S, Wb, mode, gout, idx / S, idx % S, fast);
 }
 
 }  // namespace dasp
@@ -1306,6 +1462,27 @@ int dispatch_S(int S, F&& f) {
         case 6: return f(std::integral_constant<int, 6>{});
         case 8: return f(std::integral_constant<int, 8>{});
         default: return DASP_ERR_UNSUPPORTED;
+    }
+}
+
+// kernel flags of a backward call: `designed` = the tables come from dasp_peq_prepare* (BWD_FAST is valid), gx == null -> BWD_NOGX,
+// partials == null -> BWD_NOGC; -1 = nothing to compute
+inline int bwd_flags(int designed, const void* gx, const void* partials) {
+    if (!gx && !partials) return -1;
+    if (!partials) return BWD_NOGC;
+    return (designed ? BWD_FAST : 0) | (gx ? 0 : BWD_NOGX);
+}
+
+// one launch of sos_bwd_kernel<S, kL, kWB, SEG, flags>
+template <int SS, int SEG, typename... A>
+void launch_bwd(int flags, int blocks, hipStream_t st, A... a) {
+    const dim3 g(blocks), b(64 * kWB);
+    switch (flags) {
+        case 0: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, 0>), g, b, 0, st, a...); break;
+        case BWD_FAST: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_FAST>), g, b, 0, st, a...); break;
+        case BWD_NOGX: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_NOGX>), g, b, 0, st, a...); break;
+        case BWD_FAST | BWD_NOGX: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_FAST | BWD_NOGX>), g, b, 0, st, a...); break;
+        default: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_NOGC>), g, b, 0, st, a...); break;
     }
 }
 }  // namespace
@@ -1395,31 +1572,45 @@ int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, flo
     });
 }
 
-int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
-                          float* partials, int B, int C, long N, int S, void* stream) {
-    if (!tab || !x || !gy || !carries || !gx || !partials || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B))
-        return DASP_ERR_ARG;
+// gx == null: no input gradient (BWD_NOGX); partials == null: no coefficient gradients (BWD_NOGC; x and carries are not read);
+// designed != 0: tab was filled by dasp_peq_prepare / dasp_peq_prepare_rows (the monic / identity kernel; finalize with the same flag)
+int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
+                             float* partials, int B, int C, long N, int S, int designed, void* stream) {
+    const int flags = bwd_flags(designed, gx, partials);
+    if (!tab || !gy || flags < 0 || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B)) return DASP_ERR_ARG;
+    if (!(flags & BWD_NOGC) && (!x || !carries)) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_sos_num_tiles(N);
-    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
+    const int vec = (N % 4 == 0) && aligned16(gy) && (!x || aligned16(x)) && (!gx || aligned16(gx));
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
-        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB>), dim3(B * C), dim3(64 * kWB), 0, (hipStream_t)stream, tab,
-                           Bs == 1 && B != 1, x, gy, carries, gx, partials, C, (int)N, nt, vec,
-                           (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B);
+        launch_bwd<SS, 0>(flags, B * C, (hipStream_t)stream, tab, Bs == 1 && B != 1, x, gy, carries, gx, partials, C, (int)N, nt, vec,
+                          (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, 1, 0, (const float*)nullptr, (float*)nullptr);
         return check_launch();
     });
 }
 
-// mode 0: gout (B,S,6) = dL/dsos ; mode 1: gout (B,S,3) = dL/d(gain_db, cutoff_freq, q_factor)
-int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S, int mode,
-                           float* gout, void* stream) {
-    if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2)
+int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
+                          float* partials, int B, int C, long N, int S, void* stream) {
+    if (!x || !carries || !gx || !partials) return DASP_ERR_ARG;
+    return dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, 0, stream);
+}
+
+// mode 0: gout (B,S,6) = dL/dsos ; mode 1: gout (B,S,3) = dL/d(gain_db, cutoff_freq, q_factor); mode 2: the same as (3S, B) rows.
+// segments: rows of partial sums per (row, wave) as written by the *_seg entry points (1 for the plain ones).
+int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
+                              int designed, float* gout, void* stream) {
+    if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
         return DASP_ERR_ARG;
     const int n = B * S;
     hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
-                       Bs == 1 && B != 1, partials, B, C, S, kWB, mode, gout);
+                       Bs == 1 && B != 1, partials, B, C, S, kWB * segments, mode, gout, designed ? 1 : 0);
     return check_launch();
+}
+
+int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S, int mode,
+                           float* gout, void* stream) {
+    return dasp_sos_grad_finalize_ex(dtab, Bs, partials, B, C, S, 1, mode, 0, gout, stream);
 }
 
 // dasp_sosfilt_backward followed by dasp_sos_grad_finalize (same mode / gout) as one call. Built with -DDASP_FUSED_FINALIZE=1 and
@@ -1430,24 +1621,32 @@ int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, in
 #ifndef DASP_FUSED_FINALIZE
 #define DASP_FUSED_FINALIZE 0
 #endif
-int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
-                                float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, void* stream) {
-    if (!tab || !dtab || !x || !gy || !carries || !gx || !partials || !gout || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) ||
-        mode < 0 || mode > 2)
-        return DASP_ERR_ARG;
+int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
+                                   float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, int designed,
+                                   void* stream) {
+    const int flags = bwd_flags(designed, gx, partials);
+    if (!tab || !gy || flags < 0 || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2) return DASP_ERR_ARG;
+    if (!(flags & BWD_NOGC) && (!dtab || !x || !carries || !gout)) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
-    if (!DASP_FUSED_FINALIZE || (Bs == 1 && B != 1)) {
-        const int rc = dasp_sosfilt_backward(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, stream);
-        return rc != DASP_OK ? rc : dasp_sos_grad_finalize(dtab, Bs, partials, B, C, S, mode, gout, stream);
+    if (!DASP_FUSED_FINALIZE || (flags & BWD_NOGC) || (Bs == 1 && B != 1)) {
+        const int rc = dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, designed, stream);
+        if (rc != DASP_OK || (flags & BWD_NOGC)) return rc;
+        return dasp_sos_grad_finalize_ex(dtab, Bs, partials, B, C, S, 1, mode, designed, gout, stream);
     }
     const int nt = (int)dasp_sos_num_tiles(N);
-    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
+    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && (!gx || aligned16(gx));
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
-        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB>), dim3(B * C), dim3(64 * kWB), 0, (hipStream_t)stream, tab, 0, x, gy, carries,
-                           gx, partials, C, (int)N, nt, vec, tab, dtab, mode, gout, B);
+        launch_bwd<SS, 0>(flags, B * C, (hipStream_t)stream, (const float*)tab, 0, x, gy, carries, gx, partials, C, (int)N, nt, vec, tab, dtab,
+                          mode, gout, B, 1, 0, (const float*)nullptr, (float*)nullptr);
         return check_launch();
     });
+}
+
+int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
+                                float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, void* stream) {
+    if (!gx || !partials) return DASP_ERR_ARG;
+    return dasp_sosfilt_backward_grads_ex(tab, dtab, Bs, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 0, stream);
 }
 
 // ---- segmented rows -------------------------------------------------------------------------------------------------------------
@@ -1497,14 +1696,16 @@ int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, con
     });
 }
 
-int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
-                              float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, void* stream) {
-    if (!tab || !segtab || !x || !gy || !carries || !gx || !partials || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) ||
-        Tseg <= 0)
-        return DASP_ERR_ARG;
+// gx / partials / designed as in dasp_sosfilt_backward_ex
+int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
+                                 float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
+                                 void* stream) {
+    const int flags = bwd_flags(designed, gx, partials);
+    if (!tab || !segtab || !gy || flags < 0 || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0) return DASP_ERR_ARG;
+    if (!(flags & BWD_NOGC) && (!x || !carries)) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_sos_num_tiles(N), G = (int)dasp_sos_segments(N, Tseg), bc = Bs == 1 && B != 1;
-    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
+    const int vec = (N % 4 == 0) && aligned16(gy) && (!x || aligned16(x)) && (!gx || aligned16(gx));
     float* z = segbuf;
     float* start = segbuf + (size_t)B * C * G * 2 * S;
     return dispatch_S(S, [&](auto s) {
@@ -1514,23 +1715,47 @@ int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, co
                            (float*)nullptr, C, (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg,
                            (const float*)nullptr, z);
         hipLaunchKernelGGL((sos_chain_kernel<SS>), dim3(B * C), dim3(64), 0, st, segtab, bc, C, (const float*)z, start, G, 1);
-        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 1>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, gx, partials, C,
-                           (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg, (const float*)start,
-                           (float*)nullptr);
+        launch_bwd<SS, 1>(flags, B * C * G, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec, (float*)nullptr,
+                          (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg, (const float*)start, (float*)nullptr);
         return check_launch();
     });
+}
+
+int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
+                              float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, void* stream) {
+    if (!x || !carries || !gx || !partials) return DASP_ERR_ARG;
+    return dasp_sosfilt_backward_seg_ex(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 0, stream);
 }
 
 // dasp_sos_grad_finalize for partial sums produced by dasp_sosfilt_backward_seg with `segments` segments per row
 int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
                                float* gout, void* stream) {
-    if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
-        return DASP_ERR_ARG;
-    const int n = B * S;
-    hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab, Bs == 1 && B != 1, partials, B, C, S,
-                       kWB * segments, mode, gout);
-    return check_launch();
+    return dasp_sos_grad_finalize_ex(dtab, Bs, partials, B, C, S, segments, mode, 0, gout, stream);
 }
 
+// ---- one call per direction for functional.parametric_eq (functional.py:118-272) ------------------------------------------------------
+// Forward: RBJ design from the 3 S control vectors (dasp_peq_prepare_rows) + the cascade. Tseg > 0 takes the segmented-row path
+// (segtab / segbuf as for dasp_sosfilt_forward_seg; Tseg = dasp_sos_segment_tiles(B * C, N) or 0).
+int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, double sample_rate, float* tab, double* dtab,
+                     const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
+                     void* stream) {
+    int rc = dasp_peq_prepare_rows(rows, Bp, S, types, sample_rate, tab, dtab, stream);
+    if (rc != DASP_OK) return rc;
+    if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
+    rc = dasp_sos_segment_prepare(dtab, Bp, S, Tseg, segtab, stream);
+    return rc != DASP_OK ? rc : dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+}
+
+// Backward of the same call: adjoint cascade + control gradients (mode as in dasp_sos_grad_finalize), the tables being the ones
+// dasp_peq_forward filled (designed cascade: the monic / identity kernel). gx == null: no input gradient; partials == null: none for
+// the controls. Tseg / segtab / segbuf as in the forward call (partials then hold dasp_sos_partial_floats(rows * segments, S) floats).
+int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, const float* gy, const float* carries, float* gx,
+                      float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
+                      float* segbuf, void* stream) {
+    if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 1, stream);
+    const int rc = dasp_sosfilt_backward_seg_ex(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, stream);
+    if (rc != DASP_OK || !partials) return rc;
+    return dasp_sos_grad_finalize_ex(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, 1, gout, stream);
+}
 
 }  // extern "C"

@@ -1,7 +1,5 @@
 """Drop-in for dasp_pytorch.functional on MI355X: same names, argument order and keyword names
 (dasp_pytorch/functional.py), every effect computed by hand-written HIP kernels (csrc/)."""
-import functools
-
 import torch
 
 from . import signal as _signal
@@ -160,11 +158,23 @@ def expander(
     return _dynamics(1, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples)
 
 
-@functools.lru_cache(maxsize=8)
+_FB_CACHE = {}
+
+
 def _device_filterbank(num_taps: int, sample_rate: float, device: torch.device):
     """One device-resident copy of the octave filterbank per (taps, sample_rate, device): the taps are constants, so the
-    host->device copy and their spectra (ops._filter_spectrum) are paid once, not per call."""
-    return _signal.octave_band_filterbank(num_taps, sample_rate).squeeze(1).to(device).contiguous()
+    host->device copy and their spectra (ops._filter_spectrum) are paid once, not per call. Not kept when first asked for inside a
+    HIP-graph capture (that memory belongs to the graph being captured)."""
+    key = (num_taps, sample_rate, device)
+    hit = _FB_CACHE.get(key)
+    if hit is not None:
+        return hit
+    bank = _signal.octave_band_filterbank(num_taps, sample_rate).squeeze(1).to(device).contiguous()
+    if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        if len(_FB_CACHE) >= 8:
+            _FB_CACHE.clear()
+        _FB_CACHE[key] = bank
+    return bank
 
 
 def noise_shaped_reverberation(

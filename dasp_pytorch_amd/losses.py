@@ -5,6 +5,7 @@ mean over the resolutions. Only `input` receives a gradient (the target is the r
 import ctypes
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import call, ptr, stream
@@ -15,6 +16,9 @@ class _MRSTFTFunction(torch.autograd.Function):
     def forward(ctx, inp, target, res, eps):
         _lib.require_device(inp, "input")
         _lib.require_device(target, "target")
+        _lib.require_same_device(inp, target=target)
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("MultiResolutionSTFTLoss: only `input` is differentiable (the target is the reference signal); detach the target")
         if inp.shape != target.shape:
             raise RuntimeError(f"input {tuple(inp.shape)} and target {tuple(target.shape)} must have the same shape")
         L = _lib.lib()
@@ -28,22 +32,25 @@ class _MRSTFTFunction(torch.autograd.Function):
         if nfl < 0:
             raise _lib.DaspHipError("unsupported STFT resolutions (fft a power of two in 8..4096, win <= fft, fft / 2 < seq_len, <= 8 of them)")
         dev = inp.device
-        tw = _twiddles(dev)
-        partials = torch.empty(nfl, dtype=torch.float32, device=dev)
-        stats = torch.empty(4 * nres, dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        call("dasp_mrstft_forward", ptr(p32), ptr(t32), ptr(tw), ptr(partials), ptr(stats), ptr(loss), rows, N, nres, *arr, float(eps), stream())
-        ctx.save_for_backward(p32, t32, stats)
+        with torch.cuda.device(dev):
+            tw = _twiddles(dev)
+            partials = torch.empty(nfl, dtype=torch.float32, device=dev)
+            stats = torch.empty(4 * nres, dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            call("dasp_mrstft_forward", ptr(p32), ptr(t32), ptr(tw), ptr(partials), ptr(stats), ptr(loss), rows, N, nres, *arr, float(eps), stream())
+        ctx.save_for_backward(p32, t32, stats, tw)
         ctx.cfg = (rows, N, nres, arr, float(eps), inp.shape, inp.dtype)
         return loss.to(inp.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gloss):
-        p32, t32, stats = ctx.saved_tensors
+        p32, t32, stats, tw = ctx.saved_tensors
         rows, N, nres, arr, eps, shape, dtype = ctx.cfg
-        g = torch.empty_like(p32)
-        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
-        call("dasp_mrstft_backward", ptr(p32), ptr(t32), ptr(_twiddles(p32.device)), ptr(stats), ptr(gl), ptr(g), rows, N, nres, *arr, eps, stream())
+        with torch.cuda.device(p32.device):
+            g = torch.empty_like(p32)
+            gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+            call("dasp_mrstft_backward", ptr(p32), ptr(t32), ptr(tw), ptr(stats), ptr(gl), ptr(g), rows, N, nres, *arr, eps, stream())
         return g.reshape(shape).to(dtype), None, None, None
 
 
@@ -51,12 +58,20 @@ _TW = {}
 
 
 def _twiddles(device):
-    key = (device.type, device.index)
-    if key not in _TW:
-        tw = torch.empty(2 * 4096, dtype=torch.float32, device=device)
-        call("dasp_mrstft_table", ptr(tw), stream())
+    """The 4096-entry twiddle table, one per (device, stream). Inside a HIP-graph capture the table is built fresh and not kept: memory
+    allocated while capturing belongs to that graph's pool, and its fill kernel only runs on replay (the same rule as
+    ops._filter_spectrum). Keyed by stream as well: the fill is ordered only against work on the stream it was launched on."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    if not capturing and key in _TW:
+        return _TW[key]
+    tw = torch.empty(2 * 4096, dtype=torch.float32, device=device)
+    call("dasp_mrstft_table", ptr(tw), stream())
+    if not capturing:
+        if len(_TW) >= 16:
+            _TW.clear()
         _TW[key] = tw
-    return _TW[key]
+    return tw
 
 
 class MultiResolutionSTFTLoss(torch.nn.Module):

@@ -7,6 +7,7 @@ import ctypes
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import call, check, ptr, stream
@@ -28,65 +29,78 @@ def _pad_sections(S):
 
 def _segment_tiles(rows, N):
     """Tiles per segment for the segmented-row kernels, 0 = one workgroup per row (dasp_hip.h, "Few rows").
-    With few rows the segmented path takes 2-4x less GPU time (16 x 2 x 131072: forward 0.078 -> 0.032 ms, backward 0.177 -> 0.047 ms)
-    for four more kernel launches per call. It is used when the launches are free - inside a HIP-graph capture - or when asked for:
-    DASP_SOS_SEGMENT=1 (always), =0 (never); DASP_SOS_SEGMENT_TILES=<power of two> fixes the segment length."""
-    mode = os.environ.get("DASP_SOS_SEGMENT", "auto")
-    if mode == "0" or (mode == "auto" and not torch.cuda.is_current_stream_capturing()):
+    A row is one workgroup, so fewer than 128 rows (the reference's training batches are 8-32 items: examples/style_transfer.py:403,
+    auto_eq.py:231) leave most of the 256 CUs idle; the segmented path takes 2-4x less GPU time there (16 x 2 x 131072: forward
+    0.078 -> 0.032 ms, backward 0.177 -> 0.047 ms) for four more kernel launches per call, all issued by the same C call. It is taken
+    whenever the library's planner proposes a cut (rows < 128 and at least 16 tiles per row), eager or captured.
+    DASP_SOS_SEGMENT=0 never, DASP_SOS_SEGMENT_TILES=<power of two> fixes the segment length."""
+    if os.environ.get("DASP_SOS_SEGMENT", "auto") == "0":
         return 0
     fixed = os.environ.get("DASP_SOS_SEGMENT_TILES")
     return int(fixed) if fixed else int(_lib.lib().dasp_sos_segment_tiles(rows, N))
 
 
+def _round64(n):
+    return (int(n) + 63) & ~63
+
+
 class _SosWork:
-    """Device work buffers of one filter application (tables, carries, partial sums)."""
+    """Device work buffers of one filter application: one fp32 block (tables, saved chunk states, partial sums, segment scratch) and
+    one fp64 block (design side table, segment transition matrices) - two allocations per call instead of one per buffer."""
 
-    def __init__(self, Bs, S, device):
+    def __init__(self, Bs, S, x, need_grad):
         L = _lib.lib()
-        self.Bs, self.S = Bs, S
-        self.tab = torch.empty(Bs * L.dasp_sos_table_floats(S), dtype=torch.float32, device=device)
-        self.dtab = torch.empty(Bs * L.dasp_sos_dtab_doubles(S), dtype=torch.float64, device=device)
-        self.carries = None
-        self.tseg, self.segtab = 0, None
-
-    def _segbuf(self, x):
         B, C, N = x.shape
-        return torch.empty(_lib.lib().dasp_sos_seg_floats(B * C, N, self.S, self.tseg), dtype=torch.float32, device=x.device)
+        self.Bs, self.S = Bs, S
+        self.tseg = _segment_tiles(B * C, N)
+        self.G = int(L.dasp_sos_segments(N, self.tseg))
+        n_tab = _round64(Bs * L.dasp_sos_table_floats(S))
+        n_car = _round64(L.dasp_sos_carry_floats(B * C, N, S)) if need_grad else 0
+        n_par = _round64(L.dasp_sos_partial_floats(B * C * self.G, S)) if need_grad else 0
+        n_seg = _round64(L.dasp_sos_seg_floats(B * C, N, S, self.tseg)) if self.tseg else 0
+        f32 = torch.empty(n_tab + n_car + n_par + n_seg, dtype=torch.float32, device=x.device)
+        self.tab, self.carries = f32[:n_tab], (f32[n_tab:n_tab + n_car] if need_grad else None)
+        self.partials = f32[n_tab + n_car:n_tab + n_car + n_par] if need_grad else None
+        self.segbuf = f32[n_tab + n_car + n_par:] if self.tseg else None
+        n_dt = Bs * L.dasp_sos_dtab_doubles(S)
+        f64 = torch.empty(n_dt + (Bs * L.dasp_sos_segtab_doubles(S) if self.tseg else 0), dtype=torch.float64, device=x.device)
+        self.dtab, self.segtab = f64[:n_dt], (f64[n_dt:] if self.tseg else None)
 
-    def forward(self, x, need_grad):
-        L = _lib.lib()
+    def forward(self, x):
+        """Cascade from tables that are already filled (dasp_sos_prepare)."""
         B, C, N = x.shape
         y = torch.empty_like(x)
-        if need_grad:
-            self.carries = torch.empty(L.dasp_sos_carry_floats(B * C, N, self.S), dtype=torch.float32, device=x.device)
-        self.tseg = _segment_tiles(B * C, N)
         if self.tseg:
-            self.segtab = torch.empty(self.Bs * L.dasp_sos_segtab_doubles(self.S), dtype=torch.float64, device=x.device)
             call("dasp_sos_segment_prepare", ptr(self.dtab), self.Bs, self.S, self.tseg, ptr(self.segtab), stream())
-            call("dasp_sosfilt_forward_seg", ptr(self.tab), ptr(self.segtab), self.Bs, ptr(x), ptr(y), ptr(self.carries), ptr(self._segbuf(x)),
+            call("dasp_sosfilt_forward_seg", ptr(self.tab), ptr(self.segtab), self.Bs, ptr(x), ptr(y), ptr(self.carries), ptr(self.segbuf),
                  B, C, N, self.S, self.tseg, stream())
         else:
             call("dasp_sosfilt_forward", ptr(self.tab), self.Bs, ptr(x), ptr(y), ptr(self.carries), B, C, N, self.S, stream())
         return y
 
-    def backward(self, x, gy, mode):
-        L = _lib.lib()
+    def backward(self, x, gy, mode, designed, need_gx, need_gc):
+        """Adjoint cascade and coefficient / control gradients; (gx or None, gout or None)."""
         B, C, N = x.shape
-        gx = torch.empty_like(x)
-        shape = (B, self.S, 6) if mode == 0 else (B, self.S, 3) if mode == 1 else (3 * self.S, B)
-        gout = torch.empty(shape, dtype=torch.float32, device=x.device)
-        if self.tseg:
-            G = L.dasp_sos_segments(N, self.tseg)
-            partials = torch.empty(L.dasp_sos_partial_floats(B * C * G, self.S), dtype=torch.float32, device=x.device)
-            call("dasp_sosfilt_backward_seg", ptr(self.tab), ptr(self.segtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx),
-                 ptr(partials), ptr(self._segbuf(x)), B, C, N, self.S, self.tseg, stream())
-            call("dasp_sos_grad_finalize_seg", ptr(self.dtab), self.Bs, ptr(partials), B, C, self.S, G, mode, ptr(gout), stream())
+        gx = torch.empty_like(x) if need_gx else None
+        gout = None
+        if need_gc:
+            shape = (B, self.S, 6) if mode == 0 else (B, self.S, 3) if mode == 1 else (3 * self.S, B)
+            gout = torch.empty(shape, dtype=torch.float32, device=x.device)
+        part = self.partials if need_gc else None
+        if _lib.timers.enabled and not self.tseg:      # bench.py's per-kernel HIP events: the two launches as separate entry points
+            call("dasp_sosfilt_backward_ex", ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(part), B, C, N, self.S,
+                 designed, stream())
+            if need_gc:
+                call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, 1, mode, designed, ptr(gout), stream())
+        elif self.tseg:
+            call("dasp_sosfilt_backward_seg_ex", ptr(self.tab), ptr(self.segtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx),
+                 ptr(part), ptr(self.segbuf), B, C, N, self.S, self.tseg, designed, stream())
+            if need_gc:
+                call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, self.G, mode, designed, ptr(gout), stream())
         else:
-            partials = torch.empty(L.dasp_sos_partial_floats(B * C, self.S), dtype=torch.float32, device=x.device)
-            call("dasp_sosfilt_backward", ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(partials),
-                                          B, C, N, self.S, stream())
-            call("dasp_sos_grad_finalize", ptr(self.dtab), self.Bs, ptr(partials), B, C, self.S, mode, ptr(gout), stream())
-        if self.Bs == 1 and B != 1:
+            call("dasp_sosfilt_backward_grads_ex", ptr(self.tab), ptr(self.dtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx),
+                 ptr(part), mode, ptr(gout), B, C, N, self.S, designed, stream())
+        if need_gc and self.Bs == 1 and B != 1:
             gout = gout.sum(1 if mode == 2 else 0, keepdim=True)
         return gx, gout
 
@@ -98,38 +112,48 @@ class SosFiltFunction(torch.autograd.Function):
     def forward(ctx, sos, x):
         _lib.require_device(x, "x")
         _lib.require_device(sos, "sos")
-        L = _lib.lib()
+        _lib.require_same_device(x, sos=sos)
         Bs, S, _ = sos.shape
         Sp = _pad_sections(S)
-        sos32 = _f32c(sos)
-        if Sp != S:  # identity sections [1 0 0 1 0 0]
-            pad = torch.zeros(Bs, Sp - S, 6, dtype=torch.float32, device=sos.device)
-            pad[..., 0] = 1.0
-            pad[..., 3] = 1.0
-            sos32 = torch.cat([sos32, pad], 1).contiguous()
-        x32 = _f32c(x)
-        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        w = _SosWork(Bs, Sp, x.device)
-        call("dasp_sos_prepare", ptr(sos32), Bs, Sp, ptr(w.tab), ptr(w.dtab), stream())
-        y = w.forward(x32, need)
-        if need:
-            ctx.work, ctx.S = w, S
-            ctx.save_for_backward(x32)
         ctx.dtypes = (sos.dtype, x.dtype)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            ctx.shapes = (sos.shape, x.shape)
+            return torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            sos32 = _f32c(sos)
+            if Sp != S:  # identity sections [1 0 0 1 0 0]
+                pad = torch.zeros(Bs, Sp - S, 6, dtype=torch.float32, device=sos.device)
+                pad[..., 0] = 1.0
+                pad[..., 3] = 1.0
+                sos32 = torch.cat([sos32, pad], 1).contiguous()
+            x32 = _f32c(x)
+            need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+            w = _SosWork(Bs, Sp, x32, need)
+            call("dasp_sos_prepare", ptr(sos32), Bs, Sp, ptr(w.tab), ptr(w.dtab), stream())
+            y = w.forward(x32)
+            if need:
+                ctx.work, ctx.S = w, S
+                ctx.save_for_backward(x32)
         return y.to(x.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
+        if ctx.empty:
+            return torch.zeros(ctx.shapes[0], dtype=ctx.dtypes[0], device=gy.device), torch.empty(ctx.shapes[1], dtype=ctx.dtypes[1], device=gy.device)
         (x32,) = ctx.saved_tensors
-        gx, gsos = ctx.work.backward(x32, _f32c(gy), 0)
-        return gsos[:, :ctx.S].to(ctx.dtypes[0]), gx.to(ctx.dtypes[1])
+        with torch.cuda.device(x32.device):
+            gx, gsos = ctx.work.backward(x32, _f32c(gy), 0, 0, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        return (gsos[:, :ctx.S].to(ctx.dtypes[0]) if gsos is not None else None, gx.to(ctx.dtypes[1]) if gx is not None else None)
 
 
 class ParametricEQFunction(torch.autograd.Function):
     """Fused RBJ design (fp64, in-kernel) + cascade. `controls` are the 3*S per-item controls in the
     reference's argument order [gain_db, cutoff_freq, q_factor] per section, each with Bp elements.
     They enter as separate tensors and their gradients leave as contiguous rows of one (3S, Bp)
-    buffer, so autograd neither builds a stack node nor launches 3S copy kernels."""
+    buffer, so autograd neither builds a stack node nor launches 3S copy kernels. One C call per direction
+    (dasp_peq_forward / dasp_peq_backward); the backward kernel is the variant torch.autograd's needs_input_grad asks for."""
 
     @staticmethod
     def forward(ctx, x, sample_rate, types, *controls):
@@ -139,35 +163,52 @@ class ParametricEQFunction(torch.autograd.Function):
         if not L.dasp_sos_supported_sections(S):
             raise ValueError(f"no kernel compiled for {S} sections")
         dev = x.device
-        # the usual case - a 1-D contiguous fp32 tensor on x's device - is used as it is (grad mode is off in here): 18 controls
-        # through four no-op tensor calls each were a fifth of the host time of a step
-        cols = [c if (c.dtype is torch.float32 and c.dim() == 1 and c.device == dev and c.is_contiguous())
-                else c.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() for c in controls]
-        Bp = cols[0].numel()
-        if any(c.numel() != Bp for c in cols):
-            raise ValueError("parametric_eq controls must all have the same number of elements")
-        x32 = _f32c(x)
-        need = any(ctx.needs_input_grad)
-        w = _SosWork(Bp, S, x.device)
-        ctypes_types = (ctypes.c_int * S)(*types)
-        rows = (ctypes.c_void_p * (3 * S))(*[c.data_ptr() for c in cols])        # read by the design kernel in place: no packing copy
-        call("dasp_peq_prepare_rows", rows, Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream())
-        y = w.forward(x32, need)
-        if need:
-            ctx.work = w
-            ctx.save_for_backward(x32)
         ctx.x_dtype = x.dtype
         ctx.ctl = [(c.dtype, c.shape) for c in controls]
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(dev):
+            # the usual case - a 1-D contiguous fp32 tensor on x's device - is used as it is (grad mode is off in here): 18 controls
+            # through four no-op tensor calls each were a fifth of the host time of a step
+            cols = [c if (c.dtype is torch.float32 and c.dim() == 1 and c.device == dev and c.is_contiguous())
+                    else c.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous() for c in controls]
+            Bp = cols[0].numel()
+            if any(c.numel() != Bp for c in cols):
+                raise ValueError("parametric_eq controls must all have the same number of elements")
+            x32 = _f32c(x)
+            B, C, N = x32.shape
+            need = any(ctx.needs_input_grad)
+            w = _SosWork(Bp, S, x32, need)
+            ctypes_types = (ctypes.c_int * S)(*types)
+            rows = (ctypes.c_void_p * (3 * S))(*[c.data_ptr() for c in cols])        # read by the design kernel in place: no packing copy
+            if _lib.timers.enabled and not w.tseg:   # bench.py's per-kernel HIP events: design and cascade as separate entry points
+                call("dasp_peq_prepare_rows", rows, Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), stream())
+                y = w.forward(x32)
+            else:
+                y = torch.empty_like(x32)
+                call("dasp_peq_forward", rows, Bp, S, ctypes_types, float(sample_rate), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y),
+                     ptr(w.carries), B, C, N, w.tseg, ptr(w.segtab), ptr(w.segbuf), stream())
+            if need:
+                ctx.work = w
+                ctx.save_for_backward(x32)
         return y.to(x.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
+        if ctx.empty:
+            return (torch.empty_like(gy), None, None) + tuple(torch.zeros(shape, dtype=dt, device=gy.device) for dt, shape in ctx.ctl)
         (x32,) = ctx.saved_tensors
-        gx, gpt = ctx.work.backward(x32, _f32c(gy), 2)       # (3S, Bp): one contiguous gradient row per control tensor
-        rows = gpt.unbind(0)
-        gcols = tuple((rows[i] if (dt is torch.float32 and shape == rows[i].shape) else rows[i].reshape(shape).to(dt)) if need else None
-                      for i, ((dt, shape), need) in enumerate(zip(ctx.ctl, ctx.needs_input_grad[3:])))
-        return (gx.to(ctx.x_dtype) if ctx.needs_input_grad[0] else None, None, None) + gcols
+        need_gx, need_gc = ctx.needs_input_grad[0], any(ctx.needs_input_grad[3:])
+        with torch.cuda.device(x32.device):
+            gx, gpt = ctx.work.backward(x32, _f32c(gy), 2, 1, need_gx, need_gc)       # (3S, Bp): one contiguous gradient row per control tensor
+        gcols = (None,) * len(ctx.ctl)
+        if need_gc:
+            rows = gpt.unbind(0)
+            gcols = tuple((rows[i] if (dt is torch.float32 and shape == rows[i].shape) else rows[i].reshape(shape).to(dt)) if need else None
+                          for i, ((dt, shape), need) in enumerate(zip(ctx.ctl, ctx.needs_input_grad[3:])))
+        return (gx.to(ctx.x_dtype) if need_gx else None, None, None) + gcols
 
 
 class _ElementwiseFunction(torch.autograd.Function):
@@ -178,26 +219,32 @@ class _ElementwiseFunction(torch.autograd.Function):
     @classmethod
     def _run(cls, ctx, x, ctl):
         _lib.require_device(x, "x")
-        L = _lib.lib()
         B, C, N = x.shape
-        x32 = _f32c(x)
-        c32 = ctl.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
-        y = torch.empty_like(x32)
-        call(cls.FWD, ptr(x32), ptr(c32), ptr(y), B, C, N, stream())
-        ctx.save_for_backward(x32, c32)
         ctx.meta = (x.dtype, ctl.dtype, ctl.shape)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            x32 = _f32c(x)
+            c32 = ctl.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+            y = torch.empty_like(x32)
+            call(cls.FWD, ptr(x32), ptr(c32), ptr(y), B, C, N, stream())
+            ctx.save_for_backward(x32, c32)
         return y.to(x.dtype)
 
     @classmethod
     def _grad(cls, ctx, gy):
+        xd, cd, cshape = ctx.meta
+        if ctx.empty:
+            return torch.empty_like(gy), torch.zeros(cshape, dtype=cd, device=gy.device)
         L = _lib.lib()
         x32, c32 = ctx.saved_tensors
         B, C, N = x32.shape
-        gx = torch.empty_like(x32)
-        gctl = torch.empty_like(c32)
-        partials = torch.empty(L.dasp_ew_partial_floats(B * C, N), dtype=torch.float32, device=x32.device)
-        call(cls.BWD, ptr(x32), ptr(c32), ptr(_f32c(gy)), ptr(gx), ptr(gctl), ptr(partials), B, C, N, stream())
-        xd, cd, cshape = ctx.meta
+        with torch.cuda.device(x32.device):
+            gx = torch.empty_like(x32)
+            gctl = torch.empty_like(c32)
+            partials = torch.empty(L.dasp_ew_partial_floats(B * C, N), dtype=torch.float32, device=x32.device)
+            call(cls.BWD, ptr(x32), ptr(c32), ptr(_f32c(gy)), ptr(gx), ptr(gctl), ptr(partials), B, C, N, stream())
         return gx.to(xd), gctl.reshape(cshape).to(cd)
 
 
@@ -210,6 +257,7 @@ class GainFunction(_ElementwiseFunction):
         return GainFunction._run(ctx, x, gain_db)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         return GainFunction._grad(ctx, gy)
 
@@ -223,6 +271,7 @@ class DistortionFunction(_ElementwiseFunction):
         return DistortionFunction._run(ctx, x, drive_db)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         return DistortionFunction._grad(ctx, gy)
 
@@ -237,33 +286,41 @@ class DynamicsFunction(torch.autograd.Function):
         _lib.require_device(x, "x")
         L = _lib.lib()
         B, C, N = x.shape
-        ctls = (threshold_db, ratio, attack_ms, knee_db, makeup_gain_db)
-        ctl = torch.stack([c.detach().reshape(-1).to(device=x.device, dtype=torch.float32) for c in ctls], dim=1).contiguous()
-        x32 = _f32c(x)
-        y = torch.empty_like(x32)
-        need = any(ctx.needs_input_grad)
-        carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
-        lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
-        call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
-             float(eps), int(lookahead), stream())
-        if need:
-            ctx.save_for_backward(x32, ctl, carries, lin if lin is not None else torch.empty(0, device=x.device))
-            ctx.cfg = (mode, float(sample_rate), float(eps), int(lookahead))
-            ctx.meta = (x.dtype, [(c.dtype, c.shape) for c in (threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db)])
+        ctx.meta = (x.dtype, [(c.dtype, c.shape) for c in (threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db)])
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            ctls = (threshold_db, ratio, attack_ms, knee_db, makeup_gain_db)
+            ctl = torch.stack([c.detach().reshape(-1).to(device=x.device, dtype=torch.float32) for c in ctls], dim=1).contiguous()
+            x32 = _f32c(x)
+            y = torch.empty_like(x32)
+            need = any(ctx.needs_input_grad)
+            carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
+            lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
+            call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
+                 float(eps), int(lookahead), stream())
+            if need:
+                ctx.save_for_backward(x32, ctl, carries, lin if lin is not None else torch.empty(0, device=x.device))
+                ctx.cfg = (mode, float(sample_rate), float(eps), int(lookahead))
         return y.to(x.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
+        xd, cm = ctx.meta
+        if ctx.empty:
+            return (torch.empty_like(gy), None, None, None, None) + tuple(torch.zeros(shape, dtype=dt, device=gy.device) for dt, shape in cm)
         L = _lib.lib()
         x32, ctl, carries, lin = ctx.saved_tensors
         mode, sr, eps, look = ctx.cfg
         B, C, N = x32.shape
-        gx = torch.empty_like(x32)
-        gctl = torch.empty(B, 5, dtype=torch.float32, device=x32.device)
-        partials = torch.empty(L.dasp_dyn_partial_floats(B), dtype=torch.float32, device=x32.device)
-        call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
-             ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
-        xd, cm = ctx.meta
+        with torch.cuda.device(x32.device):
+            gx = torch.empty_like(x32)
+            gctl = torch.empty(B, 5, dtype=torch.float32, device=x32.device)
+            partials = torch.empty(L.dasp_dyn_partial_floats(B), dtype=torch.float32, device=x32.device)
+            call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
+                 ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
         g = gctl.t().contiguous()      # rows: threshold, ratio, attack, knee, makeup
         rows = {0: g[0], 1: g[1], 2: g[2], 4: g[3], 5: g[4]}
         outs = []
@@ -302,25 +359,33 @@ class _StereoFunction(torch.autograd.Function):
     def _run(cls, ctx, x, ctl):
         _lib.require_device(x, "x")
         B, T, N, oshape = cls._dims(x)
-        x32 = _f32c(x)
-        c32 = ctl.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
-        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
-        dims = (B, N) if cls.OP == 0 else (B, T, N)
-        call(cls.FWD, ptr(x32), ptr(c32), ptr(y), *dims, stream())
-        ctx.save_for_backward(x32, c32)
         ctx.meta = (x.dtype, ctl.dtype, ctl.shape, B, T, N)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            ctx.xshape = x.shape
+            return torch.empty(oshape, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            x32 = _f32c(x)
+            c32 = ctl.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+            y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+            dims = (B, N) if cls.OP == 0 else (B, T, N)
+            call(cls.FWD, ptr(x32), ptr(c32), ptr(y), *dims, stream())
+            ctx.save_for_backward(x32, c32)
         return y.to(x.dtype)
 
     @classmethod
     def _grad(cls, ctx, gy):
+        xd, cd, cshape, B, T, N = ctx.meta
+        if ctx.empty:
+            return torch.empty(ctx.xshape, dtype=xd, device=gy.device), torch.zeros(cshape, dtype=cd, device=gy.device)
         L = _lib.lib()
         x32, c32 = ctx.saved_tensors
-        xd, cd, cshape, B, T, N = ctx.meta
-        gx = torch.empty_like(x32)
-        gctl = torch.empty_like(c32)
-        partials = torch.empty(L.dasp_stereo_partial_floats(cls.OP, B, T, N), dtype=torch.float32, device=x32.device)
-        dims = (B, N) if cls.OP == 0 else (B, T, N)
-        call(cls.BWD, ptr(x32), ptr(c32), ptr(_f32c(gy)), ptr(gx), ptr(gctl), ptr(partials), *dims, stream())
+        with torch.cuda.device(x32.device):
+            gx = torch.empty_like(x32)
+            gctl = torch.empty_like(c32)
+            partials = torch.empty(L.dasp_stereo_partial_floats(cls.OP, B, T, N), dtype=torch.float32, device=x32.device)
+            dims = (B, N) if cls.OP == 0 else (B, T, N)
+            call(cls.BWD, ptr(x32), ptr(c32), ptr(_f32c(gy)), ptr(gx), ptr(gctl), ptr(partials), *dims, stream())
         return gx.to(xd), gctl.reshape(cshape).to(cd)
 
 
@@ -333,6 +398,7 @@ class WidenerFunction(_StereoFunction):
         return WidenerFunction._run(ctx, x, width)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         return WidenerFunction._grad(ctx, gy)
 
@@ -346,6 +412,7 @@ class PannerFunction(_StereoFunction):
         return PannerFunction._run(ctx, x, pan)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         return PannerFunction._grad(ctx, gy)
 
@@ -359,6 +426,7 @@ class BusFunction(_StereoFunction):
         return BusFunction._run(ctx, x, send_db)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         return BusFunction._grad(ctx, gy)
 
@@ -385,50 +453,63 @@ def _filter_spectrum(filters, nb, taps, n_complex, dev):
 
 
 class ReverbFunction(torch.autograd.Function):
-    """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1), filters (nb,taps), gains/decays (B,nb), mix (B)."""
+    """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1), filters (nb,taps), gains/decays (B,nb), mix (B).
+    `noise` and `filters` are constants of the op (the reference draws the noise inside the function, functional.py:548, and designs the
+    filters with SciPy): asking for their gradient raises instead of silently returning None."""
 
     @staticmethod
     def forward(ctx, x, noise, filters, gains, decays, mix, L_ir):
         _lib.require_device(x, "x")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("noise_shaped_reverberation: `noise` and `filters` are not differentiable inputs (detach them)")
         Lb = _lib.lib()
         B, C, N = x.shape
         nb, taps = filters.shape
         dev = x.device
-        sizes = (ctypes.c_long * 12)()
-        check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
-        x32, n32 = _f32c(x), _f32c(noise)
-        g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
-        Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
-        y = torch.empty_like(x32)
-        need_grad = any(ctx.needs_input_grad)
-        A, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
-        H, Ah = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
-        ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
-        wet = torch.empty(sizes[9], dtype=torch.float32, device=dev) if need_grad else None
-        call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
-             ptr(wet) if need_grad else None, ptr(W), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
-        if need_grad:
-            ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, A, H, wet)
-            ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
-            ctx.meta = (x.dtype, gains.dtype, gains.shape, decays.dtype, decays.shape, mix.dtype, mix.shape)
+        ctx.meta = (x.dtype, gains.dtype, gains.shape, decays.dtype, decays.shape, mix.dtype, mix.shape)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(dev):
+            sizes = (ctypes.c_long * 12)()
+            check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
+            x32, n32 = _f32c(x), _f32c(noise)
+            g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
+            Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
+            y = torch.empty_like(x32)
+            need_grad = any(ctx.needs_input_grad)
+            A, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
+            H, Ah = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
+            ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
+            wet = torch.empty(sizes[9], dtype=torch.float32, device=dev) if need_grad else None
+            call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
+                 ptr(wet) if need_grad else None, ptr(W), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+            if need_grad:
+                ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, A, H, wet)
+                ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
         return y.to(x.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
+        xd, gd, gs, dd, ds, md, ms = ctx.meta
+        if ctx.empty:
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
+            return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None
         x32, n32, Fspec, g32, d32, m32, A, H, wet = ctx.saved_tensors
         B, N, L_ir, taps, nb, sizes = ctx.cfg
         dev = x32.device
-        gx = torch.empty_like(x32)
-        ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
-        gdecay = torch.empty(B, nb, dtype=torch.float32, device=dev)
-        gmix = torch.empty(B, dtype=torch.float32, device=dev)
-        Ag, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
-        P = _cbuf(sizes[7], dev)
-        gir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
-        part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
-        mix_part = torch.empty(sizes[10], dtype=torch.float32, device=dev)
-        call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(wet),
-             ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P), ptr(gir), ptr(part), ptr(mix_part),
-             B, N, L_ir, taps, nb, stream())
-        xd, gd, gs, dd, ds, md, ms = ctx.meta
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(x32)
+            ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
+            gdecay = torch.empty(B, nb, dtype=torch.float32, device=dev)
+            gmix = torch.empty(B, dtype=torch.float32, device=dev)
+            Ag, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
+            P = _cbuf(sizes[7], dev)
+            gir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
+            part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
+            mix_part = torch.empty(sizes[10], dtype=torch.float32, device=dev)
+            call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(wet),
+                 ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P), ptr(gir), ptr(part), ptr(mix_part),
+                 B, N, L_ir, taps, nb, stream())
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None

@@ -77,6 +77,36 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
                                 const float* carries, float* gx, float* partials, int mode, float* gout,
                                 int B, int C, long N, int S, void* stream);
 
+/* The backward pass as asked for (torch.autograd's needs_input_grad) and for the cascade it is:
+ *   gx == NULL        no input gradient: the adjoint output is neither transposed back nor stored (parametric_eq is the first effect of
+ *                     the reference's chain, examples/style_transfer.py:150 - its input never needs one);
+ *   partials == NULL  no coefficient gradients (a fixed filter): x and carries are not read, only the adjoint cascade runs;
+ *   designed != 0     tab / dtab were filled by dasp_peq_prepare / dasp_peq_prepare_rows (RBJ design: every b0 > 0). The kernel then
+ *                     recomputes the sections in monic form, drops the lag-0 correlation of every section and hands the finalize step
+ *                     T = <adjoint output, input> of the last section instead (sum_i b_i dL/db_i = T for every section of a cascade);
+ *                     the matching finalize call must carry the same flag. designed == 0 (tables from dasp_sos_prepare: any b0) keeps
+ *                     all five correlations.
+ * dasp_sos_grad_finalize_ex: segments = rows of partial sums per (row, wave) (1 after dasp_sosfilt_backward*, dasp_sos_segments(N, Tseg)
+ * after the *_seg calls); mode 2 = mode 1 written as 3*S rows of B values ([3 k + c][item]: one contiguous vector per control tensor). */
+int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
+                             float* partials, int B, int C, long N, int S, int designed, void* stream);
+int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
+                              int designed, float* gout, void* stream);
+int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
+                                   float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, int designed,
+                                   void* stream);
+
+/* functional.parametric_eq (dasp_pytorch/functional.py:118-272) as one call per direction. Forward = dasp_peq_prepare_rows +
+ * dasp_sosfilt_forward (Tseg == 0) or + dasp_sos_segment_prepare + dasp_sosfilt_forward_seg (Tseg = dasp_sos_segment_tiles(B*C, N) > 0;
+ * segtab / segbuf as below, NULL otherwise). Backward = the adjoint cascade and the control gradients from the tables the forward call
+ * filled (designed cascade), gx / partials / mode as above; with Tseg > 0 partials hold dasp_sos_partial_floats(rows * segments, S). */
+int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, double sample_rate, float* tab, double* dtab,
+                     const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
+                     void* stream);
+int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, const float* gy, const float* carries, float* gx,
+                      float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
+                      float* segbuf, void* stream);
+
 /* Few rows (B*C < 128): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
  * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, a
  * small kernel chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab), then the ordinary pass runs per
@@ -95,6 +125,9 @@ int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, con
 int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy,
                               const float* carries, float* gx, float* partials, float* segbuf,
                               int B, int C, long N, int S, long Tseg, void* stream);
+int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy,
+                                 const float* carries, float* gx, float* partials, float* segbuf,
+                                 int B, int C, long N, int S, long Tseg, int designed, void* stream);
 int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments,
                                int mode, float* gout, void* stream);
 

@@ -21,6 +21,16 @@ state (s1, s2), mapped once per chunk:
         z1 = g1 s1 + g2 s2,  z2 = zc1 s1 + zc2 s2  with (zc1, zc2) = C (A + a1 I)
     backward kernel's recomputation, form II:  w[-2] = s2 / om,  w[-1] = s1 + (sg / om) s2; the kept signal is w itself, so the
     coefficient correlations of a direct section are not divided by om.
+
+Coefficient correlations (backward_row, csrc/sosfilt.hip `adjoint` / finalize_section). With K[n] the kept signal of a section (w[n - 2]
+for a direct section, om w[n - 2] for a normal-form one), g its adjoint input and o its adjoint output, the kernel sums
+    direct section:       sum g K[n+2],  sum g K[n+1],  sum g K[n],  sum o K[n+1],  sum o K[n]
+    normal-form section:  sum g D[n+1],  sum g D[n],    sum g K[n],  sum o D[n],    sum o K[n]      with D[n] = K[n+1] - sg K[n]
+(the lags of K agree to many digits when the poles sit near z = 1; D is their small difference, formed before the summation instead of
+after it) and the finalize step maps them back. fast=True is the kernel variant for cascades that come from the RBJ design (b0 > 0):
+every section is recomputed in monic form (feed-through 1, its signals scaled by 1 / product of the earlier b0), the last section
+computes no output, the lag-0 sum of every section is left out and recovered from T = <adjoint output, input> of the last section,
+because sum_i b_i (sum g w[n - i]) = <g, y> is the same number for every section of a cascade.
 """
 import numpy as np
 
@@ -120,7 +130,7 @@ def tile_scan(z, M, P, carry):
     return start, out
 
 
-def cascade_chunks(secs, X, start, store_s2=False, r=None):
+def cascade_chunks(secs, X, start, store_s2=False, r=None, monic=False):
     """Run the cascade over each lane's chunk X (64,L) from start states (64,2S), one section at a time over the chunk as the
     kernels do. Returns Y (64,L) and (optionally) S2 (S,64,L+2): for a normal-form section s2_k[n] for n in chunk plus the two
     states following the chunk (s2 does not depend on the current input); for a direct section (r["direct"], when r is given)
@@ -129,6 +139,35 @@ def cascade_chunks(secs, X, start, store_s2=False, r=None):
     L = X.shape[1]
     U = X.copy()
     S2 = np.zeros((S, WAVE, L + 2)) if store_s2 else None
+    if monic:        # the backward kernel's FAST recomputation: returns (input of the last section / P_{S-1}, None, kept signals / P_k)
+        assert store_s2 and r is not None
+        q = 1.0
+        for k, (A, B, C, d) in enumerate(secs):
+            s1, s2 = start[:, 2 * k] * q, start[:, 2 * k + 1] * q
+            last = k == S - 1
+            if r["direct"][k]:
+                b0, b1, b2 = r["b"][k]
+                a1, a2 = r["a"][k]
+                w2 = s2 / r["om"][k]
+                w1 = s1 + (r["sg"][k] / r["om"][k]) * s2
+                for n in range(L):
+                    u = U[:, n].copy()
+                    S2[k, :, n] = w2
+                    w = u - a1 * w1 - a2 * w2
+                    if not last:
+                        U[:, n] = w + (b1 / b0) * w1 + (b2 / b0) * w2
+                    w2, w1 = w1, w
+                S2[k, :, L] = w2
+            else:
+                for n in range(L):
+                    u = U[:, n].copy()
+                    S2[k, :, n] = s2
+                    if not last:
+                        U[:, n] = (C[0] / d) * s1 + (C[1] / d) * s2 + u
+                    s1, s2 = A[0, 0] * s1 + A[0, 1] * s2 + u, A[1, 0] * s1 + A[1, 1] * s2
+                S2[k, :, L] = s2
+            q = q / d
+        return U, None, S2
     for k, (A, B, C, d) in enumerate(secs):
         s1, s2 = start[:, 2 * k].copy(), start[:, 2 * k + 1].copy()
         direct = r is not None and bool(r["direct"][k])
@@ -199,7 +238,7 @@ def forward_row(r, x, L, save_every=None, tiles=None, carry0=None, scan_only=Fal
     return (y if tiles is not None else y[:N]), carries
 
 
-def backward_row(r, x, gy, carries, L, tiles=None, acarry0=None, scan_only=False, raw=False):
+def backward_row(r, x, gy, carries, L, tiles=None, acarry0=None, scan_only=False, raw=False, fast=False):
     """Backward for one row: returns gx (N,), and gb (S,3), ga (S,3) -- gradients w.r.t. the
     a0-normalised coefficients (ga[:,0] is d/da0 from scale invariance).
     tiles = (t0, t1) restricts the pass to tiles t1 - 1 .. t0 starting from the adjoint cascade state acarry0; scan_only runs only the
@@ -216,8 +255,7 @@ def backward_row(r, x, gy, carries, L, tiles=None, acarry0=None, scan_only=False
     xp = np.zeros(nt * TS); xp[:N] = x
     gp = np.zeros(nt * TS); gp[:N] = gy
     gx = np.zeros(nt * TS)
-    acc_b = np.zeros((S, 3))
-    acc_a = np.zeros((S, 3))   # [:,0] unused (filled from the identity)
+    acc = np.zeros((S, 5))     # the kernel's five sums per section (module docstring); fast: [:, 0] = T
     t0, t1 = tiles if tiles is not None else (0, nt)
     acarry = np.zeros(2 * S) if acarry0 is None else np.asarray(acarry0, np.float64).copy()
     for t in range(t1 - 1, t0 - 1, -1):
@@ -230,7 +268,7 @@ def backward_row(r, x, gy, carries, L, tiles=None, acarry0=None, scan_only=False
             continue
         # forward chunk start states from the saved tile carry
         start, _ = tile_scan(X @ G.T, M, P, carries[t])
-        _, _, S2 = cascade_chunks(fs, X, start, store_s2=True, r=r)
+        Ulast, _, S2 = cascade_chunks(fs, X, start, store_s2=True, r=r, monic=fast)
         # per-lane adjoint cascade with correlations (natural lane order, descending n). As in the kernel, each adjoint section
         # runs in transposed direct form II from the chunk's entry costate (normal-form coordinates, from the scan), mapped once
         # per chunk: z1 = l1, z2 = -sg*l1 + om*l2 (same zero-input response, same transfer function H(1/z)).
@@ -247,25 +285,53 @@ def backward_row(r, x, gy, carries, L, tiles=None, acarry0=None, scan_only=False
                 k = S - 1 - i
                 b0, b1, b2 = r["b"][k]
                 a1, a2 = r["a"][k]
-                acc_b[k, 0] += np.dot(g, S2[k, :, n + 2]); acc_b[k, 1] += np.dot(g, S2[k, :, n + 1]); acc_b[k, 2] += np.dot(g, S2[k, :, n])
+                K0, K1 = S2[k, :, n], S2[k, :, n + 1]
+                if r["direct"][k]:
+                    R1, R0 = K1, K0
+                    if not fast:
+                        acc[k, 0] += np.dot(g, S2[k, :, n + 2])
+                else:
+                    R1, R0 = K1 - r["sg"][k] * K0, K0                        # D[n], K[n]
+                    if not fast:
+                        acc[k, 0] += np.dot(g, S2[k, :, n + 2] - r["sg"][k] * K1)   # D[n + 1]
+                acc[k, 1] += np.dot(g, R1); acc[k, 2] += np.dot(g, R0)
                 out = b0 * g + z[:, 2 * i]
                 z[:, 2 * i] = b1 * g - a1 * out + z[:, 2 * i + 1]
                 z[:, 2 * i + 1] = b2 * g - a2 * out
-                acc_a[k, 1] += np.dot(out, S2[k, :, n + 1]); acc_a[k, 2] += np.dot(out, S2[k, :, n])
+                acc[k, 3] += np.dot(out, R1); acc[k, 4] += np.dot(out, R0)
                 g = out
+                if fast and i == 0:
+                    acc[:, 0] += np.dot(Ulast[:, n], out)                       # T, the same number in every section's slot
             GX[:, n] = g
         gx[t * TS:(t + 1) * TS] = GX.reshape(-1)
     if scan_only:
         return acarry
     if raw:
-        return gx, acc_b, acc_a
-    return (gx if tiles is not None else gx[:N],) + _normalise_grads(r, acc_b, acc_a)
+        return gx, acc
+    return (gx if tiles is not None else gx[:N],) + _normalise_grads(r, acc, fast)
 
 
-def _normalise_grads(r, acc_b, acc_a):
+def _normalise_grads(r, acc, fast=False):
+    """The finalize step (csrc/sosfilt.hip finalize_section): the kernel's sums -> gradients w.r.t. the normalised coefficients."""
+    S = len(r["sg"])
     om = np.where(r["direct"], 1.0, r["om"])
-    gb = acc_b / om[:, None]
-    ga = -acc_a / om[:, None]
+    sg = r["sg"]
+    nf = ~r["direct"]
+    lag = np.zeros((S, 5))
+    lag[:, 2] = acc[:, 2]
+    lag[:, 1] = np.where(nf, acc[:, 1] + sg * acc[:, 2], acc[:, 1])
+    lag[:, 4] = acc[:, 4]
+    lag[:, 3] = np.where(nf, acc[:, 3] + sg * acc[:, 4], acc[:, 3])
+    if fast:
+        pk = np.concatenate([[1.0], np.cumprod(r["d"])])[:S]                    # scale of section k's signals: 1 / pk
+        rhs = acc[:, 0] * om * pk[S - 1] / pk
+        lag[:, 0] = (rhs - r["b"][:, 1] * lag[:, 1] - r["b"][:, 2] * lag[:, 2]) / r["b"][:, 0]
+        lag = lag * pk[:, None]
+    else:
+        lag[:, 0] = np.where(nf, acc[:, 0] + sg * lag[:, 1], acc[:, 0])
+    gb = lag[:, :3] / om[:, None]
+    ga = np.zeros((S, 3))
+    ga[:, 1:] = -lag[:, 3:] / om[:, None]
     # d/da0 at a0 = 1 from scale invariance of B/A:  sum_theta theta * dL/dtheta = 0
     ga[:, 0] = -(np.sum(gb * r["b"], 1) + np.sum(ga[:, 1:] * r["a"], 1))
     return gb, ga
@@ -304,7 +370,7 @@ def forward_row_segmented(r, x, L, segments):
     return y[:N], carries
 
 
-def backward_row_segmented(r, x, gy, carries, L, segments):
+def backward_row_segmented(r, x, gy, carries, L, segments, fast=False):
     TS = WAVE * L
     N = len(x)
     nt = (N + TS - 1) // TS
@@ -317,10 +383,9 @@ def backward_row_segmented(r, x, gy, carries, L, segments):
     for g in range(segments - 1, 0, -1):
         aend[g - 1] = Phia_seg @ aend[g] + za[g]
     gx = np.zeros(nt * TS)
-    acc_b = acc_a = 0
+    acc = 0
     for g in range(segments):
-        gxg, b, a = backward_row(r, x, gy, carries, L, tiles=(g * T, (g + 1) * T), acarry0=aend[g], raw=True)
+        gxg, a = backward_row(r, x, gy, carries, L, tiles=(g * T, (g + 1) * T), acarry0=aend[g], raw=True, fast=fast)
         gx[g * T * TS:(g + 1) * T * TS] = gxg[g * T * TS:(g + 1) * T * TS]
-        acc_b = acc_b + b
-        acc_a = acc_a + a
-    return (gx[:N],) + _normalise_grads(r, acc_b, acc_a)
+        acc = acc + a
+    return (gx[:N],) + _normalise_grads(r, acc, fast)

@@ -4,10 +4,11 @@ Tolerances (L-inf / peak per batch item, tests.util.linf_peak):
   * north_star bar: 1e-4 relative fp32 vs the reference.  The kernels sit well inside it (y ~3e-7, grad_x ~5e-6: its adjoint
     sections run in transposed direct form II between exact per-chunk restarts), so the tests pin y / grad_x at 1e-5 against
     the fp64 reference output.
-  * Parameter gradients: 5e-4 against the fp64 reference.  They are 131072-term fp32 correlation
-    sums pushed through the RBJ Jacobian (which cancels leading digits); random EQ settings land at
-    1e-6..1.5e-4, where the reference's own fp32 run is 1e-5..3e-2 away from its fp64 run
-    (BASELINE.md section 2), i.e. the bar is still >50x tighter than the reference's fp32 noise.
+  * Parameter gradients: the literal north_star bar, 1e-4 against the fp64 reference.  They are 131072-term fp32 correlation
+    sums pushed through the RBJ Jacobian (which cancels leading digits).  Sections whose poles sit near z = 1 sum the small
+    difference signal D[n] = K[n+1] - sg K[n] instead of three nearly equal lags (csrc/sosfilt.hip finalize_section), which is
+    what keeps the low-frequency / low-Q corner of the ParametricEQ ranges at 1e-5..5e-5 (test_parameter_range_corners); random
+    settings land at 1e-7..2e-5, where the reference's own fp32 run is 1e-5..3e-2 away from its fp64 run.
   * y is never worse than the reference's own fp32 run is against its fp64 run (+ 1e-6 slack).
 """
 import numpy as np
@@ -19,7 +20,7 @@ from tests.util import linf_peak, load_golden
 
 pytestmark = pytest.mark.gpu
 SR = 44100
-TOL_SIG, TOL_PAR = 1e-5, 5e-4
+TOL_SIG, TOL_PAR = 1e-5, 1e-4
 
 PEQ_RANGES = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
               (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
@@ -239,6 +240,125 @@ def test_full_size_properties(D):
     ys = D.parametric_eq(x1[40:44], SR, *[c[40:44] for c in cols])
     assert torch.equal(ys, y1[40:44].detach())
     assert torch.isfinite(y1).all() and torch.isfinite(xa.grad).all()
+    # eight items of the full-size launch against the oracle (rows are independent, so a sample of the launch is a test of the launch)
+    pick = [0, 3, 77, 128, 129, 200, 254, 255]
+    xs, ws, ps = x1[pick].cpu().numpy(), w[pick].cpu().numpy(), p[pick]
+    cg = [c.clone().requires_grad_(True) for c in cols]
+    xb = x1.clone().requires_grad_(True)
+    D.parametric_eq(xb, SR, *cg).backward(w)
+    gp = torch.stack([c.grad for c in cg], 1)[pick].cpu().numpy()
+    yo = orc.parametric_eq(xs, SR, ps)
+    gxo, gpo = orc.parametric_eq_vjp(xs, SR, ps, ws)
+    assert linf_peak(y1[pick].detach().cpu().numpy(), yo).max() < TOL_SIG
+    assert linf_peak(xb.grad[pick].cpu().numpy(), gxo).max() < TOL_SIG
+    assert linf_peak(gp, gpo).max() < TOL_PAR
+
+
+def corner_params():
+    """The corners of the ParametricEQ ranges (dasp_pytorch/modules.py:136-155) that scripts/eq_accuracy.py probes: lowest cut-offs with
+    the highest / lowest Q (poles nearest z = 1, complex and real), highest cut-offs (poles nearest z = -1), gains at +-20 dB."""
+    lo = np.array([r[0] for r in PEQ_RANGES], np.float32); hi = np.array([r[1] for r in PEQ_RANGES], np.float32)
+    p = random_params(8, 21)
+    for b in range(4):
+        p[b, 1::3] = lo[1::3]; p[b, 2::3] = hi[2::3]; p[b, 0::3] = 20.0 if b % 2 else -20.0
+    p[2, 2::3] = lo[2::3]; p[3, 2::3] = lo[2::3]
+    for b in (4, 5):
+        p[b, 1::3] = hi[1::3]; p[b, 2::3] = hi[2::3] if b == 4 else lo[2::3]; p[b, 0::3] = 20.0 if b % 2 else -20.0
+    return p
+
+
+def test_parameter_range_corners(D):
+    """North-star length, the worst corners of the module's parameter ranges: outputs, input gradients and all 18 control gradients
+    inside the bars (the control gradients at the low-frequency corners are where fp32 correlation sums lose their digits)."""
+    B, C, N = 8, 2, 131072
+    g = np.random.default_rng(0)
+    x = (g.random((B, C, N), dtype=np.float32) * 2 - 1)
+    w = g.standard_normal((B, C, N), dtype=np.float32)
+    p = corner_params()
+    y, gx, gp = run_eq(D, x, p, w)
+    yo = orc.parametric_eq(x, SR, p.astype(np.float64))
+    gxo, gpo = orc.parametric_eq_vjp(x, SR, p.astype(np.float64), w)
+    ey, egx, egp = linf_peak(y, yo), linf_peak(gx, gxo), linf_peak(gp, gpo)
+    print("corner errors  y", ey, " gx", egx, " gp", egp)
+    assert ey.max() < TOL_SIG and egx.max() < 2 * TOL_SIG and egp.max() < TOL_PAR
+
+
+def _raw_setup(B, C, N, S, seed, Bs=None):
+    import ctypes
+    from dasp_pytorch_amd import _lib
+    from dasp_pytorch_amd._lib import call, ptr, stream
+    L = _lib.lib()
+    Bs = B if Bs is None else Bs
+    rng = np.random.default_rng(seed)
+    lo = np.array([r[0] for r in PEQ_RANGES]); hi = np.array([r[1] for r in PEQ_RANGES])
+    p = dev((rng.random((Bs, S, 3)) * (hi - lo).reshape(S, 3) + lo.reshape(S, 3)).astype(np.float32))
+    x = dev((rng.random((B, C, N)) * 2 - 1).astype(np.float32)); gy = dev(rng.standard_normal((B, C, N)).astype(np.float32))
+    tab = torch.empty(Bs * L.dasp_sos_table_floats(S), dtype=torch.float32, device="cuda:0")
+    dtab = torch.empty(Bs * L.dasp_sos_dtab_doubles(S), dtype=torch.float64, device="cuda:0")
+    types = (ctypes.c_int * S)(1, 0, 0, 0, 0, 2)
+    call("dasp_peq_prepare", ptr(p), Bs, S, types, float(SR), ptr(tab), ptr(dtab), stream())
+    y = torch.empty_like(x)
+    car = torch.empty(L.dasp_sos_carry_floats(B * C, N, S), dtype=torch.float32, device="cuda:0")
+    call("dasp_sosfilt_forward", ptr(tab), Bs, ptr(x), ptr(y), ptr(car), B, C, N, S, stream())
+    return L, p, x, gy, tab, dtab, car
+
+
+@pytest.mark.parametrize("Bs_shared", [False, True])
+def test_backward_kernel_variants_agree(D, Bs_shared):
+    """The backward kernel variants of dasp_sosfilt_backward_ex through the raw C ABI: the variant for designed cascades (monic
+    recomputation, lag-0 correlation from the identity) gives the generic variant's input gradient bit for bit (the adjoint cascade
+    is the same code) and its control gradients to fp32 summation noise; gx == NULL leaves the control gradients bit-identical,
+    partials == NULL leaves gx bit-identical; ragged length."""
+    from dasp_pytorch_amd._lib import call, ptr, stream
+    B, C, N, S = 4, 2, 20001, 6
+    Bs = 1 if Bs_shared else B
+    L, p, x, gy, tab, dtab, car = _raw_setup(B, C, N, S, 17, Bs)
+    def run(designed, want_gx=True, want_gc=True):
+        part = torch.full((L.dasp_sos_partial_floats(B * C, S),), float("nan"), dtype=torch.float32, device="cuda:0")
+        gx = torch.full_like(x, float("nan")) if want_gx else None
+        g = torch.zeros(B, S, 3, device="cuda:0")
+        call("dasp_sosfilt_backward_ex", ptr(tab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx), ptr(part if want_gc else None), B, C, N, S,
+             designed, stream())
+        if want_gc:
+            call("dasp_sos_grad_finalize_ex", ptr(dtab), Bs, ptr(part), B, C, S, 1, 1, designed, ptr(g), stream())
+        return gx, g
+    gx0, g0 = run(0)
+    gx1, g1 = run(1)
+    assert torch.isfinite(gx0).all() and torch.isfinite(g0).all() and torch.isfinite(g1).all()
+    assert torch.equal(gx0, gx1)
+    assert ((g1 - g0).abs().amax(dim=(1, 2)) / g0.abs().amax(dim=(1, 2))).max().item() < 2e-5
+    for designed, gref in ((0, g0), (1, g1)):
+        _, g = run(designed, want_gx=False)
+        assert torch.equal(g, gref)
+    gxn, _ = run(0, want_gc=False)
+    assert torch.equal(gxn, gx0)
+    # the one-call entry points give the same numbers as the two calls
+    for designed, gref in ((0, g0), (1, g1)):
+        part = torch.empty(L.dasp_sos_partial_floats(B * C, S), dtype=torch.float32, device="cuda:0")
+        gx2, g2 = torch.empty_like(x), torch.zeros(B, S, 3, device="cuda:0")
+        call("dasp_sosfilt_backward_grads_ex", ptr(tab), ptr(dtab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx2), ptr(part), 1, ptr(g2),
+             B, C, N, S, designed, stream())
+        assert torch.equal(gx2, gx0) and torch.equal(g2, gref)
+
+
+def test_needs_input_grad_selects_the_kernel_variant(D):
+    """Through autograd: asking only for the control gradients (x is a leaf without grad - the EQ is the first effect of the reference's
+    chain, examples/style_transfer.py:150) or only for the input gradient gives the same numbers as asking for both."""
+    B, C, N = 3, 2, 30000
+    g = np.random.default_rng(5)
+    x = (g.random((B, C, N)) * 2 - 1).astype(np.float32); w = g.standard_normal((B, C, N)).astype(np.float32)
+    p = random_params(B, 6)
+    y, gx, gp = run_eq(D, x, p, w)
+    cols = [dev(p[:, i]).requires_grad_(True) for i in range(18)]
+    (D.parametric_eq(dev(x), SR, *cols) * dev(w)).sum().backward()
+    assert np.array_equal(torch.stack([c.grad for c in cols], 1).cpu().numpy(), gp)
+    xt = dev(x).requires_grad_(True)
+    (D.parametric_eq(xt, SR, *[dev(p[:, i]) for i in range(18)]) * dev(w)).sum().backward()
+    assert np.array_equal(xt.grad.cpu().numpy(), gx)
+    sos = dev(orc.peq_sos(p.astype(np.float64), SR).astype(np.float32))
+    xt2 = dev(x).requires_grad_(True)
+    (D.signal.sosfilt_via_fsm(sos, xt2) * dev(w)).sum().backward()          # fixed filter: the adjoint-only kernel
+    assert linf_peak(xt2.grad.cpu().numpy(), gx).max() < TOL_SIG
 
 
 @pytest.mark.parametrize("Bs_shared", [False, True])

@@ -196,3 +196,29 @@ def test_chunkscan_model_segmented_rows():
         gxs, gbs, gas = cm.backward_row_segmented(r, x, w, cars, L, segments)
         for a, b in ((ys, y), (cars, car), (gxs, gx), (gbs, gb), (gas, ga)):
             assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+        gxf, gbf, gaf = cm.backward_row_segmented(r, x, w, cars, L, segments, fast=True)
+        for a, b in ((gxf, gx), (gbf, gb), (gaf, ga)):
+            assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
+
+
+def test_chunkscan_model_designed_cascade_variant():
+    """The backward kernel's variant for cascades that come from the RBJ design (monic recomputation, lag-0 correlation of every section
+    recovered from T = <adjoint output, input> of the last section, difference-form sums for normal-form sections; oracle/
+    chunkscan_model.py docstring) gives the reference's gradients: against the oracle's VJP of the reference algorithm, on a parameter
+    set with both section kinds and a ragged last tile."""
+    rng = np.random.default_rng(11)
+    p = np.array([[12, 300, 0.3, -15, 500, 2.0, 9, 2000, 3, -6, 8000, 1, 4, 12000, 0.7, -20, 4000, 6],     # (impulse responses decayed within N:
+                  [-20, 2000, 0.1, 20, 2000, 6, -3, 8000, 0.1, 6, 12000, 6, -9, 21050, 0.3, 20, 21050, 0.1]], dtype=np.float64)
+    N = 16384 + 4099                                                                                       #  the reference's circular method is alias-free)
+    x, w = rng.standard_normal((2, 1, N)), rng.standard_normal((2, 1, N))
+    sos = orc.peq_sos(p, 44100)
+    gsos_ref, gx_ref = orc.sosfilt_via_fsm_vjp(sos, x, w)
+    for b in range(2):
+        r = cm.realize(sos[b])
+        assert r["direct"].any() and not r["direct"].all()
+        _, car = cm.forward_row(r, x[b, 0], 16)
+        for fast in (False, True):
+            gx, gb, ga = cm.backward_row(r, x[b, 0], w[b, 0], car, 16, fast=fast)
+            assert np.abs(gx - gx_ref[b, 0]).max() < 1e-9 * np.abs(gx_ref[b, 0]).max()
+            got = np.concatenate([gb, ga], 1)          # a0 = 1: columns b0 b1 b2 a0 a1 a2 as in sos
+            assert np.abs(got - gsos_ref[b]).max() < 2e-7 * np.abs(gsos_ref[b]).max(), (b, fast)

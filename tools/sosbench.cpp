@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dsos, sos.size() * 4)); CK(hipMalloc(&dx, n * 4)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dgy, n * 4)); CK(hipMalloc(&dgx, n * 4));
     CK(hipMalloc(&dtab, (size_t)B * dasp_sos_table_floats(S) * 4)); CK(hipMalloc(&ddtab, (size_t)B * dasp_sos_dtab_doubles(S) * 8));
     CK(hipMalloc(&dcar, (size_t)dasp_sos_carry_floats((long)B * C, N, S) * 4)); CK(hipMalloc(&dpart, (size_t)dasp_sos_partial_floats((long)B * C, S) * 4));
-    CK(hipMalloc(&dgout, (size_t)B * S * 6 * 4));
+    CK(hipMalloc(&dgout, (size_t)B * S * 6 * 4)); CK(hipMemset(dgout, 0, (size_t)B * S * 6 * 4)); CK(hipMemset(dgx, 0, n * 4));
     CK(hipMemcpy(dsos, sos.data(), sos.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dgy, gy.data(), n * 4, hipMemcpyHostToDevice));
 
@@ -83,11 +83,15 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e[1]));
         DK(dasp_sosfilt_forward(dtab, B, dx, dy, dcar, B, C, N, S, nullptr));
         CK(hipEventRecord(e[2]));
+        // DASP_DESIGNED=1 (with DASP_PEQ=1): the kernel variant for designed cascades; DASP_NOGX / DASP_NOGC: the reduced backward variants
+        const int designed = peq && getenv("DASP_DESIGNED") ? 1 : 0;
+        float* pgx = getenv("DASP_NOGX") ? nullptr : dgx;
+        float* ppart = getenv("DASP_NOGC") ? nullptr : dpart;
         if (getenv("DASP_SPLIT_FINALIZE")) {
-            DK(dasp_sosfilt_backward(dtab, B, dx, dgy, dcar, dgx, dpart, B, C, N, S, nullptr));
-            DK(dasp_sos_grad_finalize(ddtab, B, dpart, B, C, S, 0, dgout, nullptr));
+            DK(dasp_sosfilt_backward_ex(dtab, B, dx, dgy, dcar, pgx, ppart, B, C, N, S, designed, nullptr));
+            if (ppart) DK(dasp_sos_grad_finalize_ex(ddtab, B, dpart, B, C, S, 1, 0, designed, dgout, nullptr));
         } else {
-            DK(dasp_sosfilt_backward_grads(dtab, ddtab, B, dx, dgy, dcar, dgx, dpart, 0, dgout, B, C, N, S, nullptr));
+            DK(dasp_sosfilt_backward_grads_ex(dtab, ddtab, B, dx, dgy, dcar, pgx, ppart, 0, dgout, B, C, N, S, designed, nullptr));
         }
         CK(hipEventRecord(e[3]));
         CK(hipEventSynchronize(e[3]));
