@@ -38,6 +38,8 @@ SIGNATURES = {
     "dasp_peq_forward": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
     "dasp_peq_backward": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _l, _p, _p, _p]),
     "dasp_sosfilt_backward_seg_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _i, _p]),
+    "dasp_biquad_design": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p]),
+    "dasp_biquad_backward": (_i, [_p, _p, _i, _p, _p]),
     "dasp_sos_segment_tiles": (_l, [_l, _l]),
     "dasp_sos_segments": (_l, [_l, _l]),
     "dasp_sos_segtab_doubles": (_l, [_i]),

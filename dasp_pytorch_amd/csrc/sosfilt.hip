@@ -1431,6 +1431,34 @@ __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bca
     finalize_section<false>(dtab, tab_bcast, partials, B, C, S, Wb, mode, gout, idx / S, idx % S, fast);
 }
 
+// ------------------------------------------------------------------------------------------------
+// signal.biquad as a call of its own (dasp_pytorch/signal.py:242-306): the same fp64 design the prep kernel runs, one thread per
+// (item, control): thread (item, dir) writes its Jacobian column, dir 0 also the coefficients [b0 b1 b2 1 a1 a2] (normalised by a0).
+__global__ void biquad_design_kernel(const double* __restrict__ gain_db, const double* __restrict__ cutoff, const double* __restrict__ qf,
+                                     int n, int type, double sample_rate, double* __restrict__ ba, double* __restrict__ jac) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * n) return;
+    const int item = idx / 3, dir = idx % 3;
+    double c5[5], dc5[5];
+    rbj_design(type, sample_rate, gain_db[item], cutoff[item], qf[item], dir, c5, dc5);
+    for (int c = 0; c < 5; ++c) jac[(size_t)item * 15 + c * 3 + dir] = dc5[c];
+    if (dir == 0) {
+        double* o = ba + (size_t)item * 6;
+        o[0] = c5[0]; o[1] = c5[1]; o[2] = c5[2]; o[3] = 1.0; o[4] = c5[3]; o[5] = c5[4];
+    }
+}
+// gparams[item][dir] = sum_c gba[item][c'] jac[item][c][dir], c over b0 b1 b2 a1 a2 (a0 is the constant 1)
+__global__ void biquad_backward_kernel(const double* __restrict__ jac, const double* __restrict__ gba, int n, double* __restrict__ gparams) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * n) return;
+    const int item = idx / 3, dir = idx % 3;
+    const double* g = gba + (size_t)item * 6;
+    const double g5[5] = {g[0], g[1], g[2], g[4], g[5]};
+    double v = 0.0;
+    for (int c = 0; c < 5; ++c) v += g5[c] * jac[(size_t)item * 15 + c * 3 + dir];
+    gparams[(size_t)item * 3 + dir] = v;
+}
+
 }  // namespace dasp
 
 // ================================================================================================
@@ -1756,6 +1784,23 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
     const int rc = dasp_sosfilt_backward_seg_ex(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, stream);
     if (rc != DASP_OK || !partials) return rc;
     return dasp_sos_grad_finalize_ex(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, 1, gout, stream);
+}
+
+// ---- signal.biquad (dasp_pytorch/signal.py:242-306) ------------------------------------------------------------------------------
+// gain_db, cutoff_freq, q_factor: n fp64 values each; type as in dasp_peq_prepare. ba: (n, 6) fp64 rows [b0 b1 b2 1 a1 a2];
+// jac: (n, 15) fp64, d(b0 b1 b2 a1 a2)/d(gain_db, cutoff_freq, q_factor), kept for dasp_biquad_backward.
+int dasp_biquad_design(const double* gain_db, const double* cutoff_freq, const double* q_factor, int n, int type, double sample_rate,
+                       double* ba, double* jac, void* stream) {
+    if (!gain_db || !cutoff_freq || !q_factor || !ba || !jac || n <= 0 || type < 0 || type > 4) return DASP_ERR_ARG;
+    hipLaunchKernelGGL(biquad_design_kernel, dim3((3 * n + 127) / 128), dim3(128), 0, (hipStream_t)stream, gain_db, cutoff_freq, q_factor, n,
+                       type, sample_rate, ba, jac);
+    return check_launch();
+}
+// gba: (n, 6) fp64 gradient w.r.t. the rows of ba -> gparams (n, 3) fp64 = gradient w.r.t. [gain_db, cutoff_freq, q_factor]
+int dasp_biquad_backward(const double* jac, const double* gba, int n, double* gparams, void* stream) {
+    if (!jac || !gba || !gparams || n <= 0) return DASP_ERR_ARG;
+    hipLaunchKernelGGL(biquad_backward_kernel, dim3((3 * n + 127) / 128), dim3(128), 0, (hipStream_t)stream, jac, gba, n, gparams);
+    return check_launch();
 }
 
 }  // extern "C"

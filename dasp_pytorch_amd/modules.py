@@ -12,7 +12,8 @@ columns of the parameter tensor), `num_params`, `process`, `process_normalized`,
 * de-normalisation is one affine op on the (bs, P) tensor, then column views;
 * `Distortion` works: the reference's has no `sample_rate` attribute and names its parameter
   `gain_db` although `functional.distortion` takes `drive_db`, so `process_normalized` raises
-  there (modules.py:110-121, SURVEY Appendix A Q7). Here the parameter is `drive_db`;
+  there (modules.py:110-121). Here the parameter is `drive_db`; the constructor keeps the reference's
+  positional order (min_gain_db, max_gain_db) with `sample_rate` as an optional third argument;
 * `Expander` exists (the reference's functional.expander is a stub).
 """
 from typing import Dict
@@ -33,21 +34,40 @@ def normalize(val, min_val, max_val):
 
 
 class Processor:
+    """Base class with the reference's contract (modules.py:21-91): a subclass sets `sample_rate`, `process_fn` and `param_ranges`
+    (name -> (min, max), in the order of the columns of the parameter tensor) - nothing else is required, so processors written against
+    the reference work unchanged. The affine de-normalisation tables are derived from the *current* `param_ranges` on every call
+    (cached per (ranges, device, dtype)), so editing the ranges after construction takes effect, as it does in the reference."""
     sample_rate = None
     process_fn = None
     param_ranges: Dict[str, tuple] = {}
 
-    def _finish(self):
-        self.num_params = len(self.param_ranges)
-        self._lo = torch.tensor([r[0] for r in self.param_ranges.values()], dtype=torch.float32)
-        self._span = torch.tensor([r[1] - r[0] for r in self.param_ranges.values()], dtype=torch.float32)
-        self._cache = {}
+    def __init__(self):
+        pass
+
+    @property
+    def num_params(self):
+        return len(self.param_ranges)
+
+    @num_params.setter
+    def num_params(self, value):      # the reference's subclasses assign it in __init__ (modules.py:107); accepted and ignored
+        pass
 
     def _affine(self, ref: torch.Tensor):
-        key = (ref.device, ref.dtype)
-        if key not in self._cache:
-            self._cache[key] = (self._lo.to(device=ref.device, dtype=ref.dtype), self._span.to(device=ref.device, dtype=ref.dtype))
-        return self._cache[key]
+        """(min, max - min) of every parameter as two (P,) tensors on ref's device / dtype."""
+        cache = self.__dict__.setdefault("_affine_cache", {})
+        key = (tuple(self.param_ranges.items()), ref.device, ref.dtype)
+        hit = cache.get(key)
+        if hit is None:
+            capturing = ref.is_cuda and torch.cuda.is_current_stream_capturing()
+            lo = torch.tensor([float(r[0]) for r in self.param_ranges.values()], dtype=torch.float64)
+            span = torch.tensor([float(r[1]) - float(r[0]) for r in self.param_ranges.values()], dtype=torch.float64)
+            hit = (lo.to(device=ref.device, dtype=ref.dtype), span.to(device=ref.device, dtype=ref.dtype))
+            if not capturing:                  # memory allocated while a HIP graph is being captured belongs to that graph
+                if len(cache) >= 8:
+                    cache.clear()
+                cache[key] = hit
+        return hit
 
     def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
         """Run the processor with parameters normalised to [0, 1], one row per batch item, columns in the
@@ -94,18 +114,22 @@ class Processor:
 
 class Gain(Processor):
     def __init__(self, sample_rate: int, min_gain_db: float = -24.0, max_gain_db: float = 24.0):
+        super().__init__()
         self.sample_rate = sample_rate
         self.process_fn = F.gain
         self.param_ranges = {"gain_db": (min_gain_db, max_gain_db)}
-        self._finish()
 
 
 class Distortion(Processor):
-    def __init__(self, sample_rate: int = None, min_gain_db: float = 0.0, max_gain_db: float = 24.0):
+    """The reference's constructor order (min_gain_db, max_gain_db; modules.py:110-121). Its Distortion cannot run - no `sample_rate`
+    attribute and a parameter named `gain_db` where functional.distortion takes `drive_db` - so here the
+    parameter is `drive_db` and `sample_rate` is an optional trailing argument (functional.distortion ignores it)."""
+
+    def __init__(self, min_gain_db: float = 0.0, max_gain_db: float = 24.0, sample_rate: int = None):
+        super().__init__()
         self.sample_rate = sample_rate
         self.process_fn = F.distortion
         self.param_ranges = {"drive_db": (min_gain_db, max_gain_db)}
-        self._finish()
 
 
 def _eq_ranges(sample_rate, g, q):
@@ -123,10 +147,10 @@ def _eq_ranges(sample_rate, g, q):
 class ParametricEQ(Processor):
     def __init__(self, sample_rate: int, min_gain_db: float = -20.0, max_gain_db: float = 20.0, min_q_factor: float = 0.1,
                  max_q_factor: float = 6.0):
+        super().__init__()
         self.sample_rate = sample_rate
         self.process_fn = F.parametric_eq
         self.param_ranges = _eq_ranges(sample_rate, (min_gain_db, max_gain_db), (min_q_factor, max_q_factor))
-        self._finish()
 
 
 class _Dynamics(Processor):
@@ -134,23 +158,33 @@ class _Dynamics(Processor):
                  max_ratio: float = 20.0, min_attack_ms: float = 5.0, max_attack_ms: float = 100.0, min_release_ms: float = 5.0,
                  max_release_ms: float = 100.0, min_knee_db: float = 0.0, max_knee_db: float = 12.0, min_makeup_gain_db: float = 0.0,
                  max_makeup_gain_db: float = 12.0):
+        Processor.__init__(self)
         self.sample_rate = sample_rate
         self.process_fn = fn
         self.param_ranges = {
             "threshold_db": (min_threshold_db, max_threshold_db), "ratio": (min_ratio, max_ratio),
             "attack_ms": (min_attack_ms, max_attack_ms), "release_ms": (min_release_ms, max_release_ms),
             "knee_db": (min_knee_db, max_knee_db), "makeup_gain_db": (min_makeup_gain_db, max_makeup_gain_db)}
-        self._finish()
 
 
 class Compressor(_Dynamics):
-    def __init__(self, sample_rate: int, **ranges):
-        super().__init__(F.compressor, sample_rate, **ranges)
+    """Positional order of the reference's constructor (modules.py:159-187)."""
+
+    def __init__(self, sample_rate: int, min_threshold_db: float = -60.0, max_threshold_db: float = 0.0, min_ratio: float = 1.0,
+                 max_ratio: float = 20.0, min_attack_ms: float = 5.0, max_attack_ms: float = 100.0, min_release_ms: float = 5.0,
+                 max_release_ms: float = 100.0, min_knee_db: float = 0.0, max_knee_db: float = 12.0, min_makeup_gain_db: float = 0.0,
+                 max_makeup_gain_db: float = 12.0):
+        super().__init__(F.compressor, sample_rate, min_threshold_db, max_threshold_db, min_ratio, max_ratio, min_attack_ms, max_attack_ms,
+                         min_release_ms, max_release_ms, min_knee_db, max_knee_db, min_makeup_gain_db, max_makeup_gain_db)
 
 
 class Expander(_Dynamics):
-    def __init__(self, sample_rate: int, **ranges):
-        super().__init__(F.expander, sample_rate, **ranges)
+    def __init__(self, sample_rate: int, min_threshold_db: float = -60.0, max_threshold_db: float = 0.0, min_ratio: float = 1.0,
+                 max_ratio: float = 20.0, min_attack_ms: float = 5.0, max_attack_ms: float = 100.0, min_release_ms: float = 5.0,
+                 max_release_ms: float = 100.0, min_knee_db: float = 0.0, max_knee_db: float = 12.0, min_makeup_gain_db: float = 0.0,
+                 max_makeup_gain_db: float = 12.0):
+        super().__init__(F.expander, sample_rate, min_threshold_db, max_threshold_db, min_ratio, max_ratio, min_attack_ms, max_attack_ms,
+                         min_release_ms, max_release_ms, min_knee_db, max_knee_db, min_makeup_gain_db, max_makeup_gain_db)
 
 
 class NoiseShapedReverb(Processor):
@@ -159,10 +193,10 @@ class NoiseShapedReverb(Processor):
                  num_bandpass_taps: int = 1023, device_noise: bool = False):
         """The last three arguments are additions to the reference's constructor (defaults = the reference's behaviour):
         impulse-response length, filter-bank taps, and drawing the noise on the GPU instead of from the global CPU generator."""
+        super().__init__()
         self.sample_rate = sample_rate
         self.process_fn = functools.partial(F.noise_shaped_reverberation, num_samples=num_samples, num_bandpass_taps=num_bandpass_taps,
                                             device_noise=device_noise)
         self.param_ranges = {f"band{i}_gain": (min_band_gain, max_band_gain) for i in range(12)}
         self.param_ranges.update({f"band{i}_decay": (min_band_decay, max_band_decay) for i in range(12)})
         self.param_ranges["mix"] = (min_mix, max_mix)
-        self._finish()

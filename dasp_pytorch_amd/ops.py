@@ -148,6 +148,40 @@ class SosFiltFunction(torch.autograd.Function):
         return (gsos[:, :ctx.S].to(ctx.dtypes[0]) if gsos is not None else None, gx.to(ctx.dtypes[1]) if gx is not None else None)
 
 
+class BiquadFunction(torch.autograd.Function):
+    """signal.biquad: (gain_db, cutoff_freq, q_factor) with n values each -> (n, 6) fp64 rows [b0 b1 b2 1 a1 a2] (dasp_biquad_design);
+    the backward contracts the in-kernel Jacobian with the incoming gradient (dasp_biquad_backward)."""
+
+    @staticmethod
+    def forward(ctx, gain_db, cutoff_freq, q_factor, sample_rate, ftype):
+        _lib.require_device(gain_db, "gain_db")
+        _lib.require_same_device(gain_db, cutoff_freq=cutoff_freq, q_factor=q_factor)
+        n = gain_db.numel()
+        ctx.meta = [(t.dtype, t.shape) for t in (gain_db, cutoff_freq, q_factor)]
+        dev = gain_db.device
+        ba = torch.empty(n, 6, dtype=torch.float64, device=dev)
+        if n == 0:
+            return ba
+        with torch.cuda.device(dev):
+            g, f, q = (t.detach().reshape(-1).to(torch.float64).contiguous() for t in (gain_db, cutoff_freq, q_factor))
+            jac = torch.empty(n, 15, dtype=torch.float64, device=dev)
+            call("dasp_biquad_design", ptr(g), ptr(f), ptr(q), n, int(ftype), float(sample_rate), ptr(ba), ptr(jac), stream())
+        ctx.save_for_backward(jac)
+        return ba
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gba):
+        (jac,) = ctx.saved_tensors
+        n = jac.shape[0]
+        gp = torch.zeros(max(n, 1), 3, dtype=torch.float64, device=gba.device)
+        if n:
+            with torch.cuda.device(jac.device):
+                call("dasp_biquad_backward", ptr(jac), ptr(gba.to(torch.float64).contiguous()), n, ptr(gp), stream())
+        cols = gp[:n].unbind(1)
+        return tuple(c.reshape(shape).to(dt) for c, (dt, shape) in zip(cols, ctx.meta)) + (None, None)
+
+
 class ParametricEQFunction(torch.autograd.Function):
     """Fused RBJ design (fp64, in-kernel) + cascade. `controls` are the 3*S per-item controls in the
     reference's argument order [gain_db, cutoff_freq, q_factor] per section, each with Bp elements.

@@ -6,73 +6,77 @@ approximation; the two agree to <= 1e-13 in fp64 for stable filters whose impuls
 decayed within the signal length.
 """
 import functools
-import math
 
 import numpy as np
 import scipy.signal
 import torch
 
-from .ops import SosFiltFunction
+from .ops import FILTER_TYPES, BiquadFunction, SosFiltFunction
 
 
-def biquad(gain_db, cutoff_freq, q_factor, sample_rate, filter_type="peaking"):
-    """RBJ-cookbook biquad design; mirrors dasp_pytorch/signal.py:242-306 op for op (tiny (bs,1)
-    tensors, left to torch so autograd supplies d(sos)/d(params) when the un-fused path is used).
-    Returns b, a with shape (bs, 3), a0-normalised."""
-    bs = gain_db.size(0)
-    gain_db = gain_db.view(bs, -1)
-    cutoff_freq = cutoff_freq.view(bs, -1)
-    q_factor = q_factor.view(bs, -1)
-
-    A = 10 ** (gain_db / 40.0)
-    w0 = 2 * math.pi * (cutoff_freq / sample_rate)
-    alpha = torch.sin(w0) / (2 * q_factor)
-    cos_w0 = torch.cos(w0)
-    sqrt_A = torch.sqrt(A)
-
-    if filter_type == "high_shelf":
-        b0 = A * ((A + 1) + (A - 1) * cos_w0 + 2 * sqrt_A * alpha)
-        b1 = -2 * A * ((A - 1) + (A + 1) * cos_w0)
-        b2 = A * ((A + 1) + (A - 1) * cos_w0 - 2 * sqrt_A * alpha)
-        a0 = (A + 1) - (A - 1) * cos_w0 + 2 * sqrt_A * alpha
-        a1 = 2 * ((A - 1) - (A + 1) * cos_w0)
-        a2 = (A + 1) - (A - 1) * cos_w0 - 2 * sqrt_A * alpha
-    elif filter_type == "low_shelf":
-        b0 = A * ((A + 1) - (A - 1) * cos_w0 + 2 * sqrt_A * alpha)
-        b1 = 2 * A * ((A - 1) - (A + 1) * cos_w0)
-        b2 = A * ((A + 1) - (A - 1) * cos_w0 - 2 * sqrt_A * alpha)
-        a0 = (A + 1) + (A - 1) * cos_w0 + 2 * sqrt_A * alpha
-        a1 = -2 * ((A - 1) + (A + 1) * cos_w0)
-        a2 = (A + 1) + (A - 1) * cos_w0 - 2 * sqrt_A * alpha
-    elif filter_type == "peaking":
-        b0 = 1 + alpha * A
-        b1 = -2 * cos_w0
-        b2 = 1 - alpha * A
-        a0 = 1 + (alpha / A)
-        a1 = -2 * cos_w0
-        a2 = 1 - (alpha / A)
-    elif filter_type == "low_pass":
-        b0 = (1 - cos_w0) / 2
-        b1 = 1 - cos_w0
-        b2 = (1 - cos_w0) / 2
-        a0 = 1 + alpha
-        a1 = -2 * cos_w0
-        a2 = 1 - alpha
-    elif filter_type == "high_pass":
-        b0 = (1 + cos_w0) / 2
-        b1 = -(1 + cos_w0)
-        b2 = (1 + cos_w0) / 2
-        a0 = 1 + alpha
-        a1 = -2 * cos_w0
-        a2 = 1 - alpha
-    else:
+def biquad(gain_db: torch.Tensor, cutoff_freq: torch.Tensor, q_factor: torch.Tensor, sample_rate: float, filter_type: str = "peaking"):
+    """RBJ-cookbook biquad design (reference: dasp_pytorch/signal.py:242-306): gain_db, cutoff_freq, q_factor with bs values each
+    (the reference's (bs, 1)) -> b, a of shape (bs, 3), normalised by a0 (so a[:, 0] == 1), dtype and device of gain_db.
+    filter_type: "peaking", "low_shelf", "high_shelf", "low_pass", "high_pass"; anything else raises ValueError as in the reference.
+    The design runs on the device in fp64 (the kernel the fused parametric_eq path uses, csrc/sosfilt.hip rbj_design) and is
+    differentiable w.r.t. all three controls through its in-kernel Jacobian."""
+    if filter_type not in FILTER_TYPES:
         raise ValueError(f"Invalid filter_type: {filter_type}.")
+    bs = gain_db.size(0)
+    if any(t.numel() != bs for t in (gain_db, cutoff_freq, q_factor)):
+        raise RuntimeError(f"biquad: gain_db, cutoff_freq and q_factor must hold one value per batch item ({bs}); "
+                           f"got {[tuple(t.shape) for t in (gain_db, cutoff_freq, q_factor)]}")
+    ba = BiquadFunction.apply(gain_db.reshape(bs), cutoff_freq.reshape(bs), q_factor.reshape(bs), float(sample_rate), FILTER_TYPES[filter_type])
+    ba = ba.to(gain_db.dtype)
+    return ba[:, :3], ba[:, 3:]
 
-    b = torch.stack([b0, b1, b2], dim=1).view(bs, -1)
-    a = torch.stack([a0, a1, a2], dim=1).view(bs, -1)
-    b = b.type_as(gain_db) / a0
-    a = a.type_as(gain_db) / a0
-    return b, a
+
+def lfilter_via_fsm(x: torch.Tensor, b: torch.Tensor, a: torch.Tensor = None):
+    """IIR / FIR filter along the last dimension of x (reference: dasp_pytorch/signal.py:95-133): x (bs, 1, timesteps), b (bs, K)
+    numerator and a (bs, K) denominator coefficients (any a0), or a = None for an FIR filter. As in the reference x must have one
+    channel (`assert chs == 1`). Evaluated as an exact recurrence - one section of the cascaded-biquad scan (csrc/sosfilt.hip) - instead
+    of the reference's frequency-sampling approximation; differentiable w.r.t. x, b and a.
+    Orders up to 2 (K <= 3) are supported: the reference's only caller is the compressor's one-pole smoother (K = 2,
+    functional.py:372-380). Longer filters raise NotImplementedError (factor them into second-order sections and call
+    sosfilt_via_fsm)."""
+    bs, chs, seq_len = x.size()  # enforce shape
+    assert chs == 1
+    K = b.shape[-1]
+    if b.dim() != 2 or b.shape[0] not in (1, bs) or (a is not None and a.shape != b.shape):
+        raise RuntimeError(f"lfilter_via_fsm: b (and a) must have shape ({bs}, K); got {tuple(b.shape)}" + (f", {tuple(a.shape)}" if a is not None else ""))
+    if K > 3:
+        raise NotImplementedError(f"lfilter_via_fsm: K = {K} coefficients; orders above 2 are not supported (use sosfilt_via_fsm with "
+                                  "second-order sections)")
+    b = b.type_as(x)
+    if a is None:
+        a = torch.zeros_like(b)
+        a[:, 0] = 1.0
+    else:
+        a = a.type_as(x)
+    if K < 3:
+        pad = torch.zeros(b.shape[0], 3 - K, dtype=b.dtype, device=b.device)
+        b, a = torch.cat([b, pad], 1), torch.cat([a, pad], 1)
+    sos = torch.cat([b, a], 1).unsqueeze(1)                  # (bs, 1, 6) rows [b0 b1 b2 a0 a1 a2]
+    return SosFiltFunction.apply(sos, x)
+
+
+def _frequency_domain_helper(name, line):
+    def fn(*args, **kwargs):
+        raise NotImplementedError(
+            f"dasp_pytorch_amd.signal.{name}: the reference's frequency-sampling internals (dasp_pytorch/signal.py:{line}) have no counterpart "
+            "here - the filters are evaluated as exact recurrences (sosfilt_via_fsm, lfilter_via_fsm), not as spectra")
+    fn.__name__ = name
+    return fn
+
+
+# The reference's L1 helpers of the frequency-sampling method are not part of this package's boundary (SURVEY 8b); they exist as names
+# so that `from dasp_pytorch_amd.signal import *` fails loudly at the call, not at import. one_pole_butter_lowpass / one_pole_filter
+# are dead code in the reference (they print to stdout, SURVEY Appendix A Q18).
+fft_freqz = _frequency_domain_helper("fft_freqz", "7-11")
+fft_sosfreqz = _frequency_domain_helper("fft_sosfreqz", "14-32")
+freqdomain_fir = _frequency_domain_helper("freqdomain_fir", "35-39")
+one_pole_butter_lowpass = _frequency_domain_helper("one_pole_butter_lowpass", "169-198")
+one_pole_filter = _frequency_domain_helper("one_pole_filter", "201-239")
 
 
 def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
@@ -108,4 +112,4 @@ def _octave_band_taps(num_taps: int, sample_rate: float):
 def octave_band_filterbank(num_taps: int, sample_rate: float):
     """Octave-spaced linear-phase FIR bank, shape (12, 1, num_taps) float32 on the CPU, as the reference
     (dasp_pytorch/signal.py:42-92): lowpass 12 Hz, ten octave bandpasses 31.5 Hz .. 16 kHz, highpass 18 kHz."""
-    return torch.from_numpy(_octave_band_taps(int(num_taps), float(sample_rate))).unsqueeze(1)
+    return torch.from_numpy(_octave_band_taps(int(num_taps), float(sample_rate)).copy()).unsqueeze(1)   # a fresh tensor per call, as the reference

@@ -107,6 +107,14 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream);
 
+/* dasp_pytorch.signal.biquad (dasp_pytorch/signal.py:242-306) as a call of its own: the fp64 RBJ design the prepare calls run, for n
+ * (gain_db, cutoff_freq, q_factor) triples of one filter type. ba: (n, 6) fp64 rows [b0 b1 b2 1 a1 a2] (normalised by a0, as the
+ * reference returns them); jac: (n, 15) fp64 = d(b0 b1 b2 a1 a2)/d(gain_db, cutoff_freq, q_factor), which dasp_biquad_backward
+ * contracts with gba (n, 6), the gradient w.r.t. the rows of ba, into gparams (n, 3). */
+int dasp_biquad_design(const double* gain_db, const double* cutoff_freq, const double* q_factor, int n, int type,
+                       double sample_rate, double* ba, double* jac, void* stream);
+int dasp_biquad_backward(const double* jac, const double* gba, int n, double* gparams, void* stream);
+
 /* Few rows (B*C < 128): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
  * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, a
  * small kernel chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab), then the ordinary pass runs per

@@ -170,6 +170,24 @@ PEQ_SECTIONS = [("low_shelf", "low_shelf"), ("band0", "peaking"), ("band1", "pea
                 ("band3", "peaking"), ("high_shelf", "high_shelf")]
 
 
+def biquad_vjp(gain_db, cutoff_freq, q_factor, sample_rate, filter_type, gb, ga):
+    """Gradient of sum(b * gb) + sum(a * ga) w.r.t. (gain_db, cutoff_freq, q_factor), (bs, 3), by fp64 central differences of `biquad`
+    (the reference gets it from autograd through signal.py:255-304; the design is a smooth closed form, so differences at a relative
+    step of 1e-6 are good to ~1e-9)."""
+    ins = [np.asarray(v, np.float64).reshape(-1) for v in (gain_db, cutoff_freq, q_factor)]
+    out = np.zeros((ins[0].shape[0], 3))
+    for d in range(3):
+        h = 1e-6 * np.maximum(1.0, np.abs(ins[d]))
+        vals = []
+        for sgn in (+1.0, -1.0):
+            mod = [v.copy() for v in ins]
+            mod[d] = mod[d] + sgn * h
+            b, a = biquad(*mod, sample_rate, filter_type)
+            vals.append(np.sum(b * gb, 1) + np.sum(a * ga, 1))
+        out[:, d] = (vals[0] - vals[1]) / (2 * h)
+    return out
+
+
 def peq_sos(params, sample_rate, dtype=np.float64):
     """functional.py:211-265: params (bs, 18) in the reference's argument order -> sos (bs,6,6)."""
     params = np.asarray(params)
@@ -310,13 +328,37 @@ def distortion_vjp(x, sample_rate, drive_db, gy, dtype=np.float64):
 # compressor  (functional.py:275-399, smoothing filter through signal.py:95-133)
 
 
-def lfilter_via_fsm(x, b, a, dtype=np.float64):
-    """signal.py:95-133. x (bs,1,T), b, a (bs,K) -> y (bs,1,T)."""
+def lfilter_via_fsm(x, b, a=None, dtype=np.float64):
+    """signal.py:95-133. x (bs,1,T), b, a (bs,K) -> y (bs,1,T); a = None: FIR (H = rfft(b), :115-117)."""
     x = np.asarray(x, dtype)
     T = x.shape[-1]
     n_fft = n_fft_for(T)
-    H = fft_freqz(np.asarray(b, dtype), np.asarray(a, dtype), n_fft)
+    b = np.asarray(b, dtype)
+    H = np.fft.rfft(b, n_fft, axis=-1) if a is None else fft_freqz(b, np.asarray(a, dtype), n_fft)
     return freqdomain_fir(x, H[:, None], n_fft)[..., :T].astype(dtype)
+
+
+def lfilter_via_fsm_vjp(x, b, a, gy, dtype=np.float64):
+    """VJP of lfilter_via_fsm: (gx, gb, ga or None). With X = rfft(x_pad), H = B / A (A = 1 for an FIR):
+      gx = irfft(rfft(gy_pad) conj(H))[:T];  dL/db_j = sum_n gy_pad[n] q[(n - j) mod n_fft], q = irfft(X / A);
+      dL/da_j = -sum_n gy_pad[n] r[(n - j) mod n_fft], r = irfft(X H / A)."""
+    x, gy, b = np.asarray(x, dtype), np.asarray(gy, dtype), np.asarray(b, dtype)
+    bs, _, T = x.shape
+    K = b.shape[-1]
+    n_fft = n_fft_for(T)
+    Bf = np.fft.rfft(b, n_fft, axis=-1)
+    Af = np.fft.rfft(np.asarray(a, dtype), n_fft, axis=-1) if a is not None else np.ones_like(Bf)
+    H = Bf / Af
+    X = np.fft.rfft(x[:, 0], n_fft, axis=-1)
+    GY = np.fft.rfft(gy[:, 0], n_fft, axis=-1)
+    gx = np.fft.irfft(GY * np.conj(H), n_fft, axis=-1)[:, None, :T]
+    gpad = np.zeros((bs, n_fft), np.float64)
+    gpad[:, :T] = gy[:, 0]
+    q = np.fft.irfft(X / Af, n_fft, axis=-1)
+    r = np.fft.irfft(X * H / Af, n_fft, axis=-1)
+    gb = np.stack([np.sum(gpad * np.roll(q, j, axis=-1), axis=-1) for j in range(K)], 1)
+    ga = -np.stack([np.sum(gpad * np.roll(r, j, axis=-1), axis=-1) for j in range(K)], 1) if a is not None else None
+    return gx.astype(dtype), gb.astype(dtype), (ga.astype(dtype) if ga is not None else None)
 
 
 def _compressor_core(x, sample_rate, threshold_db, ratio, attack_ms, knee_db, makeup_gain_db, eps, lookahead, dtype):

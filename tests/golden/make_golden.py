@@ -181,6 +181,85 @@ def reverb_case(name, B, C, N, L, taps, seed, store_noise):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def norm_case(name, modname, B, C, N, seed, noise_seed=None):
+    """Processor.process_normalized (dasp_pytorch/modules.py:25-51, 70-91) on a normalised (B, P) parameter tensor: forward, grad x and
+    the gradient w.r.t. the normalised parameters themselves - the pin for dasp_pytorch_amd.modules."""
+    g = torch.Generator().manual_seed(seed)
+    mod = getattr(dasp_pytorch, modname)(SR)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    pn = torch.rand(B, mod.num_params, generator=g)
+    if modname == "Compressor":
+        pn[:, 4] = pn[:, 4].clamp_min(1e-3 / 12)          # knee_db > 0: the reference's backward is NaN at 0 (SURVEY Appendix A Q9)
+    oc = 2 if modname == "NoiseShapedReverb" else C
+    w = torch.randn(B, oc, N, generator=g)
+    out = dict(x=f32(x), pn=f32(pn), w=f32(w))
+    if noise_seed is not None:
+        out["noise_seed"] = np.int64(noise_seed)
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        pp = pn.to(dt).clone().requires_grad_(True)
+        if noise_seed is not None:
+            torch.manual_seed(noise_seed)
+        y = mod.process_normalized(xx, pp)
+        (y * w.to(dt)).sum().backward()
+        out["y" + tag], out["gx" + tag], out["gpn" + tag] = f32(y), f32(xx.grad), f32(pp.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+BIQUAD_TYPES = ["peaking", "low_shelf", "high_shelf", "low_pass", "high_pass"]
+
+
+def biquad_case(name, B, seed):
+    """signal.biquad (dasp_pytorch/signal.py:242-306), all five filter types: coefficients and the gradients of a random linear
+    functional of them w.r.t. gain_db, cutoff_freq, q_factor."""
+    g = torch.Generator().manual_seed(seed)
+    gain = torch.rand(B, 1, generator=g) * 40 - 20
+    fc = 20 + torch.rand(B, 1, generator=g) ** 2 * 20000
+    q = 0.1 + torch.rand(B, 1, generator=g) * 5.9
+    wb, wa = torch.randn(B, 3, generator=g), torch.randn(B, 3, generator=g)
+    out = dict(gain_db=f32(gain), cutoff_freq=f32(fc), q_factor=f32(q), wb=f32(wb), wa=f32(wa))
+    for t in BIQUAD_TYPES:
+        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+            ins = [v.to(dt).clone().requires_grad_(True) for v in (gain, fc, q)]
+            b, a = dasp_pytorch.signal.biquad(*ins, SR, t)
+            ((b * wb.to(dt)).sum() + (a * wa.to(dt)).sum()).backward()
+            out[f"{t}_b{tag}"], out[f"{t}_a{tag}"] = f32(b), f32(a)
+            # (B, 3): d/d gain_db, cutoff_freq, q_factor; low_pass / high_pass do not depend on gain_db (no gradient: stored as 0)
+            out[f"{t}_g{tag}"] = f32(torch.cat([v.grad if v.grad is not None else torch.zeros_like(v) for v in ins], 1))
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, sorted(out))
+
+
+def lfilter_case(name, B, N, seed):
+    """signal.lfilter_via_fsm (dasp_pytorch/signal.py:95-133) on (B, 1, N): the compressor's one-pole smoother (K = 2, :372-380),
+    a second-order IIR (K = 3) and an FIR (a = None, K = 3); forward and the gradients w.r.t. x, b, a."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 1, N, generator=g) * 2 - 1
+    w = torch.randn(B, 1, N, generator=g)
+    alpha = 0.9 + 0.095 * torch.rand(B, 1, generator=g)
+    b1p = torch.cat([1 - alpha, torch.zeros(B, 1)], 1)
+    a1p = torch.cat([torch.ones(B, 1), -alpha], 1)
+    r = 0.5 + 0.45 * torch.rand(B, 1, generator=g); th = 0.1 + 2.9 * torch.rand(B, 1, generator=g)
+    a0 = 0.5 + torch.rand(B, 1, generator=g)
+    a2 = torch.cat([torch.ones(B, 1), -2 * r * torch.cos(th), r * r], 1) * a0
+    b2 = torch.randn(B, 3, generator=g)
+    bf = torch.randn(B, 3, generator=g)
+    out = dict(x=f32(x), w=f32(w), b_onepole=f32(b1p), a_onepole=f32(a1p), b_iir2=f32(b2), a_iir2=f32(a2), b_fir=f32(bf))
+    for key, bb, aa in (("onepole", b1p, a1p), ("iir2", b2, a2), ("fir", bf, None)):
+        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+            xx = x.to(dt).clone().requires_grad_(True)
+            bt = bb.to(torch.float32).to(dt).clone().requires_grad_(True)
+            at = aa.to(torch.float32).to(dt).clone().requires_grad_(True) if aa is not None else None
+            y = dasp_pytorch.signal.lfilter_via_fsm(xx, bt, at)
+            (y * w.to(dt)).sum().backward()
+            out[f"{key}_y{tag}"], out[f"{key}_gx{tag}"], out[f"{key}_gb{tag}"] = f32(y), f32(xx.grad), f32(bt.grad)
+            if at is not None:
+                out[f"{key}_ga{tag}"] = f32(at.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, sorted(out))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     eq_case("eq_b3c2_n12000", 3, 2, 12000, 3, seed=101)
@@ -193,3 +272,10 @@ if __name__ == "__main__":
     reverb_case("rev_b2c2_n6000_l2048_t127", 2, 2, 6000, 2048, 127, seed=107, store_noise=True)
     reverb_case("rev_b1c1_n5000_l1000_t63", 1, 1, 5000, 1000, 63, seed=108, store_noise=True)
     reverb_case("rev_b1c2_n20000_default", 1, 2, 20000, 65536, 1023, seed=109, store_noise=False)
+    # round 2: the normalised-parameter API, the coefficient design and the first-order / FIR filter boundary
+    norm_case("norm_gain_b3c2_n4000", "Gain", 3, 2, 4000, seed=121)
+    norm_case("norm_eq_b3c2_n12000", "ParametricEQ", 3, 2, 12000, seed=122)
+    norm_case("norm_comp_b3c2_n12000", "Compressor", 3, 2, 12000, seed=123)
+    norm_case("norm_rev_b1c2_n6000", "NoiseShapedReverb", 1, 2, 6000, seed=124, noise_seed=5124)
+    biquad_case("biquad_types_b6", 6, seed=125)
+    lfilter_case("lfilter_b3_n9000", 3, 9000, seed=126)

