@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json metric): audio channel-samples/sec of the 6-band parametric_eq
-forward + backward at (B, C, N) = (256, 2, 131072) fp32 per GPU.
+forward + backward at (B, C, N) = (256, 2, 131072) fp32.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--launch eager|graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one call of dasp_pytorch_amd.functional.parametric_eq (coefficient design + cascade
 forward) followed by the full backward (grad wrt x and all 18 controls) on one synthetic batch that
 is already resident in HBM. Batches shard along the batch axis, one process per GPU, with no
-data-path collective (the effect has no cross-item exchange): every rank processes its own
-(256, 2, 131072) batch, so scaling is "weak" and `value` is the sum over ranks / max-over-ranks time.
+data-path collective (the effect has no cross-item exchange).
+  --scaling weak   (default) every rank processes its own (256, 2, 131072) batch; `value` = N * units / max-over-ranks time
+  --scaling strong the one 256-item batch is partitioned 256/N items per GPU; `value` = units / max-over-ranks time
+  --launch graph   the step (forward + backward, same kernels, same launches) is captured once into a HIP graph and replayed K times;
+                   eager (default) issues it from Python every step. Both are reported when --launch both.
 
 The JSON line also carries
   roofline     -- HBM roofline of the dominant kernel (the backward cascade): algorithmic bytes per
-                  launch / average launch duration measured with HIP events on the launch stream
+                  launch / average launch duration measured with HIP events on the launch stream inside the timed region
+                  (eager steps: every 4th launch of each entry point); `traffic` = HBM bytes per launch from the PMC counters,
+                  read from profiles/<round>/hbm_traffic.json only if that file was produced from the kernel sources now loaded
   roofline_*   -- the same for the forward kernel and for forward+backward together
-  cpu_baseline -- the numpy restatement of the reference's algorithm (oracle/dasp_oracle.py, kind
-                  "port") timed on this box's host on a bounded sample of the same workload.
+  cpu_baseline -- the reference itself (oracle/_ref, staged by __graft_entry__.build(); kind "reference") on all host cores on a
+                  bounded sub-batch, or, when it is not staged, the numpy restatement (oracle/dasp_oracle.py, kind "port").
+
+--dry-run-cpu is a test hook (tests/test_distributed_cpu.py): rank wiring, sharding, barriers, timing reduction and the JSON contract
+on CPU tensors over gloo with the kernels replaced by a copy; its numbers mean nothing and the line says so.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -41,6 +51,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # dasp_pytorch/modules.py:136-155 (ParametricEQ.param_ranges at sample_rate 44100), reference argument order
 PEQ_RANGES = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
               (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
+REF_ZIP = os.path.join(ROOT, "oracle", "_ref", "dasp_pytorch_ref.zip")
 
 
 def make_batch(B, C, N, seed, device):
@@ -54,8 +65,46 @@ def make_batch(B, C, N, seed, device):
     return x.to(device), params.to(device), w.to(device)
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """Oracle (numpy port of the reference's frequency-sampling algorithm + its VJP) on the host."""
+def kernel_source_hash():
+    """sha256 over the HIP sources the loaded library was built from: ties off-line counter files to the kernels they measured."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dasp_pytorch_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dasp_pytorch_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_reference(seconds_budget=25.0):
+    """The reference's own dasp_pytorch.functional.parametric_eq (imported from the archive oracle/_ref holds) forward + autograd backward
+    on all host cores, fp32, on a bounded sub-batch of the workload."""
+    if REF_ZIP not in sys.path:
+        sys.path.insert(0, REF_ZIP)
+    import dasp_pytorch.functional as RF
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, C, N = 8, 2, 131072
+    x, params, w = make_batch(B, C, N, 999, "cpu")
+
+    def step():
+        xx = x.clone().requires_grad_(True)
+        cols = [params[:, i].clone().requires_grad_(True) for i in range(18)]
+        y = RF.parametric_eq(xx, SR, *cols)
+        y.backward(w)
+    step()                                   # warm-up (FFT plans, allocator)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_all < seconds_budget and len(times) < 6):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": B * C * N / best, "unit": "channel-samples/s", "cores": cores, "kind": "reference",
+            "sample": f"dasp_pytorch.functional.parametric_eq fwd + autograd bwd, fp32, on ({B},{C},{N}) of the (256,2,131072) workload, "
+                      f"best of {len(times)} after 1 warm-up ({best:.2f} s per iteration), torch {torch.__version__} CPU, {cores} threads"}
+
+
+def cpu_baseline_port(seconds_budget=15.0):
+    """Fallback when the reference is not staged: the oracle (numpy port of the reference's frequency-sampling algorithm + its VJP)."""
     from oracle import dasp_oracle as orc
     C, N = 2, 131072
     x, params, w = (t.numpy() for t in make_batch(4, C, N, 999, "cpu"))
@@ -69,7 +118,18 @@ def cpu_baseline(seconds_budget=15.0):
     dt = time.perf_counter() - t0
     return {"value": done * C * N / dt, "unit": "channel-samples/s", "cores": 1, "kind": "port",
             "sample": f"parametric_eq fwd+vjp fp32 on ({done},{C},{N}) of the (256,2,131072) workload, {dt:.1f} s, "
-                      "numpy pocketfft single thread"}
+                      "numpy pocketfft single thread (oracle/_ref not staged: run __graft_entry__.build() where /root/reference exists)"}
+
+
+def cpu_baseline():
+    if os.path.exists(REF_ZIP):
+        try:
+            return cpu_baseline_reference()
+        except Exception as e:      # a broken archive must not cost the bench line; say what happened
+            out = cpu_baseline_port()
+            out["sample"] += f" [reference baseline failed: {type(e).__name__}: {e}]"
+            return out
+    return cpu_baseline_port()
 
 
 def _time_steps(fn, steps=30, warmup=10):
@@ -89,10 +149,10 @@ def secondary(dev):
     g = torch.Generator(device=dev).manual_seed(7)
     rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
 
-    def bench_op(name, B, C, N, make, bytes_per_cs, note=None, xmake=None):
-        x = (xmake(B, C, N) if xmake else rnd(B, C, N) * 2 - 1).requires_grad_(True)
+    def bench_op(name, B, C, N, make, bytes_per_cs, note=None, xmake=None, x_grad=True):
+        x = (xmake(B, C, N) if xmake else rnd(B, C, N) * 2 - 1).requires_grad_(x_grad)
         ctl, call = make(B)
-        w = torch.randn(B, 2 if name == "noise_shaped_reverberation" else C, N, device=dev, generator=g)
+        w = torch.randn(B, 2 if name.startswith("noise_shaped_reverberation") else C, N, device=dev, generator=g)
 
         def step():
             x.grad = None
@@ -113,7 +173,6 @@ def secondary(dev):
     rng = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]
     bench_op("compressor", 256, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20)
 
-
     def speechlike(B, C, N):   # white noise x a slow random envelope spanning -60 .. 0 dBFS (all three knee regions)
         knots = rnd(B, 1, N // 4096 + 2) * -60.0
         env_db = torch.nn.functional.interpolate(knots, size=N, mode="linear", align_corners=True)
@@ -124,6 +183,13 @@ def secondary(dev):
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
              2 * 1.354e9 / (128 * 2 * 262144),
              "device-generated noise; bytes = SURVEY 8(d) compulsory traffic with noise as an input (2 x 1.354 GB)")
+    # the headline op as the reference's chain calls it (examples/style_transfer.py:150: first effect, its input needs no gradient) and
+    # at the reference's training batch sizes (examples/style_transfer.py:403, auto_eq.py:231), where rows are cut into segments
+    peq = lambda B: ([ctl1(lo, hi)(B) for lo, hi in PEQ_RANGES], lambda x, c: D.parametric_eq(x, SR, *c))
+    bench_op("parametric_eq_controls_only", 256, 2, 131072, peq, 16, "no gradient for x (8 B fwd + 8 B bwd per channel-sample)", x_grad=False)
+    bench_op("parametric_eq_b16", 16, 2, 131072, peq, 20, "reference training batch: segmented rows")
+    bench_op("compressor_b8", 8, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20,
+             "reference training batch")
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
     xs = (rnd(16, 2, 131072) * 0.6 - 0.3).requires_grad_(True)
@@ -140,88 +206,146 @@ def secondary(dev):
     return res
 
 
+def load_traffic(shape):
+    """HBM bytes per launch from the newest profiles/r*/hbm_traffic.json whose shape and kernel-source hash match what is loaded."""
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            if tj.get("shape") == list(shape) and tj.get("kernel_source_hash") == want:
+                t = {"fwd": tj["sos_fwd_kernel"]["hbm_bytes"], "bwd": tj["sos_bwd_kernel"]["hbm_bytes"]}
+                t["both"] = t["fwd"] + t["bwd"]
+                return t, os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    print(f"bench.py: no profiles/r*/hbm_traffic.json matches shape {list(shape)} and kernel source hash {want}: roofline.traffic is null "
+          "(re-run scripts/hbm_traffic.sh on the GPU box)", file=sys.stderr)
+    return {}, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch items per GPU; strong: --batch items in total, partitioned over the GPUs (SURVEY 8e)")
+    ap.add_argument("--launch", choices=("eager", "graph", "both"), default="both",
+                    help="how the step is issued: from Python every step, as a replayed HIP graph of the same launches, or both (value = the better)")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed clock ramp before the warmup steps: the MI355X needs ~0.2 s of sustained load to leave its idle "
                          "clocks (measured: the same kernels run 1.28x slower in the first 10 ms)")
-    ap.add_argument("--batch", type=int, default=256, help="batch items per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="batch items per GPU (weak) / in total (strong)")
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other hot-path ops")
     ap.add_argument("--no-kernel-events", action="store_true", help="developer switch: do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="test hook: rank wiring on CPU tensors over gloo, kernels replaced by a copy")
     args = ap.parse_args()
 
     rank, local, world = dd.env_world()
-    if not torch.cuda.is_available():
+    dry = args.dry_run_cpu
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in dasp_pytorch_amd)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dd.init("nccl", dev)
+        dd.init("gloo" if dry else "nccl", None if dry else dev)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
 
-    B, C, N = args.batch, args.channels, args.samples
-    x, params, w = make_batch(B, C, N, 1234 + rank, dev)
+    C, N = args.channels, args.samples
+    if args.scaling == "strong":      # the one global batch, contiguous shards (distributed.shard_bounds)
+        lo, hi = dd.shard_bounds(args.batch, world, rank)
+        B, global_batch = hi - lo, args.batch
+        if B == 0:
+            raise SystemExit(f"--scaling strong: rank {rank} of {world} owns no item of a batch of {args.batch}")
+        x, params, w = make_batch(args.batch, C, N, 1234, "cpu")
+        x, params, w = (t[lo:hi].contiguous().to(dev) for t in (x, params, w))
+    else:
+        B, global_batch = args.batch, args.batch * world
+        x, params, w = make_batch(B, C, N, 1234 + rank, dev)
     x.requires_grad_(True)
     cols = [params[:, i].clone().requires_grad_(True) for i in range(18)]
+    peq = (lambda x, sr, *c: x * 1.0 + 0.0 * sum(c)[:, None, None]) if dry else D.parametric_eq
 
     def step():
         x.grad = None
         for c in cols:
             c.grad = None
-        y = D.parametric_eq(x, SR, *cols)
+        y = peq(x, SR, *cols)
         y.backward(w)
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
+
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        return dd.max_over_ranks(time.perf_counter() - t0, dev)
 
     # device clock ramp (untimed, before the W warmup steps; reported as "ramp_s")
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
+    while not dry and time.perf_counter() - t_ramp < args.ramp_seconds:
         for _ in range(10):
             step()
-        torch.cuda.synchronize()
+        sync()
     for _ in range(args.warmup):
         step()
-    fence()
-    if not args.no_kernel_events:
-        _lib.timers.start(every=4)   # HIP events around every 4th launch of each entry point, inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    ktimes = _lib.timers.stop() if not args.no_kernel_events else {"dasp_sosfilt_forward": [float("nan")], "dasp_sosfilt_backward_ex": [float("nan")]}
-    dt = dd.max_over_ranks(dt, dev)
+    ktimes = {}
+    results = {}
+    if args.launch in ("eager", "both") or dry:
+        if not args.no_kernel_events and not dry:
+            _lib.timers.start(every=4)   # HIP events around every 4th launch of each entry point, inside the timed region
+        results["eager"] = timed(step, args.steps)
+        if not args.no_kernel_events and not dry:
+            ktimes = _lib.timers.stop()
+    if args.launch in ("graph", "both") and not dry:
+        # the same step captured once (torch.cuda.graph: forward + backward on the capture stream, gradients land in static buffers)
+        # and replayed: no Python, ctypes or autograd time per step, launch gaps are the graph's
+        x.grad = None
+        for c in cols:
+            c.grad = None
+        sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y = peq(x, SR, *cols)
+            y.backward(w)
+        for _ in range(args.warmup):
+            graph.replay()
+        if not ktimes and not args.no_kernel_events:     # per-kernel durations need eager launches: a short untimed pass
+            _lib.timers.start(every=1)
+            for _ in range(20):
+                step()
+            ktimes = _lib.timers.stop()
+            for _ in range(5):
+                graph.replay()
+        results["graph"] = timed(graph.replay, args.steps)
     finite = bool(torch.isfinite(x.grad).all().item()) and all(bool(torch.isfinite(c.grad).all().item()) for c in cols)
 
     if rank == 0:
-        units = B * C * N                      # channel-samples per step per GPU
+        units = B * C * N                       # channel-samples per step on this GPU
+        total_units = global_batch * C * N      # ... over the whole job (weak: N x units; strong: the one batch)
+        mode = min(results, key=results.get)
+        dt = results[mode]
         ms = dt / args.steps * 1e3
-        value = units * world / (dt / args.steps)
-        t_fwd = float(np.mean(ktimes["dasp_sosfilt_forward"])) * 1e-3
-        t_bwd = float(np.mean(ktimes["dasp_sosfilt_backward_ex"])) * 1e-3
+        value = total_units / (dt / args.steps)
+        nan = float("nan")
+        t_fwd = float(np.mean(ktimes.get("dasp_sosfilt_forward", [nan]))) * 1e-3
+        t_bwd = float(np.mean(ktimes.get("dasp_sosfilt_backward_ex", [nan]))) * 1e-3
         t_small = sum(float(np.mean(v)) for k, v in ktimes.items() if k not in ("dasp_sosfilt_forward", "dasp_sosfilt_backward_ex")) * 1e-3
-
-        # HBM traffic per launch from the PMC counters: collected off-line (rocprofv3 --pmc passes cannot run inside
-        # this process) on the same shape and stored under profiles/; null when the shape differs
-        traffic = {}
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")))
-            if tj["shape"] == [B, C, N]:
-                traffic = {"fwd": tj["sos_fwd_kernel"]["hbm_bytes"], "bwd": tj["sos_bwd_kernel"]["hbm_bytes"]}
-                traffic["both"] = traffic["fwd"] + traffic["bwd"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_file = ({}, None) if dry else load_traffic((B, C, N))
 
         def roof(bytes_per_sample, t, which=None):
             a = bytes_per_sample * units / t / 1e9
@@ -231,21 +355,25 @@ def main():
         out = {
             "metric": "audio-samples/sec fwd+bwd, 6-band parametric_eq @ (256,2,131072)",
             "value": value, "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "ramp_s": args.ramp_seconds,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "ramp_s": args.ramp_seconds,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"parametric_eq fwd+bwd (grad x + 18 controls) on ({B},{C},{N}) fp32 per GPU, sr 44100, "
-                                   "controls ~ U(ParametricEQ ranges)", "global_batch": B * world,
-                       "parallelism": f"batch-shard x{world}, no collective"},
-            "roofline": dict(roof(12, t_bwd, "bwd"), kernel="sos_bwd_kernel<6>", ms=round(t_bwd * 1e3, 4),
+                                   "controls ~ U(ParametricEQ ranges)", "global_batch": global_batch,
+                       "parallelism": f"batch-shard x{world}, no collective", "launch": mode},
+            "launch_ms_per_step": {k: round(v / args.steps * 1e3, 5) for k, v in results.items()},
+            "roofline": dict(roof(12, t_bwd, "bwd"), kernel="sos_bwd_kernel<6> (designed-cascade variant)", ms=round(t_bwd * 1e3, 4),
                              algorithmic_bytes=12 * units),
             "roofline_fwd": dict(roof(8, t_fwd, "fwd"), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),
             "roofline_fwd_bwd": dict(roof(20, t_fwd + t_bwd, "both"), ms=round((t_fwd + t_bwd) * 1e3, 4), algorithmic_bytes=20 * units),
             "small_kernels_ms": round(t_small * 1e3, 4),
+            "traffic_file": traffic_file, "kernel_source_hash": kernel_source_hash(),
             "finite": finite,
         }
-        if world == 1 and not args.no_secondary:
+        if dry:
+            out["dry_run"] = "CPU wiring test: kernels replaced by a copy, numbers are meaningless"
+        if world == 1 and not args.no_secondary and not dry:
             out["secondary"] = secondary(dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:

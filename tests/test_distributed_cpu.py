@@ -87,3 +87,29 @@ def test_bench_refuses_without_gpu_and_parses_contract():
         pytest.skip("GPU present")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
     assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_rank_wiring_under_torchrun(scaling):
+    """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 ...), on CPU over gloo with the kernels replaced by a copy (--dry-run-cpu): rendezvous, sharding (weak: every rank its
+    own batch; strong: the one batch partitioned), barriers, max-over-ranks timing, and exactly one JSON line from rank 0 with the
+    contract's keys."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--scaling", scaling, "--dry-run-cpu", "--batch", "6", "--samples", "2048"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == scaling and out["dry_run"]
+    per_gpu = 6 if scaling == "weak" else 3
+    assert out["config"]["global_batch"] == (12 if scaling == "weak" else 6)
+    assert f"({per_gpu},2,2048)" in out["config"]["workload"]
+    assert abs(out["value"] - out["config"]["global_batch"] * 2 * 2048 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
