@@ -81,7 +81,6 @@ def cpu_baseline_reference(seconds_budget=25.0):
         sys.path.insert(0, REF_ZIP)
     import dasp_pytorch.functional as RF
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     B, C, N = 8, 2, 131072
     x, params, w = make_batch(B, C, N, 999, "cpu")
 
@@ -90,17 +89,27 @@ def cpu_baseline_reference(seconds_budget=25.0):
         cols = [params[:, i].clone().requires_grad_(True) for i in range(18)]
         y = RF.parametric_eq(xx, SR, *cols)
         y.backward(w)
-    step()                                   # warm-up (FFT plans, allocator)
-    times = []
+    # torch's CPU FFTs and elementwise ops stop scaling well before a 256-thread host is used up (measured on a gpurun box: 18.7 s per
+    # iteration with 256 threads): a few thread counts are tried inside the time budget, all cores included, and the best one reported
+    tried = {}
     t_all = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_all < seconds_budget and len(times) < 6):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": B * C * N / best, "unit": "channel-samples/s", "cores": cores, "kind": "reference",
+    for threads in sorted({min(cores, 16), min(cores, 64), cores}):
+        if tried and time.perf_counter() - t_all > seconds_budget:
+            break
+        torch.set_num_threads(threads)
+        step()                               # warm-up (FFT plans, allocator, thread pool)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        tried[threads] = min(times)
+    threads = min(tried, key=tried.get)
+    best = tried[threads]
+    return {"value": B * C * N / best, "unit": "channel-samples/s", "cores": threads, "kind": "reference",
             "sample": f"dasp_pytorch.functional.parametric_eq fwd + autograd bwd, fp32, on ({B},{C},{N}) of the (256,2,131072) workload, "
-                      f"best of {len(times)} after 1 warm-up ({best:.2f} s per iteration), torch {torch.__version__} CPU, {cores} threads"}
+                      f"best of 2 after 1 warm-up per thread count, s per iteration by threads: "
+                      + ", ".join(f"{k}: {v:.2f}" for k, v in tried.items()) + f" (host has {cores}); torch {torch.__version__} CPU"}
 
 
 def cpu_baseline_port(seconds_budget=15.0):
@@ -163,6 +172,12 @@ def secondary(dev):
         cs = B * C * N
         res[name] = {"shape": [B, C, N], "ms_fwd_bwd": round(t * 1e3, 3), "channel_samples_per_s": cs / t,
                      "algorithmic_GBps": round(bytes_per_cs * cs / t / 1e9, 1), "frac_of_8TBps": round(bytes_per_cs * cs / t / 1e9 / HBM_PEAK_GBS, 4)}
+        # GPU time of the step's library calls (HIP events around every C entry point): at small batches the eager wall time above is
+        # the host's (autograd + launches, ~0.2 ms per step), not the kernels'
+        _lib.timers.start(every=1)
+        for _ in range(10):
+            step()
+        res[name]["gpu_ms_fwd_bwd"] = round(sum(sum(v) for v in _lib.timers.stop().values()) / 10, 4)
         if note:
             res[name]["note"] = note
         del x, w
@@ -230,8 +245,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch items per GPU; strong: --batch items in total, partitioned over the GPUs (SURVEY 8e)")
-    ap.add_argument("--launch", choices=("eager", "graph", "both"), default="both",
-                    help="how the step is issued: from Python every step, as a replayed HIP graph of the same launches, or both (value = the better)")
+    ap.add_argument("--launch", choices=("eager", "graph", "both"), default="eager",
+                    help="how the step is issued: from Python every step (default), as a replayed HIP graph of the same launches, or both "
+                         "(value = the better; measured r02: eager 0.4107 ms, graph 0.4145 ms - the step is GPU-bound either way)")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed clock ramp before the warmup steps: the MI355X needs ~0.2 s of sustained load to leave its idle "
                          "clocks (measured: the same kernels run 1.28x slower in the first 10 ms)")

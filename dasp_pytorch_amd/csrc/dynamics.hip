@@ -149,12 +149,19 @@ __device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_v
 // ------------------------------------------------------------------------------------------------
 // Forward. x, y (B, C, N); carries (B, nt) state entering each tile (may be null); lin_buf (B, N)
 // receives the linear gain when lookahead > 0 (the backward needs it at shifted positions).
-template <int MODE, int W>
+// SEG (few batch items: one workgroup per item leaves the chip idle - the reference trains with 8 to 32 items, examples/
+// style_transfer.py:403): 0 = one workgroup per item; otherwise one workgroup per (item, segment of Tseg tiles), as for the biquad
+// cascade (sosfilt.hip): 2 = scan-only pre-pass from a zero state (side chain, gain computer, scans; nothing stored) that leaves the
+// segment's end state in zseg[item][segment]; 1 = the ordinary pass from segstart[item][segment], which dyn_chain_kernel computes
+// from the z of the segments before it (the smoothing state is one float per item: start(g+1) = alpha^(samples per segment) start(g) + z(g)).
+template <int MODE, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W)
 dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y, float* __restrict__ carries,
-               float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps) {
+               float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
     __shared__ float lds[W * 4];
-    const int lane = lane_id(), wave = wave_id(), b = blockIdx.x;
+    const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt;
     const DynItem it = load_item(ctl, b, sample_rate, eps);
     const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
     const float* __restrict__ xb = x + (size_t)b * C * N;
@@ -162,8 +169,8 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
     const int mb_in = wave * 4, mb_out = ((wave + 1) % W) * 4;
     for (int i = threadIdx.x; i < W * 4; i += 64 * W) lds[i] = 0.f;
     __syncthreads();
-    float Kreg = 0.f;
-    for (int t = wave; t < nt; t += W) {
+    float Kreg = SEG == 1 ? segstart[(size_t)b * G + seg] : 0.f;
+    for (int t = t0 + wave; t < t1; t += W) {
         const long base = (long)t * DY_TS;
         const bool fast = vec && base + DY_TS <= N;
         DYN_PRIO(1);
@@ -189,16 +196,17 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
             E[j] = lane_scan(e, it, pw16, pw32);
         }
         float K;
-        if (W == 1) K = Kreg;
-        else if (t == 0) K = 0.f;
+        if (W == 1 || t == t0) K = Kreg;                  // (only wave 0 sees t == t0: its Kreg is the start state)
         else { float dummy; mbox_wait(lds, mb_in, t, K, dummy); }
         {   // carry for the next tile: the only work on the cross-wave serial chain
             float Kn = K;
 #pragma unroll
             for (int j = 0; j < DY_SUB; ++j) Kn = fmaf(it.a256, Kn, read_lane(E[j], 63));
             if (W == 1) Kreg = Kn;
-            else if (t + 1 < nt) mbox_publish(lds, mb_out, Kn, 0.f, t + 1);
+            else if (t + 1 < t1) mbox_publish(lds, mb_out, Kn, 0.f, t + 1);
+            if (SEG == 2 && t + 1 == t1 && lane == 0) zseg[(size_t)b * G + seg] = Kn;      // the segment's end state
         }
+        if (SEG == 2) { DYN_PRIO(0); continue; }          // scan-only pre-pass
         if (carries && lane == 0) carries[(size_t)b * nt + t] = K;
         DYN_PRIO(0);
         // exact smoothed gain per sample -> linear gain
@@ -236,14 +244,19 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
 // LDS ring; the x / gy samples of its NEXT tile are in flight (global_load_lds, no staging registers) while it works on the current
 // one, gy is read from the slot a second time for the output stage instead of from memory, and the loop-top wait lets the previous
 // tile's stores stay outstanding (vmcnt is in-order on gfx9).
-template <int MODE, int W, bool DMA>
+// SEG as in the forward kernel: 2 = adjoint scan-only pre-pass from a zero adjoint state (everything up to the adjoint lane scans;
+// no gradients, no stores) leaving the adjoint state below the segment in zseg[item][segment]; 1 = the ordinary pass from
+// segstart[item][segment], the adjoint state entering the segment from above; partial sums per (item, segment, wave).
+template <int MODE, int W, bool DMA, int SEG = 0>
 __global__ void __launch_bounds__(64 * W)
 dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const float* __restrict__ gy,
                const float* __restrict__ carries, const float* __restrict__ lin_buf, float* __restrict__ gx,
-               float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps) {
+               float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
     __shared__ float lds[W * 4];
     __shared__ float ring[DMA ? W * DY_RING : 1];
-    const int lane = lane_id(), wave = wave_id(), b = blockIdx.x;
+    const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // tiles t1 - 1 .. t0
     const DynItem it = load_item(ctl, b, sample_rate, eps);
     const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
     const float* __restrict__ xb = x + (size_t)b * C * N;
@@ -252,7 +265,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
     const int mb_in = wave * 4, mb_out = ((wave + 1) % W) * 4;
     for (int i = threadIdx.x; i < W * 4; i += 64 * W) lds[i] = 0.f;
     __syncthreads();
-    float Rreg = 0.f;
+    float Rreg = SEG == 1 ? segstart[(size_t)b * G + seg] : 0.f;
     float acc_t = 0.f, acc_r = 0.f, acc_a = 0.f, acc_w = 0.f, acc_m = 0.f;
     // DMA path: slot layout [x c0 | x c1 | gy c0 | gy c1], each DY_TS floats in tile order, then the carry entering the tile.
     // Nothing on this path is an ordinary global load: the compiler would answer one in flight next to the DMA with vmcnt(0) waits.
@@ -274,10 +287,10 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
         }
     };
     int pending_stores = 0;
-    if (DMA && wave < nt) prefetch(nt - 1 - wave, 0);
+    if (DMA && wave < nr) prefetch(t1 - 1 - wave, 0);
     int slot = 0;
-    for (int r = wave; r < nt; r += W, slot ^= 1) {
-        const int t = nt - 1 - r;
+    for (int r = wave; r < nr; r += W, slot ^= 1) {
+        const int t = t1 - 1 - r;
         const long base = (long)t * DY_TS;
         const bool fast = vec && base + DY_TS <= N, fast_in = fast && lk == 0;
         DYN_PRIO(1);
@@ -293,7 +306,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             else if (pending_stores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             Kcur = cur[4 * DY_TS];
-            if (r + W < nt) prefetch(t - W, slot ^ 1);
+            if (r + W < nr) prefetch(t - W, slot ^ 1);
             for (int c = 0; c < C; ++c) {
 #pragma unroll
                 for (int j = 0; j < DY_SUB; ++j) {
@@ -355,8 +368,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
         }
         DTRACE(3);
         float R;
-        if (W == 1) R = Rreg;
-        else if (r == 0) R = 0.f;
+        if (W == 1 || r == 0) R = Rreg;                   // (only wave 0 sees r == 0: its Rreg is the adjoint state entering from above)
         else { float dummy; mbox_wait(lds, mb_in, t + 1, R, dummy); }
         DTRACE(4);
         {
@@ -364,9 +376,11 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
 #pragma unroll
             for (int j = DY_SUB - 1; j >= 0; --j) Rn = fmaf(it.a256, Rn, read_lane(Er[j], 63));
             if (W == 1) Rreg = Rn;
-            else if (t > 0) mbox_publish(lds, mb_out, Rn, 0.f, t);
+            else if (t > t0) mbox_publish(lds, mb_out, Rn, 0.f, t);
+            if (SEG == 2 && t == t0 && lane == 0) zseg[(size_t)b * G + seg] = Rn;       // the adjoint state below the segment
         }
         DYN_PRIO(0);
+        if (SEG == 2) { pending_stores = 0; continue; }    // adjoint scan-only pre-pass
         DTRACE(5);
 #pragma unroll
         for (int j = DY_SUB - 1; j >= 0; --j) {
@@ -409,9 +423,32 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
         pending_stores = fast ? C * DY_SUB : 0;       // a full tile issues exactly C * DY_SUB wave-wide stores; anything else: wait for all
         DTRACE(7);
     }
-    float* po = partials + ((size_t)b * W + wave) * 5;
+    if (SEG == 2) return;
+    float* po = partials + (((size_t)b * G + seg) * W + wave) * 5;
     const float v0 = wave_sum(acc_t), v1 = wave_sum(acc_r), v2 = wave_sum(acc_a), v3 = wave_sum(acc_w), v4 = wave_sum(acc_m);
     if (lane == 0) { po[0] = v0; po[1] = v1; po[2] = v2; po[3] = v3; po[4] = v4; }
+}
+
+// Chains the segments of an item: start(g + 1) = a start(g) + z(g) upwards (adjoint = 0), aend(g - 1) = a aend(g) + za(g) downwards
+// (adjoint = 1), a = alpha^(samples per segment) in fp64. One thread per item.
+__global__ void dyn_chain_kernel(const float* __restrict__ ctl, const float* __restrict__ z, float* __restrict__ start, int B, int G,
+                                 long seg_samples, double sample_rate, int adjoint) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
+    const double a = exp(-2.1972245773362196 / nat * (double)seg_samples);
+    double s = 0.0;
+    if (!adjoint) {
+        for (int g = 0; g < G; ++g) {
+            start[(size_t)b * G + g] = (float)s;
+            s = a * s + (double)z[(size_t)b * G + g];
+        }
+    } else {
+        for (int g = G - 1; g >= 0; --g) {
+            start[(size_t)b * G + g] = (float)s;
+            s = a * s + (double)z[(size_t)b * G + g];
+        }
+    }
 }
 
 // gctl (B, 5): dL/d threshold_db, ratio, attack_ms, knee_db, makeup_gain_db
@@ -496,6 +533,75 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
     int st = dy_check();
     if (st != DASP_OK) return st;
     hipLaunchKernelGGL(dyn_finalize_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, ctl, B, kDW, sample_rate, gctl);
+    return dy_check();
+}
+
+// ---- segmented items (few batch items) -------------------------------------------------------------------------------------------
+// One workgroup per item leaves most of the chip idle below ~128 items; every item can be cut into segments of Tseg tiles that run as
+// independent workgroups: scan-only pre-pass (end state of every segment from a zero start), dyn_chain_kernel (the scalar smoothing
+// state chained through alpha^(samples per segment)), then the ordinary pass per segment. Same results (the chain runs in fp64).
+//   Tseg   = dasp_dyn_segment_tiles(B, N): proposed tiles per segment (a power of two), 0 = use the plain calls
+//   segbuf = 2 * B * dasp_dyn_segments(N, Tseg) floats of scratch; carries as for the plain calls;
+//   partials of the backward pass: dasp_dyn_partial_floats(B * segments) floats.
+long dasp_dyn_segment_tiles(long B, long N) {
+    const long nt = dasp_dyn_num_tiles(N);
+    if (B <= 0 || B >= 128 || nt < 2 * kDWF) return 0;
+    long T = kDWF;                                     // at least one tile per forward wave
+    while (B * ((nt + T - 1) / T) > 1024 && T < nt) T *= 2;
+    return (nt + T - 1) / T > 1 ? T : 0;
+}
+long dasp_dyn_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_dyn_num_tiles(N) + Tseg - 1) / Tseg : 1; }
+
+int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
+                              int C, long N, double sample_rate, float eps, int lookahead, long Tseg, void* stream) {
+    if (!x || !ctl || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1) || Tseg <= 0) return DASP_ERR_ARG;
+    if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
+    if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_dyn_num_tiles(N), G = (int)dasp_dyn_segments(N, Tseg);
+    const int vec = (N % 4 == 0) && dy_al16(x) && dy_al16(y) && (!lin_buf || dy_al16(lin_buf));
+    float* z = segbuf;
+    float* start = segbuf + (size_t)B * G;
+    hipStream_t st = (hipStream_t)stream;
+    float* lb = lookahead > 0 ? lin_buf : nullptr;
+#define DASP_DYN_FWD_SEG(MODE_)                                                                                                                  \
+    hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 2>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, (float*)nullptr, (float*)nullptr,          \
+                       (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z);               \
+    hipLaunchKernelGGL(dyn_chain_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ctl, (const float*)z, start, B, G, (long)Tseg * DY_TS,            \
+                       sample_rate, 0);                                                                                                         \
+    hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 1>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, y, carries, lb, C, (int)N, nt, vec,        \
+                       lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
+    if (mode == 0) { DASP_DYN_FWD_SEG(0); } else { DASP_DYN_FWD_SEG(1); }
+#undef DASP_DYN_FWD_SEG
+    return dy_check();
+}
+
+int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
+                               float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N, double sample_rate, float eps,
+                               int lookahead, long Tseg, void* stream) {
+    if (!x || !ctl || !gy || !carries || !gx || !gctl || !partials || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
+        (mode != 0 && mode != 1) || Tseg <= 0)
+        return DASP_ERR_ARG;
+    if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
+    if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_dyn_num_tiles(N), G = (int)dasp_dyn_segments(N, Tseg);
+    const int vec = (N % 4 == 0) && dy_al16(x) && dy_al16(gy) && dy_al16(gx);
+    const bool dma = vec && lookahead == 0 && C <= 2;
+    float* z = segbuf;
+    float* start = segbuf + (size_t)B * G;
+    hipStream_t st = (hipStream_t)stream;
+#define DASP_DYN_BWD_SEG(MODE_, DMA_)                                                                                                            \
+    hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 2>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, (float*)nullptr, \
+                       (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z);               \
+    hipLaunchKernelGGL(dyn_chain_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ctl, (const float*)z, start, B, G, (long)Tseg * DY_TS,            \
+                       sample_rate, 1);                                                                                                         \
+    hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 1>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials,    \
+                       C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
+    if (mode == 0) { if (dma) { DASP_DYN_BWD_SEG(0, true); } else { DASP_DYN_BWD_SEG(0, false); } }
+    else { if (dma) { DASP_DYN_BWD_SEG(1, true); } else { DASP_DYN_BWD_SEG(1, false); } }
+#undef DASP_DYN_BWD_SEG
+    int rc = dy_check();
+    if (rc != DASP_OK) return rc;
+    hipLaunchKernelGGL(dyn_finalize_kernel, dim3((B + 127) / 128), dim3(128), 0, st, partials, ctl, B, kDW * G, sample_rate, gctl);
     return dy_check();
 }
 

@@ -332,11 +332,18 @@ class DynamicsFunction(torch.autograd.Function):
             need = any(ctx.needs_input_grad)
             carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
             lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
-            call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
-                 float(eps), int(lookahead), stream())
+            # few items: every item is cut into segments that run as independent workgroups (dasp_hip.h, "Few batch items")
+            tseg = 0 if os.environ.get("DASP_DYN_SEGMENT", "auto") == "0" else int(os.environ.get("DASP_DYN_SEGMENT_TILES") or L.dasp_dyn_segment_tiles(B, N))
+            segbuf = torch.empty(2 * B * L.dasp_dyn_segments(N, tseg), dtype=torch.float32, device=x.device) if tseg else None
+            if tseg:
+                call("dasp_dynamics_forward_seg", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), ptr(segbuf), B, C, N, float(sample_rate),
+                     float(eps), int(lookahead), tseg, stream())
+            else:
+                call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
+                     float(eps), int(lookahead), stream())
             if need:
                 ctx.save_for_backward(x32, ctl, carries, lin if lin is not None else torch.empty(0, device=x.device))
-                ctx.cfg = (mode, float(sample_rate), float(eps), int(lookahead))
+                ctx.cfg = (mode, float(sample_rate), float(eps), int(lookahead), tseg)
         return y.to(x.dtype)
 
     @staticmethod
@@ -347,14 +354,20 @@ class DynamicsFunction(torch.autograd.Function):
             return (torch.empty_like(gy), None, None, None, None) + tuple(torch.zeros(shape, dtype=dt, device=gy.device) for dt, shape in cm)
         L = _lib.lib()
         x32, ctl, carries, lin = ctx.saved_tensors
-        mode, sr, eps, look = ctx.cfg
+        mode, sr, eps, look, tseg = ctx.cfg
         B, C, N = x32.shape
         with torch.cuda.device(x32.device):
             gx = torch.empty_like(x32)
             gctl = torch.empty(B, 5, dtype=torch.float32, device=x32.device)
-            partials = torch.empty(L.dasp_dyn_partial_floats(B), dtype=torch.float32, device=x32.device)
-            call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
-                 ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
+            G = int(L.dasp_dyn_segments(N, tseg))
+            partials = torch.empty(L.dasp_dyn_partial_floats(B * G), dtype=torch.float32, device=x32.device)
+            if tseg:
+                segbuf = torch.empty(2 * B * G, dtype=torch.float32, device=x32.device)
+                call("dasp_dynamics_backward_seg", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
+                     ptr(gx), ptr(gctl), ptr(partials), ptr(segbuf), B, C, N, sr, eps, look, tseg, stream())
+            else:
+                call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
+                     ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
         g = gctl.t().contiguous()      # rows: threshold, ratio, attack, knee, makeup
         rows = {0: g[0], 1: g[1], 2: g[2], 4: g[3], 5: g[4]}
         outs = []

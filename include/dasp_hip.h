@@ -179,6 +179,19 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
                            const float* lin_buf, float* gx, float* gctl, float* partials, int B, int C, long N,
                            double sample_rate, float eps, int lookahead, void* stream);
 
+/* Few batch items (B < 128; the reference trains with 8 to 32: examples/style_transfer.py:403, auto_eq.py:231): one workgroup per item
+ * would leave most of the chip idle, so every item is cut into segments of Tseg tiles that run as independent workgroups - scan-only
+ * pre-pass, a scalar chain through alpha^(samples per segment) in fp64, then the ordinary pass per segment; same results.
+ *   Tseg = dasp_dyn_segment_tiles(B, N) (a power of two; 0 = use the plain calls); segbuf = 2 * B * dasp_dyn_segments(N, Tseg) floats of
+ *   scratch; carries as above; partials of the backward pass: dasp_dyn_partial_floats(B * dasp_dyn_segments(N, Tseg)) floats. */
+long dasp_dyn_segment_tiles(long B, long N);
+long dasp_dyn_segments(long N, long Tseg);
+int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf,
+                              int B, int C, long N, double sample_rate, float eps, int lookahead, long Tseg, void* stream);
+int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
+                               const float* lin_buf, float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N,
+                               double sample_rate, float eps, int lookahead, long Tseg, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Noise-shaped reverberation.  Replaces dasp_pytorch.functional.noise_shaped_reverberation
  * (dasp_pytorch/functional.py:406-577): grouped FIR filter bank over white noise (:548-558),

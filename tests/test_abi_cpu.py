@@ -99,3 +99,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_dynamics_segment_planning():
+    """Host-side planning of the segmented compressor path (no launch): few items of a long signal are cut into power-of-two runs of at
+    least one tile per forward wave so that items * segments fills the chip; many items or short signals keep one workgroup per item."""
+    L = _lib.lib()
+    T = 512                                                    # samples per compressor tile
+    assert L.dasp_dyn_num_tiles(T) == 1 and L.dasp_dyn_num_tiles(T + 1) == 2
+    N = 512 * T
+    assert L.dasp_dyn_segment_tiles(256, N) == 0 and L.dasp_dyn_segment_tiles(128, N) == 0      # enough items
+    assert L.dasp_dyn_segment_tiles(8, 31 * T) == 0                                              # too short to cut
+    for B in (1, 2, 8, 16, 32, 100):
+        t = L.dasp_dyn_segment_tiles(B, N)
+        g = L.dasp_dyn_segments(N, t)
+        assert t >= 16 and t & (t - 1) == 0 and g == -(-512 // t) and g > 1 and B * g <= 1024
+    assert L.dasp_dyn_segments(N + 1, 16) == 33 and L.dasp_dyn_segments(N, 0) == 1
+    assert L.dasp_dyn_partial_floats(4 * 33) == 33 * L.dasp_dyn_partial_floats(4)

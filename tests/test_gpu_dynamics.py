@@ -169,3 +169,38 @@ def test_config3_full_size_properties(D):
     for c in cols: c.grad = None
     y2 = D.compressor(xt, SR, *cols); y2.backward(2 * w)
     assert torch.allclose(xt.grad, 2 * gx1, rtol=1e-6, atol=0) and all(torch.allclose(c.grad, 2 * g, rtol=1e-5, atol=1e-12) for c, g in zip(cols, g1))
+
+
+@pytest.mark.parametrize("B,C,N,look,tiles,mode", [(2, 2, 40000, 0, None, "compressor"), (3, 1, 65536, 0, 32, "compressor"), (1, 2, 262144, 0, None, "compressor"),
+                                                   (2, 2, 33333, 5, 16, "compressor"), (2, 1, 16384 + 512 + 3, 0, 16, "expander"), (8, 2, 262144, 0, None, "compressor")])
+def test_segmented_items_equal_plain_items(D, monkeypatch, B, C, N, look, tiles, mode):
+    """Few batch items: the segmented kernels (scan-only pre-pass, scalar chain through alpha^(samples per segment), per-segment pass;
+    dasp_hip.h "Few batch items") give what one workgroup per item gives - outputs, input gradients and control gradients to fp32
+    rounding of the chained state - on full and ragged lengths, with look-ahead (the register-staged backward variant), for the
+    expander, and with a last segment shorter than the others; and the segmented path agrees with the oracle."""
+    rng = np.random.default_rng(B * 1000 + N)
+    x = speechlike(rng, B, C, N)
+    w = rng.standard_normal((B, C, N)).astype(np.float32)
+    p = rand_params(rng, B)
+    p[0, 2] = 100.0                                               # slowest smoothing: the segment chain must carry real state
+    fn = D.compressor if mode == "compressor" else D.expander
+
+    def go(seg):
+        monkeypatch.setenv("DASP_DYN_SEGMENT", seg)
+        if tiles:
+            monkeypatch.setenv("DASP_DYN_SEGMENT_TILES", str(tiles))
+        else:
+            monkeypatch.delenv("DASP_DYN_SEGMENT_TILES", raising=False)
+        return run(fn, x, p, w, look)
+    yp, gxp, gpp = go("0")
+    ys, gxs, gps = go("auto")
+    from dasp_pytorch_amd import _lib
+    assert tiles or _lib.lib().dasp_dyn_segment_tiles(B, N) > 0            # the planner does cut these shapes
+    assert np.abs(ys - yp).max() <= 2e-6 * np.abs(yp).max()
+    assert np.abs(gxs - gxp).max() <= 5e-6 * np.abs(gxp).max()
+    for j in range(6):
+        assert np.abs(gps[:, j] - gpp[:, j]).max() <= 2e-4 * max(np.abs(gpp[:, j]).max(), 1e-12), j
+    if mode == "compressor" and N <= 70000:
+        pd = p.astype(np.float64)
+        yo = orc.compressor(x, SR, *[pd[:, i] for i in range(6)], lookahead_samples=look)
+        assert linf_peak(ys, yo).max() < 2e-5

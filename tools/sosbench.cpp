@@ -122,6 +122,10 @@ int main(int argc, char** argv) {
                    tr[9] - tr[8], tr[10] - tr[9], tr[11] - tr[10], tr[12] - tr[11], tr[13] - tr[12], tr[14] - tr[13]);
         }
     }
+    if (peq) {   // the spot check below knows the raw-sos filters only (the designed ones are checked by the GPU tests)
+        printf("check: skipped (DASP_PEQ)\n");
+        return 0;
+    }
     // correctness spot-check on a few rows (first, a middle one, last)
     std::vector<float> y(n), gx(n);
     CK(hipMemcpy(y.data(), dy, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gx.data(), dgx, n * 4, hipMemcpyDeviceToHost));
