@@ -66,11 +66,12 @@ def make_batch(B, C, N, seed, device):
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources the loaded library was built from: ties off-line counter files to the kernels they measured."""
+    """sha256 over the HIP sources of the cascaded-biquad kernels the loaded library was built from (csrc/sosfilt.hip + common.hpp): ties
+    the off-line counter file to the kernels it measured."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "dasp_pytorch_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dasp_pytorch_amd", "csrc", "*.hpp"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in ("sosfilt.hip", "common.hpp"):
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "dasp_pytorch_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -76,7 +76,7 @@ SIGNATURES = {
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
     "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_backward": (_i, [_p] * 20 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_backward": (_i, [_p] * 19 + [_i, _l, _i, _i, _i, _p]),
 }
 
 

@@ -28,6 +28,7 @@
 // d ir = first half of IFFT(sum_k GW_k conj(X_k)), with X_k recomputed from the saved column transforms A.
 #include "common.hpp"
 #include "fft_lds.hpp"
+#include <cstdlib>
 
 namespace dasp {
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ int xcd_tile(int bx, int nx) { return (nx & 7) ? bx :
 
 // Column pass, time -> A[ka][jb]. grid (NA * 512 / 4096 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
-//                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of mix * gy, k = 2p, 2p+1
+//                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of gy, k = 2p, 2p+1
 //                                 MODE 2: zero-padded impulse responses (L samples per row), imaginary part 0
 template <int MODE>
 __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
     const int p = blockIdx.y;
     const long sig = blockIdx.z;
     const int jb = xcd_tile(blockIdx.x, gridDim.x) * g.TC + g.c;
-    const float scale = MODE == 1 ? mix[sig >> 1] : 1.f;
+    (void)mix;
+    constexpr float scale = 1.f;
     float r[8], i[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -274,13 +276,15 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
 // Inverse column pass + epilogue. 1024 threads, 8192-element tiles; thread (j, c) as in conv_load_kernel; registers q < 4 are the lower half of the frame
 // (r = (j + T q) 512 + jb < Lb), q >= 4 the upper half (r + Lb).
 //   MODE 0  grid (tiles, signals): for p = 0..: y[2p Lb + r] = Re lo + carry, y[(2p+1) Lb + r] = Im lo + Re hi, carry = Im hi;
-//           then y = x + mix (wet - x) (:575); wet saved for the mix gradient when `wet` is not null
-//   MODE 1  grid (tiles, pairs, signals): gx[2p Lb + r] = (1 - mix) gy + Re lo, gx[(2p+1) Lb + r] = (1 - mix) gy + Im lo;
-//           mix_part[sig][p * tiles + tile] = sum gy (wet - x)
-//   MODE 2  grid (tiles, signals): gir[sig][r] = Re lo, r < L
+//           then y = x + mix (wet - x) (:575)
+//   MODE 1  grid (tiles, pairs, signals): with c = the correlation of gy with the impulse response (Re lo / Im lo of the frame),
+//           gx[2p Lb + r] = (1 - mix) gy + mix c and likewise for block 2p+1;  mix_part[sig][p * tiles + tile] = sum x (c - gy):
+//           d loss / d mix = sum gy (wet - x) and sum gy wet = sum x c over a whole signal (the wet path and c are adjoint maps), so the
+//           wet signal is not kept for the backward pass
+//   MODE 2  grid (tiles, signals): gir[sig][r] = mix Re lo, r < L
 template <int MODE>
 __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
-                                                          const float* __restrict__ gy, const float* __restrict__ mix, float* __restrict__ wet,
+                                                          const float* __restrict__ gy, const float* __restrict__ mix,
                                                           float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L) {
     __shared__ f2 lds[ColsGeom::LDS];
     __shared__ float red[ColsGeom::T / 64];
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
     const long sig = MODE == 1 ? blockIdx.z : blockIdx.y;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const float inv = 1.f / (float)d.n1;
-    const float m = MODE == 2 ? 0.f : mix[sig >> 1];
+    const float m = mix[sig >> 1];
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
     float macc = 0.f;
     const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
         for (int q = 0; q < 4; ++q) {
             const int rr = (gl.j + gl.T * q) * CV_NB + jbl;          // < Lb
             if (MODE == 2) {
-                if (rr < L) out[sig * L + rr] = r[q] * inv;
+                if (rr < L) out[sig * L + rr] = m * r[q] * inv;
             } else {
                 const long na = (long)(2 * p) * d.Lb + rr, nbk = na + d.Lb;
                 if (MODE == 0) {
@@ -316,23 +320,21 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
                     if (na < d.N) {
                         const float xv = x[sig * d.N + na];
                         out[sig * d.N + na] = fmaf(m, wa - xv, xv);
-                        if (wet) wet[sig * d.N + na] = wa;
                     }
                     if (nbk < d.N) {
                         const float xv = x[sig * d.N + nbk];
                         out[sig * d.N + nbk] = fmaf(m, wb - xv, xv);
-                        if (wet) wet[sig * d.N + nbk] = wb;
                     }
                 } else {
                     if (na < d.N) {
-                        const float gv = gy[sig * d.N + na];
-                        out[sig * d.N + na] = fmaf(1.f - m, gv, r[q] * inv);      // the windows already carry the factor mix
-                        macc = fmaf(gv, wet[sig * d.N + na] - x[sig * d.N + na], macc);
+                        const float gv = gy[sig * d.N + na], c = r[q] * inv;
+                        out[sig * d.N + na] = fmaf(m, c - gv, gv);
+                        macc = fmaf(x[sig * d.N + na], c - gv, macc);
                     }
                     if (nbk < d.N) {
-                        const float gv = gy[sig * d.N + nbk];
-                        out[sig * d.N + nbk] = fmaf(1.f - m, gv, i[q] * inv);
-                        macc = fmaf(gv, wet[sig * d.N + nbk] - x[sig * d.N + nbk], macc);
+                        const float gv = gy[sig * d.N + nbk], c = i[q] * inv;
+                        out[sig * d.N + nbk] = fmaf(m, c - gv, gv);
+                        macc = fmaf(x[sig * d.N + nbk], c - gv, macc);
                     }
                 }
             }
@@ -382,7 +384,21 @@ inline int rv_check() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
 }
-struct RvDims { ConvDims c; int nblk, VQ, nwin, ltiles, ctiles, rowgroups; long R; };
+struct RvDims { ConvDims c; int nblk, VQ, nwin, ltiles, ctiles, rowgroups, chunk; long R; };
+// Signals per pass of the long-convolution pipeline. The three kernels of a pass hand 8 B per frame point to each other (column
+// transforms -> row pass -> inverse columns); run over all 2B signals at once those intermediates (0.5 GB each at the default config) go
+// to HBM and come back. Run over a chunk of signals at a time, into scratch buffers that every chunk reuses, they stay in the 256 MB
+// last-level cache: written, read back by the next kernel and overwritten by the next chunk before they are ever evicted.
+#ifndef DASP_REVERB_CHUNK_MB
+#define DASP_REVERB_CHUNK_MB 48      // target size of one chunk's scratch buffer
+#endif
+inline int rv_chunk(long R, long frame_elems_per_signal) {
+    long c = ((long)DASP_REVERB_CHUNK_MB << 20) / (frame_elems_per_signal * 8);
+    if (const char* e = getenv("DASP_REVERB_CHUNK")) c = atol(e);          // signals per chunk (developer override; 0 = all at once)
+    if (c <= 0 || c > R) c = R;
+    c &= ~1L;                                        // the two signals of a batch item stay together (they share mix)
+    return (int)(c < 2 ? 2 : c);
+}
 inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     RvDims d;
     long Lb = ColsGeom::N / 2;                       // n1 >= 8192 keeps every workgroup of the four-step kernels full
@@ -401,6 +417,7 @@ inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     if (d.VQ < 1) return false;                      // filters longer than 3585 taps do not fit the 4096-point window
     d.nwin = (L + 512 * d.VQ - 1) / (512 * d.VQ);
     if (d.R > 65535 || d.c.npairs > 65535 || B > 65535) return false;
+    d.chunk = rv_chunk(d.R, (long)d.c.npairs * d.c.n1);
     *o = d;
     return true;
 }
@@ -410,9 +427,10 @@ extern "C" {
 
 /* sizes[0] = Lb (block length), [1] = n1 (transform length), [2] = pairs of blocks per signal, [3] = blocks per signal,
  * [4] = complex elements of Fspec (twiddle table + band spectra of the filter bank), [5] = filter-bank windows per batch item,
- * [6] = complex elements of A / W / Ag (2B * pairs * n1), [7] = complex elements of H / Ah / P (2B * n1),
- * [8] = floats of ir / gir (2B * L), [9] = floats of wet (2B * N),
- * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums */
+ * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (2B * n1),
+ * [8] = floats of ir / gir (2B * L), [9] = signals per pass of the long-convolution pipeline (chunk),
+ * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums,
+ * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1), [13] = complex elements of the scratch buffers Ah / P (chunk * n1) */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!sizes || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX) return DASP_ERR_ARG;
     RvDims d;
@@ -420,8 +438,9 @@ int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     sizes[0] = d.c.Lb; sizes[1] = d.c.n1; sizes[2] = d.c.npairs; sizes[3] = d.nblk;
     sizes[4] = (long)(nb + 1) * FFT_N; sizes[5] = d.nwin;
     sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = d.R * d.c.n1;
-    sizes[8] = d.R * L; sizes[9] = d.R * N;
+    sizes[8] = d.R * L; sizes[9] = d.chunk;
     sizes[10] = d.R * d.c.npairs * d.ctiles; sizes[11] = (long)B * d.nwin * nb * 2;
+    sizes[12] = (long)d.chunk * d.c.npairs * d.c.n1; sizes[13] = (long)d.chunk * d.c.n1;
     return DASP_OK;
 }
 
@@ -435,60 +454,70 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
 }
 
 /* Forward.  x (B,2,N); noise (2B, nb, L+taps-1); Fspec (sizes[4] complex); gains, decays (B, nb); mix (B); y (B,2,N).
- * Saved for backward: A (sizes[6] complex), H (sizes[7] complex), wet (sizes[9] floats, may be NULL when no gradient is needed).
- * Scratch: W (sizes[6] complex), Ah (sizes[7] complex), ir (sizes[8] floats). */
+ * Saved for backward: H (sizes[7] complex) and, when A is not NULL, A (sizes[6] complex: the column transforms of x; pass NULL when no
+ * gradient is needed and they go to a chunk-sized scratch instead: W2, sizes[12] complex).
+ * Scratch: W (sizes[12] complex), Ah (sizes[13] complex), ir (sizes[8] floats). */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays, const float* mix,
-                        float* y, void* A, void* H, float* wet, void* W, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
+                        float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
                         void* stream) {
-    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || !A || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
+    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || (!A && !W2) || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
         nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const f2* tw = (const f2*)Fspec;
+    const ConvDims one = ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N};
     // 1. filter bank, envelope, gains, mean over bands -> impulse responses (functional.py:551-567)
     hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, ir, (const float*)nullptr,
                        (float*)nullptr, nb, L, taps, d.VQ);
-    // 2. their spectra, in the permuted four-step order
-    hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.ltiles, 1, (unsigned)d.R), dim3(LoadGeom::T), 0, st, (const float*)ir, (const float*)nullptr, tw,
-                       (f2*)Ah, ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N}, L);
-    hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, (f2*)H,
-                       (f2*)nullptr, (f2*)nullptr, ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N});
-    // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
-    hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(LoadGeom::T), 0, st, x, (const float*)nullptr,
-                       tw, (f2*)A, d.c, L);
-    hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.rowgroups, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)A, (const f2*)nullptr, tw, (f2*)H,
-                       (f2*)W, (f2*)nullptr, d.c);
-    hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.ctiles, (unsigned)d.R), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x, (const float*)nullptr, mix,
-                       wet, y, (float*)nullptr, d.c, L);
+    for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
+        const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
+        f2* Hc = (f2*)H + s0 * d.c.n1;
+        f2* Ac = A ? (f2*)A + s0 * d.c.npairs * d.c.n1 : (f2*)W2;
+        // 2. spectra of the chunk's impulse responses, in the permuted four-step order
+        hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.ltiles, 1, ns), dim3(LoadGeom::T), 0, st, (const float*)ir + s0 * L, (const float*)nullptr, tw,
+                           (f2*)Ah, one, L);
+        hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, Hc,
+                           (f2*)nullptr, (f2*)nullptr, one);
+        // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
+        hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, x + s0 * N, (const float*)nullptr,
+                           tw, Ac, d.c, L);
+        hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ac, (const f2*)nullptr, tw, Hc,
+                           (f2*)W, (f2*)nullptr, d.c);
+        hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x + s0 * N, (const float*)nullptr,
+                           mix + s0 / 2, y + s0 * N, (float*)nullptr, d.c, L);
+    }
     return rv_check();
 }
 
 /* Backward.  gx (B,2,N); ggain, gdecay (B, nb); gmix (B).
- * Scratch: Ag (sizes[6] complex), W (sizes[6] complex), P (sizes[7] complex), gir (sizes[8] floats), part (sizes[11] floats),
- * mix_part (sizes[10] floats). */
+ * Scratch: Ag, W (sizes[12] complex each), P (sizes[13] complex), gir (sizes[8] floats), part (sizes[11] floats), mix_part (sizes[10] floats). */
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
-                         const float* mix, const void* A, const void* H, const float* wet, float* gx, float* ggain, float* gdecay, float* gmix,
+                         const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
                          void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
                          void* stream) {
-    if (!x || !gy || !noise || !Fspec || !gains || !decays || !mix || !A || !H || !wet || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
+    if (!x || !gy || !noise || !Fspec || !gains || !decays || !mix || !A || !H || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
         !gir || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const f2* tw = (const f2*)Fspec;
-    // overlapped windows of mix * gy -> column transforms
-    hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(LoadGeom::T), 0, st, gy, mix, tw, (f2*)Ag, d.c, L);
-    // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
-    hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, (unsigned)d.R), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A, tw, (f2*)H, (f2*)W,
-                       (f2*)P, d.c);
-    hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, (unsigned)d.R), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x, gy, mix,
-                       (float*)wet, gx, mix_part, d.c, L);
-    hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, (unsigned)d.R), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, gir, (float*)nullptr,
-                       ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N}, L);
+    const ConvDims one = ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N};
+    for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
+        const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
+        // overlapped windows of gy -> column transforms
+        hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, gy + s0 * N, (const float*)nullptr, tw,
+                           (f2*)Ag, d.c, L);
+        // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
+        hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + s0 * d.c.npairs * d.c.n1, tw,
+                           (f2*)H + s0 * d.c.n1, (f2*)W, (f2*)P, d.c);
+        hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x + s0 * N,
+                           gy + s0 * N, mix + s0 / 2, gx + s0 * N, mix_part + s0 * d.c.npairs * d.ctiles, d.c, L);
+        hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,
+                           (const float*)nullptr, mix + s0 / 2, gir + s0 * L, (float*)nullptr, one, L);
+    }
     // d/dgain, d/ddecay: the filter bank again, weighted by gir
     hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, (float*)nullptr,
                        (const float*)gir, part, nb, L, taps, d.VQ);

@@ -938,7 +938,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     constexpr int S2 = 2 * S, TS = 64 * L, H = (GC && S > 6) ? S / 2 : 0, SH = S - H;   // SH >= H
     constexpr int NSTASH4 = (H * KEEP + 3) / 4;                 // float4 per lane of parked s2 signals
     // per wave: x landing image, gy landing image, gx staging image (unpadded, swizzled: common.hpp), saved chunk states, parked signals
-    constexpr int IMG = 64 * L, REGION = 3 * IMG + S * 128 + 64 * 4 * NSTASH4;   // floats
+    // (the adjoint-only variant has no x image and no states: two images per wave, so eight waves per workgroup fit two workgroups per CU)
+    constexpr int IMG = 64 * L, REGION = GC ? 3 * IMG + S * 128 + 64 * 4 * NSTASH4 : 2 * IMG;   // floats
     constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 24;   // COEF rows, DF rows, MN rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
@@ -951,10 +952,10 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;   // small regions first (16-bit DS offsets), as in the forward kernel
     float* cf_lds = lds + LDS_MB;
     float* pw_lds = cf_lds + LDS_CF;
-    float* tbx = pw_lds + LDS_PW + wave * REGION;  // x image of this tile; receives the next tile's as soon as it has been read
-    float* tbg = tbx + IMG;                        // gy image, likewise
+    float* tbg = pw_lds + LDS_PW + wave * REGION;  // gy image of this tile; receives the next tile's as soon as it has been read
     float* tbo = tbg + IMG;                        // gx image on its way out
-    float* tst = tbo + IMG;                        // chunk start states [section pair][lane] f4
+    float* tbx = tbo + IMG;                        // x image, likewise (GC)
+    float* tst = tbx + IMG;                        // chunk start states [section pair][lane] f4 (GC)
     float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
     // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (t1 - 1: the row's or the segment's last) waits for,
     // with the adjoint state that enters from above (zero at the end of the row)
@@ -1475,6 +1476,11 @@ constexpr int kWF = DASP_FWD_W;    // waves per row, forward (2 rows per CU -> 4
 #define DASP_BWD_W 4
 #endif
 constexpr int kWB = DASP_BWD_W;    // waves per row, backward (2 rows per CU -> 2 waves per SIMD; measured faster than 6 waves at 168 registers)
+#ifndef DASP_BWD_W_ADJ
+#define DASP_BWD_W_ADJ 8
+#endif
+constexpr int kWBA = DASP_BWD_W_ADJ;   // ... of the adjoint-only variant (no coefficient gradients: ~100 registers, 8 KiB of LDS per wave - the
+                                       // forward kernel's shape; with kWB waves it ran at 2 waves per SIMD and was latency-bound, 0.159 ms)
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
@@ -1510,7 +1516,7 @@ void launch_bwd(int flags, int blocks, hipStream_t st, A... a) {
         case BWD_FAST: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_FAST>), g, b, 0, st, a...); break;
         case BWD_NOGX: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_NOGX>), g, b, 0, st, a...); break;
         case BWD_FAST | BWD_NOGX: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_FAST | BWD_NOGX>), g, b, 0, st, a...); break;
-        default: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_NOGC>), g, b, 0, st, a...); break;
+        default: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWBA, SEG, BWD_NOGC>), g, dim3(64 * kWBA), 0, st, a...); break;
     }
 }
 }  // namespace

@@ -518,21 +518,23 @@ class ReverbFunction(torch.autograd.Function):
         if ctx.empty:
             return torch.empty_like(x)
         with torch.cuda.device(dev):
-            sizes = (ctypes.c_long * 12)()
+            sizes = (ctypes.c_long * 14)()
             check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
             x32, n32 = _f32c(x), _f32c(noise)
             g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
             y = torch.empty_like(x32)
             need_grad = any(ctx.needs_input_grad)
-            A, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
-            H, Ah = _cbuf(sizes[7], dev), _cbuf(sizes[7], dev)
+            # kept for the backward pass: the column transforms of x (A) and the spectra of the impulse responses (H); everything else is
+            # scratch the size of one chunk of signals (dasp_hip.h: the passes of the long convolution reuse it, so it stays in cache)
+            A = _cbuf(sizes[6], dev) if need_grad else None
+            W2 = None if need_grad else _cbuf(sizes[12], dev)
+            W, H, Ah = _cbuf(sizes[12], dev), _cbuf(sizes[7], dev), _cbuf(sizes[13], dev)
             ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
-            wet = torch.empty(sizes[9], dtype=torch.float32, device=dev) if need_grad else None
             call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
-                 ptr(wet) if need_grad else None, ptr(W), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+                 ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
             if need_grad:
-                ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, A, H, wet)
+                ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, A, H)
                 ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
         return y.to(x.dtype)
 
@@ -543,7 +545,7 @@ class ReverbFunction(torch.autograd.Function):
         if ctx.empty:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
             return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None
-        x32, n32, Fspec, g32, d32, m32, A, H, wet = ctx.saved_tensors
+        x32, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
         B, N, L_ir, taps, nb, sizes = ctx.cfg
         dev = x32.device
         with torch.cuda.device(dev):
@@ -551,12 +553,12 @@ class ReverbFunction(torch.autograd.Function):
             ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
             gdecay = torch.empty(B, nb, dtype=torch.float32, device=dev)
             gmix = torch.empty(B, dtype=torch.float32, device=dev)
-            Ag, W = _cbuf(sizes[6], dev), _cbuf(sizes[6], dev)
-            P = _cbuf(sizes[7], dev)
+            Ag, W = _cbuf(sizes[12], dev), _cbuf(sizes[12], dev)
+            P = _cbuf(sizes[13], dev)
             gir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
             part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
             mix_part = torch.empty(sizes[10], dtype=torch.float32, device=dev)
-            call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(wet),
+            call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H),
                  ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P), ptr(gir), ptr(part), ptr(mix_part),
                  B, N, L_ir, taps, nb, stream())
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None

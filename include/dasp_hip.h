@@ -209,18 +209,24 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
  * ------------------------------------------------------------------------------------------- */
 /* sizes[0] = block length Lb, [1] = transform length n1, [2] = pairs of blocks per signal, [3] = blocks per signal,
  * [4] = complex (2 x fp32) elements of Fspec, [5] = filter-bank windows per batch item,
- * [6] = complex elements of each of A / W / Ag, [7] = complex elements of each of H / Ah / P,
- * [8] = floats of each of ir / gir, [9] = floats of wet, [10] = floats of mix_part, [11] = floats of part. */
-int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [12] */);
+ * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (2B * n1), [8] = floats of each of ir / gir,
+ * [9] = signals per pass of the long-convolution pipeline (the passes reuse chunk-sized scratch buffers so that the 8 B per frame point
+ *       the three kernels of a pass hand to each other stay in the last-level cache instead of going to HBM and back),
+ * [10] = floats of mix_part, [11] = floats of part,
+ * [12] = complex elements of each of the scratch buffers W / W2 / Ag, [13] = complex elements of each of the scratch buffers Ah / P. */
+int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [14] */);
 /* filters (nb, taps) fp32, the host-designed bank -> Fspec: transform twiddles followed by the band spectra. */
 int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream);
-/* forward: A, H and wet (wet may be NULL when no gradient is needed) are kept for the backward pass; W, Ah, ir are scratch.
- * backward: gx, ggain (B, nb), gdecay (B, nb), gmix (B) are the results; Ag, W, P, gir, part, mix_part are scratch. */
+/* forward: H and (when a backward pass follows) A are kept for it - pass A = NULL otherwise and the column transforms of x go to the
+ * scratch W2; W, Ah, ir are scratch.
+ * backward: gx, ggain (B, nb), gdecay (B, nb), gmix (B) are the results; Ag, W, P, gir, part, mix_part are scratch. The wet signal is
+ * not needed: d loss / d mix = sum gy (wet - x) = sum x (c - gy) with c the correlation of gy with the impulse response, which the
+ * backward pass forms anyway. */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays,
-                        const float* mix, float* y, void* A, void* H, float* wet, void* W, void* Ah, float* ir, int B,
+                        const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
                         long N, int L, int taps, int nb, void* stream);
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains,
-                         const float* decays, const float* mix, const void* A, const void* H, const float* wet, float* gx,
+                         const float* decays, const float* mix, const void* A, const void* H, float* gx,
                          float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
                          float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
 

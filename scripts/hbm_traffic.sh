@@ -27,8 +27,8 @@ def counter(name):
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in vals.items()}      # second half of the launches (warm)
 f, w = counter("FETCH_SIZE"), counter("WRITE_SIZE")
 h = hashlib.sha256()
-for p in sorted(glob.glob("dasp_pytorch_amd/csrc/*.hip") + glob.glob("dasp_pytorch_amd/csrc/*.hpp")):
-    h.update(os.path.basename(p).encode()); h.update(open(p, "rb").read())
+for p in ("sosfilt.hip", "common.hpp"):        # bench.py kernel_source_hash()
+    h.update(p.encode()); h.update(open(os.path.join("dasp_pytorch_amd/csrc", p), "rb").read())
 units = 256 * 2 * 131072
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes with --kernel-trace only, KB units) on tools/sosbench 256 2 131072 "
                "(DASP_PEQ=1 DASP_DESIGNED=1: the designed-cascade backward kernel), averaged over the second half of 42 launches; FETCH_SIZE doubled "
