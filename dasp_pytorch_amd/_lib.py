@@ -73,6 +73,14 @@ SIGNATURES = {
     "dasp_mrstft_table": (_i, [_p, _p]),
     "dasp_mrstft_forward": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
     "dasp_mrstft_backward": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
+    "dasp_sos64_normalize": (_i, [_p, _i, _i, _p, _p]),
+    "dasp_sos64_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _p]),
+    "dasp_sos64_backward": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
+    "dasp_sos64_grads": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "dasp_dynamics64_forward": (_i, [_i, _p, _p, _p, _p, _i, _i, _l, _d, _d, _i, _p]),
+    "dasp_dynamics64_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, _d, _i, _p]),
+    "dasp_ew64_forward": (_i, [_i, _p, _p, _p, _i, _i, _l, _p]),
+    "dasp_ew64_backward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
     "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),

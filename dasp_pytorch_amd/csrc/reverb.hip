@@ -385,16 +385,15 @@ inline int rv_check() {
     return e == hipSuccess ? DASP_OK : (int)e;
 }
 struct RvDims { ConvDims c; int nblk, VQ, nwin, ltiles, ctiles, rowgroups, chunk; long R; };
-// Signals per pass of the long-convolution pipeline. The three kernels of a pass hand 8 B per frame point to each other (column
-// transforms -> row pass -> inverse columns); run over all 2B signals at once those intermediates (0.5 GB each at the default config) go
-// to HBM and come back. Run over a chunk of signals at a time, into scratch buffers that every chunk reuses, they stay in the 256 MB
-// last-level cache: written, read back by the next kernel and overwritten by the next chunk before they are ever evicted.
-#ifndef DASP_REVERB_CHUNK_MB
-#define DASP_REVERB_CHUNK_MB 48      // target size of one chunk's scratch buffer
-#endif
+// Signals per pass of the long-convolution pipeline: all of them by default. Passes over chunks of signals that reuse chunk-sized scratch
+// buffers were built to keep the 8 B per frame point the three kernels of a pass hand to each other in the 256 MB last-level cache; measured
+// at (128, 2, 262144) it only cost time (fwd + bwd 2.85 ms in one pass, 2.91 / 2.94 / 2.98 / 3.28 ms with 128 / 64 / 32 / 16 signals per
+// pass): the passes run at the rate of their HBM traffic either way and the extra launches and partially filled waves of small grids
+// are not paid back. DASP_REVERB_CHUNK=<signals per pass> keeps the experiment reproducible.
 inline int rv_chunk(long R, long frame_elems_per_signal) {
-    long c = ((long)DASP_REVERB_CHUNK_MB << 20) / (frame_elems_per_signal * 8);
-    if (const char* e = getenv("DASP_REVERB_CHUNK")) c = atol(e);          // signals per chunk (developer override; 0 = all at once)
+    (void)frame_elems_per_signal;
+    long c = R;
+    if (const char* e = getenv("DASP_REVERB_CHUNK")) c = atol(e);          // developer override; 0 = all at once
     if (c <= 0 || c > R) c = R;
     c &= ~1L;                                        // the two signals of a batch item stay together (they share mix)
     return (int)(c < 2 ? 2 : c);

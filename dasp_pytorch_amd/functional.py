@@ -5,6 +5,7 @@ import torch
 from . import signal as _signal
 from .ops import (FILTER_TYPES, BusFunction, DistortionFunction, DynamicsFunction, GainFunction, PannerFunction, ParametricEQFunction,
                   ReverbFunction, WidenerFunction)
+from .ops64 import Dynamics64Function, Elementwise64Function, ParametricEQ64Function, is_f64, require_fp32_ok
 
 _PEQ_TYPES = [FILTER_TYPES[t] for t in ("low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf")]
 
@@ -15,6 +16,8 @@ def gain(x: torch.Tensor, sample_rate: int, gain_db: torch.Tensor):
     bs, chs, seq_len = x.size()
     if gain_db.numel() != bs:   # the reference's gain_db.view(bs, 1, 1)
         raise RuntimeError(f"shape '[{bs}, 1, 1]' is invalid for input of size {gain_db.numel()}")
+    if is_f64(x):            # float64 in, float64 arithmetic, as the reference (ops64.py)
+        return Elementwise64Function.apply(x, gain_db, 0)
     return GainFunction.apply(x, gain_db)
 
 
@@ -27,6 +30,8 @@ def distortion(x: torch.Tensor, sample_rate: int, drive_db: torch.Tensor):
     if drive_db.numel() != bs * chs:
         raise RuntimeError(f"shape '[{bs}, {chs}, -1]' is invalid for input of size {drive_db.numel()} "
                            "(dasp_pytorch_amd supports one drive value per (batch, channel) row)")
+    if is_f64(x):
+        return Elementwise64Function.apply(x, drive_db, 1)
     return DistortionFunction.apply(x, drive_db)
 
 
@@ -37,6 +42,7 @@ def stereo_bus(x: torch.Tensor, sample_rate: int, send_db: torch.Tensor):
     assert chs == 2, "Input tensor must have shape (bs, 2, tracks, seq_len)"
     if send_db.numel() != bs * tracks:
         raise RuntimeError(f"shape '[{bs}, 1, {tracks}, 1]' is invalid for input of size {send_db.numel()}")
+    require_fp32_ok(x, "stereo_bus")
     return BusFunction.apply(x, send_db)
 
 
@@ -57,6 +63,7 @@ def stereo_widener(x: torch.Tensor, sample_rate: float, width: torch.Tensor):
     assert chs == 2, "Input tensor must have shape (bs, 2, seq_len)"
     if width.numel() != bs:
         raise RuntimeError(f"The size of tensor a ({bs}) must match the size of tensor b ({width.numel()})")
+    require_fp32_ok(x, "stereo_widener")
     return WidenerFunction.apply(x, width)
 
 
@@ -67,6 +74,7 @@ def stereo_panner(x: torch.Tensor, sample_rate: float, pan: torch.Tensor):
     bs, num_tracks, seq_len = x.size()
     if pan.numel() != bs * num_tracks:
         raise RuntimeError(f"shape '[{bs}, 1, {num_tracks}, 1]' is invalid for input of size {pan.numel()}")
+    require_fp32_ok(x, "stereo_panner")
     return PannerFunction.apply(x, pan)
 
 
@@ -107,6 +115,8 @@ def parametric_eq(
     n = controls[0].numel()
     if any(c.numel() != n for c in controls) or n not in (1, bs):
         raise RuntimeError(f"parametric_eq controls must each hold {bs} (or 1) values, got {[c.numel() for c in controls]}")
+    if is_f64(x):
+        return ParametricEQ64Function.apply(x, float(sample_rate), _PEQ_TYPES, *controls)
     return ParametricEQFunction.apply(x, float(sample_rate), _PEQ_TYPES, *controls)
 
 
@@ -116,7 +126,8 @@ def _dynamics(mode, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, 
     for c in ctls:   # the reference's .view(-1, 1, 1) against a (bs, 1, seq_len) side chain: no parameter broadcasting
         if c.numel() != bs:
             raise RuntimeError(f"The size of tensor a ({c.numel()}) must match the size of tensor b ({bs}) at non-singleton dimension 0")
-    return DynamicsFunction.apply(x, mode, float(sample_rate), float(eps), int(lookahead_samples), *ctls)
+    fn = Dynamics64Function if is_f64(x) else DynamicsFunction
+    return fn.apply(x, mode, float(sample_rate), float(eps), int(lookahead_samples), *ctls)
 
 
 def compressor(
@@ -221,6 +232,7 @@ def noise_shaped_reverberation(
     assert num_bandpass_taps % 2 == 1, "num_bandpass_taps must be odd"
     bs, chs, seq_len = x.size()
     assert chs <= 2, "only mono/stereo signals are supported"
+    require_fp32_ok(x, "noise_shaped_reverberation")
     if chs == 1:   # if mono copy to stereo (autograd sums the two channel gradients)
         x = x.repeat(1, 2, 1)
     band_gains = torch.stack([band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,

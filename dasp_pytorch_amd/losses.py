@@ -17,6 +17,8 @@ class _MRSTFTFunction(torch.autograd.Function):
         _lib.require_device(inp, "input")
         _lib.require_device(target, "target")
         _lib.require_same_device(inp, target=target)
+        from .ops64 import require_fp32_ok
+        require_fp32_ok(inp, "MultiResolutionSTFTLoss")
         if ctx.needs_input_grad[1]:
             raise RuntimeError("MultiResolutionSTFTLoss: only `input` is differentiable (the target is the reference signal); detach the target")
         if inp.shape != target.shape:

@@ -525,8 +525,7 @@ class ReverbFunction(torch.autograd.Function):
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
             y = torch.empty_like(x32)
             need_grad = any(ctx.needs_input_grad)
-            # kept for the backward pass: the column transforms of x (A) and the spectra of the impulse responses (H); everything else is
-            # scratch the size of one chunk of signals (dasp_hip.h: the passes of the long convolution reuse it, so it stays in cache)
+            # kept for the backward pass: the column transforms of x (A) and the spectra of the impulse responses (H); everything else is scratch
             A = _cbuf(sizes[6], dev) if need_grad else None
             W2 = None if need_grad else _cbuf(sizes[12], dev)
             W, H, Ah = _cbuf(sizes[12], dev), _cbuf(sizes[7], dev), _cbuf(sizes[13], dev)

@@ -3,7 +3,8 @@
 `sosfilt_via_fsm` keeps the reference's name for drop-in use, but it is evaluated as an exact
 recurrence (chunked parallel scan, csrc/sosfilt.hip) instead of the reference's frequency-sampling
 approximation; the two agree to <= 1e-13 in fp64 for stable filters whose impulse response has
-decayed within the signal length.
+decayed within the signal length. float64 input takes the double-precision
+kernels of csrc/ref64.hip (ops64.py): float64 in, float64 arithmetic, as in the reference.
 """
 import functools
 
@@ -12,6 +13,7 @@ import scipy.signal
 import torch
 
 from .ops import FILTER_TYPES, BiquadFunction, SosFiltFunction
+from .ops64 import SosFilt64Function, is_f64
 
 
 def biquad(gain_db: torch.Tensor, cutoff_freq: torch.Tensor, q_factor: torch.Tensor, sample_rate: float, filter_type: str = "peaking"):
@@ -57,7 +59,7 @@ def lfilter_via_fsm(x: torch.Tensor, b: torch.Tensor, a: torch.Tensor = None):
         pad = torch.zeros(b.shape[0], 3 - K, dtype=b.dtype, device=b.device)
         b, a = torch.cat([b, pad], 1), torch.cat([a, pad], 1)
     sos = torch.cat([b, a], 1).unsqueeze(1)                  # (bs, 1, 6) rows [b0 b1 b2 a0 a1 a2]
-    return SosFiltFunction.apply(sos, x)
+    return (SosFilt64Function if is_f64(x) else SosFiltFunction).apply(sos, x)
 
 
 def _frequency_domain_helper(name, line):
@@ -88,6 +90,8 @@ def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
     assert n_coeffs == 6  # must be second order (signal.py:24)
     shape = x.shape
     xx = x.reshape(shape[0], -1, shape[-1])
+    if is_f64(x):            # float64 in, float64 arithmetic, as the reference (ops64.py): any number of sections in one call
+        return SosFilt64Function.apply(sos, xx).reshape(shape)
     for s0 in range(0, n_sections, 8):
         xx = SosFiltFunction.apply(sos[:, s0:s0 + 8], xx)
     return xx.reshape(shape)

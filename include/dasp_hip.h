@@ -210,8 +210,8 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
 /* sizes[0] = block length Lb, [1] = transform length n1, [2] = pairs of blocks per signal, [3] = blocks per signal,
  * [4] = complex (2 x fp32) elements of Fspec, [5] = filter-bank windows per batch item,
  * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (2B * n1), [8] = floats of each of ir / gir,
- * [9] = signals per pass of the long-convolution pipeline (the passes reuse chunk-sized scratch buffers so that the 8 B per frame point
- *       the three kernels of a pass hand to each other stay in the last-level cache instead of going to HBM and back),
+ * [9] = signals per pass of the long-convolution pipeline (all 2B by default; a developer switch can cut the pipeline into passes over
+ *       chunks of signals that reuse chunk-sized scratch buffers),
  * [10] = floats of mix_part, [11] = floats of part,
  * [12] = complex elements of each of the scratch buffers W / W2 / Ag, [13] = complex elements of each of the scratch buffers Ah / P. */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [14] */);
@@ -264,6 +264,31 @@ int dasp_mrstft_forward(const float* pred, const float* target, const void* tw, 
                         int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
 int dasp_mrstft_backward(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss, float* gpred,
                          int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Double precision.  The reference follows the dtype of its input (`.type_as(x)`, dasp_pytorch/signal.py:113,119,
+ * functional.py:211), so float64 tensors mean float64 arithmetic. These entry points are that path for the recurrences and the
+ * elementwise effects - the same maps as above evaluated plainly, one thread per row / batch item, sequential in time: meant for
+ * validation, torch.autograd.gradcheck and small reference runs, not for throughput (csrc/ref64.hip).
+ *   c5: (Bs, S, 5) fp64 normalised coefficients [b0 b1 b2 a1 a2] (from dasp_sos64_normalize, or rows of dasp_biquad_design's ba);
+ *   wsave: (B*C, S, N) doubles written by the forward pass for the coefficient gradients (NULL when none are wanted);
+ *   gc5: (Bs, S, 5) gradient w.r.t. c5, mapped by dasp_sos64_grads to sos (mode 0) or to (gain_db, cutoff_freq, q_factor) (mode 1,
+ *   jac = the (Bs, S, 15) Jacobians of dasp_biquad_design);  gsave: (B, N) smoothed gain kept by dasp_dynamics64_forward.
+ * ------------------------------------------------------------------------------------------- */
+int dasp_sos64_normalize(const double* sos, int Bs, int S, double* c5, void* stream);
+int dasp_sos64_forward(const double* c5, int Bs, const double* x, double* y, double* wsave, int B, int C, long N, int S, void* stream);
+int dasp_sos64_backward(const double* c5, int Bs, const double* gy, const double* wsave, double* gx, double* gc5, int B, int C, long N,
+                        int S, void* stream);
+int dasp_sos64_grads(const double* c5, const double* sos, const double* gc5, const double* jac, int Bs, int S, int mode, double* out,
+                     void* stream);
+int dasp_dynamics64_forward(int mode, const double* x, const double* ctl, double* y, double* gsave, int B, int C, long N,
+                            double sample_rate, double eps, int lookahead, void* stream);
+int dasp_dynamics64_backward(int mode, const double* x, const double* ctl, const double* gy, const double* gsave, double* gx,
+                             double* gctl, int B, int C, long N, double sample_rate, double eps, int lookahead, void* stream);
+/* op 0: gain (ctl: B values), op 1: distortion (ctl: B*C values) */
+int dasp_ew64_forward(int op, const double* x, const double* ctl, double* y, int B, int C, long N, void* stream);
+int dasp_ew64_backward(int op, const double* x, const double* ctl, const double* gy, double* gx, double* gctl, int B, int C, long N,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,8 +70,7 @@ def test_reverb_size_query():
     assert sizes[4] == 13 * 4096 and sizes[5] == -(-65536 // 3072)            # twiddles + 12 band spectra; 3072 valid samples per window
     assert sizes[6] == 256 * pairs * n1 and sizes[7] == 256 * n1 and sizes[8] == 256 * 65536
     chunk = sizes[9]                                                          # signals per pass of the long-convolution pipeline
-    assert 2 <= chunk <= 256 and chunk % 2 == 0 and sizes[12] == chunk * pairs * n1 and sizes[13] == chunk * n1
-    assert sizes[12] * 8 <= 64 << 20                                          # a chunk's scratch is sized for the last-level cache
+    assert chunk == 256 and sizes[12] == chunk * pairs * n1 and sizes[13] == chunk * n1   # one pass over all signals by default
     assert L.dasp_reverb_sizes(1, 9000, 1000, 63, 12, sizes) == 0 and (sizes[0], sizes[3], sizes[2]) == (4096, 3, 2)   # minimum block; odd block count: zero partner
     assert L.dasp_reverb_sizes(1, 1000, 4096, 3587, 12, sizes) == -2         # filter longer than the filter-bank window
     assert L.dasp_reverb_sizes(1, 1000, (1 << 20) + 1, 63, 12, sizes) == -2  # impulse response beyond 2^20 samples

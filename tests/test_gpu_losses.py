@@ -42,6 +42,38 @@ def test_mrstft_vs_oracle(D, B, C, N, res):
     assert np.abs(g - go).max() < 2e-2 * np.abs(go).max()
 
 
+@pytest.mark.parametrize("N,res", [(3000, ((256, 64, 256), (64, 16, 64))), (6000, ((512, 128, 400), (128, 32, 128)))])
+def test_mrstft_gradient_on_well_conditioned_input(D, N, res):
+    """The gradient where it is well-conditioned: the prediction is 1.5 x the target plus a small perturbation, so the sign of every
+    log-magnitude difference is fixed (log 1.5 > 0; the draw is checked with the oracle's own spectra to keep every difference above
+    0.1 and every predicted magnitude above 1e-3 of the largest one). There the kernels are held to 1e-3 in relative L2 norm and 3e-3
+    of the largest entry - a wrong window, padding or scaling term would be off by far more."""
+    for seed in range(40):
+        rng = np.random.default_rng(1000 * N + seed)
+        b = (rng.standard_normal((1, 1, N)) * 0.3).astype(np.float32)
+        a = (1.5 * b + 1e-3 * rng.standard_normal((1, 1, N))).astype(np.float32)
+        ok = True
+        for n_fft, hop, win in res:
+            pm = orc._stft_mag(a[0], n_fft, hop, win, 1e-8, np.float64)[0]
+            tm = orc._stft_mag(b[0], n_fft, hop, win, 1e-8, np.float64)[0]
+            ok = ok and pm.min() > 1e-3 * pm.max() and (np.log(pm) - np.log(tm)).min() > 0.1
+        if ok:
+            break
+    else:
+        pytest.skip("no well-conditioned draw found")
+    kw = dict(fft_sizes=[r[0] for r in res], hop_sizes=[r[1] for r in res], win_lengths=[r[2] for r in res])
+    at = dev(a).requires_grad_(True)
+    loss = D.losses.MultiResolutionSTFTLoss(**kw)(at, dev(b))
+    loss.backward()
+    lo = orc.mrstft_loss(a, b, resolutions=res)
+    go = orc.mrstft_loss_vjp(a, b, resolutions=res)
+    g = at.grad.cpu().numpy()
+    assert abs(float(loss.detach()) - lo) < 2e-5 * abs(lo)
+    e2, einf = np.linalg.norm(g - go) / np.linalg.norm(go), np.abs(g - go).max() / np.abs(go).max()
+    print("mrstft well-conditioned gradient error: rel L2 %.2e, max %.2e" % (e2, einf))
+    assert e2 < 1e-3 and einf < 3e-3
+
+
 def test_mrstft_conventions(D):
     x = torch.rand(2, 1, 3000, device="cuda:0")
     fn = D.losses.MultiResolutionSTFTLoss()

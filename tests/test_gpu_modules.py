@@ -206,3 +206,36 @@ def test_hip_graph_capture_replays_the_eager_step(D):
         for a, b in ((sx.grad, xe.grad), (sp.grad, pe.grad)):
             assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
         assert torch.isfinite(sp.grad).all() and sp.grad.abs().sum() > 0
+
+
+def test_empty_inputs_return_empty_tensors(D):
+    """An empty batch / zero-length signal returns an empty tensor (and zero control gradients), as the reference's tensor ops do,
+    instead of a launch error."""
+    for shape in ((0, 2, 512), (2, 2, 0)):
+        x = torch.zeros(shape, device="cuda:0", requires_grad=True)
+        bs = shape[0]
+        g = torch.zeros(bs, device="cuda:0", requires_grad=True)
+        y = D.gain(x, SR, g)
+        assert y.shape == x.shape
+        y.sum().backward()
+        assert g.grad.shape == g.shape and float(g.grad.abs().sum()) == 0.0
+        cols = [torch.ones(bs, device="cuda:0") * v for v in (0.0, 100.0, 1.0) * 6]
+        assert D.parametric_eq(x, SR, *cols).shape == x.shape
+        assert D.compressor(x, SR, *[torch.ones(bs, device="cuda:0")] * 6).shape == x.shape
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_tensors_on_a_non_current_device(D):
+    """x on cuda:1 while cuda:0 is the current device: kernels are launched on x's device and stream (ops wrap every call in
+    torch.cuda.device(x.device)); tensors of different devices in one call are refused."""
+    from dasp_pytorch_amd._lib import DaspHipError
+    g = torch.Generator(device="cuda:1").manual_seed(0)
+    x1 = torch.rand(2, 2, 8192, device="cuda:1", generator=g) * 2 - 1
+    p = torch.rand(2, 18, device="cuda:1", generator=g)
+    assert torch.cuda.current_device() == 0
+    eq = D.ParametricEQ(SR)
+    y1 = eq.process_normalized(x1, p)
+    y0 = eq.process_normalized(x1.to("cuda:0"), p.to("cuda:0"))
+    assert y1.device == x1.device and torch.equal(y1.cpu(), y0.cpu())
+    with pytest.raises(DaspHipError):
+        D.signal.sosfilt_via_fsm(torch.rand(2, 2, 6, device="cuda:0"), x1)

@@ -179,12 +179,12 @@ def test_identity_and_dtype_and_layout(D):
     # integer-dtype controls are legal in the reference (examples/demo.py:44)
     cols_i = [c.round().to(torch.int64) if i % 3 == 1 else c for i, c in enumerate(cols)]
     assert torch.isfinite(D.parametric_eq(x, SR, *cols_i)).all()
-    # fp64 in -> fp64 out; non-contiguous view gives the same numbers
+    # fp64 in -> fp64 out, computed in fp64 (tests/test_gpu_fp64.py); non-contiguous view gives the same numbers
     p = random_params(B, 2)
     cols = [dev(p[:, i]) for i in range(18)]
     y32 = D.parametric_eq(x, SR, *cols)
     y64 = D.parametric_eq(x.double(), SR, *cols)
-    assert y64.dtype == torch.float64 and (y64.float() - y32).abs().max().item() == 0.0
+    assert y64.dtype == torch.float64 and 0.0 < (y64.float() - y32).abs().max().item() < 2e-5
     xt = x.transpose(0, 1).contiguous().transpose(0, 1)
     assert not xt.is_contiguous() and torch.equal(D.parametric_eq(xt, SR, *cols), y32)
     # sosfilt_via_fsm accepts x of any rank (signal.py:142,157)
