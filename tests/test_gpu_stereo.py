@@ -79,5 +79,7 @@ def test_stereo_conventions(D):
         D.graphic_eq(x, SR)
     with pytest.raises(NotImplementedError):
         D.advanced_distortion(x, SR, None, None, None, None)
-    yd = D.stereo_bus(torch.rand(1, 2, 3, 64, device="cuda:0", dtype=torch.float64), SR, torch.zeros(1, 3, 1, device="cuda:0", dtype=torch.float64))
-    assert yd.dtype == torch.float64
+    # the stereo utilities compute in fp32 only: float64 input is refused rather than rounded silently (tests/test_gpu_fp64.py)
+    from dasp_pytorch_amd._lib import DaspHipError
+    with pytest.raises(DaspHipError, match="float64"):
+        D.stereo_bus(torch.rand(1, 2, 3, 64, device="cuda:0", dtype=torch.float64), SR, torch.zeros(1, 3, 1, device="cuda:0", dtype=torch.float64))
