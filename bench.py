@@ -90,13 +90,14 @@ def cpu_baseline_reference(seconds_budget=25.0):
         cols = [params[:, i].clone().requires_grad_(True) for i in range(18)]
         y = RF.parametric_eq(xx, SR, *cols)
         y.backward(w)
-    # torch's CPU FFTs and elementwise ops stop scaling well before a 256-thread host is used up (measured on a gpurun box: 18.7 s per
-    # iteration with 256 threads): a few thread counts are tried inside the time budget, all cores included, and the best one reported
+    # torch's CPU FFTs and elementwise ops stop scaling well before a 256-thread host is used up (measured on a gpurun box: 0.21 s per
+    # iteration with 16 threads, 0.46 s with 64, 18.4 s with all 256): thread counts are tried in increasing order until the time budget
+    # is spent or more threads made it slower, and the best one is reported
     tried = {}
     t_all = time.perf_counter()
     for threads in sorted({min(cores, 16), min(cores, 64), cores}):
-        if tried and time.perf_counter() - t_all > seconds_budget:
-            break
+        if tried and (time.perf_counter() - t_all > seconds_budget or (len(tried) > 1 and list(tried.values())[-1] > list(tried.values())[-2])):
+            break                            # out of budget, or more threads already made it slower (256 threads: 18 s per iteration)
         torch.set_num_threads(threads)
         step()                               # warm-up (FFT plans, allocator, thread pool)
         times = []

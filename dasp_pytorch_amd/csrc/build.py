@@ -31,7 +31,7 @@ def build_lib(force=False, verbose=False):
         obj = src[:-4] + ".o"
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *[os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".hpp")]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", src, "-o", obj]
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed", "-Wno-inline-asm", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

@@ -94,8 +94,20 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 #else
 #define DASP_GLDS_POLICY ""
 #endif
+// DASP_GLDS_CLOBBER=1: M0 declared clobbered instead of saved and restored around every DMA (two s_mov less per instruction, 22 per
+// tile in the backward kernel). Measured (profiles/r02/ab_micro_variants.log): no difference, 0.395 vs 0.396 ms fwd + bwd - and M0 is a
+// reserved register whose clobber the compiler does not promise to honour - so the save / restore form stays the default.
+#ifndef DASP_GLDS_CLOBBER
+#define DASP_GLDS_CLOBBER 0
+#endif
 template <bool STREAM = true>   // STREAM: the data is touched once (non-temporal); false: leave it to the caches' normal policy
 __device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
+#if DASP_GLDS_CLOBBER
+    if (STREAM)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" DASP_GLDS_POLICY :: "v"(src), "s"(dst_uniform) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst_uniform) : "memory", "m0");
+#else
     unsigned keep;
     if (STREAM)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
@@ -103,11 +115,16 @@ __device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
     else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+#endif
 }
 __device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
+#if DASP_GLDS_CLOBBER
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst_uniform) : "memory", "m0");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+#endif
 }
 
 

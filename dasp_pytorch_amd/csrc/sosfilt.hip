@@ -54,6 +54,10 @@
 #define DASP_PRIO_WIDE 1     // 1: also the load / transposition and store phases of a tile, i.e. everything but the cascade
 #endif
 #define WIDE_PRIO(p) do { if (DASP_SCAN_PRIO && DASP_PRIO_WIDE) __builtin_amdgcn_s_setprio(p); } while (0)
+#ifndef DASP_SPLIT_COUPLING
+#define DASP_SPLIT_COUPLING 0     // lane scan: the coupling sum of sections >= 3 on two accumulators (shorter dependent chain, one more packed
+                                  // add). Measured: 0.396 -> 0.398 ms fwd + bwd, i.e. nothing (profiles/r02/ab_micro_variants.log)
+#endif
 
 namespace dasp {
 
@@ -605,8 +609,18 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
         { float a = pw16.x, b = pw32.x, c = pw64.x; pin(a); pin(b); pin(c); pw16.x = a; pw32.x = b; pw64.x = c; }
         TRACE2(9);
         __builtin_amdgcn_sched_barrier(0);
+#if DASP_SPLIT_COUPLING
+        if (k >= 3) {       // two accumulators: the coupling sum is a dependent chain of 2 k packed FMAs otherwise
+            f2 fb = f2{0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < k; ++j) f = blk_apply_s(MC[j], st[j], f);
+            for (int j = 0; j < k; ++j) { if (j & 1) fb = blk_apply_s(MC[j], st[j], fb); else f = blk_apply_s(MC[j], st[j], f); }
+            f = f + fb;
+        } else
+#endif
+        {
+#pragma unroll
+            for (int j = 0; j < k; ++j) f = blk_apply_s(MC[j], st[j], f);
+        }
         pin(f); TRACE2(10);
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < S) {
