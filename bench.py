@@ -29,7 +29,6 @@ on CPU tensors over gloo with the kernels replaced by a copy; its numbers mean n
 """
 import argparse
 import glob
-import hashlib
 import json
 import os
 import sys
@@ -66,13 +65,10 @@ def make_batch(B, C, N, seed, device):
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources of the cascaded-biquad kernels the loaded library was built from (csrc/sosfilt.hip + common.hpp): ties
-    the off-line counter file to the kernels it measured."""
-    h = hashlib.sha256()
-    for f in ("sosfilt.hip", "common.hpp"):
-        h.update(f.encode())
-        h.update(open(os.path.join(ROOT, "dasp_pytorch_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    """Code hash (comments and whitespace ignored) of the cascaded-biquad kernel sources the loaded library was built from: ties the
+    off-line counter file to the kernels it measured (dasp_pytorch_amd/csrc/build.py)."""
+    from dasp_pytorch_amd.csrc.build import kernel_source_hash as h
+    return h()
 
 
 def cpu_baseline_reference(seconds_budget=25.0):
@@ -207,6 +203,9 @@ def secondary(dev):
     bench_op("parametric_eq_b16", 16, 2, 131072, peq, 20, "reference training batch: segmented rows")
     bench_op("compressor_b8", 8, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20,
              "reference training batch")
+    bench_op("noise_shaped_reverberation_b8", 8, 2, 131072,
+             lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
+             2 * 1.354e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
     xs = (rnd(16, 2, 131072) * 0.6 - 0.3).requires_grad_(True)

@@ -10,6 +10,21 @@ LIB = os.path.join(HERE, "libdasp_hip.so")
 ARCH = "gfx950"
 
 
+def kernel_source_hash(files=("sosfilt.hip", "common.hpp"), root=HERE):
+    """sha256 (16 hex digits) over the code of the cascaded-biquad kernels - comments stripped, whitespace collapsed - so that off-line
+    measurements (profiles/rNN/hbm_traffic.json) can be tied to the kernels they were taken from without breaking on a reworded comment."""
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for f in files:
+        src = open(os.path.join(root, f)).read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(f.encode())
+        h.update(" ".join(src.split()).encode())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
 

@@ -68,10 +68,15 @@ __global__ __launch_bounds__(FFT_T) void fb_spectrum_kernel(const float* __restr
 //   o_band     = IFFT(FFT(z_band) conj(F_band))  -> valid cross-correlations for idx < V   (:551-558)
 //   MODE 0:  ir[b,c][n] = 1/nb sum_band gain env_band(t_n) o_band                   (:561-567)
 //   MODE 1:  part[(b, w), band] = (sum_n gir o env / nb,  sum_n gir o env gain (-10 t_n) / nb),  gir (2B, L) = d loss / d ir
+// Few batch items: a workgroup's loop over the bands is its whole run time (12 x two transforms), and B * windows workgroups may not fill
+// the chip (8 items: 176 of 1024 slots). bsplit > 1 deals the bands out to gridDim.z workgroups per (item, window): MODE 0 then adds its
+// bands' share into ir with float atomics (ir zeroed by the caller; the order of the additions is not deterministic), MODE 1 writes the
+// partial sums of its own bands only.
 template <int MODE>
 __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const float* __restrict__ gains,
                                                          const float* __restrict__ decays, float* __restrict__ ir, const float* __restrict__ gir,
                                                          float* __restrict__ part, int nb, int L, int taps, int VQ) {
+    const int bsplit = gridDim.z, bper = (nb + bsplit - 1) / bsplit, band_lo = blockIdx.z * bper, band_hi = band_lo + bper < nb ? band_lo + bper : nb;
     __shared__ f2 lds[2 * FFT_LDS];
     __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
     const int j = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
             acci[q] = gir[(long)(2 * b + 1) * L + n];
         }
     }
-    for (int band = 0; band < nb; ++band) {
+    for (int band = band_lo; band < band_hi; ++band) {
         float r[8], i[8];
         {
             const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
@@ -138,11 +143,14 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = n0 + j + 512 * q;
-            if (q < VQ && n < L) { ir[(long)(2 * b) * L + n] = accr[q]; ir[(long)(2 * b + 1) * L + n] = acci[q]; }
+            if (q < VQ && n < L) {
+                if (bsplit == 1) { ir[(long)(2 * b) * L + n] = accr[q]; ir[(long)(2 * b + 1) * L + n] = acci[q]; }
+                else { atomicAdd(ir + (long)(2 * b) * L + n, accr[q]); atomicAdd(ir + (long)(2 * b + 1) * L + n, acci[q]); }
+            }
         }
     } else {
         __syncthreads();
-        if (j < nb * 2) {
+        if (j < nb * 2 && (j >> 1) >= band_lo && (j >> 1) < band_hi) {
             const int band = j >> 1, k = j & 1;
             float a = 0.f;
             for (int v = 0; v < FFT_T / 64; ++v) a += red[v][band][k];
@@ -398,6 +406,14 @@ inline int rv_chunk(long R, long frame_elems_per_signal) {
     c &= ~1L;                                        // the two signals of a batch item stay together (they share mix)
     return (int)(c < 2 ? 2 : c);
 }
+// workgroups per (item, window) of the filter-bank kernel: the bands are dealt out when B * windows would leave most of the chip idle
+inline int rv_band_split(int B, int nwin, int nb) {
+    if (const char* e = getenv("DASP_REVERB_BAND_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nb) return v; }
+    int split = 1;
+    while (split < nb && (long)B * nwin * split < 1024) ++split;
+    while (nb % split) ++split;             // equal shares
+    return split;
+}
 inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     RvDims d;
     long Lb = ColsGeom::N / 2;                       // n1 >= 8192 keeps every workgroup of the four-step kernels full
@@ -468,8 +484,13 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
     const f2* tw = (const f2*)Fspec;
     const ConvDims one = ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N};
     // 1. filter bank, envelope, gains, mean over bands -> impulse responses (functional.py:551-567)
-    hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, ir, (const float*)nullptr,
-                       (float*)nullptr, nb, L, taps, d.VQ);
+    const int bsplit = rv_band_split(B, d.nwin, nb);
+    if (bsplit > 1) {
+        const hipError_t e = hipMemsetAsync(ir, 0, sizeof(float) * (size_t)d.R * L, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit), dim3(FFT_T), 0, st, noise, tw, gains, decays, ir,
+                       (const float*)nullptr, (float*)nullptr, nb, L, taps, d.VQ);
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
         const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
         f2* Hc = (f2*)H + s0 * d.c.n1;
@@ -518,8 +539,8 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
                            (const float*)nullptr, mix + s0 / 2, gir + s0 * L, (float*)nullptr, one, L);
     }
     // d/dgain, d/ddecay: the filter bank again, weighted by gir
-    hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B), dim3(FFT_T), 0, st, noise, tw, gains, decays, (float*)nullptr,
-                       (const float*)gir, part, nb, L, taps, d.VQ);
+    hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B, (unsigned)rv_band_split(B, d.nwin, nb)), dim3(FFT_T), 0, st, noise, tw, gains,
+                       decays, (float*)nullptr, (const float*)gir, part, nb, L, taps, d.VQ);
     const int nfin = B * nb > B ? B * nb : B;
     hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
                        d.c.npairs * d.ctiles);

@@ -26,14 +26,13 @@ def counter(name):
                 vals.setdefault(k, []).append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in vals.items()}      # second half of the launches (warm)
 f, w = counter("FETCH_SIZE"), counter("WRITE_SIZE")
-h = hashlib.sha256()
-for p in ("sosfilt.hip", "common.hpp"):        # bench.py kernel_source_hash()
-    h.update(p.encode()); h.update(open(os.path.join("dasp_pytorch_amd/csrc", p), "rb").read())
+sys.path.insert(0, os.getcwd())
+from dasp_pytorch_amd.csrc.build import kernel_source_hash
 units = 256 * 2 * 131072
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes with --kernel-trace only, KB units) on tools/sosbench 256 2 131072 "
                "(DASP_PEQ=1 DASP_DESIGNED=1: the designed-cascade backward kernel), averaged over the second half of 42 launches; FETCH_SIZE doubled "
                "per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE as is. scripts/hbm_traffic.sh",
-       "shape": [256, 2, 131072], "kernel_source_hash": h.hexdigest()[:16]}
+       "shape": [256, 2, 131072], "kernel_source_hash": kernel_source_hash()}
 for k, alg in (("sos_fwd_kernel", 8 * units), ("sos_bwd_kernel", 12 * units)):
     res[k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k], "hbm_bytes": int(2 * f[k] * 1024 + w[k] * 1024), "algorithmic_bytes": alg}
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)

@@ -114,3 +114,21 @@ def test_reverb_semantics(D):
     assert y1[..., :100].abs().max().item() < 1e-6 and y1[..., 100 + 512:].abs().max().item() < 1e-6
     y2 = D.noise_shaped_reverberation(2.5 * imp, SR, *c1, one[:1], num_samples=512, num_bandpass_taps=31, noise=nz)
     assert torch.allclose(y2, 2.5 * y1, rtol=1e-4, atol=1e-6)
+
+
+def test_band_split_filter_bank_equals_one_workgroup_per_window(D, monkeypatch):
+    """Few batch items: the filter-bank kernel deals the 12 bands out to several workgroups per (item, window) (float atomics into the
+    impulse responses; csrc/reverb.hip fb_fused_kernel) - same results as one workgroup per window, forward and every gradient."""
+    rng = np.random.default_rng(5)
+    B, C, N, L, taps = 2, 2, 20000, 9000, 255
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 2, N)).astype(np.float32)
+    p = rng.random((B, 25)).astype(np.float32)
+    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+    monkeypatch.setenv("DASP_REVERB_BAND_SPLIT", "1")
+    y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
+    for split in ("4", "12"):
+        monkeypatch.setenv("DASP_REVERB_BAND_SPLIT", split)
+        y2, gx2, gp2 = run(D, x, p, w, noise, L, taps)
+        assert np.abs(y2 - y1).max() <= 2e-6 * np.abs(y1).max() and np.abs(gx2 - gx1).max() <= 2e-6 * np.abs(gx1).max()
+        assert np.abs(gp2 - gp1).max() <= 1e-5 * np.abs(gp1).max()
