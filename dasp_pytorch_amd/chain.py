@@ -8,6 +8,7 @@ bit-for-bit the same mathematics (up to fp32 rounding of one multiply) and the g
 """
 import torch
 
+from . import functional as _functional
 from . import modules as _modules
 
 
@@ -36,9 +37,14 @@ class StyleTransferChain:
         gain_db = gain_params * span + lo                                   # (bs, 1), differentiable
         clo, cspan = self.compressor._affine(comp_params)
         comp = comp_params * cspan + clo                                    # denormalised compressor controls, columns in param_ranges order
+        y = self.equalizer.process_normalized(x, eq_params)                 # fused de-normalise + design; no gradient for x: the no-gx kernel
         names = list(self.compressor.param_ranges)
-        kwargs = {n: comp[:, i] for i, n in enumerate(names)}
-        kwargs["makeup_gain_db"] = kwargs["makeup_gain_db"] + gain_db[:, 0]   # the fold
-        y = self.equalizer.process_normalized(x, eq_params)
-        y = self.compressor.process_fn(y, self.sample_rate, **kwargs)
+        if y.is_cuda and y.dtype is torch.float32 and names == _modules._DYN_NAMES:
+            fold = torch.zeros(6, dtype=comp.dtype, device=comp.device)
+            fold[5] = 1.0
+            y = _functional._dynamics_from_matrix(0, y, self.sample_rate, comp + gain_db * fold)      # the fold: make-up gain += gain
+        else:
+            kwargs = {n: comp[:, i] for i, n in enumerate(names)}
+            kwargs["makeup_gain_db"] = kwargs["makeup_gain_db"] + gain_db[:, 0]
+            y = self.compressor.process_fn(y, self.sample_rate, **kwargs)
         return self.reverb.process_normalized(y, reverb_params)

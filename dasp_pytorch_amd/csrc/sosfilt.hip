@@ -146,6 +146,12 @@ struct PeqSpec {
     int types[8];        // 0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass
     double sample_rate;
     const float* rows[24];   // optional: the 3 S controls as separate vectors of Bs values ([3 k + dir]); used when `params` is null
+    // normalised controls (Processor.process_normalized, dasp_pytorch/modules.py:25-91): when `norm` is set the packed `params` hold values
+    // on [0, 1]; control i of a section row is lo[i] + span[i] * p (modules.py:13-14), the Jacobian columns are taken w.r.t. p, and a value
+    // outside [0, 1] sets bit i of *flag (the reference's ValueError, modules.py:83-84, raised by the host after one read-back)
+    int norm;
+    double lo[24], span[24];
+    unsigned* flag;
 };
 
 // RBJ cookbook design, same formulas as dasp_pytorch/signal.py:255-304, in fp64 with the Jacobian
@@ -243,7 +249,17 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     if (tid < 3 * S) {   // thread = (section k, control dir): values + one Jacobian column each
         const int k = tid / 3, dir = tid % 3;
         double c5[5], dc5[5] = {0, 0, 0, 0, 0}, a0 = 1.0;
-        if (params) {
+        if (params && spec.norm) {
+            const float* p = params + ((size_t)item * S + k) * 3;
+            double v[3];
+            for (int c = 0; c < 3; ++c) {
+                const double pc = (double)p[c];
+                if (spec.flag && (pc < 0.0 || pc > 1.0) && dir == 0) atomicOr(spec.flag, 1u << (3 * k + c));   // (NaN passes, as in the reference)
+                v[c] = spec.lo[3 * k + c] + spec.span[3 * k + c] * pc;
+            }
+            rbj_design(spec.types[k], spec.sample_rate, v[0], v[1], v[2], dir, c5, dc5);
+            for (int c = 0; c < 5; ++c) dc5[c] *= spec.span[3 * k + dir];          // d/d(normalised control)
+        } else if (params) {
             const float* p = params + ((size_t)item * S + k) * 3;
             rbj_design(spec.types[k], spec.sample_rate, (double)p[0], (double)p[1], (double)p[2], dir, c5, dc5);
         } else if (!sos) {
@@ -1788,6 +1804,34 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
                      const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
                      void* stream) {
     int rc = dasp_peq_prepare_rows(rows, Bp, S, types, sample_rate, tab, dtab, stream);
+    if (rc != DASP_OK) return rc;
+    if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
+    rc = dasp_sos_segment_prepare(dtab, Bp, S, Tseg, segtab, stream);
+    return rc != DASP_OK ? rc : dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+}
+
+// The same from the normalised (Bp, 3 S) parameter tensor of Processor.process_normalized (dasp_pytorch/modules.py:25-91): de-normalisation
+// (lo / span: host arrays of 3 S doubles, min and max - min per column, modules.py:136-155), range check (flag: one device word, bit i set
+// when column i leaves [0, 1]; zero it before the call, read it back to raise the reference's ValueError; NULL = no check), design and
+// cascade in the two launches of dasp_peq_forward. dasp_peq_backward with mode 1 then returns the gradient w.r.t. the normalised tensor.
+int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                          unsigned* flag, float* tab, double* dtab, const float* x, float* y, float* carries, int B, int C, long N, long Tseg,
+                          double* segtab, float* segbuf, void* stream) {
+    if (!pn || !types || !lo || !span || !tab || !dtab || Bp <= 0 || S > 8 || S <= 0) return DASP_ERR_ARG;
+    int rc = dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        PeqSpec spec = {};
+        for (int i = 0; i < S; ++i) {
+            if (types[i] < 0 || types[i] > 4) return DASP_ERR_ARG;
+            spec.types[i] = types[i];
+        }
+        for (int i = 0; i < 3 * S; ++i) { spec.lo[i] = lo[i]; spec.span[i] = span[i]; }
+        spec.sample_rate = sample_rate;
+        spec.norm = 1;
+        spec.flag = flag;
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bp), dim3(256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab);
+        return check_launch();
+    });
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
     rc = dasp_sos_segment_prepare(dtab, Bp, S, Tseg, segtab, stream);

@@ -239,9 +239,21 @@ def noise_shaped_reverberation(
                               band8_gain, band9_gain, band10_gain, band11_gain], dim=1).view(bs, 12)
     band_decays = torch.stack([band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
                                band7_decay, band8_decay, band9_decay, band10_decay, band11_decay], dim=1).view(bs, 12)
-    mix = mix.view(bs)
+    return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise)
+
+
+def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False):
+    """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what the function above stacks its 24 + 1
+    arguments into, and what NoiseShapedReverb.process_normalized has as slices of its de-normalised (bs, 25) tensor. x: (bs, 2, seq_len)."""
+    bs = x.shape[0]
     filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
     if noise is None:
         shape = (bs * 2, 12, num_samples + num_bandpass_taps - 1)
         noise = torch.randn(*shape, device=x.device) if device_noise else torch.randn(*shape).to(x.device)
     return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples))
+
+
+def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):
+    """compressor / expander on the (bs, 6) matrix of controls (columns in the functions' argument order)."""
+    from .ops import DynamicsMatrixFunction
+    return DynamicsMatrixFunction.apply(x, mode, float(sample_rate), float(eps), int(lookahead_samples), controls)

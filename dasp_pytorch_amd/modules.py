@@ -144,6 +144,9 @@ def _eq_ranges(sample_rate, g, q):
     return ranges
 
 
+_EQ_NAMES = list(_eq_ranges(44100, (0, 1), (0, 1)))
+
+
 class ParametricEQ(Processor):
     def __init__(self, sample_rate: int, min_gain_db: float = -20.0, max_gain_db: float = 20.0, min_q_factor: float = 0.1,
                  max_q_factor: float = 6.0):
@@ -151,6 +154,21 @@ class ParametricEQ(Processor):
         self.sample_rate = sample_rate
         self.process_fn = F.parametric_eq
         self.param_ranges = _eq_ranges(sample_rate, (min_gain_db, max_gain_db), (min_q_factor, max_q_factor))
+
+    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
+        """As Processor.process_normalized; float32 audio on the GPU takes the fused op (ops.ParametricEQNormFunction): de-normalisation,
+        [0, 1] check and filter design inside the design kernel, gradients returned w.r.t. `param_tensor` itself. Anything else (float64,
+        a replaced process_fn, renamed ranges) goes through the generic path."""
+        names = list(self.param_ranges)
+        fused = (self.process_fn is F.parametric_eq and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and param_tensor.dim() == 2
+                 and param_tensor.shape[1] == 18 and param_tensor.shape[0] in (1, x.shape[0]) and names == _EQ_NAMES
+                 and param_tensor.is_floating_point())
+        if not fused:
+            return super().process_normalized(x, param_tensor)
+        from .ops import ParametricEQNormFunction
+        lo = [float(r[0]) for r in self.param_ranges.values()]
+        span = [float(r[1]) - float(r[0]) for r in self.param_ranges.values()]
+        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, names)
 
 
 class _Dynamics(Processor):
@@ -167,6 +185,21 @@ class _Dynamics(Processor):
             "knee_db": (min_knee_db, max_knee_db), "makeup_gain_db": (min_makeup_gain_db, max_makeup_gain_db)}
 
 
+_DYN_NAMES = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
+
+
+def _dynamics_process_normalized(self, mode, x, param_tensor):
+    """Compressor / Expander.process_normalized: float32 audio on the GPU hands the de-normalised (bs, 6) matrix to the kernels as one
+    tensor (ops.DynamicsMatrixFunction) instead of six column views that are stacked again one call further down."""
+    fused = (x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and param_tensor.dim() == 2 and param_tensor.shape == (x.shape[0], 6)
+             and list(self.param_ranges) == _DYN_NAMES and param_tensor.is_floating_point())
+    if not fused:
+        return Processor.process_normalized(self, x, param_tensor)
+    self._check_range(param_tensor)
+    lo, span = self._affine(param_tensor)
+    return F._dynamics_from_matrix(mode, x, self.sample_rate, param_tensor * span + lo)
+
+
 class Compressor(_Dynamics):
     """Positional order of the reference's constructor (modules.py:159-187)."""
 
@@ -177,6 +210,11 @@ class Compressor(_Dynamics):
         super().__init__(F.compressor, sample_rate, min_threshold_db, max_threshold_db, min_ratio, max_ratio, min_attack_ms, max_attack_ms,
                          min_release_ms, max_release_ms, min_knee_db, max_knee_db, min_makeup_gain_db, max_makeup_gain_db)
 
+    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
+        if self.process_fn is not F.compressor:
+            return super().process_normalized(x, param_tensor)
+        return _dynamics_process_normalized(self, 0, x, param_tensor)
+
 
 class Expander(_Dynamics):
     def __init__(self, sample_rate: int, min_threshold_db: float = -60.0, max_threshold_db: float = 0.0, min_ratio: float = 1.0,
@@ -185,6 +223,14 @@ class Expander(_Dynamics):
                  max_makeup_gain_db: float = 12.0):
         super().__init__(F.expander, sample_rate, min_threshold_db, max_threshold_db, min_ratio, max_ratio, min_attack_ms, max_attack_ms,
                          min_release_ms, max_release_ms, min_knee_db, max_knee_db, min_makeup_gain_db, max_makeup_gain_db)
+
+    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
+        if self.process_fn is not F.expander:
+            return super().process_normalized(x, param_tensor)
+        return _dynamics_process_normalized(self, 1, x, param_tensor)
+
+
+_REV_NAMES = [f"band{i}_gain" for i in range(12)] + [f"band{i}_decay" for i in range(12)] + ["mix"]
 
 
 class NoiseShapedReverb(Processor):
@@ -200,3 +246,20 @@ class NoiseShapedReverb(Processor):
         self.param_ranges = {f"band{i}_gain": (min_band_gain, max_band_gain) for i in range(12)}
         self.param_ranges.update({f"band{i}_decay": (min_band_decay, max_band_decay) for i in range(12)})
         self.param_ranges["mix"] = (min_mix, max_mix)
+        self._rev_kwargs = dict(num_samples=num_samples, num_bandpass_taps=num_bandpass_taps, device_noise=device_noise)
+        self._rev_fn = self.process_fn
+
+    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
+        """As Processor.process_normalized; float32 audio on the GPU passes the de-normalised (bs, 25) tensor on as three slices (band
+        gains, band decays, mix) instead of 25 column views that functional.noise_shaped_reverberation would stack again."""
+        fused = (self.process_fn is self._rev_fn and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and x.shape[1] <= 2
+                 and param_tensor.dim() == 2 and param_tensor.shape == (x.shape[0], 25) and param_tensor.is_floating_point()
+                 and list(self.param_ranges) == _REV_NAMES)
+        if not fused:
+            return super().process_normalized(x, param_tensor)
+        self._check_range(param_tensor)
+        lo, span = self._affine(param_tensor)
+        d = param_tensor * span + lo
+        if x.shape[1] == 1:   # if mono copy to stereo (functional.py:493-495)
+            x = x.repeat(1, 2, 1)
+        return F._reverb_from_matrices(x, self.sample_rate, d[:, :12], d[:, 12:24], d[:, 24], **self._rev_kwargs)

@@ -245,6 +245,73 @@ class ParametricEQFunction(torch.autograd.Function):
         return (gx.to(ctx.x_dtype) if need_gx else None, None, None) + gcols
 
 
+_RANGE_FLAGS = {}
+
+
+def _range_flag(dev):
+    """One zeroed device word per (device, stream) for the in-kernel [0, 1] check of normalised parameters (dasp_peq_forward_norm)."""
+    key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
+    t = _RANGE_FLAGS.get(key)
+    if t is None:
+        if len(_RANGE_FLAGS) >= 32:
+            _RANGE_FLAGS.clear()
+        t = _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+class ParametricEQNormFunction(torch.autograd.Function):
+    """Processor.process_normalized for the EQ as one op (reference: dasp_pytorch/modules.py:25-91 + functional.py:118-272):
+    the normalised (Bp, 3 S) tensor goes straight into the design kernel, which de-normalises it (lo + span * p in fp64), checks [0, 1] and
+    builds the tables; the backward pass returns the gradient w.r.t. the normalised tensor. One tensor input instead of 3 S, no
+    de-normalisation / slicing / stacking ops around the kernels, and the range check costs one word read back (none inside a HIP-graph
+    capture) instead of a reduction."""
+
+    @staticmethod
+    def forward(ctx, x, pn, sample_rate, types, lo, span, names):
+        _lib.require_device(x, "x")
+        _lib.require_same_device(x, param_tensor=pn)
+        S = len(types)
+        dev = x.device
+        ctx.meta = (x.dtype, pn.dtype, pn.shape)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(dev):
+            pn32 = _f32c(pn)
+            Bp = pn32.shape[0]
+            x32 = _f32c(x)
+            B, C, N = x32.shape
+            need = any(ctx.needs_input_grad)
+            w = _SosWork(Bp, S, x32, need)
+            y = torch.empty_like(x32)
+            check_range = not torch.cuda.is_current_stream_capturing()       # a capture cannot read the flag back (modules._check_range)
+            flag = _range_flag(dev) if check_range else None
+            call("dasp_peq_forward_norm", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
+                 (ctypes.c_double * (3 * S))(*span), ptr(flag), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y), ptr(w.carries), B, C, N, w.tseg,
+                 ptr(w.segtab), ptr(w.segbuf), stream())
+            if check_range:
+                bits = int(flag.item())              # the one host sync of the call (the reference: two per parameter, modules.py:83)
+                if bits:
+                    flag.zero_()
+                    raise ValueError(f"Parameter {names[(bits & -bits).bit_length() - 1]} of is out of range.")
+            if need:
+                ctx.work = w
+                ctx.save_for_backward(x32)
+        return y.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xd, pd, pshape = ctx.meta
+        if ctx.empty:
+            return torch.empty_like(gy), torch.zeros(pshape, dtype=pd, device=gy.device), None, None, None, None, None
+        (x32,) = ctx.saved_tensors
+        need_gx, need_gp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        with torch.cuda.device(x32.device):
+            gx, gp = ctx.work.backward(x32, _f32c(gy), 1, 1, need_gx, need_gp)       # mode 1: (Bp, S, 3) = the layout of the (Bp, 3 S) tensor
+        return (gx.to(xd) if need_gx else None, gp.reshape(pshape).to(pd) if need_gp else None, None, None, None, None, None)
+
+
 class _ElementwiseFunction(torch.autograd.Function):
     """Shared plumbing of gain / distortion: y = f(x, ctl), ctl one dB value per batch item (gain)
     or per (b, c) row (distortion)."""
@@ -310,6 +377,48 @@ class DistortionFunction(_ElementwiseFunction):
         return DistortionFunction._grad(ctx, gy)
 
 
+def _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need):
+    """The compressor / expander kernels on ctl (B, 5) fp32 rows [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db]; returns y (fp32)
+    and what the backward pass needs."""
+    L = _lib.lib()
+    B, C, N = x.shape
+    x32 = _f32c(x)
+    y = torch.empty_like(x32)
+    carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
+    lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
+    # few items: every item is cut into segments that run as independent workgroups (dasp_hip.h, "Few batch items")
+    tseg = 0 if os.environ.get("DASP_DYN_SEGMENT", "auto") == "0" else int(os.environ.get("DASP_DYN_SEGMENT_TILES") or L.dasp_dyn_segment_tiles(B, N))
+    segbuf = torch.empty(2 * B * L.dasp_dyn_segments(N, tseg), dtype=torch.float32, device=x.device) if tseg else None
+    if tseg:
+        call("dasp_dynamics_forward_seg", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), ptr(segbuf), B, C, N, float(sample_rate),
+             float(eps), int(lookahead), tseg, stream())
+    else:
+        call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
+             float(eps), int(lookahead), stream())
+    saved = (x32, ctl, carries, lin if lin is not None else torch.empty(0, device=x.device))
+    return y, saved, (mode, float(sample_rate), float(eps), int(lookahead), tseg)
+
+
+def _dyn_backward(saved, cfg, gy):
+    """gx (fp32) and gctl (B, 5) for the rows of ctl."""
+    L = _lib.lib()
+    x32, ctl, carries, lin = saved
+    mode, sr, eps, look, tseg = cfg
+    B, C, N = x32.shape
+    gx = torch.empty_like(x32)
+    gctl = torch.empty(B, 5, dtype=torch.float32, device=x32.device)
+    G = int(L.dasp_dyn_segments(N, tseg))
+    partials = torch.empty(L.dasp_dyn_partial_floats(B * G), dtype=torch.float32, device=x32.device)
+    if tseg:
+        segbuf = torch.empty(2 * B * G, dtype=torch.float32, device=x32.device)
+        call("dasp_dynamics_backward_seg", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
+             ptr(gx), ptr(gctl), ptr(partials), ptr(segbuf), B, C, N, sr, eps, look, tseg, stream())
+    else:
+        call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
+             ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
+    return gx, gctl
+
+
 class DynamicsFunction(torch.autograd.Function):
     """Compressor (mode 0) / expander (mode 1). Controls enter as separate tensors with bs elements
     each, in the reference's order: threshold_db, ratio, attack_ms, release_ms, knee_db,
@@ -318,8 +427,6 @@ class DynamicsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mode, sample_rate, eps, lookahead, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db):
         _lib.require_device(x, "x")
-        L = _lib.lib()
-        B, C, N = x.shape
         ctx.meta = (x.dtype, [(c.dtype, c.shape) for c in (threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db)])
         ctx.empty = x.numel() == 0
         if ctx.empty:
@@ -327,23 +434,11 @@ class DynamicsFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             ctls = (threshold_db, ratio, attack_ms, knee_db, makeup_gain_db)
             ctl = torch.stack([c.detach().reshape(-1).to(device=x.device, dtype=torch.float32) for c in ctls], dim=1).contiguous()
-            x32 = _f32c(x)
-            y = torch.empty_like(x32)
             need = any(ctx.needs_input_grad)
-            carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
-            lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
-            # few items: every item is cut into segments that run as independent workgroups (dasp_hip.h, "Few batch items")
-            tseg = 0 if os.environ.get("DASP_DYN_SEGMENT", "auto") == "0" else int(os.environ.get("DASP_DYN_SEGMENT_TILES") or L.dasp_dyn_segment_tiles(B, N))
-            segbuf = torch.empty(2 * B * L.dasp_dyn_segments(N, tseg), dtype=torch.float32, device=x.device) if tseg else None
-            if tseg:
-                call("dasp_dynamics_forward_seg", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), ptr(segbuf), B, C, N, float(sample_rate),
-                     float(eps), int(lookahead), tseg, stream())
-            else:
-                call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
-                     float(eps), int(lookahead), stream())
+            y, saved, cfg = _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need)
             if need:
-                ctx.save_for_backward(x32, ctl, carries, lin if lin is not None else torch.empty(0, device=x.device))
-                ctx.cfg = (mode, float(sample_rate), float(eps), int(lookahead), tseg)
+                ctx.save_for_backward(*saved)
+                ctx.cfg = cfg
         return y.to(x.dtype)
 
     @staticmethod
@@ -352,22 +447,9 @@ class DynamicsFunction(torch.autograd.Function):
         xd, cm = ctx.meta
         if ctx.empty:
             return (torch.empty_like(gy), None, None, None, None) + tuple(torch.zeros(shape, dtype=dt, device=gy.device) for dt, shape in cm)
-        L = _lib.lib()
-        x32, ctl, carries, lin = ctx.saved_tensors
-        mode, sr, eps, look, tseg = ctx.cfg
-        B, C, N = x32.shape
+        x32 = ctx.saved_tensors[0]
         with torch.cuda.device(x32.device):
-            gx = torch.empty_like(x32)
-            gctl = torch.empty(B, 5, dtype=torch.float32, device=x32.device)
-            G = int(L.dasp_dyn_segments(N, tseg))
-            partials = torch.empty(L.dasp_dyn_partial_floats(B * G), dtype=torch.float32, device=x32.device)
-            if tseg:
-                segbuf = torch.empty(2 * B * G, dtype=torch.float32, device=x32.device)
-                call("dasp_dynamics_backward_seg", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
-                     ptr(gx), ptr(gctl), ptr(partials), ptr(segbuf), B, C, N, sr, eps, look, tseg, stream())
-            else:
-                call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
-                     ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
+            gx, gctl = _dyn_backward(ctx.saved_tensors, ctx.cfg, gy)
         g = gctl.t().contiguous()      # rows: threshold, ratio, attack, knee, makeup
         rows = {0: g[0], 1: g[1], 2: g[2], 4: g[3], 5: g[4]}
         outs = []
@@ -379,6 +461,45 @@ class DynamicsFunction(torch.autograd.Function):
             else:
                 outs.append(rows[i].reshape(shape).to(dt))
         return (gx.to(xd) if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(outs)
+
+
+class DynamicsMatrixFunction(torch.autograd.Function):
+    """The same kernels on the six controls as one (bs, 6) matrix, columns in the reference's order (threshold_db, ratio, attack_ms,
+    release_ms, knee_db, makeup_gain_db) - what Processor.process_normalized has after de-normalising (modules.py:159-187): one tensor in,
+    one gradient matrix out (zero column for release_ms), no per-control slicing and stacking."""
+
+    @staticmethod
+    def forward(ctx, x, mode, sample_rate, eps, lookahead, controls):
+        _lib.require_device(x, "x")
+        _lib.require_same_device(x, controls=controls)
+        ctx.meta = (x.dtype, controls.dtype, controls.shape)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            ctl = controls.detach().to(torch.float32)[:, [0, 1, 2, 4, 5]].contiguous()
+            need = any(ctx.needs_input_grad)
+            y, saved, cfg = _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need)
+            if need:
+                ctx.save_for_backward(*saved)
+                ctx.cfg = cfg
+        return y.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xd, cd, cshape = ctx.meta
+        if ctx.empty:
+            return torch.empty_like(gy), None, None, None, None, torch.zeros(cshape, dtype=cd, device=gy.device)
+        x32 = ctx.saved_tensors[0]
+        with torch.cuda.device(x32.device):
+            gx, gctl = _dyn_backward(ctx.saved_tensors, ctx.cfg, gy)
+            g6 = None
+            if ctx.needs_input_grad[5]:
+                g6 = torch.zeros(cshape, dtype=torch.float32, device=x32.device)
+                g6[:, [0, 1, 2, 4, 5]] = gctl
+                g6 = g6.to(cd)
+        return gx.to(xd) if ctx.needs_input_grad[0] else None, None, None, None, None, g6
 
 
 def _cbuf(n, device):

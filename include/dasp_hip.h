@@ -103,6 +103,13 @@ int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const
 int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, double sample_rate, float* tab, double* dtab,
                      const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
                      void* stream);
+/* The same from the normalised (Bp, 3 S) tensor of Processor.process_normalized (dasp_pytorch/modules.py:25-91) - SURVEY 8(f1)'s fused op:
+ * de-normalisation (lo, span: host arrays of 3 S doubles, min and max - min of every column, modules.py:136-155), range check (flag: one
+ * device word, zeroed by the caller; bit i is set when column i leaves [0, 1] - read it back to raise the reference's ValueError,
+ * modules.py:83-84; NULL = no check), design and cascade. dasp_peq_backward with mode 1 returns the gradient w.r.t. the normalised tensor. */
+int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                          unsigned* flag, float* tab, double* dtab, const float* x, float* y, float* carries, int B, int C, long N,
+                          long Tseg, double* segtab, float* segbuf, void* stream);
 int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, const float* gy, const float* carries, float* gx,
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream);

@@ -25,12 +25,28 @@ def test_process_normalized_matches_functional(D):
     lo = torch.tensor([r[0] for r in eq.param_ranges.values()], device="cuda:0")
     hi = torch.tensor([r[1] for r in eq.param_ranges.values()], device="cuda:0")
     d = p.detach() * (hi - lo) + lo
-    assert torch.equal(y, D.parametric_eq(x, SR, *[d[:, i] for i in range(18)]))
+    # (the fused op de-normalises in fp64 inside the design kernel; the functional call gets the fp32-rounded physical values)
+    assert torch.allclose(y, D.parametric_eq(x, SR, *[d[:, i] for i in range(18)]), rtol=0, atol=2e-5 * float(y.abs().max()))
     y.square().mean().backward()
     assert p.grad.shape == p.shape and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
     with pytest.raises(ValueError, match="band2_gain_db"):
         bad = p.detach().clone(); bad[0, 9] = -0.1
         eq.process_normalized(x, bad)
+    assert torch.isfinite(eq.process_normalized(x, p.detach())).all()      # the in-kernel range flag was reset by the failed call
+    # Compressor / reverb hand their de-normalised matrix to the kernels as one tensor: same numbers as the per-control functional calls
+    comp = D.Compressor(SR)
+    pc = torch.rand(B, 6, device="cuda:0", generator=g, requires_grad=True)
+    yc = comp.process_normalized(x, pc)
+    lo = torch.tensor([r[0] for r in comp.param_ranges.values()], device="cuda:0"); hi = torch.tensor([r[1] for r in comp.param_ranges.values()], device="cuda:0")
+    dc = (pc.detach() * (hi - lo) + lo).requires_grad_(True)
+    yc2 = D.compressor(x, SR, *[dc[:, i] for i in range(6)])
+    assert torch.equal(yc, yc2)
+    w = torch.randn(B, 2, N, device="cuda:0", generator=g)
+    (yc * w).sum().backward(); (yc2 * w).sum().backward()
+    assert torch.allclose(pc.grad, dc.grad * (hi - lo), rtol=1e-5, atol=1e-9) and float(pc.grad[:, 3].abs().max()) == 0.0
+    with pytest.raises(ValueError, match="knee_db"):
+        badc = pc.detach().clone(); badc[1, 4] = 1.5
+        comp.process_normalized(x, badc)
     # Distortion works here (it raises in the reference); mono so that (bs,) drives are legal
     dist = D.Distortion()
     assert torch.isfinite(dist.process_normalized(x[:, :1], torch.rand(B, 1, device="cuda:0", generator=g))).all()
