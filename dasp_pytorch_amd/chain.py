@@ -40,9 +40,8 @@ class StyleTransferChain:
         y = self.equalizer.process_normalized(x, eq_params)                 # fused de-normalise + design; no gradient for x: the no-gx kernel
         names = list(self.compressor.param_ranges)
         if y.is_cuda and y.dtype is torch.float32 and names == _modules._DYN_NAMES:
-            fold = torch.zeros(6, dtype=comp.dtype, device=comp.device)
-            fold[5] = 1.0
-            y = _functional._dynamics_from_matrix(0, y, self.sample_rate, comp + gain_db * fold)      # the fold: make-up gain += gain
+            folded = torch.cat([comp[:, :5], comp[:, 5:] + gain_db], dim=1)                            # the fold: make-up gain += gain
+            y = _functional._dynamics_from_matrix(0, y, self.sample_rate, folded)
         else:
             kwargs = {n: comp[:, i] for i, n in enumerate(names)}
             kwargs["makeup_gain_db"] = kwargs["makeup_gain_db"] + gain_db[:, 0]

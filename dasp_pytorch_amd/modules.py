@@ -41,6 +41,10 @@ class Processor:
     sample_rate = None
     process_fn = None
     param_ranges: Dict[str, tuple] = {}
+    # The reference validates every normalised parameter on every call (modules.py:83-84: two host syncs per parameter). Here it is one
+    # word read back per call - still a pipeline drain. A training loop whose controls come out of a sigmoid can switch it off per
+    # processor (`proc.validate_range = False`) or for the class; inside a HIP-graph capture it is skipped in any case.
+    validate_range = True
 
     def __init__(self):
         pass
@@ -87,7 +91,7 @@ class Processor:
     def _check_range(self, param_tensor: torch.Tensor):
         # a HIP-graph capture cannot read a result back on the host: inside one the [0, 1] check is skipped (validate the
         # controls once in eager mode; a sigmoid head, as in the reference's models, satisfies it by construction)
-        if param_tensor.is_cuda and torch.cuda.is_current_stream_capturing():
+        if not self.validate_range or (param_tensor.is_cuda and torch.cuda.is_current_stream_capturing()):
             return
         p = param_tensor.detach()
         bad = ((p < 0) | (p > 1)).any(dim=0)                   # one reduction ...
@@ -168,7 +172,7 @@ class ParametricEQ(Processor):
         from .ops import ParametricEQNormFunction
         lo = [float(r[0]) for r in self.param_ranges.values()]
         span = [float(r[1]) - float(r[0]) for r in self.param_ranges.values()]
-        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, names)
+        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, names if self.validate_range else None)
 
 
 class _Dynamics(Processor):

@@ -284,7 +284,8 @@ class ParametricEQNormFunction(torch.autograd.Function):
             need = any(ctx.needs_input_grad)
             w = _SosWork(Bp, S, x32, need)
             y = torch.empty_like(x32)
-            check_range = not torch.cuda.is_current_stream_capturing()       # a capture cannot read the flag back (modules._check_range)
+            # names = None: the caller switched the validation off; a capture cannot read the flag back (modules._check_range)
+            check_range = names is not None and not torch.cuda.is_current_stream_capturing()
             flag = _range_flag(dev) if check_range else None
             call("dasp_peq_forward_norm", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
                  (ctypes.c_double * (3 * S))(*span), ptr(flag), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y), ptr(w.carries), B, C, N, w.tseg,
@@ -477,7 +478,8 @@ class DynamicsMatrixFunction(torch.autograd.Function):
         if ctx.empty:
             return torch.empty_like(x)
         with torch.cuda.device(x.device):
-            ctl = controls.detach().to(torch.float32)[:, [0, 1, 2, 4, 5]].contiguous()
+            c32 = controls.detach().to(torch.float32)
+            ctl = torch.cat([c32[:, :3], c32[:, 4:]], dim=1)         # (no index tensor: a list index is a host -> device copy per call)
             need = any(ctx.needs_input_grad)
             y, saved, cfg = _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need)
             if need:
@@ -496,9 +498,7 @@ class DynamicsMatrixFunction(torch.autograd.Function):
             gx, gctl = _dyn_backward(ctx.saved_tensors, ctx.cfg, gy)
             g6 = None
             if ctx.needs_input_grad[5]:
-                g6 = torch.zeros(cshape, dtype=torch.float32, device=x32.device)
-                g6[:, [0, 1, 2, 4, 5]] = gctl
-                g6 = g6.to(cd)
+                g6 = torch.cat([gctl[:, :3], torch.zeros_like(gctl[:, :1]), gctl[:, 3:]], dim=1).to(cd)      # release_ms: zero column
         return gx.to(xd) if ctx.needs_input_grad[0] else None, None, None, None, None, g6
 
 

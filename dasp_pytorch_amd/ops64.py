@@ -104,7 +104,7 @@ class ParametricEQ64Function(torch.autograd.Function):
             for k in range(S):
                 call("dasp_biquad_design", ptr(cols[3 * k]), ptr(cols[3 * k + 1]), ptr(cols[3 * k + 2]), Bp, int(types[k]), float(sample_rate),
                      ptr(ba[k]), ptr(jac[k]), stream())
-            c5 = ba[:, :, [0, 1, 2, 4, 5]].permute(1, 0, 2).contiguous()          # (Bp, S, 5): a re-layout, no arithmetic
+            c5 = torch.cat([ba[:, :, :3], ba[:, :, 4:]], dim=2).permute(1, 0, 2).contiguous()          # (Bp, S, 5): a re-layout, no arithmetic
             x64 = _d(x, dev)
             y = torch.empty_like(x64)
             need_c = any(ctx.needs_input_grad[3:])

@@ -33,6 +33,9 @@ def test_process_normalized_matches_functional(D):
         bad = p.detach().clone(); bad[0, 9] = -0.1
         eq.process_normalized(x, bad)
     assert torch.isfinite(eq.process_normalized(x, p.detach())).all()      # the in-kernel range flag was reset by the failed call
+    eq.validate_range = False                                              # opt-out: no read-back, out-of-range values are simply used
+    assert torch.isfinite(eq.process_normalized(x, bad)).all()
+    eq.validate_range = True
     # Compressor / reverb hand their de-normalised matrix to the kernels as one tensor: same numbers as the per-control functional calls
     comp = D.Compressor(SR)
     pc = torch.rand(B, 6, device="cuda:0", generator=g, requires_grad=True)
