@@ -547,7 +547,9 @@ long dasp_dyn_segment_tiles(long B, long N) {
     const long nt = dasp_dyn_num_tiles(N);
     if (B <= 0 || B >= 128 || nt < 2 * kDWF) return 0;
     long T = kDWF;                                     // at least one tile per forward wave
-    while (B * ((nt + T - 1) / T) > 1024 && T < nt) T *= 2;
+    // one (16-wave) workgroup per CU: measured at (8 / 16 / 32, 2, 262144) forward + backward 0.080 / 0.085 / 0.123 ms with this rule against
+    // 0.080 / 0.106 / 0.168 ms with up to four per CU (profiles/r02/segment_length_sweep.log)
+    while (B * ((nt + T - 1) / T) > 256 && T < nt) T *= 2;
     return (nt + T - 1) / T > 1 ? T : 0;
 }
 long dasp_dyn_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_dyn_num_tiles(N) + Tseg - 1) / Tseg : 1; }

@@ -1722,7 +1722,9 @@ long dasp_sos_segment_tiles(long rows, long N) {
     const long nt = dasp_sos_num_tiles(N);
     if (rows <= 0 || rows >= 128 || nt < 16) return 0;
     long T = 8;                                        // at least one tile per forward wave
-    while (rows * ((nt + T - 1) / T) > 1024 && T < nt) T *= 2;
+    // two workgroups per CU: measured at (8 / 16 / 32, 2, 131072) forward + backward 0.107 / 0.114 / 0.142 ms with this rule against 0.106 /
+    // 0.114 / 0.162 ms with up to four per CU and 0.12 / 0.12 / 0.167 with one (profiles/r02/segment_length_sweep.log)
+    while (rows * ((nt + T - 1) / T) > 512 && T < nt) T *= 2;
     return (nt + T - 1) / T > 1 ? T : 0;
 }
 long dasp_sos_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_sos_num_tiles(N) + Tseg - 1) / Tseg : 1; }
