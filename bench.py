@@ -208,6 +208,25 @@ def secondary(dev):
              2 * 1.354e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
+    # the reference's whole effect chain as its training loop calls it (examples/style_transfer.py:150-154: EQ -> compressor -> reverb -> gain
+    # through process_normalized, mono input, no gradient for it) at its batch size: everything of SURVEY 8(f) that is in - fused
+    # process_normalized, no-gx EQ backward, segmented rows / items, gain folded into the make-up gain, no saved wet signal
+    chain = D.chain.StyleTransferChain(SR, device_noise=True)
+    xc = rnd(16, 1, 131072) * 2 - 1
+    pcs = [(rnd(16, n) * 0.9 + 0.05).requires_grad_(True) for n in chain.num_params]
+    wc = torch.randn(16, 2, 131072, device=dev, generator=g)
+
+    def chain_step():
+        for p in pcs:
+            p.grad = None
+        chain.process_normalized(xc, *pcs).backward(wc)
+    t = _time_steps(chain_step)
+    _lib.timers.start(every=1)
+    for _ in range(10):
+        chain_step()
+    res["style_transfer_chain_b16"] = {"shape": [16, 1, 131072], "ms_fwd_bwd": round(t * 1e3, 3),
+                                       "gpu_ms_fwd_bwd": round(sum(sum(v) for v in _lib.timers.stop().values()) / 10, 4),
+                                       "note": "EQ -> compressor -> reverb -> gain on normalised parameters, gradients for all 50 of them"}
     xs = (rnd(16, 2, 131072) * 0.6 - 0.3).requires_grad_(True)
     ys = rnd(16, 2, 131072) * 0.6 - 0.3
     loss_fn = D.losses.MultiResolutionSTFTLoss()

@@ -26,7 +26,7 @@ def test_process_normalized_matches_functional(D):
     hi = torch.tensor([r[1] for r in eq.param_ranges.values()], device="cuda:0")
     d = p.detach() * (hi - lo) + lo
     # (the fused op de-normalises in fp64 inside the design kernel; the functional call gets the fp32-rounded physical values)
-    assert torch.allclose(y, D.parametric_eq(x, SR, *[d[:, i] for i in range(18)]), rtol=0, atol=2e-5 * float(y.abs().max()))
+    assert torch.allclose(y, D.parametric_eq(x, SR, *[d[:, i] for i in range(18)]), rtol=0, atol=2e-5 * float(y.detach().abs().max()))
     y.square().mean().backward()
     assert p.grad.shape == p.shape and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
     with pytest.raises(ValueError, match="band2_gain_db"):
