@@ -163,6 +163,40 @@ __device__ __forceinline__ void fft4096_split_inv(float (&r)[8], float (&i)[8], 
     radix8<1>(r, i);
 }
 
+// ---- the same forward transform holding 6 twiddle registers instead of 42 --------------------------------------------------
+// For kernels that keep several spectra in registers across a loop of transforms: only the three base twiddles stay live, their powers
+// are rebuilt in front of each pass (18 complex products per transform, the same operations as tw_powers: results identical to
+// fft4096_split_fwd). The empty asm keeps the compiler from hoisting the powers out of the caller's loop, which would bring the 42
+// registers back.
+struct SplitTwLean { f2 outer, s1, s2; };
+__device__ __forceinline__ SplitTwLean split_twiddles_lean(int j, const f2* __restrict__ tw) {
+    SplitTwLean t;
+    t.outer = tw[j]; t.s1 = tw[(j & 7) * 64]; t.s2 = tw[(j & 63) * 8];
+    return t;
+}
+__device__ __forceinline__ Tw8 tw_powers_here(f2 w) {
+    asm volatile("" : "+v"(w.x), "+v"(w.y));
+    return tw_powers(w);
+}
+__device__ __forceinline__ void fft4096_split_fwd_lean(float (&r)[8], float (&i)[8], int j, const SplitTwLean& tw, f2* buf) {
+    radix8<-1>(r, i);
+    twiddle8<-1>(r, i, tw_powers_here(tw.outer));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) buf[q * FFT512_LDS + j] = f2{r[q], i[q]};
+    __syncthreads();
+    f2* row = buf + (j >> 6) * FFT512_LDS;
+    const int l = j & 63, rb = l + (l >> 3);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f2 v = row[l + 64 * q]; r[q] = v.x; i[q] = v.y; }
+    radix8<-1>(r, i);
+    wave_exchange(r, i, row, 9 * l, 1, rb);
+    twiddle8<-1>(r, i, tw_powers_here(tw.s1));
+    radix8<-1>(r, i);
+    wave_exchange(r, i, row, (l >> 3) * 72 + (l & 7), 9, rb);
+    twiddle8<-1>(r, i, tw_powers_here(tw.s2));
+    radix8<-1>(r, i);
+}
+
 // ---- TC = 2^LOGN / P transforms of P points side by side (batch index fastest in LDS and across lanes) ------------
 // A workgroup of 2^LOGN / 8 threads holds 2^LOGN elements. LOGN = 12: 512 threads; LOGN = 13: 1024 threads, at P = 256 a tile is then 32
 // columns wide, i.e. whole 128-byte lines of a float signal (pays in the epilogue kernels that read and write several float streams).

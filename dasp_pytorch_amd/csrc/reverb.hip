@@ -9,9 +9,11 @@
 // The reference's direct convolutions are 99.6 % of its time. Here both are frequency-domain products.
 //
 // Filter bank (short filters, 2B*12 independent noise rows): ONE fused kernel - overlap-save windows of 4096 samples,
-// the left/right rows of an item packed as one complex signal, forward FFT, product with the band's spectrum and
-// inverse FFT inside the workgroup, envelope / gain / band mean applied in registers. The filtered noise never exists
-// in HBM; the backward pass re-runs the kernel with d loss / d ir as a weight instead of saving it.
+// the left/right rows of an item packed as one complex signal, forward FFT and product with the band's spectrum inside
+// the workgroup; the decay envelope is folded into the transform's inputs, so the band sum happens in the frequency
+// domain and a window costs 12 forward transforms + 1 inverse (fb_fused_kernel). The filtered noise never exists in
+// HBM; the backward pass re-runs the forward transforms and takes its sums over frequency (Parseval) against the
+// transform of d loss / d ir - no inverse transform at all.
 //
 // Long convolution (L taps, L up to 2^20): overlap-add over blocks of Lb = nextpow2(L) samples, n1 = 2 Lb-point complex
 // transforms of PAIRS of consecutive blocks of one signal (block 2p real, block 2p+1 imaginary; both meet the same real
@@ -38,9 +40,14 @@ constexpr int LOAD_LOG = 12, COLS_LOG = 13;   // workgroup size (log2 elements) 
 typedef ColGeom<LOAD_LOG> LoadGeom;
 typedef ColGeom<COLS_LOG> ColsGeom;
 
+// Workgroups are dealt round-robin to the 8 XCDs in launch order: physical index bx of nx -> logical index, a contiguous run per XCD
+// (identity when nx is not a multiple of 8). Used where neighbouring logical workgroups share cache lines: neighbouring column tiles of the
+// four-step kernels touch neighbouring (at small NA: the same) 128-byte lines of the signal; the windows of an item share its band spectra.
+__device__ __forceinline__ int xcd_tile(int bx, int nx) { return (nx & 7) ? bx : (bx & 7) * (nx >> 3) + (bx >> 3); }
+
 // ---- fused filter bank ---------------------------------------------------------------------------------------------
 // spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096
-// in the split order of fft4096_split_fwd.
+// in the split order of fft4096_split_fwd; then the taps themselves, nb * taps floats (fb_wspectrum_kernel weights them per item).
 __global__ void fb_twiddle_kernel(f2* __restrict__ spec) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < FFT_N) {
@@ -55,6 +62,9 @@ __global__ __launch_bounds__(FFT_T) void fb_spectrum_kernel(const float* __restr
     float r[8], i[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int idx = j + 512 * q; r[q] = idx < taps ? filters[(long)band * taps + idx] : 0.f; i[q] = 0.f; }
+    float* keep = reinterpret_cast<float*>(spec + (long)(gridDim.x + 1) * FFT_N) + (long)band * taps;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int idx = j + 512 * q; if (idx < taps) keep[idx] = r[q]; }
     const SplitTw tw = split_twiddles(j, spec);
     fft4096_split_fwd(r, i, j, tw, lds);
     constexpr float inv = 1.f / (float)FFT_N;
@@ -63,28 +73,71 @@ __global__ __launch_bounds__(FFT_T) void fb_spectrum_kernel(const float* __restr
     for (int q = 0; q < 8; ++q) spec[FFT_N + (long)band * FFT_N + so + 64 * q] = f2{r[q] * inv, -i[q] * inv};
 }
 
+// The envelope inside the transform. The decay exp(-d t_n), d = 10 decay + 1, splits over a window starting at n0 as
+//   exp(-d t_n0) exp(-rho idx),   rho = d / (L - 1),   and   exp(-rho idx) sum_k f[k] z[idx + k] = sum_k (f[k] exp(rho k)) (z[idx + k] exp(-rho (idx + k))):
+// weighting the noise by exp(-rho m) on the way in and the band filter by exp(+rho k) makes the transform deliver the ENVELOPED band
+// output, so the sum over the bands is taken in the frequency domain and a window needs 12 forward transforms + ONE inverse instead of
+// 12 + 12 (forward), or 12 + 2 forward transforms of the weight and no inverse at all (backward: the sums over n become sums over
+// frequency by Parseval's identity). The weighted band spectra depend on the item's decays: fb_wspectrum_kernel computes them per
+// (item, band) at the start of every call (1 transform per 22 windows' worth of noise transforms).
+// The weights span exp(|rho| 4096) inside a window, which the fp32 transform's rounding floor (relative to the largest element) does
+// not see: the route is taken while |rho| 4096 <= RV_WEIGHT_LIMIT (a factor e^2 = 7.4; the default L = 65536 with decay in [0, 1]
+// has |rho| 4096 <= 0.69), decided per batch item inside the kernel; short impulse responses with fast decays take the per-band route.
+constexpr float RV_WEIGHT_LIMIT = 2.f;
+
+// grid (nb, B): wspec[(b nb + band)] = conj(FFT(f_band[k] exp(rho k))) / 4096 in split order; taps_f (nb, taps) raw filter taps
+__global__ __launch_bounds__(FFT_T) void fb_wspectrum_kernel(const f2* __restrict__ spec, const float* __restrict__ taps_f, const float* __restrict__ decays,
+                                                             f2* __restrict__ wspec, int nb, int taps, float tstep) {
+    __shared__ f2 lds[FFT_LDS];
+    const int j = threadIdx.x, band = blockIdx.x, b = blockIdx.y;
+    const float rho = (10.f * decays[b * nb + band] + 1.f) * tstep;
+    float r[8], i[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = j + 512 * q;
+        r[q] = idx < taps ? taps_f[(long)band * taps + idx] * expf(fminf(rho * (float)idx, 80.f)) : 0.f;      // the clamp only matters off the weighted route
+        i[q] = 0.f;
+    }
+    const SplitTw tw = split_twiddles(j, spec);
+    fft4096_split_fwd(r, i, j, tw, lds);
+    constexpr float inv = 1.f / (float)FFT_N;
+    const int so = (j >> 6) * 512 + (j & 63);
+    f2* out = wspec + ((long)b * nb + band) * FFT_N + so;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[64 * q] = f2{r[q] * inv, -i[q] * inv};
+}
+
 // One workgroup = one (batch item b, window w): output samples n = w V + idx, idx < V = 512 VQ <= 4096 - (taps - 1).
 //   z_band[idx] = noise[b,0,band][n0 + idx] + i noise[b,1,band][n0 + idx]          (functional.py:548; both rows share the band filter)
 //   o_band     = IFFT(FFT(z_band) conj(F_band))  -> valid cross-correlations for idx < V   (:551-558)
 //   MODE 0:  ir[b,c][n] = 1/nb sum_band gain env_band(t_n) o_band                   (:561-567)
 //   MODE 1:  part[(b, w), band] = (sum_n gir o env / nb,  sum_n gir o env gain (-10 t_n) / nb),  gir (2B, L) = d loss / d ir
-// Few batch items: a workgroup's loop over the bands is its whole run time (12 x two transforms), and B * windows workgroups may not fill
+// computed with the envelope inside the transform (ROUTE 1, above) or, for |rho| beyond the limit, band by band in the time domain
+// (ROUTE 0). Both instantiations are launched over the same grid and a workgroup returns at once when its item belongs to the other
+// route (one kernel holding both loops spills ~140 registers at the 128 it may use; the empty workgroups cost a few microseconds).
+// Few batch items: a workgroup's loop over the bands is its whole run time, and B * windows workgroups may not fill
 // the chip (8 items: 176 of 1024 slots). bsplit > 1 deals the bands out to gridDim.z workgroups per (item, window): MODE 0 then adds its
 // bands' share into ir with float atomics (ir zeroed by the caller; the order of the additions is not deterministic), MODE 1 writes the
 // partial sums of its own bands only.
-template <int MODE>
-__global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const float* __restrict__ gains,
-                                                         const float* __restrict__ decays, float* __restrict__ ir, const float* __restrict__ gir,
-                                                         float* __restrict__ part, int nb, int L, int taps, int VQ) {
+template <int MODE, int ROUTE>
+__global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const f2* __restrict__ wspec,
+                                                         const float* __restrict__ gains, const float* __restrict__ decays, float* __restrict__ ir,
+                                                         const float* __restrict__ gir, float* __restrict__ part, int nb, int L, int taps, int VQ, float limit) {
     const int bsplit = gridDim.z, bper = (nb + bsplit - 1) / bsplit, band_lo = blockIdx.z * bper, band_hi = band_lo + bper < nb ? band_lo + bper : nb;
     __shared__ f2 lds[2 * FFT_LDS];
     __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
-    const int j = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
+    // Workgroups go round-robin to the 8 XCDs in launch order. All windows of an item read the same 12 weighted band spectra (384 KB,
+    // private to the item): each XCD takes a contiguous run of items so that they meet in one L2 instead of being fetched by all eight.
+    const int lin = xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int j = threadIdx.x, w = lin % (int)gridDim.x, b = lin / (int)gridDim.x;
     const int V = VQ * 512, n0 = w * V, row_len = L + taps - 1;
     const float tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f, inv_nb = 1.f / (float)nb;
-    const SplitTw tw = split_twiddles(j, spec);
     const int so = (j >> 6) * 512 + (j & 63);
     const float t0 = (float)(n0 + j) * tstep, t512 = 512.f * tstep;      // t_n = n / (L - 1), torch.linspace(0, 1, L)
+    const float tw0 = (float)n0 * tstep;                                 // time of the window's first sample
+    float dmax = 0.f;
+    for (int band = 0; band < nb; ++band) dmax = fmaxf(dmax, fabsf(10.f * decays[b * nb + band] + 1.f));
+    if ((dmax * tstep * (float)FFT_N <= limit) != (ROUTE == 1)) return;        // uniform over the workgroup (and over the item's workgroups)
     float accr[8], acci[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -95,48 +148,118 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
             acci[q] = gir[(long)(2 * b + 1) * L + n];
         }
     }
-    for (int band = band_lo; band < band_hi; ++band) {
-        float r[8], i[8];
-        {
-            const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
-            const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
+    if constexpr (ROUTE == 1) {
+        // The band loop keeps spectra in registers across its transforms (MODE 0: the running sum over the bands; MODE 1: two weight
+        // spectra): the transform variant with 6 twiddle registers (fft_lds.hpp) leaves room to have a band's 16 noise loads and 8
+        // spectrum loads in flight together. The one inverse transform of MODE 0 builds its twiddles after the loop.
+        const SplitTwLean tw = split_twiddles_lean(j, spec);
+        auto fwd = [&](float (&rr_)[8], float (&ii_)[8], f2* buf) { fft4096_split_fwd_lean(rr_, ii_, j, tw, buf); };
+        float g2r[8], g2i[8];
+        if (MODE == 1) {                             // G1 = FFT(gir), G2 = FFT(window time * gir); zero outside the valid range
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int idx = n0 + j + 512 * q;
-                r[q] = idx < row_len ? rl[idx] : 0.f;
-                i[q] = idx < row_len ? rr[idx] : 0.f;
+                const float tq = (float)(j + 512 * q) * tstep;
+                g2r[q] = accr[q] * tq; g2i[q] = acci[q] * tq;
+            }
+            fwd(accr, acci, lds);
+            fwd(g2r, g2i, lds + FFT_LDS);
+        }
+        int flip = 0;
+        for (int band = band_lo; band < band_hi; ++band, flip ^= 1) {
+            const float g = gains[b * nb + band], d = 10.f * decays[b * nb + band] + 1.f, rho = d * tstep;
+            float r[8], i[8];
+            {
+                const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
+                const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {       // all 16 loads in flight before the first use (a product inside the select makes each a branch + wait)
+                    const int idx = n0 + j + 512 * q, ic = idx < row_len ? idx : row_len - 1;      // clamped address: a plain load, no branch
+                    const float vl = rl[ic], vr = rr[ic];
+                    r[q] = idx < row_len ? vl : 0.f;
+                    i[q] = idx < row_len ? vr : 0.f;
+                }
+                float wq = __expf(-rho * (float)j);
+                const float ws = __expf(-rho * 512.f);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { r[q] *= wq; i[q] *= wq; wq *= ws; }
+            }
+            const f2* F = wspec + ((long)b * nb + band) * FFT_N + so;
+            fwd(r, i, lds + flip * FFT_LDS);
+            const float e0 = __expf(-d * tw0) * inv_nb;
+            if (MODE == 0) {
+                const float c = g * e0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f2 f = F[64 * q];
+                    accr[q] = fmaf(c, r[q] * f.x - i[q] * f.y, accr[q]);
+                    acci[q] = fmaf(c, r[q] * f.y + i[q] * f.x, acci[q]);
+                }
+            } else {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f2 f = F[64 * q];
+                    const float pr = r[q] * f.x - i[q] * f.y, pi = r[q] * f.y + i[q] * f.x;
+                    s1 = fmaf(accr[q], pr, fmaf(acci[q], pi, s1));
+                    s2 = fmaf(g2r[q], pr, fmaf(g2i[q], pi, s2));
+                }
+                s1 = wave_sum_uniform(s1); s2 = wave_sum_uniform(s2);
+                if (lane_id() == 0) { red[wave_id()][band][0] = e0 * s1; red[wave_id()][band][1] = -10.f * g * e0 * fmaf(tw0, s1, s2); }
             }
         }
-        fft4096_split_fwd(r, i, j, tw, lds);
-        const f2* F = spec + FFT_N + (long)band * FFT_N + so;
+        if constexpr (MODE == 0) fft4096_split_inv(accr, acci, j, split_twiddles(j, spec), lds + flip * FFT_LDS);
+    } else {
+        const SplitTw tw = split_twiddles(j, spec);
+        float sumr[8], sumi[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f2 f = F[64 * q];
-            const float t = r[q] * f.x - i[q] * f.y;
-            i[q] = r[q] * f.y + i[q] * f.x;
-            r[q] = t;
+        for (int q = 0; q < 8; ++q) { sumr[q] = 0.f; sumi[q] = 0.f; }
+        for (int band = band_lo; band < band_hi; ++band) {
+            float r[8], i[8];
+            {
+                const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
+                const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = n0 + j + 512 * q;
+                    r[q] = idx < row_len ? rl[idx] : 0.f;
+                    i[q] = idx < row_len ? rr[idx] : 0.f;
+                }
+            }
+            fft4096_split_fwd(r, i, j, tw, lds);
+            const f2* F = spec + FFT_N + (long)band * FFT_N + so;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f2 f = F[64 * q];
+                const float t = r[q] * f.x - i[q] * f.y;
+                i[q] = r[q] * f.y + i[q] * f.x;
+                r[q] = t;
+            }
+            fft4096_split_inv(r, i, j, tw, lds + FFT_LDS);
+            const float g = gains[b * nb + band], d = 10.f * decays[b * nb + band] + 1.f;
+            if (MODE == 0) {
+                const float gs = g * inv_nb;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float e = __expf(-d * fmaf((float)q, t512, t0)) * gs;
+                    sumr[q] = fmaf(e, r[q], sumr[q]);
+                    sumi[q] = fmaf(e, i[q], sumi[q]);
+                }
+            } else {
+                float sg = 0.f, sd = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float tq = fmaf((float)q, t512, t0);
+                    const float e = (accr[q] * r[q] + acci[q] * i[q]) * __expf(-d * tq) * inv_nb;     // weights are zero outside the valid range
+                    sg += e;
+                    sd = fmaf(e, -10.f * tq * g, sd);
+                }
+                sg = wave_sum_uniform(sg); sd = wave_sum_uniform(sd);
+                if (lane_id() == 0) { red[wave_id()][band][0] = sg; red[wave_id()][band][1] = sd; }
+            }
         }
-        fft4096_split_inv(r, i, j, tw, lds + FFT_LDS);
-        const float g = gains[b * nb + band], d = 10.f * decays[b * nb + band] + 1.f;
         if (MODE == 0) {
-            const float gs = g * inv_nb;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float e = __expf(-d * fmaf((float)q, t512, t0)) * gs;
-                accr[q] = fmaf(e, r[q], accr[q]);
-                acci[q] = fmaf(e, i[q], acci[q]);
-            }
-        } else {
-            float sg = 0.f, sd = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float tq = fmaf((float)q, t512, t0);
-                const float e = (accr[q] * r[q] + acci[q] * i[q]) * __expf(-d * tq) * inv_nb;     // weights are zero outside the valid range
-                sg += e;
-                sd = fmaf(e, -10.f * tq * g, sd);
-            }
-            sg = wave_sum_uniform(sg); sd = wave_sum_uniform(sd);
-            if (lane_id() == 0) { red[wave_id()][band][0] = sg; red[wave_id()][band][1] = sd; }
+            for (int q = 0; q < 8; ++q) { accr[q] = sumr[q]; acci[q] = sumi[q]; }
         }
     }
     if (MODE == 0) {
@@ -173,9 +296,6 @@ __device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (
     for (int q = 1; q < 8; ++q) { wr[q] = wr[q - 1] * c1 - wi[q - 1] * s1; wi[q] = wr[q - 1] * s1 + wi[q - 1] * c1; }
 }
 
-// Workgroups are dealt round-robin to the 8 XCDs in launch order; neighbouring column tiles touch neighbouring (at small NA: the same)
-// 128-byte lines of the signal, so each XCD gets a contiguous run of tiles and the shared lines meet in one L2.
-__device__ __forceinline__ int xcd_tile(int bx, int nx) { return (nx & 7) ? bx : (bx & 7) * (nx >> 3) + (bx >> 3); }
 
 // Column pass, time -> A[ka][jb]. grid (NA * 512 / 4096 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
@@ -406,6 +526,12 @@ inline int rv_chunk(long R, long frame_elems_per_signal) {
     c &= ~1L;                                        // the two signals of a batch item stay together (they share mix)
     return (int)(c < 2 ? 2 : c);
 }
+// largest |rho| * 4096 served with the envelope inside the transform (fb_fused_kernel); DASP_REVERB_WEIGHT_LIMIT=0 sends every item the
+// per-band way (developer A/B and the route-equality test)
+inline float rv_weight_limit() {
+    if (const char* e = getenv("DASP_REVERB_WEIGHT_LIMIT")) { const float v = (float)atof(e); if (v >= 0.f && v <= 8.f) return v == 0.f ? -1.f : v; }
+    return RV_WEIGHT_LIMIT;
+}
 // workgroups per (item, window) of the filter-bank kernel: the bands are dealt out when B * windows would leave most of the chip idle
 inline int rv_band_split(int B, int nwin, int nb) {
     if (const char* e = getenv("DASP_REVERB_BAND_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nb) return v; }
@@ -441,25 +567,26 @@ inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
 extern "C" {
 
 /* sizes[0] = Lb (block length), [1] = n1 (transform length), [2] = pairs of blocks per signal, [3] = blocks per signal,
- * [4] = complex elements of Fspec (twiddle table + band spectra of the filter bank), [5] = filter-bank windows per batch item,
+ * [4] = complex elements of Fspec (twiddle table + band spectra of the filter bank + the taps), [5] = filter-bank windows per batch item,
  * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (2B * n1),
  * [8] = floats of ir / gir (2B * L), [9] = signals per pass of the long-convolution pipeline (chunk),
  * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums,
- * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1), [13] = complex elements of the scratch buffers Ah / P (chunk * n1) */
+ * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1, at least B * nb * 4096), [13] = complex elements of the scratch buffers Ah / P (chunk * n1) */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!sizes || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX) return DASP_ERR_ARG;
     RvDims d;
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
     sizes[0] = d.c.Lb; sizes[1] = d.c.n1; sizes[2] = d.c.npairs; sizes[3] = d.nblk;
-    sizes[4] = (long)(nb + 1) * FFT_N; sizes[5] = d.nwin;
+    sizes[4] = (long)(nb + 1) * FFT_N + ((long)nb * taps + 1) / 2; sizes[5] = d.nwin;
     sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = d.R * d.c.n1;
     sizes[8] = d.R * L; sizes[9] = d.chunk;
     sizes[10] = d.R * d.c.npairs * d.ctiles; sizes[11] = (long)B * d.nwin * nb * 2;
     sizes[12] = (long)d.chunk * d.c.npairs * d.c.n1; sizes[13] = (long)d.chunk * d.c.n1;
+    if (sizes[12] < (long)B * nb * FFT_N) sizes[12] = (long)B * nb * FFT_N;       // W / Ag also hold the per-item weighted band spectra of the filter bank
     return DASP_OK;
 }
 
-/* filters (nb, taps) fp32 -> Fspec (sizes[4] complex): the 4096-point twiddle table followed by conj(FFT(filter)) / 4096 per band */
+/* filters (nb, taps) fp32 -> Fspec (sizes[4] complex): the 4096-point twiddle table, conj(FFT(filter)) / 4096 per band, the taps */
 int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream) {
     if (!filters || !Fspec || nb <= 0 || nb > RV_BANDS_MAX || taps <= 0) return DASP_ERR_ARG;
     if (taps - 1 > FFT_N - 512) return DASP_ERR_UNSUPPORTED;
@@ -489,8 +616,14 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
         const hipError_t e = hipMemsetAsync(ir, 0, sizeof(float) * (size_t)d.R * L, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(fb_fused_kernel<0>, dim3((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit), dim3(FFT_T), 0, st, noise, tw, gains, decays, ir,
-                       (const float*)nullptr, (float*)nullptr, nb, L, taps, d.VQ);
+    const float* taps_f = reinterpret_cast<const float*>(tw + (long)(nb + 1) * FFT_N);
+    const float limit = rv_weight_limit();
+    const float tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f;
+    hipLaunchKernelGGL(fb_wspectrum_kernel, dim3((unsigned)nb, (unsigned)B), dim3(FFT_T), 0, st, tw, taps_f, decays, (f2*)W, nb, taps, tstep);
+    hipLaunchKernelGGL((fb_fused_kernel<0, 1>), dim3((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit), dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays,
+                       ir, (const float*)nullptr, (float*)nullptr, nb, L, taps, d.VQ, limit);
+    hipLaunchKernelGGL((fb_fused_kernel<0, 0>), dim3((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit), dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays,
+                       ir, (const float*)nullptr, (float*)nullptr, nb, L, taps, d.VQ, limit);
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
         const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
         f2* Hc = (f2*)H + s0 * d.c.n1;
@@ -539,8 +672,15 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
                            (const float*)nullptr, mix + s0 / 2, gir + s0 * L, (float*)nullptr, one, L);
     }
     // d/dgain, d/ddecay: the filter bank again, weighted by gir
-    hipLaunchKernelGGL(fb_fused_kernel<1>, dim3((unsigned)d.nwin, (unsigned)B, (unsigned)rv_band_split(B, d.nwin, nb)), dim3(FFT_T), 0, st, noise, tw, gains,
-                       decays, (float*)nullptr, (const float*)gir, part, nb, L, taps, d.VQ);
+    const float* taps_f = reinterpret_cast<const float*>(tw + (long)(nb + 1) * FFT_N);
+    const float limit = rv_weight_limit();
+    hipLaunchKernelGGL(fb_wspectrum_kernel, dim3((unsigned)nb, (unsigned)B), dim3(FFT_T), 0, st, tw, taps_f, decays, (f2*)Ag, nb, taps,
+                       L > 1 ? 1.f / (float)(L - 1) : 0.f);
+    const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)rv_band_split(B, d.nwin, nb));
+    hipLaunchKernelGGL((fb_fused_kernel<1, 1>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr, (const float*)gir, part,
+                       nb, L, taps, d.VQ, limit);
+    hipLaunchKernelGGL((fb_fused_kernel<1, 0>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr, (const float*)gir, part,
+                       nb, L, taps, d.VQ, limit);
     const int nfin = B * nb > B ? B * nb : B;
     hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 127) / 128), dim3(128), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
                        d.c.npairs * d.ctiles);

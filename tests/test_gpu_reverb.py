@@ -132,3 +132,33 @@ def test_band_split_filter_bank_equals_one_workgroup_per_window(D, monkeypatch):
         y2, gx2, gp2 = run(D, x, p, w, noise, L, taps)
         assert np.abs(y2 - y1).max() <= 2e-6 * np.abs(y1).max() and np.abs(gx2 - gx1).max() <= 2e-6 * np.abs(gx1).max()
         assert np.abs(gp2 - gp1).max() <= 1e-5 * np.abs(gp1).max()
+
+
+def test_envelope_inside_the_transform_equals_per_band_route(D, monkeypatch):
+    """The filter bank applies the decay envelope inside the transform (weighted noise and filters, one inverse transform per window;
+    csrc/reverb.hip fb_fused_kernel ROUTE 1) while |rho| 4096 <= 2 and band by band in the time domain beyond. L = 16384 puts the limit at
+    decay ~ 0.7: item 0 (decays <= 0.5) takes the first route, item 1 (one band at 0.95) the second, item 2 sits on neither edge.
+    Both against the oracle, and against each other with every item forced down the per-band route."""
+    rng = np.random.default_rng(11)
+    B, C, N, L, taps = 3, 2, 30000, 16384, 1023
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 2, N)).astype(np.float32)
+    p = rng.random((B, 25)).astype(np.float32)
+    p[0, 12:24] *= 0.5
+    p[1, 12:24] *= 0.5; p[1, 17] = 0.95
+    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+    monkeypatch.setenv("DASP_REVERB_BAND_SPLIT", "1")            # no float atomics: an item that keeps its route is bit-identical
+    y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
+    monkeypatch.setenv("DASP_REVERB_WEIGHT_LIMIT", "0")
+    y0, gx0, gp0 = run(D, x, p, w, noise, L, taps)
+    monkeypatch.delenv("DASP_REVERB_WEIGHT_LIMIT")
+    pd = p.astype(np.float64)
+    yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
+    gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, w, L, taps)
+    gpo = np.concatenate([gg, gd, gm[:, None]], 1)
+    for y, gx, gp in ((y1, gx1, gp1), (y0, gx0, gp0)):
+        assert np.abs(y - yo).max() <= 3e-5 * np.abs(yo).max() and np.abs(gx - gxo).max() <= 3e-5 * np.abs(gxo).max()
+        assert (np.abs(gp - gpo).max(1) <= 1e-4 * np.abs(gpo).max(1)).all()
+    assert np.abs(y1 - y0).max() <= 1e-5 * np.abs(y0).max() and np.abs(gx1 - gx0).max() <= 1e-5 * np.abs(gx0).max()
+    assert (np.abs(gp1 - gp0).max(1) <= 3e-5 * np.abs(gp0).max(1)).all()
+    assert not np.array_equal(y1[0], y0[0]) and np.array_equal(y1[1], y0[1])          # item 0 changed route, item 1 did not
