@@ -90,6 +90,40 @@ __global__ void ew_finalize_kernel(const float* __restrict__ partials, float* __
     gctl[i] = (float)(s * (double)LN10_OVER_20);
 }
 
+// distortion with one drive value PER SAMPLE (the reference's drive_db.view(bs, chs, -1) with bs * chs * seq_len values, functional.py:78):
+// plain elementwise, n = B * C * N; forward 12 B per sample, backward 20 B (read x, drive, gy; write gx, gdrive)
+template <bool BWD>
+__global__ void __launch_bounds__(EW_THREADS)
+dist_sample_kernel(const float* __restrict__ x, const float* __restrict__ drive_db, const float* __restrict__ gy, float* __restrict__ out,
+                   float* __restrict__ gdrive, long n, int vec) {
+    const long t = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    auto one = [&](float xv, float dv, float gv, float& o, float& gd) {
+        const float lin = exp10f(dv * 0.05f), y = tanhf(xv * lin);
+        if (BWD) {
+            const float tt = gv * (1.f - y * y) * lin;
+            o = tt; gd = tt * xv * LN10_OVER_20;
+        } else {
+            o = y;
+        }
+    };
+    if (vec) {
+        const long i = t * 4;
+        if (i >= n) return;
+        const f4 xv = *reinterpret_cast<const f4*>(x + i), dv = *reinterpret_cast<const f4*>(drive_db + i);
+        f4 gv = f4{0.f, 0.f, 0.f, 0.f};
+        if (BWD) gv = *reinterpret_cast<const f4*>(gy + i);
+        float o[4], gd[4];
+        one(xv.x, dv.x, gv.x, o[0], gd[0]); one(xv.y, dv.y, gv.y, o[1], gd[1]); one(xv.z, dv.z, gv.z, o[2], gd[2]); one(xv.w, dv.w, gv.w, o[3], gd[3]);
+        *reinterpret_cast<f4*>(out + i) = f4{o[0], o[1], o[2], o[3]};
+        if (BWD) *reinterpret_cast<f4*>(gdrive + i) = f4{gd[0], gd[1], gd[2], gd[3]};
+    } else if (t < n) {
+        float o, gd;
+        one(x[t], drive_db[t], BWD ? gy[t] : 0.f, o, gd);
+        out[t] = o;
+        if (BWD) gdrive[t] = gd;
+    }
+}
+
 }  // namespace dasp
 
 // ================================================================================================
@@ -146,5 +180,21 @@ int dasp_distortion_forward(const float* x, const float* drive_db, float* y, int
 int dasp_distortion_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive, float* partials, int B,
                              int C, long N, void* stream) {
     return ew_backward<EW_DIST>(x, drive_db, gy, gx, gdrive, partials, B, C, N, stream);
+}
+int dasp_distortion_sample_forward(const float* x, const float* drive_db, float* y, long n, void* stream) {
+    if (!x || !drive_db || !y || n <= 0) return DASP_ERR_ARG;
+    const int vec = (n % 4 == 0) && ew_al16(x) && ew_al16(drive_db) && ew_al16(y);
+    const long threads = vec ? n / 4 : n, blocks = (threads + EW_THREADS - 1) / EW_THREADS;
+    if (blocks > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dist_sample_kernel<false>, dim3((unsigned)blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, drive_db, nullptr, y, nullptr, n, vec);
+    return ew_check();
+}
+int dasp_distortion_sample_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive, long n, void* stream) {
+    if (!x || !drive_db || !gy || !gx || !gdrive || n <= 0) return DASP_ERR_ARG;
+    const int vec = (n % 4 == 0) && ew_al16(x) && ew_al16(drive_db) && ew_al16(gy) && ew_al16(gx) && ew_al16(gdrive);
+    const long threads = vec ? n / 4 : n, blocks = (threads + EW_THREADS - 1) / EW_THREADS;
+    if (blocks > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dist_sample_kernel<true>, dim3((unsigned)blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, drive_db, gy, gx, gdrive, n, vec);
+    return ew_check();
 }
 }  // extern "C"

@@ -3,7 +3,7 @@
 import torch
 
 from . import signal as _signal
-from .ops import (FILTER_TYPES, BusFunction, DistortionFunction, DynamicsFunction, GainFunction, PannerFunction, ParametricEQFunction,
+from .ops import (FILTER_TYPES, BusFunction, DistortionFunction, DistortionSampleFunction, DynamicsFunction, GainFunction, PannerFunction, ParametricEQFunction,
                   ReverbFunction, WidenerFunction)
 from .ops64 import Dynamics64Function, Elementwise64Function, ParametricEQ64Function, is_f64, require_fp32_ok
 
@@ -23,13 +23,19 @@ def gain(x: torch.Tensor, sample_rate: int, gain_db: torch.Tensor):
 
 def distortion(x: torch.Tensor, sample_rate: int, drive_db: torch.Tensor):
     """Soft-clipping distortion tanh(x * 10^(drive_db/20)) (reference: dasp_pytorch/functional.py:65-78).
-    As in the reference's drive_db.view(bs, chs, -1), drive_db must hold one value per (batch item,
-    channel) row, i.e. bs*chs values (so a (bs,) drive only works for mono input). The reference would
-    also accept bs*chs*k values broadcastable against seq_len; that per-sample form is not supported."""
+    As in the reference's drive_db.view(bs, chs, -1), drive_db holds one value per (batch item, channel) row, i.e. bs*chs values (so a
+    (bs,) drive only works for mono input), or one value per sample, bs*chs*seq_len values; any other count fails as the reference's
+    view / broadcast does."""
     bs, chs, seq_len = x.size()
-    if drive_db.numel() != bs * chs:
-        raise RuntimeError(f"shape '[{bs}, {chs}, -1]' is invalid for input of size {drive_db.numel()} "
-                           "(dasp_pytorch_amd supports one drive value per (batch, channel) row)")
+    n = drive_db.numel()
+    if n == bs * chs * seq_len and seq_len != 1:
+        if is_f64(x):
+            require_fp32_ok(x, "distortion with per-sample drive_db")
+        return DistortionSampleFunction.apply(x, drive_db)
+    if n != bs * chs:
+        if bs * chs == 0 or n % (bs * chs) != 0:
+            raise RuntimeError(f"shape '[{bs}, {chs}, -1]' is invalid for input of size {n}")
+        raise RuntimeError(f"The size of tensor a ({seq_len}) must match the size of tensor b ({n // (bs * chs)}) at non-singleton dimension 2")
     if is_f64(x):
         return Elementwise64Function.apply(x, drive_db, 1)
     return DistortionFunction.apply(x, drive_db)
@@ -235,11 +241,27 @@ def noise_shaped_reverberation(
     require_fp32_ok(x, "noise_shaped_reverberation")
     if chs == 1:   # if mono copy to stereo (autograd sums the two channel gradients)
         x = x.repeat(1, 2, 1)
-    band_gains = torch.stack([band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,
-                              band8_gain, band9_gain, band10_gain, band11_gain], dim=1).view(bs, 12)
-    band_decays = torch.stack([band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
-                               band7_decay, band8_decay, band9_decay, band10_decay, band11_decay], dim=1).view(bs, 12)
+    band_gains = _StackColumns.apply(band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,
+                                     band8_gain, band9_gain, band10_gain, band11_gain)
+    band_decays = _StackColumns.apply(band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
+                                      band7_decay, band8_decay, band9_decay, band10_decay, band11_decay)
     return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise)
+
+
+class _StackColumns(torch.autograd.Function):
+    """torch.stack([c.view(bs) for c in cols], dim=1) with a backward that hands every column its gradient as a contiguous row of one
+    transposed matrix: autograd's own stack backward returns 12 strided column views, each of which AccumulateGrad then copies with a
+    kernel of its own (24 launches per reverb step for the 2 x 12 band controls; here: one transpose per matrix)."""
+
+    @staticmethod
+    def forward(ctx, *cols):
+        ctx.shapes = [c.shape for c in cols]
+        return torch.stack([c.reshape(-1) for c in cols], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        rows = g.t().contiguous().unbind(0)
+        return tuple(r.reshape(shape) if need else None for r, shape, need in zip(rows, ctx.shapes, ctx.needs_input_grad))
 
 
 def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False):

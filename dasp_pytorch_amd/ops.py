@@ -378,6 +378,40 @@ class DistortionFunction(_ElementwiseFunction):
         return DistortionFunction._grad(ctx, gy)
 
 
+class DistortionSampleFunction(torch.autograd.Function):
+    """y = tanh(x * 10^(drive_db/20)) with one drive value per sample: drive_db holds bs * chs * seq_len values (the other case the reference's
+    drive_db.view(bs, chs, -1) accepts, functional.py:78)."""
+
+    @staticmethod
+    def forward(ctx, x, drive_db):
+        _lib.require_device(x, "x")
+        _lib.require_same_device(x, drive_db=drive_db)
+        ctx.meta = (x.dtype, drive_db.dtype, drive_db.shape)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            x32 = _f32c(x)
+            d32 = _f32c(drive_db).reshape(x.shape)
+            y = torch.empty_like(x32)
+            call("dasp_distortion_sample_forward", ptr(x32), ptr(d32), ptr(y), x32.numel(), stream())
+            ctx.save_for_backward(x32, d32)
+        return y.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xd, dd, dshape = ctx.meta
+        if ctx.empty:
+            return torch.empty_like(gy), torch.zeros(dshape, dtype=dd, device=gy.device)
+        x32, d32 = ctx.saved_tensors
+        with torch.cuda.device(x32.device):
+            gx = torch.empty_like(x32)
+            gd = torch.empty_like(x32)
+            call("dasp_distortion_sample_backward", ptr(x32), ptr(d32), ptr(_f32c(gy)), ptr(gx), ptr(gd), x32.numel(), stream())
+        return gx.to(xd), gd.reshape(dshape).to(dd)
+
+
 def _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need):
     """The compressor / expander kernels on ctl (B, 5) fp32 rows [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db]; returns y (fp32)
     and what the backward pass needs."""

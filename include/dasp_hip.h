@@ -161,6 +161,10 @@ int dasp_gain_backward(const float* x, const float* gain_db, const float* gy, fl
 int dasp_distortion_forward(const float* x, const float* drive_db, float* y, int B, int C, long N, void* stream);
 int dasp_distortion_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive,
                              float* partials, int B, int C, long N, void* stream);
+/* distortion with one drive value per SAMPLE: the reference's drive_db.view(bs, chs, -1) also takes bs * chs * seq_len values
+ * (functional.py:78). x, drive_db, y, gy, gx, gdrive: n = B * C * N floats each; gdrive = dL/d(drive_db) per sample. */
+int dasp_distortion_sample_forward(const float* x, const float* drive_db, float* y, long n, void* stream);
+int dasp_distortion_sample_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive, long n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dynamics: compressor / expander.  mode 0 replaces dasp_pytorch.functional.compressor

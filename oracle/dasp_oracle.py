@@ -306,7 +306,7 @@ def stereo_bus_vjp(x, sample_rate, send_db, gy, dtype=np.float64):
 
 
 def distortion(x, sample_rate, drive_db, dtype=np.float64):
-    """functional.py:65-78: drive_db.view(bs, chs, -1) -> needs bs*chs drive values."""
+    """functional.py:65-78: drive_db.view(bs, chs, -1) -> bs*chs drive values (one per row) or bs*chs*seq_len (one per sample)."""
     x = np.asarray(x, dtype)
     d = np.asarray(drive_db, dtype).reshape(x.shape[0], x.shape[1], -1)
     return np.tanh(x * (10 ** (d / dtype(20.0))))
@@ -320,7 +320,9 @@ def distortion_vjp(x, sample_rate, drive_db, gy, dtype=np.float64):
     y = np.tanh(x * lin)
     t = gy * (1 - y * y)
     gx = t * lin
-    gd = np.sum(t * x * lin, axis=2, keepdims=True) * (math.log(10.0) / 20.0)
+    gd = t * x * lin * (math.log(10.0) / 20.0)
+    if d.shape[2] == 1:                      # one drive per row: the broadcast's adjoint sums over time
+        gd = np.sum(gd, axis=2, keepdims=True)
     return gx.astype(dtype), gd.reshape(np.asarray(drive_db).shape).astype(dtype)
 
 

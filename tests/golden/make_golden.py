@@ -102,6 +102,23 @@ def gain_dist_case(name, B, C, N, seed):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def dist_sample_case(name, B, C, N, seed):
+    """distortion() with one drive value per sample: drive_db (B, C, N), the other shape functional.py:78's view(bs, chs, -1) accepts."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    drive_db = torch.rand(B, C, N, generator=g) * 24
+    w = torch.randn(B, C, N, generator=g)
+    out = dict(x=f32(x), drive_db=f32(drive_db), w=f32(w))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        dd = drive_db.to(dt).clone().requires_grad_(True)
+        y = RF.distortion(xx, SR, dd)
+        (y * w.to(dt)).sum().backward()
+        out["y" + tag], out["gx" + tag], out["gp" + tag] = f32(y), f32(xx.grad), f32(dd.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
 def stereo_case(name, B, T, N, seed):
     """stereo_widener (B,2,N), stereo_panner (B,T,N) -> (B,2,T,N), stereo_bus (B,2,T,N) -> (B,2,N): forward and all gradients."""
     g = torch.Generator().manual_seed(seed)
@@ -279,3 +296,4 @@ if __name__ == "__main__":
     norm_case("norm_rev_b1c2_n6000", "NoiseShapedReverb", 1, 2, 6000, seed=124, noise_seed=5124)
     biquad_case("biquad_types_b6", 6, seed=125)
     lfilter_case("lfilter_b3_n9000", 3, 9000, seed=126)
+    dist_sample_case("dist_sample_b2c2_n3001", 2, 2, 3001, seed=127)

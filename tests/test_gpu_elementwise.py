@@ -38,6 +38,32 @@ def test_config1_golden(D):
         assert linf_peak(y.detach().cpu().numpy(), g[name + "_y32"]).max() < 1e-4
 
 
+def test_per_sample_drive_golden_and_shapes(D):
+    """distortion with one drive value per sample: the reference's drive_db.view(bs, chs, -1) with bs*chs*seq_len values (functional.py:78).
+    Reference-generated golden, then odd sizes (scalar tail path) against the oracle; counts the reference's view / broadcast rejects raise."""
+    g = load_golden("dist_sample_b2c2_n3001")
+    x = dev(g["x"]).requires_grad_(True)
+    d = dev(g["drive_db"]).requires_grad_(True)
+    y = D.distortion(x, SR, d)
+    (y * dev(g["w"])).sum().backward()
+    assert linf_peak(y.detach().cpu().numpy(), g["y64"]).max() < 1e-6 and linf_peak(y.detach().cpu().numpy(), g["y32"]).max() < 1e-4
+    assert linf_peak(x.grad.cpu().numpy(), g["gx64"]).max() < 2e-6
+    assert d.grad.shape == d.shape and linf_peak(d.grad.cpu().numpy(), g["gp64"]).max() < 2e-6
+    rng = np.random.default_rng(3)
+    for B, C, N in ((1, 1, 2), (2, 3, 5), (1, 2, 4096), (3, 1, 10001)):
+        xs = (rng.random((B, C, N)) * 2 - 1).astype(np.float32); ds = (rng.random((B, C, N)) * 24).astype(np.float32)
+        ws = rng.standard_normal((B, C, N)).astype(np.float32)
+        xt = dev(xs).requires_grad_(True); dt = dev(ds.reshape(-1)).requires_grad_(True)          # any shape with the right count, as view() takes
+        (D.distortion(xt, SR, dt) * dev(ws)).sum().backward()
+        gxo, gdo = orc.distortion_vjp(xs, SR, ds, ws)
+        assert np.abs(xt.grad.cpu().numpy() - gxo).max() < 2e-6 * max(1.0, np.abs(gxo).max())
+        assert dt.grad.shape == dt.shape and np.abs(dt.grad.cpu().numpy().reshape(B, C, N) - gdo).max() < 2e-6 * max(1.0, np.abs(gdo).max())
+    with pytest.raises(RuntimeError):
+        D.distortion(torch.zeros(2, 2, 8, device="cuda:0"), SR, torch.zeros(5, device="cuda:0"))       # view(2, 2, -1) fails
+    with pytest.raises(RuntimeError):
+        D.distortion(torch.zeros(2, 2, 8, device="cuda:0"), SR, torch.zeros(8, device="cuda:0"))       # views to (2, 2, 2): no broadcast against 8
+
+
 @pytest.mark.parametrize("B,C,N", [(1, 1, 1), (2, 3, 5), (3, 2, 8191), (2, 2, 8192), (1, 2, 8193), (4, 2, 100000), (70000, 1, 64), (256, 2, 131072)])
 def test_shapes_vs_oracle(D, B, C, N):
     rng = np.random.default_rng(N + B)

@@ -58,6 +58,15 @@ def test_oracle_gain_distortion_match_reference():
     assert linf_peak(y32, g["gain_y32"]).max() < 1e-6
 
 
+def test_oracle_per_sample_distortion_matches_reference():
+    """distortion with one drive value per sample (drive_db of bs*chs*seq_len values, functional.py:78): no sum over time in the adjoint."""
+    g = load_golden("dist_sample_b2c2_n3001")
+    assert linf_peak(orc.distortion(g["x"], SR, g["drive_db"]), g["y64"]).max() < 1e-6
+    gx, gd = orc.distortion_vjp(g["x"], SR, g["drive_db"], g["w"])
+    assert gd.shape == g["gp64"].shape
+    assert linf_peak(gx, g["gx64"]).max() < 1e-6 and linf_peak(gd, g["gp64"]).max() < 1e-6
+
+
 def test_oracle_stereo_utilities_match_reference():
     """stereo_widener / stereo_panner / stereo_bus restatements and their hand VJPs vs the reference's forward and autograd."""
     g = load_golden("stereo_b2t3_n1501")
