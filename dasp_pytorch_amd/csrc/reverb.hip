@@ -115,8 +115,8 @@ __global__ __launch_bounds__(FFT_T) void fb_wspectrum_kernel(const f2* __restric
 // computed with the envelope inside the transform (ROUTE 1, above) or, for |rho| beyond the limit, band by band in the time domain
 // (ROUTE 0). Both instantiations are launched over the same grid and a workgroup returns at once when its item belongs to the other
 // route (one kernel holding both loops spills ~140 registers at the 128 it may use; the empty workgroups cost a few microseconds).
-// Few batch items: a workgroup's loop over the bands is its whole run time, and B * windows workgroups may not fill
-// the chip (8 items: 176 of 1024 slots). bsplit > 1 deals the bands out to gridDim.z workgroups per (item, window): MODE 0 then adds its
+// Very few batch items: a workgroup's loop over the bands is its whole run time, and B * windows workgroups may not fill
+// the chip (1 item: 22 workgroups). bsplit > 1 deals the bands out to gridDim.z workgroups per (item, window): MODE 0 then adds its
 // bands' share into ir with float atomics (ir zeroed by the caller; the order of the additions is not deterministic), MODE 1 writes the
 // partial sums of its own bands only.
 template <int MODE, int ROUTE>
@@ -535,8 +535,11 @@ inline float rv_weight_limit() {
 // workgroups per (item, window) of the filter-bank kernel: the bands are dealt out when B * windows would leave most of the chip idle
 inline int rv_band_split(int B, int nwin, int nb) {
     if (const char* e = getenv("DASP_REVERB_BAND_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nb) return v; }
+    // every share repeats the window's inverse transform (forward) and adds its part with atomics, so the bands are only dealt out until
+    // ~128 workgroups exist (measured at 131072 samples, fwd + bwd: 1 item 0.148 -> 0.113 ms, 2 items 0.155 -> 0.129, 4 items 0.164 -> 0.146,
+    // 8 items and more: no split is fastest; profiles/r02/reverb_band_split.log)
     int split = 1;
-    while (split < nb && (long)B * nwin * split < 1024) ++split;
+    while (split < nb && (long)B * nwin * split < 128) ++split;
     while (nb % split) ++split;             // equal shares
     return split;
 }

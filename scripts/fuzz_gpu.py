@@ -64,9 +64,10 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         xt = T(x).requires_grad_(True); ct = T(c).requires_grad_(True)
         y = fn(xt, SR, ct); (y * T(w)).sum().backward()
         gxo, gco = fv(x, SR, c, w)
-        # floors: a short, fully saturated tanh has gradients ~1e-12 of the cotangent, where fp32 returns exact zeros
-        fl = 1e-3 * float(np.abs(w).max())
-        note(name, "y", rel(y.detach().cpu().numpy(), f(x, SR, c)), 2e-6, cfg); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo, fl), 3e-6, cfg)
+        # floor for the control gradient: a signed sum of N terms that nearly cancels is ill-conditioned relative to itself; its error is
+        # measured against the size such a sum typically has (sqrt(terms) * |w|), not against a near-zero result
+        fl = 0.05 * float(np.abs(w).max()) * float(np.sqrt(x.size / c.size))
+        note(name, "y", rel(y.detach().cpu().numpy(), f(x, SR, c)), 2e-6, cfg); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo), 3e-6, cfg)
         note(name, "gc", rel(ct.grad.cpu().numpy(), gco, fl), 1e-4, cfg)
     # compressor (signals bounded away from silence so that the gain computer's kinks are not sampled exactly)
     if N >= 8192 or True:
@@ -94,7 +95,7 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         y = fn(xt, SR, ct); (y * T(ww)).sum().backward()
         gxo, gco = fv(xx, SR, c, ww)
         note(name, "y", rel(y.detach().cpu().numpy(), f(xx, SR, c)), 3e-6, cfg + (Tn,)); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo), 3e-6, cfg + (Tn,))
-        note(name, "gc", rel(ct.grad.cpu().numpy(), gco), 2e-4, cfg + (Tn,))
+        note(name, "gc", rel(ct.grad.cpu().numpy(), gco, 0.05 * float(np.abs(ww).max()) * float(np.sqrt(xx.size / c.size))), 2e-4, cfg + (Tn,))
     # reverb (small impulse responses, odd shapes)
     if n_cfg % 3 == 0:
         L = int(rng.choice([64, 300, 1000, 2048, 3000, 5000, 9000])); taps = int(rng.choice([15, 63, 127, 1023]))
