@@ -31,6 +31,17 @@ class StyleTransferChain:
         for proc, p in ((self.equalizer, eq_params), (self.compressor, comp_params), (self.reverb, reverb_params), (self.gain, gain_params)):
             if p.shape[1] != proc.num_params:
                 raise ValueError(f"Parameter tensor has {p.shape[1]} parameters, but processor has {proc.num_params} parameters.")
+        # one [0, 1] check for all 50 parameters - one reduction, one read-back, before any kernel of the chain is queued
+        procs = (self.equalizer, self.compressor, self.reverb, self.gain)
+        if all(p.validate_range for p in procs) and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            every = (eq_params, comp_params, reverb_params, gain_params)
+            if all(t.dim() == 2 and t.shape[0] == every[0].shape[0] and t.dtype == every[0].dtype and t.device == every[0].device for t in every):
+                _modules.check_unit_range(torch.cat([t.detach() for t in every], dim=1), [n for p in procs for n in p.param_ranges])
+                with _modules.already_validated():
+                    return self._run(x, eq_params, comp_params, reverb_params, gain_params)
+        return self._run(x, eq_params, comp_params, reverb_params, gain_params)
+
+    def _run(self, x, eq_params, comp_params, reverb_params, gain_params):
         self.gain._check_range(gain_params)
         self.compressor._check_range(comp_params)
         lo, span = self.gain._affine(gain_params)

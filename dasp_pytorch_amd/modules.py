@@ -5,10 +5,10 @@ Same class names, constructor arguments, `param_ranges` (name -> (min, max), in 
 columns of the parameter tensor), `num_params`, `process`, `process_normalized`,
 `extract_param_dict` and `denormalize_param_dict`. Differences, all deliberate:
 
-* the range check of `process_normalized` is one fused reduction over the whole (bs, P) tensor and
-  one host sync, instead of the reference's two syncs per parameter (modules.py:83: 50 syncs for
-  an EQ -> compressor -> reverb -> gain chain, each a GPU pipeline drain); the ValueError still
-  names the offending parameter;
+* the range check of `process_normalized` is one min/max reduction over the whole (bs, P) tensor and
+  one host sync *before* the processor's kernels are queued (so the host never waits for them), instead of the
+  reference's two syncs per parameter (modules.py:83: 50 syncs for an EQ -> compressor -> reverb -> gain chain,
+  each a GPU pipeline drain); the ValueError still names the offending parameter;
 * de-normalisation is one affine op on the (bs, P) tensor, then column views;
 * `Distortion` works: the reference's has no `sample_rate` attribute and names its parameter
   `gain_db` although `functional.distortion` takes `drive_db`, so `process_normalized` raises
@@ -18,7 +18,9 @@ columns of the parameter tensor), `num_params`, `process`, `process_normalized`,
 """
 from typing import Dict
 
+import contextlib
 import functools
+import threading
 
 import torch
 
@@ -33,6 +35,33 @@ def normalize(val, min_val, max_val):
     return (val - min_val) / (max_val - min_val)
 
 
+_validated = threading.local()
+
+
+@contextlib.contextmanager
+def already_validated():
+    """Inside this block `Processor._check_range` is a no-op: for callers that checked the parameter tensors of several processors with one
+    reduction and one sync (chain.StyleTransferChain) before calling them."""
+    prev = getattr(_validated, "on", False)
+    _validated.on = True
+    try:
+        yield
+    finally:
+        _validated.on = prev
+
+
+def check_unit_range(param_tensor: torch.Tensor, names):
+    """ValueError naming the first column of the (bs, P) tensor with an entry outside [0, 1] (reference: modules.py:83-84, same message).
+    One min/max reduction, one two-element read-back; columns are only looked at when the check fails."""
+    p = param_tensor.detach()
+    if p.numel() == 0:
+        return
+    lo, hi = torch.stack(torch.aminmax(p)).tolist()            # NaNs pass, as they do the reference's (p < 0).any() / (p > 1).any()
+    if lo < 0 or hi > 1:
+        bad = ((p < 0) | (p > 1)).any(dim=0)
+        raise ValueError(f"Parameter {list(names)[int(torch.nonzero(bad)[0])]} of is out of range.")
+
+
 class Processor:
     """Base class with the reference's contract (modules.py:21-91): a subclass sets `sample_rate`, `process_fn` and `param_ranges`
     (name -> (min, max), in the order of the columns of the parameter tensor) - nothing else is required, so processors written against
@@ -42,8 +71,9 @@ class Processor:
     process_fn = None
     param_ranges: Dict[str, tuple] = {}
     # The reference validates every normalised parameter on every call (modules.py:83-84: two host syncs per parameter). Here it is one
-    # word read back per call - still a pipeline drain. A training loop whose controls come out of a sigmoid can switch it off per
-    # processor (`proc.validate_range = False`) or for the class; inside a HIP-graph capture it is skipped in any case.
+    # min/max read back per call, before the call's kernels are queued - still a sync with whatever was queued earlier. A training loop
+    # whose controls come out of a sigmoid can switch it off per processor (`proc.validate_range = False`) or for the class; inside a
+    # HIP-graph capture it is skipped in any case.
     validate_range = True
 
     def __init__(self):
@@ -91,13 +121,9 @@ class Processor:
     def _check_range(self, param_tensor: torch.Tensor):
         # a HIP-graph capture cannot read a result back on the host: inside one the [0, 1] check is skipped (validate the
         # controls once in eager mode; a sigmoid head, as in the reference's models, satisfies it by construction)
-        if not self.validate_range or (param_tensor.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if not self.validate_range or getattr(_validated, "on", False) or (param_tensor.is_cuda and torch.cuda.is_current_stream_capturing()):
             return
-        p = param_tensor.detach()
-        bad = ((p < 0) | (p > 1)).any(dim=0)                   # one reduction ...
-        if bool(bad.any()):                                    # ... one sync
-            name = list(self.param_ranges)[int(torch.nonzero(bad)[0])]
-            raise ValueError(f"Parameter {name} of is out of range.")
+        check_unit_range(param_tensor, self.param_ranges)
 
     def extract_param_dict(self, param_tensor: torch.Tensor):
         if param_tensor.shape[1] != len(self.param_ranges):
@@ -161,7 +187,7 @@ class ParametricEQ(Processor):
 
     def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
         """As Processor.process_normalized; float32 audio on the GPU takes the fused op (ops.ParametricEQNormFunction): de-normalisation,
-        [0, 1] check and filter design inside the design kernel, gradients returned w.r.t. `param_tensor` itself. Anything else (float64,
+        filter design inside the design kernel, gradients returned w.r.t. `param_tensor` itself. Anything else (float64,
         a replaced process_fn, renamed ranges) goes through the generic path."""
         names = list(self.param_ranges)
         fused = (self.process_fn is F.parametric_eq and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and param_tensor.dim() == 2
@@ -172,7 +198,10 @@ class ParametricEQ(Processor):
         from .ops import ParametricEQNormFunction
         lo = [float(r[0]) for r in self.param_ranges.values()]
         span = [float(r[1]) - float(r[0]) for r in self.param_ranges.values()]
-        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, names if self.validate_range else None)
+        # the check runs before the kernels are queued (one small reduction + read-back): the op's own in-kernel check (names != None) would
+        # make the host wait for the forward kernel it has just launched
+        self._check_range(param_tensor)
+        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, None)
 
 
 class _Dynamics(Processor):
