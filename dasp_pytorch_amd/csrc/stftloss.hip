@@ -4,10 +4,12 @@
 // auraloss is not vendored in the reference: the algorithm of auraloss 0.4.0 with default arguments is restated in
 // oracle/dasp_oracle.py:mrstft_loss, "parity unpinned").
 //
-// One fused kernel per direction, all resolutions in one launch (blockIdx.z): a 512-thread workgroup owns 4096 / n_fft frames of
+// One fused kernel per direction and resolution: a 512-thread workgroup owns 4096 / n_fft frames of
 // one signal row. The frames of the two signals are gathered (reflect padding, periodic Hann window zero-padded to n_fft) as ONE
-// complex signal p + i t, transformed with col_fft (fft_lds.hpp: frames side by side in registers + LDS), split into the two
-// one-sided spectra through one LDS read of the mirrored bin, reduced to the three sums of a resolution
+// complex signal p + i t and transformed - frames of 512 / 1024 / 2048 points (the default resolutions) as 1 / 2 / 4 interleaved
+// 512-point transforms, one per wave, with at most one workgroup barrier (split kernels, below); any other power of two with col_fft
+// (fft_lds.hpp: frames side by side in registers + LDS) -, split into the two
+// one-sided spectra through the mirrored bin, reduced to the three sums of a resolution
 //   S1 = sum (|T| - |P|)^2,  S2 = sum |T|^2,  S3 = sum |log|P| - log|T||       (|.| = sqrt(max(re^2 + im^2, eps)))
 // per workgroup; a finalize kernel adds them in fp64:  loss = mean_r( sqrt(S1)/sqrt(S2) + S3 / count ).
 // Backward recomputes the spectra, forms dL/d|P| * P/|P| on the one-sided bins, runs the inverse transform of that half spectrum and
@@ -44,20 +46,50 @@ __device__ __forceinline__ Bin split_bin(float zr, float zi, float mr, float mi)
     return Bin{0.5f * (zr + mr), 0.5f * (zi - mi), 0.5f * (zi + mi), -0.5f * (zr - mr)};
 }
 
+// one bin's contribution to the three sums of a resolution
+__device__ __forceinline__ void loss_terms(const Bin& b, float eps, float& s1, float& s2, float& s3) {
+    const float p2 = fmaxf(b.pr * b.pr + b.pi * b.pi, eps), t2 = fmaxf(b.tr * b.tr + b.ti * b.ti, eps);
+    const float pm = __builtin_amdgcn_sqrtf(p2), tm = __builtin_amdgcn_sqrtf(t2);      // operands in [eps, ~1e6]: the plain instructions are exact enough (1 ulp)
+    s1 = fmaf(tm - pm, tm - pm, s1);
+    s2 += t2;
+    s3 += 0.5f * fabsf(__logf(__fdividef(p2, t2)));       // |log pm - log tm| = |log(p2 / t2)| / 2; the ratio stays within 1e-14 .. 1e14
+}
+// one bin of the gradient spectrum: dL/d|P| * P / |P|
+__device__ __forceinline__ void grad_bin(const Bin& b, float eps, float k_sc, float k_lm, float& hr, float& hi) {
+    hr = 0.f; hi = 0.f;
+    const float praw = b.pr * b.pr + b.pi * b.pi;
+    if (praw > eps) {                                            // the clamp has zero slope below eps
+        const float tm = sqrtf(fmaxf(b.tr * b.tr + b.ti * b.ti, eps)), pm = sqrtf(praw);
+        const float sgn = tm > pm ? 1.f : (tm < pm ? -1.f : 0.f);            // sign(log tm - log pm)
+        const float gm = (k_sc * (pm - tm) - k_lm * sgn / pm) / pm;           // dL/d|P| / |P|
+        hr = gm * b.pr; hi = gm * b.pi;
+    }
+}
+
 // gather + window + forward transform of this thread's 8 samples of its frame; afterwards r/i = Z[j + T q] and mr/mi = Z[F - (j + T q)]
-__device__ __forceinline__ void frames_to_spectra(const float* __restrict__ prow, const float* __restrict__ trow, int N, int frame, bool live,
-                                                  const StftRes& R, const ColCfg& g, const f2* __restrict__ tw, f2* lds, float (&r)[8],
-                                                  float (&i)[8], float (&mr)[8], float (&mi)[8]) {
+// the window of a resolution, once per workgroup (all its frames share it): wlds[n] = hann_in_frame(n), n < F; a barrier follows in the caller's path
+__device__ __forceinline__ void window_to_lds(float* wlds, const StftRes& R) {
     const int F = 1 << R.logF;
+    for (int n = threadIdx.x; n < F; n += 512) wlds[n] = hann_in_frame(n, F, R.win);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void frames_to_spectra(const float* __restrict__ prow, const float* __restrict__ trow, int N, int frame, bool live,
+                                                  const StftRes& R, const ColCfg& g, const f2* __restrict__ tw, f2* lds, const float* wlds,
+                                                  float (&r)[8], float (&i)[8], float (&mr)[8], float (&mi)[8]) {
+    const int F = 1 << R.logF;
+    // all 16 loads first, at indices that are always valid (a load under `if (w != 0)` is a branch with its own wait: 8 exposed round
+    // trips per thread); the window, zero outside its support and for frames past the end, is applied afterwards
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int n = g.j + g.T * q;
-        const float w = hann_in_frame(n, F, R.win);
-        r[q] = 0.f; i[q] = 0.f;
-        if (live && w != 0.f) {
-            const int s = reflect_index(frame * R.hop - F / 2 + n, N);
-            r[q] = w * prow[s]; i[q] = w * trow[s];
-        }
+        int s = reflect_index(frame * R.hop - F / 2 + g.j + g.T * q, N);
+        s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+        r[q] = prow[s]; i[q] = trow[s];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float w = live ? wlds[g.j + g.T * q] : 0.f;
+        r[q] *= w; i[q] *= w;
     }
     col_fft<-1>(r, i, g, tw, lds);
     __syncthreads();
@@ -72,31 +104,30 @@ __device__ __forceinline__ void frames_to_spectra(const float* __restrict__ prow
     __syncthreads();       // the caller may reuse lds for another transform
 }
 
+// One launch per resolution. These two kernels take any power of two 8 .. 4096 (col_fft with run-time geometry); frames of 512, 1024 and
+// 2048 points - the default resolutions - run the split kernels further down.
 // partials[((res * rows + row) * groups + group) * 3 + {0, 1, 2}]
 __global__ void __launch_bounds__(512)
 mrstft_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const f2* __restrict__ tw, float* __restrict__ partials,
-                  StftSpec spec, int N) {
+                  StftSpec spec, int N, int res) {
     __shared__ f2 lds[ColGeom<12>::LDS];
+    __shared__ float wlds[FFT_N];
     __shared__ float red[8][3];
-    const StftRes R = spec.r[blockIdx.z];
+    const StftRes R = spec.r[res];
     const ColCfg g = col_config<12>(R.logF, threadIdx.x);
     const int row = blockIdx.y, F = 1 << R.logF;
     if ((int)blockIdx.x * g.TC >= R.frames) return;          // uniform: this resolution has fewer frame groups than the grid
     const int frame = blockIdx.x * g.TC + g.c;
     const bool live = frame < R.frames;
+    window_to_lds(wlds, R);
     float r[8], i[8], mr[8], mi[8];
-    frames_to_spectra(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, R, g, tw, lds, r, i, mr, mi);
+    frames_to_spectra(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, R, g, tw, lds, wlds, r, i, mr, mi);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int k = g.j + g.T * q;
         if (live && k <= F / 2) {
-            const Bin b = split_bin(r[q], i[q], mr[q], mi[q]);
-            const float p2 = fmaxf(b.pr * b.pr + b.pi * b.pi, spec.eps), t2 = fmaxf(b.tr * b.tr + b.ti * b.ti, spec.eps);
-            const float pm = sqrtf(p2), tm = sqrtf(t2);
-            s1 = fmaf(tm - pm, tm - pm, s1);
-            s2 += t2;
-            s3 += 0.5f * fabsf(logf(p2) - logf(t2));       // |log pm - log tm|
+            loss_terms(split_bin(r[q], i[q], mr[q], mi[q]), spec.eps, s1, s2, s3);
         }
     }
     s1 = wave_sum_uniform(s1); s2 = wave_sum_uniform(s2); s3 = wave_sum_uniform(s3);
@@ -105,10 +136,9 @@ mrstft_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ
     if (threadIdx.x < 3) {
         float a = 0.f;
         for (int v = 0; v < 8; ++v) a += red[v][threadIdx.x];
-        partials[(((size_t)blockIdx.z * gridDim.y + row) * spec.groups + blockIdx.x) * 3 + threadIdx.x] = a;
+        partials[(((size_t)res * gridDim.y + row) * spec.groups + blockIdx.x) * 3 + threadIdx.x] = a;
     }
 }
-
 // step 1, one workgroup per (resolution, sum): stats[res * 4 + c] = S_c, added up in fp64
 __global__ void __launch_bounds__(256)
 mrstft_reduce_kernel(const float* __restrict__ partials, StftSpec spec, int rows, float* __restrict__ stats) {
@@ -141,33 +171,26 @@ __global__ void mrstft_finalize_kernel(StftSpec spec, int rows, float* __restric
 // gpred (rows, N) must be zero on entry; gloss = d(objective)/d(loss), a device scalar
 __global__ void __launch_bounds__(512)
 mrstft_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const f2* __restrict__ tw, const float* __restrict__ stats,
-                  const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N) {
+                  const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N, int res) {
     __shared__ f2 lds[ColGeom<12>::LDS];
-    const StftRes R = spec.r[blockIdx.z];
+    __shared__ float wlds[FFT_N];
+    const StftRes R = spec.r[res];
     const ColCfg g = col_config<12>(R.logF, threadIdx.x);
     const int row = blockIdx.y, F = 1 << R.logF;
     if ((int)blockIdx.x * g.TC >= R.frames) return;
     const int frame = blockIdx.x * g.TC + g.c;
     const bool live = frame < R.frames;
+    window_to_lds(wlds, R);
     float r[8], i[8], mr[8], mi[8];
-    frames_to_spectra(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, R, g, tw, lds, r, i, mr, mi);
-    const float s1 = stats[blockIdx.z * 4], s2 = stats[blockIdx.z * 4 + 1], count = stats[blockIdx.z * 4 + 2];
+    frames_to_spectra(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, R, g, tw, lds, wlds, r, i, mr, mi);
+    const float s1 = stats[res * 4], s2 = stats[res * 4 + 1], count = stats[res * 4 + 2];
     const float gl = gloss[0] / (float)spec.nres;
     const float k_sc = s1 > 0.f ? gl / (s1 * s2) : 0.f, k_lm = gl / count;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int k = g.j + g.T * q;
         float hr = 0.f, hi = 0.f;
-        if (live && k <= F / 2) {
-            const Bin b = split_bin(r[q], i[q], mr[q], mi[q]);
-            const float praw = b.pr * b.pr + b.pi * b.pi;
-            if (praw > spec.eps) {                                   // the clamp has zero slope below eps
-                const float tm = sqrtf(fmaxf(b.tr * b.tr + b.ti * b.ti, spec.eps)), pm = sqrtf(praw);
-                const float sgn = tm > pm ? 1.f : (tm < pm ? -1.f : 0.f);        // sign(log tm - log pm)
-                const float gm = (k_sc * (pm - tm) - k_lm * sgn / pm) / pm;       // dL/d|P| / |P|
-                hr = gm * b.pr; hi = gm * b.pi;
-            }
-        }
+        if (live && k <= F / 2) grad_bin(split_bin(r[q], i[q], mr[q], mi[q]), spec.eps, k_sc, k_lm, hr, hi);
         r[q] = hr; i[q] = hi;
     }
     col_fft<1>(r, i, g, tw, lds);                                    // sum_k H[k] e^{+2 pi i k n / F}, H = 0 on the upper half
@@ -175,11 +198,195 @@ mrstft_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int n = g.j + g.T * q;
-        const float w = hann_in_frame(n, F, R.win);
+        const float w = hann_in_frame(n, F, R.win);     // measured: reading the LDS table here instead costs 7 % of the kernel
         if (live && w != 0.f) atomicAdd(grow + reflect_index(frame * R.hop - F / 2 + n, N), w * r[q]);
     }
 }
 
+// ---- n_fft = 512 R, R = 1, 2, 4: R waves per frame ------------------------------------------------------------------------------------
+// A frame of F = 512 R points is R interleaved 512-point transforms (decimation in frequency): y_r'[m] = W_F^(m r') sum_rho x[m + 512 rho]
+// W_R^(rho r'), X[r' + R kappa] = FFT512(y_r')[kappa]. Thread u of a frame (64 R threads, lanes along consecutive samples: coalesced gather
+// and scatter) holds x[m + 512 rho] for 8 / R values of m, does the radix-R step in registers, and one transpose through LDS (the only
+// workgroup barrier of the transform; none for R = 1) hands wave r' its y_r', which it transforms on its own (fft512_wave: wave-private
+// exchanges). Afterwards lane l, register s of wave r' holds bin k = r' + R (l + 64 s). The one-sided bins k <= F / 2 are exactly the
+// registers s < 4 of every wave (plus bin F / 2 in lane 0 of wave 0), so no lane idles through the logarithms, and the mirrored bin F - k
+// sits in registers 7 - s of wave (R - r') % R, lane 63 - l (wave 0: lane 64 - l; its lane 0 keeps bin 0): lane permutes when that is the
+// same wave (R = 1, 2), one more exchange of the upper registers through LDS for R = 4. 8 / R frames per workgroup, as the generic
+// kernels group them (they remain for every other power of two).
+template <int R> struct SplitCfg {
+    int l, wv, c, rp, u;
+    __device__ __forceinline__ SplitCfg() { l = lane_id(); wv = wave_id(); c = wv / R; rp = wv % R; u = rp * 64 + l; }
+};
+
+// forward: r/i <- this wave's bins, mr/mi <- the mirrored bins of registers 0..3
+template <int R>
+__device__ __forceinline__ void split_frame_spectrum(const float* __restrict__ prow, const float* __restrict__ trow, int N, int frame, bool live,
+                                                     const StftRes& Rs, const SplitCfg<R>& g, const f2* __restrict__ tw, const Fft512Tw& t5,
+                                                     f2* lds, const float* wlds, float (&r)[8], float (&i)[8], float (&mr)[4], float (&mi)[4]) {
+    constexpr int F = 512 * R, G = 8 / R;
+    f2* row = lds + g.wv * FFT512_LDS;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {              // register q = gi * R + rho  <->  sample n = (u + 64 R gi) + 512 rho
+        const int n = g.u + 64 * R * (q / R) + 512 * (q % R);
+        int s = reflect_index(frame * Rs.hop - F / 2 + n, N);
+        s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+        r[q] = prow[s]; i[q] = trow[s];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float w = live ? wlds[g.u + 64 * R * (q / R) + 512 * (q % R)] : 0.f;
+        r[q] *= w; i[q] *= w;
+    }
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int m = g.u + 64 * R * gi;
+            if constexpr (R == 2) {
+                const float ar = r[2 * gi], ai = i[2 * gi];
+                r[2 * gi] = ar + r[2 * gi + 1]; i[2 * gi] = ai + i[2 * gi + 1];
+                r[2 * gi + 1] = ar - r[2 * gi + 1]; i[2 * gi + 1] = ai - i[2 * gi + 1];
+            } else {
+                dft4<-1>(r[4 * gi], i[4 * gi], r[4 * gi + 1], i[4 * gi + 1], r[4 * gi + 2], i[4 * gi + 2], r[4 * gi + 3], i[4 * gi + 3]);
+            }
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                const f2 w = tw[m * k * (8 / R)];                       // W_F^(m k): m k < F, table step 4096 / F
+                cmul_dir<-1>(r[R * gi + k], i[R * gi + k], w.x, w.y);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) lds[(g.c * R + k) * FFT512_LDS + m] = f2{r[R * gi + k], i[R * gi + k]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f2 v = row[g.l + 64 * q]; r[q] = v.x; i[q] = v.y; }
+    }
+    fft512_wave<-1>(r, i, g.l, t5, row);
+    if constexpr (R == 4) {
+        // the upper registers of every wave through LDS: wave r' reads those of wave (4 - r') % 4
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 4; s < 8; ++s) row[g.l + 64 * s] = f2{r[s], i[s]};
+        __syncthreads();
+        const f2* prow2 = lds + (g.c * R + ((R - g.rp) & (R - 1))) * FFT512_LDS;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kap = g.l + 64 * s;
+            const f2 v = prow2[g.rp == 0 ? ((512 - kap) & 511) : 511 - kap];
+            const bool self = g.rp == 0 && kap == 0;                    // bin 0 mirrors onto itself (and was not published)
+            mr[s] = self ? r[0] : v.x; mi[s] = self ? i[0] : v.y;
+        }
+        __syncthreads();                                                // the rows are reused (inverse transform / next exchange)
+    } else {
+        // same wave: wave 0 (and R = 1) pairs lane l with lane 64 - l, its lane 0 with its own registers; wave 1 of R = 2 pairs l with 63 - l
+        const bool w0 = g.rp == 0;
+        const int src = w0 ? ((64 - g.l) & 63) : 63 - g.l;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float zr = __shfl(r[7 - s], src), zi = __shfl(i[7 - s], src);
+            const bool own = w0 && g.l == 0;
+            mr[s] = own ? r[(8 - s) & 7] : zr;
+            mi[s] = own ? i[(8 - s) & 7] : zi;
+        }
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(512)
+mrstft_fwd_split_kernel(const float* __restrict__ pred, const float* __restrict__ target, const f2* __restrict__ tw, float* __restrict__ partials,
+                        StftSpec spec, int N, int res) {
+    __shared__ f2 lds[8 * FFT512_LDS];
+    __shared__ float wlds[512 * R];
+    __shared__ float red[8][3];
+    const StftRes Rs = spec.r[res];
+    const SplitCfg<R> g;
+    const int row = blockIdx.y;
+    const int frame = blockIdx.x * (8 / R) + g.c;
+    const bool live = frame < Rs.frames;
+    window_to_lds(wlds, Rs);
+    const Fft512Tw t5 = fft512_twiddles(g.l, tw);
+    float r[8], i[8], mr[4], mi[4];
+    split_frame_spectrum<R>(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, Rs, g, tw, t5, lds, wlds, r, i, mr, mi);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) loss_terms(split_bin(r[s], i[s], mr[s], mi[s]), spec.eps, s1, s2, s3);
+        if (g.rp == 0 && g.l == 0) loss_terms(split_bin(r[4], i[4], r[4], i[4]), spec.eps, s1, s2, s3);       // bin F / 2 mirrors onto itself
+    }
+    s1 = wave_sum_uniform(s1); s2 = wave_sum_uniform(s2); s3 = wave_sum_uniform(s3);
+    if (g.l == 0) { red[g.wv][0] = s1; red[g.wv][1] = s2; red[g.wv][2] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float a = 0.f;
+        for (int v = 0; v < 8; ++v) a += red[v][threadIdx.x];
+        partials[(((size_t)res * gridDim.y + row) * spec.groups + blockIdx.x) * 3 + threadIdx.x] = a;
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(512)
+mrstft_bwd_split_kernel(const float* __restrict__ pred, const float* __restrict__ target, const f2* __restrict__ tw, const float* __restrict__ stats,
+                        const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N, int res) {
+    constexpr int F = 512 * R, G = 8 / R;
+    __shared__ f2 lds[8 * FFT512_LDS];
+    __shared__ float wlds[512 * R];
+    const StftRes Rs = spec.r[res];
+    const SplitCfg<R> g;
+    const int row = blockIdx.y;
+    const int frame = blockIdx.x * (8 / R) + g.c;
+    const bool live = frame < Rs.frames;
+    window_to_lds(wlds, Rs);
+    const Fft512Tw t5 = fft512_twiddles(g.l, tw);
+    float r[8], i[8], mr[4], mi[4];
+    f2* rowbuf = lds + g.wv * FFT512_LDS;
+    split_frame_spectrum<R>(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, Rs, g, tw, t5, lds, wlds, r, i, mr, mi);
+    const float s1 = stats[res * 4], s2 = stats[res * 4 + 1], count = stats[res * 4 + 2];
+    const float gl = gloss[0] / (float)spec.nres;
+    const float k_sc = s1 > 0.f ? gl / (s1 * s2) : 0.f, k_lm = gl / count;
+    float h4r = 0.f, h4i = 0.f;
+    if (live && g.rp == 0 && g.l == 0) grad_bin(split_bin(r[4], i[4], r[4], i[4]), spec.eps, k_sc, k_lm, h4r, h4i);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float hr = 0.f, hi = 0.f;
+        if (live) grad_bin(split_bin(r[s], i[s], mr[s], mi[s]), spec.eps, k_sc, k_lm, hr, hi);
+        r[s] = hr; i[s] = hi;
+    }
+    r[4] = h4r; i[4] = h4i;
+#pragma unroll
+    for (int s = 5; s < 8; ++s) { r[s] = 0.f; i[s] = 0.f; }
+    // x[n] = sum_k H[k] e^(+2 pi i k n / F), H = 0 above bin F / 2: the forward steps mirrored
+    fft512_wave<1>(r, i, g.l, t5, rowbuf);
+    if constexpr (R > 1) {
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rowbuf[g.l + 64 * q] = f2{r[q], i[q]};
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int m = g.u + 64 * R * gi;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { const f2 v = lds[(g.c * R + k) * FFT512_LDS + m]; r[R * gi + k] = v.x; i[R * gi + k] = v.y; }
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                const f2 w = tw[m * k * (8 / R)];
+                cmul_dir<1>(r[R * gi + k], i[R * gi + k], w.x, w.y);
+            }
+            if constexpr (R == 2) {
+                const float ar = r[2 * gi], ai = i[2 * gi];
+                r[2 * gi] = ar + r[2 * gi + 1]; i[2 * gi] = ai + i[2 * gi + 1];
+                r[2 * gi + 1] = ar - r[2 * gi + 1]; i[2 * gi + 1] = ai - i[2 * gi + 1];
+            } else {
+                dft4<1>(r[4 * gi], i[4 * gi], r[4 * gi + 1], i[4 * gi + 1], r[4 * gi + 2], i[4 * gi + 2], r[4 * gi + 3], i[4 * gi + 3]);
+            }
+        }
+    }
+    float* grow = gpred + (size_t)row * N;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int n = g.u + 64 * R * (q / R) + 512 * (q % R);
+        const float w = hann_in_frame(n, F, Rs.win);
+        if (live && w != 0.f) atomicAdd(grow + reflect_index(frame * Rs.hop - F / 2 + n, N), w * r[q]);
+    }
+}
 }  // namespace dasp
 
 // ================================================================================================
@@ -230,8 +437,17 @@ int dasp_mrstft_forward(const float* pred, const float* target, const void* tw, 
     StftSpec s;
     if (!sl_spec(N, nres, fft, hop, win, eps, &s)) return DASP_ERR_UNSUPPORTED;
     if (rows > 65535) return DASP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(mrstft_fwd_kernel, dim3((unsigned)s.groups, (unsigned)rows, (unsigned)nres), dim3(512), 0, (hipStream_t)stream, pred, target,
-                       (const f2*)tw, partials, s, N);
+    for (int r = 0; r < nres; ++r) {
+        const int TC = FFT_N >> s.r[r].logF;
+        const dim3 grid((unsigned)((s.r[r].frames + TC - 1) / TC), (unsigned)rows);
+#define SL_FWD(LG) hipLaunchKernelGGL(mrstft_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, partials, s, N, r)
+        switch (s.r[r].logF) {
+#define SL_FWDS(RR) hipLaunchKernelGGL(mrstft_fwd_split_kernel<RR>, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, partials, s, N, r)
+            case 9: SL_FWDS(1); break; case 10: SL_FWDS(2); break; case 11: SL_FWDS(4); break; default: SL_FWD(0);
+#undef SL_FWDS
+        }
+#undef SL_FWD
+    }
     hipLaunchKernelGGL(mrstft_reduce_kernel, dim3((unsigned)(nres * 3)), dim3(256), 0, (hipStream_t)stream, (const float*)partials, s, rows, stats);
     hipLaunchKernelGGL(mrstft_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s, rows, stats, loss);
     return sl_check();
@@ -244,8 +460,17 @@ int dasp_mrstft_backward(const float* pred, const float* target, const void* tw,
     if (!sl_spec(N, nres, fft, hop, win, eps, &s)) return DASP_ERR_UNSUPPORTED;
     if (rows > 65535) return DASP_ERR_UNSUPPORTED;
     if (hipMemsetAsync(gpred, 0, (size_t)rows * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return sl_check();
-    hipLaunchKernelGGL(mrstft_bwd_kernel, dim3((unsigned)s.groups, (unsigned)rows, (unsigned)nres), dim3(512), 0, (hipStream_t)stream, pred, target,
-                       (const f2*)tw, stats, gloss, gpred, s, N);
+    for (int r = 0; r < nres; ++r) {
+        const int TC = FFT_N >> s.r[r].logF;
+        const dim3 grid((unsigned)((s.r[r].frames + TC - 1) / TC), (unsigned)rows);
+#define SL_BWD(LG) hipLaunchKernelGGL(mrstft_bwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r)
+        switch (s.r[r].logF) {
+#define SL_BWDS(RR) hipLaunchKernelGGL(mrstft_bwd_split_kernel<RR>, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r)
+            case 9: SL_BWDS(1); break; case 10: SL_BWDS(2); break; case 11: SL_BWDS(4); break; default: SL_BWD(0);
+#undef SL_BWDS
+        }
+#undef SL_BWD
+    }
     return sl_check();
 }
 
