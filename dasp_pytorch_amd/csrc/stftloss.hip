@@ -379,6 +379,8 @@ mrstft_bwd_split_kernel(const float* __restrict__ pred, const float* __restrict_
             }
         }
     }
+    // (adding the workgroup's overlapping frames up in LDS first - float atomics on LDS, then one global atomic per sample of the span,
+    // 2.5x fewer of them - was measured at +90 us per kernel: the global float atomics below are the cheaper ones)
     float* grow = gpred + (size_t)row * N;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
