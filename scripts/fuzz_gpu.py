@@ -94,7 +94,8 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         xt = T(xx).requires_grad_(True); ct = T(c).requires_grad_(True)
         y = fn(xt, SR, ct); (y * T(ww)).sum().backward()
         gxo, gco = fv(xx, SR, c, ww)
-        note(name, "y", rel(y.detach().cpu().numpy(), f(xx, SR, c)), 3e-6, cfg + (Tn,)); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo), 3e-6, cfg + (Tn,))
+        # (gx of the panner / widener is a two-term signed sum per sample: on a one-sample signal it can cancel, hence the floor)
+        note(name, "y", rel(y.detach().cpu().numpy(), f(xx, SR, c)), 3e-6, cfg + (Tn,)); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo, 0.05 * float(np.abs(ww).max())), 3e-6, cfg + (Tn,))
         note(name, "gc", rel(ct.grad.cpu().numpy(), gco, 0.05 * float(np.abs(ww).max()) * float(np.sqrt(xx.size / c.size))), 2e-4, cfg + (Tn,))
     # reverb (small impulse responses, odd shapes)
     if n_cfg % 3 == 0:
