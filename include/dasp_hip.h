@@ -224,9 +224,11 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
  * [9] = signals per pass of the long-convolution pipeline (all 2B by default; a developer switch can cut the pipeline into passes over
  *       chunks of signals that reuse chunk-sized scratch buffers),
  * [10] = floats of mix_part, [11] = floats of part,
- * [12] = complex elements of each of the scratch buffers W / W2 / Ag, [13] = complex elements of each of the scratch buffers Ah / P. */
+ * [12] = complex elements of each of the scratch buffers W / W2 / Ag (at least B * nb * 4096: W and Ag also hold the per-item weighted
+ *        band spectra of the filter bank while it runs), [13] = complex elements of each of the scratch buffers Ah / P. */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [14] */);
-/* filters (nb, taps) fp32, the host-designed bank -> Fspec: transform twiddles followed by the band spectra. */
+/* filters (nb, taps) fp32, the host-designed bank -> Fspec: transform twiddles, the band spectra, the taps themselves (the filter bank
+ * re-weights them by each item's decay envelope per call). */
 int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream);
 /* forward: H and (when a backward pass follows) A are kept for it - pass A = NULL otherwise and the column transforms of x go to the
  * scratch W2; W, Ah, ir are scratch.
