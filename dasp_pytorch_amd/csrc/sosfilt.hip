@@ -858,6 +858,8 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 // mode 0: gradient w.r.t. sos (B,S,6) as given (a0 included); mode 1: gradient w.r.t. (gain_db, cutoff_freq, q_factor) (B,S,3)
 // through the RBJ design Jacobian; mode 2: the same as 3 S rows of B values ([3 k + dir][item]: one contiguous gradient vector per
 // control tensor of parametric_eq).
+__device__ __forceinline__ void finish_section(const double* __restrict__ dtab, int tab_bcast, const double (&acc)[5], int B, int S, int mode,
+                                               float* __restrict__ gout, int item, int k, int fast);
 template <bool COHERENT>   // COHERENT: the partial sums were written by other workgroups of the running kernel (device-scope loads)
 __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab, int tab_bcast, const float* partials,
                                                  int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int item, int k, int fast) {
@@ -879,6 +881,11 @@ __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab
 #pragma unroll
             for (int i = 0; i < 5; ++i) acc[i] += r0 + j < R ? (double)v[j][i] : 0.0;
     }
+    finish_section(dtab, tab_bcast, acc, B, S, mode, gout, item, k, fast);
+}
+// acc: the five sums of section k of the item over all its rows -> its gradients
+__device__ __forceinline__ void finish_section(const double* __restrict__ dtab, int tab_bcast, const double (&acc)[5], int B, int S, int mode,
+                                               float* __restrict__ gout, int item, int k, int fast) {
     const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
     const double* d = d0 + k * DT_STRIDE;
     // What the backward kernel summed (sos_bwd_kernel, `adjoint`): with K[n] the kept signal of the section (w[n - 2] itself for a
@@ -1367,9 +1374,11 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // Segmented rows (few rows: B*C workgroups do not fill the chip). Per item: Phi^(samples per segment) of the forward and the adjoint
-// cascade, in fp64 from the fp64 design in dtab (same realisation and Phi as the prep kernel), by repeated squaring. One wave per item.
+// cascade, in fp64 from the fp64 design in dtab (same realisation and Phi as the prep kernel), by repeated squaring. One workgroup of four
+// waves per item; Phi and its powers are block lower triangular, so a squaring is 2 x 84 inner products - one per thread - and a
+// barrier (one wave walking all 2 x 144 elements of every squaring took 14 us for the 14 squarings of a 16-tile segment; this: ~5).
 template <int S>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 sos_segprep_kernel(const double* __restrict__ dtab, int nsq, double* __restrict__ segtab) {
     constexpr int S2 = 2 * S, NN = S2 * S2;
     __shared__ double sec[S][8];
@@ -1384,8 +1393,8 @@ sos_segprep_kernel(const double* __restrict__ dtab, int nsq, double* __restrict_
         const double g1 = b1 - b0 * a1, g2 = ((b2 - b0 * a2) + g1 * sg) / om;
         sec[l][0] = sg; sec[l][1] = om; sec[l][2] = kap * om; sec[l][3] = g1; sec[l][4] = g2; sec[l][5] = b0;
     }
-    wave_lds_sync();
-    for (int e = l; e < 2 * NN; e += 64) {   // as in sos_prep_kernel
+    __syncthreads();
+    for (int e = l; e < 2 * NN; e += 256) {   // as in sos_prep_kernel
         const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
         const int kk = i / 2, r = i % 2, jj = j / 2, c = j % 2;
         const int fk = sys ? S - 1 - kk : kk, fj = sys ? S - 1 - jj : jj;
@@ -1401,22 +1410,27 @@ sos_segprep_kernel(const double* __restrict__ dtab, int nsq, double* __restrict_
             gain *= (m > jj && m < kk) ? dm : 1.0;
         }
         T1[sys][i * S2 + j] = jj == kk ? a_el : (jj < kk ? Bk * gain * Cj : 0.0);
+        T2[sys][i * S2 + j] = 0.0;                                  // the blocks above the diagonal stay zero in every power
     }
-    wave_lds_sync();
+    __syncthreads();
     double (*src)[NN] = T1;
     double (*dst)[NN] = T2;
+    constexpr int NTRI = S * (S + 1) / 2 * 4;                       // elements of the blocks on and below the diagonal, per system
     for (int step = 0; step < nsq; ++step) {
-        for (int e = l; e < 2 * NN; e += 64) {
-            const int sys = e / NN, i = (e % NN) / S2, j = e % S2;
+        for (int e = l; e < 2 * NTRI; e += 256) {
+            const int sys = e / NTRI, q = e % NTRI, blk = q >> 2;
+            const int kk = (blk >= 1) + (blk >= 3) + (blk >= 6) + (blk >= 10) + (blk >= 15) + (blk >= 21) + (blk >= 28);
+            const int jj = blk - kk * (kk + 1) / 2;
+            const int i = 2 * kk + ((q >> 1) & 1), j = 2 * jj + (q & 1);
             double acc = 0.0;
 #pragma unroll
             for (int m = 0; m < S2; ++m) acc += src[sys][i * S2 + m] * src[sys][m * S2 + j];
             dst[sys][i * S2 + j] = acc;
         }
-        wave_lds_sync();
+        __syncthreads();
         double (*tmp)[NN] = src; src = dst; dst = tmp;
     }
-    for (int e = l; e < 2 * NN; e += 64) segtab[(size_t)item * 2 * NN + e] = src[e / NN][e % NN];
+    for (int e = l; e < 2 * NN; e += 256) segtab[(size_t)item * 2 * NN + e] = src[e / NN][e % NN];
 }
 
 // Chains the segments of a row: start(g + 1) = Phi_seg start(g) + z(g) upwards for the forward system (adjoint = 0), downwards
@@ -1460,6 +1474,24 @@ __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bca
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * S) return;
     finalize_section<false>(dtab, tab_bcast, partials, B, C, S, Wb, mode, gout, idx / S, idx % S, fast);
+}
+// The same with one wave per (item, section), its lanes across the item's rows of sums: segmented rows leave C * 4 * segments rows per
+// item (64 at 16 x 2 x 131072), which one thread fetches in C * Wb / 8 dependent rounds (12 us); a wave needs one.
+__global__ void __launch_bounds__(256) sos_finalize_wave_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
+                                                                int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int fast) {
+    const int idx = blockIdx.x * (blockDim.x / 64) + wave_id(), l = lane_id();
+    if (idx >= B * S) return;
+    const int item = idx / S, k = idx % S, R = C * Wb;
+    const float* p0 = partials + ((size_t)item * R * S + k) * 5;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int r = l; r < R; r += 64) {
+        const float* p = p0 + (size_t)r * S * 5;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] += (double)p[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
+    if (l == 0) finish_section(dtab, tab_bcast, acc, B, S, mode, gout, item, k, fast);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1667,8 +1699,12 @@ int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials,
     if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
         return DASP_ERR_ARG;
     const int n = B * S;
-    hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
-                       Bs == 1 && B != 1, partials, B, C, S, kWB * segments, mode, gout, designed ? 1 : 0);
+    if (C * kWB * segments > 16)      // many rows of sums per item (segmented rows): one wave per (item, section)
+        hipLaunchKernelGGL(sos_finalize_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dtab,
+                           Bs == 1 && B != 1, partials, B, C, S, kWB * segments, mode, gout, designed ? 1 : 0);
+    else
+        hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
+                           Bs == 1 && B != 1, partials, B, C, S, kWB * segments, mode, gout, designed ? 1 : 0);
     return check_launch();
 }
 
@@ -1737,7 +1773,7 @@ int dasp_sos_segment_prepare(const double* dtab, int Bs, int S, long Tseg, doubl
     for (long n = 64L * kL * Tseg; n > 1; n >>= 1) ++nsq;   // Phi^(64 L Tseg): log2 squarings
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
-        hipLaunchKernelGGL((sos_segprep_kernel<SS>), dim3(Bs), dim3(64), 0, (hipStream_t)stream, dtab, nsq, segtab);
+        hipLaunchKernelGGL((sos_segprep_kernel<SS>), dim3(Bs), dim3(256), 0, (hipStream_t)stream, dtab, nsq, segtab);
         return check_launch();
     });
 }
