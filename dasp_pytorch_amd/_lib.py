@@ -55,6 +55,8 @@ SIGNATURES = {
     "dasp_gain_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
     "dasp_distortion_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dasp_distortion_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
+    "dasp_chain_controls": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "dasp_chain_controls_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "dasp_distortion_sample_forward": (_i, [_p, _p, _p, _l, _p]),
     "dasp_distortion_sample_backward": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "dasp_dyn_num_tiles": (_l, [_l]),

@@ -6,6 +6,8 @@ commutes with it:  gain * reverb(c) = reverb(gain * c);  and a gain applied to t
 already does:  gain_db just adds to makeup_gain_db. The chain below therefore runs three kernels' worth of passes, not four, with
 bit-for-bit the same mathematics (up to fp32 rounding of one multiply) and the gradient of gain_db falling out of the make-up gain's.
 """
+import os
+
 import torch
 
 from . import functional as _functional
@@ -41,7 +43,39 @@ class StyleTransferChain:
                     return self._run(x, eq_params, comp_params, reverb_params, gain_params)
         return self._run(x, eq_params, comp_params, reverb_params, gain_params)
 
+    def _tables(self):
+        """lo / span of the compressor's 6, the reverb's 25 and the gain's 1 parameter as the two float[32] arrays dasp_chain_controls takes."""
+        ranges = list(self.compressor.param_ranges.values()) + list(self.reverb.param_ranges.values()) + list(self.gain.param_ranges.values())
+        key = tuple(ranges)
+        if getattr(self, "_tab_key", None) != key:
+            import ctypes
+            self._tab = ((ctypes.c_float * 32)(*[float(r[0]) for r in ranges]), (ctypes.c_float * 32)(*[float(r[1]) - float(r[0]) for r in ranges]))
+            self._tab_key = key
+        return self._tab
+
     def _run(self, x, eq_params, comp_params, reverb_params, gain_params):
+        m = _modules
+        every = (comp_params, reverb_params, gain_params)
+        fused = (os.environ.get("DASP_CHAIN_FUSED_CONTROLS", "1") != "0"        # developer A/B: the torch-op de-normalisation below
+                 and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and x.shape[1] <= 2
+                 and all(t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.shape[0] == x.shape[0] for t in every)
+                 and comp_params.shape[1] == 6 and reverb_params.shape[1] == 25 and gain_params.shape[1] == 1
+                 and list(self.compressor.param_ranges) == m._DYN_NAMES and list(self.reverb.param_ranges) == m._REV_NAMES
+                 and self.compressor.process_fn is _functional.compressor and self.reverb.process_fn is self.reverb._rev_fn
+                 and self.gain.process_fn is _functional.gain)
+        if fused:
+            # every control of the three stages behind the EQ from one launch (and one back): ops.ChainControlsFunction
+            from .ops import ChainControlsFunction, DynamicsCtlFunction
+            self.gain._check_range(gain_params)
+            self.compressor._check_range(comp_params)
+            self.reverb._check_range(reverb_params)
+            lo, span = self._tables()
+            ctl, gains, decays, mix = ChainControlsFunction.apply(comp_params, reverb_params, gain_params, lo, span)
+            y = self.equalizer.process_normalized(x, eq_params)             # fused de-normalise + design; no gradient for x: the no-gx kernel
+            y = DynamicsCtlFunction.apply(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
+            if y.shape[1] == 1:   # if mono copy to stereo (functional.py:493-495)
+                y = y.repeat(1, 2, 1)
+            return _functional._reverb_from_matrices(y, self.sample_rate, gains, decays, mix, **self.reverb._rev_kwargs)
         self.gain._check_range(gain_params)
         self.compressor._check_range(comp_params)
         lo, span = self.gain._affine(gain_params)

@@ -130,6 +130,46 @@ dist_sample_kernel(const float* __restrict__ x, const float* __restrict__ drive_
     }
 }
 
+// Controls of the reference's effect chain (examples/style_transfer.py:150-154: EQ -> compressor -> reverb -> gain) from the normalised
+// parameter tensors of Processor.process_normalized (modules.py:25-51) in one launch per direction: de-normalisation lo + span * p of the
+// compressor's (B, 6), the reverb's (B, 25) and the gain's (B, 1) parameters, written in the layouts the kernels take - ctl (B, 5)
+// [threshold, ratio, attack, knee, make-up + gain] (the chain's final gain folded into the make-up gain; release_ms is unused,
+// functional.py:340), band gains (B, 12), band decays (B, 12), mix (B) - and the adjoint map back to the three parameter tensors.
+// As separate torch ops this is ~30 launches of 3-4 us per training step.
+struct ChainAffine { float lo[32], span[32]; };        // [0, 6) compressor, [6, 31) reverb, [31] gain
+
+__global__ void chain_controls_kernel(const float* __restrict__ pc, const float* __restrict__ pr, const float* __restrict__ pg, ChainAffine a,
+                                      float* __restrict__ ctl, float* __restrict__ gains, float* __restrict__ decays, float* __restrict__ mix, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = t / 30, j = t % 30;
+    if (b >= B) return;
+    if (j < 5) {
+        const int c = j < 3 ? j : j + 1;
+        float v = fmaf(a.span[c], pc[b * 6 + c], a.lo[c]);
+        if (j == 4) v += fmaf(a.span[31], pg[b], a.lo[31]);
+        ctl[b * 5 + j] = v;
+    } else {
+        const int c = j - 5;                              // reverb column 0 .. 24
+        const float v = fmaf(a.span[6 + c], pr[b * 25 + c], a.lo[6 + c]);
+        if (c < 12) gains[b * 12 + c] = v; else if (c < 24) decays[b * 12 + c - 12] = v; else mix[b] = v;
+    }
+}
+__global__ void chain_controls_backward_kernel(const float* __restrict__ gctl, const float* __restrict__ ggain, const float* __restrict__ gdecay,
+                                               const float* __restrict__ gmix, ChainAffine a, float* __restrict__ gpc, float* __restrict__ gpr,
+                                               float* __restrict__ gpg, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = t / 32, j = t % 32;
+    if (b >= B) return;
+    if (j < 6) {
+        const int k = j < 3 ? j : j - 1;                  // row of ctl; column 3 (release_ms) has no path to the output
+        gpc[b * 6 + j] = j == 3 ? 0.f : gctl[b * 5 + k] * a.span[j];
+    } else if (j < 31) {
+        const int c = j - 6;
+        const float g = c < 12 ? ggain[b * 12 + c] : (c < 24 ? gdecay[b * 12 + c - 12] : gmix[b]);
+        gpr[b * 25 + c] = g * a.span[j];
+    } else {
+        gpg[b] = gctl[b * 5 + 4] * a.span[31];
+    }
+}
+
 }  // namespace dasp
 
 // ================================================================================================
@@ -201,6 +241,24 @@ int dasp_distortion_sample_backward(const float* x, const float* drive_db, const
     const long threads = vec ? n / 4 : n, blocks = (threads + EW_THREADS - 1) / EW_THREADS;
     if (blocks > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dist_sample_kernel<true>, dim3((unsigned)blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, x, drive_db, gy, gx, gdrive, n, vec);
+    return ew_check();
+}
+int dasp_chain_controls(const float* comp_pn, const float* reverb_pn, const float* gain_pn, const float* lo, const float* span, float* ctl,
+                        float* gains, float* decays, float* mix, int B, void* stream) {
+    if (!comp_pn || !reverb_pn || !gain_pn || !lo || !span || !ctl || !gains || !decays || !mix || B <= 0) return DASP_ERR_ARG;
+    ChainAffine a;
+    for (int i = 0; i < 32; ++i) { a.lo[i] = lo[i]; a.span[i] = span[i]; }
+    hipLaunchKernelGGL(chain_controls_kernel, dim3((B * 30 + 255) / 256), dim3(256), 0, (hipStream_t)stream, comp_pn, reverb_pn, gain_pn, a, ctl, gains,
+                       decays, mix, B);
+    return ew_check();
+}
+int dasp_chain_controls_backward(const float* gctl, const float* ggain, const float* gdecay, const float* gmix, const float* span,
+                                 float* gcomp_pn, float* greverb_pn, float* ggain_pn, int B, void* stream) {
+    if (!gctl || !ggain || !gdecay || !gmix || !span || !gcomp_pn || !greverb_pn || !ggain_pn || B <= 0) return DASP_ERR_ARG;
+    ChainAffine a;
+    for (int i = 0; i < 32; ++i) { a.lo[i] = 0.f; a.span[i] = span[i]; }
+    hipLaunchKernelGGL(chain_controls_backward_kernel, dim3((B * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, gctl, ggain, gdecay, gmix, a,
+                       gcomp_pn, greverb_pn, ggain_pn, B);
     return ew_check();
 }
 }  // extern "C"

@@ -536,6 +536,76 @@ class DynamicsMatrixFunction(torch.autograd.Function):
         return gx.to(xd) if ctx.needs_input_grad[0] else None, None, None, None, None, g6
 
 
+class DynamicsCtlFunction(torch.autograd.Function):
+    """The dynamics kernels on the (bs, 5) fp32 control rows they read, [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db], with the
+    gradient returned in the same layout (the chain's fused control op, ChainControlsFunction, produces and consumes it)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, sample_rate, eps, lookahead, ctl):
+        _lib.require_device(x, "x")
+        _lib.require_same_device(x, ctl=ctl)
+        ctx.xdtype = x.dtype
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            need = any(ctx.needs_input_grad)
+            y, saved, cfg = _dyn_forward(x, mode, sample_rate, eps, lookahead, _f32c(ctl), need)
+            if need:
+                ctx.save_for_backward(*saved)
+                ctx.cfg = cfg
+        return y.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        if ctx.empty:
+            return torch.empty_like(gy), None, None, None, None, torch.zeros(gy.shape[0], 5, dtype=torch.float32, device=gy.device)
+        with torch.cuda.device(gy.device):
+            gx, gctl = _dyn_backward(ctx.saved_tensors, ctx.cfg, gy)
+        return gx.to(ctx.xdtype) if ctx.needs_input_grad[0] else None, None, None, None, None, gctl
+
+
+class ChainControlsFunction(torch.autograd.Function):
+    """De-normalisation of the compressor's (bs, 6), the reverb's (bs, 25) and the gain's (bs, 1) normalised parameters of the reference's
+    effect chain in one launch (dasp_chain_controls), in the layouts the kernels read: ctl (bs, 5) with the chain's final gain folded into
+    the make-up gain, band gains (bs, 12), band decays (bs, 12), mix (bs); backward: one launch back to the three parameter tensors.
+    lo, span: ctypes float[32] (compressor 0-5, reverb 6-30, gain 31)."""
+
+    @staticmethod
+    def forward(ctx, comp_pn, reverb_pn, gain_pn, lo, span):
+        _lib.require_device(comp_pn, "comp_params")
+        _lib.require_same_device(comp_pn, reverb_params=reverb_pn, gain_params=gain_pn)
+        B = comp_pn.shape[0]
+        dev = comp_pn.device
+        ctx.span, ctx.B = span, B
+        ctx.dtypes = (comp_pn.dtype, reverb_pn.dtype, gain_pn.dtype)
+        with torch.cuda.device(dev):
+            buf = torch.empty(B, 30, dtype=torch.float32, device=dev)          # one allocation: ctl | gains | decays | mix
+            flat = buf.view(-1)
+            ctl, gains, decays, mix = flat[:5 * B].view(B, 5), flat[5 * B:17 * B].view(B, 12), flat[17 * B:29 * B].view(B, 12), flat[29 * B:]
+            if B:
+                call("dasp_chain_controls", ptr(_f32c(comp_pn)), ptr(_f32c(reverb_pn)), ptr(_f32c(gain_pn)), lo, span, ptr(ctl), ptr(gains),
+                     ptr(decays), ptr(mix), B, stream())
+        return ctl, gains, decays, mix
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gctl, ggain, gdecay, gmix):
+        B = ctx.B
+        dev = next(g for g in (gctl, ggain, gdecay, gmix) if g is not None).device
+        with torch.cuda.device(dev):
+            z = lambda g, *shape: _f32c(g) if g is not None else torch.zeros(*shape, dtype=torch.float32, device=dev)
+            gc = torch.empty(B, 6, dtype=torch.float32, device=dev)
+            gr = torch.empty(B, 25, dtype=torch.float32, device=dev)
+            gg = torch.empty(B, 1, dtype=torch.float32, device=dev)
+            if B:
+                call("dasp_chain_controls_backward", ptr(z(gctl, B, 5)), ptr(z(ggain, B, 12)), ptr(z(gdecay, B, 12)), ptr(z(gmix, B)), ctx.span,
+                     ptr(gc), ptr(gr), ptr(gg), B, stream())
+        cd, rd, gd = ctx.dtypes
+        return gc.to(cd), gr.to(rd), gg.to(gd), None, None
+
+
 def _cbuf(n, device):
     """n complex64 elements as a float32 buffer (the C ABI takes void*)."""
     return torch.empty(2 * n, dtype=torch.float32, device=device)

@@ -166,6 +166,17 @@ int dasp_distortion_backward(const float* x, const float* drive_db, const float*
 int dasp_distortion_sample_forward(const float* x, const float* drive_db, float* y, long n, void* stream);
 int dasp_distortion_sample_backward(const float* x, const float* drive_db, const float* gy, float* gx, float* gdrive, long n, void* stream);
 
+/* Controls of the reference's effect chain (examples/style_transfer.py:150-154: equalizer -> compressor -> reverb -> gain, each through
+ * Processor.process_normalized, dasp_pytorch/modules.py:25-51) from the normalised parameter tensors in one launch: comp_pn (B, 6),
+ * reverb_pn (B, 25), gain_pn (B, 1) in [0, 1]; lo, span: HOST arrays of 32 floats, [0, 6) the compressor's ranges in the order of its
+ * param_ranges (modules.py:159-187), [6, 31) the reverb's, [31] the gain's. Out: ctl (B, 5) as dasp_dynamics_forward takes it, with the
+ * gain added to the make-up gain (a per-item gain commutes with the linear reverb); gains, decays (B, 12), mix (B) as
+ * dasp_reverb_forward takes them. The backward call maps the gradients of those four back to the three parameter tensors. */
+int dasp_chain_controls(const float* comp_pn, const float* reverb_pn, const float* gain_pn, const float* lo, const float* span, float* ctl,
+                        float* gains, float* decays, float* mix, int B, void* stream);
+int dasp_chain_controls_backward(const float* gctl, const float* ggain, const float* gdecay, const float* gmix, const float* span,
+                                 float* gcomp_pn, float* greverb_pn, float* ggain_pn, int B, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dynamics: compressor / expander.  mode 0 replaces dasp_pytorch.functional.compressor
  * (dasp_pytorch/functional.py:275-399: side-chain sum :328, level in dB :347, soft-knee gain

@@ -177,6 +177,36 @@ def test_style_transfer_chain_folds_the_gain(D):
         assert float((a - b).abs().max()) < 2e-3 * max(float(b.abs().max()), 1e-12)
 
 
+def test_chain_controls_in_one_launch_equal_the_torch_ops(D, monkeypatch):
+    """The chain de-normalises the compressor's, the reverb's and the gain's parameters and folds the gain in one launch per direction
+    (dasp_chain_controls / ops.ChainControlsFunction); with DASP_CHAIN_FUSED_CONTROLS=0 the same is done by torch ops on the tensors.
+    Mono input (the reference's training shape), outputs and all 50 parameter gradients; the release_ms column gets an exact zero."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    B, N = 4, 20000
+    x = torch.rand(B, 1, N, device="cuda:0", generator=g) * 2 - 1
+    chain = StyleTransferChain(SR, num_samples=4096)
+    ps = [torch.rand(B, n, device="cuda:0", generator=g).clamp(0.02, 0.98) for n in chain.num_params]
+    w = torch.randn(B, 2, N, device="cuda:0", generator=g)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DASP_CHAIN_FUSED_CONTROLS", flag)
+        pp = [p.clone().requires_grad_(True) for p in ps]
+        torch.manual_seed(13)
+        y = chain.process_normalized(x, *pp)
+        (y * w).sum().backward()
+        outs.append((y.detach(), [p.grad for p in pp]))
+    (y1, gp1), (y0, gp0) = outs
+    assert float((y1 - y0).abs().max()) <= 1e-6 * float(y0.abs().max())
+    for a, b in zip(gp1, gp0):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12)
+    assert float(gp1[1][:, 3].abs().max()) == 0.0
+    bad = [p.clone() for p in ps]
+    bad[2][1, 7] = 1.5
+    with pytest.raises(ValueError, match="band7_gain"):
+        chain.process_normalized(x, *bad)
+
+
 def test_hip_graph_capture_replays_the_eager_step(D):
     """The ops are plain stream launches, so a training step through them can be captured into a HIP graph (torch.cuda.CUDAGraph)
     and replayed on new data: EQ -> compressor -> gain on normalised controls plus the multi-resolution STFT loss, forward and
