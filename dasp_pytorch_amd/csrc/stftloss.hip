@@ -453,13 +453,13 @@ int dasp_mrstft_forward(const float* pred, const float* target, const void* tw, 
     for (int r = 0; r < nres; ++r) {
         const int TC = FFT_N >> s.r[r].logF;
         const dim3 grid((unsigned)((s.r[r].frames + TC - 1) / TC), (unsigned)rows);
-#define SL_FWD(LG) hipLaunchKernelGGL(mrstft_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, partials, s, N, r)
-        switch (s.r[r].logF) {
-#define SL_FWDS(RR) hipLaunchKernelGGL(mrstft_fwd_split_kernel<RR>, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, partials, s, N, r)
-            case 9: SL_FWDS(1); break; case 10: SL_FWDS(2); break; case 11: SL_FWDS(4); break; default: SL_FWD(0);
-#undef SL_FWDS
+        hipStream_t st = (hipStream_t)stream;
+        switch (s.r[r].logF) {          // 512 / 1024 / 2048-point frames: 1 / 2 / 4 waves per frame; any other power of two: col_fft
+            case 9: hipLaunchKernelGGL(mrstft_fwd_split_kernel<1>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, partials, s, N, r); break;
+            case 10: hipLaunchKernelGGL(mrstft_fwd_split_kernel<2>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, partials, s, N, r); break;
+            case 11: hipLaunchKernelGGL(mrstft_fwd_split_kernel<4>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, partials, s, N, r); break;
+            default: hipLaunchKernelGGL(mrstft_fwd_kernel, grid, dim3(512), 0, st, pred, target, (const f2*)tw, partials, s, N, r);
         }
-#undef SL_FWD
     }
     hipLaunchKernelGGL(mrstft_reduce_kernel, dim3((unsigned)(nres * 3)), dim3(1024), 0, (hipStream_t)stream, (const float*)partials, s, rows, stats);
     hipLaunchKernelGGL(mrstft_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s, rows, stats, loss);
@@ -476,13 +476,13 @@ int dasp_mrstft_backward(const float* pred, const float* target, const void* tw,
     for (int r = 0; r < nres; ++r) {
         const int TC = FFT_N >> s.r[r].logF;
         const dim3 grid((unsigned)((s.r[r].frames + TC - 1) / TC), (unsigned)rows);
-#define SL_BWD(LG) hipLaunchKernelGGL(mrstft_bwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r)
+        hipStream_t st = (hipStream_t)stream;
         switch (s.r[r].logF) {
-#define SL_BWDS(RR) hipLaunchKernelGGL(mrstft_bwd_split_kernel<RR>, grid, dim3(512), 0, (hipStream_t)stream, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r)
-            case 9: SL_BWDS(1); break; case 10: SL_BWDS(2); break; case 11: SL_BWDS(4); break; default: SL_BWD(0);
-#undef SL_BWDS
+            case 9: hipLaunchKernelGGL(mrstft_bwd_split_kernel<1>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r); break;
+            case 10: hipLaunchKernelGGL(mrstft_bwd_split_kernel<2>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r); break;
+            case 11: hipLaunchKernelGGL(mrstft_bwd_split_kernel<4>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r); break;
+            default: hipLaunchKernelGGL(mrstft_bwd_kernel, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r);
         }
-#undef SL_BWD
     }
     return sl_check();
 }
