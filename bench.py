@@ -13,7 +13,10 @@ data-path collective (the effect has no cross-item exchange).
   --scaling weak   (default) every rank processes its own (256, 2, 131072) batch; `value` = N * units / max-over-ranks time
   --scaling strong the one 256-item batch is partitioned 256/N items per GPU; `value` = units / max-over-ranks time
   --launch graph   the step (forward + backward, same kernels, same launches) is captured once into a HIP graph and replayed K times;
-                   eager (default) issues it from Python every step. Both are reported when --launch both.
+                   eager issues it from Python every step. --launch both (default) times K steps each way: `launch_ms_per_step` has both,
+                   `value` / `ms_per_step` are the faster one and `config.launch` names it (the step is 0.40 ms of kernels behind ~0.3 ms of
+                   host work per eager step, so a slow or loaded host makes the eager figure a host measurement: seen 0.405 -> 0.452 ms
+                   between two runs on one box while the replayed graph stayed at 0.405).
 
 The JSON line also carries
   roofline     -- HBM roofline of the dominant kernel (the backward cascade): algorithmic bytes per
@@ -265,9 +268,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch items per GPU; strong: --batch items in total, partitioned over the GPUs (SURVEY 8e)")
-    ap.add_argument("--launch", choices=("eager", "graph", "both"), default="eager",
-                    help="how the step is issued: from Python every step (default), as a replayed HIP graph of the same launches, or both "
-                         "(value = the better; measured r02: eager 0.4107 ms, graph 0.4145 ms - the step is GPU-bound either way)")
+    ap.add_argument("--launch", choices=("eager", "graph", "both"), default="both",
+                    help="how the step is issued: from Python every step, as a replayed HIP graph of the same launches, or both (default; "
+                         "K timed steps each, value = the faster, config.launch names it, launch_ms_per_step has both)")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed clock ramp before the warmup steps: the MI355X needs ~0.2 s of sustained load to leave its idle "
                          "clocks (measured: the same kernels run 1.28x slower in the first 10 ms)")
