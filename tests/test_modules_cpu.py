@@ -61,3 +61,57 @@ def test_process_normalized_routes_by_keyword_without_gpu(monkeypatch):
     comp.process_normalized(torch.zeros(4, 2, 16), p)
     assert seen["sample_rate"] == SR and list(seen)[:6] == list(comp.param_ranges)
     assert torch.allclose(seen["ratio"], p[:, 1] * 19 + 1) and torch.allclose(seen["threshold_db"], p[:, 0] * 60 - 60)
+
+
+def test_range_check_is_one_reduction_and_can_be_delegated():
+    """modules.check_unit_range: the reference's message and parameter name (modules.py:83-84), NaN passes as it does there, empty tensors
+    pass; inside modules.already_validated() a processor's own check is a no-op (the chain checks all its parameters at once)."""
+    from dasp_pytorch_amd import modules as M
+    names = ["a", "b", "c"]
+    M.check_unit_range(torch.tensor([[0.0, 1.0, 0.5]]), names)
+    M.check_unit_range(torch.tensor([[0.5, float("nan"), 0.5]]), names)
+    M.check_unit_range(torch.zeros(0, 3), names)
+    with pytest.raises(ValueError, match="Parameter c of is out of range."):
+        M.check_unit_range(torch.tensor([[0.5, 0.5, 0.5], [0.5, 0.5, -1e-3]]), names)
+    with pytest.raises(ValueError, match="Parameter b of is out of range."):
+        M.check_unit_range(torch.tensor([[0.5, 1.0001, 2.0]]), names)          # the first offending column is the one named
+    g = D.Gain(SR)
+    with M.already_validated():
+        g._check_range(torch.tensor([[2.0]]))
+        with M.already_validated():
+            pass
+        g._check_range(torch.tensor([[2.0]]))                                  # still inside the outer block
+    with pytest.raises(ValueError, match="gain_db"):
+        g._check_range(torch.tensor([[2.0]]))
+    g.validate_range = False
+    g._check_range(torch.tensor([[2.0]]))
+
+
+def test_stacked_columns_hand_out_contiguous_gradient_rows():
+    """functional._StackColumns: torch.stack(cols, 1) whose backward gives each column a contiguous row (autograd then keeps it as .grad
+    without a copy); columns that need no gradient get None."""
+    from dasp_pytorch_amd.functional import _StackColumns
+    cols = [torch.rand(5, 1, dtype=torch.double, requires_grad=(i != 1)) for i in range(3)]
+    m = _StackColumns.apply(*cols)
+    assert m.shape == (5, 3) and torch.equal(m, torch.stack([c.reshape(-1) for c in cols], 1))
+    w = torch.rand(5, 3, dtype=torch.double)
+    (m * w).sum().backward()
+    assert cols[1].grad is None
+    for i in (0, 2):
+        assert cols[i].grad.shape == (5, 1) and cols[i].grad.is_contiguous() and torch.equal(cols[i].grad.reshape(-1), w[:, i])
+    torch.autograd.gradcheck(lambda *c: _StackColumns.apply(*c), [torch.rand(4, dtype=torch.double, requires_grad=True) for _ in range(3)])
+
+
+def test_chain_control_tables_follow_the_processors():
+    """chain.StyleTransferChain._tables: lo / span of compressor (6), reverb (25), gain (1) in the order dasp_chain_controls reads them,
+    rebuilt when a range is edited (the reference reads param_ranges on every call)."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    ch = StyleTransferChain(SR)
+    lo, span = ch._tables()
+    assert len(lo) == 32 and len(span) == 32
+    assert [lo[i] for i in range(6)] == [-60.0, 1.0, 5.0, 5.0, 0.0, 0.0] and [span[i] for i in range(6)] == [60.0, 19.0, 95.0, 95.0, 12.0, 12.0]
+    assert all(lo[6 + i] == 0.0 and span[6 + i] == 1.0 for i in range(25)) and (lo[31], span[31]) == (-24.0, 48.0)
+    assert ch._tables()[0] is lo                                               # cached
+    ch.gain.param_ranges["gain_db"] = (-12.0, 12.0)
+    lo2, span2 = ch._tables()
+    assert (lo2[31], span2[31]) == (-12.0, 24.0)
