@@ -141,6 +141,34 @@ def test_section_counts(D, S):
     assert st.grad.shape == st.shape and torch.isfinite(st.grad).all() and torch.isfinite(xt.grad).all()
 
 
+@pytest.mark.parametrize("S", [7, 8])
+def test_seven_and_eight_sections_on_a_full_grid(D, S):
+    """From 128 rows on, 7 / 8 sections run as two calls of 4 (signal.sosfilt_via_fsm: the 8-section backward kernel holds one wave per
+    SIMD): outputs against the recursion oracle, gradients against the one-call path on a 127-row slice-free rerun of the same rows."""
+    from oracle.recursion import sosfilt_ref, sosfilt_vjp_ref
+    g = np.random.default_rng(40 + S)
+    B, C, N = 64, 2, 3000
+    r = 0.2 + 0.7 * g.random((B, S)); th = 3.0 * g.random((B, S)) + 0.05
+    sos = np.zeros((B, S, 6))
+    sos[..., :3] = g.standard_normal((B, S, 3)) * 0.7
+    sos[..., 3] = 1.0; sos[..., 4] = -2 * r * np.cos(th); sos[..., 5] = r * r
+    sos = sos.astype(np.float32)
+    x = (g.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = g.standard_normal((B, C, N)).astype(np.float32)
+    xt = dev(x).requires_grad_(True); st = dev(sos).requires_grad_(True)
+    y = D.signal.sosfilt_via_fsm(st, xt)                       # 128 rows: 4 + 4 (4 + 3)
+    (y * dev(w)).sum().backward()
+    yo = sosfilt_ref(sos.astype(np.float64), x)
+    gxo = sosfilt_vjp_ref(sos.astype(np.float64), w)
+    assert linf_peak(y.detach().cpu().numpy(), yo).max() < 5e-5
+    assert linf_peak(xt.grad.cpu().numpy(), gxo).max() < 5e-5
+    sel = slice(0, 20)                                          # the same items as 40 rows: one call of 8 sections
+    x2 = dev(x[sel]).requires_grad_(True); s2 = dev(sos[sel]).requires_grad_(True)
+    (D.signal.sosfilt_via_fsm(s2, x2) * dev(w[sel])).sum().backward()
+    a, b = st.grad[sel].cpu().numpy(), s2.grad.cpu().numpy()
+    assert np.abs(a - b).max() < 2e-4 * np.abs(b).max()
+
+
 def test_sos_gradcheck_against_finite_differences(D):
     """d/dsos from the kernels vs central differences of the fp64 recursion oracle."""
     from oracle.recursion import sosfilt_ref
