@@ -12,20 +12,30 @@ is already resident in HBM. Batches shard along the batch axis, one process per 
 data-path collective (the effect has no cross-item exchange).
   --scaling weak   (default) every rank processes its own (256, 2, 131072) batch; `value` = N * units / max-over-ranks time
   --scaling strong the one 256-item batch is partitioned 256/N items per GPU; `value` = units / max-over-ranks time
-  --launch graph   the step (forward + backward, same kernels, same launches) is captured once into a HIP graph and replayed K times;
-                   eager issues it from Python every step. --launch both (default) times K steps each way: `launch_ms_per_step` has both,
+  --launch graph   the step (forward + backward, same kernels, same launches) is captured once into a HIP graph and replayed;
+                   eager issues it from Python every step. --launch both (default) times both: `launch_ms_per_step` has both,
                    `value` / `ms_per_step` are the faster one and `config.launch` names it (the step is 0.40 ms of kernels behind ~0.3 ms of
-                   host work per eager step, so a slow or loaded host makes the eager figure a host measurement: seen 0.405 -> 0.452 ms
-                   between two runs on one box while the replayed graph stayed at 0.405).
+                   host work per eager step, so a slow or loaded host makes the eager figure a host measurement).
+  --gpus N         N ranks. Under torchrun (WORLD_SIZE set) the world size must equal N; without it and N > 1, bench.py re-launches
+                   itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`. `n_gpus` = ranks that joined the
+                   process group.
+
+Timing. Each launch mode is measured on the product path as a user calls it (one C call per direction, no timers, no events): an
+untimed clock ramp issued in that mode (--ramp-seconds), W warm-up steps, then --blocks blocks of EXACTLY K steps, each bracketed by
+barrier + device synchronize on both sides, max over ranks; `value` / `ms_per_step` are the median block (`block_ms_per_step` has
+min / median / max). A 20-step block is 8 ms, shorter than the 0.2 s the shader clock needs to ramp and of the same order as a host
+hiccup: the ramp precedes every mode and the median keeps a single disturbed block out of `value`.
 
 The JSON line also carries
-  roofline     -- HBM roofline of the dominant kernel (the backward cascade): algorithmic bytes per
-                  launch / average launch duration measured with HIP events on the launch stream inside the timed region
-                  (eager steps: every 4th launch of each entry point); `traffic` = HBM bytes per launch from the PMC counters,
-                  read from profiles/<round>/hbm_traffic.json only if that file was produced from the kernel sources now loaded
+  roofline     -- HBM roofline of the dominant kernel (the backward cascade): algorithmic bytes per launch / average launch duration,
+                  measured live with HIP events on the launch stream in a separate, untimed pass directly behind the timed blocks (the
+                  events need the kernels as separate entry points, which is not how the product issues them, so they stay out of the
+                  timed region); `traffic` = HBM bytes per launch from the PMC counters, read from profiles/<round>/hbm_traffic.json
+                  only if that file was produced from the kernel sources now loaded
   roofline_*   -- the same for the forward kernel and for forward+backward together
-  cpu_baseline -- the reference itself (oracle/_ref, staged by __graft_entry__.build(); kind "reference") on all host cores on a
-                  bounded sub-batch, or, when it is not staged, the numpy restatement (oracle/dasp_oracle.py, kind "port").
+  cpu_baseline -- the reference itself (oracle/_ref, staged by __graft_entry__.build(); kind "reference") on the host cores on a
+                  bounded sub-batch (its best-case batch size), or, when it is not staged, the numpy restatement
+                  (oracle/dasp_oracle.py, kind "port").
 
 --dry-run-cpu is a test hook (tests/test_distributed_cpu.py): rank wiring, sharding, barriers, timing reduction and the JSON contract
 on CPU tensors over gloo with the kernels replaced by a copy; its numbers mean nothing and the line says so.
@@ -261,35 +271,60 @@ def load_traffic(shape):
     return {}, None
 
 
+def _respawn_under_torchrun(n):
+    """`python bench.py --gpus N` outside a torchrun environment: re-launch this command line as N ranks on this node, one per GPU
+    (the launch line the driver uses for N > 1), so that --gpus N cannot silently be a one-rank run."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a torchrun environment: launching %s" % (n, " ".join(cmd)), file=sys.stderr)
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of exactly --steps steps each (every block bracketed by barrier + device sync, max over ranks); "
+                         "`value` / `ms_per_step` are the median block, `block_ms_per_step` has min / median / max per launch mode")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch items per GPU; strong: --batch items in total, partitioned over the GPUs (SURVEY 8e)")
     ap.add_argument("--launch", choices=("eager", "graph", "both"), default="both",
                     help="how the step is issued: from Python every step, as a replayed HIP graph of the same launches, or both (default; "
-                         "K timed steps each, value = the faster, config.launch names it, launch_ms_per_step has both)")
+                         "value = the faster, config.launch names it, launch_ms_per_step has both)")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
-                    help="untimed clock ramp before the warmup steps: the MI355X needs ~0.2 s of sustained load to leave its idle "
-                         "clocks (measured: the same kernels run 1.28x slower in the first 10 ms)")
+                    help="untimed clock ramp before each launch mode's warmup steps, issued in that mode: the MI355X needs ~0.2 s of "
+                         "sustained load to leave its idle clocks (measured: the same kernels run 1.28x slower in the first 10 ms)")
     ap.add_argument("--batch", type=int, default=256, help="batch items per GPU (weak) / in total (strong)")
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other hot-path ops")
-    ap.add_argument("--no-kernel-events", action="store_true", help="developer switch: do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-kernel-events", action="store_true", help="developer switch: skip the per-kernel HIP-event pass (roofline is then NaN)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="test hook: rank wiring on CPU tensors over gloo, kernels replaced by a copy")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _respawn_under_torchrun(args.gpus)
     rank, local, world = dd.env_world()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a "
+                         f"{args.gpus}-GPU number from {world} process(es)")
     dry = args.dry_run_cpu
     if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in dasp_pytorch_amd)")
     if dry:
         dev = torch.device("cpu")
     else:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but this node shows {torch.cuda.device_count()} device(s)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     dist = None
@@ -297,6 +332,7 @@ def main():
         import torch.distributed as dist
         dd.init("gloo" if dry else "nccl", None if dry else dev)
     sync = (lambda: None) if dry else torch.cuda.synchronize
+    joined = dist.get_world_size() if dist is not None else 1      # ranks that actually joined the process group (RCCL / gloo)
 
     C, N = args.channels, args.samples
     if args.scaling == "strong":      # the one global batch, contiguous shards (distributed.shard_bounds)
@@ -334,22 +370,25 @@ def main():
         fence()
         return dd.max_over_ranks(time.perf_counter() - t0, dev)
 
-    # device clock ramp (untimed, before the W warmup steps; reported as "ramp_s")
-    t_ramp = time.perf_counter()
-    while not dry and time.perf_counter() - t_ramp < args.ramp_seconds:
-        for _ in range(10):
-            step()
-        sync()
-    for _ in range(args.warmup):
-        step()
-    ktimes = {}
-    results = {}
+    def ramp(fn, seconds):
+        """Untimed sustained load issued the way the timed steps will be (the queue is drained every 25 steps so that it stays short)."""
+        t0 = time.perf_counter()
+        while not dry and time.perf_counter() - t0 < seconds:
+            for _ in range(25):
+                fn()
+            sync()
+
+    def measure(fn):
+        """Ramp, W warm-up steps, then --blocks blocks of exactly K steps; the product path only: no timers, no events, no extra calls."""
+        ramp(fn, args.ramp_seconds)
+        for _ in range(args.warmup):
+            fn()
+        return [timed(fn, args.steps) for _ in range(max(1, args.blocks))]
+
+    assert not _lib.timers.enabled
+    blocks = {}
     if args.launch in ("eager", "both") or dry:
-        if not args.no_kernel_events and not dry:
-            _lib.timers.start(every=4)   # HIP events around every 4th launch of each entry point, inside the timed region
-        results["eager"] = timed(step, args.steps)
-        if not args.no_kernel_events and not dry:
-            ktimes = _lib.timers.stop()
+        blocks["eager"] = measure(step)
     if args.launch in ("graph", "both") and not dry:
         # the same step captured once (torch.cuda.graph: forward + backward on the capture stream, gradients land in static buffers)
         # and replayed: no Python, ctypes or autograd time per step, launch gaps are the graph's
@@ -361,23 +400,25 @@ def main():
         with torch.cuda.graph(graph):
             y = peq(x, SR, *cols)
             y.backward(w)
-        for _ in range(args.warmup):
-            graph.replay()
-        if not ktimes and not args.no_kernel_events:     # per-kernel durations need eager launches: a short untimed pass
-            _lib.timers.start(every=1)
-            for _ in range(20):
-                step()
-            ktimes = _lib.timers.stop()
-            for _ in range(5):
-                graph.replay()
-        results["graph"] = timed(graph.replay, args.steps)
+        blocks["graph"] = measure(graph.replay)
+    ktimes = {}
+    if not args.no_kernel_events and not dry:
+        # per-kernel durations: a separate, untimed pass right behind the timed blocks (warm clocks) with HIP events on the launch stream
+        # around every C entry point. With the timers on, the ops issue design / cascade / adjoint / finalize as separate entry points
+        # (the same kernels the one-call product path launches), so that each kernel gets its own pair of events.
+        ramp(step, 0.25)
+        _lib.timers.start(every=1)
+        for _ in range(max(20, min(args.steps, 100))):
+            step()
+        ktimes = _lib.timers.stop()
     finite = bool(torch.isfinite(x.grad).all().item()) and all(bool(torch.isfinite(c.grad).all().item()) for c in cols)
 
     if rank == 0:
         units = B * C * N                       # channel-samples per step on this GPU
         total_units = global_batch * C * N      # ... over the whole job (weak: N x units; strong: the one batch)
-        mode = min(results, key=results.get)
-        dt = results[mode]
+        med = {k: float(np.median(v)) for k, v in blocks.items()}
+        mode = min(med, key=med.get)
+        dt = med[mode]
         ms = dt / args.steps * 1e3
         value = total_units / (dt / args.steps)
         nan = float("nan")
@@ -391,15 +432,19 @@ def main():
             return {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get(which)}
 
+        per_step = lambda v: round(v / args.steps * 1e3, 5)
         out = {
             "metric": "audio-samples/sec fwd+bwd, 6-band parametric_eq @ (256,2,131072)",
-            "value": value, "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "channel-samples/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "ramp_s": args.ramp_seconds,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"parametric_eq fwd+bwd (grad x + 18 controls) on ({B},{C},{N}) fp32 per GPU, sr 44100, "
                                    "controls ~ U(ParametricEQ ranges)", "global_batch": global_batch,
-                       "parallelism": f"batch-shard x{world}, no collective", "launch": mode},
-            "launch_ms_per_step": {k: round(v / args.steps * 1e3, 5) for k, v in results.items()},
+                       "parallelism": f"batch-shard x{world}, no collective", "launch": mode, "world_size": joined,
+                       "timing": f"median of {len(blocks[mode])} blocks of {args.steps} steps, product path (no timers / events in the timed region)"},
+            "launch_ms_per_step": {k: per_step(v) for k, v in med.items()},
+            "block_ms_per_step": {k: {"min": per_step(min(v)), "median": per_step(float(np.median(v))), "max": per_step(max(v))}
+                                  for k, v in blocks.items()},
             "roofline": dict(roof(12, t_bwd, "bwd"), kernel="sos_bwd_kernel<6> (designed-cascade variant)", ms=round(t_bwd * 1e3, 4),
                              algorithmic_bytes=12 * units),
             "roofline_fwd": dict(roof(8, t_fwd, "fwd"), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),

@@ -239,6 +239,11 @@ def noise_shaped_reverberation(
     bs, chs, seq_len = x.size()
     assert chs <= 2, "only mono/stereo signals are supported"
     require_fp32_ok(x, "noise_shaped_reverberation")
+    for c in (band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain, band8_gain, band9_gain,
+              band10_gain, band11_gain, band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
+              band7_decay, band8_decay, band9_decay, band10_decay, band11_decay, mix):
+        if c.numel() != bs:   # the reference's torch.stack(...).view(bs, 12) / mix.view(bs, 1, 1) (functional.py:498-544): no broadcasting
+            raise RuntimeError(f"shape '[{bs}, 12]' is invalid for input of size {12 * c.numel()}")
     if chs == 1:   # if mono copy to stereo (autograd sums the two channel gradients)
         x = x.repeat(1, 2, 1)
     band_gains = _StackColumns.apply(band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,

@@ -198,10 +198,10 @@ class ParametricEQ(Processor):
         from .ops import ParametricEQNormFunction
         lo = [float(r[0]) for r in self.param_ranges.values()]
         span = [float(r[1]) - float(r[0]) for r in self.param_ranges.values()]
-        # the check runs before the kernels are queued (one small reduction + read-back): the op's own in-kernel check (names != None) would
+        # the check runs before the kernels are queued (one small reduction + read-back): the C entry point's in-kernel flag word would
         # make the host wait for the forward kernel it has just launched
         self._check_range(param_tensor)
-        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, None)
+        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span)
 
 
 class _Dynamics(Processor):

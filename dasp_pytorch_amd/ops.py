@@ -160,13 +160,12 @@ class BiquadFunction(torch.autograd.Function):
         ctx.meta = [(t.dtype, t.shape) for t in (gain_db, cutoff_freq, q_factor)]
         dev = gain_db.device
         ba = torch.empty(n, 6, dtype=torch.float64, device=dev)
-        if n == 0:
-            return ba
-        with torch.cuda.device(dev):
-            g, f, q = (t.detach().reshape(-1).to(torch.float64).contiguous() for t in (gain_db, cutoff_freq, q_factor))
-            jac = torch.empty(n, 15, dtype=torch.float64, device=dev)
-            call("dasp_biquad_design", ptr(g), ptr(f), ptr(q), n, int(ftype), float(sample_rate), ptr(ba), ptr(jac), stream())
-        ctx.save_for_backward(jac)
+        jac = torch.empty(n, 15, dtype=torch.float64, device=dev)
+        if n:
+            with torch.cuda.device(dev):
+                g, f, q = (t.detach().reshape(-1).to(torch.float64).contiguous() for t in (gain_db, cutoff_freq, q_factor))
+                call("dasp_biquad_design", ptr(g), ptr(f), ptr(q), n, int(ftype), float(sample_rate), ptr(ba), ptr(jac), stream())
+        ctx.save_for_backward(jac)        # also for n == 0: the backward pass then returns empty gradients of the recorded shapes
         return ba
 
     @staticmethod
@@ -174,11 +173,11 @@ class BiquadFunction(torch.autograd.Function):
     def backward(ctx, gba):
         (jac,) = ctx.saved_tensors
         n = jac.shape[0]
-        gp = torch.zeros(max(n, 1), 3, dtype=torch.float64, device=gba.device)
+        gp = torch.zeros(n, 3, dtype=torch.float64, device=gba.device)
         if n:
             with torch.cuda.device(jac.device):
                 call("dasp_biquad_backward", ptr(jac), ptr(gba.to(torch.float64).contiguous()), n, ptr(gp), stream())
-        cols = gp[:n].unbind(1)
+        cols = gp.unbind(1)
         return tuple(c.reshape(shape).to(dt) for c, (dt, shape) in zip(cols, ctx.meta)) + (None, None)
 
 
@@ -245,29 +244,16 @@ class ParametricEQFunction(torch.autograd.Function):
         return (gx.to(ctx.x_dtype) if need_gx else None, None, None) + gcols
 
 
-_RANGE_FLAGS = {}
-
-
-def _range_flag(dev):
-    """One zeroed device word per (device, stream) for the in-kernel [0, 1] check of normalised parameters (dasp_peq_forward_norm)."""
-    key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
-    t = _RANGE_FLAGS.get(key)
-    if t is None:
-        if len(_RANGE_FLAGS) >= 32:
-            _RANGE_FLAGS.clear()
-        t = _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
-    return t
-
-
 class ParametricEQNormFunction(torch.autograd.Function):
     """Processor.process_normalized for the EQ as one op (reference: dasp_pytorch/modules.py:25-91 + functional.py:118-272):
     the normalised (Bp, 3 S) tensor goes straight into the design kernel, which de-normalises it (lo + span * p in fp64), checks [0, 1] and
     builds the tables; the backward pass returns the gradient w.r.t. the normalised tensor. One tensor input instead of 3 S, no
-    de-normalisation / slicing / stacking ops around the kernels, and the range check costs one word read back (none inside a HIP-graph
-    capture) instead of a reduction."""
+    de-normalisation / slicing / stacking ops around the kernels. The [0, 1] check of the reference (modules.py:83) is the caller's
+    (modules.check_unit_range, before anything is queued); the C entry point's own in-kernel flag word (dasp_hip.h) is not used from
+    Python: reading it back would make the host wait for the forward kernel it has just queued."""
 
     @staticmethod
-    def forward(ctx, x, pn, sample_rate, types, lo, span, names):
+    def forward(ctx, x, pn, sample_rate, types, lo, span):
         _lib.require_device(x, "x")
         _lib.require_same_device(x, param_tensor=pn)
         S = len(types)
@@ -284,17 +270,9 @@ class ParametricEQNormFunction(torch.autograd.Function):
             need = any(ctx.needs_input_grad)
             w = _SosWork(Bp, S, x32, need)
             y = torch.empty_like(x32)
-            # names = None: the caller switched the validation off; a capture cannot read the flag back (modules._check_range)
-            check_range = names is not None and not torch.cuda.is_current_stream_capturing()
-            flag = _range_flag(dev) if check_range else None
             call("dasp_peq_forward_norm", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
-                 (ctypes.c_double * (3 * S))(*span), ptr(flag), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y), ptr(w.carries), B, C, N, w.tseg,
+                 (ctypes.c_double * (3 * S))(*span), ptr(None), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y), ptr(w.carries), B, C, N, w.tseg,
                  ptr(w.segtab), ptr(w.segbuf), stream())
-            if check_range:
-                bits = int(flag.item())              # the one host sync of the call (the reference: two per parameter, modules.py:83)
-                if bits:
-                    flag.zero_()
-                    raise ValueError(f"Parameter {names[(bits & -bits).bit_length() - 1]} of is out of range.")
             if need:
                 ctx.work = w
                 ctx.save_for_backward(x32)
@@ -305,12 +283,12 @@ class ParametricEQNormFunction(torch.autograd.Function):
     def backward(ctx, gy):
         xd, pd, pshape = ctx.meta
         if ctx.empty:
-            return torch.empty_like(gy), torch.zeros(pshape, dtype=pd, device=gy.device), None, None, None, None, None
+            return torch.empty_like(gy), torch.zeros(pshape, dtype=pd, device=gy.device), None, None, None, None
         (x32,) = ctx.saved_tensors
         need_gx, need_gp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         with torch.cuda.device(x32.device):
             gx, gp = ctx.work.backward(x32, _f32c(gy), 1, 1, need_gx, need_gp)       # mode 1: (Bp, S, 3) = the layout of the (Bp, 3 S) tensor
-        return (gx.to(xd) if need_gx else None, gp.reshape(pshape).to(pd) if need_gp else None, None, None, None, None, None)
+        return (gx.to(xd) if need_gx else None, gp.reshape(pshape).to(pd) if need_gp else None, None, None, None, None)
 
 
 class _ElementwiseFunction(torch.autograd.Function):
@@ -412,6 +390,15 @@ class DistortionSampleFunction(torch.autograd.Function):
         return gx.to(xd), gd.reshape(dshape).to(dd)
 
 
+def _require_rows(x, t, ncols, name):
+    """The dynamics kernels read `ncols` controls per batch item of x at t[b * ncols ...]: anything but a (bs, ncols) matrix would be read
+    past its end. Same error as functional._dynamics (the reference's .view(-1, 1, 1) against a (bs, 1, seq_len) side chain does not
+    broadcast a parameter batch of 1 either, functional.py:330-336)."""
+    if t.dim() != 2 or t.shape[0] != x.shape[0] or t.shape[1] != ncols:
+        raise RuntimeError(f"The size of tensor a ({t.shape[0] if t.dim() else 1}) must match the size of tensor b ({x.shape[0]}) at "
+                           f"non-singleton dimension 0 ({name} must be ({x.shape[0]}, {ncols}), got {tuple(t.shape)})")
+
+
 def _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need):
     """The compressor / expander kernels on ctl (B, 5) fp32 rows [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db]; returns y (fp32)
     and what the backward pass needs."""
@@ -507,6 +494,7 @@ class DynamicsMatrixFunction(torch.autograd.Function):
     def forward(ctx, x, mode, sample_rate, eps, lookahead, controls):
         _lib.require_device(x, "x")
         _lib.require_same_device(x, controls=controls)
+        _require_rows(x, controls, 6, "controls")
         ctx.meta = (x.dtype, controls.dtype, controls.shape)
         ctx.empty = x.numel() == 0
         if ctx.empty:
@@ -544,6 +532,7 @@ class DynamicsCtlFunction(torch.autograd.Function):
     def forward(ctx, x, mode, sample_rate, eps, lookahead, ctl):
         _lib.require_device(x, "x")
         _lib.require_same_device(x, ctl=ctl)
+        _require_rows(x, ctl, 5, "ctl")
         ctx.xdtype = x.dtype
         ctx.empty = x.numel() == 0
         if ctx.empty:
@@ -745,7 +734,14 @@ class ReverbFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             sizes = (ctypes.c_long * 14)()
             check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
+            if tuple(gains.shape) != (B, nb) or tuple(decays.shape) != (B, nb) or mix.numel() != B:
+                # the kernels index gains[b * nb + band]: a (k, nb) stack with k != bs must not be reshaped into (bs, ...) silently
+                # (the reference's torch.stack(...).view(bs, 12) raises for it, functional.py:498-544)
+                raise RuntimeError(f"shape '[{B}, {nb}]' is invalid for band gains / decays of shapes {tuple(gains.shape)} / "
+                                   f"{tuple(decays.shape)} and mix with {mix.numel()} values")
             x32, n32 = _f32c(x), _f32c(noise)
+            if n32.numel() != 2 * B * nb * (L_ir + taps - 1):
+                raise RuntimeError(f"noise must hold (2 * {B}, {nb}, {L_ir + taps - 1}) values, got {tuple(noise.shape)}")
             g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
             y = torch.empty_like(x32)

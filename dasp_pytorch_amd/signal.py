@@ -47,8 +47,10 @@ def lfilter_via_fsm(x: torch.Tensor, b: torch.Tensor, a: torch.Tensor = None):
     if b.dim() != 2 or b.shape[0] not in (1, bs) or (a is not None and a.shape != b.shape):
         raise RuntimeError(f"lfilter_via_fsm: b (and a) must have shape ({bs}, K); got {tuple(b.shape)}" + (f", {tuple(a.shape)}" if a is not None else ""))
     if K > 3:
-        raise NotImplementedError(f"lfilter_via_fsm: K = {K} coefficients; orders above 2 are not supported (use sosfilt_via_fsm with "
-                                  "second-order sections)")
+        raise NotImplementedError(f"lfilter_via_fsm: K = {K} coefficients; this package evaluates recurrences of order <= 2 per section. "
+                                  "Factor the filter into second-order sections, e.g. sos = scipy.signal.tf2sos(b, a) per batch item, "
+                                  "stack them as (bs, n_sections, 6) and call dasp_pytorch_amd.signal.sosfilt_via_fsm(sos, x) "
+                                  "(differentiable w.r.t. the sections; any number of sections)")
     b = b.type_as(x)
     if a is None:
         a = torch.zeros_like(b)

@@ -113,3 +113,26 @@ def test_bench_rank_wiring_under_torchrun(scaling):
     assert out["config"]["global_batch"] == (12 if scaling == "weak" else 6)
     assert f"({per_gpu},2,2048)" in out["config"]["workload"]
     assert abs(out["value"] - out["config"]["global_batch"] * 2 * 2048 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_means_ranks():
+    """`python bench.py --gpus 2` without a torchrun environment starts two ranks itself (n_gpus = ranks that joined the process group);
+    a launcher whose world size disagrees with --gpus is refused instead of reported as an N-GPU number."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "2", "--dry-run-cpu",
+           "--batch", "4", "--samples", "1024"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["global_batch"] == 8
+    assert set(out["block_ms_per_step"]["eager"]) == {"min", "median", "max"}
+    # world size 2 from the launcher, --gpus 1 on the command line: refuse
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu"],
+                         capture_output=True, text=True, timeout=120,
+                         env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

@@ -9,12 +9,14 @@ import pytest
 import torch
 
 from oracle import dasp_oracle as orc
-from tests.util import linf_peak, load_golden
+from tests.util import linf_peak, load_golden, record
 
 pytestmark = pytest.mark.gpu
 SR = 44100
 KEYS = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
 RANGES = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]       # modules.py:179-186, knee kept > 0
+CTL_TOL = 2e-4           # control gradients vs the reference's fp64 run on the goldens (column maximum)
+CTL_TOL_SHAPES = 5e-4    # ... vs the oracle on random shapes
 
 
 @pytest.fixture(scope="module")
@@ -56,9 +58,11 @@ def test_compressor_golden(D, name):
     y, gx, gp = run(D.compressor, g["x"], g["params"], g["w"], int(g["lookahead"]))
     ey, egx = linf_peak(y, g["y64"]), linf_peak(gx, g["gx64"])
     assert ey.max() < 2e-5 and egx.max() < 2e-5, (ey, egx)
+    eg = [np.abs(gp[:, j] - g["gp64"][:, j]).max() / max(np.abs(g["gp64"][:, j]).max(), 1e-30) for j in range(6)]
+    record(f"compressor_golden[{name}]", y=ey.max(), gx=egx.max(), gctl=eg)
     for j in range(6):
         ref = g["gp64"][:, j]
-        assert np.abs(gp[:, j] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), (KEYS[j], gp[:, j], ref)
+        assert np.abs(gp[:, j] - ref).max() <= CTL_TOL * max(np.abs(ref).max(), 1e-30), (KEYS[j], gp[:, j], ref)
     assert np.all(gp[:, 3] == 0)                                  # release_ms has no path to the output
     assert linf_peak(y, g["y32"]).max() < 1e-4                    # literal north_star bar vs the reference's fp32 output
     assert np.all(ey <= linf_peak(g["y32"], g["y64"]) + 5e-6)     # not worse than the reference's own fp32 noise
@@ -80,8 +84,10 @@ def test_compressor_shapes_vs_oracle(D, B, C, N, look):
         assert linf_peak(y, yo).max() < 2e-5
         assert linf_peak(gx, gxo).max() < 5e-5
         gpo = np.stack([gco[k] for k in KEYS], 1)
+        record(f"compressor_shapes[{B},{C},{N},{look}]", y=linf_peak(y, yo).max(), gx=linf_peak(gx, gxo).max(),
+               gctl=[np.abs(gp[:, j] - gpo[:, j]).max() / max(np.abs(gpo[:, j]).max(), 1e-30) for j in range(6)])
         for j in range(6):
-            assert np.abs(gp[:, j] - gpo[:, j]).max() <= 5e-4 * max(np.abs(gpo[:, j]).max(), 1e-30), (KEYS[j], gp[:, j], gpo[:, j])
+            assert np.abs(gp[:, j] - gpo[:, j]).max() <= CTL_TOL_SHAPES * max(np.abs(gpo[:, j]).max(), 1e-30), (KEYS[j], gp[:, j], gpo[:, j])
     else:           # short signals: exact recursion (one_pole) is the ground truth
         from oracle.recursion import one_pole_ref
         c = orc._compressor_core(x, SR, pd[:, 0], pd[:, 1], pd[:, 2], pd[:, 4], pd[:, 5], 1e-8, look, np.float64)
@@ -175,6 +181,21 @@ def test_config3_full_size_properties(D, monkeypatch):
     for c in cols: c.grad = None
     y2 = D.compressor(xt, SR, *cols); y2.backward(2 * w)
     assert torch.allclose(xt.grad, 2 * gx1, rtol=1e-6, atol=0) and all(torch.allclose(c.grad, 2 * g, rtol=1e-5, atol=1e-12) for c, g in zip(cols, g1))
+    # eight sampled items of the full-size launch against the oracle (items are independent, so a sample of the launch tests the launch):
+    # y, grad x and the five control gradients, as the EQ's full-size test does
+    idx = [0, 1, 37, 100, 101, 128, 200, 255]
+    xs, ws, ps = x[idx].cpu().numpy(), w[idx].cpu().numpy(), p[idx].astype(np.float64)
+    yo = orc.compressor(xs, SR, *[ps[:, i] for i in range(6)])
+    gxo, gco = orc.compressor_vjp(xs, SR, *[ps[:, i] for i in range(6)], ws)
+    ey, egx = linf_peak(y.detach()[idx].cpu().numpy(), yo), linf_peak(gx1[idx].cpu().numpy(), gxo)
+    gpo = np.stack([gco[k] for k in KEYS], 1)
+    gp = torch.stack([g[idx] for g in g1], 1).cpu().numpy()
+    eg = [np.abs(gp[:, j] - gpo[:, j]).max() / max(np.abs(gpo[:, j]).max(), 1e-30) for j in range(6)]
+    record("compressor_config3_full_size_sampled_items", y=ey.max(), gx=egx.max(), gctl=eg)
+    assert ey.max() < 2e-5 and egx.max() < 5e-5, (ey, egx)
+    for j in range(6):
+        assert eg[j] <= CTL_TOL_SHAPES, (KEYS[j], eg[j])
+    assert np.all(gp[:, 3] == 0)
 
 
 @pytest.mark.parametrize("B,C,N,look,tiles,mode", [(2, 2, 40000, 0, None, "compressor"), (3, 1, 65536, 0, 32, "compressor"), (1, 2, 262144, 0, None, "compressor"),

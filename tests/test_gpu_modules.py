@@ -32,7 +32,7 @@ def test_process_normalized_matches_functional(D):
     with pytest.raises(ValueError, match="band2_gain_db"):
         bad = p.detach().clone(); bad[0, 9] = -0.1
         eq.process_normalized(x, bad)
-    assert torch.isfinite(eq.process_normalized(x, p.detach())).all()      # the in-kernel range flag was reset by the failed call
+    assert torch.isfinite(eq.process_normalized(x, p.detach())).all()      # a refused call leaves no state behind
     eq.validate_range = False                                              # opt-out: no read-back, out-of-range values are simply used
     assert torch.isfinite(eq.process_normalized(x, bad)).all()
     eq.validate_range = True
@@ -205,6 +205,39 @@ def test_chain_controls_in_one_launch_equal_the_torch_ops(D, monkeypatch):
     bad[2][1, 7] = 1.5
     with pytest.raises(ValueError, match="band7_gain"):
         chain.process_normalized(x, *bad)
+
+
+def test_parameter_rows_that_do_not_match_the_batch_are_refused(D):
+    """Only the EQ broadcasts a parameter batch of 1 over the batch (functional.py:208-220); compressor, gain and
+    reverb raise RuntimeError in the reference. The kernels read controls at ctl[b * n ...], so a (1, P) tensor with bs > 1 must never
+    reach them - neither through the chain (fused and torch-op control paths), nor through the matrix ops, nor as mis-sized reverb columns."""
+    from dasp_pytorch_amd import ops
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    B, N = 3, 9000
+    x = torch.rand(B, 2, N, device="cuda:0") * 2 - 1
+    chain = StyleTransferChain(SR, num_samples=2048)
+    full = [torch.rand(B, n, device="cuda:0").clamp(0.05, 0.95) for n in chain.num_params]
+    assert torch.isfinite(chain.process_normalized(x, full[0][:1], *full[1:])).all()           # the EQ's broadcast is legal
+    for k in (1, 2, 3):
+        ps = [p.clone() for p in full]
+        ps[k] = ps[k][:1]
+        with pytest.raises(RuntimeError):
+            chain.process_normalized(x, *ps)
+    with pytest.raises(RuntimeError):
+        ops.DynamicsMatrixFunction.apply(x, 0, float(SR), 1e-8, 0, torch.rand(1, 6, device="cuda:0"))
+    with pytest.raises(RuntimeError):
+        ops.DynamicsCtlFunction.apply(x, 0, float(SR), 1e-8, 0, torch.rand(1, 5, device="cuda:0"))
+    with pytest.raises(RuntimeError):
+        ops.DynamicsMatrixFunction.apply(x, 0, float(SR), 1e-8, 0, torch.rand(B, 5, device="cuda:0"))
+    # reverb columns with k != bs values each, 12 k divisible by bs (the reference's .view(bs, 12) raises)
+    cols = [torch.rand(2 * B, device="cuda:0") for _ in range(24)]
+    with pytest.raises(RuntimeError):
+        D.noise_shaped_reverberation(x, SR, *cols, torch.rand(B, device="cuda:0"), num_samples=512, num_bandpass_taps=31)
+    # signal.biquad on zero filters: empty design, empty gradients of the recorded shapes
+    e = torch.zeros(0, 1, 1, device="cuda:0", requires_grad=True)
+    b, a = D.signal.biquad(e, e.detach().clone().requires_grad_(True), e.detach().clone().requires_grad_(True), SR, "peaking")
+    (b.sum() + a.sum()).backward()
+    assert e.grad is not None and e.grad.shape == e.shape
 
 
 def test_hip_graph_capture_replays_the_eager_step(D):

@@ -7,10 +7,11 @@ import torch
 
 from oracle import dasp_oracle as orc
 from tests.test_oracle_cpu import _reverb_noise
-from tests.util import linf_peak, load_golden
+from tests.util import linf_peak, load_golden, record
 
 pytestmark = pytest.mark.gpu
 SR = 44100
+CTL_TOL = 2e-4      # the 25 control gradients on random shapes, of the largest entry (goldens: 1e-4)
 
 
 @pytest.fixture(scope="module")
@@ -39,6 +40,7 @@ def test_reverb_golden(D, name):
     noise = _reverb_noise(g)
     y, gx, gp = run(D, g["x"], g["params"], g["w"], noise, int(g["L"]), int(g["taps"]))
     assert y.shape == g["y64"].shape and gx.shape == g["gx64"].shape          # mono in -> stereo out, grad_x mono
+    record(f"reverb_golden[{name}]", y=linf_peak(y, g["y64"]).max(), gx=linf_peak(gx, g["gx64"]).max(), gctl=linf_peak(gp, g["gp64"]).max())
     assert linf_peak(y, g["y64"]).max() < 2e-5
     assert linf_peak(gx, g["gx64"]).max() < 2e-5
     assert linf_peak(gp, g["gp64"]).max() < 1e-4
@@ -77,7 +79,38 @@ def test_reverb_shapes_vs_oracle(D, B, C, N, L, taps):
     assert np.abs(y - yo).max() < 3e-5 * max(np.abs(yo).max(), 1e-6)
     assert np.abs(gx - gxo).max() < 3e-5 * max(np.abs(gxo).max(), 1e-6)
     gpo = np.concatenate([gg, gd, gm[:, None]], 1)
-    assert np.abs(gp - gpo).max() < 2e-4 * np.abs(gpo).max()
+    record(f"reverb_shapes[{B},{C},{N},{L},{taps}]", y=np.abs(y - yo).max() / max(np.abs(yo).max(), 1e-6), gx=np.abs(gx - gxo).max() / max(np.abs(gxo).max(), 1e-6),
+           gctl=np.abs(gp - gpo).max() / np.abs(gpo).max())
+    assert np.abs(gp - gpo).max() < CTL_TOL * np.abs(gpo).max()
+
+
+def test_config4_full_size_sampled_items(D):
+    """BASELINE config 4, noise_shaped_reverberation at (128, 2, 262144) with the default 65536-tap impulse responses and 1023-tap filter
+    bank: the launch whose scratch sizes, XCD tile map and band-split planner depend on the batch size. Three sampled items (first, middle,
+    last) of the full launch against the oracle on the same noise: y, grad x and the 25 control gradients (items are independent)."""
+    B, C, N, L, taps = 128, 2, 262144, 65536, 1023
+    gen = torch.Generator(device="cuda:0").manual_seed(44)
+    x = torch.rand(B, C, N, device="cuda:0", generator=gen) * 2 - 1
+    w = torch.randn(B, 2, N, device="cuda:0", generator=gen)
+    p = torch.rand(B, 25, device="cuda:0", generator=gen)
+    noise = torch.randn(2 * B, 12, L + taps - 1, device="cuda:0", generator=gen)
+    xt = x.clone().requires_grad_(True)
+    cols = [p[:, i].clone().requires_grad_(True) for i in range(25)]
+    y = D.noise_shaped_reverberation(xt, SR, *cols, num_samples=L, num_bandpass_taps=taps, noise=noise)
+    y.backward(w)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(xt.grad).all() and all(torch.isfinite(c.grad).all() for c in cols)
+    gp = torch.stack([c.grad for c in cols], 1)
+    idx = [0, 77, 127]
+    nidx = [2 * i + k for i in idx for k in (0, 1)]
+    xs, ws, ps, ns = x[idx].cpu().numpy(), w[idx].cpu().numpy(), p[idx].cpu().numpy().astype(np.float64), noise[nidx].cpu().numpy()
+    yo = orc.noise_shaped_reverberation(xs, SR, ps[:, :12], ps[:, 12:24], ps[:, 24], ns, L, taps)
+    gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(xs, SR, ps[:, :12], ps[:, 12:24], ps[:, 24], ns, ws, L, taps)
+    gpo = np.concatenate([gg, gd, gm[:, None]], 1)
+    ey, egx = linf_peak(y.detach()[idx].cpu().numpy(), yo), linf_peak(xt.grad[idx].cpu().numpy(), gxo)
+    eg = linf_peak(gp[idx].cpu().numpy(), gpo)
+    record("reverb_config4_full_size_sampled_items", y=ey.max(), gx=egx.max(), gctl=eg.max())
+    assert ey.max() < 3e-5 and egx.max() < 3e-5 and eg.max() < CTL_TOL, (ey, egx, eg)
 
 
 def test_reverb_unsupported_sizes_raise(D):
