@@ -38,6 +38,11 @@ SIGNATURES = {
     "dasp_peq_forward": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
     "dasp_peq_forward_norm": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _p,
                                    _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
+    "dasp_peq_prepare_norm": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _p, _p, _p, _p]),
+    "dasp_sos_segment_starts": (_i, [_p, _p, _i, _p, _p, _i, _i, _l, _i, _l, _p]),
+    "dasp_chain_segment_tiles": (_l, [_l, _l]),
+    "dasp_chain_seg_floats": (_l, [_l, _l, _l, _i, _l]),
+    "dasp_chain_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _d, ctypes.c_float, _l, _p, _p, _p]),
     "dasp_peq_backward": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _l, _p, _p, _p]),
     "dasp_sosfilt_backward_seg_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _i, _p]),
     "dasp_biquad_design": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p]),

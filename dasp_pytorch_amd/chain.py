@@ -56,6 +56,12 @@ class StyleTransferChain:
     def _run(self, x, eq_params, comp_params, reverb_params, gain_params):
         m = _modules
         every = (comp_params, reverb_params, gain_params)
+        # only the EQ broadcasts a parameter batch of 1 (functional.py:208-220); compressor, reverb and gain raise in the reference
+        # (their .view(bs, ...) / side-chain broadcast), and the kernels read one row of controls per batch item
+        for name, t in (("compressor", comp_params), ("reverb", reverb_params), ("gain", gain_params)):
+            if t.dim() != 2 or t.shape[0] != x.shape[0]:
+                raise RuntimeError(f"The size of tensor a ({t.shape[0] if t.dim() else 1}) must match the size of tensor b ({x.shape[0]}) at "
+                                   f"non-singleton dimension 0 ({name} parameters: one row per batch item, got {tuple(t.shape)})")
         fused = (os.environ.get("DASP_CHAIN_FUSED_CONTROLS", "1") != "0"        # developer A/B: the torch-op de-normalisation below
                  and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and x.shape[1] <= 2
                  and all(t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.shape[0] == x.shape[0] for t in every)
@@ -71,8 +77,21 @@ class StyleTransferChain:
             self.reverb._check_range(reverb_params)
             lo, span = self._tables()
             ctl, gains, decays, mix = ChainControlsFunction.apply(comp_params, reverb_params, gain_params, lo, span)
-            y = self.equalizer.process_normalized(x, eq_params)             # fused de-normalise + design; no gradient for x: the no-gx kernel
-            y = DynamicsCtlFunction.apply(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
+            eq = self.equalizer
+            no_grad = not (torch.is_grad_enabled() and (x.requires_grad or eq_params.requires_grad or ctl.requires_grad))
+            if (no_grad and os.environ.get("DASP_CHAIN_FUSED_FORWARD", "1") != "0" and eq.process_fn is _functional.parametric_eq
+                    and list(eq.param_ranges) == m._EQ_NAMES and eq_params.dim() == 2 and eq_params.shape[1] == 18
+                    and eq_params.shape[0] in (1, x.shape[0]) and eq_params.is_cuda and eq_params.is_floating_point()):
+                # forward only (the reference's target synthesis, examples/style_transfer.py:293-299): EQ and compressor as ONE pass over x
+                # (csrc/chainfwd.hip) - the EQ's output never goes to memory
+                from .ops import chain_eq_compressor_forward
+                eq._check_range(eq_params)
+                elo = [float(r[0]) for r in eq.param_ranges.values()]
+                espan = [float(r[1]) - float(r[0]) for r in eq.param_ranges.values()]
+                y = chain_eq_compressor_forward(x, eq_params, _functional._PEQ_TYPES, elo, espan, float(self.sample_rate), ctl)
+            else:
+                y = eq.process_normalized(x, eq_params)                     # fused de-normalise + design; no gradient for x: the no-gx kernel
+                y = DynamicsCtlFunction.apply(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
             if y.shape[1] == 1:   # if mono copy to stereo (functional.py:493-495)
                 y = y.repeat(1, 2, 1)
             return _functional._reverb_from_matrices(y, self.sample_rate, gains, decays, mix, **self.reverb._rev_kwargs)

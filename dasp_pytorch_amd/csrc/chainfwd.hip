@@ -1,0 +1,299 @@
+// Fused forward of the first two stages of the reference's effect chain: parametric EQ -> compressor (+ the chain's final gain,
+// which the caller folds into the make-up gain), for gfx950.
+//
+// The reference runs `equalizer -> compressor -> reverb -> gain` with gradients for the prediction (examples/style_transfer.py:150-154)
+// and, every training step, the same chain once more without gradients to synthesise the target (examples/style_transfer.py:293-299).
+// Unfused, the EQ writes its output y1 (4 B per channel-sample) and the compressor reads it back twice (side chain, output stage):
+// 16 B per channel-sample for the two forwards. Here one workgroup owns a batch item - both channels, because the compressor's side
+// chain is their sum (functional.py:328) - and a tile of the EQ's output never leaves the chip: per 1024-sample tile a wave runs the
+// cascade of channel 0, then of channel 1 (sos_tile.hpp: LDS-DMA tile image, chunk products on the matrix cores, lane scan, carries
+// from wave to wave through LDS mailboxes), forms the side chain in registers, runs the gain computer (dyn_common.hpp), the one-pole
+// smoothing as a per-lane recursion + lane scan in the EQ's chunk layout (16 consecutive samples per lane: factor alpha^16 between lanes,
+// alpha^1024 between tiles, a third mailbox chain), multiplies both channels and stores: 8 B per channel-sample, no saved states
+// (forward only: the chunk states and tile carries the backward kernels need are not written).
+// Few batch items: every item is cut into segments of Tseg tiles that run as independent workgroups, as in sosfilt.hip / dynamics.hip;
+// the compressor's segment start state depends on the EQ's output, so the order is: EQ scan-only pre-pass + chain (sosfilt.hip,
+// dasp_sos_segment_starts), this kernel with the compressor scan-only (SEG 2: EQ from its segment start state, nothing stored), the
+// scalar chain of the smoothing state, this kernel again from both start states (SEG 1).
+#include "sos_tile.hpp"
+#include "dyn_common.hpp"
+
+extern "C" long dasp_sos_num_tiles(long N);
+extern "C" long dasp_sos_segments(long N, long Tseg);
+extern "C" long dasp_sos_seg_floats(long rows, long N, int S, long Tseg);
+extern "C" int dasp_sos_segment_starts(const float* tab, const double* segtab, int Bs, const float* x, float* segbuf, int B, int C, long N, int S,
+                                       long Tseg, void* stream);
+
+namespace dasp {
+
+// alpha^(16 m) for a per-lane m < 128, fp64 repeated squaring
+__device__ __forceinline__ float alpha_pow16(double alpha, int m) {
+    double p = 1.0, s = alpha;
+    s = s * s; s = s * s; s = s * s; s = s * s;   // alpha^16
+    for (int bit = 0; bit < 7; ++bit) {
+        if (m & (1 << bit)) p *= s;
+        s *= s;
+    }
+    return (float)p;
+}
+
+// MODE: 0 compressor, 1 expander (dyn_common.hpp). SEG: 0 = one workgroup per item; 1 = one workgroup per (item, segment), EQ from
+// segstart_eq[row][segment][2S], smoothing state from segstart_dyn[item][segment]; 2 = the same EQ pass with the compressor scan-only:
+// nothing stored, the zero-state end of the segment's smoothing state goes to zseg_dyn[item][segment].
+template <int S, int L, int W, int MODE, int SEG>
+__global__ void __launch_bounds__(64 * W, (W + 3) / 4)   // one workgroup of W = 16 waves per CU: four waves per SIMD, <= 128 registers
+chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y,
+                 int C, int N, int nt, int vec, double sample_rate, float eps, int G, int Tseg, const float* __restrict__ segstart_eq,
+                 const float* __restrict__ segstart_dyn, float* __restrict__ zseg_dyn) {
+    using LY = SosLayout<S, L>;
+    static_assert(L == 16, "chunk layout of the smoothing scan");
+    constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L, CH = 2;
+    constexpr int LDS_MB = W * CH * S * 4, LDS_MD = W * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 8, LDS_T = W * 2 * IMG;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MB + LDS_MD + LDS_PW + LDS_CF + LDS_T];
+    const int lane = lane_id(), wave = wave_id();
+    const int b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt;
+    const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : b) * LY::TOTAL;
+    const float* __restrict__ xb = x + (size_t)b * C * N;
+    float* __restrict__ yb = y + (size_t)b * C * N;
+    float* md_lds = lds + LDS_MB;
+    float* pw_lds = md_lds + LDS_MD;
+    float* cf_lds = pw_lds + LDS_PW;
+    float* tbx = cf_lds + LDS_CF + wave * 2 * IMG;     // x image of the current pass, then (LDS-DMA) of the next one
+    float* tby = tbx + IMG;                             // scratch of the chunk products, then the y image on its way out
+    // EQ mailboxes [wave][channel][section]{v0, v1, seq, -}: zero, except that wave 0's inboxes hold what its first tile waits for
+    for (int i = threadIdx.x; i < LDS_MB + LDS_MD; i += 64 * W) {
+        float v = 0.f;
+        if (SEG && i < CH * S * 4) {
+            const int c = i / (S * 4), k = (i >> 2) % S, comp = i & 3;
+            if (comp == 2) v = __builtin_bit_cast(float, t0);
+            else if (comp < 2 && c < C) v = segstart_eq[(((size_t)b * C + c) * G + seg) * S2 + 2 * k + comp];
+        }
+        lds[i] = v;
+    }
+    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PW + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    __syncthreads();
+    const f4* pws = reinterpret_cast<const f4*>(pw_lds);
+
+    // per-item constants of the compressor; the powers of alpha the chunk layout needs, in fp64 once per thread
+    const DynItem it = load_item(ctl, b, sample_rate, eps);
+    double a_d;
+    {
+        const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
+        a_d = exp(-2.1972245773362196 / nat);
+    }
+    const float q16 = alpha_pow16(a_d, 1), q32 = alpha_pow16(a_d, 2), q64 = alpha_pow16(a_d, 4), q128 = alpha_pow16(a_d, 8), q1024 = alpha_pow16(a_d, 64);
+    const float dpw16 = alpha_pow16(a_d, (lane & 15) + 1), dpw32 = alpha_pow16(a_d, (lane & 31) + 1), dpws = alpha_pow16(a_d, lane);
+    float Kdyn = SEG == 1 ? segstart_dyn[(size_t)b * G + seg] : 0.f;
+
+    const int mb_in = wave * CH * S * 4, mb_out = ((wave + 1) % W) * CH * S * 4;
+    const int md_in = wave * 4, md_out = ((wave + 1) % W) * 4;
+    const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx));
+    if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xb + (size_t)(t0 + wave) * TS, a_x, lane);
+    int stores_in_flight = 0;
+    float Aop[4];
+    chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
+
+    for (int t = t0 + wave; t < t1; t += W) {
+        int toff = 0;
+        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
+        const float* __restrict__ tbl = tb + toff;
+        const bool full = tile_full<L>((long)t * TS, N, vec);
+        float Y[CH][L];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c >= C) {
+#pragma unroll
+                for (int n = 0; n < L; ++n) Y[c][n] = 0.f;
+                continue;
+            }
+            const float* __restrict__ xr = xb + (size_t)c * N;
+            float X[L];
+            WIDE_PRIO(DASP_SCAN_PRIO);
+            // the image of this pass was requested one pass ago; vmcnt is in order: the previous tile's y stores were issued before the
+            // request of channel 0's image and may stay in flight, the request of channel 1's image came after them
+            if (full) wait_vmcnt(c == 0 ? stores_in_flight : 0);
+            else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
+            lds_to_chunks_swz<L>(tbx, X, lane);
+            f4 Bop[4], zacc[4];
+            chunk_products_load(tbx, Bop, lane);
+            pin(X); pin(Bop);
+            {   // next pass: the other channel of this tile, or channel 0 of this wave's next tile
+                const int tn = c + 1 < C ? t : t + W, cn = c + 1 < C ? c + 1 : 0;
+                if (tn < t1 && tile_full<L>((long)tn * TS, N, vec)) tile_dma_issue_swz(xb + (size_t)cn * N + (size_t)tn * TS, a_x, lane);
+            }
+            float Z[L];
+            chunk_products_issue(Bop, Aop, zacc);
+            chunk_products_collect<L>(tby, zacc, Z, lane, lane);
+            pin(Z);
+            f2 st[S];
+            MboxPeek pk;
+            SCAN_PRIO(DASP_SCAN_PRIO);
+            tile_scan<S, L>(Z, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+                [&](int k) { pk = mbox_peek(lds, mb_in + (c * S + k) * 4); },
+                [&](int k, f2& K) {
+                    if (pk.seq == t) K = f2{pk.a, pk.b};   // tile 0 finds the zero-initialised inbox: sequence 0, carry 0
+                    else { float a, bb; mbox_wait(lds, mb_in + (c * S + k) * 4, t, a, bb); K = f2{a, bb}; }
+                },
+                [&](int k, f2 Kn) { if (t + 1 < t1) mbox_publish<63>(lds, mb_out + (c * S + k) * 4, Kn.x, Kn.y, t + 1); });
+            SCAN_PRIO(0);
+            // the cascade, one section at a time in place over the chunk (sos_fwd_kernel; normal form, coefficients in VGPRs)
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int oz = opaque_zero_after(X[0]);
+                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
+                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+                float s1 = st[k].x, s2 = st[k].y;
+                const float nk = -ca.z;
+#pragma unroll
+                for (int n = 0; n < L; ++n) {
+                    const float u = X[n];
+                    X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                    const float t1_ = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                    s2 = fmaf(ca.y, s1, ca.x * s2);
+                    s1 = t1_;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < L; ++n) Y[c][n] = X[n];
+            pin(Y[c]);
+        }
+        // ---- compressor on the tile while it is in registers (functional.py:325-399) ----
+        WIDE_PRIO(DASP_SCAN_PRIO);
+        float gc[L];
+        float e = 0.f;
+#pragma unroll
+        for (int n = 0; n < L; ++n) {
+            float d0, d1, d2, d3;
+            const float s = Y[0][n] + Y[1][n];                                             // side chain: sum over channels (:328)
+            const float x_db = DB_PER_LOG2 * log2f(fmaxf(fabsf(s), it.eps));               // :347
+            gc[n] = it.beta * gain_computer<MODE, false>(x_db, it, d0, d1, d2, d3);        // (1 - alpha) g_c[n]
+            e = fmaf(it.alpha, e, gc[n]);                                                  // zero-state end of the chunk
+        }
+        // inclusive scan over the 64 chunks: E_i = e_i + alpha^16 E_{i-1}
+        e = fmaf(q16, dpp0<0x111, 0xf>(e), e);
+        e = fmaf(q32, dpp0<0x112, 0xf>(e), e);
+        e = fmaf(q64, dpp0<0x114, 0xf>(e), e);
+        e = fmaf(q128, dpp0<0x118, 0xf>(e), e);
+        e = fmaf(dpw16, dpp0<0x142, 0xa>(e), e);
+        e = fmaf(dpw32, dpp0<0x143, 0xc>(e), e);
+        float K;
+        if (t == t0) K = Kdyn;                   // (only wave 0 sees t == t0: the state the item / segment starts from)
+        else { float dummy; mbox_wait(lds, LDS_MB + md_in, t, K, dummy); }
+        {
+            const float Kn = fmaf(q1024, K, read_lane(e, 63));       // the only work on the cross-wave chain of the smoothing state
+            if (t + 1 < t1) mbox_publish(lds, LDS_MB + md_out, Kn, 0.f, t + 1);
+            else if (SEG == 2 && lane == 0) zseg_dyn[(size_t)b * G + seg] = Kn;
+        }
+        if (SEG == 2) { WIDE_PRIO(0); continue; }
+        float g = fmaf(dpws, K, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x138, 0xf, 0xf, true)));
+#pragma unroll
+        for (int n = 0; n < L; ++n) {
+            g = fmaf(it.alpha, g, gc[n]);                                                  // :372-380 as a recursion
+            const float lin = exp2f((g + it.makeup) * LOG2_PER_DB);                        // :388-391
+            Y[0][n] *= lin;
+            Y[1][n] *= lin;
+        }
+        int nst = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c >= C) continue;
+            float* __restrict__ yr = yb + (size_t)c * N;
+            chunks_to_lds_swz<L>(tby, Y[c], lane);
+            if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, true, lane);
+            else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
+            nst += L / 4;
+        }
+        stores_in_flight = full ? nst : -1;
+        WIDE_PRIO(0);
+    }
+}
+
+// Chains the segments of an item's smoothing state: start(g + 1) = alpha^(samples per segment) start(g) + z(g), fp64, one thread per item
+__global__ void chain_dyn_chain_kernel(const float* __restrict__ ctl, const float* __restrict__ z, float* __restrict__ start, int B, int G,
+                                       long seg_samples, double sample_rate) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
+    const double a = exp(-2.1972245773362196 / nat * (double)seg_samples);
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) {
+        start[(size_t)b * G + g] = (float)s;
+        s = a * s + (double)z[(size_t)b * G + g];
+    }
+}
+
+}  // namespace dasp
+
+// ================================================================================================
+// C-ABI (include/dasp_hip.h)
+using namespace dasp;
+
+namespace {
+constexpr int kL = 16, kWC = 16, kS = 6;
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int chk() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DASP_OK : (int)e;
+}
+}  // namespace
+
+extern "C" {
+
+/* Tiles per segment for dasp_chain_forward, 0 = one workgroup per item. A workgroup is 16 waves and fills a CU; below 128 items the items are
+ * cut until about 256 workgroups exist (every wave at least one tile). */
+long dasp_chain_segment_tiles(long B, long N) {
+    const long nt = dasp_sos_num_tiles(N);
+    if (B <= 0 || B >= 128 || nt < 2 * kWC) return 0;
+    long T = kWC;
+    while (B * ((nt + T - 1) / T) > 256 && T < nt) T *= 2;
+    return (nt + T - 1) / T > 1 ? T : 0;
+}
+/* floats of segbuf for dasp_chain_forward with Tseg > 0 */
+long dasp_chain_seg_floats(long B, long C, long N, int S, long Tseg) {
+    if (Tseg <= 0) return 0;
+    return dasp_sos_seg_floats(B * C, N, S, Tseg) + 2 * B * dasp_sos_segments(N, Tseg);
+}
+
+/* y = compressor(parametric_eq(x)) (mode 0; 1 = expander) in one pass over x, forward only.
+ *   tab    : the EQ's tables as dasp_peq_prepare / dasp_peq_prepare_rows / dasp_peq_prepare_norm fill them (Bs = 1 or B items, S = 6 sections)
+ *   ctl    : (B, 5) rows [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db] as for dasp_dynamics_forward (no look-ahead)
+ *   x, y   : (B, C, N), C = 1 or 2
+ *   Tseg   : 0, or dasp_chain_segment_tiles(B, N) with segtab from dasp_sos_segment_prepare(dtab, Bs, S, Tseg, ...) and
+ *            segbuf of dasp_chain_seg_floats(B, C, N, S, Tseg) floats */
+int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ctl, float* y, int B, int C, long N, int S, int mode,
+                       double sample_rate, float eps, long Tseg, const double* segtab, float* segbuf, void* stream) {
+    if (!tab || !x || !ctl || !y || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || (mode != 0 && mode != 1)) return DASP_ERR_ARG;
+    if (C > 2 || S != kS || N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    if (Tseg > 0 && (!segtab || !segbuf)) return DASP_ERR_ARG;
+    const int nt = (int)dasp_sos_num_tiles(N), bc = Bs == 1 && B != 1;
+    const int vec = (N % 4 == 0) && al16(x) && al16(y);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 blk(64 * kWC);
+#define DASP_CHAIN_LAUNCH(MODE_, SEG_, grid, se, sd, zd)                                                                                    \
+    hipLaunchKernelGGL((chain_fwd_kernel<kS, kL, kWC, MODE_, SEG_>), dim3(grid), blk, 0, st, tab, bc, x, ctl, y, C, (int)N, nt, vec, sample_rate, \
+                       eps, G, (int)Tseg, se, sd, zd)
+    if (Tseg <= 0) {
+        const int G = 1;
+        if (mode == 0) DASP_CHAIN_LAUNCH(0, 0, B, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+        else DASP_CHAIN_LAUNCH(1, 0, B, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+        return chk();
+    }
+    const int G = (int)dasp_sos_segments(N, Tseg);
+    const int rc = dasp_sos_segment_starts(tab, segtab, Bs, x, segbuf, B, C, N, S, Tseg, stream);      // EQ scan-only pre-pass + chain
+    if (rc != DASP_OK) return rc;
+    const float* start_eq = segbuf + (size_t)B * C * G * 2 * S;
+    float* zd = segbuf + dasp_sos_seg_floats((long)B * C, N, S, Tseg);
+    float* start_dyn = zd + (size_t)B * G;
+    if (mode == 0) DASP_CHAIN_LAUNCH(0, 2, B * G, start_eq, (const float*)nullptr, zd);
+    else DASP_CHAIN_LAUNCH(1, 2, B * G, start_eq, (const float*)nullptr, zd);
+    hipLaunchKernelGGL(chain_dyn_chain_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ctl, (const float*)zd, start_dyn, B, G, (long)Tseg * 64 * kL,
+                       sample_rate);
+    if (mode == 0) DASP_CHAIN_LAUNCH(0, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
+    else DASP_CHAIN_LAUNCH(1, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
+#undef DASP_CHAIN_LAUNCH
+    return chk();
+}
+
+}  // extern "C"

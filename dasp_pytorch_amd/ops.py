@@ -595,6 +595,45 @@ class ChainControlsFunction(torch.autograd.Function):
         return gc.to(cd), gr.to(rd), gg.to(gd), None, None
 
 
+def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mode=0, eps=1e-8):
+    """y = compressor(parametric_eq(x)) in one pass over x (dasp_chain_forward, csrc/chainfwd.hip): the EQ designed from its normalised
+    (Bp, 18) parameter tensor (dasp_peq_prepare_norm: de-normalisation + RBJ design on the device), the compressor on its (B, 5) control rows
+    [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db]. Forward only - no autograd node, nothing saved: the reference's target
+    synthesis (examples/style_transfer.py:293-299 runs the chain under no_grad every step). Refuses tensors that require a gradient."""
+    _lib.require_device(x, "x")
+    _lib.require_same_device(x, eq_params=eq_pn, ctl=ctl)
+    if torch.is_grad_enabled() and (x.requires_grad or eq_pn.requires_grad or ctl.requires_grad):
+        raise RuntimeError("chain_eq_compressor_forward is forward-only: call it under torch.no_grad() or on detached tensors")
+    _require_rows(x, ctl, 5, "ctl")
+    L = _lib.lib()
+    S = len(types)
+    B, C, N = x.shape
+    if eq_pn.dim() != 2 or eq_pn.shape[1] != 3 * S or eq_pn.shape[0] not in (1, B):
+        raise RuntimeError(f"EQ parameters must be ({B} or 1, {3 * S}), got {tuple(eq_pn.shape)}")
+    if x.numel() == 0:
+        return torch.empty_like(x)
+    dev = x.device
+    with torch.cuda.device(dev):
+        x32, pn32, c32 = _f32c(x), _f32c(eq_pn), _f32c(ctl)
+        Bp = pn32.shape[0]
+        tseg = 0 if os.environ.get("DASP_CHAIN_SEGMENT", "auto") == "0" else int(os.environ.get("DASP_CHAIN_SEGMENT_TILES") or L.dasp_chain_segment_tiles(B, N))
+        n_tab = _round64(Bp * L.dasp_sos_table_floats(S))
+        n_seg = _round64(L.dasp_chain_seg_floats(B, C, N, S, tseg)) if tseg else 0
+        f32 = torch.empty(n_tab + n_seg, dtype=torch.float32, device=dev)
+        n_dt = Bp * L.dasp_sos_dtab_doubles(S)
+        f64 = torch.empty(n_dt + (Bp * L.dasp_sos_segtab_doubles(S) if tseg else 0), dtype=torch.float64, device=dev)
+        tab, segbuf = f32[:n_tab], (f32[n_tab:] if tseg else None)
+        dtab, segtab = f64[:n_dt], (f64[n_dt:] if tseg else None)
+        y = torch.empty_like(x32)
+        call("dasp_peq_prepare_norm", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
+             (ctypes.c_double * (3 * S))(*span), ptr(None), ptr(tab), ptr(dtab), stream())
+        if tseg:
+            call("dasp_sos_segment_prepare", ptr(dtab), Bp, S, tseg, ptr(segtab), stream())
+        call("dasp_chain_forward", ptr(tab), Bp, ptr(x32), ptr(c32), ptr(y), B, C, N, S, int(mode), float(sample_rate), float(eps), tseg,
+             ptr(segtab), ptr(segbuf), stream())
+    return y.to(x.dtype)
+
+
 def _cbuf(n, device):
     """n complex64 elements as a float32 buffer (the C ABI takes void*)."""
     return torch.empty(2 * n, dtype=torch.float32, device=device)

@@ -113,6 +113,29 @@ int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, doub
 int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, const float* gy, const float* carries, float* gx,
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream);
+/* The design step of dasp_peq_forward_norm on its own: tables from the normalised (Bp, 3 S) tensor, no cascade. */
+int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                          unsigned* flag, float* tab, double* dtab, void* stream);
+/* The first two launches of dasp_sosfilt_forward_seg on their own (scan-only pre-pass + chain): afterwards the second half of segbuf
+ * (dasp_sos_seg_floats floats) holds the state every (row, segment) starts from, [row][segment][2 S]. */
+int dasp_sos_segment_starts(const float* tab, const double* segtab, int Bs, const float* x, float* segbuf, int B, int C, long N, int S,
+                            long Tseg, void* stream);
+
+/* ---- fused forward of the reference's effect chain: parametric EQ -> compressor -----------------------------------------------------------
+ * examples/style_transfer.py:150-154 (equalizer -> compressor -> reverb -> gain) and :293-299 (the same chain without gradients, every
+ * training step, to synthesise the target). y = compressor(parametric_eq(x)) in ONE pass over x: a workgroup owns a batch item (both
+ * channels: the compressor's side chain is their sum, functional.py:328), a tile of the EQ's output goes through the gain computer, the
+ * one-pole smoothing scan and the output multiply before it leaves the chip. 8 B per channel-sample instead of 16 for the two separate
+ * forward calls; forward only (no chunk states or carries are saved). The chain's final gain commutes with the reverb and is folded
+ * into makeup_gain_db by the caller (dasp_chain_controls).
+ *   tab  : the EQ's tables (dasp_peq_prepare / _rows / _norm; Bs = 1 or B items; S = 6)      ctl : (B, 5) as for dasp_dynamics_forward
+ *   mode : 0 compressor, 1 expander; no look-ahead                                            x, y: (B, C, N), C = 1 or 2
+ *   Tseg : 0 = one workgroup per item, or dasp_chain_segment_tiles(B, N) (few items: every item cut into segments of Tseg tiles) with
+ *          segtab from dasp_sos_segment_prepare(dtab, Bs, S, Tseg, ...) and segbuf of dasp_chain_seg_floats(B, C, N, S, Tseg) floats */
+long dasp_chain_segment_tiles(long B, long N);
+long dasp_chain_seg_floats(long B, long C, long N, int S, long Tseg);
+int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ctl, float* y, int B, int C, long N, int S, int mode,
+                       double sample_rate, float eps, long Tseg, const double* segtab, float* segbuf, void* stream);
 
 /* dasp_pytorch.signal.biquad (dasp_pytorch/signal.py:242-306) as a call of its own: the fp64 RBJ design the prepare calls run, for n
  * (gain_db, cutoff_freq, q_factor) triples of one filter type. ba: (n, 6) fp64 rows [b0 b1 b2 1 a1 a2] (normalised by a0, as the

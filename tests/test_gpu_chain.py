@@ -1,0 +1,137 @@
+"""GPU parity of the fused forward chain kernel (csrc/chainfwd.hip, dasp_chain_forward): parametric EQ -> compressor in one pass over x,
+the forward-only path of the reference's target synthesis (examples/style_transfer.py:293-299).
+
+Checked against (i) the unfused sequence of this package - the EQ's half is the same arithmetic from the same tables, the smoothing scan is
+associated differently (16-sample chunks instead of 4-sample groups): equal to rounding; (ii) the oracle (the reference's algorithm: FFT EQ,
+then FFT one-pole) on signals long enough for the reference's circular method to be alias-free. Tolerances: y at 2e-5 L-inf / peak per item
+(the compressor's own bar, tests/test_gpu_dynamics.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dasp_oracle as orc
+from tests.util import linf_peak, record
+
+pytestmark = pytest.mark.gpu
+SR = 44100
+PEQ_RANGES = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
+              (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
+DYN_RANGES = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]       # modules.py:179-186, knee kept > 0
+
+
+@pytest.fixture(scope="module")
+def D():
+    assert torch.cuda.is_available()
+    import dasp_pytorch_amd as D
+    return D
+
+
+def make(B, C, N, seed):
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    lvl = 10 ** (-(torch.rand(B, 1, 1, device="cuda:0", generator=g) * 30) / 20)            # items at 0 .. -30 dBFS: all knee regions
+    x = (torch.rand(B, C, N, device="cuda:0", generator=g) * 2 - 1) * lvl
+    eq_pn = torch.rand(B, 18, device="cuda:0", generator=g)
+    cu = torch.rand(B, 6, device="cuda:0", generator=g)
+    lo = torch.tensor([r[0] for r in DYN_RANGES], device="cuda:0"); hi = torch.tensor([r[1] for r in DYN_RANGES], device="cuda:0")
+    comp = cu * (hi - lo) + lo
+    return x, eq_pn, comp
+
+
+def eq_physical(eq_pn):
+    lo = torch.tensor([r[0] for r in PEQ_RANGES], device=eq_pn.device, dtype=torch.float64)
+    hi = torch.tensor([r[1] for r in PEQ_RANGES], device=eq_pn.device, dtype=torch.float64)
+    return eq_pn.double() * (hi - lo) + lo
+
+
+def fused(x, eq_pn, comp):
+    from dasp_pytorch_amd import ops
+    from dasp_pytorch_amd.functional import _PEQ_TYPES
+    lo = [float(r[0]) for r in PEQ_RANGES]; span = [float(r[1] - r[0]) for r in PEQ_RANGES]
+    ctl = torch.cat([comp[:, :3], comp[:, 4:]], 1).contiguous()
+    with torch.no_grad():
+        return ops.chain_eq_compressor_forward(x, eq_pn, _PEQ_TYPES, lo, span, float(SR), ctl)
+
+
+def unfused(D, x, eq_pn, comp):
+    with torch.no_grad():
+        y1 = D.ParametricEQ(SR).process_normalized(x, eq_pn)
+        return D.compressor(y1, SR, *[comp[:, i] for i in range(6)])
+
+
+@pytest.mark.parametrize("B,C,N,tiles", [(3, 2, 12000, None), (2, 1, 5003, None), (1, 2, 1024, None), (2, 2, 1, None), (5, 1, 40000, None), (4, 2, 131072, None),
+                                         (2, 2, 65536 + 1024 + 17, 16), (3, 1, 131072, 32), (16, 1, 262144, None), (2, 2, 262144, None)])
+def test_fused_forward_equals_unfused_sequence(D, monkeypatch, B, C, N, tiles):
+    """One workgroup per item and, for few items, segmented items (planner's choice or a forced segment length, incl. a ragged last
+    tile and a last segment shorter than the others): the fused pass gives what parametric_eq followed by compressor gives."""
+    x, eq_pn, comp = make(B, C, N, 100 + N % 97 + B)
+    if tiles:
+        monkeypatch.setenv("DASP_CHAIN_SEGMENT_TILES", str(tiles))
+    yf = fused(x, eq_pn, comp)
+    monkeypatch.delenv("DASP_CHAIN_SEGMENT_TILES", raising=False)
+    yu = unfused(D, x, eq_pn, comp)
+    from dasp_pytorch_amd import _lib
+    if tiles is None and B == 16:
+        assert _lib.lib().dasp_chain_segment_tiles(B, N) > 0                       # the planner does cut the reference's training shape
+    e = linf_peak(yf.cpu().numpy(), yu.cpu().numpy())
+    record(f"chain_fused_vs_unfused[{B},{C},{N},{tiles}]", y=e.max())
+    assert torch.isfinite(yf).all() and e.max() < 5e-6, e
+    if tiles is None and B <= 5:      # segmented and plain fused passes agree with each other as well
+        monkeypatch.setenv("DASP_CHAIN_SEGMENT", "0")
+        y0 = fused(x, eq_pn, comp)
+        assert linf_peak(yf.cpu().numpy(), y0.cpu().numpy()).max() < 5e-6
+
+
+@pytest.mark.parametrize("B,C,N", [(3, 2, 20000), (2, 1, 70001)])
+def test_fused_forward_vs_oracle(D, B, C, N):
+    x, eq_pn, comp = make(B, C, N, 7 + B)
+    yf = fused(x, eq_pn, comp).cpu().numpy()
+    p = eq_physical(eq_pn).cpu().numpy()
+    cd = comp.double().cpu().numpy()
+    y1 = orc.parametric_eq(x.cpu().numpy(), SR, p)
+    yo = orc.compressor(y1, SR, *[cd[:, i] for i in range(6)])
+    e = linf_peak(yf, yo)
+    record(f"chain_fused_vs_oracle[{B},{C},{N}]", y=e.max())
+    assert e.max() < 2e-5, e
+
+
+def test_full_size_launch_sampled_items(D):
+    """(256, 2, 131072): one workgroup of 16 waves per item, one per CU. Eight sampled items against the oracle, all items against the
+    unfused sequence."""
+    B, C, N = 256, 2, 131072
+    x, eq_pn, comp = make(B, C, N, 5)
+    yf = fused(x, eq_pn, comp)
+    yu = unfused(D, x, eq_pn, comp)
+    scale = yu.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    e_all = ((yf - yu).abs().amax(dim=(1, 2)) / scale).max().item()
+    idx = [0, 1, 63, 128, 129, 200, 254, 255]
+    p = eq_physical(eq_pn)[idx].cpu().numpy(); cd = comp[idx].double().cpu().numpy()
+    yo = orc.compressor(orc.parametric_eq(x[idx].cpu().numpy(), SR, p), SR, *[cd[:, i] for i in range(6)])
+    e = linf_peak(yf[idx].cpu().numpy(), yo)
+    record("chain_fused_full_size", vs_unfused=e_all, vs_oracle=e.max())
+    assert e_all < 1e-5 and e.max() < 2e-5        # (the unfused sequence itself sits at ~2e-6 of the oracle)
+
+
+def test_chain_module_takes_the_fused_path_without_grad(D, monkeypatch):
+    """StyleTransferChain.process_normalized under no_grad (the reference's target synthesis) runs EQ + compressor as the fused pass and
+    gives the output of the differentiable path; with gradients required it keeps the differentiable kernels."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    B, N = 4, 30000
+    x = torch.rand(B, 1, N, device="cuda:0", generator=g) * 2 - 1
+    chain = StyleTransferChain(SR, num_samples=4096)
+    ps = [torch.rand(B, n, device="cuda:0", generator=g).clamp(0.02, 0.98) for n in chain.num_params]
+    calls = []
+    from dasp_pytorch_amd import ops
+    real = ops.chain_eq_compressor_forward
+    monkeypatch.setattr(ops, "chain_eq_compressor_forward", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    torch.manual_seed(21)
+    with torch.no_grad():
+        y_ng = chain.process_normalized(x, *ps)
+    assert len(calls) == 1
+    pp = [p.clone().requires_grad_(True) for p in ps]
+    torch.manual_seed(21)
+    y_g = chain.process_normalized(x, *pp)
+    assert len(calls) == 1 and y_g.requires_grad
+    assert float((y_ng - y_g.detach()).abs().max()) <= 5e-6 * float(y_g.detach().abs().max())
+    with pytest.raises(RuntimeError):
+        ops.chain_eq_compressor_forward(x.requires_grad_(True), ps[0], [1, 0, 0, 0, 0, 2], [0.0] * 18, [1.0] * 18, float(SR), torch.zeros(B, 5, device="cuda:0"))

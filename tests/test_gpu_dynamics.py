@@ -3,7 +3,8 @@
 
 Tolerances (L-inf / peak per batch item): y and grad_x 2e-5 (north_star bar 1e-4; the dB->linear
 map amplifies fp32 log2/exp2 rounding by ~ln10/20*|gain dB|, the reference's own fp32 run sits at
-1e-5..3e-5); control gradients 2e-4 of the column maximum."""
+1e-5..3e-5); control gradients 1e-4 of the column maximum (the north_star bar; measured
+3e-7 .. 2.7e-5 on the GPU, profiles/r03/parity_measured.jsonl)."""
 import numpy as np
 import pytest
 import torch
@@ -15,8 +16,8 @@ pytestmark = pytest.mark.gpu
 SR = 44100
 KEYS = ["threshold_db", "ratio", "attack_ms", "release_ms", "knee_db", "makeup_gain_db"]
 RANGES = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]       # modules.py:179-186, knee kept > 0
-CTL_TOL = 2e-4           # control gradients vs the reference's fp64 run on the goldens (column maximum)
-CTL_TOL_SHAPES = 5e-4    # ... vs the oracle on random shapes
+CTL_TOL = 1e-4           # control gradients vs the reference's fp64 run on the goldens (column maximum)
+CTL_TOL_SHAPES = 1e-4    # ... vs the oracle on random shapes
 
 
 @pytest.fixture(scope="module")
