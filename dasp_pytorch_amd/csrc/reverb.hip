@@ -45,6 +45,49 @@ typedef ColGeom<COLS_LOG> ColsGeom;
 // four-step kernels touch neighbouring (at small NA: the same) 128-byte lines of the signal; the windows of an item share its band spectra.
 __device__ __forceinline__ int xcd_tile(int bx, int nx) { return (nx & 7) ? bx : (bx & 7) * (nx >> 3) + (bx >> 3); }
 
+// ---- counter-based white noise (device_noise): the reference's torch.randn(bs * 2, 12, num_samples + taps - 1) (functional.py:548) ---------
+// generated where it is consumed. Written to memory by torch.randn and read by the forward and the backward filter bank it was 0.82 GB of
+// HBM traffic three times over per step; the stream below is a pure function of (seed, batch item, band, sample index), so both kernels -
+// and every overlapping window inside them - recompute the same values. One 32-bit hash per (item, band, index) gives BOTH noise rows of the
+// item (rows 2b and 2b+1, which enter the transform as one complex signal anyway) as a Box-Muller pair:
+//   (a, c) = stream key of (seed, b * nb + band): 24-bit odd multiplier, 32-bit offset       h = lowbias32(m * a + c)   (m < 2^24)
+//   u1 = ((h >> 16) + 0.5) / 65536, u2 = (h & 0xffff) / 65536;   r = sqrt(-2 ln u1);   (re, im) = r (cos, sin)(2 pi u2)
+// lowbias32 = Wellons' two-round multiply-xorshift finaliser. Different streams are different affine index maps into the hash: they share
+// at most isolated values, never a run. Executable specification and its statistics: oracle/noise_stream.py, tests/test_oracle_cpu.py.
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct NoiseKey { unsigned a, c; };
+__device__ __forceinline__ NoiseKey noise_key(unsigned long long seed, unsigned sid) {
+    const unsigned k0 = lowbias32(sid + 0x9E3779B9U);
+    const unsigned k1 = lowbias32(k0 ^ (unsigned)seed);
+    const unsigned k2 = lowbias32(k1 ^ (unsigned)(seed >> 32) ^ 0x85EBCA6BU);
+    return NoiseKey{(k1 & 0xFFFFFFU) | 1U, k2};
+}
+__device__ __forceinline__ void noise_pair(NoiseKey k, unsigned m, float& re, float& im) {
+    const unsigned h = lowbias32(__umul24(m, k.a) + k.c);
+    const float u1 = ((float)(h >> 16) + 0.5f) * (1.f / 65536.f);
+    const float t = (float)(h & 0xFFFFU) * (1.f / 65536.f);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // v_log_f32 is log2: -2 ln 2 log2(u1)
+    re = r * __builtin_amdgcn_cosf(t);                                                             // v_cos / v_sin take revolutions
+    im = r * __builtin_amdgcn_sinf(t);
+}
+// The same stream written out in the reference's layout (2B, nb, row_len): the test hook that lets the explicit-noise path and the oracle
+// see what the kernels generate (dasp_reverb_noise).
+__global__ void reverb_noise_kernel(unsigned long long seed, float* __restrict__ out, int nb, int row_len) {
+    const int sid = blockIdx.y;                      // b * nb + band
+    const int b = sid / nb, band = sid % nb;
+    const NoiseKey key = noise_key(seed, (unsigned)sid);
+    float* rl = out + ((long)(2 * b) * nb + band) * row_len;
+    float* rr = out + ((long)(2 * b + 1) * nb + band) * row_len;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < row_len; m += gridDim.x * blockDim.x) {
+        float re, im;
+        noise_pair(key, (unsigned)m, re, im);
+        rl[m] = re; rr[m] = im;
+    }
+}
+
 // ---- fused filter bank ---------------------------------------------------------------------------------------------
 // spec layout (complex): [0, 4096) forward twiddles exp(-2 pi i e / 4096); then nb rows of 4096: conj(FFT(filter_band)) / 4096
 // in the split order of fft4096_split_fwd; then the taps themselves, nb * taps floats (fb_wspectrum_kernel weights them per item).
@@ -124,10 +167,12 @@ __global__ __launch_bounds__(FFT_T) void fb_wspectrum_kernel(const f2* __restric
 // the chip (1 item: 22 workgroups). bsplit > 1 deals the bands out to gridDim.z workgroups per (item, window): MODE 0 then adds its
 // bands' share into ir with float atomics (ir zeroed by the caller; the order of the additions is not deterministic), MODE 1 writes the
 // partial sums of its own bands only.
-template <int MODE, int ROUTE>
+// GEN: the noise is generated (stream above, `seed`) instead of read from `noise`.
+template <int MODE, int ROUTE, bool GEN>
 __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const f2* __restrict__ wspec,
                                                          const float* __restrict__ gains, const float* __restrict__ decays, float* __restrict__ ir,
-                                                         const float* __restrict__ gir, float* __restrict__ part, int nb, int L, int taps, int VQ, float limit) {
+                                                         const float* __restrict__ gir, float* __restrict__ part, int nb, int L, int taps, int VQ, float limit,
+                                                         unsigned long long seed) {
     const int bsplit = gridDim.z, bper = (nb + bsplit - 1) / bsplit, band_lo = blockIdx.z * bper, band_hi = band_lo + bper < nb ? band_lo + bper : nb;
     __shared__ f2 lds[2 * FFT_LDS];
     __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
@@ -174,14 +219,26 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
             const float g = gains[b * nb + band], d = 10.f * decays[b * nb + band] + 1.f, rho = d * tstep;
             float r[8], i[8];
             {
-                const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
-                const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
+                if (GEN) {
+                    const NoiseKey key = noise_key(seed, (unsigned)(b * nb + band));
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {       // all 16 loads in flight before the first use (a product inside the select makes each a branch + wait)
-                    const int idx = n0 + j + 512 * q, ic = idx < row_len ? idx : row_len - 1;      // clamped address: a plain load, no branch
-                    const float vl = rl[ic], vr = rr[ic];
-                    r[q] = idx < row_len ? vl : 0.f;
-                    i[q] = idx < row_len ? vr : 0.f;
+                    for (int q = 0; q < 8; ++q) {
+                        const int idx = n0 + j + 512 * q;
+                        float vl, vr;
+                        noise_pair(key, (unsigned)idx, vl, vr);
+                        r[q] = idx < row_len ? vl : 0.f;
+                        i[q] = idx < row_len ? vr : 0.f;
+                    }
+                } else {
+                    const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
+                    const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {       // all 16 loads in flight before the first use (a product inside the select makes each a branch + wait)
+                        const int idx = n0 + j + 512 * q, ic = idx < row_len ? idx : row_len - 1;      // clamped address: a plain load, no branch
+                        const float vl = rl[ic], vr = rr[ic];
+                        r[q] = idx < row_len ? vl : 0.f;
+                        i[q] = idx < row_len ? vr : 0.f;
+                    }
                 }
                 float wq = __expf(-rho * (float)j);
                 const float ws = __expf(-rho * 512.f);
@@ -220,7 +277,17 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
         for (int q = 0; q < 8; ++q) { sumr[q] = 0.f; sumi[q] = 0.f; }
         for (int band = band_lo; band < band_hi; ++band) {
             float r[8], i[8];
-            {
+            if (GEN) {
+                const NoiseKey key = noise_key(seed, (unsigned)(b * nb + band));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = n0 + j + 512 * q;
+                    float vl, vr;
+                    noise_pair(key, (unsigned)idx, vl, vr);
+                    r[q] = idx < row_len ? vl : 0.f;
+                    i[q] = idx < row_len ? vr : 0.f;
+                }
+            } else {
                 const float* rl = noise + ((long)(2 * b) * nb + band) * row_len;
                 const float* rr = noise + ((long)(2 * b + 1) * nb + band) * row_len;
 #pragma unroll
@@ -630,10 +697,10 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
  * Saved for backward: H (sizes[7] complex) and, when A is not NULL, A (sizes[6] complex: the column transforms of x; pass NULL when no
  * gradient is needed and they go to a chunk-sized scratch instead: W2, sizes[12] complex).
  * Scratch: W (sizes[12] complex), Ah (sizes[13] complex), ir (sizes[8] floats). */
-int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays, const float* mix,
-                        float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
-                        void* stream) {
-    if (!x || !noise || !Fspec || !gains || !decays || !mix || !y || (!A && !W2) || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
+static int reverb_forward_impl(const float* x, const float* noise, unsigned long long seed, const void* Fspec, const float* gains,
+                               const float* decays, const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
+                               long N, int L, int taps, int nb, void* stream) {
+    if (!x || !Fspec || !gains || !decays || !mix || !y || (!A && !W2) || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
         nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
@@ -651,10 +718,13 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
     const float limit = rv_weight_limit();
     const float tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f;
     hipLaunchKernelGGL(fb_wspectrum_kernel, dim3((unsigned)nb, (unsigned)B), dim3(FFT_T), 0, st, tw, taps_f, decays, (f2*)W, nb, taps, tstep);
-    hipLaunchKernelGGL((fb_fused_kernel<0, 1>), dim3((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit), dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays,
-                       ir, (const float*)nullptr, (float*)nullptr, nb, L, taps, d.VQ, limit);
-    hipLaunchKernelGGL((fb_fused_kernel<0, 0>), dim3((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit), dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays,
-                       ir, (const float*)nullptr, (float*)nullptr, nb, L, taps, d.VQ, limit);
+    if ((long)L + taps - 1 >= (1L << 24)) return DASP_ERR_UNSUPPORTED;        // (the generator's sample index is a 24-bit factor; L <= 2^20 anyway)
+    const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit);
+#define DASP_FB_FWD(ROUTE_, GEN_)                                                                                                           \
+    hipLaunchKernelGGL((fb_fused_kernel<0, ROUTE_, GEN_>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays, ir, (const float*)nullptr, \
+                       (float*)nullptr, nb, L, taps, d.VQ, limit, seed)
+    if (noise) { DASP_FB_FWD(1, false); DASP_FB_FWD(0, false); } else { DASP_FB_FWD(1, true); DASP_FB_FWD(0, true); }
+#undef DASP_FB_FWD
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
         const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
         f2* Hc = (f2*)H + s0 * d.c.n1;
@@ -677,11 +747,11 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
 
 /* Backward.  gx (B,2,N); ggain, gdecay (B, nb); gmix (B).
  * Scratch: Ag, W (sizes[12] complex each), P (sizes[13] complex), gir (sizes[8] floats), part (sizes[11] floats), mix_part (sizes[10] floats). */
-int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
-                         const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
-                         void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
-                         void* stream) {
-    if (!x || !gy || !noise || !Fspec || !gains || !decays || !mix || !A || !H || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
+static int reverb_backward_impl(const float* x, const float* gy, const float* noise, unsigned long long seed, const void* Fspec, const float* gains,
+                                const float* decays, const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay,
+                                float* gmix, void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps,
+                                int nb, void* stream) {
+    if (!x || !gy || !Fspec || !gains || !decays || !mix || !A || !H || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
         !gir || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
@@ -708,13 +778,50 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
     hipLaunchKernelGGL(fb_wspectrum_kernel, dim3((unsigned)nb, (unsigned)B), dim3(FFT_T), 0, st, tw, taps_f, decays, (f2*)Ag, nb, taps,
                        L > 1 ? 1.f / (float)(L - 1) : 0.f);
     const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)rv_band_split(B, d.nwin, nb));
-    hipLaunchKernelGGL((fb_fused_kernel<1, 1>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr, (const float*)gir, part,
-                       nb, L, taps, d.VQ, limit);
-    hipLaunchKernelGGL((fb_fused_kernel<1, 0>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr, (const float*)gir, part,
-                       nb, L, taps, d.VQ, limit);
+#define DASP_FB_BWD(ROUTE_, GEN_)                                                                                                           \
+    hipLaunchKernelGGL((fb_fused_kernel<1, ROUTE_, GEN_>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr,         \
+                       (const float*)gir, part, nb, L, taps, d.VQ, limit, seed)
+    if (noise) { DASP_FB_BWD(1, false); DASP_FB_BWD(0, false); } else { DASP_FB_BWD(1, true); DASP_FB_BWD(0, true); }
+#undef DASP_FB_BWD
     const int nfin = B * nb + B;                      // one wave per output value
     hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 3) / 4), dim3(256), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
                        d.c.npairs * d.ctiles);
+    return rv_check();
+}
+
+int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays, const float* mix,
+                        float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
+                        void* stream) {
+    if (!noise) return DASP_ERR_ARG;
+    return reverb_forward_impl(x, noise, 0ULL, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
+}
+int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
+                         const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
+                         void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
+                         void* stream) {
+    if (!noise) return DASP_ERR_ARG;
+    return reverb_backward_impl(x, gy, noise, 0ULL, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
+                                taps, nb, stream);
+}
+/* The same two calls with the white noise generated inside the filter-bank kernels from `seed` (the counter-based stream documented at
+ * the top of reverb.hip) instead of read from memory: nothing of size (2B, nb, L + taps - 1) exists. Forward and backward must be given
+ * the same seed. dasp_reverb_noise writes that stream out in the reference's layout, out (2B, nb, L + taps - 1) - a test hook. */
+int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const void* Fspec, const float* gains, const float* decays, const float* mix,
+                            float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
+                            void* stream) {
+    return reverb_forward_impl(x, nullptr, seed, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
+}
+int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const void* Fspec, const float* gains, const float* decays,
+                             const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
+                             void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
+                             void* stream) {
+    return reverb_backward_impl(x, gy, nullptr, seed, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
+                                taps, nb, stream);
+}
+int dasp_reverb_noise(unsigned long long seed, float* out, int B, int nb, long row_len, void* stream) {
+    if (!out || B <= 0 || nb <= 0 || nb > RV_BANDS_MAX || row_len <= 0 || row_len >= (1L << 24) || (long)B * nb > 65535) return DASP_ERR_ARG;
+    const unsigned gx = (unsigned)((row_len + 255) / 256 < 64 ? (row_len + 255) / 256 : 64);
+    hipLaunchKernelGGL(reverb_noise_kernel, dim3(gx, (unsigned)(B * nb)), dim3(256), 0, (hipStream_t)stream, seed, out, nb, (int)row_len);
     return rv_check();
 }
 

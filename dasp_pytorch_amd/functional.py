@@ -226,15 +226,19 @@ def noise_shaped_reverberation(
     num_bandpass_taps: int = 1023,
     noise: torch.Tensor = None,
     device_noise: bool = False,
+    noise_seed: int = None,
 ):
     """Artificial reverberation from frequency-band noise shaping (reference: dasp_pytorch/functional.py:406-577).
     Mono input is duplicated to stereo and the output always has 2 channels, as in the reference.
 
     White noise: by default it is drawn exactly like the reference does -- torch.randn(bs*2, 12, num_samples +
     num_bandpass_taps - 1) from the global *CPU* generator (functional.py:548) and copied to x's device -- so the same
-    torch.manual_seed gives the same impulse responses as the reference. `device_noise=True` draws it on x's device
-    instead (no host->device copy; a different random stream); `noise=` supplies it explicitly. Both keywords are
-    additions; Processor.process_normalized passes only the named parameters above."""
+    torch.manual_seed gives the same impulse responses as the reference. `device_noise=True` generates it on x's device
+    instead, inside the filter-bank kernels (a counter-based stream, csrc/reverb.hip: the noise tensor - 0.8 GB at the default sizes
+    and 128 items - never exists, forward and backward recompute it); its 63-bit seed is `noise_seed`, or, when that is None, one draw
+    from torch's global CPU generator per call - so torch.manual_seed makes it reproducible and successive calls differ, as with the
+    reference (inside a HIP-graph capture that draw happens once, at capture time: replays reuse the seed). `noise=` supplies the
+    noise tensor explicitly. The keywords are additions; Processor.process_normalized passes only the named parameters above."""
     assert num_bandpass_taps % 2 == 1, "num_bandpass_taps must be odd"
     bs, chs, seq_len = x.size()
     assert chs <= 2, "only mono/stereo signals are supported"
@@ -250,7 +254,7 @@ def noise_shaped_reverberation(
                                      band8_gain, band9_gain, band10_gain, band11_gain)
     band_decays = _StackColumns.apply(band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
                                       band7_decay, band8_decay, band9_decay, band10_decay, band11_decay)
-    return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise)
+    return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise, noise_seed)
 
 
 class _StackColumns(torch.autograd.Function):
@@ -269,15 +273,20 @@ class _StackColumns(torch.autograd.Function):
         return tuple(r.reshape(shape) if need else None for r, shape, need in zip(rows, ctx.shapes, ctx.needs_input_grad))
 
 
-def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False):
+def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False,
+                          noise_seed=None):
     """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what the function above stacks its 24 + 1
     arguments into, and what NoiseShapedReverb.process_normalized has as slices of its de-normalised (bs, 25) tensor. x: (bs, 2, seq_len)."""
     bs = x.shape[0]
     filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
+    seed = None
     if noise is None:
-        shape = (bs * 2, 12, num_samples + num_bandpass_taps - 1)
-        noise = torch.randn(*shape, device=x.device) if device_noise else torch.randn(*shape).to(x.device)
-    return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples))
+        if device_noise or noise_seed is not None:
+            # one 63-bit draw from the global CPU generator (a host-side scalar: no device work, no sync) unless the caller fixed the seed
+            seed = int(noise_seed) if noise_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+        else:
+            noise = torch.randn(bs * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
+    return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed)
 
 
 def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):

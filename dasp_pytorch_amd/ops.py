@@ -752,16 +752,30 @@ def _filter_spectrum(filters, nb, taps, n_complex, dev):
     return Fspec
 
 
+def reverb_noise(seed, B, nb, row_len, device):
+    """The white-noise stream the filter-bank kernels generate for `seed` (dasp_reverb_forward_rng), written out in the reference's layout
+    (2B, nb, row_len) (dasp_pytorch/functional.py:548). A test / inspection hook: the product never materialises it."""
+    dev = torch.device(device)
+    out = torch.empty(2 * B, nb, row_len, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        call("dasp_reverb_noise", ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), ptr(out), B, nb, row_len, stream())
+    return out
+
+
 class ReverbFunction(torch.autograd.Function):
-    """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1), filters (nb,taps), gains/decays (B,nb), mix (B).
+    """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1) or None, filters (nb,taps), gains/decays (B,nb), mix (B).
     `noise` and `filters` are constants of the op (the reference draws the noise inside the function, functional.py:548, and designs the
-    filters with SciPy): asking for their gradient raises instead of silently returning None."""
+    filters with SciPy): asking for their gradient raises instead of silently returning None. noise = None: the noise is generated inside
+    the filter-bank kernels from the integer `seed` (csrc/reverb.hip, counter-based: forward and backward recompute the same stream) and
+    never exists in memory."""
 
     @staticmethod
-    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir):
+    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir, seed=None):
         _lib.require_device(x, "x")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise RuntimeError("noise_shaped_reverberation: `noise` and `filters` are not differentiable inputs (detach them)")
+        if noise is None and seed is None:
+            raise ValueError("ReverbFunction: either a noise tensor or a seed")
         Lb = _lib.lib()
         B, C, N = x.shape
         nb, taps = filters.shape
@@ -778,9 +792,13 @@ class ReverbFunction(torch.autograd.Function):
                 # (the reference's torch.stack(...).view(bs, 12) raises for it, functional.py:498-544)
                 raise RuntimeError(f"shape '[{B}, {nb}]' is invalid for band gains / decays of shapes {tuple(gains.shape)} / "
                                    f"{tuple(decays.shape)} and mix with {mix.numel()} values")
-            x32, n32 = _f32c(x), _f32c(noise)
-            if n32.numel() != 2 * B * nb * (L_ir + taps - 1):
-                raise RuntimeError(f"noise must hold (2 * {B}, {nb}, {L_ir + taps - 1}) values, got {tuple(noise.shape)}")
+            x32 = _f32c(x)
+            n32 = None
+            if noise is not None:
+                n32 = _f32c(noise)
+                if n32.numel() != 2 * B * nb * (L_ir + taps - 1):
+                    raise RuntimeError(f"noise must hold (2 * {B}, {nb}, {L_ir + taps - 1}) values, got {tuple(noise.shape)}")
+            useed = ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF) if noise is None else None
             g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
             y = torch.empty_like(x32)
@@ -790,11 +808,15 @@ class ReverbFunction(torch.autograd.Function):
             W2 = None if need_grad else _cbuf(sizes[12], dev)
             W, H, Ah = _cbuf(sizes[12], dev), _cbuf(sizes[7], dev), _cbuf(sizes[13], dev)
             ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
-            call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
-                 ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+            if noise is None:
+                call("dasp_reverb_forward_rng", ptr(x32), useed, ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
+                     ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+            else:
+                call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
+                     ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
             if need_grad:
-                ctx.save_for_backward(x32, n32, Fspec, g32, d32, m32, A, H)
-                ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes])
+                ctx.save_for_backward(x32, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H)
+                ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes], useed)
         return y.to(x.dtype)
 
     @staticmethod
@@ -803,9 +825,9 @@ class ReverbFunction(torch.autograd.Function):
         xd, gd, gs, dd, ds, md, ms = ctx.meta
         if ctx.empty:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
-            return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None
+            return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None
         x32, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
-        B, N, L_ir, taps, nb, sizes = ctx.cfg
+        B, N, L_ir, taps, nb, sizes, useed = ctx.cfg
         dev = x32.device
         with torch.cuda.device(dev):
             gx = torch.empty_like(x32)
@@ -817,7 +839,10 @@ class ReverbFunction(torch.autograd.Function):
             gir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
             part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
             mix_part = torch.empty(sizes[10], dtype=torch.float32, device=dev)
-            call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H),
-                 ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P), ptr(gir), ptr(part), ptr(mix_part),
-                 B, N, L_ir, taps, nb, stream())
-        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None
+            tail = (ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P),
+                    ptr(gir), ptr(part), ptr(mix_part), B, N, L_ir, taps, nb, stream())
+            if useed is not None:
+                call("dasp_reverb_backward_rng", ptr(x32), ptr(_f32c(gy)), useed, *tail)
+            else:
+                call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), *tail)
+        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None

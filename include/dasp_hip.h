@@ -276,6 +276,21 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
                          const float* decays, const float* mix, const void* A, const void* H, float* gx,
                          float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
                          float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
+/* The same two calls with the white noise of functional.py:548 generated inside the filter-bank kernels from a 64-bit seed instead of read
+ * from memory (the `device_noise=True` mode of the Python layer): a counter-based stream, a pure function of (seed, batch item, band,
+ * sample index) - one 32-bit hash per (item, band, index), its halves a Box-Muller pair = the item's two noise rows - so the forward and
+ * the backward pass recompute identical values and nothing of size (2B, nb, L + taps - 1) exists (0.82 GB at B = 128 and the default
+ * sizes, which torch.randn wrote once and the two filter-bank kernels read once each). Both calls of a step take the same seed.
+ * dasp_reverb_noise writes the stream out in the reference's layout, out (2B, nb, row_len), row_len = L + taps - 1 < 2^24: a test hook
+ * (the explicit-noise calls above, given that tensor, must reproduce the seeded calls). Specification: oracle/noise_stream.py. */
+int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const void* Fspec, const float* gains, const float* decays,
+                            const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
+                            long N, int L, int taps, int nb, void* stream);
+int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const void* Fspec, const float* gains,
+                             const float* decays, const float* mix, const void* A, const void* H, float* gx,
+                             float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
+                             float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
+int dasp_reverb_noise(unsigned long long seed, float* out, int B, int nb, long row_len, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stereo utilities.  Replace dasp_pytorch.functional.stereo_widener (dasp_pytorch/functional.py:580-605),

@@ -195,3 +195,44 @@ def test_envelope_inside_the_transform_equals_per_band_route(D, monkeypatch):
     assert np.abs(y1 - y0).max() <= 1e-5 * np.abs(y0).max() and np.abs(gx1 - gx0).max() <= 1e-5 * np.abs(gx0).max()
     assert (np.abs(gp1 - gp0).max(1) <= 3e-5 * np.abs(gp0).max(1)).all()
     assert not np.array_equal(y1[0], y0[0]) and np.array_equal(y1[1], y0[1])          # item 0 changed route, item 1 did not
+
+
+def test_generated_noise_equals_the_explicit_noise_path(D):
+    """device_noise=True: the noise is generated inside the filter-bank kernels (counter-based stream keyed by the seed; csrc/reverb.hip).
+    dasp_reverb_noise writes that stream out; (i) it is the stream oracle/noise_stream.py specifies, (ii) fed through the explicit-noise
+    path it reproduces the seeded call - output and every gradient - to rounding, on both filter-bank routes and with the bands dealt out;
+    (iii) the seeded call agrees with the oracle on that noise; (iv) the seed comes from torch's global CPU generator unless given."""
+    from dasp_pytorch_amd import ops
+    from oracle import noise_stream as ns
+    rng = np.random.default_rng(3)
+    for B, C, N, L, taps, seed in ((2, 2, 9000, 5000, 255, 123456789012345), (3, 1, 30000, 16384, 1023, 7), (1, 2, 40000, 65536, 1023, 2 ** 62 + 5)):
+        x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+        w = rng.standard_normal((B, 2, N)).astype(np.float32)
+        p = rng.random((B, 25)).astype(np.float32)
+        if L == 16384:
+            p[1, 17] = 0.95                       # item 1 takes the per-band route (see test_envelope_inside_the_transform...)
+        nz = ops.reverb_noise(seed, B, 12, L + taps - 1, "cuda:0")
+        e_model = np.abs(nz.cpu().numpy() - ns.noise(seed, B, 12, L + taps - 1)).max()
+        assert e_model < 2e-5, e_model            # fp32 log2 / sqrt / sin / cos intrinsics against the fp64 model, values up to 4.9
+        outs = []
+        for kw in (dict(noise=nz), dict(device_noise=True, noise_seed=seed)):
+            xt = dev(x).requires_grad_(True)
+            cols = [dev(p[:, i]).requires_grad_(True) for i in range(25)]
+            y = D.noise_shaped_reverberation(xt, SR, *cols, num_samples=L, num_bandpass_taps=taps, **kw)
+            (y * dev(w)).sum().backward()
+            outs.append((y.detach().cpu().numpy(), xt.grad.cpu().numpy(), torch.stack([c.grad for c in cols], 1).cpu().numpy()))
+        (y0, gx0, gp0), (y1, gx1, gp1) = outs
+        ey, egx, egp = np.abs(y1 - y0).max() / np.abs(y0).max(), np.abs(gx1 - gx0).max() / np.abs(gx0).max(), np.abs(gp1 - gp0).max() / np.abs(gp0).max()
+        record(f"reverb_generated_noise[{B},{C},{N},{L},{taps}]", stream_vs_model=e_model, y=ey, gx=egx, gctl=egp)
+        assert ey < 2e-6 and egx < 2e-6 and egp < 1e-5, (ey, egx, egp)
+        if N <= 30000:
+            pd = p.astype(np.float64)
+            yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], nz.cpu().numpy(), L, taps)
+            assert np.abs(y1 - yo).max() < 3e-5 * np.abs(yo).max()
+    # seeding: torch.manual_seed makes the default draw reproducible, successive calls differ (as with the reference's CPU randn)
+    xs = torch.rand(1, 2, 4000, device="cuda:0")
+    cols = [torch.rand(1, device="cuda:0") for _ in range(24)] + [torch.ones(1, device="cuda:0")]
+    run = lambda: D.noise_shaped_reverberation(xs, SR, *cols, num_samples=2048, num_bandpass_taps=127, device_noise=True)
+    torch.manual_seed(99); a1 = run(); a2 = run()
+    torch.manual_seed(99); b1 = run()
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)

@@ -310,3 +310,29 @@ def test_oracle_process_normalized_goldens():
     gx, gg, gd, gm = orc.noise_shaped_reverberation_vjp(g["x"], SR, p[:, :12], p[:, 12:24], p[:, 24], noise, g["w"])
     assert linf_peak(gx, g["gx64"]).max() < 2e-6
     assert linf_peak(np.concatenate([gg, gd, gm[:, None]], 1) * span, g["gpn64"]).max() < 2e-5
+
+
+def test_noise_stream_model_is_white_unit_gaussian():
+    """oracle/noise_stream.py, the specification of the counter-based noise of csrc/reverb.hip (device_noise=True): unit variance, Gaussian
+    kurtosis, no correlation along a row, between the two rows of an item, between bands or items, flat spectrum; streams are keyed by the
+    seed."""
+    from oracle import noise_stream as ns
+    z = ns.noise(20240917, 3, 12, 40000)
+    assert z.shape == (6, 12, 40000)
+    assert abs(z.mean()) < 3e-3 and abs(z.var() - 1.0) < 5e-3
+    kurt = ((z - z.mean()) ** 4).mean() / z.var() ** 2
+    assert abs(kurt - 3.0) < 0.03
+    f = z.reshape(-1, z.shape[-1])
+    bound = 5.0 / np.sqrt(f.shape[1])
+    for lag in (1, 2, 3, 16, 512, 1023):
+        c = [np.corrcoef(r[:-lag], r[lag:])[0, 1] for r in f[::5]]
+        assert np.abs(c).max() < bound, (lag, np.abs(c).max())
+    C = np.corrcoef(f)
+    np.fill_diagonal(C, 0.0)
+    assert np.abs(C).max() < bound            # rows 2b / 2b+1 (one hash, two normals), bands and items alike
+    P = (np.abs(np.fft.rfft(f, axis=1)) ** 2).mean(0)
+    edges = np.linspace(1, len(P) - 1, 9).astype(int)
+    bands = np.array([P[a:b].mean() for a, b in zip(edges[:-1], edges[1:])])
+    assert np.abs(bands / bands.mean() - 1).max() < 0.03
+    assert not np.allclose(ns.noise(1, 1, 1, 64), ns.noise(2, 1, 1, 64))
+    np.testing.assert_array_equal(ns.noise(7, 2, 3, 50)[2:, 1], ns.noise(7, 2, 3, 50)[2:4, 1])        # deterministic
