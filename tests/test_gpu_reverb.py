@@ -235,4 +235,5 @@ def test_generated_noise_equals_the_explicit_noise_path(D):
     run = lambda: D.noise_shaped_reverberation(xs, SR, *cols, num_samples=2048, num_bandpass_taps=127, device_noise=True)
     torch.manual_seed(99); a1 = run(); a2 = run()
     torch.manual_seed(99); b1 = run()
-    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    # (one item: the bands are dealt out over workgroups that add into the impulse response with float atomics - equal to rounding, not to the bit)
+    assert float((a1 - b1).abs().max()) < 1e-5 * float(a1.abs().max()) and float((a1 - a2).abs().max()) > 1e-2 * float(a1.abs().max())
