@@ -39,6 +39,8 @@ SIGNATURES = {
     "dasp_peq_forward_norm": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _p,
                                    _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
     "dasp_peq_prepare_norm": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _p, _p, _p, _p]),
+    "dasp_peq_prepare_norm_seg": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _p, _p, _p,
+                                       _l, _p, _p]),
     "dasp_sos_segment_starts": (_i, [_p, _p, _i, _p, _p, _i, _i, _l, _i, _l, _p]),
     "dasp_chain_segment_tiles": (_l, [_l, _l]),
     "dasp_chain_seg_floats": (_l, [_l, _l, _l, _i, _l]),

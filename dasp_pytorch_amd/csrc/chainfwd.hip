@@ -44,7 +44,8 @@ template <int S, int L, int W, int MODE, int SEG>
 __global__ void __launch_bounds__(64 * W, (W + 3) / 4)   // one workgroup of W = 16 waves per CU: four waves per SIMD, <= 128 registers
 chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y,
                  int C, int N, int nt, int vec, double sample_rate, float eps, int G, int Tseg, const float* __restrict__ segstart_eq,
-                 const float* __restrict__ segstart_dyn, float* __restrict__ zseg_dyn) {
+                 const float* __restrict__ segstart_dyn, float* __restrict__ zseg_dyn, float* __restrict__ chain_tab = nullptr,
+                 float* __restrict__ chain_start = nullptr) {
     using LY = SosLayout<S, L>;
     static_assert(L == 16, "chunk layout of the smoothing scan");
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L, CH = 2;
@@ -208,19 +209,34 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
         stores_in_flight = full ? nst : -1;
         WIDE_PRIO(0);
     }
-}
-
-// Chains the segments of an item's smoothing state: start(g + 1) = alpha^(samples per segment) start(g) + z(g), fp64, one thread per item
-__global__ void chain_dyn_chain_kernel(const float* __restrict__ ctl, const float* __restrict__ z, float* __restrict__ start, int B, int G,
-                                       long seg_samples, double sample_rate) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
-    const double a = exp(-2.1972245773362196 / nat * (double)seg_samples);
-    double s = 0.0;
-    for (int g = 0; g < G; ++g) {
-        start[(size_t)b * G + g] = (float)s;
-        s = a * s + (double)z[(size_t)b * G + g];
+    if (SEG == 2 && chain_tab) {
+        // The chain of the smoothing state over the item's segments, start(g + 1) = alpha^(samples per segment) start(g) + z(g) in fp64, by
+        // the last of the item's workgroups to finish (as sosfilt.hip's chain_by_last_workgroup: the pre-pass stores nothing but z, so the
+        // release fence is cheap; the counter is word 3 of the item's table, zeroed by the prep kernel, reset here) - no launch of its own.
+        __shared__ int s_last;
+        __threadfence();
+        __syncthreads();
+        const int item = tab_bcast ? 0 : b;
+        int* cnt = reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 3;
+        if (threadIdx.x == 0) {
+            const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = done == (tab_bcast ? (int)gridDim.x : G) - 1;
+            if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const int b0 = tab_bcast ? 0 : b, nb_ = tab_bcast ? (int)gridDim.x / G : 1;
+            for (int bi = b0 + (int)threadIdx.x; bi < b0 + nb_; bi += 64 * W) {
+                const double nat = sample_rate * ((double)ctl[(size_t)bi * 5 + 2] / 1e3);
+                const double a = exp(-2.1972245773362196 / nat * (double)Tseg * (double)TS);
+                double s = 0.0;
+                for (int g = 0; g < G; ++g) {
+                    chain_start[(size_t)bi * G + g] = (float)s;
+                    s = a * s + (double)__hip_atomic_load(zseg_dyn + (size_t)bi * G + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 }
 
@@ -286,10 +302,12 @@ int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ct
     const float* start_eq = segbuf + (size_t)B * C * G * 2 * S;
     float* zd = segbuf + dasp_sos_seg_floats((long)B * C, N, S, Tseg);
     float* start_dyn = zd + (size_t)B * G;
-    if (mode == 0) DASP_CHAIN_LAUNCH(0, 2, B * G, start_eq, (const float*)nullptr, zd);
-    else DASP_CHAIN_LAUNCH(1, 2, B * G, start_eq, (const float*)nullptr, zd);
-    hipLaunchKernelGGL(chain_dyn_chain_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ctl, (const float*)zd, start_dyn, B, G, (long)Tseg * 64 * kL,
-                       sample_rate);
+    // compressor scan-only pass; its last workgroup per item chains the smoothing state over the segments
+#define DASP_CHAIN_LAUNCH_PRE(MODE_)                                                                                                        \
+    hipLaunchKernelGGL((chain_fwd_kernel<kS, kL, kWC, MODE_, 2>), dim3(B * G), blk, 0, st, tab, bc, x, ctl, y, C, (int)N, nt, vec, sample_rate,  \
+                       eps, G, (int)Tseg, start_eq, (const float*)nullptr, zd, const_cast<float*>(tab), start_dyn)
+    if (mode == 0) DASP_CHAIN_LAUNCH_PRE(0); else DASP_CHAIN_LAUNCH_PRE(1);
+#undef DASP_CHAIN_LAUNCH_PRE
     if (mode == 0) DASP_CHAIN_LAUNCH(0, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
     else DASP_CHAIN_LAUNCH(1, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
 #undef DASP_CHAIN_LAUNCH

@@ -163,7 +163,7 @@ constexpr double OM_MIN = 1e-5;
 template <int S, int L>
 __global__ void __launch_bounds__(256)
 sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params, PeqSpec spec,
-                float* __restrict__ tab, double* __restrict__ dtab) {
+                float* __restrict__ tab, double* __restrict__ dtab, int nsq_seg = 0, double* __restrict__ segtab = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, NN = S2 * S2;
     __shared__ double sec[S][10];       // sg, om, kom, g1, g2, d, kappa, b1, b2
@@ -366,6 +366,80 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
         put_blk(tb + LY::PWA + ((S - 1 - k) * 64 + c) * 4, p, q, kap, 1);
     }
     PTRACE(45, 0);
+    // Segmented rows (few rows, dasp_hip.h): the per-item segment transition matrices Phi^(samples per segment) of both systems, i.e.
+    // nsq_seg more squarings of the Phi^L that wave 1 left behind - what sos_segprep_kernel computes from dtab in a launch of its own
+    // (same Phi, same triangular inner products, same order: the same bits), here with all four waves and a barrier per squaring.
+    if (segtab) {
+        constexpr int NTRI = S * (S + 1) / 2 * 4;
+        int nl = 0;
+        for (int v = L; v > 1; v >>= 1) ++nl;
+        double (*src)[NN] = (nl & 1) ? T2 : T1;         // where the log2(L) squarings above ended
+        double (*dst)[NN] = (nl & 1) ? T1 : T2;
+        for (int step = 0; step < nsq_seg; ++step) {
+            for (int e = tid; e < 2 * NTRI; e += 256) {
+                const int sys = e / NTRI, q = e % NTRI, blk = q >> 2;
+                const int kk = (blk >= 1) + (blk >= 3) + (blk >= 6) + (blk >= 10) + (blk >= 15) + (blk >= 21) + (blk >= 28);
+                const int jj = blk - kk * (kk + 1) / 2;
+                const int i = 2 * kk + ((q >> 1) & 1), j = 2 * jj + (q & 1);
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < S2; ++m) acc += src[sys][i * S2 + m] * src[sys][m * S2 + j];
+                dst[sys][i * S2 + j] = acc;
+            }
+            __syncthreads();
+            double (*tmp)[NN] = src; src = dst; dst = tmp;
+        }
+        for (int e = tid; e < 2 * NN; e += 256) segtab[(size_t)item * 2 * NN + e] = src[e / NN][e % NN];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented rows: the chain start(g + 1) = Phi_seg start(g) + z(g) over a row's segments (upwards for the forward system, downwards for
+// the adjoint one), in fp64 - sos_chain_kernel's arithmetic - run by the LAST workgroup of the scan-only pre-pass to finish instead of
+// by a launch of its own (a 64-thread kernel between two grid-filling ones costs a launch gap on both sides; the reference's training
+// batches are launch-bound). Every workgroup makes its end state visible device-wide (the pre-pass stores nothing else, so
+// the agent-scope release fence has next to nothing to write back), bumps the counter of its item - a word of the item's table that the
+// prep kernel zeroed - and the one that completes the count chains the item's rows, one wave per row, and resets the counter.
+template <int S, int W>
+__device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, int n_wg, const double* __restrict__ Phi, const float* z,
+                                                        float* __restrict__ start, int row0, int nrows, int G, int adjoint) {
+    constexpr int S2 = 2 * S;
+    __shared__ int s_last;
+    __shared__ double s_st[W][2][S2];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = done == n_wg - 1;
+        if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the table can serve another pre-pass
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int l = lane_id(), w = wave_id();
+    double prow[S2];
+#pragma unroll
+    for (int j = 0; j < S2; ++j) prow[j] = l < S2 ? Phi[l * S2 + j] : 0.0;
+    const int first = adjoint ? G - 1 : 0, step = adjoint ? -1 : 1;
+    for (int row = row0 + w; row < row0 + nrows; row += W) {
+        if (l < S2) {
+            s_st[w][0][l] = 0.0;
+            start[((size_t)row * G + first) * S2 + l] = 0.f;
+        }
+        wave_lds_sync();
+        int cur = 0;
+        for (int n = 0, g = first; n < G - 1; ++n, g += step) {
+            if (l < S2) {
+                double acc = (double)__hip_atomic_load(z + ((size_t)row * G + g) * S2 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < S2; ++j) acc += prow[j] * s_st[w][cur][j];
+                s_st[w][cur ^ 1][l] = acc;
+                start[((size_t)row * G + g + step) * S2 + l] = (float)acc;
+            }
+            wave_lds_sync();
+            cur ^= 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -376,7 +450,8 @@ template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
                float* __restrict__ carries, int C, int N, int nt, int vec,
-               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
+               float* __restrict__ chain_tab = nullptr, const double* __restrict__ segtab = nullptr, float* __restrict__ chain_start = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L;        // unpadded, swizzled tile images (common.hpp)
     constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
@@ -548,6 +623,12 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #endif      // -1: a ragged tile issues a data-dependent number of stores
         TRACE(4);
     }
+    if (SEG == 2 && chain_tab) {      // scan-only pre-pass: the last workgroup of the item (of the call, with a shared table) chains its rows
+        const int item = tab_bcast ? 0 : row / C;
+        chain_by_last_workgroup<S, W>(reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 1, tab_bcast ? (int)gridDim.x : C * G,
+                                      segtab + (size_t)item * 2 * S2 * S2, zseg, chain_start, tab_bcast ? 0 : item * C,
+                                      tab_bcast ? (int)gridDim.x / G : C, G, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -663,7 +744,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec,
                float* __restrict__ cnt_tab, const double* __restrict__ dtab, int mode, float* __restrict__ gout, int B,
-               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
+               float* __restrict__ chain_tab = nullptr, const double* __restrict__ segtab = nullptr, float* __restrict__ chain_start = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr bool GC = SEG != 2 && !(FLAGS & BWD_NOGC), GX = SEG != 2 && !(FLAGS & BWD_NOGX), FAST = GC && (FLAGS & BWD_FAST);
     constexpr int NACC = FAST ? 4 : 5;            // running correlation sums per section
@@ -1029,6 +1111,12 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         }
         TRACE(24);
     }
+    if (SEG == 2 && chain_tab) {      // adjoint scan-only pre-pass: chain downwards with the adjoint system's segment matrix (word 2 of the counters)
+        const int item = tab_bcast ? 0 : row / C;
+        chain_by_last_workgroup<S, W>(reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 2, tab_bcast ? (int)gridDim.x : C * G,
+                                      segtab + ((size_t)item * 2 + 1) * S2 * S2, zseg, chain_start, tab_bcast ? 0 : item * C,
+                                      tab_bcast ? (int)gridDim.x / G : C, G, 1);
+    }
     // per-wave partial sums -> partials[row][wave][S][5]
     if (!GC) return;
     float* po = partials + ((SEG ? (size_t)row * G + seg : (size_t)row) * W + wave) * S * 5;
@@ -1061,11 +1149,27 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         int* cnt = reinterpret_cast<int*>(cnt_tab + (size_t)item * LY::TOTAL + LY::CNT);
         if (threadIdx.x == 0) {
             const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_row = done == C - 1;
+            last_row = done == C * G - 1;           // (G = 1 unless the rows are segmented: then every (row, segment) workgroup counts)
             if (last_row) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the table can serve another backward pass
         }
         __syncthreads();
-        if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x, FAST ? 1 : 0);
+        if (!SEG) {
+            if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x, FAST ? 1 : 0);
+        } else if (last_row) {
+            // segmented rows leave C * G * W rows of sums per item: a wave per section, its lanes across the rows (sos_finalize_wave_kernel)
+            const int R = C * G * W;
+            for (int k = wave; k < S; k += W) {
+                const float* p0 = partials + ((size_t)item * R * S + k) * 5;
+                double a5[5] = {0, 0, 0, 0, 0};
+                for (int r = lane; r < R; r += 64) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) a5[i] += (double)__hip_atomic_load(p0 + (size_t)r * S * 5 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) a5[i] = wave_sum(a5[i]);
+                if (lane == 0) finish_section(dtab, 0, a5, B, S, mode, gout, item, k, FAST ? 1 : 0);
+            }
+        }
     }
 }
 
@@ -1247,6 +1351,13 @@ inline int check_launch() {
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// squarings that take Phi^L (what the prep kernel has after its chunk tables) to Phi^(64 L Tseg), one segment of Tseg tiles
+inline int seg_extra_squarings(long Tseg) {
+    int n = 0;
+    for (long v = 64L * Tseg; v > 1; v >>= 1) ++n;
+    return n;
+}
+
 template <typename F>
 int dispatch_S(int S, F&& f) {
     switch (S) {
@@ -1331,9 +1442,9 @@ int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, doubl
 
 /* The same design from 3 S separate control vectors (host array of device pointers, [3 k + dir] -> Bs values): what
  * functional.parametric_eq receives (functional.py:118-139), without packing them first. */
-int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
-                          void* stream) {
-    if (!rows || !types || !tab || !dtab || Bs <= 0 || S > 8 || S <= 0) return DASP_ERR_ARG;
+static int peq_prepare_rows_impl(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
+                                 long Tseg, double* segtab, void* stream) {
+    if (!rows || !types || !tab || !dtab || Bs <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1))))) return DASP_ERR_ARG;
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         PeqSpec spec = {};
@@ -1346,9 +1457,14 @@ int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* ty
             spec.rows[i] = rows[i];
         }
         spec.sample_rate = sample_rate;
-        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bs), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab);
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bs), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab,
+                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr);
         return check_launch();
     });
+}
+int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
+                          void* stream) {
+    return peq_prepare_rows_impl(rows, Bs, S, types, sample_rate, tab, dtab, 0, nullptr, stream);
 }
 
 int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries, int B, int C, long N,
@@ -1418,6 +1534,9 @@ int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, in
 #ifndef DASP_FUSED_FINALIZE
 #define DASP_FUSED_FINALIZE 0
 #endif
+#ifndef DASP_SEG_FUSED_FINALIZE
+#define DASP_SEG_FUSED_FINALIZE 1     // segmented rows (few rows: the step is launch-bound): finalize inside the backward launch (dasp_peq_backward)
+#endif
 int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
                                    float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, int designed,
                                    void* stream) {
@@ -1486,9 +1605,9 @@ int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, con
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         hipStream_t st = (hipStream_t)stream;
+        // scan-only pre-pass; its last workgroup per item chains the segments (chain_by_last_workgroup: the counter word lives in the table)
         hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 2>), dim3(B * C * G), dim3(64 * kWF), 0, st, tab, bc, x, (float*)nullptr,
-                           (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg, (const float*)nullptr, z);
-        hipLaunchKernelGGL((sos_chain_kernel<SS>), dim3(B * C), dim3(64), 0, st, segtab, bc, C, (const float*)z, start, G, 0);
+                           (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg, (const float*)nullptr, z, const_cast<float*>(tab), segtab, start);
         hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 1>), dim3(B * C * G), dim3(64 * kWF), 0, st, tab, bc, x, y, carries, C, (int)N, nt,
                            vec, G, (int)Tseg, (const float*)start, (float*)nullptr);
         return check_launch();
@@ -1510,16 +1629,17 @@ int dasp_sos_segment_starts(const float* tab, const double* segtab, int Bs, cons
         constexpr int SS = decltype(s)::value;
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 2>), dim3(B * C * G), dim3(64 * kWF), 0, st, tab, bc, x, (float*)nullptr,
-                           (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg, (const float*)nullptr, z);
-        hipLaunchKernelGGL((sos_chain_kernel<SS>), dim3(B * C), dim3(64), 0, st, segtab, bc, C, (const float*)z, start, G, 0);
+                           (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg, (const float*)nullptr, z, const_cast<float*>(tab), segtab, start);
         return check_launch();
     });
 }
 
 // gx / partials / designed as in dasp_sosfilt_backward_ex
-int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
-                                 float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
-                                 void* stream) {
+// fin_dtab != null (with one table per item and coefficient gradients asked for): the workgroup that completes an item's count maps its
+// partial sums to the gradients gout (mode as in dasp_sos_grad_finalize_ex) - no finalize launch
+static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
+                                     float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
+                                     const double* fin_dtab, int fin_mode, float* fin_gout, void* stream) {
     const int flags = bwd_flags(designed, gx, partials);
     if (!tab || !segtab || !gy || flags < 0 || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0) return DASP_ERR_ARG;
     if (!(flags & BWD_NOGC) && (!x || !carries)) return DASP_ERR_ARG;
@@ -1533,12 +1653,18 @@ int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs,
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 2>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, (float*)nullptr,
                            (float*)nullptr, C, (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg,
-                           (const float*)nullptr, z);
-        hipLaunchKernelGGL((sos_chain_kernel<SS>), dim3(B * C), dim3(64), 0, st, segtab, bc, C, (const float*)z, start, G, 1);
-        launch_bwd<SS, 1>(flags, B * C * G, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec, (float*)nullptr,
-                          (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg, (const float*)start, (float*)nullptr);
+                           (const float*)nullptr, z, const_cast<float*>(tab), segtab, start);
+        const bool fuse = fin_dtab && fin_gout && !bc && !(flags & BWD_NOGC);
+        launch_bwd<SS, 1>(flags, B * C * G, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec, fuse ? const_cast<float*>(tab) : (float*)nullptr,
+                          fuse ? fin_dtab : (const double*)nullptr, fin_mode, fuse ? fin_gout : (float*)nullptr, B, G, (int)Tseg, (const float*)start,
+                          (float*)nullptr);
         return check_launch();
     });
+}
+int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
+                                 float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
+                                 void* stream) {
+    return sosfilt_backward_seg_impl(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, designed, nullptr, 0, nullptr, stream);
 }
 
 int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
@@ -1559,11 +1685,11 @@ int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials
 int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, double sample_rate, float* tab, double* dtab,
                      const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
                      void* stream) {
-    int rc = dasp_peq_prepare_rows(rows, Bp, S, types, sample_rate, tab, dtab, stream);
+    // (segmented rows: the segment transition matrices come out of the design launch - no dasp_sos_segment_prepare launch)
+    const int rc = peq_prepare_rows_impl(rows, Bp, S, types, sample_rate, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
-    rc = dasp_sos_segment_prepare(dtab, Bp, S, Tseg, segtab, stream);
-    return rc != DASP_OK ? rc : dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    return dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
 }
 
 // The same from the normalised (Bp, 3 S) parameter tensor of Processor.process_normalized (dasp_pytorch/modules.py:25-91): de-normalisation
@@ -1571,9 +1697,9 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
 // when column i leaves [0, 1]; zero it before the call, read it back to raise the reference's ValueError; NULL = no check), design and
 // cascade in the two launches of dasp_peq_forward. dasp_peq_backward with mode 1 then returns the gradient w.r.t. the normalised tensor.
 // dasp_peq_prepare_norm is the design step on its own (tables only).
-int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
-                          unsigned* flag, float* tab, double* dtab, void* stream) {
-    if (!pn || !types || !lo || !span || !tab || !dtab || Bp <= 0 || S > 8 || S <= 0) return DASP_ERR_ARG;
+static int peq_prepare_norm_impl(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                                 unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, void* stream) {
+    if (!pn || !types || !lo || !span || !tab || !dtab || Bp <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1))))) return DASP_ERR_ARG;
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         PeqSpec spec = {};
@@ -1585,18 +1711,27 @@ int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, doub
         spec.sample_rate = sample_rate;
         spec.norm = 1;
         spec.flag = flag;
-        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bp), dim3(256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab);
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bp), dim3(256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab,
+                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr);
         return check_launch();
     });
+}
+/* Tseg > 0 (a power of two) with segtab: the design launch also leaves the segment transition matrices of dasp_sos_segment_prepare. */
+int dasp_peq_prepare_norm_seg(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                              unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, void* stream) {
+    return peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg, segtab, stream);
+}
+int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                          unsigned* flag, float* tab, double* dtab, void* stream) {
+    return peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, 0, nullptr, stream);
 }
 int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                           unsigned* flag, float* tab, double* dtab, const float* x, float* y, float* carries, int B, int C, long N, long Tseg,
                           double* segtab, float* segbuf, void* stream) {
-    int rc = dasp_peq_prepare_norm(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, stream);
+    const int rc = peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
-    rc = dasp_sos_segment_prepare(dtab, Bp, S, Tseg, segtab, stream);
-    return rc != DASP_OK ? rc : dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    return dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
 }
 
 // Backward of the same call: adjoint cascade + control gradients (mode as in dasp_sos_grad_finalize), the tables being the ones
@@ -1606,8 +1741,12 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream) {
     if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 1, stream);
-    const int rc = dasp_sosfilt_backward_seg_ex(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, stream);
-    if (rc != DASP_OK || !partials) return rc;
+    // one table per item: the last (row, segment) workgroup of an item finalizes it inside the backward launch (DASP_SEG_FUSED_FINALIZE=0
+    // at build time keeps the separate launch); a shared table (Bp == 1 < B) always takes the separate launch
+    const bool fuse = DASP_SEG_FUSED_FINALIZE && partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
+    const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, fuse ? dtab : nullptr, mode,
+                                             fuse ? gout : nullptr, stream);
+    if (rc != DASP_OK || !partials || fuse) return rc;
     return dasp_sos_grad_finalize_ex(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, 1, gout, stream);
 }
 

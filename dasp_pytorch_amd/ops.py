@@ -92,6 +92,10 @@ class _SosWork:
                  designed, stream())
             if need_gc:
                 call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, 1, mode, designed, ptr(gout), stream())
+        elif self.tseg and designed:
+            # segmented rows of a designed cascade: pre-pass (+ chain), adjoint pass (+ finalize in its last workgroup per item) - two launches
+            call("dasp_peq_backward", ptr(self.tab), ptr(self.dtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(part), mode,
+                 ptr(gout), B, C, N, self.S, self.tseg, ptr(self.segtab), ptr(self.segbuf), stream())
         elif self.tseg:
             call("dasp_sosfilt_backward_seg_ex", ptr(self.tab), ptr(self.segtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx),
                  ptr(part), ptr(self.segbuf), B, C, N, self.S, self.tseg, designed, stream())
@@ -625,10 +629,8 @@ def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mod
         tab, segbuf = f32[:n_tab], (f32[n_tab:] if tseg else None)
         dtab, segtab = f64[:n_dt], (f64[n_dt:] if tseg else None)
         y = torch.empty_like(x32)
-        call("dasp_peq_prepare_norm", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
-             (ctypes.c_double * (3 * S))(*span), ptr(None), ptr(tab), ptr(dtab), stream())
-        if tseg:
-            call("dasp_sos_segment_prepare", ptr(dtab), Bp, S, tseg, ptr(segtab), stream())
+        call("dasp_peq_prepare_norm_seg", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
+             (ctypes.c_double * (3 * S))(*span), ptr(None), ptr(tab), ptr(dtab), tseg, ptr(segtab), stream())      # design (+ segment matrices)
         call("dasp_chain_forward", ptr(tab), Bp, ptr(x32), ptr(c32), ptr(y), B, C, N, S, int(mode), float(sample_rate), float(eps), tseg,
              ptr(segtab), ptr(segbuf), stream())
     return y.to(x.dtype)

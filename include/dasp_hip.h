@@ -116,6 +116,9 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
 /* The design step of dasp_peq_forward_norm on its own: tables from the normalised (Bp, 3 S) tensor, no cascade. */
 int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                           unsigned* flag, float* tab, double* dtab, void* stream);
+/* ... and, with Tseg > 0 (a power of two) and segtab, also the segment transition matrices of dasp_sos_segment_prepare, from the same launch. */
+int dasp_peq_prepare_norm_seg(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
+                              unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, void* stream);
 /* The first two launches of dasp_sosfilt_forward_seg on their own (scan-only pre-pass + chain): afterwards the second half of segbuf
  * (dasp_sos_seg_floats floats) holds the state every (row, segment) starts from, [row][segment][2 S]. */
 int dasp_sos_segment_starts(const float* tab, const double* segtab, int Bs, const float* x, float* segbuf, int B, int C, long N, int S,
@@ -146,9 +149,12 @@ int dasp_biquad_design(const double* gain_db, const double* cutoff_freq, const d
 int dasp_biquad_backward(const double* jac, const double* gba, int n, double* gparams, void* stream);
 
 /* Few rows (B*C < 128): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
- * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, a
- * small kernel chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab), then the ordinary pass runs per
- * segment from its start state; same results (oracle/chunkscan_model.py forward_row_segmented / backward_row_segmented).
+ * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, the
+ * last of an item's workgroups to finish chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab; the
+ * completion counter is a word of the item's table, zeroed by the prepare call and reset after use - the one place where a call
+ * writes into `tab`), then the ordinary pass runs per segment from its start state; same results (oracle/chunkscan_model.py
+ * forward_row_segmented / backward_row_segmented). Launches per direction: pre-pass, pass (dasp_peq_forward / dasp_peq_backward: the
+ * design launch also produces segtab and the last workgroup of the adjoint pass finalizes the gradients - five launches per step).
  *   Tseg   = dasp_sos_segment_tiles(rows, N): proposed tiles per segment (a power of two), 0 = use the plain calls
  *   segtab = dasp_sos_segtab_doubles(S) doubles per item (Bs items);  segbuf = dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch
  *   partials of the backward pass: dasp_sos_partial_floats(rows * dasp_sos_segments(N, Tseg), S) floats, finalized by
