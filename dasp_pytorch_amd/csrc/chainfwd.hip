@@ -185,7 +185,7 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
         {
             const float Kn = fmaf(q1024, K, read_lane(e, 63));       // the only work on the cross-wave chain of the smoothing state
             if (t + 1 < t1) mbox_publish(lds, LDS_MB + md_out, Kn, 0.f, t + 1);
-            else if (SEG == 2 && lane == 0) zseg_dyn[(size_t)b * G + seg] = Kn;
+            else if (SEG == 2 && lane == 0) __hip_atomic_store(zseg_dyn + (size_t)b * G + seg, Kn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (SEG == 2) { WIDE_PRIO(0); continue; }
         float g = fmaf(dpws, K, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x138, 0xf, 0xf, true)));
@@ -211,29 +211,40 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
     }
     if (SEG == 2 && chain_tab) {
         // The chain of the smoothing state over the item's segments, start(g + 1) = alpha^(samples per segment) start(g) + z(g) in fp64, by
-        // the last of the item's workgroups to finish (as sosfilt.hip's chain_by_last_workgroup: the pre-pass stores nothing but z, so the
-        // release fence is cheap; the counter is word 3 of the item's table, zeroed by the prep kernel, reset here) - no launch of its own.
+        // the last of the item's workgroups to finish (as sosfilt.hip's chain_by_last_workgroup; the counter is word 3 of the item's table,
+        // zeroed by the prep kernel, reset here) - no launch of its own.
         __shared__ int s_last;
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (device-scope relaxed atomics instead of fences: see chain_by_last_workgroup, sosfilt.hip)
         __syncthreads();
         const int item = tab_bcast ? 0 : b;
         int* cnt = reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 3;
         if (threadIdx.x == 0) {
-            const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = done == (tab_bcast ? (int)gridDim.x : G) - 1;
             if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (s_last) {
-            __threadfence();
             const int b0 = tab_bcast ? 0 : b, nb_ = tab_bcast ? (int)gridDim.x / G : 1;
-            for (int bi = b0 + (int)threadIdx.x; bi < b0 + nb_; bi += 64 * W) {
-                const double nat = sample_rate * ((double)ctl[(size_t)bi * 5 + 2] / 1e3);
-                const double a = exp(-2.1972245773362196 / nat * (double)Tseg * (double)TS);
-                double s = 0.0;
-                for (int g = 0; g < G; ++g) {
-                    chain_start[(size_t)bi * G + g] = (float)s;
-                    s = a * s + (double)__hip_atomic_load(zseg_dyn + (size_t)bi * G + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // z of the item(s) into LDS first (the tile images are idle), all loads in flight together: they bypass this XCD's caches,
+            // and one inside the dependent chain cost ~2.5 us per segment
+            float* zs = cf_lds + LDS_CF;
+            constexpr int ZMAX = W * 2 * IMG;
+            for (int bi0 = b0; bi0 < b0 + nb_; bi0 += ZMAX / G) {
+                const int nbi = b0 + nb_ - bi0 < ZMAX / G ? b0 + nb_ - bi0 : ZMAX / G;
+                __syncthreads();
+                for (int e = threadIdx.x; e < nbi * G; e += 64 * W)
+                    zs[e] = __hip_atomic_load(zseg_dyn + (size_t)bi0 * G + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                for (int i = threadIdx.x; i < nbi; i += 64 * W) {
+                    const int bi = bi0 + i;
+                    const double nat = sample_rate * ((double)ctl[(size_t)bi * 5 + 2] / 1e3);
+                    const double a = exp(-2.1972245773362196 / nat * (double)Tseg * (double)TS);
+                    double s = 0.0;
+                    for (int g = 0; g < G; ++g) {
+                        chain_start[(size_t)bi * G + g] = (float)s;
+                        s = a * s + (double)zs[i * G + g];
+                    }
                 }
             }
         }

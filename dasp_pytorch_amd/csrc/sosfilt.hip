@@ -400,23 +400,33 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
 // batches are launch-bound). Every workgroup makes its end state visible device-wide (the pre-pass stores nothing else, so
 // the agent-scope release fence has next to nothing to write back), bumps the counter of its item - a word of the item's table that the
 // prep kernel zeroed - and the one that completes the count chains the item's rows, one wave per row, and resets the counter.
+__device__ __forceinline__ void seg_state_store(float* p, f2 v) {      // a segment's end state, visible to the other XCDs (see below)
+    __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int S, int W>
 __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, int n_wg, const double* __restrict__ Phi, const float* z,
-                                                        float* __restrict__ start, int row0, int nrows, int G, int adjoint) {
-    constexpr int S2 = 2 * S;
+                                                        float* __restrict__ start, int row0, int nrows, int G, int adjoint,
+                                                        float* __restrict__ scratch /* LDS, >= 64 * 2S floats per wave, idle by now */, int scratch_stride) {
+    constexpr int S2 = 2 * S, GB = 64;
     __shared__ int s_last;
     __shared__ double s_st[W][2][S2];
-    __threadfence();
+    // The workgroups of an item run on different XCDs, whose L2s are not coherent with each other. A release fence (__threadfence)
+    // makes every wave write back its XCD's L2 - measured: the pre-pass went from 14 to 60 us. Instead the few values that cross
+    // workgroups travel as device-scope relaxed atomics (write-through stores by the writers - seg_state_store below -, cache-bypassing
+    // loads here), each wave waits for the acknowledgement of its own stores (vmcnt), the barrier orders that before thread 0's counter
+    // increment: the protocol of the fused finalize of sos_bwd_kernel.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = done == n_wg - 1;
         if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the table can serve another pre-pass
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const int l = lane_id(), w = wave_id();
+    float* zs = scratch + w * scratch_stride;
     double prow[S2];
 #pragma unroll
     for (int j = 0; j < S2; ++j) prow[j] = l < S2 ? Phi[l * S2 + j] : 0.0;
@@ -426,18 +436,29 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
             s_st[w][0][l] = 0.0;
             start[((size_t)row * G + first) * S2 + l] = 0.f;
         }
-        wave_lds_sync();
         int cur = 0;
-        for (int n = 0, g = first; n < G - 1; ++n, g += step) {
-            if (l < S2) {
-                double acc = (double)__hip_atomic_load(z + ((size_t)row * G + g) * S2 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int j = 0; j < S2; ++j) acc += prow[j] * s_st[w][cur][j];
-                s_st[w][cur ^ 1][l] = acc;
-                start[((size_t)row * G + g + step) * S2 + l] = (float)acc;
+        // the end states of GB segments at a time into LDS, every load of a block in flight together: they come from other workgroups
+        // (other XCDs) and bypass this one's caches - a load inside the dependent chain below cost ~2.5 us per segment
+        for (int n0 = 0; n0 < G - 1; n0 += GB) {
+            const int nblk = G - 1 - n0 < GB ? G - 1 - n0 : GB;
+            wave_lds_sync();
+            for (int e = l; e < nblk * S2; e += 64) {
+                const int g = first + (n0 + e / S2) * step;
+                zs[e] = __hip_atomic_load(z + ((size_t)row * G + g) * S2 + e % S2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             wave_lds_sync();
-            cur ^= 1;
+            for (int i = 0; i < nblk; ++i) {
+                const int g = first + (n0 + i) * step;
+                if (l < S2) {
+                    double acc = (double)zs[i * S2 + l];
+#pragma unroll
+                    for (int j = 0; j < S2; ++j) acc += prow[j] * s_st[w][cur][j];
+                    s_st[w][cur ^ 1][l] = acc;
+                    start[((size_t)row * G + g + step) * S2 + l] = (float)acc;
+                }
+                wave_lds_sync();
+                cur ^= 1;
+            }
         }
     }
 }
@@ -544,7 +565,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             [&](int k, f2 Kn) {
                 if (W == 1) Kreg[k] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
                 else if (t + 1 < t1) mbox_publish<63>(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
-                else if (SEG == 2 && lane == 63) *reinterpret_cast<f2*>(zseg + ((size_t)row * G + seg) * S2 + 2 * k) = Kn;   // the segment's end state
+                else if (SEG == 2 && lane == 63) seg_state_store(zseg + ((size_t)row * G + seg) * S2 + 2 * k, Kn);   // the segment's end state
             }
 #ifdef DASP_TRACE
             , blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W
@@ -627,7 +648,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         const int item = tab_bcast ? 0 : row / C;
         chain_by_last_workgroup<S, W>(reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 1, tab_bcast ? (int)gridDim.x : C * G,
                                       segtab + (size_t)item * 2 * S2 * S2, zseg, chain_start, tab_bcast ? 0 : item * C,
-                                      tab_bcast ? (int)gridDim.x / G : C, G, 0);
+                                      tab_bcast ? (int)gridDim.x / G : C, G, 0, pw_lds + LDS_PW, 2 * IMG);      // (the tile images are idle now)
     }
 }
 
@@ -889,7 +910,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 [&](int i, f2 Kn) {
                     if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
                     else if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
-                    else if (SEG == 2 && lane == 63) *reinterpret_cast<f2*>(zseg + ((size_t)row * G + seg) * S2 + 2 * i) = Kn;   // state below the segment
+                    else if (SEG == 2 && lane == 63) seg_state_store(zseg + ((size_t)row * G + seg) * S2 + 2 * i, Kn);   // state below the segment
                 });
         }
         SCAN_PRIO(0);
@@ -1115,7 +1136,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         const int item = tab_bcast ? 0 : row / C;
         chain_by_last_workgroup<S, W>(reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 2, tab_bcast ? (int)gridDim.x : C * G,
                                       segtab + ((size_t)item * 2 + 1) * S2 * S2, zseg, chain_start, tab_bcast ? 0 : item * C,
-                                      tab_bcast ? (int)gridDim.x / G : C, G, 1);
+                                      tab_bcast ? (int)gridDim.x / G : C, G, 1, pw_lds + LDS_PW, REGION);       // (the tile images are idle now)
     }
     // per-wave partial sums -> partials[row][wave][S][5]
     if (!GC) return;
@@ -1161,9 +1182,15 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             for (int k = wave; k < S; k += W) {
                 const float* p0 = partials + ((size_t)item * R * S + k) * 5;
                 double a5[5] = {0, 0, 0, 0, 0};
-                for (int r = lane; r < R; r += 64) {
+                for (int r = lane; r < R; r += 128) {          // two rows of sums per lane and round trip
+                    float v[2][5];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) a5[i] += (double)__hip_atomic_load(p0 + (size_t)r * S * 5 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 5; ++i)
+                            v[h][i] = __hip_atomic_load(p0 + (size_t)(r + 64 * h < R ? r + 64 * h : r) * S * 5 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) a5[i] += (double)v[0][i] + (r + 64 < R ? (double)v[1][i] : 0.0);
                 }
 #pragma unroll
                 for (int i = 0; i < 5; ++i) a5[i] = wave_sum(a5[i]);
