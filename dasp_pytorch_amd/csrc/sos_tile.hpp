@@ -26,6 +26,9 @@
 #define DASP_PRIO_WIDE 1     // 1: also the load / transposition and store phases of a tile, i.e. everything but the cascade
 #endif
 #define WIDE_PRIO(p) do { if (DASP_SCAN_PRIO && DASP_PRIO_WIDE) __builtin_amdgcn_s_setprio(p); } while (0)
+#ifndef DASP_BWD_DIRECT_GX
+#define DASP_BWD_DIRECT_GX 0      // backward kernel: gx stored by every lane from its registers (64 contiguous bytes per lane) instead of through a staging image
+#endif
 #ifndef DASP_SPLIT_COUPLING
 #define DASP_SPLIT_COUPLING 0     // lane scan: the coupling sum of sections >= 3 on two accumulators (shorter dependent chain, one more packed
                                   // add). Measured: 0.396 -> 0.398 ms fwd + bwd, i.e. nothing (profiles/r02/ab_micro_variants.log)

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "sos_tile.hpp"
+#include <cstdlib>
 
 namespace dasp {
 
@@ -1125,9 +1126,20 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         WIDE_PRIO(DASP_SCAN_PRIO);
         __builtin_amdgcn_sched_barrier(0);
         if (GX) {
+#if DASP_BWD_DIRECT_GX
+            if (full) {       // experiment: every lane stores its chunk (64 contiguous bytes) itself - no staging image, partial lines merge in L2
+                f4* o = reinterpret_cast<f4*>(gxr + (size_t)t * TS + cl * L);
+#pragma unroll
+                for (int k = 0; k < L / 4; ++k) o[k] = f4{GY[4 * k], GY[4 * k + 1], GY[4 * k + 2], GY[4 * k + 3]};
+            } else {
+                chunks_to_lds_swz<L>(tbo, GY, cl);
+                tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+            }
+#else
             chunks_to_lds_swz<L>(tbo, GY, cl);
             if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
             else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+#endif
             stores_in_flight = full ? L / 4 : 0;
         }
         TRACE(24);
@@ -1196,6 +1208,333 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 for (int i = 0; i < 5; ++i) a5[i] = wave_sum(a5[i]);
                 if (lane == 0) finish_section(dtab, 0, a5, B, S, mode, gout, item, k, FAST ? 1 : 0);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward, three waves per SIMD (S = 6, designed cascade, coefficient gradients wanted, one workgroup per row) - an experiment that LOST
+// (numbers at the dispatch switch below, DASP_BWD_3W); selectable with DASP_BWD_KERNEL=3w, covered by tests/test_gpu_sosfilt.py.
+// sos_bwd_kernel above holds the kept signals of all six sections at once (102 registers; 255 in all) and three 4 KiB tile images per
+// wave: two waves per SIMD, and a wave issues at most one VALU instruction per ~6 cycles whatever its instruction-level parallelism
+// (tools/ubench) - a SIMD with two waves cannot use more than two thirds of its issue slots, and every lane-scan / LDS / mailbox phase of
+// one wave has only one partner to hide behind. This variant fits three waves per SIMD (<= 168 registers, ~12 KiB of LDS per wave, six
+// waves per row, two rows per CU):
+//   * checkpointed recomputation: sections 0..2 run forward once WITHOUT keeping anything (their output is the input of section 3);
+//     sections 3..5 are recomputed keeping their signals (51 registers) and their adjoints 5, 4, 3 run; then the tile's x is read from its
+//     LDS image a second time, sections 0..2 are recomputed keeping theirs in the same registers, and adjoints 2, 1, 0 run. Price: three
+//     section-passes of the cheap kind per tile (+ ~190 of ~1,600 VALU instructions);
+//   * two tile images per wave instead of three: gx leaves the registers directly (every lane stores its chunk, 64 contiguous bytes;
+//     partial lines merge in L2 - measured against the staged stores in the old kernel: +1 %), and the chunk products' D registers
+//     go through the states region (3 KiB: [row group][chunk] float4, the 12 meaningful rows only) once the states have been read;
+//   * the next tile's x is requested when the second pass over x starts (about 45 % of a tile ahead), gy at the top, the states after
+//     the lane scan.
+// Arithmetic, tables, saved states, partial sums and the finalize step are those of sos_bwd_kernel (same sums in the same order per wave,
+// except that a row's tiles are dealt to six waves instead of four).
+template <int S, int L, int W, int FLAGS>
+__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
+sos_bwd3w_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
+                 const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
+                 float* __restrict__ partials, int C, int N, int nt, int vec) {
+    using LY = SosLayout<S, L>;
+    static_assert(S == 6 && L == 16, "checkpoint split 3 + 3, 16-sample chunks");
+    constexpr bool GX = !(FLAGS & BWD_NOGX), FAST = FLAGS & BWD_FAST;
+    constexpr int NACC = FAST ? 4 : 5, KEEP = FAST ? L + 1 : L + 2, HS = S / 2;
+    constexpr int TS = 64 * L, IMG = 64 * L, STR = S * 128, REGION = 2 * IMG + STR;      // floats per wave: gy image, x image, states
+#ifndef DASP_BWD3_PAD
+#define DASP_BWD3_PAD 0        // measurement builds: floats of unused LDS per workgroup (lowers the number of workgroups a CU holds)
+#endif
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 24, LDS_A = 256;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MB + LDS_CF + LDS_A + LDS_PW + LDS_T + DASP_BWD3_PAD];
+    const int lane0 = lane_id(), lane = lane0, wave = wave_id(), row = blockIdx.x;
+    const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
+    const float* __restrict__ xr = x + (size_t)row * N;
+    const float* __restrict__ gr = gy + (size_t)row * N;
+    float* __restrict__ gxr = gx + (size_t)row * N;
+    const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;
+    float* cf_lds = lds + LDS_MB;
+    float* a_lds = cf_lds + LDS_CF;                // A operands of the chunk products, [lane] f4 (loop invariant: kept here, not in registers)
+    float* pw_lds = a_lds + LDS_A;
+    float* tbg = pw_lds + LDS_PW + wave * REGION;  // gy image of this tile, then scratch of the chunk products, then the next tile's gy
+    float* tbx = tbg + IMG;                        // x image: read twice per tile, then handed to the next tile's request
+    float* tst = tbx + IMG;                        // saved chunk states [section pair][chunk] f4: read three times per tile, then likewise
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
+    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
+    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 16 + i] = tb[LY::MN + i];
+    if (wave == 0) {
+        float Aop[4];
+        chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
+        *reinterpret_cast<f4*>(a_lds + 4 * lane) = f4{Aop[0], Aop[1], Aop[2], Aop[3]};
+    }
+    __syncthreads();
+    const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
+    float acc[S][NACC], Tacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[k][i] = 0.f;
+    const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
+                   a_s = __builtin_amdgcn_readfirstlane(lds_addr(tst));
+    auto dma_states = [&](int tt, int lane) {
+        const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
+#pragma unroll
+        for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
+    };
+    if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) {
+        tile_dma_issue_swz(gr + (size_t)(nt - 1 - wave) * TS, a_g, lane);
+        tile_dma_issue_swz(xr + (size_t)(nt - 1 - wave) * TS, a_x, lane);
+        dma_states(nt - 1 - wave, lane);
+    }
+    int stores_in_flight = 0;
+    const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
+
+    for (int r = wave; r < nt; r += W) {
+        const int t = nt - 1 - r;
+        int toff = 0;
+        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
+        const float* __restrict__ tbl = tb + toff;
+        const bool full = tile_full<L>((long)t * TS, N, vec);
+        const bool more = r + W < nt;                      // (tiles below a row's last one are always full)
+        // the lane index passes through an opaque move once per tile: left visible, every LDS / global address of the loop body (swizzled
+        // granule offsets of three images, DMA sources, store pointers) is hoisted out of the loop, and at 168 registers those ~20
+        // loop invariants are spilled and reloaded - scratch loads in between the DMA requests, whose vmcnt waits then expose them
+        const int lane = lane0 + opaque_zero();
+        const int cl = 63 - lane;        // lane l works on chunk 63 - l: the adjoint lane scan is an ordinary ascending scan
+        float GY[L];
+        WIDE_PRIO(DASP_SCAN_PRIO);
+        if (full) {
+            if (GX && stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {      // ragged last tile of the row (cold): images and states by plain loads
+            tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
+            tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
+            const f4* cs = reinterpret_cast<const f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + lane;
+#pragma unroll 1
+            for (int m = 0; m < S / 2; ++m) *reinterpret_cast<f4*>(tst + (m * 64 + lane) * 4) = cs[m * 64];
+            wave_lds_sync();
+        }
+        lds_to_chunks_swz<L>(tbg, GY, cl);
+        f4 Bop[4], zacc[4];
+        chunk_products_load(tbg, Bop, lane);
+        float Z[L];
+        {
+            const f4 av = *reinterpret_cast<const f4*>(a_lds + 4 * (lane + opaque_zero()));
+            const float Aop[4] = {av.x, av.y, av.z, av.w};
+            pin(GY); pin(Bop);
+            chunk_products_issue(Bop, Aop, zacc);
+        }
+        chunk_products_collect<L>(tbg, zacc, Z, lane, cl);      // the gy image is free until the next tile is requested into it
+        pin(Z);
+        if (more) tile_dma_issue_swz(gr + (size_t)(t - W) * TS, a_g, lane);
+        f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
+        {
+            MboxPeek pk;
+            SCAN_PRIO(DASP_SCAN_PRIO);
+            tile_scan<S, L>(Z, [](f2 v) { return v; }, lam,
+                tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
+                [&](int i) { pk = mbox_peek(lds, mb_in + 4 * i); },
+                [&](int i, f2& K) {
+                    if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
+                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
+                },
+                [&](int i, f2 Kn) { if (t > 0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t); });
+        }
+        SCAN_PRIO(0);
+        pin(GY); pin(lam);
+        __builtin_amdgcn_sched_barrier(0);
+        float X[L];
+        float S2v[HS][KEEP];
+        // chunk start state of section k from the states region ([section pair][chunk] f4)
+        auto start_state = [&](int k, int oz) {
+            const f2 q = *reinterpret_cast<const f2*>(tst + ((k >> 1) * 64 + cl) * 4 + 2 * (k & 1) + oz);
+            return q;
+        };
+        // forward section k over the chunk in place over X; keep: K_k[n] (normal form: s2, direct form: w[n - 2]) into S2v[slot]
+        auto forward_sec = [&](int k, int slot, int oz, bool keep) {
+            const f2 st = start_state(k, oz);
+            float s1 = st.x, s2 = st.y;
+            const bool last = FAST && k == S - 1;
+            if ((direct >> k) & 1) {
+                const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
+                if (FAST) {
+                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + oz);       // b1 / b0, b2 / b0
+                    const f4 cq = *reinterpret_cast<const f4*>(cf_lds + S * 16 + k * 8 + 4 + oz);   // q, q / om, q sg / om
+                    float w2 = cq.y * s2, w1 = fmaf(cq.z, s2, cq.x * s1);
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        if (keep) S2v[slot][n] = w2;
+                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
+                        if (!last) X[n] = fmaf(cm.x, w1, fmaf(cm.y, w2, w));
+                        w2 = w1;
+                        w1 = w;
+                    }
+                    if (keep) S2v[slot][L] = w2;
+                } else {
+                    const float d = cf_lds[k * 8 + 5 + oz];                                         // b0
+                    const f2 cw = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 6 + oz);   // 1 / om, sg / om
+                    float w2 = cw.x * s2, w1 = fmaf(cw.y, s2, s1);
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        if (keep) S2v[slot][n] = w2;
+                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
+                        X[n] = fmaf(d, w, fmaf(cd.x, w1, cd.y * w2));
+                        w2 = w1;
+                        w1 = w;
+                    }
+                    if (keep) { S2v[slot][L] = w2; S2v[slot][KEEP - 1] = w1; }
+                }
+            } else {
+                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
+                const float nk = -ca.z;
+                if (FAST) {
+                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + 2 + oz);   // g1 / d, g2 / d
+                    const float q = cf_lds[S * 16 + k * 8 + 4 + oz];
+                    s1 *= q; s2 *= q;
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        if (keep) S2v[slot][n] = s2;
+                        if (!last) X[n] = fmaf(cm.x, s1, fmaf(cm.y, s2, u));
+                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                        s2 = fmaf(ca.y, s1, ca.x * s2);
+                        s1 = t1;
+                    }
+                    if (keep) S2v[slot][L] = s2;
+                } else {
+                    const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const float u = X[n];
+                        if (keep) S2v[slot][n] = s2;
+                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
+                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
+                        s2 = fmaf(ca.y, s1, ca.x * s2);
+                        s1 = t1;
+                    }
+                    if (keep) { S2v[slot][L] = s2; S2v[slot][KEEP - 1] = fmaf(ca.y, s1, ca.x * s2); }
+                }
+            }
+        };
+        // adjoint section k (descending time) + coefficient correlations, in place over GY (sos_bwd_kernel::adjoint)
+        auto adjoint = [&](int k, int slot, int oz) {
+            const int i = S - 1 - k;
+            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);           // sg, om, kom, g1
+            const float d = cf_lds[k * 8 + 5 + oz];                                     // b0
+            const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);   // b1, b2, -a1, -a2
+            float z1 = lam[i].x, z2 = fmaf(ca.y, lam[i].y, -ca.x * lam[i].x);
+            float c[NACC];
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) c[j] = acc[k][j];
+            if ((direct >> k) & 1) {
+#pragma unroll
+                for (int n = L - 1; n >= 0; --n) {
+                    const float g = GY[n];
+                    if (!FAST) c[0] = fmaf(g, S2v[slot][KEEP - 1 - (L - 1 - n)], c[0]);      // K[n + 2]
+                    c[NACC - 4] = fmaf(g, S2v[slot][n + 1], c[NACC - 4]);
+                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
+                    const float o = fmaf(d, g, z1);
+                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                    z2 = fmaf(cd.y, g, cd.w * o);
+                    c[NACC - 2] = fmaf(o, S2v[slot][n + 1], c[NACC - 2]);
+                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
+                    GY[n] = o;
+                }
+            } else {
+                const float nsg = -ca.x;
+#pragma unroll
+                for (int n = L - 1; n >= 0; --n) {
+                    const float g = GY[n];
+                    const float dlo = fmaf(nsg, S2v[slot][n], S2v[slot][n + 1]);              // D[n]
+                    if (!FAST) c[0] = fmaf(g, fmaf(nsg, S2v[slot][n + 1], S2v[slot][KEEP - 1 - (L - 1 - n)]), c[0]);
+                    c[NACC - 4] = fmaf(g, dlo, c[NACC - 4]);
+                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
+                    const float o = fmaf(d, g, z1);
+                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                    z2 = fmaf(cd.y, g, cd.w * o);
+                    c[NACC - 2] = fmaf(o, dlo, c[NACC - 2]);
+                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
+                    GY[n] = o;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) { pin(c[j]); acc[k][j] = c[j]; }
+        };
+        // phase A: sections 0..2 forward, nothing kept: X becomes the input of section 3
+        lds_to_chunks_swz<L>(tbx + opaque_zero_after(GY[0]), X, cl);
+        pin(X);
+#pragma unroll
+        for (int k = 0; k < HS; ++k) forward_sec(k, 0, opaque_zero_after(X[0]), false);
+        pin(X);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase B: sections 3..5 kept, adjoints 5, 4, 3 (X is dead once section 5 has been recomputed: T is taken in phase C)
+#pragma unroll
+        for (int k = HS; k < S; ++k) forward_sec(k, k - HS, opaque_zero_after(X[0]), true);
+        pin(S2v); pin(GY);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = S - 1; k >= HS; --k) adjoint(k, k - HS, opaque_zero_after(GY[0]));
+        pin(GY);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase C: the tile's x once more, sections 0..2 kept, adjoints 2, 1, 0
+        lds_to_chunks_swz<L>(tbx + opaque_zero_after(GY[0]), X, cl);
+        pin(X);
+#pragma unroll
+        for (int k = 0; k < HS; ++k) forward_sec(k, k, opaque_zero_after(X[0]), true);
+        pin(S2v); pin(GY); pin(X);
+        // the x image and the states have been read for the last time: the next tile's request (about 40 % of a tile ahead of its use)
+        if (more) {
+            tile_dma_issue_swz(xr + (size_t)(t - W) * TS, a_x, lane);
+            dma_states(t - W, lane);
+        }
+        if (FAST) {
+            // T = <adjoint input of section 2, its output> = sum GY X, X being the input of section 3 again, in units of 1 / (b0 of
+            // sections 0..2): <adjoint input, output> is the same number at every section boundary of a cascade (sos_bwd_kernel takes it
+            // at the last section, where its X would have to stay alive through phase B; rescaled to that convention after the loop)
+            float tt = Tacc;
+#pragma unroll
+            for (int n = 0; n < L; ++n) tt = fmaf(X[n], GY[n], tt);
+            pin(tt);
+            Tacc = tt;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = HS - 1; k >= 0; --k) adjoint(k, k, opaque_zero_after(GY[0]));
+        pin(GY);
+        WIDE_PRIO(DASP_SCAN_PRIO);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GX) {
+            if (full) {       // every lane stores its chunk (64 contiguous bytes); the partial lines of a wave instruction merge in L2
+                f4* o = reinterpret_cast<f4*>(gxr + (size_t)t * TS + cl * L);
+#pragma unroll
+                for (int k = 0; k < L / 4; ++k) o[k] = f4{GY[4 * k], GY[4 * k + 1], GY[4 * k + 2], GY[4 * k + 3]};
+            } else {
+#pragma unroll 1
+                for (int n = 0; n < L; ++n)
+                    if ((long)t * TS + cl * L + n < N) gxr[(size_t)t * TS + cl * L + n] = GY[n];
+            }
+            stores_in_flight = full ? L / 4 : 0;
+        }
+    }
+    // per-wave partial sums -> partials[row][wave][S][5]
+    float* po = partials + ((size_t)row * W + wave) * S * 5;
+    float vT = 0.f;
+    if (FAST) {       // T was taken at the input of section 3 (scale q_3 = 1 / (b0_0 b0_1 b0_2)); the finalize step expects the last section's scale
+        const float q3 = tb[LY::MN + HS * 8 + 4], ql = tb[LY::MN + (S - 1) * 8 + 4];
+        vT = wave_sum(Tacc) * (ql / q3);
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        float v[5];
+        v[0] = FAST ? vT : wave_sum(acc[k][0]);
+#pragma unroll
+        for (int i = 1; i < 5; ++i) v[i] = wave_sum(acc[k][NACC - 5 + i]);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) po[k * 5 + i] = v[i];
         }
     }
 }
@@ -1369,7 +1708,30 @@ constexpr int kWB = DASP_BWD_W;    // waves per row, backward (2 rows per CU -> 
 #ifndef DASP_BWD_W_ADJ
 #define DASP_BWD_W_ADJ 8
 #endif
-constexpr int kWBA = DASP_BWD_W_ADJ;   // ... of the adjoint-only variant (no coefficient gradients: ~100 registers, 8 KiB of LDS per wave - the
+constexpr int kWBA = DASP_BWD_W_ADJ;
+// The three-waves-per-SIMD backward kernel (sos_bwd3w_kernel: S = 6, coefficient gradients, one workgroup of kWB3 waves per row).
+// DASP_BWD_KERNEL=2w / 3w at run time overrides the build's default (developer A/B in one library).
+// MEASURED NEGATIVE (profiles/r03/ab_bwd3w*.log, same box, bwd + finalize at (256, 2, 131072)): two-wave kernel 0.256 ms; this one with six-wave
+// workgroups 0.349 - 0.361, with four-wave workgroups (three per CU) 0.284, and the same four-wave build with its LDS padded so that only
+// two workgroups fit a CU - two waves per SIMD again - 0.286: occupancy changes nothing, the + 11 % is the price of the extra recomputation.
+// The backward kernel is bound by VALU throughput (115.8 M VALU instructions per launch over 1024 SIMDs = 4.6 SIMD cycles per instruction
+// at 86 % VALU-busy, profiles/r01/v14_sq_counters.json), not by the latency a third wave would hide. Off by default; kept selectable.
+#ifndef DASP_BWD_3W
+#define DASP_BWD_3W 0
+#endif
+#ifndef DASP_BWD3_W
+#define DASP_BWD3_W 4
+#endif
+constexpr int kWB3 = DASP_BWD3_W;
+inline bool use_bwd3w(int S, int designed) {     // designed cascades only: the generic variant (five correlations per section) does not fit 168 registers without spills
+    static const int pick = [] {
+        const char* e = getenv("DASP_BWD_KERNEL");
+        if (e && e[0] == '2') return 0;
+        if (e && e[0] == '3') return 1;
+        return DASP_BWD_3W;
+    }();
+    return pick && S == 6 && designed;
+}   // ... of the adjoint-only variant (no coefficient gradients: ~100 registers, 8 KiB of LDS per wave - the
                                        // forward kernel's shape; with kWB waves it ran at 2 waves per SIMD and was latency-bound, 0.159 ms)
 
 inline int check_launch() {
@@ -1437,7 +1799,7 @@ long dasp_sos_table_floats(int S) {
 long dasp_sos_dtab_doubles(int S) { return (long)S * DT_STRIDE; }
 long dasp_sos_num_tiles(long N) { return (N + 64 * kL - 1) / (64 * kL); }
 long dasp_sos_carry_floats(long rows, long N, int S) { return rows * dasp_sos_num_tiles(N) * 2 * S * 64; }
-long dasp_sos_partial_floats(long rows, int S) { return rows * kWB * S * 5; }
+long dasp_sos_partial_floats(long rows, int S) { return rows * (kWB3 > kWB ? kWB3 : kWB) * S * 5; }
 
 // sos: (Bs, S, 6) fp32 rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Builds tables for Bs items.
 int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, void* stream) {
@@ -1518,6 +1880,16 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_sos_num_tiles(N);
     const int vec = (N % 4 == 0) && aligned16(gy) && (!x || aligned16(x)) && (!gx || aligned16(gx));
+    if (use_bwd3w(S, designed) && !(flags & BWD_NOGC)) {
+        const dim3 g(B * C), b(64 * kWB3);
+        hipStream_t st = (hipStream_t)stream;
+        const int bc = Bs == 1 && B != 1;
+        if (flags & BWD_NOGX)
+            hipLaunchKernelGGL((sos_bwd3w_kernel<6, kL, kWB3, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
+        else
+            hipLaunchKernelGGL((sos_bwd3w_kernel<6, kL, kWB3, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
+        return check_launch();
+    }
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         launch_bwd<SS, 0>(flags, B * C, (hipStream_t)stream, tab, Bs == 1 && B != 1, x, gy, carries, gx, partials, C, (int)N, nt, vec,
@@ -1539,12 +1911,13 @@ int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials,
     if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
         return DASP_ERR_ARG;
     const int n = B * S;
-    if (C * kWB * segments > 16)      // many rows of sums per item (segmented rows): one wave per (item, section)
+    const int wb = (segments == 1 && use_bwd3w(S, designed) ? kWB3 : kWB) * segments;      // rows of sums per signal row: the waves of the kernel that wrote them
+    if (C * wb > 16)      // many rows of sums per item (segmented rows): one wave per (item, section)
         hipLaunchKernelGGL(sos_finalize_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dtab,
-                           Bs == 1 && B != 1, partials, B, C, S, kWB * segments, mode, gout, designed ? 1 : 0);
+                           Bs == 1 && B != 1, partials, B, C, S, wb, mode, gout, designed ? 1 : 0);
     else
         hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
-                           Bs == 1 && B != 1, partials, B, C, S, kWB * segments, mode, gout, designed ? 1 : 0);
+                           Bs == 1 && B != 1, partials, B, C, S, wb, mode, gout, designed ? 1 : 0);
     return check_launch();
 }
 

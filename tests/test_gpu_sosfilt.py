@@ -497,3 +497,38 @@ def test_lfilter_via_fsm_matches_reference(D):
         D.signal.lfilter_via_fsm(torch.zeros(2, 2, 64, device="cuda:0"), torch.ones(2, 2, device="cuda:0"))      # signal.py:106: chs == 1
     with pytest.raises(NotImplementedError):
         D.signal.lfilter_via_fsm(torch.zeros(2, 1, 64, device="cuda:0"), torch.ones(2, 5, device="cuda:0"))
+
+
+def test_three_wave_backward_kernel_variant_agrees(D):
+    """sos_bwd3w_kernel (checkpointed recomputation, three waves per SIMD; measured slower than the shipped kernel and off by default,
+    profiles/r03/ab_bwd3w.log) stays correct: selected with DASP_BWD_KERNEL=3w in a fresh process (the switch is read once), it gives the
+    shipped kernel's input gradient and control gradients - with and without a gradient for x, full and ragged last tile."""
+    import subprocess, sys, tempfile, os
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import dasp_pytorch_amd as D
+from tests.test_gpu_sosfilt import random_params
+out = {}
+for B, C, N, gx in ((5, 2, 40000, True), (3, 1, 16384 * 3 + 777, True), (4, 2, 33000, False)):
+    g = np.random.default_rng(N)
+    x = torch.from_numpy((g.random((B, C, N)) * 2 - 1).astype(np.float32)).cuda().requires_grad_(gx)
+    w = torch.from_numpy(g.standard_normal((B, C, N)).astype(np.float32)).cuda()
+    cols = [torch.from_numpy(random_params(B, 3)[:, i].copy()).cuda().requires_grad_(True) for i in range(18)]
+    os.environ["DASP_SOS_SEGMENT"] = "0"
+    D.parametric_eq(x, 44100, *cols).backward(w)
+    out[f"gp{N}"] = torch.stack([c.grad for c in cols], 1).cpu().numpy()
+    if gx: out[f"gx{N}"] = x.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("2w", "3w"):
+            path = os.path.join(td, mode + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DASP_BWD_KERNEL=mode), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[mode] = dict(np.load(path))
+    for k in res["2w"]:
+        a, b = res["2w"][k], res["3w"][k]
+        tol = 2e-5 if k.startswith("gp") else 2e-6          # (the tiles of a row are dealt to the waves differently: other summation order)
+        assert np.abs(a - b).max() <= tol * np.abs(a).max(), (k, np.abs(a - b).max() / np.abs(a).max())
