@@ -163,6 +163,40 @@ def _time_steps(fn, steps=30, warmup=10):
     return (time.perf_counter() - t0) / steps
 
 
+def secondary_traffic(name):
+    """HBM bytes per fwd+bwd step of a secondary op from the newest profiles/r*/hbm_traffic_secondary.json that has it (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes, scripts/reverb_traffic.sh; null when no counter file covers the op)."""
+    key = {"noise_shaped_reverberation": "hbm_bytes_per_step"}.get(name)
+    if key is None:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_secondary.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            if tj.get("noise_mode", "explicit") == "generated" and key in tj:
+                return {"bytes": int(tj[key]), "file": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def mrstft_roofline(gpu_ms):
+    """The MR-STFT loss is compute-bound: its roofline is the fp32 vector peak. VALU instruction counts per launch come from the counter
+    file of scripts/mrstft_roofline.sh (profiles/rNN/mrstft_roofline.json, (16, 2, 131072), default resolutions); the duration is this
+    run's. frac = VALU instructions x 64 lanes / time / (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "mrstft_roofline.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            valu = sum(k["valu_insts"] for n, k in tj["kernels"].items() if "split_kernel" in n)
+            hbm = sum(k.get("hbm_bytes", 0) for n, k in tj["kernels"].items() if "split_kernel" in n)
+            peak = 256 * 4 * 32 * 2.4e9
+            return {"bound": "valu", "achieved": round(valu * 64 / (gpu_ms * 1e-3) / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "T lane-op/s",
+                    "frac": round(valu * 64 / (gpu_ms * 1e-3) / peak, 4), "valu_instructions_per_step": int(valu),
+                    "hbm_bytes_per_step": int(hbm), "hbm_frac_of_8TBps": round(hbm / (gpu_ms * 1e-3) / 8e12, 4), "counter_file": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def secondary(dev):
     """Short fwd+bwd timings of the other hot-path ops at their BASELINE.json configs (1 GPU, not the headline)."""
     res = {}
@@ -188,7 +222,15 @@ def secondary(dev):
         _lib.timers.start(every=1)
         for _ in range(10):
             step()
-        res[name]["gpu_ms_fwd_bwd"] = round(sum(sum(v) for v in _lib.timers.stop().values()) / 10, 4)
+        kt = _lib.timers.stop()
+        gpu_ms = sum(sum(v) for v in kt.values()) / 10
+        res[name]["gpu_ms_fwd_bwd"] = round(gpu_ms, 4)
+        res[name]["launch_calls"] = {k: len(v) // 10 for k, v in kt.items()}
+        # HBM roofline of the op on its algorithmic bytes over the GPU time of its library calls (HIP events, this run); `traffic` = bytes
+        # per step from the PMC counters where a counter file of this round's kernels exists (profiles/rNN/hbm_traffic_secondary.json)
+        a = bytes_per_cs * cs / (gpu_ms * 1e-3) / 1e9
+        res[name]["roofline"] = {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes": int(bytes_per_cs * cs), "traffic": secondary_traffic(name)}
         if note:
             res[name]["note"] = note
         del x, w
@@ -207,8 +249,9 @@ def secondary(dev):
              "same op on white noise x slow random envelope, -60 .. 0 dBFS", xmake=speechlike)
     bench_op("noise_shaped_reverberation", 128, 2, 262144,
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
-             2 * 1.354e9 / (128 * 2 * 262144),
-             "device-generated noise; bytes = SURVEY 8(d) compulsory traffic with noise as an input (2 x 1.354 GB)")
+             2 * 0.537e9 / (128 * 2 * 262144),
+             "noise generated inside the filter-bank kernels (device_noise=True): algorithmic bytes = x, y, gy, gx only (2 x 0.537 GB; SURVEY 8(d) "
+             "with the noise terms dropped). With the noise counted as an input (2 x 1.354 GB, the round-2 convention) multiply frac by 2.52")
     # the headline op as the reference's chain calls it (examples/style_transfer.py:150: first effect, its input needs no gradient) and
     # at the reference's training batch sizes (examples/style_transfer.py:403, auto_eq.py:231), where rows are cut into segments
     peq = lambda B: ([ctl1(lo, hi)(B) for lo, hi in PEQ_RANGES], lambda x, c: D.parametric_eq(x, SR, *c))
@@ -218,7 +261,7 @@ def secondary(dev):
              "reference training batch")
     bench_op("noise_shaped_reverberation_b8", 8, 2, 131072,
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
-             2 * 1.354e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
+             2 * 0.537e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
     # the reference's whole effect chain as its training loop calls it (examples/style_transfer.py:150-154: EQ -> compressor -> reverb -> gain
@@ -237,8 +280,10 @@ def secondary(dev):
     _lib.timers.start(every=1)
     for _ in range(10):
         chain_step()
+    kt = _lib.timers.stop()
     res["style_transfer_chain_b16"] = {"shape": [16, 1, 131072], "ms_fwd_bwd": round(t * 1e3, 3),
-                                       "gpu_ms_fwd_bwd": round(sum(sum(v) for v in _lib.timers.stop().values()) / 10, 4),
+                                       "gpu_ms_fwd_bwd": round(sum(sum(v) for v in kt.values()) / 10, 4),
+                                       "library_calls_per_step": sum(len(v) for v in kt.values()) // 10,
                                        "note": "EQ -> compressor -> reverb -> gain on normalised parameters, gradients for all 50 of them"}
     xs = (rnd(16, 2, 131072) * 0.6 - 0.3).requires_grad_(True)
     ys = rnd(16, 2, 131072) * 0.6 - 0.3
@@ -248,9 +293,47 @@ def secondary(dev):
         xs.grad = None
         loss_fn(xs, ys).backward()
     t = _time_steps(loss_step)
-    res["mrstft_loss"] = {"shape": [16, 2, 131072], "ms_fwd_bwd": round(t * 1e3, 3), "channel_samples_per_s": 16 * 2 * 131072 / t,
+    _lib.timers.start(every=1)
+    for _ in range(10):
+        loss_step()
+    gpu_ms = sum(sum(v) for v in _lib.timers.stop().values()) / 10
+    res["mrstft_loss"] = {"shape": [16, 2, 131072], "ms_fwd_bwd": round(t * 1e3, 3), "gpu_ms_fwd_bwd": round(gpu_ms, 4),
+                          "channel_samples_per_s": 16 * 2 * 131072 / t, "roofline": mrstft_roofline(gpu_ms),
                           "note": "3 resolutions (1024/120/600, 2048/240/1200, 512/50/240); compute-bound (7.4 transforms per input sample "
-                                  "and direction), HBM traffic is the two signals and the gradient"}
+                                  "and direction), HBM traffic is the two signals and the gradient; parity unpinned (auraloss absent)"}
+    # the reference's target synthesis (examples/style_transfer.py:293-299: the chain without gradients, every training step): EQ + compressor
+    # as one fused pass (csrc/chainfwd.hip) against the two separate forward calls
+    from dasp_pytorch_amd import ops as _ops
+    from dasp_pytorch_amd.functional import _PEQ_TYPES
+    elo = [float(r[0]) for r in PEQ_RANGES]
+    espan = [float(r[1] - r[0]) for r in PEQ_RANGES]
+    dlo = torch.tensor([r[0] for r in rng], device=dev)
+    dhi = torch.tensor([r[1] for r in rng], device=dev)
+    for B, C, N in ((256, 2, 131072), (16, 1, 262144)):
+        xf = rnd(B, C, N) * 2 - 1
+        pn = rnd(B, 18)
+        comp = rnd(B, 6) * (dhi - dlo) + dlo
+        ctl = torch.cat([comp[:, :3], comp[:, 4:]], 1).contiguous()
+        eqm = D.ParametricEQ(SR)
+        eqm.validate_range = False
+        ccols = [comp[:, i].contiguous() for i in range(6)]
+        out = {}
+        with torch.no_grad():
+            for tag, fn in (("separate", lambda: D.compressor(eqm.process_normalized(xf, pn), SR, *ccols)),
+                            ("fused", lambda: _ops.chain_eq_compressor_forward(xf, pn, _PEQ_TYPES, elo, espan, float(SR), ctl))):
+                tw = _time_steps(fn)
+                _lib.timers.start(every=1)
+                for _ in range(10):
+                    fn()
+                out[tag] = {"ms": round(tw * 1e3, 4), "gpu_ms": round(sum(sum(v) for v in _lib.timers.stop().values()) / 10, 4)}
+        cs = B * C * N
+        a = 8 * cs / (out["fused"]["gpu_ms"] * 1e-3) / 1e9
+        res[f"chain_forward_eq_compressor_b{B}"] = {"shape": [B, C, N], "separate": out["separate"], "fused": out["fused"],
+                                                    "gpu_ratio_fused_over_separate": round(out["fused"]["gpu_ms"] / out["separate"]["gpu_ms"], 3),
+                                                    "roofline": {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                 "frac": round(a / HBM_PEAK_GBS, 4), "algorithmic_bytes": 8 * cs, "traffic": None},
+                                                    "note": "forward only (no grad): 8 B per channel-sample fused, 16 B as two calls"}
+        del xf
     return res
 
 
