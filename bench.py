@@ -30,7 +30,7 @@ The JSON line also carries
   roofline     -- HBM roofline of the dominant kernel (the backward cascade): algorithmic bytes per launch / average launch duration,
                   measured live with HIP events on the launch stream in a separate, untimed pass directly behind the timed blocks (the
                   events need the kernels as separate entry points, which is not how the product issues them, so they stay out of the
-                  timed region); `traffic` = HBM bytes per launch from the PMC counters, read from profiles/<round>/hbm_traffic.json
+                  timed region; 240 back-to-back steps, events around every 4th launch of each entry point); `traffic` = HBM bytes per launch from the PMC counters, read from profiles/<round>/hbm_traffic.json
                   only if that file was produced from the kernel sources now loaded
   roofline_*   -- the same for the forward kernel and for forward+backward together
   cpu_baseline -- the reference itself (oracle/_ref, staged by __graft_entry__.build(); kind "reference") on the host cores on a
@@ -489,9 +489,12 @@ def main():
         # per-kernel durations: a separate, untimed pass right behind the timed blocks (warm clocks) with HIP events on the launch stream
         # around every C entry point. With the timers on, the ops issue design / cascade / adjoint / finalize as separate entry points
         # (the same kernels the one-call product path launches), so that each kernel gets its own pair of events.
+        # Events around every 4th launch of each entry point only, over 240 back-to-back steps: the chip runs these kernels at its power
+        # limit, and the idle microseconds an event pair inserts let the next kernel run at a higher clock - with events around every
+        # launch the kernels measured 4 % faster than rocprofv3 sees them in the uninstrumented step (profiles/r03/README.md).
         ramp(step, 0.25)
-        _lib.timers.start(every=1)
-        for _ in range(max(20, min(args.steps, 100))):
+        _lib.timers.start(every=4)
+        for _ in range(240):
             step()
         ktimes = _lib.timers.stop()
     finite = bool(torch.isfinite(x.grad).all().item()) and all(bool(torch.isfinite(c.grad).all().item()) for c in cols)

@@ -1,6 +1,6 @@
 """GPU parity of noise_shaped_reverberation against reference-generated goldens (same noise) and the numpy oracle.
 Tolerance: 2e-5 L-inf/peak for y / grad_x (fp32 FFTs of length 2^12..2^17; SURVEY measured 4.9e-6 for an fp32 FFT
-restatement), 1e-4 of the largest entry for the 25 control gradients."""
+restatement), 1e-4 of the largest entry for the 25 control gradients (measured: y / grad_x <= 8.2e-7, control gradients <= 1.9e-6)."""
 import numpy as np
 import pytest
 import torch
@@ -11,7 +11,7 @@ from tests.util import linf_peak, load_golden, record
 
 pytestmark = pytest.mark.gpu
 SR = 44100
-CTL_TOL = 2e-4      # the 25 control gradients on random shapes, of the largest entry (goldens: 1e-4)
+CTL_TOL = 1e-4      # the 25 control gradients, of the largest entry: the north_star bar (measured 3e-9 .. 1.9e-6, profiles/r03/parity_measured.jsonl)
 
 
 @pytest.fixture(scope="module")
