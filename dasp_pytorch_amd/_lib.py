@@ -98,9 +98,9 @@ SIGNATURES = {
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
     "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),
     "dasp_reverb_backward": (_i, [_p] * 19 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_forward_rng": (_i, [_p, ctypes.c_ulonglong] + [_p] * 11 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_backward_rng": (_i, [_p, _p, ctypes.c_ulonglong] + [_p] * 16 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_noise": (_i, [ctypes.c_ulonglong, _p, _i, _i, _l, _p]),
+    "dasp_reverb_forward_rng": (_i, [_p, ctypes.c_ulonglong, _p] + [_p] * 11 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_backward_rng": (_i, [_p, _p, ctypes.c_ulonglong, _p] + [_p] * 16 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_noise": (_i, [ctypes.c_ulonglong, _p, _p, _i, _i, _l, _p]),
 }
 
 

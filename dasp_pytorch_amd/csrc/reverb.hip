@@ -75,7 +75,8 @@ __device__ __forceinline__ void noise_pair(NoiseKey k, unsigned m, float& re, fl
 }
 // The same stream written out in the reference's layout (2B, nb, row_len): the test hook that lets the explicit-noise path and the oracle
 // see what the kernels generate (dasp_reverb_noise).
-__global__ void reverb_noise_kernel(unsigned long long seed, float* __restrict__ out, int nb, int row_len) {
+__global__ void reverb_noise_kernel(unsigned long long seed, const unsigned long long* __restrict__ seed_dev, float* __restrict__ out, int nb, int row_len) {
+    if (seed_dev) seed += *seed_dev;
     const int sid = blockIdx.y;                      // b * nb + band
     const int b = sid / nb, band = sid % nb;
     const NoiseKey key = noise_key(seed, (unsigned)sid);
@@ -172,7 +173,8 @@ template <int MODE, int ROUTE, bool GEN>
 __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const f2* __restrict__ wspec,
                                                          const float* __restrict__ gains, const float* __restrict__ decays, float* __restrict__ ir,
                                                          const float* __restrict__ gir, float* __restrict__ part, int nb, int L, int taps, int VQ, float limit,
-                                                         unsigned long long seed) {
+                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+    if (GEN && seed_dev) seed += *seed_dev;      // per-replay offset of a captured launch (the by-value seed is frozen at capture time)
     const int bsplit = gridDim.z, bper = (nb + bsplit - 1) / bsplit, band_lo = blockIdx.z * bper, band_hi = band_lo + bper < nb ? band_lo + bper : nb;
     __shared__ f2 lds[2 * FFT_LDS];
     __shared__ float red[FFT_T / 64][RV_BANDS_MAX][2];
@@ -697,7 +699,7 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
  * Saved for backward: H (sizes[7] complex) and, when A is not NULL, A (sizes[6] complex: the column transforms of x; pass NULL when no
  * gradient is needed and they go to a chunk-sized scratch instead: W2, sizes[12] complex).
  * Scratch: W (sizes[12] complex), Ah (sizes[13] complex), ir (sizes[8] floats). */
-static int reverb_forward_impl(const float* x, const float* noise, unsigned long long seed, const void* Fspec, const float* gains,
+static int reverb_forward_impl(const float* x, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                                const float* decays, const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
                                long N, int L, int taps, int nb, void* stream) {
     if (!x || !Fspec || !gains || !decays || !mix || !y || (!A && !W2) || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
@@ -722,7 +724,7 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
     const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit);
 #define DASP_FB_FWD(ROUTE_, GEN_)                                                                                                           \
     hipLaunchKernelGGL((fb_fused_kernel<0, ROUTE_, GEN_>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays, ir, (const float*)nullptr, \
-                       (float*)nullptr, nb, L, taps, d.VQ, limit, seed)
+                       (float*)nullptr, nb, L, taps, d.VQ, limit, seed, seed_dev)
     if (noise) { DASP_FB_FWD(1, false); DASP_FB_FWD(0, false); } else { DASP_FB_FWD(1, true); DASP_FB_FWD(0, true); }
 #undef DASP_FB_FWD
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
@@ -747,7 +749,7 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
 
 /* Backward.  gx (B,2,N); ggain, gdecay (B, nb); gmix (B).
  * Scratch: Ag, W (sizes[12] complex each), P (sizes[13] complex), gir (sizes[8] floats), part (sizes[11] floats), mix_part (sizes[10] floats). */
-static int reverb_backward_impl(const float* x, const float* gy, const float* noise, unsigned long long seed, const void* Fspec, const float* gains,
+static int reverb_backward_impl(const float* x, const float* gy, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                                 const float* decays, const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay,
                                 float* gmix, void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps,
                                 int nb, void* stream) {
@@ -780,7 +782,7 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
     const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)rv_band_split(B, d.nwin, nb));
 #define DASP_FB_BWD(ROUTE_, GEN_)                                                                                                           \
     hipLaunchKernelGGL((fb_fused_kernel<1, ROUTE_, GEN_>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr,         \
-                       (const float*)gir, part, nb, L, taps, d.VQ, limit, seed)
+                       (const float*)gir, part, nb, L, taps, d.VQ, limit, seed, seed_dev)
     if (noise) { DASP_FB_BWD(1, false); DASP_FB_BWD(0, false); } else { DASP_FB_BWD(1, true); DASP_FB_BWD(0, true); }
 #undef DASP_FB_BWD
     const int nfin = B * nb + B;                      // one wave per output value
@@ -793,35 +795,37 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
                         float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
                         void* stream) {
     if (!noise) return DASP_ERR_ARG;
-    return reverb_forward_impl(x, noise, 0ULL, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
+    return reverb_forward_impl(x, noise, 0ULL, nullptr, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
 }
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
                          const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
                          void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
                          void* stream) {
     if (!noise) return DASP_ERR_ARG;
-    return reverb_backward_impl(x, gy, noise, 0ULL, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
+    return reverb_backward_impl(x, gy, noise, 0ULL, nullptr, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
                                 taps, nb, stream);
 }
 /* The same two calls with the white noise generated inside the filter-bank kernels from `seed` (the counter-based stream documented at
  * the top of reverb.hip) instead of read from memory: nothing of size (2B, nb, L + taps - 1) exists. Forward and backward must be given
- * the same seed. dasp_reverb_noise writes that stream out in the reference's layout, out (2B, nb, L + taps - 1) - a test hook. */
-int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const void* Fspec, const float* gains, const float* decays, const float* mix,
+ * the same seed. seed_dev (may be NULL): one 64-bit word in device memory that is ADDED to `seed` when the kernels run - a launch captured
+ * into a HIP graph has its by-value seed frozen, the word lets every replay draw new noise (the caller bumps it between replays).
+ * dasp_reverb_noise writes the stream out in the reference's layout, out (2B, nb, L + taps - 1) - a test hook. */
+int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays, const float* mix,
                             float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
                             void* stream) {
-    return reverb_forward_impl(x, nullptr, seed, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
+    return reverb_forward_impl(x, nullptr, seed, seed_dev, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
 }
-int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const void* Fspec, const float* gains, const float* decays,
+int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
                              const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
                              void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
                              void* stream) {
-    return reverb_backward_impl(x, gy, nullptr, seed, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
+    return reverb_backward_impl(x, gy, nullptr, seed, seed_dev, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
                                 taps, nb, stream);
 }
-int dasp_reverb_noise(unsigned long long seed, float* out, int B, int nb, long row_len, void* stream) {
+int dasp_reverb_noise(unsigned long long seed, const unsigned long long* seed_dev, float* out, int B, int nb, long row_len, void* stream) {
     if (!out || B <= 0 || nb <= 0 || nb > RV_BANDS_MAX || row_len <= 0 || row_len >= (1L << 24) || (long)B * nb > 65535) return DASP_ERR_ARG;
     const unsigned gx = (unsigned)((row_len + 255) / 256 < 64 ? (row_len + 255) / 256 : 64);
-    hipLaunchKernelGGL(reverb_noise_kernel, dim3(gx, (unsigned)(B * nb)), dim3(256), 0, (hipStream_t)stream, seed, out, nb, (int)row_len);
+    hipLaunchKernelGGL(reverb_noise_kernel, dim3(gx, (unsigned)(B * nb)), dim3(256), 0, (hipStream_t)stream, seed, seed_dev, out, nb, (int)row_len);
     return rv_check();
 }
 

@@ -227,6 +227,7 @@ def noise_shaped_reverberation(
     noise: torch.Tensor = None,
     device_noise: bool = False,
     noise_seed: int = None,
+    noise_seed_offset: torch.Tensor = None,
 ):
     """Artificial reverberation from frequency-band noise shaping (reference: dasp_pytorch/functional.py:406-577).
     Mono input is duplicated to stereo and the output always has 2 channels, as in the reference.
@@ -237,8 +238,9 @@ def noise_shaped_reverberation(
     instead, inside the filter-bank kernels (a counter-based stream, csrc/reverb.hip: the noise tensor - 0.8 GB at the default sizes
     and 128 items - never exists, forward and backward recompute it); its 63-bit seed is `noise_seed`, or, when that is None, one draw
     from torch's global CPU generator per call - so torch.manual_seed makes it reproducible and successive calls differ, as with the
-    reference (inside a HIP-graph capture that draw happens once, at capture time: replays reuse the seed). `noise=` supplies the
-    noise tensor explicitly. The keywords are additions; Processor.process_normalized passes only the named parameters above."""
+    reference. Inside a HIP-graph capture that draw happens once, at capture time; `noise_seed_offset`, a 1-element int64 tensor
+    on x's device, is added to the seed when the kernels run - bump it once per replay (e.g. `offset.add_(1)` at the end of the
+    captured step) and every replay draws new noise. `noise=` supplies the noise tensor explicitly. The keywords are additions; Processor.process_normalized passes only the named parameters above."""
     assert num_bandpass_taps % 2 == 1, "num_bandpass_taps must be odd"
     bs, chs, seq_len = x.size()
     assert chs <= 2, "only mono/stereo signals are supported"
@@ -254,7 +256,8 @@ def noise_shaped_reverberation(
                                      band8_gain, band9_gain, band10_gain, band11_gain)
     band_decays = _StackColumns.apply(band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
                                       band7_decay, band8_decay, band9_decay, band10_decay, band11_decay)
-    return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise, noise_seed)
+    return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise, noise_seed,
+                                 noise_seed_offset)
 
 
 class _StackColumns(torch.autograd.Function):
@@ -274,7 +277,7 @@ class _StackColumns(torch.autograd.Function):
 
 
 def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False,
-                          noise_seed=None):
+                          noise_seed=None, noise_seed_offset=None):
     """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what the function above stacks its 24 + 1
     arguments into, and what NoiseShapedReverb.process_normalized has as slices of its de-normalised (bs, 25) tensor. x: (bs, 2, seq_len)."""
     bs = x.shape[0]
@@ -286,7 +289,8 @@ def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samp
             seed = int(noise_seed) if noise_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         else:
             noise = torch.randn(bs * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
-    return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed)
+    return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed,
+                                noise_seed_offset if seed is not None else None)
 
 
 def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):

@@ -754,13 +754,22 @@ def _filter_spectrum(filters, nb, taps, n_complex, dev):
     return Fspec
 
 
-def reverb_noise(seed, B, nb, row_len, device):
+def _seed_offset(t, dev):
+    """The optional per-replay seed offset: a 1-element int64 tensor on the op's device (read by the kernels when they run)."""
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype is torch.int64 and t.numel() == 1 and t.device == dev):
+        raise ValueError("noise_seed_offset must be a 1-element int64 tensor on x's device")
+    return t
+
+
+def reverb_noise(seed, B, nb, row_len, device, seed_offset=None):
     """The white-noise stream the filter-bank kernels generate for `seed` (dasp_reverb_forward_rng), written out in the reference's layout
     (2B, nb, row_len) (dasp_pytorch/functional.py:548). A test / inspection hook: the product never materialises it."""
     dev = torch.device(device)
     out = torch.empty(2 * B, nb, row_len, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        call("dasp_reverb_noise", ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), ptr(out), B, nb, row_len, stream())
+        call("dasp_reverb_noise", ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), ptr(_seed_offset(seed_offset, dev)), ptr(out), B, nb, row_len, stream())
     return out
 
 
@@ -772,7 +781,7 @@ class ReverbFunction(torch.autograd.Function):
     never exists in memory."""
 
     @staticmethod
-    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir, seed=None):
+    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir, seed=None, seed_offset=None):
         _lib.require_device(x, "x")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise RuntimeError("noise_shaped_reverberation: `noise` and `filters` are not differentiable inputs (detach them)")
@@ -801,6 +810,7 @@ class ReverbFunction(torch.autograd.Function):
                 if n32.numel() != 2 * B * nb * (L_ir + taps - 1):
                     raise RuntimeError(f"noise must hold (2 * {B}, {nb}, {L_ir + taps - 1}) values, got {tuple(noise.shape)}")
             useed = ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF) if noise is None else None
+            soff = _seed_offset(seed_offset, dev) if noise is None else None
             g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
             y = torch.empty_like(x32)
@@ -811,14 +821,14 @@ class ReverbFunction(torch.autograd.Function):
             W, H, Ah = _cbuf(sizes[12], dev), _cbuf(sizes[7], dev), _cbuf(sizes[13], dev)
             ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
             if noise is None:
-                call("dasp_reverb_forward_rng", ptr(x32), useed, ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
+                call("dasp_reverb_forward_rng", ptr(x32), useed, ptr(soff), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
                      ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
             else:
                 call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
                      ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
             if need_grad:
                 ctx.save_for_backward(x32, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H)
-                ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes], useed)
+                ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes], useed, soff)
         return y.to(x.dtype)
 
     @staticmethod
@@ -827,9 +837,9 @@ class ReverbFunction(torch.autograd.Function):
         xd, gd, gs, dd, ds, md, ms = ctx.meta
         if ctx.empty:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
-            return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None
+            return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None, None
         x32, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
-        B, N, L_ir, taps, nb, sizes, useed = ctx.cfg
+        B, N, L_ir, taps, nb, sizes, useed, soff = ctx.cfg
         dev = x32.device
         with torch.cuda.device(dev):
             gx = torch.empty_like(x32)
@@ -844,7 +854,7 @@ class ReverbFunction(torch.autograd.Function):
             tail = (ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P),
                     ptr(gir), ptr(part), ptr(mix_part), B, N, L_ir, taps, nb, stream())
             if useed is not None:
-                call("dasp_reverb_backward_rng", ptr(x32), ptr(_f32c(gy)), useed, *tail)
+                call("dasp_reverb_backward_rng", ptr(x32), ptr(_f32c(gy)), useed, ptr(soff), *tail)
             else:
                 call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), *tail)
-        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None
+        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None, None

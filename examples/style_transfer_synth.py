@@ -44,8 +44,10 @@ class EffectChain:
     """EQ -> compressor -> reverb -> gain, controls normalised to (0, 1): the reference's StyleTransferModel wiring
     (examples/style_transfer.py:150-154) on dasp_pytorch_amd.chain.StyleTransferChain, which folds the gain into the compressor."""
 
-    def __init__(self, sample_rate, ir_samples=65536):
-        self.chain = D.chain.StyleTransferChain(sample_rate, num_samples=ir_samples, device_noise=True)
+    def __init__(self, sample_rate, ir_samples=65536, noise_seed_offset=None):
+        # device_noise: the reverb's white noise is generated inside its filter-bank kernels. Its seed is a host draw per call, frozen when a
+        # launch is captured into a HIP graph: the offset word (a device int64 the step bumps) gives every replay new noise
+        self.chain = D.chain.StyleTransferChain(sample_rate, num_samples=ir_samples, device_noise=True, noise_seed_offset=noise_seed_offset)
         self.sizes = self.chain.num_params
 
     @property
@@ -76,7 +78,8 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
     dd.init("nccl", dev)
     torch.manual_seed(seed)                                   # identical predictor weights on every rank
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # different data per rank
-    chain = EffectChain(sample_rate, ir_samples)
+    noise_step = torch.zeros(1, dtype=torch.int64, device=dev) if graph else None
+    chain = EffectChain(sample_rate, ir_samples, noise_step)
     model = ControlPredictor(chain.num_controls, width).to(dev)
     whole = graph and world == 1                              # one GPU: the optimizer step is captured too (no collective in between)
     opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=whole)
@@ -108,6 +111,7 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
             loss = fwd_bwd(static["x"], static["target"])
             if whole:
                 opt.step()
+            noise_step.add_(1)                                # captured too: the next replay's reverbs draw different noise
             return loss
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

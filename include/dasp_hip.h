@@ -287,16 +287,18 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
  * sample index) - one 32-bit hash per (item, band, index), its halves a Box-Muller pair = the item's two noise rows - so the forward and
  * the backward pass recompute identical values and nothing of size (2B, nb, L + taps - 1) exists (0.82 GB at B = 128 and the default
  * sizes, which torch.randn wrote once and the two filter-bank kernels read once each). Both calls of a step take the same seed.
+ * seed_dev (may be NULL): one 64-bit device word added to `seed` when the kernels run - a launch captured into a HIP graph has its by-value
+ * seed frozen; bumping the word between replays gives every replay new noise.
  * dasp_reverb_noise writes the stream out in the reference's layout, out (2B, nb, row_len), row_len = L + taps - 1 < 2^24: a test hook
  * (the explicit-noise calls above, given that tensor, must reproduce the seeded calls). Specification: oracle/noise_stream.py. */
-int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const void* Fspec, const float* gains, const float* decays,
+int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
                             const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
                             long N, int L, int taps, int nb, void* stream);
-int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const void* Fspec, const float* gains,
+int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                              const float* decays, const float* mix, const void* A, const void* H, float* gx,
                              float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
                              float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
-int dasp_reverb_noise(unsigned long long seed, float* out, int B, int nb, long row_len, void* stream);
+int dasp_reverb_noise(unsigned long long seed, const unsigned long long* seed_dev, float* out, int B, int nb, long row_len, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stereo utilities.  Replace dasp_pytorch.functional.stereo_widener (dasp_pytorch/functional.py:580-605),

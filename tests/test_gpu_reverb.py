@@ -233,6 +233,14 @@ def test_generated_noise_equals_the_explicit_noise_path(D):
     xs = torch.rand(1, 2, 4000, device="cuda:0")
     cols = [torch.rand(1, device="cuda:0") for _ in range(24)] + [torch.ones(1, device="cuda:0")]
     run = lambda: D.noise_shaped_reverberation(xs, SR, *cols, num_samples=2048, num_bandpass_taps=127, device_noise=True)
+    # the per-replay offset word: seed + offset, read by the kernels when they run (what a captured launch varies between replays)
+    off = torch.tensor([5], dtype=torch.int64, device="cuda:0")
+    n_a = ops.reverb_noise(100, 1, 12, 300, "cuda:0", seed_offset=off)
+    assert torch.equal(n_a, ops.reverb_noise(105, 1, 12, 300, "cuda:0"))
+    run_off = lambda: D.noise_shaped_reverberation(xs, SR, *cols, num_samples=2048, num_bandpass_taps=127, device_noise=True, noise_seed=100, noise_seed_offset=off)
+    r5 = run_off(); off.add_(1); r6 = run_off()
+    r6b = D.noise_shaped_reverberation(xs, SR, *cols, num_samples=2048, num_bandpass_taps=127, device_noise=True, noise_seed=106)
+    assert float((r6 - r6b).abs().max()) < 1e-5 * float(r6.abs().max()) and float((r5 - r6).abs().max()) > 1e-2 * float(r5.abs().max())
     torch.manual_seed(99); a1 = run(); a2 = run()
     torch.manual_seed(99); b1 = run()
     # (one item: the bands are dealt out over workgroups that add into the impulse response with float atomics - equal to rounding, not to the bit)
