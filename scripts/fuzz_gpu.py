@@ -82,6 +82,24 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         yo = c["x_d"] * 10 ** ((g + c["mk"]) / 20)
         note("comp", "y", rel(y.detach().cpu().numpy(), yo), 3e-5, cfg + (look,))
         assert torch.isfinite(xt.grad).all() and all(torch.isfinite(q.grad).all() for q in cc)
+    # fused EQ -> compressor forward (csrc/chainfwd.hip) on mono / stereo x, plain and with forced segment lengths, against the exact
+    # recursions (EQ through the fp64 sos recursion, compressor core + one-pole recursion): valid at any length
+    if C <= 2:
+        from dasp_pytorch_amd import ops as _ops
+        from dasp_pytorch_amd.functional import _PEQ_TYPES
+        pn = rng.random((B, 18)).astype(np.float32)
+        pq = (pn.astype(np.float64) * (hi - lo) + lo)
+        tiles = rng.choice([0, 0, 16, 32])
+        if tiles: os.environ["DASP_CHAIN_SEGMENT_TILES"] = str(int(tiles))
+        else: os.environ.pop("DASP_CHAIN_SEGMENT_TILES", None)
+        ctl = np.stack([pc[:, 0], pc[:, 1], pc[:, 2], pc[:, 4], pc[:, 5]], 1).astype(np.float32)
+        with torch.no_grad():
+            yf = _ops.chain_eq_compressor_forward(T(x), T(pn), _PEQ_TYPES, [float(v) for v in lo], [float(v) for v in hi - lo], float(SR), T(ctl))
+        os.environ.pop("DASP_CHAIN_SEGMENT_TILES", None)
+        y1 = sosfilt_ref(orc.peq_sos(pq, SR), x)
+        c2 = orc._compressor_core(y1, SR, pd[:, 0], pd[:, 1], pd[:, 2], pd[:, 4], pd[:, 5], 1e-8, 0, np.float64)
+        g2 = one_pole_ref(c2["g_c"][:, 0], c2["alpha"][:, 0, 0])[:, None]
+        note("chainfwd", "y", rel(yf.cpu().numpy(), c2["x_d"] * 10 ** ((g2 + c2["mk"]) / 20)), 5e-5, cfg + (int(tiles),))
     # stereo utilities
     Tn = int(rng.integers(1, 6))
     xw = (rng.random((B, 2, N)) * 2 - 1).astype(np.float32); wd = rng.random((B, 1)).astype(np.float32)
@@ -110,6 +128,17 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         note("rev", "y", rel(y.detach().cpu().numpy(), yo), 5e-5, cfg + (Cr, L, taps)); note("rev", "gx", rel(xt.grad.cpu().numpy(), gxo), 5e-5, cfg + (Cr, L, taps))
         gp = torch.stack([q.grad for q in cr], 1).cpu().numpy(); gpo = np.concatenate([gg, gd, gm[:, None]], 1)
         note("rev", "gp", float(np.abs(gp - gpo).max() / np.abs(gpo).max()), 5e-4, cfg + (Cr, L, taps))
+        # the same call with the noise generated inside the kernels: the stream written out and fed back must reproduce it
+        from dasp_pytorch_amd import ops as _ops
+        seed = int(rng.integers(0, 2 ** 62))
+        nz = _ops.reverb_noise(seed, B, 12, L + taps - 1, dev)
+        outs = []
+        for kw in (dict(noise=nz), dict(device_noise=True, noise_seed=seed)):
+            xt = T(xr).requires_grad_(True); cr = [T(pr[:, i]).requires_grad_(True) for i in range(25)]
+            y = D.noise_shaped_reverberation(xt, SR, *cr, num_samples=L, num_bandpass_taps=taps, **kw); (y * T(wr)).sum().backward()
+            outs.append((y.detach().cpu().numpy(), xt.grad.cpu().numpy(), torch.stack([q.grad for q in cr], 1).cpu().numpy()))
+        note("rev_gen", "y", rel(outs[1][0], outs[0][0]), 1e-5, cfg + (Cr, L, taps)); note("rev_gen", "gx", rel(outs[1][1], outs[0][1]), 3e-6, cfg + (Cr, L, taps))
+        note("rev_gen", "gp", rel(outs[1][2], outs[0][2]), 2e-5, cfg + (Cr, L, taps))
 print("configs", n_cfg)
 if "worst_eq" in globals(): print("worst eq control-gradient row:", worst_eq)
 if eq_rows:
