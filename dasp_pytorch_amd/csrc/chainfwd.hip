@@ -308,6 +308,7 @@ int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ct
         return chk();
     }
     const int G = (int)dasp_sos_segments(N, Tseg);
+    if (G > 4096) return DASP_ERR_UNSUPPORTED;        // (the chain of the smoothing state stages an item's G segment states in LDS; the planner proposes <= 256)
     const int rc = dasp_sos_segment_starts(tab, segtab, Bs, x, segbuf, B, C, N, S, Tseg, stream);      // EQ scan-only pre-pass + chain
     if (rc != DASP_OK) return rc;
     const float* start_eq = segbuf + (size_t)B * C * G * 2 * S;

@@ -236,7 +236,8 @@ def noise_shaped_reverberation(
     num_bandpass_taps - 1) from the global *CPU* generator (functional.py:548) and copied to x's device -- so the same
     torch.manual_seed gives the same impulse responses as the reference. `device_noise=True` generates it on x's device
     instead, inside the filter-bank kernels (a counter-based stream, csrc/reverb.hip: the noise tensor - 0.8 GB at the default sizes
-    and 128 items - never exists, forward and backward recompute it); its 63-bit seed is `noise_seed`, or, when that is None, one draw
+    and 128 items - never exists, forward and backward recompute it); its 63-bit seed is `noise_seed` (giving a seed selects this
+    mode by itself), or, when that is None, one draw
     from torch's global CPU generator per call - so torch.manual_seed makes it reproducible and successive calls differ, as with the
     reference. Inside a HIP-graph capture that draw happens once, at capture time; `noise_seed_offset`, a 1-element int64 tensor
     on x's device, is added to the seed when the kernels run - bump it once per replay (e.g. `offset.add_(1)` at the end of the

@@ -606,6 +606,8 @@ def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mod
     synthesis (examples/style_transfer.py:293-299 runs the chain under no_grad every step). Refuses tensors that require a gradient."""
     _lib.require_device(x, "x")
     _lib.require_same_device(x, eq_params=eq_pn, ctl=ctl)
+    from .ops64 import require_fp32_ok
+    require_fp32_ok(x, "chain_eq_compressor_forward")       # fp32 kernel: float64 input is refused, not rounded behind the caller's back
     if torch.is_grad_enabled() and (x.requires_grad or eq_pn.requires_grad or ctl.requires_grad):
         raise RuntimeError("chain_eq_compressor_forward is forward-only: call it under torch.no_grad() or on detached tensors")
     _require_rows(x, ctl, 5, "ctl")
