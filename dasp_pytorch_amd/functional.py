@@ -284,6 +284,8 @@ def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samp
     bs = x.shape[0]
     filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
     seed = None
+    if noise_seed_offset is not None and (noise is not None or not (device_noise or noise_seed is not None)):
+        raise ValueError("noise_seed_offset only applies to the generated noise (device_noise=True or noise_seed=...)")
     if noise is None:
         if device_noise or noise_seed is not None:
             # one 63-bit draw from the global CPU generator (a host-side scalar: no device work, no sync) unless the caller fixed the seed
