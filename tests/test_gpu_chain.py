@@ -81,6 +81,21 @@ def test_fused_forward_equals_unfused_sequence(D, monkeypatch, B, C, N, tiles):
         assert linf_peak(yf.cpu().numpy(), y0.cpu().numpy()).max() < 5e-6
 
 
+@pytest.mark.parametrize("B,C,N,tiles", [(3, 2, 9000, None), (4, 1, 70000, None), (2, 2, 131072, 16)])
+def test_fused_forward_with_one_shared_eq(D, monkeypatch, B, C, N, tiles):
+    """The EQ broadcasts a parameter batch of 1 over the batch (functional.py:208-220, used by the reference's virtual-analog example): one
+    table shared by every workgroup, the segment counters of the pre-passes then count the whole call's workgroups."""
+    x, eq_pn, comp = make(B, C, N, 55 + B)
+    if tiles:
+        monkeypatch.setenv("DASP_CHAIN_SEGMENT_TILES", str(tiles))
+    yf = fused(x, eq_pn[:1], comp)
+    monkeypatch.delenv("DASP_CHAIN_SEGMENT_TILES", raising=False)
+    yu = unfused(D, x, eq_pn[:1], comp)
+    e = linf_peak(yf.cpu().numpy(), yu.cpu().numpy())
+    record(f"chain_fused_shared_eq[{B},{C},{N},{tiles}]", y=e.max())
+    assert e.max() < 5e-6, e
+
+
 @pytest.mark.parametrize("B,C,N", [(3, 2, 20000), (2, 1, 70001)])
 def test_fused_forward_vs_oracle(D, B, C, N):
     x, eq_pn, comp = make(B, C, N, 7 + B)
