@@ -532,3 +532,30 @@ np.savez(sys.argv[1], **out)
         a, b = res["2w"][k], res["3w"][k]
         tol = 2e-5 if k.startswith("gp") else 2e-6          # (the tiles of a row are dealt to the waves differently: other summation order)
         assert np.abs(a - b).max() <= tol * np.abs(a).max(), (k, np.abs(a - b).max() / np.abs(a).max())
+
+
+def test_segmented_hand_off_is_stable_over_many_launches(D):
+    """The segmented path hands a few values from workgroup to workgroup inside a launch (segment end states to the workgroup that chains
+    them, partial sums to the one that finalizes; device-scope relaxed atomics across XCDs). 300 back-to-back forward + backward
+    steps at a reference training shape must give the first step's outputs, input gradients and control gradients bit for bit - a stale
+    read of another XCD's value would show up as a different number."""
+    B, C, N = 8, 2, 131072
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    x = (torch.rand(B, C, N, device="cuda:0", generator=g) * 2 - 1).requires_grad_(True)
+    w = torch.randn(B, C, N, device="cuda:0", generator=g)
+    cols = [dev(random_params(B, 9)[:, i].copy()).requires_grad_(True) for i in range(18)]
+    from dasp_pytorch_amd import _lib
+    assert _lib.lib().dasp_sos_segment_tiles(B * C, N) > 0
+    first = None
+    for it in range(300):
+        x.grad = None
+        for c in cols:
+            c.grad = None
+        y = D.parametric_eq(x, SR, *cols)
+        y.backward(w)
+        cur = (y.detach().clone(), x.grad.clone(), torch.stack([c.grad for c in cols], 1).clone())
+        if first is None:
+            first = cur
+        elif it % 10 == 0 or it > 290:
+            assert all(torch.equal(a, b) for a, b in zip(cur, first)), it
+    torch.cuda.synchronize()
