@@ -73,8 +73,8 @@ SIGNATURES = {
     "dasp_dynamics_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
     "dasp_dyn_segment_tiles": (_l, [_l, _l]),
     "dasp_dyn_segments": (_l, [_l, _l]),
-    "dasp_dynamics_forward_seg": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p]),
-    "dasp_dynamics_backward_seg": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p]),
+    "dasp_dynamics_forward_seg": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p, _p]),
+    "dasp_dynamics_backward_seg": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p, _p]),
     "dasp_stereo_partial_floats": (_l, [_i, _l, _i, _l]),
     "dasp_widener_forward": (_i, [_p, _p, _p, _i, _l, _p]),
     "dasp_widener_backward": (_i, [_p] * 6 + [_i, _l, _p]),
@@ -96,10 +96,10 @@ SIGNATURES = {
     "dasp_ew64_backward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
-    "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_backward": (_i, [_p] * 19 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_forward_rng": (_i, [_p, ctypes.c_ulonglong, _p] + [_p] * 11 + [_i, _l, _i, _i, _i, _p]),
-    "dasp_reverb_backward_rng": (_i, [_p, _p, ctypes.c_ulonglong, _p] + [_p] * 16 + [_i, _l, _i, _i, _i, _p]),
+    "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
+    "dasp_reverb_backward": (_i, [_p] * 19 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
+    "dasp_reverb_forward_rng": (_i, [_p, ctypes.c_ulonglong, _p] + [_p] * 11 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
+    "dasp_reverb_backward_rng": (_i, [_p, _p, ctypes.c_ulonglong, _p] + [_p] * 16 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
     "dasp_reverb_noise": (_i, [ctypes.c_ulonglong, _p, _p, _i, _i, _l, _p]),
 }
 

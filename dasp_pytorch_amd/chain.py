@@ -92,9 +92,8 @@ class StyleTransferChain:
             else:
                 y = eq.process_normalized(x, eq_params)                     # fused de-normalise + design; no gradient for x: the no-gx kernel
                 y = DynamicsCtlFunction.apply(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
-            if y.shape[1] == 1:   # if mono copy to stereo (functional.py:493-495)
-                y = y.repeat(1, 2, 1)
-            return _functional._reverb_from_matrices(y, self.sample_rate, gains, decays, mix, **self.reverb._rev_kwargs)
+            # (mono: the reverb kernels read the one row for both output channels - no duplicated copy, functional.py:493-495)
+            return _functional._reverb_from_matrices(y, self.sample_rate, gains, decays, mix, decay_bound=self.reverb._decay_bound(), **self.reverb._rev_kwargs)
         self.gain._check_range(gain_params)
         self.compressor._check_range(comp_params)
         lo, span = self.gain._affine(gain_params)

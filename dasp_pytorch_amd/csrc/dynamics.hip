@@ -97,6 +97,43 @@ __device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_v
 }
 
 // ------------------------------------------------------------------------------------------------
+// Segmented items, fewer launches (as sosfilt.hip's chain_by_last_workgroup): the workgroups of an item count themselves in
+// a counter word that the caller keeps zeroed between calls (every use returns it to zero); the values that cross workgroups travel as
+// device-scope relaxed atomics, each wave waits for the acknowledgement of its own stores (vmcnt) before the barrier that precedes
+// thread 0's increment. Returns true (uniformly) in the workgroup that completed the count.
+constexpr int DY_GMAX = 256;       // segments per item the in-kernel chain stages in LDS (the planner proposes <= 256 workgroups in all)
+__device__ __forceinline__ bool dyn_last_workgroup(int* cnt, int n_wg) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = done == n_wg - 1;
+        if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+// start(g + 1) = a start(g) + z(g) upwards (adjoint = 0) or aend(g - 1) = a aend(g) + za(g) downwards, a = alpha^(samples per segment),
+// fp64 (dyn_chain_kernel's arithmetic) for item b, by the calling workgroup: z staged in LDS with all loads in flight together
+__device__ __forceinline__ void dyn_chain_item(const float* __restrict__ ctl, const float* z, float* __restrict__ start, int b, int G,
+                                               long seg_samples, double sample_rate, int adjoint) {
+    __shared__ float s_z[DY_GMAX];
+    for (int g = threadIdx.x; g < G; g += blockDim.x) s_z[g] = __hip_atomic_load(z + (size_t)b * G + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
+        const double a = exp(-2.1972245773362196 / nat * (double)seg_samples);
+        double s = 0.0;
+        if (!adjoint) {
+            for (int g = 0; g < G; ++g) { start[(size_t)b * G + g] = (float)s; s = a * s + (double)s_z[g]; }
+        } else {
+            for (int g = G - 1; g >= 0; --g) { start[(size_t)b * G + g] = (float)s; s = a * s + (double)s_z[g]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward. x, y (B, C, N); carries (B, nt) state entering each tile (may be null); lin_buf (B, N)
 // receives the linear gain when lookahead > 0 (the backward needs it at shifted positions).
 // SEG (few batch items: one workgroup per item leaves the chip idle - the reference trains with 8 to 32 items, examples/
@@ -108,7 +145,8 @@ template <int MODE, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W)
 dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y, float* __restrict__ carries,
                float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
-               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
+               int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr) {
     __shared__ float lds[W * 4];
     const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt;
@@ -154,7 +192,7 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
             for (int j = 0; j < DY_SUB; ++j) Kn = fmaf(it.a256, Kn, read_lane(E[j], 63));
             if (W == 1) Kreg = Kn;
             else if (t + 1 < t1) mbox_publish(lds, mb_out, Kn, 0.f, t + 1);
-            if (SEG == 2 && t + 1 == t1 && lane == 0) zseg[(size_t)b * G + seg] = Kn;      // the segment's end state
+            if (SEG == 2 && t + 1 == t1 && lane == 0) __hip_atomic_store(zseg + (size_t)b * G + seg, Kn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the segment's end state (read by the workgroup that chains the item)
         }
         if (SEG == 2) { DYN_PRIO(0); continue; }          // scan-only pre-pass
         if (carries && lane == 0) carries[(size_t)b * nt + t] = K;
@@ -182,6 +220,9 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
             }
         }
     }
+    if (SEG == 2 && counters) {       // scan-only pre-pass: the item's last workgroup chains its segments (no dyn_chain_kernel launch)
+        if (dyn_last_workgroup(counters + 4 * b, G)) dyn_chain_item(ctl, zseg, chain_start, b, G, (long)Tseg * DY_TS, sample_rate, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,7 +243,8 @@ __global__ void __launch_bounds__(64 * W)
 dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const float* __restrict__ gy,
                const float* __restrict__ carries, const float* __restrict__ lin_buf, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
-               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr) {
+               int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
+               int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr, float* __restrict__ gctl = nullptr) {
     __shared__ float lds[W * 4];
     __shared__ float ring[DMA ? W * DY_RING : 1];
     const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
@@ -327,7 +369,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             for (int j = DY_SUB - 1; j >= 0; --j) Rn = fmaf(it.a256, Rn, read_lane(Er[j], 63));
             if (W == 1) Rreg = Rn;
             else if (t > t0) mbox_publish(lds, mb_out, Rn, 0.f, t);
-            if (SEG == 2 && t == t0 && lane == 0) zseg[(size_t)b * G + seg] = Rn;       // the adjoint state below the segment
+            if (SEG == 2 && t == t0 && lane == 0) __hip_atomic_store(zseg + (size_t)b * G + seg, Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the adjoint state below the segment
         }
         DYN_PRIO(0);
         if (SEG == 2) { pending_stores = 0; continue; }    // adjoint scan-only pre-pass
@@ -373,9 +415,42 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
         pending_stores = fast ? C * DY_SUB : 0;       // a full tile issues exactly C * DY_SUB wave-wide stores; anything else: wait for all
         DTRACE(7);
     }
-    if (SEG == 2) return;
+    if (SEG == 2) {                   // adjoint scan-only pre-pass: the item's last workgroup chains its segments downwards
+        if (counters && dyn_last_workgroup(counters + 4 * b + 1, G)) dyn_chain_item(ctl, zseg, chain_start, b, G, (long)Tseg * DY_TS, sample_rate, 1);
+        return;
+    }
     float* po = partials + (((size_t)b * G + seg) * W + wave) * 5;
     const float v0 = wave_sum(acc_t), v1 = wave_sum(acc_r), v2 = wave_sum(acc_a), v3 = wave_sum(acc_w), v4 = wave_sum(acc_m);
+    if (SEG == 1 && counters) {
+        // the item's last workgroup maps its G * W rows of partial sums to the control gradients (dyn_finalize_kernel's arithmetic) - no
+        // finalize launch; the sums cross workgroups as device-scope atomics
+        if (lane == 0) {
+            const float v[5] = {v0, v1, v2, v3, v4};
+#pragma unroll
+            for (int i = 0; i < 5; ++i) __hip_atomic_store(po + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (dyn_last_workgroup(counters + 4 * b + 2, G) && wave == 0) {
+            const int Wn = G * W;
+            double a[5] = {0, 0, 0, 0, 0};
+            for (int w = lane; w < Wn; w += 64) {
+                const float* p = partials + ((size_t)b * Wn + w) * 5;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) a[i] += (double)__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[i] = wave_sum(a[i]);
+            if (lane == 0) {
+                const double atk = (double)ctl[(size_t)b * 5 + 2], nat = sample_rate * (atk / 1e3), alpha = exp(-2.1972245773362196 / nat);
+                float* o = gctl + (size_t)b * 5;
+                o[0] = (float)a[0];
+                o[1] = (float)a[1];
+                o[2] = (float)(a[2] * alpha * 2.1972245773362196 / (nat * nat) * (sample_rate / 1e3));   // d alpha / d attack_ms
+                o[3] = (float)a[3];
+                o[4] = (float)a[4];
+            }
+        }
+        return;
+    }
     if (lane == 0) { po[0] = v0; po[1] = v1; po[2] = v2; po[3] = v3; po[4] = v4; }
 }
 
@@ -512,7 +587,7 @@ long dasp_dyn_segment_tiles(long B, long N) {
 long dasp_dyn_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_dyn_num_tiles(N) + Tseg - 1) / Tseg : 1; }
 
 int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
-                              int C, long N, double sample_rate, float eps, int lookahead, long Tseg, void* stream) {
+                              int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream) {
     if (!x || !ctl || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1) || Tseg <= 0) return DASP_ERR_ARG;
     if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
     if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
@@ -529,14 +604,22 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
                        sample_rate, 0);                                                                                                         \
     hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 1>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, y, carries, lb, C, (int)N, nt, vec,        \
                        lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
-    if (mode == 0) { DASP_DYN_FWD_SEG(0); } else { DASP_DYN_FWD_SEG(1); }
+    /* counters: the pre-pass's last workgroup per item chains the segments - two launches instead of three */
+#define DASP_DYN_FWD_SEG2(MODE_)                                                                                                                 \
+    hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 2>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, (float*)nullptr, (float*)nullptr,          \
+                       (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z, counters, start); \
+    hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 1>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, y, carries, lb, C, (int)N, nt, vec,        \
+                       lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
+    if (counters && G <= DY_GMAX) { if (mode == 0) { DASP_DYN_FWD_SEG2(0); } else { DASP_DYN_FWD_SEG2(1); } }
+    else if (mode == 0) { DASP_DYN_FWD_SEG(0); } else { DASP_DYN_FWD_SEG(1); }
+#undef DASP_DYN_FWD_SEG2
 #undef DASP_DYN_FWD_SEG
     return dy_check();
 }
 
 int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
                                float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N, double sample_rate, float eps,
-                               int lookahead, long Tseg, void* stream) {
+                               int lookahead, long Tseg, int* counters, void* stream) {
     if (!x || !ctl || !gy || !carries || !gx || !gctl || !partials || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
         (mode != 0 && mode != 1) || Tseg <= 0)
         return DASP_ERR_ARG;
@@ -555,6 +638,20 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
                        sample_rate, 1);                                                                                                         \
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 1>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials,    \
                        C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
+    /* counters: chain by the pre-pass's last workgroup per item, control gradients by the adjoint pass's - two launches instead of four */
+#define DASP_DYN_BWD_SEG2(MODE_, DMA_)                                                                                                           \
+    hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 2>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, (float*)nullptr, \
+                       (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z, counters, start,\
+                       (float*)nullptr);                                                                                                        \
+    hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 1>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials,    \
+                       C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr, counters,           \
+                       (float*)nullptr, gctl)
+    if (counters && G <= DY_GMAX) {
+        if (mode == 0) { if (dma) { DASP_DYN_BWD_SEG2(0, true); } else { DASP_DYN_BWD_SEG2(0, false); } }
+        else { if (dma) { DASP_DYN_BWD_SEG2(1, true); } else { DASP_DYN_BWD_SEG2(1, false); } }
+        return dy_check();
+    }
+#undef DASP_DYN_BWD_SEG2
     if (mode == 0) { if (dma) { DASP_DYN_BWD_SEG(0, true); } else { DASP_DYN_BWD_SEG(0, false); } }
     else { if (dma) { DASP_DYN_BWD_SEG(1, true); } else { DASP_DYN_BWD_SEG(1, false); } }
 #undef DASP_DYN_BWD_SEG

@@ -173,7 +173,7 @@ template <int MODE, int ROUTE, bool GEN>
 __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restrict__ noise, const f2* __restrict__ spec, const f2* __restrict__ wspec,
                                                          const float* __restrict__ gains, const float* __restrict__ decays, float* __restrict__ ir,
                                                          const float* __restrict__ gir, float* __restrict__ part, int nb, int L, int taps, int VQ, float limit,
-                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int force) {
     if (GEN && seed_dev) seed += *seed_dev;      // per-replay offset of a captured launch (the by-value seed is frozen at capture time)
     const int bsplit = gridDim.z, bper = (nb + bsplit - 1) / bsplit, band_lo = blockIdx.z * bper, band_hi = band_lo + bper < nb ? band_lo + bper : nb;
     __shared__ f2 lds[2 * FFT_LDS];
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
     const float tw0 = (float)n0 * tstep;                                 // time of the window's first sample
     float dmax = 0.f;
     for (int band = 0; band < nb; ++band) dmax = fmaxf(dmax, fabsf(10.f * decays[b * nb + band] + 1.f));
-    if ((dmax * tstep * (float)FFT_N <= limit) != (ROUTE == 1)) return;        // uniform over the workgroup (and over the item's workgroups)
+    if (!force && (dmax * tstep * (float)FFT_N <= limit) != (ROUTE == 1)) return;        // uniform over the workgroup (and over the item's workgroups)
+    // (force: the caller vouches that every item belongs to this route - the other route's launch, empty but not free, is not issued)
     float accr[8], acci[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -375,13 +376,15 @@ __device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
 //                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of gy, k = 2p, 2p+1
 //                                 MODE 2: zero-padded impulse responses (L samples per row), imaginary part 0
+// src_shift: 1 = mono input, both signals of an item read row (sig >> 1) of src (the reference duplicates a mono input to stereo,
+// functional.py:493-495: here the duplicate never exists); 0 otherwise.
 template <int MODE>
 __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
-                                                          f2* __restrict__ A, ConvDims d, int L) {
+                                                          f2* __restrict__ A, ConvDims d, int L, int src_shift = 0) {
     __shared__ f2 lds[LoadGeom::LDS];
     const ColCfg g = col_config<LOAD_LOG>(d.logNA, threadIdx.x);
     const int p = blockIdx.y;
-    const long sig = blockIdx.z;
+    const long sig = blockIdx.z, srow = sig >> src_shift;
     const int jb = xcd_tile(blockIdx.x, gridDim.x) * g.TC + g.c;
     (void)mix;
     constexpr float scale = 1.f;
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
             r[q] = src[sig * L + (tt < L ? tt : L - 1)];
         } else if (MODE == 1 || q < 4) {                        // MODE 0: the upper half of the frame is padding
             const long n0 = (long)(2 * p) * d.Lb + tt, n1i = n0 + d.Lb;
-            if (!(MODE == 1 && q >= 4)) r[q] = src[sig * d.N + (n0 < d.N ? n0 : d.N - 1)];      // MODE 1, q >= 4: same sample as i[q - 4]
-            i[q] = src[sig * d.N + (n1i < d.N ? n1i : d.N - 1)];
+            if (!(MODE == 1 && q >= 4)) r[q] = src[srow * d.N + (n0 < d.N ? n0 : d.N - 1)];      // MODE 1, q >= 4: same sample as i[q - 4]
+            i[q] = src[srow * d.N + (n1i < d.N ? n1i : d.N - 1)];
         }
     }
 #pragma unroll
@@ -497,20 +500,27 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
 //           d loss / d mix = sum gy (wet - x) and sum gy wet = sum x c over a whole signal (the wet path and c are adjoint maps), so the
 //           wet signal is not kept for the backward pass
 //   MODE 2  grid (tiles, signals): gir[sig][r] = mix Re lo, r < L
+// x_shift: 1 = mono input x (B, 1, N): the dry signal (MODE 0) / the x of the mix gradient (MODE 1) of both of an item's signals is row
+// (sig >> 1). The input gradient stays per signal, gx (B, 2, N): the caller adds the two rows (one workgroup walking both signals of an
+// item to store their sum was measured at the reference's batch size: 16 -> 49 us, twice the serial work on half the workgroups).
 template <int MODE>
 __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
                                                           const float* __restrict__ gy, const float* __restrict__ mix,
-                                                          float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L) {
+                                                          float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L, int x_shift = 0) {
     __shared__ f2 lds[ColsGeom::LDS];
     __shared__ float red[ColsGeom::T / 64];
     const ColCfg g = col_config<COLS_LOG>(d.logNA, threadIdx.x);
-    const long sig = MODE == 1 ? blockIdx.z : blockIdx.y;
+    constexpr int nsum = 1;
+    const long sig0 = MODE == 1 ? (long)blockIdx.z : blockIdx.y;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const float inv = 1.f / (float)d.n1;
-    const float m = mix[sig >> 1];
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
-    float macc = 0.f;
+    float gsum_a[4] = {0.f, 0.f, 0.f, 0.f}, gsum_b[4] = {0.f, 0.f, 0.f, 0.f};
     const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
+    for (int sidx = 0; sidx < nsum; ++sidx) {
+    const long sig = sig0 + sidx, xrow = sig >> x_shift;
+    const float m = mix[sig >> 1];
+    float macc = 0.f;
     for (int p = p_lo; p < p_hi; ++p) {
         // the thread coordinates pass through an opaque move once per pair: without it every LDS / global address of the loop body is
         // hoisted out of the loop and the kernel needs 208 VGPRs (one workgroup per CU) instead of ~100
@@ -530,9 +540,9 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const long na = (long)(2 * p) * d.Lb + (gl.j + gl.T * q) * CV_NB + jbl, nbk = na + d.Lb;
-                const long ia = sig * d.N + (na < d.N ? na : d.N - 1), ib = sig * d.N + (nbk < d.N ? nbk : d.N - 1);
-                xa[q] = x[ia]; xb[q] = x[ib];
-                if (MODE == 1) { ga[q] = gy[ia]; gb[q] = gy[ib]; }
+                const long oa = na < d.N ? na : d.N - 1, ob = nbk < d.N ? nbk : d.N - 1;
+                xa[q] = x[xrow * d.N + oa]; xb[q] = x[xrow * d.N + ob];
+                if (MODE == 1) { ga[q] = gy[sig * d.N + oa]; gb[q] = gy[sig * d.N + ob]; }
             }
         }
 #pragma unroll
@@ -550,12 +560,14 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
                 } else {
                     const float ca = r[q] * inv, cb = i[q] * inv;
                     if (na < d.N) {
-                        out[sig * d.N + na] = fmaf(m, ca - ga[q], ga[q]);
+                        gsum_a[q] += fmaf(m, ca - ga[q], ga[q]);
                         macc = fmaf(xa[q], ca - ga[q], macc);
+                        if (sidx == nsum - 1) out[sig * d.N + na] = gsum_a[q];
                     }
                     if (nbk < d.N) {
-                        out[sig * d.N + nbk] = fmaf(m, cb - gb[q], gb[q]);
+                        gsum_b[q] += fmaf(m, cb - gb[q], gb[q]);
                         macc = fmaf(xb[q], cb - gb[q], macc);
+                        if (sidx == nsum - 1) out[sig * d.N + nbk] = gsum_b[q];
                     }
                 }
             }
@@ -563,6 +575,7 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
     }
     if (MODE == 1) {
         const float s = wave_sum(macc);
+        __syncthreads();                 // (red is reused by the second signal of a mono item)
         if (lane_id() == 0) red[wave_id()] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -570,6 +583,7 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
             for (int v = 0; v < ColsGeom::T / 64; ++v) a += red[v];
             mix_part[(sig * d.npairs + blockIdx.y) * gridDim.x + blockIdx.x] = a;
         }
+    }
     }
 }
 
@@ -628,6 +642,13 @@ inline int rv_chunk(long R, long frame_elems_per_signal) {
 inline float rv_weight_limit() {
     if (const char* e = getenv("DASP_REVERB_WEIGHT_LIMIT")) { const float v = (float)atof(e); if (v >= 0.f && v <= 8.f) return v == 0.f ? -1.f : v; }
     return RV_WEIGHT_LIMIT;
+}
+// decay_bound > 0: the caller vouches that no band decay exceeds it (Processor.process_normalized: the validated upper end of the parameter
+// range). If even that decay keeps an item on the envelope-inside-the-transform route, the per-band route's launch is not issued and the
+// kernel takes every item down route 1 without looking (a value beyond the bound then costs accuracy - the fp32 transform of widely spread
+// weights - not correctness of the launch structure). 0 = unknown: both launches, each item picks its route.
+inline int rv_only_route1(float decay_bound, float tstep, float limit) {
+    return decay_bound > 0.f && limit > 0.f && (10.f * decay_bound + 1.f) * tstep * (float)FFT_N <= limit;
 }
 // workgroups per (item, window) of the filter-bank kernel: the bands are dealt out when B * windows would leave most of the chip idle
 inline int rv_band_split(int B, int nwin, int nb) {
@@ -695,18 +716,21 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
     return rv_check();
 }
 
-/* Forward.  x (B,2,N); noise (2B, nb, L+taps-1); Fspec (sizes[4] complex); gains, decays (B, nb); mix (B); y (B,2,N).
+/* Forward.  x (B,Cx,N), Cx = 2, or 1 for a mono input that the reference duplicates to stereo (functional.py:493-495; here the copy never
+ * exists: both output channels read the one row); noise (2B, nb, L+taps-1); Fspec (sizes[4] complex); gains, decays (B, nb); mix (B); y (B,2,N).
  * Saved for backward: H (sizes[7] complex) and, when A is not NULL, A (sizes[6] complex: the column transforms of x; pass NULL when no
  * gradient is needed and they go to a chunk-sized scratch instead: W2, sizes[12] complex).
  * Scratch: W (sizes[12] complex), Ah (sizes[13] complex), ir (sizes[8] floats). */
 static int reverb_forward_impl(const float* x, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                                const float* decays, const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
-                               long N, int L, int taps, int nb, void* stream) {
+                               int Cx, long N, int L, int taps, int nb, float decay_bound, void* stream) {
     if (!x || !Fspec || !gains || !decays || !mix || !y || (!A && !W2) || !H || !W || !Ah || !ir || B <= 0 || N <= 0 || L <= 0 || taps <= 0 ||
         nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
+    if (Cx != 1 && Cx != 2) return DASP_ERR_ARG;
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
+    const int xs = Cx == 1 ? 1 : 0;         // mono input: both signals of an item read the one row of x (no duplicated copy)
     hipStream_t st = (hipStream_t)stream;
     const f2* tw = (const f2*)Fspec;
     const ConvDims one = ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N};
@@ -719,13 +743,14 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
     const float* taps_f = reinterpret_cast<const float*>(tw + (long)(nb + 1) * FFT_N);
     const float limit = rv_weight_limit();
     const float tstep = L > 1 ? 1.f / (float)(L - 1) : 0.f;
+    const int only1 = rv_only_route1(decay_bound, tstep, limit);
     hipLaunchKernelGGL(fb_wspectrum_kernel, dim3((unsigned)nb, (unsigned)B), dim3(FFT_T), 0, st, tw, taps_f, decays, (f2*)W, nb, taps, tstep);
     if ((long)L + taps - 1 >= (1L << 24)) return DASP_ERR_UNSUPPORTED;        // (the generator's sample index is a 24-bit factor; L <= 2^20 anyway)
     const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)bsplit);
 #define DASP_FB_FWD(ROUTE_, GEN_)                                                                                                           \
     hipLaunchKernelGGL((fb_fused_kernel<0, ROUTE_, GEN_>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)W, gains, decays, ir, (const float*)nullptr, \
-                       (float*)nullptr, nb, L, taps, d.VQ, limit, seed, seed_dev)
-    if (noise) { DASP_FB_FWD(1, false); DASP_FB_FWD(0, false); } else { DASP_FB_FWD(1, true); DASP_FB_FWD(0, true); }
+                       (float*)nullptr, nb, L, taps, d.VQ, limit, seed, seed_dev, only1)
+    if (noise) { DASP_FB_FWD(1, false); if (!only1) DASP_FB_FWD(0, false); } else { DASP_FB_FWD(1, true); if (!only1) DASP_FB_FWD(0, true); }
 #undef DASP_FB_FWD
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
         const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
@@ -737,27 +762,29 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
         hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, Hc,
                            (f2*)nullptr, (f2*)nullptr, one);
         // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
-        hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, x + s0 * N, (const float*)nullptr,
-                           tw, Ac, d.c, L);
+        hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, x + (s0 >> xs) * N,
+                           (const float*)nullptr, tw, Ac, d.c, L, xs);
         hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ac, (const f2*)nullptr, tw, Hc,
                            (f2*)W, (f2*)nullptr, d.c);
-        hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x + s0 * N, (const float*)nullptr,
-                           mix + s0 / 2, y + s0 * N, (float*)nullptr, d.c, L);
+        hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x + (s0 >> xs) * N,
+                           (const float*)nullptr, mix + s0 / 2, y + s0 * N, (float*)nullptr, d.c, L, xs);
     }
     return rv_check();
 }
 
-/* Backward.  gx (B,2,N); ggain, gdecay (B, nb); gmix (B).
+/* Backward.  gx (B,2,N) (mono input: the gradient w.r.t. x is the sum of its two rows, left to the caller); ggain, gdecay (B, nb); gmix (B).
  * Scratch: Ag, W (sizes[12] complex each), P (sizes[13] complex), gir (sizes[8] floats), part (sizes[11] floats), mix_part (sizes[10] floats). */
 static int reverb_backward_impl(const float* x, const float* gy, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                                 const float* decays, const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay,
-                                float* gmix, void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps,
-                                int nb, void* stream) {
+                                float* gmix, void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, int Cx, long N, int L,
+                                int taps, int nb, float decay_bound, void* stream) {
     if (!x || !gy || !Fspec || !gains || !decays || !mix || !A || !H || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
         !gir || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
+    if (Cx != 1 && Cx != 2) return DASP_ERR_ARG;
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
+    const int xs = Cx == 1 ? 1 : 0;         // mono input: x has one row per item; gx stays (B, 2, N), the caller adds its two rows
     hipStream_t st = (hipStream_t)stream;
     const f2* tw = (const f2*)Fspec;
     const ConvDims one = ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N};
@@ -769,21 +796,22 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
         // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
         hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + s0 * d.c.npairs * d.c.n1, tw,
                            (f2*)H + s0 * d.c.n1, (f2*)W, (f2*)P, d.c);
-        hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x + s0 * N,
-                           gy + s0 * N, mix + s0 / 2, gx + s0 * N, mix_part + s0 * d.c.npairs * d.ctiles, d.c, L);
+        hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw,
+                           x + (s0 >> xs) * N, gy + s0 * N, mix + s0 / 2, gx + s0 * N, mix_part + s0 * d.c.npairs * d.ctiles, d.c, L, xs);
         hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,
                            (const float*)nullptr, mix + s0 / 2, gir + s0 * L, (float*)nullptr, one, L);
     }
     // d/dgain, d/ddecay: the filter bank again, weighted by gir
     const float* taps_f = reinterpret_cast<const float*>(tw + (long)(nb + 1) * FFT_N);
     const float limit = rv_weight_limit();
+    const int only1 = rv_only_route1(decay_bound, L > 1 ? 1.f / (float)(L - 1) : 0.f, limit);
     hipLaunchKernelGGL(fb_wspectrum_kernel, dim3((unsigned)nb, (unsigned)B), dim3(FFT_T), 0, st, tw, taps_f, decays, (f2*)Ag, nb, taps,
                        L > 1 ? 1.f / (float)(L - 1) : 0.f);
     const dim3 fbgrid((unsigned)d.nwin, (unsigned)B, (unsigned)rv_band_split(B, d.nwin, nb));
 #define DASP_FB_BWD(ROUTE_, GEN_)                                                                                                           \
     hipLaunchKernelGGL((fb_fused_kernel<1, ROUTE_, GEN_>), fbgrid, dim3(FFT_T), 0, st, noise, tw, (const f2*)Ag, gains, decays, (float*)nullptr,         \
-                       (const float*)gir, part, nb, L, taps, d.VQ, limit, seed, seed_dev)
-    if (noise) { DASP_FB_BWD(1, false); DASP_FB_BWD(0, false); } else { DASP_FB_BWD(1, true); DASP_FB_BWD(0, true); }
+                       (const float*)gir, part, nb, L, taps, d.VQ, limit, seed, seed_dev, only1)
+    if (noise) { DASP_FB_BWD(1, false); if (!only1) DASP_FB_BWD(0, false); } else { DASP_FB_BWD(1, true); if (!only1) DASP_FB_BWD(0, true); }
 #undef DASP_FB_BWD
     const int nfin = B * nb + B;                      // one wave per output value
     hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 3) / 4), dim3(256), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
@@ -792,18 +820,18 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
 }
 
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays, const float* mix,
-                        float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
-                        void* stream) {
+                        float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, int Cx, long N, int L, int taps, int nb,
+                        float decay_bound, void* stream) {
     if (!noise) return DASP_ERR_ARG;
-    return reverb_forward_impl(x, noise, 0ULL, nullptr, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
+    return reverb_forward_impl(x, noise, 0ULL, nullptr, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, Cx, N, L, taps, nb, decay_bound, stream);
 }
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
                          const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
-                         void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
-                         void* stream) {
+                         void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, int Cx, long N, int L, int taps, int nb,
+                         float decay_bound, void* stream) {
     if (!noise) return DASP_ERR_ARG;
-    return reverb_backward_impl(x, gy, noise, 0ULL, nullptr, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
-                                taps, nb, stream);
+    return reverb_backward_impl(x, gy, noise, 0ULL, nullptr, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, Cx, N,
+                                L, taps, nb, decay_bound, stream);
 }
 /* The same two calls with the white noise generated inside the filter-bank kernels from `seed` (the counter-based stream documented at
  * the top of reverb.hip) instead of read from memory: nothing of size (2B, nb, L + taps - 1) exists. Forward and backward must be given
@@ -811,16 +839,16 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
  * into a HIP graph has its by-value seed frozen, the word lets every replay draw new noise (the caller bumps it between replays).
  * dasp_reverb_noise writes the stream out in the reference's layout, out (2B, nb, L + taps - 1) - a test hook. */
 int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays, const float* mix,
-                            float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, long N, int L, int taps, int nb,
-                            void* stream) {
-    return reverb_forward_impl(x, nullptr, seed, seed_dev, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, N, L, taps, nb, stream);
+                            float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, int Cx, long N, int L, int taps, int nb,
+                            float decay_bound, void* stream) {
+    return reverb_forward_impl(x, nullptr, seed, seed_dev, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, Cx, N, L, taps, nb, decay_bound, stream);
 }
 int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
                              const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
-                             void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, long N, int L, int taps, int nb,
-                             void* stream) {
-    return reverb_backward_impl(x, gy, nullptr, seed, seed_dev, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, N, L,
-                                taps, nb, stream);
+                             void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, int Cx, long N, int L, int taps, int nb,
+                             float decay_bound, void* stream) {
+    return reverb_backward_impl(x, gy, nullptr, seed, seed_dev, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, Cx, N,
+                                L, taps, nb, decay_bound, stream);
 }
 int dasp_reverb_noise(unsigned long long seed, const unsigned long long* seed_dev, float* out, int B, int nb, long row_len, void* stream) {
     if (!out || B <= 0 || nb <= 0 || nb > RV_BANDS_MAX || row_len <= 0 || row_len >= (1L << 24) || (long)B * nb > 65535) return DASP_ERR_ARG;

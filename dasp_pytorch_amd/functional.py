@@ -251,8 +251,8 @@ def noise_shaped_reverberation(
               band7_decay, band8_decay, band9_decay, band10_decay, band11_decay, mix):
         if c.numel() != bs:   # the reference's torch.stack(...).view(bs, 12) / mix.view(bs, 1, 1) (functional.py:498-544): no broadcasting
             raise RuntimeError(f"shape '[{bs}, 12]' is invalid for input of size {12 * c.numel()}")
-    if chs == 1:   # if mono copy to stereo (autograd sums the two channel gradients)
-        x = x.repeat(1, 2, 1)
+    # (chs == 1: the reference copies mono to stereo, functional.py:493-495; the kernels read the one row for both output channels,
+    # ops.ReverbFunction)
     band_gains = _StackColumns.apply(band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,
                                      band8_gain, band9_gain, band10_gain, band11_gain)
     band_decays = _StackColumns.apply(band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
@@ -278,9 +278,10 @@ class _StackColumns(torch.autograd.Function):
 
 
 def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False,
-                          noise_seed=None, noise_seed_offset=None):
+                          noise_seed=None, noise_seed_offset=None, decay_bound=0.0):
     """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what the function above stacks its 24 + 1
-    arguments into, and what NoiseShapedReverb.process_normalized has as slices of its de-normalised (bs, 25) tensor. x: (bs, 2, seq_len)."""
+    arguments into, and what NoiseShapedReverb.process_normalized has as slices of its de-normalised (bs, 25) tensor. x: (bs, 1 or 2, seq_len).
+    decay_bound > 0: the caller vouches that no band decay exceeds it (a validated parameter range) - lets the filter bank skip a launch."""
     bs = x.shape[0]
     filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
     seed = None
@@ -293,7 +294,7 @@ def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samp
         else:
             noise = torch.randn(bs * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
     return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed,
-                                noise_seed_offset if seed is not None else None)
+                                noise_seed_offset if seed is not None else None, float(decay_bound))
 
 
 def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):

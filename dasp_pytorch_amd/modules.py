@@ -125,6 +125,11 @@ class Processor:
             return
         check_unit_range(param_tensor, self.param_ranges)
 
+    def _range_is_enforced(self):
+        """True when the [0, 1] contract of process_normalized holds for this call: the check is on (inside a HIP-graph capture it is only
+        deferred - the caller validated in eager mode - not waived) or the caller already ran it (chain.StyleTransferChain)."""
+        return bool(self.validate_range or getattr(_validated, "on", False))
+
     def extract_param_dict(self, param_tensor: torch.Tensor):
         if param_tensor.shape[1] != len(self.param_ranges):
             raise ValueError(
@@ -296,6 +301,11 @@ class NoiseShapedReverb(Processor):
         self._check_range(param_tensor)
         lo, span = self._affine(param_tensor)
         d = param_tensor * span + lo
-        if x.shape[1] == 1:   # if mono copy to stereo (functional.py:493-495)
-            x = x.repeat(1, 2, 1)
-        return F._reverb_from_matrices(x, self.sample_rate, d[:, :12], d[:, 12:24], d[:, 24], **self._rev_kwargs)
+        # the validated parameter range bounds the decays: the filter bank then knows which of its two routes every item takes
+        return F._reverb_from_matrices(x, self.sample_rate, d[:, :12], d[:, 12:24], d[:, 24], decay_bound=self._decay_bound(), **self._rev_kwargs)
+
+    def _decay_bound(self):
+        """Largest band decay the validated parameter range allows (0 = no promise: the range check is switched off)."""
+        if not self._range_is_enforced() or list(self.param_ranges) != _REV_NAMES:
+            return 0.0
+        return max(abs(float(v)) for i in range(12) for v in self.param_ranges[f"band{i}_decay"])

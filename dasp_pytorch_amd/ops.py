@@ -403,6 +403,25 @@ def _require_rows(x, t, ncols, name):
                            f"non-singleton dimension 0 ({name} must be ({x.shape[0]}, {ncols}), got {tuple(t.shape)})")
 
 
+_DYN_COUNTERS = {}
+
+
+def _dyn_counters(dev):
+    """The zeroed completion counters of the segmented dynamics calls (4 ints per batch item, one buffer per (device, stream); every
+    call returns them to zero). Inside a HIP-graph capture a fresh buffer is used and not kept: it belongs to the graph's pool, and its
+    captured zero-fill runs again on every replay."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
+    t = None if capturing else _DYN_COUNTERS.get(key)
+    if t is None:
+        t = torch.zeros(4 * 128, dtype=torch.int32, device=dev)          # (the segmented path is only taken below 128 items)
+        if not capturing:
+            if len(_DYN_COUNTERS) >= 16:
+                _DYN_COUNTERS.clear()
+            _DYN_COUNTERS[key] = t
+    return t
+
+
 def _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need):
     """The compressor / expander kernels on ctl (B, 5) fp32 rows [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db]; returns y (fp32)
     and what the backward pass needs."""
@@ -417,7 +436,7 @@ def _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need):
     segbuf = torch.empty(2 * B * L.dasp_dyn_segments(N, tseg), dtype=torch.float32, device=x.device) if tseg else None
     if tseg:
         call("dasp_dynamics_forward_seg", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), ptr(segbuf), B, C, N, float(sample_rate),
-             float(eps), int(lookahead), tseg, stream())
+             float(eps), int(lookahead), tseg, ptr(_dyn_counters(x.device) if B <= 128 else None), stream())
     else:
         call("dasp_dynamics_forward", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), B, C, N, float(sample_rate),
              float(eps), int(lookahead), stream())
@@ -438,7 +457,8 @@ def _dyn_backward(saved, cfg, gy):
     if tseg:
         segbuf = torch.empty(2 * B * G, dtype=torch.float32, device=x32.device)
         call("dasp_dynamics_backward_seg", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
-             ptr(gx), ptr(gctl), ptr(partials), ptr(segbuf), B, C, N, sr, eps, look, tseg, stream())
+             ptr(gx), ptr(gctl), ptr(partials), ptr(segbuf), B, C, N, sr, eps, look, tseg, ptr(_dyn_counters(x32.device) if B <= 128 else None),
+             stream())
     else:
         call("dasp_dynamics_backward", mode, ptr(x32), ptr(ctl), ptr(_f32c(gy)), ptr(carries), ptr(lin if look > 0 else None),
              ptr(gx), ptr(gctl), ptr(partials), B, C, N, sr, eps, look, stream())
@@ -776,14 +796,16 @@ def reverb_noise(seed, B, nb, row_len, device, seed_offset=None):
 
 
 class ReverbFunction(torch.autograd.Function):
-    """noise_shaped_reverberation core: x (B,2,N), noise (2B,nb,L+taps-1) or None, filters (nb,taps), gains/decays (B,nb), mix (B).
+    """noise_shaped_reverberation core: x (B,2,N) or mono (B,1,N) (the reference duplicates a mono input to stereo, functional.py:493-495; here
+    both output channels read the one row - no copy; the backward adds the two channels' input gradients), output (B,2,N);
+    noise (2B,nb,L+taps-1) or None, filters (nb,taps), gains/decays (B,nb), mix (B).
     `noise` and `filters` are constants of the op (the reference draws the noise inside the function, functional.py:548, and designs the
     filters with SciPy): asking for their gradient raises instead of silently returning None. noise = None: the noise is generated inside
     the filter-bank kernels from the integer `seed` (csrc/reverb.hip, counter-based: forward and backward recompute the same stream) and
     never exists in memory."""
 
     @staticmethod
-    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir, seed=None, seed_offset=None):
+    def forward(ctx, x, noise, filters, gains, decays, mix, L_ir, seed=None, seed_offset=None, decay_bound=0.0):
         _lib.require_device(x, "x")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise RuntimeError("noise_shaped_reverberation: `noise` and `filters` are not differentiable inputs (detach them)")
@@ -795,8 +817,11 @@ class ReverbFunction(torch.autograd.Function):
         dev = x.device
         ctx.meta = (x.dtype, gains.dtype, gains.shape, decays.dtype, decays.shape, mix.dtype, mix.shape)
         ctx.empty = x.numel() == 0
+        ctx.xC = C
+        if C not in (1, 2):
+            raise RuntimeError(f"noise_shaped_reverberation takes mono or stereo input, got {C} channels")
         if ctx.empty:
-            return torch.empty_like(x)
+            return torch.empty(B, 2, N, dtype=x.dtype, device=dev)
         with torch.cuda.device(dev):
             sizes = (ctypes.c_long * 14)()
             check(Lb.dasp_reverb_sizes(B, N, L_ir, taps, nb, sizes), "dasp_reverb_sizes")
@@ -815,7 +840,7 @@ class ReverbFunction(torch.autograd.Function):
             soff = _seed_offset(seed_offset, dev) if noise is None else None
             g32, d32, m32 = (_f32c(t.reshape(B, -1)) for t in (gains, decays, mix))
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
-            y = torch.empty_like(x32)
+            y = torch.empty(B, 2, N, dtype=torch.float32, device=dev)
             need_grad = any(ctx.needs_input_grad)
             # kept for the backward pass: the column transforms of x (A) and the spectra of the impulse responses (H); everything else is scratch
             A = _cbuf(sizes[6], dev) if need_grad else None
@@ -824,13 +849,13 @@ class ReverbFunction(torch.autograd.Function):
             ir = torch.empty(sizes[8], dtype=torch.float32, device=dev)
             if noise is None:
                 call("dasp_reverb_forward_rng", ptr(x32), useed, ptr(soff), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
-                     ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+                     ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, C, N, L_ir, taps, nb, float(decay_bound), stream())
             else:
                 call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
-                     ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, N, L_ir, taps, nb, stream())
+                     ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, C, N, L_ir, taps, nb, float(decay_bound), stream())
             if need_grad:
                 ctx.save_for_backward(x32, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H)
-                ctx.cfg = (B, N, L_ir, taps, nb, [int(v) for v in sizes], useed, soff)
+                ctx.cfg = (B, C, N, L_ir, taps, nb, [int(v) for v in sizes], useed, soff, float(decay_bound))
         return y.to(x.dtype)
 
     @staticmethod
@@ -839,12 +864,12 @@ class ReverbFunction(torch.autograd.Function):
         xd, gd, gs, dd, ds, md, ms = ctx.meta
         if ctx.empty:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
-            return torch.empty_like(gy), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None, None
+            return torch.empty(gy.shape[0], ctx.xC, gy.shape[2], dtype=xd, device=gy.device), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None, None, None
         x32, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
-        B, N, L_ir, taps, nb, sizes, useed, soff = ctx.cfg
+        B, C, N, L_ir, taps, nb, sizes, useed, soff, dbound = ctx.cfg
         dev = x32.device
         with torch.cuda.device(dev):
-            gx = torch.empty_like(x32)
+            gx = torch.empty(B, 2, N, dtype=torch.float32, device=dev)
             ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
             gdecay = torch.empty(B, nb, dtype=torch.float32, device=dev)
             gmix = torch.empty(B, dtype=torch.float32, device=dev)
@@ -854,9 +879,11 @@ class ReverbFunction(torch.autograd.Function):
             part = torch.empty(sizes[11], dtype=torch.float32, device=dev)
             mix_part = torch.empty(sizes[10], dtype=torch.float32, device=dev)
             tail = (ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P),
-                    ptr(gir), ptr(part), ptr(mix_part), B, N, L_ir, taps, nb, stream())
+                    ptr(gir), ptr(part), ptr(mix_part), B, C, N, L_ir, taps, nb, dbound, stream())
             if useed is not None:
                 call("dasp_reverb_backward_rng", ptr(x32), ptr(_f32c(gy)), useed, ptr(soff), *tail)
             else:
                 call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), *tail)
-        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None, None
+        if C == 1:
+            gx = gx.sum(1, keepdim=True)           # the adjoint of the mono -> stereo duplication
+        return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None, None, None

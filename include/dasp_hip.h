@@ -238,10 +238,13 @@ int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const flo
 long dasp_dyn_segment_tiles(long B, long N);
 long dasp_dyn_segments(long N, long Tseg);
 int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf,
-                              int B, int C, long N, double sample_rate, float eps, int lookahead, long Tseg, void* stream);
+                              int B, int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
 int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
                                const float* lin_buf, float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N,
-                               double sample_rate, float eps, int lookahead, long Tseg, void* stream);
+                               double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
+/* counters (may be NULL): 4 B ints that the caller keeps ZERO between calls (every call returns them to zero) - with them the item's last
+ * workgroup of a pre-pass chains the segments and the last one of the adjoint pass forms the control gradients: two launches per direction
+ * instead of three / four (workgroup to workgroup by device-scope atomics, as for the biquad cascade). One buffer per stream. */
 
 /* ---------------------------------------------------------------------------------------------
  * Noise-shaped reverberation.  Replaces dasp_pytorch.functional.noise_shaped_reverberation
@@ -276,13 +279,18 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
  * not needed: d loss / d mix = sum gy (wet - x) = sum x (c - gy) with c the correlation of gy with the impulse response, which the
  * backward pass forms anyway. */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays,
-                        const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
-                        long N, int L, int taps, int nb, void* stream);
+                        const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, int Cx,
+                        long N, int L, int taps, int nb, float decay_bound, void* stream);
 int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains,
                          const float* decays, const float* mix, const void* A, const void* H, float* gx,
                          float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
-                         float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
-/* The same two calls with the white noise of functional.py:548 generated inside the filter-bank kernels from a 64-bit seed instead of read
+                         float* mix_part, int B, int Cx, long N, int L, int taps, int nb, float decay_bound, void* stream);
+/* Cx: channels of x, 2, or 1 for a mono input (the reference duplicates it to stereo, functional.py:493-495: here both output channels read
+ * the one row - no copy; gx stays (B, 2, N), the gradient w.r.t. the mono input is the sum of its two rows).
+ * decay_bound: > 0 = the caller vouches that no band decay exceeds this value (Processor.process_normalized: the validated upper end of the
+ * parameter range); when even that decay stays on the envelope-inside-the-transform route of the filter bank, the other route's (empty) launch
+ * is skipped. 0 = unknown.
+ * The same two calls with the white noise of functional.py:548 generated inside the filter-bank kernels from a 64-bit seed instead of read
  * from memory (the `device_noise=True` mode of the Python layer): a counter-based stream, a pure function of (seed, batch item, band,
  * sample index) - one 32-bit hash per (item, band, index), its halves a Box-Muller pair = the item's two noise rows - so the forward and
  * the backward pass recompute identical values and nothing of size (2B, nb, L + taps - 1) exists (0.82 GB at B = 128 and the default
@@ -292,12 +300,12 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
  * dasp_reverb_noise writes the stream out in the reference's layout, out (2B, nb, row_len), row_len = L + taps - 1 < 2^24: a test hook
  * (the explicit-noise calls above, given that tensor, must reproduce the seeded calls). Specification: oracle/noise_stream.py. */
 int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
-                            const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
-                            long N, int L, int taps, int nb, void* stream);
+                            const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, int Cx,
+                            long N, int L, int taps, int nb, float decay_bound, void* stream);
 int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                              const float* decays, const float* mix, const void* A, const void* H, float* gx,
                              float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
-                             float* mix_part, int B, long N, int L, int taps, int nb, void* stream);
+                             float* mix_part, int B, int Cx, long N, int L, int taps, int nb, float decay_bound, void* stream);
 int dasp_reverb_noise(unsigned long long seed, const unsigned long long* seed_dev, float* out, int B, int nb, long row_len, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
