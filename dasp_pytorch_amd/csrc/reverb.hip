@@ -432,8 +432,10 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
 //   MODE 1  backward:  Wout[p] = rowIFFT(rowFFT(Ag[p] tw) conj(H)) conj(tw);  Pout = rowIFFT(sum_p rowFFT(Ag[p] tw) conj(rowFFT(Ax[p] tw))) conj(tw)
 //   MODE 2  spectrum:  H = rowFFT(A tw)   (pairs = 1)
 template <int MODE>
+// x_shift: 1 = mono input: the two signals of an item are convolved from ONE set of column transforms of x (frames of item = sig >> 1;
+// conv_load_kernel<0> is then launched per item): MODE 0 reads A, MODE 1 reads Ax, at the item's index.
 __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__ A, const f2* __restrict__ Ax, const f2* __restrict__ tw,
-                                                          f2* __restrict__ H, f2* __restrict__ Wout, f2* __restrict__ Pout, ConvDims d) {
+                                                          f2* __restrict__ H, f2* __restrict__ Wout, f2* __restrict__ Pout, ConvDims d, int x_shift = 0) {
     __shared__ f2 lds_all[FFT_T / 64][FFT512_LDS];
     const int j = lane_id(), ka = blockIdx.x * 8 + wave_id();
     const long sig = blockIdx.y;
@@ -463,16 +465,16 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
         for (int q = 0; q < 8; ++q) base[rowoff + 64 * q] = f2{r[q] * wr[q] + i[q] * wi[q], i[q] * wr[q] - r[q] * wi[q]};
     };
     for (int p = 0; p < d.npairs; ++p) {
-        const long off = (sig * d.npairs + p) * (long)d.n1;
+        const long off = (sig * d.npairs + p) * (long)d.n1, xoff = ((sig >> x_shift) * d.npairs + p) * (long)d.n1;
         float r[8], i[8];
-        load_spec(A + off, r, i);
+        load_spec(A + (MODE == 0 ? xoff : off), r, i);
         if (MODE == 2) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) H[sig * d.n1 + rowoff + 64 * q] = f2{r[q], i[q]};
         } else {
             if (MODE == 1) {
                 float xr[8], xi[8];
-                load_spec(Ax + off, xr, xi);
+                load_spec(Ax + xoff, xr, xi);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {          // G conj(X)
                     pr[q] += r[q] * xr[q] + i[q] * xi[q];
@@ -755,17 +757,18 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
         const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
         f2* Hc = (f2*)H + s0 * d.c.n1;
-        f2* Ac = A ? (f2*)A + s0 * d.c.npairs * d.c.n1 : (f2*)W2;
         // 2. spectra of the chunk's impulse responses, in the permuted four-step order
         hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.ltiles, 1, ns), dim3(LoadGeom::T), 0, st, (const float*)ir + s0 * L, (const float*)nullptr, tw,
                            (f2*)Ah, one, L);
         hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, Hc,
                            (f2*)nullptr, (f2*)nullptr, one);
         // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
-        hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, x + (s0 >> xs) * N,
-                           (const float*)nullptr, tw, Ac, d.c, L, xs);
-        hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ac, (const f2*)nullptr, tw, Hc,
-                           (f2*)W, (f2*)nullptr, d.c);
+        // mono input: one set of column transforms per ITEM (both of its signals are convolutions of the same x), half the frames of A
+        f2* Acx = A ? (f2*)A + (s0 >> xs) * d.c.npairs * d.c.n1 : (f2*)W2;
+        hipLaunchKernelGGL(conv_load_kernel<0>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns >> xs), dim3(LoadGeom::T), 0, st, x + (s0 >> xs) * N,
+                           (const float*)nullptr, tw, Acx, d.c, L, 0);
+        hipLaunchKernelGGL(conv_rows_kernel<0>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Acx, (const f2*)nullptr, tw, Hc,
+                           (f2*)W, (f2*)nullptr, d.c, xs);
         hipLaunchKernelGGL(conv_cols_kernel<0>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw, x + (s0 >> xs) * N,
                            (const float*)nullptr, mix + s0 / 2, y + s0 * N, (float*)nullptr, d.c, L, xs);
     }
@@ -794,8 +797,8 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
         hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, gy + s0 * N, (const float*)nullptr, tw,
                            (f2*)Ag, d.c, L);
         // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
-        hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + s0 * d.c.npairs * d.c.n1, tw,
-                           (f2*)H + s0 * d.c.n1, (f2*)W, (f2*)P, d.c);
+        hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + (s0 >> xs) * d.c.npairs * d.c.n1, tw,
+                           (f2*)H + s0 * d.c.n1, (f2*)W, (f2*)P, d.c, xs);
         hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw,
                            x + (s0 >> xs) * N, gy + s0 * N, mix + s0 / 2, gx + s0 * N, mix_part + s0 * d.c.npairs * d.ctiles, d.c, L, xs);
         hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,
