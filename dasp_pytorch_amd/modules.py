@@ -274,20 +274,20 @@ _REV_NAMES = [f"band{i}_gain" for i in range(12)] + [f"band{i}_decay" for i in r
 class NoiseShapedReverb(Processor):
     def __init__(self, sample_rate, min_band_gain: float = 0.0, max_band_gain: float = 1.0, min_band_decay: float = 0.0,
                  max_band_decay: float = 1.0, min_mix: float = 0.0, max_mix: float = 1.0, num_samples: int = 65536,
-                 num_bandpass_taps: int = 1023, device_noise: bool = False, noise_seed_offset: torch.Tensor = None):
+                 num_bandpass_taps: int = 1023, device_noise: bool = False, noise_seed_offset: torch.Tensor = None, noise_seed: int = None):
         """The last four arguments are additions to the reference's constructor (defaults = the reference's behaviour):
         impulse-response length, filter-bank taps, generating the noise on the GPU instead of drawing it from the global CPU generator, and
-        (with device_noise) a 1-element int64 device tensor added to the noise seed when the kernels run - for HIP-graph replays, see
-        functional.noise_shaped_reverberation."""
+        (with device_noise) a 1-element int64 device tensor added to the noise seed when the kernels run - for HIP-graph replays - and a fixed
+        base seed instead of one draw per call from torch's CPU generator; see functional.noise_shaped_reverberation."""
         super().__init__()
         self.sample_rate = sample_rate
         self.process_fn = functools.partial(F.noise_shaped_reverberation, num_samples=num_samples, num_bandpass_taps=num_bandpass_taps,
-                                            device_noise=device_noise, noise_seed_offset=noise_seed_offset)
+                                            device_noise=device_noise, noise_seed_offset=noise_seed_offset, noise_seed=noise_seed)
         self.param_ranges = {f"band{i}_gain": (min_band_gain, max_band_gain) for i in range(12)}
         self.param_ranges.update({f"band{i}_decay": (min_band_decay, max_band_decay) for i in range(12)})
         self.param_ranges["mix"] = (min_mix, max_mix)
         self._rev_kwargs = dict(num_samples=num_samples, num_bandpass_taps=num_bandpass_taps, device_noise=device_noise,
-                                noise_seed_offset=noise_seed_offset)
+                                noise_seed_offset=noise_seed_offset, noise_seed=noise_seed)
         self._rev_fn = self.process_fn
 
     def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):

@@ -321,3 +321,37 @@ def test_tensors_on_a_non_current_device(D):
     assert y1.device == x1.device and torch.equal(y1.cpu(), y0.cpu())
     with pytest.raises(DaspHipError):
         D.signal.sosfilt_via_fsm(torch.rand(2, 2, 6, device="cuda:0"), x1)
+
+
+def test_chain_as_graphed_callable(D):
+    """torch.cuda.make_graphed_callables over the chain's process_normalized: forward and backward become HIP-graph replays (no Python, no
+    ctypes, no autograd bookkeeping per step - the answer to the host time of eager steps at the reference's batch sizes). The ops
+    are plain stream launches without host read-backs (the [0, 1] check is skipped while capturing), so they capture as they are; the
+    reverb's generated noise takes a fixed base seed plus a device offset word that the caller bumps between replays. Outputs and all 50
+    parameter gradients equal the eager call's with the same seed and offset."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(31)
+    B, N = 4, 32768
+    off = torch.zeros(1, dtype=torch.int64, device=dev)
+    chain = StyleTransferChain(SR, num_samples=4096, device_noise=True, noise_seed=1234, noise_seed_offset=off)
+    x = torch.rand(B, 1, N, device=dev, generator=g) * 2 - 1
+    ps = [torch.rand(B, n, device=dev, generator=g).clamp(0.05, 0.95) for n in chain.num_params]
+    w = torch.randn(B, 2, N, device=dev, generator=g)
+    fn = lambda x_, a, b, c, d: chain.process_normalized(x_, a, b, c, d)
+    sample = (x.clone(),) + tuple(p.clone().requires_grad_(True) for p in ps)
+    graphed = torch.cuda.make_graphed_callables(fn, sample)
+    for step in range(3):
+        off.fill_(step)
+        pe = [p.clone().requires_grad_(True) for p in ps]
+        ye = fn(x, *pe)
+        (ye * w).sum().backward()
+        pg = [p.clone().requires_grad_(True) for p in ps]
+        yg = graphed(x, *pg)
+        (yg * w).sum().backward()
+        assert float((yg - ye).abs().max()) <= 2e-6 * float(ye.abs().max())
+        for a, b in zip(pg, pe):
+            assert float((a.grad - b.grad).abs().max()) <= 1e-5 * max(float(b.grad.abs().max()), 1e-12)
+        if step:
+            assert float((yg - y_prev).abs().max()) > 1e-3 * float(yg.abs().max())       # the offset word changed the noise of the replay
+        y_prev = yg.detach().clone()
