@@ -375,7 +375,9 @@ __device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (
 // Column pass, time -> A[ka][jb]. grid (NA * 512 / 4096 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
 //                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of gy, k = 2p, 2p+1
-//                                 MODE 2: zero-padded impulse responses (L samples per row), imaginary part 0
+//                                 MODE 2: the zero-padded impulse responses of one batch item (L samples per row) as ONE complex frame,
+//                                         left = real part, right = imaginary part (blockIdx.z = item); the row pass splits the
+//                                         spectrum of the pair by its Hermitian symmetry (pair_spectrum_rows)
 // src_shift: 1 = mono input, both signals of an item read row (sig >> 1) of src (the reference duplicates a mono input to stereo,
 // functional.py:493-495: here the duplicate never exists); 0 otherwise.
 template <int MODE>
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
         const int tt = (g.j + g.T * q) * CV_NB + jb;          // time index inside the n1-point frame
         r[q] = 0.f; i[q] = 0.f;
         if (MODE == 2) {
-            r[q] = src[sig * L + (tt < L ? tt : L - 1)];
+            r[q] = src[2 * sig * L + (tt < L ? tt : L - 1)];
+            i[q] = src[(2 * sig + 1) * L + (tt < L ? tt : L - 1)];
         } else if (MODE == 1 || q < 4) {                        // MODE 0: the upper half of the frame is padding
             const long n0 = (long)(2 * p) * d.Lb + tt, n1i = n0 + d.Lb;
             if (!(MODE == 1 && q >= 4)) r[q] = src[srow * d.N + (n0 < d.N ? n0 : d.N - 1)];      // MODE 1, q >= 4: same sample as i[q - 4]
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
         const int tt = (g.j + g.T * q) * CV_NB + jb;
         if (MODE == 2) {
             r[q] = tt < L ? r[q] : 0.f;
+            i[q] = tt < L ? i[q] : 0.f;
         } else if (MODE == 1 || q < 4) {
             const long n0 = (long)(2 * p) * d.Lb + tt, n1i = n0 + d.Lb;
             r[q] = n0 < d.N ? r[q] : 0.f;
@@ -427,28 +431,50 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
     }
 }
 
-// Row pass. grid (NA / 8, signals), 512 threads = 8 waves, wave = row ka, lane j holds columns j + 64 q.
+// Row pass. grid (NA / 8, signals), 512 threads = 8 waves, wave = one row ka, lane j holds columns j + 64 q. A workgroup takes four
+// rows ka and the four rows NA - ka that hold their mirrored frequencies (see below).
 //   MODE 0  forward:   Wout[p] = rowIFFT(rowFFT(A[p] tw) H) conj(tw)                        for every pair p of the signal
 //   MODE 1  backward:  Wout[p] = rowIFFT(rowFFT(Ag[p] tw) conj(H)) conj(tw);  Pout = rowIFFT(sum_p rowFFT(Ag[p] tw) conj(rowFFT(Ax[p] tw))) conj(tw)
-//   MODE 2  spectrum:  H = rowFFT(A tw)   (pairs = 1)
-template <int MODE>
+//   MODE 2  spectrum:  Z = rowFFT(A tw)   (pairs = 1, blockIdx.y = batch item)
+// The spectra of an item's two real impulse responses are kept as the ONE complex spectrum Z of left + i right (half the frames to
+// transform, store and read): H_left[k] = (Z[k] + conj Z[-k]) / 2, H_right[k] = (Z[k] - conj Z[-k]) / 2i. In the permuted order of the
+// four-step transform, k = ka + NA kb, the mirrored frequency -k sits in row NA - ka at column 511 - kb (row 0: column (512 - kb) % 512),
+// so a wave reads its own row and the mirrored row backwards; the wave of the mirrored row shares the workgroup and both signals of an
+// item run on the same XCD (their workgroup ids differ by a multiple of 8), so the second reads come from the caches.
 // x_shift: 1 = mono input: the two signals of an item are convolved from ONE set of column transforms of x (frames of item = sig >> 1;
 // conv_load_kernel<0> is then launched per item): MODE 0 reads A, MODE 1 reads Ax, at the item's index.
+template <int MODE>
 __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__ A, const f2* __restrict__ Ax, const f2* __restrict__ tw,
                                                           f2* __restrict__ H, f2* __restrict__ Wout, f2* __restrict__ Pout, ConvDims d, int x_shift = 0) {
     __shared__ f2 lds_all[FFT_T / 64][FFT512_LDS];
-    const int j = lane_id(), ka = blockIdx.x * 8 + wave_id();
+    const int j = lane_id(), v = wave_id();
+    int ka = blockIdx.x * 4 + (v & 3);                                             // rows 0 .. NA / 2 - 1 and, waves 4 - 7, their mirrors
+    if (v >= 4) ka = (blockIdx.x == 0 && v == 4) ? d.NA / 2 : d.NA - ka;           // (rows 0 and NA / 2 are their own mirrors)
     const long sig = blockIdx.y;
-    f2* lds = lds_all[wave_id()];
+    f2* lds = lds_all[v];
     const Fft512Tw t5 = fft512_twiddles(j, tw);
     float wr[8], wi[8];
     fourstep_twiddles(ka, j, d.n1, wr, wi);
     const long rowoff = (long)ka * CV_NB + j;
     float hr[8], hi[8], pr[8], pi[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        pr[q] = 0.f; pi[q] = 0.f; hr[q] = 0.f; hi[q] = 0.f;
-        if (MODE != 2) { const f2 h = H[sig * d.n1 + rowoff + 64 * q]; hr[q] = h.x; hi[q] = MODE == 1 ? -h.y : h.y; }
+    for (int q = 0; q < 8; ++q) { pr[q] = 0.f; pi[q] = 0.f; hr[q] = 0.f; hi[q] = 0.f; }
+    if (MODE != 2) {
+        const f2* Z = H + (sig >> 1) * (long)d.n1;
+        const long mrow = (long)((d.NA - ka) & (d.NA - 1)) * CV_NB;
+        f2 z[8], zm[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kb = j + 64 * q;
+            z[q] = Z[rowoff + 64 * q];
+            zm[q] = Z[mrow + (ka == 0 ? (CV_NB - kb) & (CV_NB - 1) : CV_NB - 1 - kb)];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if ((sig & 1) == 0) { hr[q] = 0.5f * (z[q].x + zm[q].x); hi[q] = 0.5f * (z[q].y - zm[q].y); }
+            else                { hr[q] = 0.5f * (z[q].y + zm[q].y); hi[q] = 0.5f * (zm[q].x - z[q].x); }
+            if (MODE == 1) hi[q] = -hi[q];
+        }
     }
     auto load_spec = [&](const f2* base, float (&r)[8], float (&i)[8]) {
 #pragma unroll
@@ -691,7 +717,7 @@ extern "C" {
 
 /* sizes[0] = Lb (block length), [1] = n1 (transform length), [2] = pairs of blocks per signal, [3] = blocks per signal,
  * [4] = complex elements of Fspec (twiddle table + band spectra of the filter bank + the taps), [5] = filter-bank windows per batch item,
- * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (2B * n1),
+ * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (B * n1: one complex frame per item = both impulse responses),
  * [8] = floats of ir / gir (2B * L), [9] = signals per pass of the long-convolution pipeline (chunk),
  * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums,
  * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1, at least B * nb * 4096), [13] = complex elements of the scratch buffers Ah / P (chunk * n1) */
@@ -701,7 +727,7 @@ int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
     sizes[0] = d.c.Lb; sizes[1] = d.c.n1; sizes[2] = d.c.npairs; sizes[3] = d.nblk;
     sizes[4] = (long)(nb + 1) * FFT_N + ((long)nb * taps + 1) / 2; sizes[5] = d.nwin;
-    sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = d.R * d.c.n1;
+    sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = (long)B * d.c.n1;
     sizes[8] = d.R * L; sizes[9] = d.chunk;
     sizes[10] = d.R * d.c.npairs * d.ctiles; sizes[11] = (long)B * d.nwin * nb * 2;
     sizes[12] = (long)d.chunk * d.c.npairs * d.c.n1; sizes[13] = (long)d.chunk * d.c.n1;
@@ -756,11 +782,11 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
 #undef DASP_FB_FWD
     for (long s0 = 0; s0 < d.R; s0 += d.chunk) {
         const unsigned ns = (unsigned)(d.R - s0 < d.chunk ? d.R - s0 : d.chunk);
-        f2* Hc = (f2*)H + s0 * d.c.n1;
-        // 2. spectra of the chunk's impulse responses, in the permuted four-step order
-        hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.ltiles, 1, ns), dim3(LoadGeom::T), 0, st, (const float*)ir + s0 * L, (const float*)nullptr, tw,
+        f2* Hc = (f2*)H + (s0 / 2) * d.c.n1;
+        // 2. spectra of the chunk's impulse responses - one complex frame per batch item - in the permuted four-step order
+        hipLaunchKernelGGL(conv_load_kernel<2>, dim3((unsigned)d.ltiles, 1, ns / 2), dim3(LoadGeom::T), 0, st, (const float*)ir + s0 * L, (const float*)nullptr, tw,
                            (f2*)Ah, one, L);
-        hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, Hc,
+        hipLaunchKernelGGL(conv_rows_kernel<2>, dim3((unsigned)d.rowgroups, ns / 2), dim3(FFT_T), 0, st, (const f2*)Ah, (const f2*)nullptr, tw, Hc,
                            (f2*)nullptr, (f2*)nullptr, one);
         // 3. overlap-add convolution (:570-572) and wet/dry mix (:575)
         // mono input: one set of column transforms per ITEM (both of its signals are convolutions of the same x), half the frames of A
@@ -798,7 +824,7 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
                            (f2*)Ag, d.c, L);
         // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
         hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + (s0 >> xs) * d.c.npairs * d.c.n1, tw,
-                           (f2*)H + s0 * d.c.n1, (f2*)W, (f2*)P, d.c, xs);
+                           (f2*)H + (s0 / 2) * d.c.n1, (f2*)W, (f2*)P, d.c, xs);
         hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw,
                            x + (s0 >> xs) * N, gy + s0 * N, mix + s0 / 2, gx + s0 * N, mix_part + s0 * d.c.npairs * d.ctiles, d.c, L, xs);
         hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,

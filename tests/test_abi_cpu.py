@@ -68,7 +68,7 @@ def test_reverb_size_query():
     Lb, n1, pairs, nblk = sizes[0], sizes[1], sizes[2], sizes[3]
     assert (Lb, n1, pairs, nblk) == (65536, 131072, 2, 4)
     assert sizes[4] == 13 * 4096 + 12 * 1023 // 2 and sizes[5] == -(-65536 // 3072)   # twiddles + 12 band spectra + the taps; 3072 valid samples per window
-    assert sizes[6] == 256 * pairs * n1 and sizes[7] == 256 * n1 and sizes[8] == 256 * 65536
+    assert sizes[6] == 256 * pairs * n1 and sizes[7] == 128 * n1 and sizes[8] == 256 * 65536
     chunk = sizes[9]                                                          # signals per pass of the long-convolution pipeline
     assert chunk == 256 and sizes[12] == chunk * pairs * n1 and sizes[13] == chunk * n1   # one pass over all signals by default
     assert L.dasp_reverb_sizes(1, 9000, 1000, 63, 12, sizes) == 0 and (sizes[0], sizes[3], sizes[2]) == (4096, 3, 2)   # minimum block; odd block count: zero partner
