@@ -431,26 +431,35 @@ __global__ __launch_bounds__(LoadGeom::T) void conv_load_kernel(const float* __r
     }
 }
 
-// Row pass. grid (NA / 8, signals), 512 threads = 8 waves, wave = one row ka, lane j holds columns j + 64 q. A workgroup takes four
-// rows ka and the four rows NA - ka that hold their mirrored frequencies (see below).
+// Row pass. 512 threads = 8 waves, wave = one row ka of one signal, lane j holds columns j + 64 q.
 //   MODE 0  forward:   Wout[p] = rowIFFT(rowFFT(A[p] tw) H) conj(tw)                        for every pair p of the signal
-//   MODE 1  backward:  Wout[p] = rowIFFT(rowFFT(Ag[p] tw) conj(H)) conj(tw);  Pout = rowIFFT(sum_p rowFFT(Ag[p] tw) conj(rowFFT(Ax[p] tw))) conj(tw)
-//   MODE 2  spectrum:  Z = rowFFT(A tw)   (pairs = 1, blockIdx.y = batch item)
-// The spectra of an item's two real impulse responses are kept as the ONE complex spectrum Z of left + i right (half the frames to
-// transform, store and read): H_left[k] = (Z[k] + conj Z[-k]) / 2, H_right[k] = (Z[k] - conj Z[-k]) / 2i. In the permuted order of the
-// four-step transform, k = ka + NA kb, the mirrored frequency -k sits in row NA - ka at column 511 - kb (row 0: column (512 - kb) % 512),
-// so a wave reads its own row and the mirrored row backwards; the wave of the mirrored row shares the workgroup and both signals of an
-// item run on the same XCD (their workgroup ids differ by a multiple of 8), so the second reads come from the caches.
+//   MODE 1  backward:  Wout[p] = rowIFFT(rowFFT(Ag[p] tw) conj(H)) conj(tw);  P = sum_p rowFFT(Ag[p] tw) conj(rowFFT(Ax[p] tw))
+//   MODE 2  spectrum:  Z = rowFFT(A tw)   (pairs = 1)
+// The two real impulse responses of a batch item (and, backward, the two real gradients w.r.t. them) travel as ONE complex frame,
+// left + i right: half the frames to transform, store and read. H_left[k] = (Z[k] + conj Z[-k]) / 2, H_right[k] = (Z[k] - conj Z[-k]) / 2i;
+// backward, d/d ir = Re IFFT(P) of each signal (the imaginary part is cross-talk of the two blocks packed into a frame), i.e. the
+// transform of P's Hermitian part, so Pout = Herm(P_left) + i Herm(P_right), Herm(P)[k] = (P[k] + conj P[-k]) / 2. In the permuted
+// order of the four-step transform, k = ka + NA kb, the mirrored frequency -k sits in row NA - ka at column 511 - kb (row 0: column
+// (512 - kb) % 512; rows 0 and NA / 2 mirror themselves), so a workgroup takes rows together with their mirrors:
+//   MODE 0, 2  grid (NA / 8, signals / items):  waves = 4 rows below NA / 2, their 4 mirrors (the two signals of an item run on the same
+//              XCD - their workgroup ids differ by a multiple of 8 - so the second fetch of a Z row is served by its L2)
+//   MODE 1     grid (NA / 4, items):  waves = (2 rows, their 2 mirrors) x the item's 2 signals: the four P rows that make one row of
+//              Pout meet in one workgroup's LDS.
 // x_shift: 1 = mono input: the two signals of an item are convolved from ONE set of column transforms of x (frames of item = sig >> 1;
 // conv_load_kernel<0> is then launched per item): MODE 0 reads A, MODE 1 reads Ax, at the item's index.
 template <int MODE>
-__global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__ A, const f2* __restrict__ Ax, const f2* __restrict__ tw,
+__global__ __launch_bounds__(FFT_T, MODE == 1 ? 2 : 4) void conv_rows_kernel(const f2* __restrict__ A, const f2* __restrict__ Ax, const f2* __restrict__ tw,
                                                           f2* __restrict__ H, f2* __restrict__ Wout, f2* __restrict__ Pout, ConvDims d, int x_shift = 0) {
     __shared__ f2 lds_all[FFT_T / 64][FFT512_LDS];
+    __shared__ f2 pex_all[MODE == 1 ? FFT_T / 64 : 1][MODE == 1 ? CV_NB : 1];      // MODE 1: the P rows meet here (one barrier; the transforms' own images stay private)
+    constexpr int RW = MODE == 1 ? 2 : 4;                                          // rows below NA / 2 per workgroup
     const int j = lane_id(), v = wave_id();
-    int ka = blockIdx.x * 4 + (v & 3);                                             // rows 0 .. NA / 2 - 1 and, waves 4 - 7, their mirrors
-    if (v >= 4) ka = (blockIdx.x == 0 && v == 4) ? d.NA / 2 : d.NA - ka;           // (rows 0 and NA / 2 are their own mirrors)
-    const long sig = blockIdx.y;
+    const int rw = v % RW, mir = (v / RW) & 1;
+    const bool self = blockIdx.x == 0 && rw == 0;                                  // rows 0 and NA / 2
+    int ka = blockIdx.x * RW + rw;
+    if (mir) ka = self ? d.NA / 2 : d.NA - ka;
+    const int ch = MODE == 1 ? v / (2 * RW) : MODE == 0 ? (int)(blockIdx.y & 1) : 0;
+    const long item = MODE == 0 ? blockIdx.y >> 1 : blockIdx.y, sig = MODE == 2 ? item : 2 * item + ch;
     f2* lds = lds_all[v];
     const Fft512Tw t5 = fft512_twiddles(j, tw);
     float wr[8], wi[8];
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) { pr[q] = 0.f; pi[q] = 0.f; hr[q] = 0.f; hi[q] = 0.f; }
     if (MODE != 2) {
-        const f2* Z = H + (sig >> 1) * (long)d.n1;
+        const f2* Z = H + item * (long)d.n1;
         const long mrow = (long)((d.NA - ka) & (d.NA - 1)) * CV_NB;
         f2 z[8], zm[8];
 #pragma unroll
@@ -471,17 +480,17 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if ((sig & 1) == 0) { hr[q] = 0.5f * (z[q].x + zm[q].x); hi[q] = 0.5f * (z[q].y - zm[q].y); }
-            else                { hr[q] = 0.5f * (z[q].y + zm[q].y); hi[q] = 0.5f * (zm[q].x - z[q].x); }
+            if (ch == 0) { hr[q] = 0.5f * (z[q].x + zm[q].x); hi[q] = 0.5f * (z[q].y - zm[q].y); }
+            else         { hr[q] = 0.5f * (z[q].y + zm[q].y); hi[q] = 0.5f * (zm[q].x - z[q].x); }
             if (MODE == 1) hi[q] = -hi[q];
         }
     }
     auto load_spec = [&](const f2* base, float (&r)[8], float (&i)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const f2 v = base[rowoff + 64 * q];
-            r[q] = v.x * wr[q] - v.y * wi[q];
-            i[q] = v.x * wi[q] + v.y * wr[q];
+            const f2 v2 = base[rowoff + 64 * q];
+            r[q] = v2.x * wr[q] - v2.y * wi[q];
+            i[q] = v2.x * wi[q] + v2.y * wr[q];
         }
         fft512_wave<-1>(r, i, j, t5, lds);
     };
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
                 float xr[8], xi[8];
                 load_spec(Ax + xoff, xr, xi);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {          // G conj(X)
+                for (int q = 0; q < 8; ++q) {          // P += G conj(X)
                     pr[q] += r[q] * xr[q] + i[q] * xi[q];
                     pi[q] += i[q] * xr[q] - r[q] * xi[q];
                 }
@@ -516,39 +525,45 @@ __global__ __launch_bounds__(FFT_T) void conv_rows_kernel(const f2* __restrict__
             store_time(Wout + off, r, i);
         }
     }
-    if (MODE == 1) store_time(Pout + sig * (long)d.n1, pr, pi);
+    if (MODE == 1) {
+        // the four P rows (this row and its mirror, left and right signal) -> rows ka of Pout, by the waves of the left signal
+        f2* pex = pex_all[MODE == 1 ? v : 0];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pex[j + 64 * q] = f2{pr[q], pi[q]};
+        __syncthreads();
+        if (ch == 0) {
+            const int vm = self ? v : v ^ RW;                                      // the wave holding the mirrored row of the left signal
+            const f2* pR = pex_all[MODE == 1 ? v + 2 * RW : 0];
+            const f2* mL = pex_all[MODE == 1 ? vm : 0];
+            const f2* mR = pex_all[MODE == 1 ? vm + 2 * RW : 0];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kb = j + 64 * q, kbm = ka == 0 ? (CV_NB - kb) & (CV_NB - 1) : CV_NB - 1 - kb;
+                const f2 b = pR[kb], cl = mL[kbm], cr = mR[kbm];
+                const float qr = 0.5f * ((pr[q] + cl.x) - (b.y - cr.y));
+                const float qi = 0.5f * ((pi[q] - cl.y) + (b.x + cr.x));
+                pr[q] = qr; pi[q] = qi;
+            }
+            store_time(Pout + item * (long)d.n1, pr, pi);
+        }
+    }
 }
 
-// Inverse column pass + epilogue. 1024 threads, 8192-element tiles; thread (j, c) as in conv_load_kernel; registers q < 4 are the lower half of the frame
-// (r = (j + T q) 512 + jb < Lb), q >= 4 the upper half (r + Lb).
-//   MODE 0  grid (tiles, signals): for p = 0..: y[2p Lb + r] = Re lo + carry, y[(2p+1) Lb + r] = Im lo + Re hi, carry = Im hi;
-//           then y = x + mix (wet - x) (:575)
-//   MODE 1  grid (tiles, pairs, signals): with c = the correlation of gy with the impulse response (Re lo / Im lo of the frame),
-//           gx[2p Lb + r] = (1 - mix) gy + mix c and likewise for block 2p+1;  mix_part[sig][p * tiles + tile] = sum x (c - gy):
-//           d loss / d mix = sum gy (wet - x) and sum gy wet = sum x c over a whole signal (the wet path and c are adjoint maps), so the
-//           wet signal is not kept for the backward pass
-//   MODE 2  grid (tiles, signals): gir[sig][r] = mix Re lo, r < L
-// x_shift: 1 = mono input x (B, 1, N): the dry signal (MODE 0) / the x of the mix gradient (MODE 1) of both of an item's signals is row
-// (sig >> 1). The input gradient stays per signal, gx (B, 2, N): the caller adds the two rows (one workgroup walking both signals of an
-// item to store their sum was measured at the reference's batch size: 16 -> 49 us, twice the serial work on half the workgroups).
+// (launch bounds: 8 waves per SIMD = two workgroups per CU, <= 64 VGPRs; left to itself the forward instance took 66 and ran alone on its CU: 217 -> 250 us)
 template <int MODE>
-__global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
+__global__ __launch_bounds__(ColsGeom::T, 8) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
                                                           const float* __restrict__ gy, const float* __restrict__ mix,
                                                           float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L, int x_shift = 0) {
     __shared__ f2 lds[ColsGeom::LDS];
     __shared__ float red[ColsGeom::T / 64];
     const ColCfg g = col_config<COLS_LOG>(d.logNA, threadIdx.x);
-    constexpr int nsum = 1;
-    const long sig0 = MODE == 1 ? (long)blockIdx.z : blockIdx.y;
+    const long sig = MODE == 1 ? (long)blockIdx.z : blockIdx.y, xrow = sig >> x_shift;          // MODE 2: sig = batch item
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const float inv = 1.f / (float)d.n1;
+    const float m = mix[MODE == 2 ? sig : sig >> 1];
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
-    float gsum_a[4] = {0.f, 0.f, 0.f, 0.f}, gsum_b[4] = {0.f, 0.f, 0.f, 0.f};
-    const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
-    for (int sidx = 0; sidx < nsum; ++sidx) {
-    const long sig = sig0 + sidx, xrow = sig >> x_shift;
-    const float m = mix[sig >> 1];
     float macc = 0.f;
+    const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
     for (int p = p_lo; p < p_hi; ++p) {
         // the thread coordinates pass through an opaque move once per pair: without it every LDS / global address of the loop body is
         // hoisted out of the loop and the kernel needs 208 VGPRs (one workgroup per CU) instead of ~100
@@ -563,21 +578,31 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
         // the signal values the epilogue combines with the frame: all requested together at clamped addresses (under the bounds checks
         // below each was a load, a wait and a store in turn; 255 -> 225 us forward, 285 -> 273 backward. Requesting them before the
         // transform instead gained nothing forward and cost occupancy backward)
-        float xa[4], xb[4], ga[4], gb[4];
-        if (MODE != 2) {
+        float xa[4], xb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long na = (long)(2 * p) * d.Lb + (gl.j + gl.T * q) * CV_NB + jbl, nbk = na + d.Lb;
+        for (int q = 0; q < 4; ++q) {
+            const int rr = (gl.j + gl.T * q) * CV_NB + jbl;
+            if (MODE == 2) {                                   // x = the impulse responses (2 items, L)
+                const int o = rr < L ? rr : L - 1;
+                xa[q] = x[2 * sig * L + o]; xb[q] = x[(2 * sig + 1) * L + o];
+            } else {
+                const long na = (long)(2 * p) * d.Lb + rr, nbk = na + d.Lb;
                 const long oa = na < d.N ? na : d.N - 1, ob = nbk < d.N ? nbk : d.N - 1;
-                xa[q] = x[xrow * d.N + oa]; xb[q] = x[xrow * d.N + ob];
-                if (MODE == 1) { ga[q] = gy[sig * d.N + oa]; gb[q] = gy[sig * d.N + ob]; }
+                if (MODE == 0) { xa[q] = x[xrow * d.N + oa]; xb[q] = x[xrow * d.N + ob]; }
+                else { xa[q] = gy[sig * d.N + oa]; xb[q] = gy[sig * d.N + ob]; }
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int rr = (gl.j + gl.T * q) * CV_NB + jbl;          // < Lb
             if (MODE == 2) {
-                if (rr < L) out[sig * L + rr] = m * r[q] * inv;
+                if (rr < L) {
+                    const float ca = r[q] * inv, cb = i[q] * inv;
+                    out[2 * sig * L + rr] = m * ca;
+                    out[(2 * sig + 1) * L + rr] = m * cb;
+                    macc = fmaf(xa[q], ca, fmaf(xb[q], cb, macc));
+                    if (rr == 0) macc -= ca + cb;
+                }
             } else {
                 const long na = (long)(2 * p) * d.Lb + rr, nbk = na + d.Lb;
                 if (MODE == 0) {
@@ -587,31 +612,21 @@ __global__ __launch_bounds__(ColsGeom::T) void conv_cols_kernel(const f2* __rest
                     if (nbk < d.N) out[sig * d.N + nbk] = fmaf(m, wb - xb[q], xb[q]);
                 } else {
                     const float ca = r[q] * inv, cb = i[q] * inv;
-                    if (na < d.N) {
-                        gsum_a[q] += fmaf(m, ca - ga[q], ga[q]);
-                        macc = fmaf(xa[q], ca - ga[q], macc);
-                        if (sidx == nsum - 1) out[sig * d.N + na] = gsum_a[q];
-                    }
-                    if (nbk < d.N) {
-                        gsum_b[q] += fmaf(m, cb - gb[q], gb[q]);
-                        macc = fmaf(xb[q], cb - gb[q], macc);
-                        if (sidx == nsum - 1) out[sig * d.N + nbk] = gsum_b[q];
-                    }
+                    if (na < d.N) out[sig * d.N + na] = fmaf(m, ca - xa[q], xa[q]);
+                    if (nbk < d.N) out[sig * d.N + nbk] = fmaf(m, cb - xb[q], xb[q]);
                 }
             }
         }
     }
-    if (MODE == 1) {
+    if (MODE == 2) {
         const float s = wave_sum(macc);
-        __syncthreads();                 // (red is reused by the second signal of a mono item)
         if (lane_id() == 0) red[wave_id()] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
             float a = 0.f;
             for (int v = 0; v < ColsGeom::T / 64; ++v) a += red[v];
-            mix_part[(sig * d.npairs + blockIdx.y) * gridDim.x + blockIdx.x] = a;
+            mix_part[sig * gridDim.x + blockIdx.x] = a;
         }
-    }
     }
 }
 
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(256) void reverb_finalize_kernel(const float* __res
     } else if (o < B * nb + B) {
         const int b = o - B * nb;
         double m = 0.0;
-        for (long j = l; j < 2L * mix_chunks; j += 64) m += (double)mix_part[(long)b * 2 * mix_chunks + j];
+        for (long j = l; j < mix_chunks; j += 64) m += (double)mix_part[(long)b * mix_chunks + j];
         m = wave_sum(m);
         if (l == 0) gmix[b] = (float)m;
     }
@@ -720,7 +735,7 @@ extern "C" {
  * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (B * n1: one complex frame per item = both impulse responses),
  * [8] = floats of ir / gir (2B * L), [9] = signals per pass of the long-convolution pipeline (chunk),
  * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums,
- * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1, at least B * nb * 4096), [13] = complex elements of the scratch buffers Ah / P (chunk * n1) */
+ * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1, at least B * nb * 4096), [13] = complex elements of the scratch buffers Ah / P (chunk / 2 * n1: one complex frame per item of a pass) */
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!sizes || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX) return DASP_ERR_ARG;
     RvDims d;
@@ -729,8 +744,8 @@ int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     sizes[4] = (long)(nb + 1) * FFT_N + ((long)nb * taps + 1) / 2; sizes[5] = d.nwin;
     sizes[6] = d.R * d.c.npairs * d.c.n1; sizes[7] = (long)B * d.c.n1;
     sizes[8] = d.R * L; sizes[9] = d.chunk;
-    sizes[10] = d.R * d.c.npairs * d.ctiles; sizes[11] = (long)B * d.nwin * nb * 2;
-    sizes[12] = (long)d.chunk * d.c.npairs * d.c.n1; sizes[13] = (long)d.chunk * d.c.n1;
+    sizes[10] = (long)B * d.ctiles; sizes[11] = (long)B * d.nwin * nb * 2;
+    sizes[12] = (long)d.chunk * d.c.npairs * d.c.n1; sizes[13] = (long)(d.chunk / 2) * d.c.n1;
     if (sizes[12] < (long)B * nb * FFT_N) sizes[12] = (long)B * nb * FFT_N;       // W / Ag also hold the per-item weighted band spectra of the filter bank
     return DASP_OK;
 }
@@ -746,9 +761,9 @@ int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fs
 
 /* Forward.  x (B,Cx,N), Cx = 2, or 1 for a mono input that the reference duplicates to stereo (functional.py:493-495; here the copy never
  * exists: both output channels read the one row); noise (2B, nb, L+taps-1); Fspec (sizes[4] complex); gains, decays (B, nb); mix (B); y (B,2,N).
- * Saved for backward: H (sizes[7] complex) and, when A is not NULL, A (sizes[6] complex: the column transforms of x; pass NULL when no
+ * Saved for backward: H (sizes[7] complex), ir (sizes[8] floats: the impulse responses) and, when A is not NULL, A (sizes[6] complex: the column transforms of x; pass NULL when no
  * gradient is needed and they go to a chunk-sized scratch instead: W2, sizes[12] complex).
- * Scratch: W (sizes[12] complex), Ah (sizes[13] complex), ir (sizes[8] floats). */
+ * Scratch: W (sizes[12] complex), Ah (sizes[13] complex). */
 static int reverb_forward_impl(const float* x, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                                const float* decays, const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B,
                                int Cx, long N, int L, int taps, int nb, float decay_bound, void* stream) {
@@ -801,19 +816,20 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
     return rv_check();
 }
 
-/* Backward.  gx (B,2,N) (mono input: the gradient w.r.t. x is the sum of its two rows, left to the caller); ggain, gdecay (B, nb); gmix (B).
+/* Backward.  ir = the impulse responses the forward call left in its `ir` buffer (sizes[8] floats); gx (B,2,N) (mono input: the gradient
+ * w.r.t. x is the sum of its two rows, left to the caller); ggain, gdecay (B, nb); gmix (B). x itself is not read (its column transforms A are).
  * Scratch: Ag, W (sizes[12] complex each), P (sizes[13] complex), gir (sizes[8] floats), part (sizes[11] floats), mix_part (sizes[10] floats). */
-static int reverb_backward_impl(const float* x, const float* gy, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
+static int reverb_backward_impl(const float* ir, const float* gy, const float* noise, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                                 const float* decays, const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay,
                                 float* gmix, void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, int Cx, long N, int L,
                                 int taps, int nb, float decay_bound, void* stream) {
-    if (!x || !gy || !Fspec || !gains || !decays || !mix || !A || !H || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
+    if (!ir || !gy || !Fspec || !gains || !decays || !mix || !A || !H || !gx || !ggain || !gdecay || !gmix || !Ag || !W || !P ||
         !gir || !part || !mix_part || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX)
         return DASP_ERR_ARG;
     RvDims d;
     if (Cx != 1 && Cx != 2) return DASP_ERR_ARG;
     if (!rv_dims(B, N, L, taps, &d)) return DASP_ERR_UNSUPPORTED;
-    const int xs = Cx == 1 ? 1 : 0;         // mono input: x has one row per item; gx stays (B, 2, N), the caller adds its two rows
+    const int xs = Cx == 1 ? 1 : 0;         // mono input: one set of column transforms A per item; gx stays (B, 2, N), the caller adds its two rows
     hipStream_t st = (hipStream_t)stream;
     const f2* tw = (const f2*)Fspec;
     const ConvDims one = ConvDims{d.c.logNA, d.c.NA, d.c.n1, d.c.Lb, 1, d.c.N};
@@ -822,13 +838,13 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
         // overlapped windows of gy -> column transforms
         hipLaunchKernelGGL(conv_load_kernel<1>, dim3((unsigned)d.ltiles, (unsigned)d.c.npairs, ns), dim3(LoadGeom::T), 0, st, gy + s0 * N, (const float*)nullptr, tw,
                            (f2*)Ag, d.c, L);
-        // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir), one row pass
-        hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups, ns), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + (s0 >> xs) * d.c.npairs * d.c.n1, tw,
+        // correlation with the impulse response (-> gx) and with the input blocks (-> d/dir, one complex frame per item), one row pass
+        hipLaunchKernelGGL(conv_rows_kernel<1>, dim3((unsigned)d.rowgroups * 2, ns / 2), dim3(FFT_T), 0, st, (const f2*)Ag, (const f2*)A + (s0 >> xs) * d.c.npairs * d.c.n1, tw,
                            (f2*)H + (s0 / 2) * d.c.n1, (f2*)W, (f2*)P, d.c, xs);
         hipLaunchKernelGGL(conv_cols_kernel<1>, dim3((unsigned)d.ctiles, (unsigned)d.c.npairs, ns), dim3(ColsGeom::T), 0, st, (const f2*)W, tw,
-                           x + (s0 >> xs) * N, gy + s0 * N, mix + s0 / 2, gx + s0 * N, mix_part + s0 * d.c.npairs * d.ctiles, d.c, L, xs);
-        hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, ns), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, (const float*)nullptr,
-                           (const float*)nullptr, mix + s0 / 2, gir + s0 * L, (float*)nullptr, one, L);
+                           (const float*)nullptr, gy + s0 * N, mix + s0 / 2, gx + s0 * N, (float*)nullptr, d.c, L, 0);
+        hipLaunchKernelGGL(conv_cols_kernel<2>, dim3((unsigned)d.ctiles, ns / 2), dim3(ColsGeom::T), 0, st, (const f2*)P, tw, ir + s0 * L,
+                           (const float*)nullptr, mix + s0 / 2, gir + s0 * L, mix_part + (s0 / 2) * d.ctiles, one, L);
     }
     // d/dgain, d/ddecay: the filter bank again, weighted by gir
     const float* taps_f = reinterpret_cast<const float*>(tw + (long)(nb + 1) * FFT_N);
@@ -844,7 +860,7 @@ static int reverb_backward_impl(const float* x, const float* gy, const float* no
 #undef DASP_FB_BWD
     const int nfin = B * nb + B;                      // one wave per output value
     hipLaunchKernelGGL(reverb_finalize_kernel, dim3((nfin + 3) / 4), dim3(256), 0, st, part, mix_part, ggain, gdecay, gmix, B, nb, d.nwin,
-                       d.c.npairs * d.ctiles);
+                       d.ctiles);
     return rv_check();
 }
 
@@ -854,12 +870,12 @@ int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, c
     if (!noise) return DASP_ERR_ARG;
     return reverb_forward_impl(x, noise, 0ULL, nullptr, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, Cx, N, L, taps, nb, decay_bound, stream);
 }
-int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
+int dasp_reverb_backward(const float* ir, const float* gy, const float* noise, const void* Fspec, const float* gains, const float* decays,
                          const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
                          void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, int Cx, long N, int L, int taps, int nb,
                          float decay_bound, void* stream) {
     if (!noise) return DASP_ERR_ARG;
-    return reverb_backward_impl(x, gy, noise, 0ULL, nullptr, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, Cx, N,
+    return reverb_backward_impl(ir, gy, noise, 0ULL, nullptr, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, Cx, N,
                                 L, taps, nb, decay_bound, stream);
 }
 /* The same two calls with the white noise generated inside the filter-bank kernels from `seed` (the counter-based stream documented at
@@ -872,11 +888,11 @@ int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const unsig
                             float decay_bound, void* stream) {
     return reverb_forward_impl(x, nullptr, seed, seed_dev, Fspec, gains, decays, mix, y, A, H, W, W2, Ah, ir, B, Cx, N, L, taps, nb, decay_bound, stream);
 }
-int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
+int dasp_reverb_backward_rng(const float* ir, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
                              const float* mix, const void* A, const void* H, float* gx, float* ggain, float* gdecay, float* gmix,
                              void* Ag, void* W, void* P, float* gir, float* part, float* mix_part, int B, int Cx, long N, int L, int taps, int nb,
                              float decay_bound, void* stream) {
-    return reverb_backward_impl(x, gy, nullptr, seed, seed_dev, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, Cx, N,
+    return reverb_backward_impl(ir, gy, nullptr, seed, seed_dev, Fspec, gains, decays, mix, A, H, gx, ggain, gdecay, gmix, Ag, W, P, gir, part, mix_part, B, Cx, N,
                                 L, taps, nb, decay_bound, stream);
 }
 int dasp_reverb_noise(unsigned long long seed, const unsigned long long* seed_dev, float* out, int B, int nb, long row_len, void* stream) {

@@ -842,7 +842,8 @@ class ReverbFunction(torch.autograd.Function):
             Fspec = _filter_spectrum(filters, nb, taps, sizes[4], dev)
             y = torch.empty(B, 2, N, dtype=torch.float32, device=dev)
             need_grad = any(ctx.needs_input_grad)
-            # kept for the backward pass: the column transforms of x (A) and the spectra of the impulse responses (H); everything else is scratch
+            # kept for the backward pass: the column transforms of x (A), the impulse responses (ir) and their spectra (H: one complex frame
+            # per item); everything else is scratch
             A = _cbuf(sizes[6], dev) if need_grad else None
             W2 = None if need_grad else _cbuf(sizes[12], dev)
             W, H, Ah = _cbuf(sizes[12], dev), _cbuf(sizes[7], dev), _cbuf(sizes[13], dev)
@@ -854,7 +855,7 @@ class ReverbFunction(torch.autograd.Function):
                 call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
                      ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, C, N, L_ir, taps, nb, float(decay_bound), stream())
             if need_grad:
-                ctx.save_for_backward(x32, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H)
+                ctx.save_for_backward(ir, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H)
                 ctx.cfg = (B, C, N, L_ir, taps, nb, [int(v) for v in sizes], useed, soff, float(decay_bound))
         return y.to(x.dtype)
 
@@ -865,9 +866,9 @@ class ReverbFunction(torch.autograd.Function):
         if ctx.empty:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
             return torch.empty(gy.shape[0], ctx.xC, gy.shape[2], dtype=xd, device=gy.device), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None, None, None
-        x32, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
+        ir, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
         B, C, N, L_ir, taps, nb, sizes, useed, soff, dbound = ctx.cfg
-        dev = x32.device
+        dev = ir.device
         with torch.cuda.device(dev):
             gx = torch.empty(B, 2, N, dtype=torch.float32, device=dev)
             ggain = torch.empty(B, nb, dtype=torch.float32, device=dev)
@@ -881,9 +882,9 @@ class ReverbFunction(torch.autograd.Function):
             tail = (ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(A), ptr(H), ptr(gx), ptr(ggain), ptr(gdecay), ptr(gmix), ptr(Ag), ptr(W), ptr(P),
                     ptr(gir), ptr(part), ptr(mix_part), B, C, N, L_ir, taps, nb, dbound, stream())
             if useed is not None:
-                call("dasp_reverb_backward_rng", ptr(x32), ptr(_f32c(gy)), useed, ptr(soff), *tail)
+                call("dasp_reverb_backward_rng", ptr(ir), ptr(_f32c(gy)), useed, ptr(soff), *tail)
             else:
-                call("dasp_reverb_backward", ptr(x32), ptr(_f32c(gy)), ptr(n32), *tail)
+                call("dasp_reverb_backward", ptr(ir), ptr(_f32c(gy)), ptr(n32), *tail)
         if C == 1:
             gx = gx.sum(1, keepdim=True)           # the adjoint of the mono -> stereo duplication
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None, None, None

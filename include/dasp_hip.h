@@ -263,7 +263,8 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
  * ------------------------------------------------------------------------------------------- */
 /* sizes[0] = block length Lb, [1] = transform length n1, [2] = pairs of blocks per signal, [3] = blocks per signal,
  * [4] = complex (2 x fp32) elements of Fspec, [5] = filter-bank windows per batch item,
- * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (2B * n1), [8] = floats of each of ir / gir,
+ * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (B * n1: the two impulse responses of an item are one complex
+ *       frame, left + i right), [8] = floats of each of ir / gir,
  * [9] = signals per pass of the long-convolution pipeline (all 2B by default; a developer switch can cut the pipeline into passes over
  *       chunks of signals that reuse chunk-sized scratch buffers),
  * [10] = floats of mix_part, [11] = floats of part,
@@ -273,15 +274,16 @@ int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes /* [14
 /* filters (nb, taps) fp32, the host-designed bank -> Fspec: transform twiddles, the band spectra, the taps themselves (the filter bank
  * re-weights them by each item's decay envelope per call). */
 int dasp_reverb_filter_spectrum(const float* filters, int nb, int taps, void* Fspec, void* stream);
-/* forward: H and (when a backward pass follows) A are kept for it - pass A = NULL otherwise and the column transforms of x go to the
- * scratch W2; W, Ah, ir are scratch.
- * backward: gx, ggain (B, nb), gdecay (B, nb), gmix (B) are the results; Ag, W, P, gir, part, mix_part are scratch. The wet signal is
- * not needed: d loss / d mix = sum gy (wet - x) = sum x (c - gy) with c the correlation of gy with the impulse response, which the
- * backward pass forms anyway. */
+/* forward: H, ir (the impulse responses) and (when a backward pass follows) A are kept for it - pass A = NULL otherwise and the column
+ * transforms of x go to the scratch W2; W, Ah are scratch.
+ * backward: takes the forward call's ir (first argument), H and A - not x; gx, ggain (B, nb), gdecay (B, nb), gmix (B) are the results;
+ * Ag, W, P, gir, part, mix_part are scratch. Neither the wet signal nor x is needed for d loss / d mix = sum_n gy (wet - x):
+ * sum_n gy wet = sum_r ir[r] c[r] and sum_n gy x = c[0] with c[r] = sum_n gy[n] x[n - r], r < L - the correlation the pass forms for
+ * d loss / d ir anyway. */
 int dasp_reverb_forward(const float* x, const float* noise, const void* Fspec, const float* gains, const float* decays,
                         const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, int Cx,
                         long N, int L, int taps, int nb, float decay_bound, void* stream);
-int dasp_reverb_backward(const float* x, const float* gy, const float* noise, const void* Fspec, const float* gains,
+int dasp_reverb_backward(const float* ir, const float* gy, const float* noise, const void* Fspec, const float* gains,
                          const float* decays, const float* mix, const void* A, const void* H, float* gx,
                          float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
                          float* mix_part, int B, int Cx, long N, int L, int taps, int nb, float decay_bound, void* stream);
@@ -302,7 +304,7 @@ int dasp_reverb_backward(const float* x, const float* gy, const float* noise, co
 int dasp_reverb_forward_rng(const float* x, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains, const float* decays,
                             const float* mix, float* y, void* A, void* H, void* W, void* W2, void* Ah, float* ir, int B, int Cx,
                             long N, int L, int taps, int nb, float decay_bound, void* stream);
-int dasp_reverb_backward_rng(const float* x, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
+int dasp_reverb_backward_rng(const float* ir, const float* gy, unsigned long long seed, const unsigned long long* seed_dev, const void* Fspec, const float* gains,
                              const float* decays, const float* mix, const void* A, const void* H, float* gx,
                              float* ggain, float* gdecay, float* gmix, void* Ag, void* W, void* P, float* gir, float* part,
                              float* mix_part, int B, int Cx, long N, int L, int taps, int nb, float decay_bound, void* stream);

@@ -70,7 +70,7 @@ def test_reverb_size_query():
     assert sizes[4] == 13 * 4096 + 12 * 1023 // 2 and sizes[5] == -(-65536 // 3072)   # twiddles + 12 band spectra + the taps; 3072 valid samples per window
     assert sizes[6] == 256 * pairs * n1 and sizes[7] == 128 * n1 and sizes[8] == 256 * 65536
     chunk = sizes[9]                                                          # signals per pass of the long-convolution pipeline
-    assert chunk == 256 and sizes[12] == chunk * pairs * n1 and sizes[13] == chunk * n1   # one pass over all signals by default
+    assert chunk == 256 and sizes[12] == chunk * pairs * n1 and sizes[13] == chunk // 2 * n1   # one pass over all signals by default
     assert L.dasp_reverb_sizes(1, 9000, 1000, 63, 12, sizes) == 0 and (sizes[0], sizes[3], sizes[2]) == (4096, 3, 2)   # minimum block; odd block count: zero partner
     assert sizes[12] == 1 * 12 * 4096                                         # small problems: W / Ag sized by the per-item band spectra they also hold
     assert L.dasp_reverb_sizes(1, 1000, 4096, 3587, 12, sizes) == -2         # filter longer than the filter-bank window

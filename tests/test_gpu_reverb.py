@@ -245,3 +245,27 @@ def test_generated_noise_equals_the_explicit_noise_path(D):
     torch.manual_seed(99); b1 = run()
     # (one item: the bands are dealt out over workgroups that add into the impulse response with float atomics - equal to rounding, not to the bit)
     assert float((a1 - b1).abs().max()) < 1e-5 * float(a1.abs().max()) and float((a1 - a2).abs().max()) > 1e-2 * float(a1.abs().max())
+
+
+@pytest.mark.parametrize("C", [2, 1])
+def test_chunked_passes_equal_one_pass(D, monkeypatch, C):
+    """DASP_REVERB_CHUNK (a developer switch kept for the measurement in DESIGN 3.3): the long-convolution pipeline run in passes over 2 and
+    4 signals with chunk-sized scratch buffers - every per-chunk pointer offset (A per item for mono input, the items' paired spectra, the
+    mix partial sums) - gives what the single pass gives, and that is held to the oracle."""
+    B, N, L, taps = 5, 30000, 9000, 255
+    rng = np.random.default_rng(17 + C)
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 2, N)).astype(np.float32)
+    p = rng.random((B, 25)).astype(np.float32)
+    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+    y0, gx0, gp0 = run(D, x, p, w, noise, L, taps)
+    pd = p.astype(np.float64)
+    yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
+    assert np.abs(y0 - yo).max() < 3e-5 * np.abs(yo).max()
+    for chunk in (2, 4):
+        monkeypatch.setenv("DASP_REVERB_CHUNK", str(chunk))
+        y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
+        monkeypatch.delenv("DASP_REVERB_CHUNK")
+        assert np.abs(y1 - y0).max() <= 1e-6 * np.abs(y0).max()
+        assert np.abs(gx1 - gx0).max() <= 1e-6 * np.abs(gx0).max()
+        assert np.abs(gp1 - gp0).max() <= 2e-6 * np.abs(gp0).max()
