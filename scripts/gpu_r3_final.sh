@@ -9,11 +9,12 @@ if [ "$1" != "skip-tests" ]; then
 fi
 bash scripts/hbm_traffic.sh $out > $out/hbm_traffic.log 2>&1; tail -c 600 $out/hbm_traffic.log
 mkdir -p profiles/r03; cp $out/hbm_traffic.json profiles/r03/hbm_traffic.json       # bench.py reads the counter file from profiles/ (hash-checked)
+DASP_RV_NOISE=generated bash scripts/reverb_traffic.sh $out/hbm_traffic_secondary.json 2>&1 | tail -2
+cp $out/hbm_traffic_secondary.json profiles/r03/hbm_traffic_secondary.json           # (the reverb's roofline dict in bench.py's `secondary` quotes it)
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_args.json 2> $out/bench_driver_args.err
 timeout 600 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rprof.err )
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv; rm -rf $out/rprof
-DASP_RV_NOISE=generated bash scripts/reverb_traffic.sh $out/hbm_traffic_secondary.json 2>&1 | tail -2
 ( cd /tmp && DASP_RV_NOISE=generated rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/scripts/reverb_time.py 128 2 262144 > /dev/null 2>> $GRAFT_REPO_ROOT/$out/rprof.err )
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/reverb_kernel_stats.csv; rm -rf $out/rprof
 python - <<'PY'
