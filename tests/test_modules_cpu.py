@@ -115,3 +115,29 @@ def test_chain_control_tables_follow_the_processors():
     ch.gain.param_ranges["gain_db"] = (-12.0, 12.0)
     lo2, span2 = ch._tables()
     assert (lo2[31], span2[31]) == (-12.0, 24.0)
+
+
+def test_reverb_module_passes_its_noise_keywords(monkeypatch):
+    """NoiseShapedReverb(device_noise=, noise_seed=, noise_seed_offset=) and StyleTransferChain hand the three to the functional (kernels
+    stubbed): what torch.cuda.make_graphed_callables over a chain relies on - a fixed base seed, a device word added to it per replay."""
+    from dasp_pytorch_amd import modules as M
+    seen = {}
+
+    def fake(x, sample_rate, band_gains, band_decays, mix, num_samples, num_bandpass_taps, noise=None, device_noise=False, noise_seed=None,
+             noise_seed_offset=None, decay_bound=0.0):
+        seen.update(device_noise=device_noise, noise_seed=noise_seed, noise_seed_offset=noise_seed_offset, decay_bound=decay_bound,
+                    num_samples=num_samples, shapes=(tuple(band_gains.shape), tuple(band_decays.shape), tuple(mix.shape)))
+        return x
+    monkeypatch.setattr(M, "_reverb_from_matrices", fake, raising=False)
+    import dasp_pytorch_amd.functional as F
+    monkeypatch.setattr(F, "_reverb_from_matrices", fake)
+    off = torch.zeros(1, dtype=torch.int64)
+    rev = D.NoiseShapedReverb(SR, num_samples=4096, device_noise=True, noise_seed=77, noise_seed_offset=off)
+    rev.process_normalized(torch.zeros(3, 2, 64), torch.rand(3, 25))
+    assert seen["device_noise"] is True and seen["noise_seed"] == 77 and seen["noise_seed_offset"] is off and seen["num_samples"] == 4096
+    assert seen["shapes"] == ((3, 12), (3, 12), (3,))
+    assert rev._decay_bound() == pytest.approx(1.0)                          # what the fused (float32, GPU) path vouches for: the validated upper
+    rev.validate_range = False                                               # end of the decay range (modules.py:204-230) - nothing once the check is off
+    assert rev._decay_bound() == 0.0
+    with pytest.raises(ValueError, match="noise_seed_offset"):
+        F.noise_shaped_reverberation(torch.zeros(1, 2, 8), SR, *[torch.zeros(1)] * 25, noise_seed_offset=off)
