@@ -139,5 +139,6 @@ def test_reverb_module_passes_its_noise_keywords(monkeypatch):
     assert rev._decay_bound() == pytest.approx(1.0)                          # what the fused (float32, GPU) path vouches for: the validated upper
     rev.validate_range = False                                               # end of the decay range (modules.py:204-230) - nothing once the check is off
     assert rev._decay_bound() == 0.0
+    monkeypatch.undo()                                                        # the real function: an offset without generated noise is refused
     with pytest.raises(ValueError, match="noise_seed_offset"):
         F.noise_shaped_reverberation(torch.zeros(1, 2, 8), SR, *[torch.zeros(1)] * 25, noise_seed_offset=off)
