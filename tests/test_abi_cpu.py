@@ -95,6 +95,15 @@ def test_product_has_no_cpu_path():
         D.signal.sosfilt_via_fsm(torch.zeros(1, 2, 6), x)
 
 
+def test_tensors_of_one_call_must_share_a_device():
+    """_lib.require_same_device (every op calls it before handing raw pointers to the library): a tensor on another device than x is
+    refused with both devices named. Host logic - torch's meta device stands in for a second GPU."""
+    x = torch.zeros(2, 2, 8)
+    _lib.require_same_device(x, sos=torch.zeros(2, 1, 6), nothing=None, number=3.0)           # same device, non-tensors: fine
+    with pytest.raises(_lib.DaspHipError, match="sos is on meta but x is on cpu"):
+        _lib.require_same_device(x, sos=torch.zeros(2, 1, 6, device="meta"))
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "dasp_pytorch_amd")
     for dirpath, _, files in os.walk(pkg):

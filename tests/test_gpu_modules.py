@@ -306,6 +306,16 @@ def test_empty_inputs_return_empty_tensors(D):
         assert D.compressor(x, SR, *[torch.ones(bs, device="cuda:0")] * 6).shape == x.shape
 
 
+def test_host_and_device_tensors_in_one_call_are_refused(D):
+    """The one-GPU half of the device guards: a parameter tensor left on the host is refused by name (the kernels take raw pointers)."""
+    from dasp_pytorch_amd._lib import DaspHipError
+    x = torch.rand(2, 2, 4096, device="cuda:0")
+    with pytest.raises(DaspHipError, match="cpu"):
+        D.signal.sosfilt_via_fsm(torch.rand(2, 2, 6), x)
+    with pytest.raises(DaspHipError, match="cpu"):
+        D.losses.MultiResolutionSTFTLoss()(x, x.cpu())
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
 def test_tensors_on_a_non_current_device(D):
     """x on cuda:1 while cuda:0 is the current device: kernels are launched on x's device and stream (ops wrap every call in
