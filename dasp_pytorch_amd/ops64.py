@@ -79,6 +79,60 @@ class SosFilt64Function(torch.autograd.Function):
         return gsos, (gx if ctx.needs_input_grad[1] else None)
 
 
+class LFilterFunction(torch.autograd.Function):
+    """lfilter_via_fsm for K = 4 .. 16 coefficients (reference: signal.py:95-133): x (B, 1, N) float32 or float64, bn / an (Bs, K) with
+    an[:, 0] == 1 (the caller normalises by a0 in torch, so that step differentiates itself), Bs = B or 1. Exact recurrence in double
+    arithmetic (csrc/lfilter.hip); differentiable w.r.t. x, bn and an[:, 1:]."""
+
+    @staticmethod
+    def forward(ctx, x, bn, an):
+        _lib.require_device(x, "x")
+        _lib.require_same_device(x, b=bn, a=an)
+        B, C, N = x.shape
+        Bs, K = bn.shape
+        dev = x.device
+        ctx.meta = (x.dtype, x.shape, bn.dtype, an.dtype, bn.shape)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:
+            return torch.empty_like(x)
+        f64 = x.dtype == torch.float64
+        with torch.cuda.device(dev):
+            xc = x.detach().to(torch.float64 if f64 else torch.float32).contiguous()
+            b64, a64 = _d(bn, dev), _d(an, dev)
+            y = torch.empty_like(xc)
+            need = any(ctx.needs_input_grad)
+            wsave = torch.empty(N * B * C, dtype=torch.float64, device=dev) if need else None
+            nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K)
+            work = torch.empty(nwork, dtype=torch.float64, device=dev) if nwork > 0 else None
+            call("dasp_lfilter_forward", ptr(xc), ptr(b64), ptr(a64), Bs, ptr(y), ptr(wsave), ptr(work), B * C, N, K, int(f64), stream())
+            if need:
+                ctx.save_for_backward(b64, a64, wsave)
+        return y.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xdt, xshape, bdt, adt, bshape = ctx.meta
+        if ctx.empty:
+            return torch.empty(xshape, dtype=xdt, device=gy.device), torch.zeros(bshape, dtype=bdt, device=gy.device), torch.zeros(bshape, dtype=adt, device=gy.device)
+        b64, a64, wsave = ctx.saved_tensors
+        B, C, N = xshape
+        Bs, K = bshape
+        dev = gy.device
+        f64 = xdt == torch.float64
+        with torch.cuda.device(dev):
+            g = gy.detach().to(torch.float64 if f64 else torch.float32).contiguous()
+            gx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+            gb = torch.empty(B * C, K, dtype=torch.float64, device=dev)
+            ga = torch.empty(B * C, K, dtype=torch.float64, device=dev)
+            nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K)
+            work = torch.empty(nwork, dtype=torch.float64, device=dev) if nwork > 0 else None
+            call("dasp_lfilter_backward", ptr(g), ptr(b64), ptr(a64), Bs, ptr(wsave), ptr(gx), ptr(gb), ptr(ga), ptr(work), B * C, N, K, int(f64), stream())
+            if Bs == 1 and B * C > 1:
+                gb, ga = gb.sum(0, keepdim=True), ga.sum(0, keepdim=True)
+        return (gx.to(xdt) if gx is not None else None), gb.to(bdt), ga.to(adt)
+
+
 class ParametricEQ64Function(torch.autograd.Function):
     """RBJ design in fp64 (dasp_biquad_design per section) + the fp64 cascade; `controls` as for ops.ParametricEQFunction."""
 

@@ -13,7 +13,7 @@ import scipy.signal
 import torch
 
 from .ops import FILTER_TYPES, BiquadFunction, SosFiltFunction
-from .ops64 import SosFilt64Function, is_f64
+from .ops64 import LFilterFunction, SosFilt64Function, is_f64
 
 
 def biquad(gain_db: torch.Tensor, cutoff_freq: torch.Tensor, q_factor: torch.Tensor, sample_rate: float, filter_type: str = "peaking"):
@@ -38,19 +38,30 @@ def lfilter_via_fsm(x: torch.Tensor, b: torch.Tensor, a: torch.Tensor = None):
     numerator and a (bs, K) denominator coefficients (any a0), or a = None for an FIR filter. As in the reference x must have one
     channel (`assert chs == 1`). Evaluated as an exact recurrence - one section of the cascaded-biquad scan (csrc/sosfilt.hip) - instead
     of the reference's frequency-sampling approximation; differentiable w.r.t. x, b and a.
-    Orders up to 2 (K <= 3) are supported: the reference's only caller is the compressor's one-pole smoother (K = 2,
-    functional.py:372-380). Longer filters raise NotImplementedError (factor them into second-order sections and call
-    sosfilt_via_fsm)."""
+    K <= 3 (the reference's only caller is the compressor's one-pole smoother, K = 2, functional.py:372-380) is one section of the
+    cascaded-biquad kernels. K = 4 .. 16 runs the recurrence of order K - 1 in double arithmetic, chunks of time side by side and
+    stitched by their state transition (csrc/lfilter.hip - the boundary's long tail, not one of the tuned kernels). More than 16
+    coefficients raise NotImplementedError (factor into second-order sections and call sosfilt_via_fsm)."""
     bs, chs, seq_len = x.size()  # enforce shape
     assert chs == 1
     K = b.shape[-1]
     if b.dim() != 2 or b.shape[0] not in (1, bs) or (a is not None and a.shape != b.shape):
         raise RuntimeError(f"lfilter_via_fsm: b (and a) must have shape ({bs}, K); got {tuple(b.shape)}" + (f", {tuple(a.shape)}" if a is not None else ""))
-    if K > 3:
-        raise NotImplementedError(f"lfilter_via_fsm: K = {K} coefficients; this package evaluates recurrences of order <= 2 per section. "
+    if K > 16:
+        raise NotImplementedError(f"lfilter_via_fsm: K = {K} coefficients; recurrences of up to 16 coefficients are evaluated directly. "
                                   "Factor the filter into second-order sections, e.g. sos = scipy.signal.tf2sos(b, a) per batch item, "
                                   "stack them as (bs, n_sections, 6) and call dasp_pytorch_amd.signal.sosfilt_via_fsm(sos, x) "
                                   "(differentiable w.r.t. the sections; any number of sections)")
+    if K > 3:
+        b = b.type_as(x).double()                        # the reference's rounding of the coefficients (signal.py:113,119), then exact
+        if a is None:
+            an = torch.zeros_like(b)
+            an[:, 0] = 1.0
+            bn = b
+        else:
+            a = a.type_as(x).double()
+            bn, an = b / a[:, :1], a / a[:, :1]          # H = B / A for any a0 (signal.py:7-11); torch differentiates the normalisation
+        return LFilterFunction.apply(x, bn, an)
     b = b.type_as(x)
     if a is None:
         a = torch.zeros_like(b)

@@ -346,6 +346,22 @@ int dasp_mrstft_backward(const float* pred, const float* target, const void* tw,
                          int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Filters longer than one biquad.  Replaces dasp_pytorch.signal.lfilter_via_fsm (dasp_pytorch/signal.py:95-133) for K = 4 .. 16
+ * coefficients per row (orders 3 .. 15; K <= 3 goes through the cascaded-biquad entry points above; the reference's only caller uses
+ * K = 2, functional.py:372-380). Exact recurrence in double arithmetic, one thread per (row, chunk of time); the chunks run side by side
+ * and are stitched by their state transition (csrc/lfilter.hip: three launches per direction).
+ *   x, y, gy, gx: (rows, N) float (f64 = 0) or double (f64 = 1);  bn, an: (Bs, K) doubles, Bs = rows or 1, normalised so that
+ *   an[:, 0] = 1 (FIR: an = 1, 0, ...);  wsave: (N, rows) doubles written by the forward pass for the backward pass (NULL: none follows);
+ *   work: dasp_lfilter_work_doubles(rows, N, K) doubles of scratch;
+ *   gb, ga: (rows, K) doubles, per row (the caller adds the rows of a broadcast filter; ga[:, 0] = 0);  gx may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+long dasp_lfilter_work_doubles(int rows, long N, int K);
+int dasp_lfilter_forward(const void* x, const double* bn, const double* an, int Bs, void* y, double* wsave, double* work, int rows, long N,
+                         int K, int f64, void* stream);
+int dasp_lfilter_backward(const void* gy, const double* bn, const double* an, int Bs, const double* wsave, void* gx, double* gb,
+                          double* ga, double* work, int rows, long N, int K, int f64, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Double precision.  The reference follows the dtype of its input (`.type_as(x)`, dasp_pytorch/signal.py:113,119,
  * functional.py:211), so float64 tensors mean float64 arithmetic. These entry points are that path for the recurrences and the
  * elementwise effects - the same maps as above evaluated plainly, one thread per row / batch item, sequential in time: meant for

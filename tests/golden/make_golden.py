@@ -277,7 +277,45 @@ def lfilter_case(name, B, N, seed):
     print(name, sorted(out))
 
 
+def lfilter_long_case(name, B, N, seed):
+    """signal.lfilter_via_fsm (dasp_pytorch/signal.py:95-133) with more than three coefficients, (B, 1, N): a 4th-order Butterworth
+    low-pass per item (K = 5, a0 scaled away from 1), a 7th-order Chebyshev-I band of cut-offs (K = 8), a 16-tap FIR (a = None), and one
+    6th-order filter shared by the batch (b, a of shape (1, 7)); forward and the gradients w.r.t. x, b, a from the reference's fp32 and
+    fp64 runs. The impulse responses have decayed within N, so the reference's frequency-sampling result is the recurrence's."""
+    import scipy.signal
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 1, N, generator=g) * 2 - 1
+    w = torch.randn(B, 1, N, generator=g)
+    cut = 0.08 + 0.5 * torch.rand(B, generator=g)
+    a0 = 0.5 + torch.rand(B, 1, generator=g)
+    bw4 = [scipy.signal.butter(4, float(c)) for c in cut]
+    b5 = torch.tensor(np.stack([q[0] for q in bw4])) * a0
+    a5 = torch.tensor(np.stack([q[1] for q in bw4])) * a0
+    ch7 = [scipy.signal.cheby1(7, 1.0, float(c)) for c in cut]
+    b8 = torch.tensor(np.stack([q[0] for q in ch7]))
+    a8 = torch.tensor(np.stack([q[1] for q in ch7]))
+    bf = torch.randn(B, 16, generator=g) * 0.3
+    sh = scipy.signal.butter(6, 0.3)
+    b7 = torch.tensor(sh[0])[None]; a7 = torch.tensor(sh[1])[None] * 1.7
+    out = dict(x=f32(x), w=f32(w), b_k5=f32(b5), a_k5=f32(a5), b_k8=f32(b8), a_k8=f32(a8), b_fir16=f32(bf), b_shared7=f32(b7), a_shared7=f32(a7))
+    for key, bb, aa in (("k5", b5, a5), ("k8", b8, a8), ("fir16", bf, None), ("shared7", b7, a7)):
+        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+            xx = x.to(dt).clone().requires_grad_(True)
+            bt = bb.to(torch.float32).to(dt).clone().requires_grad_(True)
+            at = aa.to(torch.float32).to(dt).clone().requires_grad_(True) if aa is not None else None
+            y = dasp_pytorch.signal.lfilter_via_fsm(xx, bt, at)
+            (y * w.to(dt)).sum().backward()
+            out[f"{key}_y{tag}"], out[f"{key}_gx{tag}"], out[f"{key}_gb{tag}"] = f32(y), f32(xx.grad), f32(bt.grad)
+            if at is not None:
+                out[f"{key}_ga{tag}"] = f32(at.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, sorted(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lfilter_long":          # round 3 addition; the other files regenerate bit-identically
+        lfilter_long_case("lfilter_long_b3_n9000", 3, 9000, seed=131)
+        sys.exit(0)
     torch.set_num_threads(8)
     eq_case("eq_b3c2_n12000", 3, 2, 12000, 3, seed=101)
     eq_case("eq_bcast_b2c1_n4099", 2, 1, 4099, 1, seed=102)
@@ -297,3 +335,4 @@ if __name__ == "__main__":
     biquad_case("biquad_types_b6", 6, seed=125)
     lfilter_case("lfilter_b3_n9000", 3, 9000, seed=126)
     dist_sample_case("dist_sample_b2c2_n3001", 2, 2, 3001, seed=127)
+    lfilter_long_case("lfilter_long_b3_n9000", 3, 9000, seed=131)

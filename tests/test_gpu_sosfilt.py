@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import dasp_oracle as orc
-from tests.util import linf_peak, load_golden
+from tests.util import linf_peak, load_golden, record
 
 pytestmark = pytest.mark.gpu
 SR = 44100
@@ -495,8 +495,107 @@ def test_lfilter_via_fsm_matches_reference(D):
             assert linf_peak(a.grad.cpu().numpy(), g[key + "_ga64"]).max() < TOL_PAR, key
     with pytest.raises(AssertionError):
         D.signal.lfilter_via_fsm(torch.zeros(2, 2, 64, device="cuda:0"), torch.ones(2, 2, device="cuda:0"))      # signal.py:106: chs == 1
-    with pytest.raises(NotImplementedError):
-        D.signal.lfilter_via_fsm(torch.zeros(2, 1, 64, device="cuda:0"), torch.ones(2, 5, device="cuda:0"))
+    with pytest.raises(NotImplementedError, match="tf2sos"):
+        D.signal.lfilter_via_fsm(torch.zeros(2, 1, 64, device="cuda:0"), torch.ones(2, 17, device="cuda:0"))
+
+
+LONG_KEYS = ("k5", "k8", "fir16", "shared7")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_lfilter_via_fsm_long_filters_match_reference(D, dtype):
+    """K = 4 .. 16 coefficients (csrc/lfilter.hip: the recurrence of order K - 1, double arithmetic) on the reference's own outputs: a
+    4th-order Butterworth per item with a0 != 1 (K = 5), a 7th-order Chebyshev (K = 8), a 16-tap FIR (a = None) and a 6th-order filter
+    shared by the batch (b, a of shape (1, 7)); forward and the gradients w.r.t. x, b and a, float32 and float64 input."""
+    g = load_golden("lfilter_long_b3_n9000")
+    t = lambda v: dev(v).to(dtype)
+    tol_sig, tol_par = (TOL_SIG, TOL_PAR) if dtype == torch.float32 else (5e-7, 5e-6)       # (fp64: the golden is stored as fp32)
+    for key in LONG_KEYS:
+        x = t(g["x"]).requires_grad_(True)
+        b = t(g["b_" + key]).requires_grad_(True)
+        a = t(g["a_" + key]).requires_grad_(True) if "a_" + key in g else None
+        y = D.signal.lfilter_via_fsm(x, b, a)
+        (y * t(g["w"])).sum().backward()
+        assert y.shape == x.shape and y.dtype == dtype and b.grad.shape == b.shape
+        e = dict(y=linf_peak(y.detach().cpu().numpy(), g[key + "_y64"]).max(), gx=linf_peak(x.grad.cpu().numpy(), g[key + "_gx64"]).max(),
+                 gb=linf_peak(b.grad.cpu().numpy(), g[key + "_gb64"]).max())
+        if a is not None:
+            assert a.grad.shape == a.shape
+            e["ga"] = linf_peak(a.grad.cpu().numpy(), g[key + "_ga64"]).max()
+        record(f"lfilter_long[{key},{str(dtype)[6:]}]", **e)
+        assert e["y"] < tol_sig and e["gx"] < 2 * tol_sig and e["gb"] < tol_par and e.get("ga", 0.0) < tol_par, (key, e)
+        if dtype == torch.float32:
+            assert linf_peak(y.detach().cpu().numpy(), g[key + "_y32"]).max() < 1e-4, key      # literal north_star bar vs the reference's fp32 run
+
+
+def test_lfilter_via_fsm_long_filters_vs_oracle(D):
+    """Every kernel instantiation (K <= 4, <= 8, <= 16), more rows than a wave (rows 64 .. 69 are a second workgroup), a broadcast FIR, no
+    gradient for x, against the oracle (the reference's frequency-sampling algorithm in fp64)."""
+    import scipy.signal
+    rng = np.random.default_rng(5)
+    for B, N, K, kind in ((70, 6000, 4, "iir"), (5, 30000, 9, "iir"), (3, 20000, 16, "iir"), (4, 7001, 12, "fir1"), (2, 5000, 6, "iir_nogx")):
+        x = (rng.random((B, 1, N)) * 2 - 1).astype(np.float32)
+        w = rng.standard_normal((B, 1, N)).astype(np.float32)
+        if kind == "fir1":
+            b = (rng.standard_normal((1, K)) * 0.4).astype(np.float32); a = None
+        else:
+            ba = [scipy.signal.butter(K - 1, float(c)) for c in rng.uniform(0.15, 0.6, B)]
+            b = np.stack([q[0] for q in ba]).astype(np.float32); a = (np.stack([q[1] for q in ba]) * rng.uniform(0.5, 2.0, (B, 1))).astype(np.float32)
+        xt = dev(x).requires_grad_(kind != "iir_nogx")
+        bt = dev(b).requires_grad_(True); at = dev(a).requires_grad_(True) if a is not None else None
+        y = D.signal.lfilter_via_fsm(xt, bt, at)
+        (y * dev(w)).sum().backward()
+        bo = np.broadcast_to(b, (B, K)).astype(np.float64); ao = a.astype(np.float64) if a is not None else None
+        yo = orc.lfilter_via_fsm(x, bo, ao)
+        gxo, gbo, gao = orc.lfilter_via_fsm_vjp(x, bo, ao, w)
+        if kind == "fir1":
+            gbo = gbo.sum(0, keepdims=True)
+        e = dict(y=linf_peak(y.detach().cpu().numpy(), yo).max(), gb=linf_peak(bt.grad.cpu().numpy(), gbo).max())
+        if kind != "iir_nogx":
+            e["gx"] = linf_peak(xt.grad.cpu().numpy(), gxo).max()
+        else:
+            assert xt.grad is None
+        if a is not None:
+            e["ga"] = linf_peak(at.grad.cpu().numpy(), gao).max()
+        record(f"lfilter_long_oracle[{B},{N},{K},{kind}]", **e)
+        assert e["y"] < TOL_SIG and e.get("gx", 0.0) < 2 * TOL_SIG and e["gb"] < TOL_PAR and e.get("ga", 0.0) < TOL_PAR, (B, N, K, kind, e)
+
+
+@pytest.mark.parametrize("chunk", [None, 1, 7, 100, 4096])
+def test_lfilter_via_fsm_long_filters_chunk_stitching(D, monkeypatch, chunk):
+    """The chunks of time of csrc/lfilter.hip run side by side and are stitched by the state transition over a chunk: chunk lengths forced
+    to 1 sample, to lengths that are no multiple of the register block, to more than the signal (one chunk: no stitching) and the planner's
+    own choice on a signal long enough for 1024-sample chunks with a short last one - slowly decaying filters (poles at radius 0.999), so
+    that a wrong start state would be seen across the whole next chunk - all against the oracle."""
+    rng = np.random.default_rng(9)
+    B, N, K = 3, (40000 + 333 if chunk is None else 3000), 6
+    th = rng.uniform(0.05, 3.0, (B, 2)); rad = np.array([0.999, 0.97])
+    a = np.stack([np.real(np.poly(np.concatenate([[0.9], *[(rad[i] * np.exp(1j * t), rad[i] * np.exp(-1j * t)) for i, t in enumerate(th[q])]]))) for q in range(B)])
+    b = rng.standard_normal((B, K)) * 0.01
+    x = (rng.random((B, 1, N)) * 2 - 1).astype(np.float32); w = rng.standard_normal((B, 1, N)).astype(np.float32)
+    b32, a32 = b.astype(np.float32), a.astype(np.float32)
+    if chunk is not None:
+        monkeypatch.setenv("DASP_LFILTER_CHUNK", str(chunk))
+    xt, bt, at = dev(x).requires_grad_(True), dev(b32).requires_grad_(True), dev(a32).requires_grad_(True)
+    y = D.signal.lfilter_via_fsm(xt, bt, at)
+    (y * dev(w)).sum().backward()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("DASP_LFILTER_CHUNK", raising=False)
+    # the true recurrence in fp64 (scipy) - with poles at 0.999 the impulse response has not decayed within 3000 samples, where the
+    # reference's circular frequency-sampling result differs from it by design (SURVEY Appendix A, Q1)
+    import scipy.signal
+    yo = np.stack([scipy.signal.lfilter(b32[q].astype(np.float64), a32[q].astype(np.float64), x[q, 0].astype(np.float64)) for q in range(B)])[:, None]
+    gxo = np.stack([scipy.signal.lfilter(b32[q].astype(np.float64), a32[q].astype(np.float64), w[q, 0, ::-1].astype(np.float64))[::-1] for q in range(B)])[:, None]
+    e = dict(y=linf_peak(y.detach().cpu().numpy(), yo).max(), gx=linf_peak(xt.grad.cpu().numpy(), gxo).max())
+    record(f"lfilter_long_chunks[{chunk}]", **e)
+    assert e["y"] < TOL_SIG and e["gx"] < 2 * TOL_SIG, e
+    if chunk is not None:                      # coefficient gradients: the same call in one chunk is the yardstick
+        monkeypatch.setenv("DASP_LFILTER_CHUNK", str(10 ** 9))
+        x2, b2, a2 = dev(x).requires_grad_(True), dev(b32).requires_grad_(True), dev(a32).requires_grad_(True)
+        (D.signal.lfilter_via_fsm(x2, b2, a2) * dev(w)).sum().backward()
+        monkeypatch.delenv("DASP_LFILTER_CHUNK")
+        assert linf_peak(bt.grad.cpu().numpy(), b2.grad.cpu().numpy()).max() < 1e-9
+        assert linf_peak(at.grad.cpu().numpy(), a2.grad.cpu().numpy()).max() < 1e-9
 
 
 def test_three_wave_backward_kernel_variant_agrees(D):

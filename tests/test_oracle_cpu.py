@@ -263,6 +263,26 @@ def test_oracle_lfilter_matches_reference():
             assert linf_peak(ga, g[key + "_ga64"]).max() < 5e-6, key
 
 
+def test_oracle_lfilter_long_filters_match_reference():
+    """The oracle's lfilter_via_fsm (the reference's frequency-sampling algorithm, any K) and its hand VJP against the reference's own
+    outputs for K = 5, 8, a 16-tap FIR and a filter shared by the batch: the pin of the checker the long-filter GPU tests use."""
+    g = load_golden("lfilter_long_b3_n9000")
+    B = g["x"].shape[0]
+    for key in ("k5", "k8", "fir16", "shared7"):
+        b0 = g["b_" + key].astype(np.float64)
+        b = np.broadcast_to(b0, (B, b0.shape[1]))
+        a = np.broadcast_to(g["a_" + key].astype(np.float64), b.shape) if "a_" + key in g else None
+        y = orc.lfilter_via_fsm(g["x"], b, a)
+        assert linf_peak(y, g[key + "_y64"]).max() < 2e-6, key
+        gx, gb, ga = orc.lfilter_via_fsm_vjp(g["x"], b, a, g["w"])
+        if b0.shape[0] == 1:
+            gb = gb.sum(0, keepdims=True); ga = ga.sum(0, keepdims=True) if ga is not None else None
+        assert linf_peak(gx, g[key + "_gx64"]).max() < 2e-6, key
+        assert linf_peak(gb, g[key + "_gb64"]).max() < 1e-5, key
+        if a is not None:
+            assert linf_peak(ga, g[key + "_ga64"]).max() < 1e-5, key
+
+
 # dasp_pytorch/modules.py:104-106, 136-155, 179-186, 204-230 restated: (min, max) per column of the normalised parameter tensor
 NORM_RANGES = {
     "gain": [(-24.0, 24.0)],
