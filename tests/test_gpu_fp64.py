@@ -121,6 +121,18 @@ def test_gradcheck_all_fp64_ops(D):
     a = torch.cat([torch.ones(B, 1, device="cuda:0", dtype=torch.float64), -0.9 * rnd(B, 1)], 1).requires_grad_(True)
     x1 = (rnd(B, 1, N) * 2 - 1).requires_grad_(True)
     assert torch.autograd.gradcheck(D.signal.lfilter_via_fsm, (x1, b, a), eps=1e-6, atol=1e-7, rtol=1e-5, nondet_tol=1e-12)
+    # K = 5 and K = 11 coefficients (csrc/lfilter.hip; a0 != 1: the normalisation is differentiated by torch), several chunks of time
+    import os
+    os.environ["DASP_LFILTER_CHUNK"] = "13"
+    try:
+        for K in (5, 11):
+            bl = ((rnd(B, K) - 0.5) * 0.5).requires_grad_(True)
+            al = torch.cat([1.0 + rnd(B, 1), (rnd(B, K - 1) - 0.5) * (0.8 / K)], 1).requires_grad_(True)
+            assert torch.autograd.gradcheck(D.signal.lfilter_via_fsm, (x1, bl, al), eps=1e-6, atol=1e-7, rtol=1e-5, nondet_tol=1e-10), K
+        assert torch.autograd.gradcheck(lambda x_, b_: D.signal.lfilter_via_fsm(x_, b_, None), (x1, ((rnd(1, 7) - 0.5)).requires_grad_(True)), eps=1e-6,
+                                        atol=1e-7, rtol=1e-5, nondet_tol=1e-10)                      # FIR shared by the batch
+    finally:
+        del os.environ["DASP_LFILTER_CHUNK"]
 
 
 def test_ops_without_a_double_path_refuse_float64(D, monkeypatch):
