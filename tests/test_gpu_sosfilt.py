@@ -598,6 +598,40 @@ def test_lfilter_via_fsm_long_filters_chunk_stitching(D, monkeypatch, chunk):
         assert linf_peak(at.grad.cpu().numpy(), a2.grad.cpu().numpy()).max() < 1e-9
 
 
+def test_sixteen_million_samples(D):
+    """A signal far beyond every BASELINE shape, (2, 1, 2^24 + 1029) - 16,385 tiles per row, 64-bit sample offsets everywhere: parametric_eq
+    forward and input gradient against scipy.signal.sosfilt in float64 on the oracle's coefficient design (the frequency-sampling oracle
+    would need 2^25-point transforms), and the compressor's prefix against the oracle with finite results to the end."""
+    import scipy.signal
+    N, B = (1 << 24) + 1029, 2
+    rng = np.random.default_rng(0)
+    x = (rng.random((B, 1, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 1, N)).astype(np.float32)
+    p = random_params(B, 77)
+    xt = dev(x).requires_grad_(True)
+    cols = [dev(p[:, i].copy()).requires_grad_(True) for i in range(18)]
+    y = D.parametric_eq(xt, SR, *cols)
+    (y * dev(w)).sum().backward()
+    assert all(torch.isfinite(c.grad).all() for c in cols)
+    pd = p.astype(np.float64)
+    sos = np.stack([np.concatenate(orc.biquad(pd[:, 3 * k], pd[:, 3 * k + 1], pd[:, 3 * k + 2], SR, t), 1)
+                    for k, t in enumerate(["low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf"])], 1)
+    for q in range(B):
+        yo = scipy.signal.sosfilt(sos[q], x[q, 0].astype(np.float64))
+        gxo = scipy.signal.sosfilt(sos[q], w[q, 0, ::-1].astype(np.float64))[::-1]
+        ey = np.abs(y[q, 0].detach().cpu().numpy() - yo).max() / np.abs(yo).max()
+        eg = np.abs(xt.grad[q, 0].cpu().numpy() - gxo).max() / np.abs(gxo).max()
+        record(f"sixteen_million_samples[{q}]", y=ey, gx=eg)
+        assert ey < TOL_SIG and eg < 2 * TOL_SIG, (q, ey, eg)
+    ctl = [torch.tensor(v, device="cuda:0") for v in ([-30.0, -12.0], [4.0, 8.0], [10.0, 50.0], [50.0, 80.0], [6.0, 2.0], [3.0, 0.0])]
+    xc = dev(x).requires_grad_(True)
+    yc = D.compressor(xc, SR, *ctl)
+    (yc * dev(w)).sum().backward()
+    assert torch.isfinite(yc).all() and torch.isfinite(xc.grad).all()
+    yo = orc.compressor(x[:, :, :300000], SR, *[c.cpu().numpy().astype(np.float64) for c in ctl])
+    assert np.abs(yc[:, :, :200000].detach().cpu().numpy() - yo[:, :, :200000]).max() < 2e-5 * np.abs(yo).max()
+
+
 def test_three_wave_backward_kernel_variant_agrees(D):
     """sos_bwd3w_kernel (checkpointed recomputation, three waves per SIMD; measured slower than the shipped kernel and off by default,
     profiles/r03/ab_bwd3w.log) stays correct: selected with DASP_BWD_KERNEL=3w in a fresh process (the switch is read once), it gives the
