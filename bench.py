@@ -264,6 +264,21 @@ def secondary(dev):
              2 * 0.537e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
+    # the boundary's long tail: lfilter_via_fsm with more than three coefficients (signal.py:95-133; csrc/lfilter.hip: double arithmetic,
+    # chunks of time side by side - not one of the tuned kernels, timed so that the record is complete)
+    import scipy.signal as _ss
+    _ba = _ss.butter(4, 0.3)
+    lf_b = torch.tensor(np.tile(_ba[0], (16, 1)), dtype=torch.float32, device=dev).requires_grad_(True)
+    lf_a = torch.tensor(np.tile(_ba[1], (16, 1)), dtype=torch.float32, device=dev).requires_grad_(True)
+    lf_x = (rnd(16, 1, 262144) * 2 - 1).requires_grad_(True)
+    lf_w = torch.randn(16, 1, 262144, device=dev, generator=g)
+
+    def lf_step():
+        lf_x.grad = None; lf_b.grad = None; lf_a.grad = None
+        D.signal.lfilter_via_fsm(lf_x, lf_b, lf_a).backward(lf_w)
+    res["lfilter_via_fsm_k5_b16"] = {"shape": [16, 1, 262144], "coefficients": 5, "ms_fwd_bwd": round(_time_steps(lf_step, steps=10, warmup=3) * 1e3, 3),
+                                     "note": "4th-order Butterworth per row, gradients for x, b, a; recurrence in double arithmetic"}
+    del lf_x, lf_w
     # the reference's whole effect chain as its training loop calls it (examples/style_transfer.py:150-154: EQ -> compressor -> reverb -> gain
     # through process_normalized, mono input, no gradient for it) at its batch size: everything of SURVEY 8(f) that is in - fused
     # process_normalized, no-gx EQ backward, segmented rows / items, gain folded into the make-up gain, no saved wet signal
