@@ -1237,7 +1237,7 @@ sos_bwd3w_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
                  const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                  float* __restrict__ partials, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
-    static_assert(S == 6 && L == 16, "checkpoint split 3 + 3, 16-sample chunks");
+    static_assert((S == 6 || S == 8) && L == 16, "checkpoint split 3 + 3 or 4 + 4, 16-sample chunks");
     constexpr bool GX = !(FLAGS & BWD_NOGX), FAST = FLAGS & BWD_FAST;
     constexpr int NACC = FAST ? 4 : 5, KEEP = FAST ? L + 1 : L + 2, HS = S / 2;
     constexpr int TS = 64 * L, IMG = 64 * L, STR = S * 128, REGION = 2 * IMG + STR;      // floats per wave: gy image, x image, states
@@ -1734,6 +1734,20 @@ inline bool use_bwd3w(int S, int designed) {     // designed cascades only: the 
 }   // ... of the adjoint-only variant (no coefficient gradients: ~100 registers, 8 KiB of LDS per wave - the
                                        // forward kernel's shape; with kWB waves it ran at 2 waves per SIMD and was latency-bound, 0.159 ms)
 
+// Eight sections: sos_bwd_kernel<8> parks half of its kept signals in LDS (145 KiB per workgroup: one wave per SIMD). The checkpointed
+// kernel instantiated for 4 + 4 sections keeps 4 x 18 registers, 12 KiB of LDS per wave and runs two waves per SIMD like the six-section
+// kernel (kWB waves per row: the partial sums keep their layout). DASP_BWD8_CHECKPOINT=0 / 1 at run time overrides the build's default.
+#ifndef DASP_BWD8_CHECKPOINT
+#define DASP_BWD8_CHECKPOINT 1
+#endif
+inline bool use_bwd8cp(int S) {
+    static const int pick = [] {
+        const char* e = getenv("DASP_BWD8_CHECKPOINT");
+        return e ? (e[0] != '0') : (DASP_BWD8_CHECKPOINT != 0);
+    }();
+    return pick && S == 8;
+}
+
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
@@ -1888,6 +1902,18 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
             hipLaunchKernelGGL((sos_bwd3w_kernel<6, kL, kWB3, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
         else
             hipLaunchKernelGGL((sos_bwd3w_kernel<6, kL, kWB3, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
+        return check_launch();
+    }
+    if (use_bwd8cp(S) && !(flags & BWD_NOGC)) {
+        const dim3 g(B * C), b(64 * kWB);
+        hipStream_t st = (hipStream_t)stream;
+        const int bc = Bs == 1 && B != 1;
+        switch (flags) {
+            case 0: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            case BWD_NOGX: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            case BWD_FAST: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            default: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+        }
         return check_launch();
     }
     return dispatch_S(S, [&](auto s) {

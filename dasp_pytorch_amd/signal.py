@@ -98,9 +98,10 @@ def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
     """Cascade of second-order sections along the last dim of x (reference: signal.py:136-166).
 
     sos: (bs, n_sections, 6) rows [b0 b1 b2 a0 a1 a2]; bs may be 1 (broadcast). x: (bs, ..., T).
-    Differentiable w.r.t. both. Up to 8 sections are one launch per direction (7 and 8 sections on 128 rows or more: two calls of 4);
-    longer cascades are applied as successive calls of at most 6 sections (the 8-section backward kernel holds one wave per SIMD, the 6-section one two: 12 sections on (256, 2, 131072)
-    take 0.89 ms as 6 + 6 against 1.08 ms as 8 + 4, profiles/r02/sections_per_call.log)."""
+    Differentiable w.r.t. both. Up to 8 sections are one launch per direction (round 3: the 8-section backward is the checkpointed
+    kernel, 4 + 4 sections at two waves per SIMD - 0.61 ms forward + backward on (256, 2, 131072) against 0.67 ms as two calls of 4);
+    longer cascades are applied as successive calls of at most 6 sections (12 sections: 0.85 ms as 6 + 6 against 0.94 as 8 + 4,
+    profiles/r02/sections_per_call.log, profiles/r03/sections_per_call.log)."""
     bs, n_sections, n_coeffs = sos.size()
     assert n_coeffs == 6  # must be second order (signal.py:24)
     shape = x.shape
@@ -108,8 +109,6 @@ def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
     if is_f64(x):            # float64 in, float64 arithmetic, as the reference (ops64.py): any number of sections in one call
         return SosFilt64Function.apply(sos, xx).reshape(shape)
     step = 8 if n_sections <= 8 else 6
-    if 6 < n_sections <= 8 and xx.shape[0] * xx.shape[1] >= 128:
-        step = 4              # enough rows to fill the chip: two 4-section launches beat the one-wave-per-SIMD 8-section backward (0.714 -> 0.668 ms)
     for s0 in range(0, n_sections, step):
         xx = SosFiltFunction.apply(sos[:, s0:s0 + step], xx)
     return xx.reshape(shape)

@@ -143,8 +143,10 @@ def test_section_counts(D, S):
 
 @pytest.mark.parametrize("S", [7, 8])
 def test_seven_and_eight_sections_on_a_full_grid(D, S):
-    """From 128 rows on, 7 / 8 sections run as two calls of 4 (signal.sosfilt_via_fsm: the 8-section backward kernel holds one wave per
-    SIMD): outputs against the recursion oracle, gradients against the one-call path on a 127-row slice-free rerun of the same rows."""
+    """7 / 8 sections on 128 rows: one call per direction, its backward the checkpointed kernel (sos_bwd3w_kernel<8>: 4 + 4 sections, two
+    waves per SIMD; round 2 split these into two calls of 4 because sos_bwd_kernel<8> holds one wave per SIMD): outputs and input gradient
+    against the recursion oracle, coefficient gradients against a rerun of 20 of the items as 40 rows - segmented rows, i.e. the other
+    8-section backward kernel."""
     from oracle.recursion import sosfilt_ref, sosfilt_vjp_ref
     g = np.random.default_rng(40 + S)
     B, C, N = 64, 2, 3000
@@ -156,13 +158,13 @@ def test_seven_and_eight_sections_on_a_full_grid(D, S):
     x = (g.random((B, C, N)) * 2 - 1).astype(np.float32)
     w = g.standard_normal((B, C, N)).astype(np.float32)
     xt = dev(x).requires_grad_(True); st = dev(sos).requires_grad_(True)
-    y = D.signal.sosfilt_via_fsm(st, xt)                       # 128 rows: 4 + 4 (4 + 3)
+    y = D.signal.sosfilt_via_fsm(st, xt)                       # 128 rows, one workgroup per row: the checkpointed 8-section backward
     (y * dev(w)).sum().backward()
     yo = sosfilt_ref(sos.astype(np.float64), x)
     gxo = sosfilt_vjp_ref(sos.astype(np.float64), w)
     assert linf_peak(y.detach().cpu().numpy(), yo).max() < 5e-5
     assert linf_peak(xt.grad.cpu().numpy(), gxo).max() < 5e-5
-    sel = slice(0, 20)                                          # the same items as 40 rows: one call of 8 sections
+    sel = slice(0, 20)                                          # the same items as 40 rows: segmented rows, sos_bwd_kernel<8>
     x2 = dev(x[sel]).requires_grad_(True); s2 = dev(sos[sel]).requires_grad_(True)
     (D.signal.sosfilt_via_fsm(s2, x2) * dev(w[sel])).sum().backward()
     a, b = st.grad[sel].cpu().numpy(), s2.grad.cpu().numpy()
