@@ -363,5 +363,5 @@ def test_chain_as_graphed_callable(D):
         for a, b in zip(pg, pe):
             assert float((a.grad - b.grad).abs().max()) <= 1e-5 * max(float(b.grad.abs().max()), 1e-12)
         if step:
-            assert float((yg - y_prev).abs().max()) > 1e-3 * float(yg.abs().max())       # the offset word changed the noise of the replay
+            assert float((yg.detach() - y_prev).abs().max()) > 1e-3 * float(yg.detach().abs().max())       # the offset word changed the noise of the replay
         y_prev = yg.detach().clone()
