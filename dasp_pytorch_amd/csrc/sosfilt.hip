@@ -1213,8 +1213,12 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward, three waves per SIMD (S = 6, designed cascade, coefficient gradients wanted, one workgroup per row) - an experiment that LOST
-// (numbers at the dispatch switch below, DASP_BWD_3W); selectable with DASP_BWD_KERNEL=3w, covered by tests/test_gpu_sosfilt.py.
+// Backward with checkpointed recomputation (coefficient gradients wanted, one workgroup per row). Two uses:
+//   S = 8 (sosfilt_via_fsm with 7 / 8 sections; 4 + 4 sections, kWB waves per row, two waves per SIMD): the shipped kernel - it replaces
+//         sos_bwd_kernel<8>, whose parked signals (145 KiB of LDS per workgroup) leave one wave per SIMD: 0.72 -> 0.61 ms (DASP_BWD8_CHECKPOINT);
+//   S = 6 (the EQ; 3 + 3 sections, three waves per SIMD) - an experiment that LOST against sos_bwd_kernel<6> (numbers at the dispatch switch
+//         below, DASP_BWD_3W); selectable with DASP_BWD_KERNEL=3w, covered by tests/test_gpu_sosfilt.py.
+// The description that follows is the S = 6 case.
 // sos_bwd_kernel above holds the kept signals of all six sections at once (102 registers; 255 in all) and three 4 KiB tile images per
 // wave: two waves per SIMD, and a wave issues at most one VALU instruction per ~6 cycles whatever its instruction-level parallelism
 // (tools/ubench) - a SIMD with two waves cannot use more than two thirds of its issue slots, and every lane-scan / LDS / mailbox phase of
@@ -1233,7 +1237,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 // except that a row's tiles are dealt to six waves instead of four).
 template <int S, int L, int W, int FLAGS>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
-sos_bwd3w_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
+sos_bwd_ckpt_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                  const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                  float* __restrict__ partials, int C, int N, int nt, int vec) {
     using LY = SosLayout<S, L>;
@@ -1709,7 +1713,7 @@ constexpr int kWB = DASP_BWD_W;    // waves per row, backward (2 rows per CU -> 
 #define DASP_BWD_W_ADJ 8
 #endif
 constexpr int kWBA = DASP_BWD_W_ADJ;
-// The three-waves-per-SIMD backward kernel (sos_bwd3w_kernel: S = 6, coefficient gradients, one workgroup of kWB3 waves per row).
+// The three-waves-per-SIMD backward kernel (sos_bwd_ckpt_kernel: S = 6, coefficient gradients, one workgroup of kWB3 waves per row).
 // DASP_BWD_KERNEL=2w / 3w at run time overrides the build's default (developer A/B in one library).
 // MEASURED NEGATIVE (profiles/r03/ab_bwd3w*.log, same box, bwd + finalize at (256, 2, 131072)): two-wave kernel 0.256 ms; this one with six-wave
 // workgroups 0.349 - 0.361, with four-wave workgroups (three per CU) 0.284, and the same four-wave build with its LDS padded so that only
@@ -1899,9 +1903,9 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
         hipStream_t st = (hipStream_t)stream;
         const int bc = Bs == 1 && B != 1;
         if (flags & BWD_NOGX)
-            hipLaunchKernelGGL((sos_bwd3w_kernel<6, kL, kWB3, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
+            hipLaunchKernelGGL((sos_bwd_ckpt_kernel<6, kL, kWB3, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
         else
-            hipLaunchKernelGGL((sos_bwd3w_kernel<6, kL, kWB3, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
+            hipLaunchKernelGGL((sos_bwd_ckpt_kernel<6, kL, kWB3, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
         return check_launch();
     }
     if (use_bwd8cp(S) && !(flags & BWD_NOGC)) {
@@ -1909,10 +1913,10 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
         hipStream_t st = (hipStream_t)stream;
         const int bc = Bs == 1 && B != 1;
         switch (flags) {
-            case 0: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-            case BWD_NOGX: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-            case BWD_FAST: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-            default: hipLaunchKernelGGL((sos_bwd3w_kernel<8, kL, kWB, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            case 0: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            case BWD_NOGX: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            case BWD_FAST: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
+            default: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
         }
         return check_launch();
     }

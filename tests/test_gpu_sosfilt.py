@@ -143,7 +143,7 @@ def test_section_counts(D, S):
 
 @pytest.mark.parametrize("S", [7, 8])
 def test_seven_and_eight_sections_on_a_full_grid(D, S):
-    """7 / 8 sections on 128 rows: one call per direction, its backward the checkpointed kernel (sos_bwd3w_kernel<8>: 4 + 4 sections, two
+    """7 / 8 sections on 128 rows: one call per direction, its backward the checkpointed kernel (sos_bwd_ckpt_kernel<8>: 4 + 4 sections, two
     waves per SIMD; round 2 split these into two calls of 4 because sos_bwd_kernel<8> holds one wave per SIMD): outputs and input gradient
     against the recursion oracle, coefficient gradients against a rerun of 20 of the items as 40 rows - segmented rows, i.e. the other
     8-section backward kernel."""
@@ -635,7 +635,7 @@ def test_sixteen_million_samples(D):
 
 
 def test_three_wave_backward_kernel_variant_agrees(D):
-    """sos_bwd3w_kernel (checkpointed recomputation, three waves per SIMD; measured slower than the shipped kernel and off by default,
+    """sos_bwd_ckpt_kernel (checkpointed recomputation, three waves per SIMD; measured slower than the shipped kernel and off by default,
     profiles/r03/ab_bwd3w.log) stays correct: selected with DASP_BWD_KERNEL=3w in a fresh process (the switch is read once), it gives the
     shipped kernel's input gradient and control gradients - with and without a gradient for x, full and ragged last tile."""
     import subprocess, sys, tempfile, os
