@@ -41,16 +41,20 @@ def build_lib(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    objs = []
+    objs, jobs = [], []
     for src in sources():
         obj = src[:-4] + ".o"
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *[os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".hpp")]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed", "-Wno-inline-asm", "-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed", "-Wno-inline-asm", "-c", src, "-o", obj])
         objs.append(obj)
+    if jobs:        # one hipcc per stale source, side by side (sosfilt.hip alone is most of a serial build)
+        from concurrent.futures import ThreadPoolExecutor
+        if verbose:
+            for cmd in jobs:
+                print(" ".join(cmd), file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(subprocess.check_call, jobs))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
