@@ -91,6 +91,15 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         return _MRSTFTFunction.apply(input, target, self.resolutions, self.eps)
 
 
+class STFTLoss(MultiResolutionSTFTLoss):
+    """auraloss.freq.STFTLoss with its default arguments (one resolution: fft 1024, hop 256, window 1024; w_sc = w_log_mag = 1, hann window,
+    L1 magnitude distance, mean reduction) - the loss of the reference's examples/blind_estimation.py:141. One resolution of the same
+    kernels (csrc/stftloss.hip)."""
+
+    def __init__(self, fft_size: int = 1024, hop_size: int = 256, win_length: int = 1024, eps: float = 1e-8):
+        super().__init__((fft_size,), (hop_size,), (win_length,), eps)
+
+
 def mrstft_loss(input: torch.Tensor, target: torch.Tensor, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240),
                 eps: float = 1e-8):
     return _MRSTFTFunction.apply(input, target, tuple(zip(fft_sizes, hop_sizes, win_lengths)), eps)

@@ -96,3 +96,21 @@ def test_mrstft_conventions(D):
         fn(x, y[:, :, :100])
     with pytest.raises(DaspHipError):
         fn(x.cpu(), y.cpu())
+
+
+def test_single_resolution_stft_loss(D):
+    """losses.STFTLoss (auraloss.freq.STFTLoss with its defaults: fft 1024, hop 256, window 1024; the reference's
+    examples/blind_estimation.py:141) = one resolution of the same kernels: value and gradient against the oracle."""
+    rng = np.random.default_rng(12)
+    B, C, N = 3, 2, 20000
+    x = (rng.random((B, C, N)) * 0.8 - 0.4).astype(np.float32)
+    y = (x + 0.05 * rng.standard_normal((B, C, N))).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    loss = D.losses.STFTLoss()(xt, torch.from_numpy(y).cuda())
+    loss.backward()
+    res = ((1024, 256, 1024),)
+    lo = orc.mrstft_loss(x, y, res)
+    go = orc.mrstft_loss_vjp(x, y, res)
+    assert abs(float(loss) - lo) < 2e-5 * abs(lo)
+    g = xt.grad.cpu().numpy()                   # (sign(log P - log T) flips where the two magnitudes meet: a norm, not the largest entry)
+    assert np.linalg.norm(g - go) < 1e-2 * np.linalg.norm(go)
