@@ -565,6 +565,9 @@ def main():
             "roofline_fwd": dict(roof(8, t_fwd, "fwd"), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),
             "roofline_fwd_bwd": dict(roof(20, t_fwd + t_bwd, "both"), ms=round((t_fwd + t_bwd) * 1e3, 4), algorithmic_bytes=20 * units),
             "small_kernels_ms": round(t_small * 1e3, 4),
+            # the same rate in frames (B N per step over all ranks) and the step as achieved HBM rate on its algorithmic bytes
+            "frames_per_s": value / C,
+            "step_algorithmic_GBps_per_gpu": round(20 * units / (dt / args.steps) / 1e9, 1),
             "traffic_file": traffic_file, "kernel_source_hash": kernel_source_hash(),
             "finite": finite,
         }
