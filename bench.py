@@ -521,8 +521,15 @@ def main():
         # Events around every 4th launch of each entry point only, over 240 back-to-back steps: the chip runs these kernels at its power
         # limit, and the idle microseconds an event pair inserts let the next kernel run at a higher clock - with events around every
         # launch the kernels measured 4 % faster than rocprofv3 sees them in the uninstrumented step (profiles/r03/README.md).
+        # The instrumented step costs more host time than the product path (four C calls and event records instead of two calls): on
+        # a slow host the GPU would wait for launches and run the kernels at a higher clock than inside the timed step (seen: events 10 %
+        # below the step, box dependent). 0.1 s of graph replays queued in front keep the GPU busy while the host issues the instrumented
+        # steps into the queue behind them, so that these run back to back as the timed ones did.
         ramp(step, 0.25)
         _lib.timers.start(every=4)
+        if "graph" in blocks and os.environ.get("DASP_BENCH_EVENT_BLOCKER", "1") != "0":
+            for _ in range(250):
+                graph.replay()
         for _ in range(240):
             step()
         ktimes = _lib.timers.stop()
@@ -565,6 +572,9 @@ def main():
             "roofline_fwd": dict(roof(8, t_fwd, "fwd"), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),
             "roofline_fwd_bwd": dict(roof(20, t_fwd + t_bwd, "both"), ms=round((t_fwd + t_bwd) * 1e3, 4), algorithmic_bytes=20 * units),
             "small_kernels_ms": round(t_small * 1e3, 4),
+            # consistency of the event pass with the timed step: the four kernels' event durations over the step (gaps between the kernels
+            # are the rest; a ratio well below ~0.97 means the instrumented pass ran the kernels at another clock than the timed step did)
+            "kernel_events_over_step": round((t_fwd + t_bwd + t_small) / (dt / args.steps), 4),
             # the same rate in frames (B N per step over all ranks) and the step as achieved HBM rate on its algorithmic bytes
             "frames_per_s": value / C,
             "step_algorithmic_GBps_per_gpu": round(20 * units / (dt / args.steps) / 1e9, 1),
