@@ -521,18 +521,31 @@ def main():
         # Events around every 4th launch of each entry point only, over 240 back-to-back steps: the chip runs these kernels at its power
         # limit, and the idle microseconds an event pair inserts let the next kernel run at a higher clock - with events around every
         # launch the kernels measured 4 % faster than rocprofv3 sees them in the uninstrumented step (profiles/r03/README.md).
-        # The instrumented step costs more host time than the product path (four C calls and event records instead of two calls): on
-        # a slow host the GPU would wait for launches and run the kernels at a higher clock than inside the timed step (seen: events 10 %
-        # below the step, box dependent). 0.1 s of graph replays queued in front keep the GPU busy while the host issues the instrumented
-        # steps into the queue behind them, so that these run back to back as the timed ones did.
+        # The instrumented step costs more host time than the GPU needs for it (four C calls, autograd and event records: 0.47 - 0.62 ms
+        # issued per step on the boxes measured, against 0.40 ms of kernels): left alone the pass is host-bound, the GPU waits for
+        # launches, and a power-limited kernel runs at a higher clock after every wait (seen: backward events 3 - 11 % below the timed
+        # step, by box). So the GPU is given a backlog first - graph replays, which cost the host ~15 us each - sized from a probe of the
+        # host's issue rate so that the queue never runs dry while the 240 instrumented steps are issued behind it.
         ramp(step, 0.25)
         _lib.timers.start(every=4)
+        sync()
+        t_p0 = time.perf_counter()
+        for _ in range(16):
+            step()
+        host_per_step = (time.perf_counter() - t_p0) / 16
+        sync()
+        _lib.timers.start(every=4)                                     # (the probe's samples are dropped)
+        gpu_per_step = min(float(np.median(v)) for v in blocks.values()) / args.steps
+        n_rep = 0
         if "graph" in blocks and os.environ.get("DASP_BENCH_EVENT_BLOCKER", "1") != "0":
-            for _ in range(250):
+            n_rep = min(4000, 200 + int(3.0 * 240 * max(0.0, host_per_step - gpu_per_step) / gpu_per_step))      # 3x the computed deficit: the probe ran on an idle host
+            for _ in range(n_rep):
                 graph.replay()
         for _ in range(240):
             step()
         ktimes = _lib.timers.stop()
+        print(f"[bench] event pass: {1e3 * host_per_step:.3f} ms of host time per instrumented step, {1e3 * gpu_per_step:.3f} ms of GPU time; "
+              f"{n_rep} graph replays queued in front", file=sys.stderr)
     finite = bool(torch.isfinite(x.grad).all().item()) and all(bool(torch.isfinite(c.grad).all().item()) for c in cols)
 
     if rank == 0:
