@@ -115,6 +115,29 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         # (gx of the panner / widener is a two-term signed sum per sample: on a one-sample signal it can cancel, hence the floor)
         note(name, "y", rel(y.detach().cpu().numpy(), f(xx, SR, c)), 3e-6, cfg + (Tn,)); note(name, "gx", rel(xt.grad.cpu().numpy(), gxo, 0.05 * float(np.abs(ww).max())), 3e-6, cfg + (Tn,))
         note(name, "gc", rel(ct.grad.cpu().numpy(), gco, 0.05 * float(np.abs(ww).max()) * float(np.sqrt(xx.size / c.size))), 2e-4, cfg + (Tn,))
+    # sosfilt_via_fsm with 1 .. 8 sections (one call per direction) on few and many rows (from ~128 rows on a row has a workgroup of its own: for 7 / 8 sections
+    # that is the checkpointed backward kernel, for fewer rows the segmented kernels): y and grad x against the fp64 recursion, the
+    # coefficient gradients against the float64 path. Random cascades are far worse conditioned than the EQ's (a resonance in one section,
+    # a zero next to it in another: intermediate signals dwarf the output) - the bounds are those a plain fp32 recursion meets on the
+    # same inputs (scripts/sections_accuracy.py)
+    if n_cfg % 4 == 0:
+        Sx = int(rng.integers(1, 9)); Bq = int(rng.choice([1, 3, 40, 70, 100])); Cq = int(rng.integers(1, 3)); Nq = min(randN(), 6000)
+        rr = 0.2 + 0.75 * rng.random((Bq, Sx)); th = 3.0 * rng.random((Bq, Sx)) + 0.05
+        sq = np.zeros((Bq, Sx, 6)); sq[..., :3] = rng.standard_normal((Bq, Sx, 3)) * 0.7
+        sq[..., 3] = 1.0 + 0.2 * rng.random((Bq, Sx)); sq[..., 4] = -2 * rr * np.cos(th) * sq[..., 3]; sq[..., 5] = rr * rr * sq[..., 3]
+        sq = sq.astype(np.float32)
+        xq = (rng.random((Bq, Cq, Nq)) * 2 - 1).astype(np.float32); wq = rng.standard_normal((Bq, Cq, Nq)).astype(np.float32)
+        needx = bool(rng.random() < 0.7)
+        xt = T(xq).requires_grad_(needx); st = T(sq).requires_grad_(True)
+        y = D.signal.sosfilt_via_fsm(st, xt); (y * T(wq)).sum().backward()
+        sqn = sq.astype(np.float64) / sq[..., 3:4].astype(np.float64)
+        note("sos", "y", rel(y.detach().cpu().numpy(), sosfilt_ref(sqn, xq)), 3e-4, (Bq, Cq, Nq, Sx))
+        if needx:
+            note("sos", "gx", rel(xt.grad.cpu().numpy(), sosfilt_vjp_ref(sqn, wq)), 3e-4, (Bq, Cq, Nq, Sx))
+        s64 = T(sq.astype(np.float64)).requires_grad_(True)
+        (D.signal.sosfilt_via_fsm(s64, T(xq.astype(np.float64))) * T(wq.astype(np.float64))).sum().backward()
+        gref = s64.grad.cpu().numpy()
+        note("sos", "gsos", float(np.abs(st.grad.cpu().numpy() - gref).max() / np.abs(gref).max()), 1e-3, (Bq, Cq, Nq, Sx, needx))
     # reverb (small impulse responses, odd shapes)
     if n_cfg % 3 == 0:
         L = int(rng.choice([64, 300, 1000, 2048, 3000, 5000, 9000])); taps = int(rng.choice([15, 63, 127, 1023]))
