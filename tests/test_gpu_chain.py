@@ -74,11 +74,11 @@ def test_fused_forward_equals_unfused_sequence(D, monkeypatch, B, C, N, tiles):
         assert _lib.lib().dasp_chain_segment_tiles(B, N) > 0                       # the planner does cut the reference's training shape
     e = linf_peak(yf.cpu().numpy(), yu.cpu().numpy())
     record(f"chain_fused_vs_unfused[{B},{C},{N},{tiles}]", y=e.max())
-    assert torch.isfinite(yf).all() and e.max() < 5e-6, e
+    assert torch.isfinite(yf).all() and e.max() < 1e-5, e          # (measured <= 4.0e-6; the differentiable sequence is itself ~2e-6 from the oracle, this path 2.8e-7)
     if tiles is None and B <= 5:      # segmented and plain fused passes agree with each other as well
         monkeypatch.setenv("DASP_CHAIN_SEGMENT", "0")
         y0 = fused(x, eq_pn, comp)
-        assert linf_peak(yf.cpu().numpy(), y0.cpu().numpy()).max() < 5e-6
+        assert linf_peak(yf.cpu().numpy(), y0.cpu().numpy()).max() < 1e-5
 
 
 @pytest.mark.parametrize("B,C,N,tiles", [(3, 2, 9000, None), (4, 1, 70000, None), (2, 2, 131072, 16)])
@@ -93,7 +93,7 @@ def test_fused_forward_with_one_shared_eq(D, monkeypatch, B, C, N, tiles):
     yu = unfused(D, x, eq_pn[:1], comp)
     e = linf_peak(yf.cpu().numpy(), yu.cpu().numpy())
     record(f"chain_fused_shared_eq[{B},{C},{N},{tiles}]", y=e.max())
-    assert e.max() < 5e-6, e
+    assert e.max() < 1e-5, e
 
 
 @pytest.mark.parametrize("B,C,N", [(3, 2, 20000), (2, 1, 70001)])
