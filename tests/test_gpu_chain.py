@@ -147,6 +147,6 @@ def test_chain_module_takes_the_fused_path_without_grad(D, monkeypatch):
     torch.manual_seed(21)
     y_g = chain.process_normalized(x, *pp)
     assert len(calls) == 1 and y_g.requires_grad
-    assert float((y_ng - y_g.detach()).abs().max()) <= 5e-6 * float(y_g.detach().abs().max())
+    assert float((y_ng - y_g.detach()).abs().max()) <= 1e-5 * float(y_g.detach().abs().max())
     with pytest.raises(RuntimeError):
         ops.chain_eq_compressor_forward(x.requires_grad_(True), ps[0], [1, 0, 0, 0, 0, 2], [0.0] * 18, [1.0] * 18, float(SR), torch.zeros(B, 5, device="cuda:0"))
