@@ -55,13 +55,16 @@ __device__ __forceinline__ void loss_terms(const Bin& b, float eps, float& s1, f
     s3 += 0.5f * fabsf(__logf(__fdividef(p2, t2)));       // |log pm - log tm| = |log(p2 / t2)| / 2; the ratio stays within 1e-14 .. 1e14
 }
 // one bin of the gradient spectrum: dL/d|P| * P / |P|
-__device__ __forceinline__ void grad_bin(const Bin& b, float eps, float k_sc, float k_lm, float& hr, float& hi) {
+// k_self: the gradient w.r.t. the SECOND signal of the loss (the kernels are then called with the two signals swapped): the spectral
+// convergence term is normalised by that signal's own norm, d/d|T| (s1 / s2) = (|T| - |P|) / (s1 s2) - s1 |T| / s2^3 - the first part is what
+// the swapped call computes anyway, the second is k_self = - s1 / s2^3 times the spectrum itself; the log-magnitude term is symmetric.
+__device__ __forceinline__ void grad_bin(const Bin& b, float eps, float k_sc, float k_lm, float k_self, float& hr, float& hi) {
     hr = 0.f; hi = 0.f;
     const float praw = b.pr * b.pr + b.pi * b.pi;
     if (praw > eps) {                                            // the clamp has zero slope below eps
         const float tm = sqrtf(fmaxf(b.tr * b.tr + b.ti * b.ti, eps)), pm = sqrtf(praw);
         const float sgn = tm > pm ? 1.f : (tm < pm ? -1.f : 0.f);            // sign(log tm - log pm)
-        const float gm = (k_sc * (pm - tm) - k_lm * sgn / pm) / pm;           // dL/d|P| / |P|
+        const float gm = (k_sc * (pm - tm) - k_lm * sgn / pm) / pm + k_self;  // dL/d|P| / |P|
         hr = gm * b.pr; hi = gm * b.pi;
     }
 }
@@ -182,7 +185,7 @@ __global__ void mrstft_finalize_kernel(StftSpec spec, int rows, float* __restric
 // gpred (rows, N) must be zero on entry; gloss = d(objective)/d(loss), a device scalar
 __global__ void __launch_bounds__(512)
 mrstft_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const f2* __restrict__ tw, const float* __restrict__ stats,
-                  const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N, int res) {
+                  const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N, int res, int wrt_second) {
     __shared__ f2 lds[ColGeom<12>::LDS];
     __shared__ float wlds[FFT_N];
     const StftRes R = spec.r[res];
@@ -196,12 +199,12 @@ mrstft_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ
     frames_to_spectra(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, R, g, tw, lds, wlds, r, i, mr, mi);
     const float s1 = stats[res * 4], s2 = stats[res * 4 + 1], count = stats[res * 4 + 2];
     const float gl = gloss[0] / (float)spec.nres;
-    const float k_sc = s1 > 0.f ? gl / (s1 * s2) : 0.f, k_lm = gl / count;
+    const float k_sc = s1 > 0.f ? gl / (s1 * s2) : 0.f, k_lm = gl / count, k_self = wrt_second ? -gl * s1 / (s2 * s2 * s2) : 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int k = g.j + g.T * q;
         float hr = 0.f, hi = 0.f;
-        if (live && k <= F / 2) grad_bin(split_bin(r[q], i[q], mr[q], mi[q]), spec.eps, k_sc, k_lm, hr, hi);
+        if (live && k <= F / 2) grad_bin(split_bin(r[q], i[q], mr[q], mi[q]), spec.eps, k_sc, k_lm, k_self, hr, hi);
         r[q] = hr; i[q] = hi;
     }
     col_fft<1>(r, i, g, tw, lds);                                    // sum_k H[k] e^{+2 pi i k n / F}, H = 0 on the upper half
@@ -336,7 +339,7 @@ mrstft_fwd_split_kernel(const float* __restrict__ pred, const float* __restrict_
 template <int R>
 __global__ void __launch_bounds__(512)
 mrstft_bwd_split_kernel(const float* __restrict__ pred, const float* __restrict__ target, const f2* __restrict__ tw, const float* __restrict__ stats,
-                        const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N, int res) {
+                        const float* __restrict__ gloss, float* __restrict__ gpred, StftSpec spec, int N, int res, int wrt_second) {
     constexpr int F = 512 * R, G = 8 / R;
     __shared__ f2 lds[8 * FFT512_LDS];
     __shared__ float wlds[512 * R];
@@ -352,13 +355,13 @@ mrstft_bwd_split_kernel(const float* __restrict__ pred, const float* __restrict_
     split_frame_spectrum<R>(pred + (size_t)row * N, target + (size_t)row * N, N, frame, live, Rs, g, tw, t5, lds, wlds, r, i, mr, mi);
     const float s1 = stats[res * 4], s2 = stats[res * 4 + 1], count = stats[res * 4 + 2];
     const float gl = gloss[0] / (float)spec.nres;
-    const float k_sc = s1 > 0.f ? gl / (s1 * s2) : 0.f, k_lm = gl / count;
+    const float k_sc = s1 > 0.f ? gl / (s1 * s2) : 0.f, k_lm = gl / count, k_self = wrt_second ? -gl * s1 / (s2 * s2 * s2) : 0.f;
     float h4r = 0.f, h4i = 0.f;
-    if (live && g.rp == 0 && g.l == 0) grad_bin(split_bin(r[4], i[4], r[4], i[4]), spec.eps, k_sc, k_lm, h4r, h4i);
+    if (live && g.rp == 0 && g.l == 0) grad_bin(split_bin(r[4], i[4], r[4], i[4]), spec.eps, k_sc, k_lm, k_self, h4r, h4i);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         float hr = 0.f, hi = 0.f;
-        if (live) grad_bin(split_bin(r[s], i[s], mr[s], mi[s]), spec.eps, k_sc, k_lm, hr, hi);
+        if (live) grad_bin(split_bin(r[s], i[s], mr[s], mi[s]), spec.eps, k_sc, k_lm, k_self, hr, hi);
         r[s] = hr; i[s] = hi;
     }
     r[4] = h4r; i[4] = h4i;
@@ -465,26 +468,36 @@ int dasp_mrstft_forward(const float* pred, const float* target, const void* tw, 
     hipLaunchKernelGGL(mrstft_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s, rows, stats, loss);
     return sl_check();
 }
-/* gpred (rows, N) is overwritten with gloss * d loss / d pred (gloss: device scalar) */
-int dasp_mrstft_backward(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss, float* gpred, int rows,
-                         int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream) {
-    if (!pred || !target || !tw || !stats || !gloss || !gpred || rows <= 0 || N <= 0) return DASP_ERR_ARG;
+/* gpred (rows, N) is overwritten with gloss * d loss / d pred (gloss: device scalar); dasp_mrstft_backward_target: the same for the
+ * second signal, gtarget = gloss * d loss / d target (auraloss differentiates both arguments: a consistency loss between two model
+ * outputs needs it; the reference's call sites pass the reference signal there and never ask) */
+static int mrstft_backward_impl(const float* first, const float* second, const void* tw, const float* stats, const float* gloss, float* gfirst,
+                                int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps, int wrt_second, void* stream) {
+    if (!first || !second || !tw || !stats || !gloss || !gfirst || rows <= 0 || N <= 0) return DASP_ERR_ARG;
     StftSpec s;
     if (!sl_spec(N, nres, fft, hop, win, eps, &s)) return DASP_ERR_UNSUPPORTED;
     if (rows > 65535) return DASP_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(gpred, 0, (size_t)rows * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return sl_check();
+    if (hipMemsetAsync(gfirst, 0, (size_t)rows * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return sl_check();
     for (int r = 0; r < nres; ++r) {
         const int TC = FFT_N >> s.r[r].logF;
         const dim3 grid((unsigned)((s.r[r].frames + TC - 1) / TC), (unsigned)rows);
         hipStream_t st = (hipStream_t)stream;
         switch (s.r[r].logF) {
-            case 9: hipLaunchKernelGGL(mrstft_bwd_split_kernel<1>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r); break;
-            case 10: hipLaunchKernelGGL(mrstft_bwd_split_kernel<2>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r); break;
-            case 11: hipLaunchKernelGGL(mrstft_bwd_split_kernel<4>, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r); break;
-            default: hipLaunchKernelGGL(mrstft_bwd_kernel, grid, dim3(512), 0, st, pred, target, (const f2*)tw, stats, gloss, gpred, s, N, r);
+            case 9: hipLaunchKernelGGL(mrstft_bwd_split_kernel<1>, grid, dim3(512), 0, st, first, second, (const f2*)tw, stats, gloss, gfirst, s, N, r, wrt_second); break;
+            case 10: hipLaunchKernelGGL(mrstft_bwd_split_kernel<2>, grid, dim3(512), 0, st, first, second, (const f2*)tw, stats, gloss, gfirst, s, N, r, wrt_second); break;
+            case 11: hipLaunchKernelGGL(mrstft_bwd_split_kernel<4>, grid, dim3(512), 0, st, first, second, (const f2*)tw, stats, gloss, gfirst, s, N, r, wrt_second); break;
+            default: hipLaunchKernelGGL(mrstft_bwd_kernel, grid, dim3(512), 0, st, first, second, (const f2*)tw, stats, gloss, gfirst, s, N, r, wrt_second);
         }
     }
     return sl_check();
+}
+int dasp_mrstft_backward(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss, float* gpred, int rows,
+                         int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream) {
+    return mrstft_backward_impl(pred, target, tw, stats, gloss, gpred, rows, N, nres, fft, hop, win, eps, 0, stream);
+}
+int dasp_mrstft_backward_target(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss, float* gtarget,
+                                int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream) {
+    return mrstft_backward_impl(target, pred, tw, stats, gloss, gtarget, rows, N, nres, fft, hop, win, eps, 1, stream);
 }
 
 }  // extern "C"

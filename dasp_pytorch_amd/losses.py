@@ -19,8 +19,6 @@ class _MRSTFTFunction(torch.autograd.Function):
         _lib.require_same_device(inp, target=target)
         from .ops64 import require_fp32_ok
         require_fp32_ok(inp, "MultiResolutionSTFTLoss")
-        if ctx.needs_input_grad[1]:
-            raise RuntimeError("MultiResolutionSTFTLoss: only `input` is differentiable (the target is the reference signal); detach the target")
         if inp.shape != target.shape:
             raise RuntimeError(f"input {tuple(inp.shape)} and target {tuple(target.shape)} must have the same shape")
         L = _lib.lib()
@@ -42,6 +40,7 @@ class _MRSTFTFunction(torch.autograd.Function):
             call("dasp_mrstft_forward", ptr(p32), ptr(t32), ptr(tw), ptr(partials), ptr(stats), ptr(loss), rows, N, nres, *arr, float(eps), stream())
         ctx.save_for_backward(p32, t32, stats, tw)
         ctx.cfg = (rows, N, nres, arr, float(eps), inp.shape, inp.dtype)
+        ctx.tdtype = target.dtype
         return loss.to(inp.dtype)
 
     @staticmethod
@@ -49,11 +48,18 @@ class _MRSTFTFunction(torch.autograd.Function):
     def backward(ctx, gloss):
         p32, t32, stats, tw = ctx.saved_tensors
         rows, N, nres, arr, eps, shape, dtype = ctx.cfg
+        g = gt = None
         with torch.cuda.device(p32.device):
-            g = torch.empty_like(p32)
             gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
-            call("dasp_mrstft_backward", ptr(p32), ptr(t32), ptr(tw), ptr(stats), ptr(gl), ptr(g), rows, N, nres, *arr, eps, stream())
-        return g.reshape(shape).to(dtype), None, None, None
+            if ctx.needs_input_grad[0]:
+                g = torch.empty_like(p32)
+                call("dasp_mrstft_backward", ptr(p32), ptr(t32), ptr(tw), ptr(stats), ptr(gl), ptr(g), rows, N, nres, *arr, eps, stream())
+                g = g.reshape(shape).to(dtype)
+            if ctx.needs_input_grad[1]:      # auraloss differentiates both arguments (a consistency loss between two model outputs)
+                gt = torch.empty_like(t32)
+                call("dasp_mrstft_backward_target", ptr(p32), ptr(t32), ptr(tw), ptr(stats), ptr(gl), ptr(gt), rows, N, nres, *arr, eps, stream())
+                gt = gt.reshape(shape).to(ctx.tdtype)
+        return g, gt, None, None
 
 
 _TW = {}

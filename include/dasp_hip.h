@@ -344,6 +344,10 @@ int dasp_mrstft_forward(const float* pred, const float* target, const void* tw, 
                         int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
 int dasp_mrstft_backward(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss, float* gpred,
                          int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps, void* stream);
+/* the gradient w.r.t. the second signal (auraloss differentiates both): gtarget (rows, N) = gloss * d loss / d target */
+int dasp_mrstft_backward_target(const float* pred, const float* target, const void* tw, const float* stats, const float* gloss,
+                                float* gtarget, int rows, int N, int nres, const int* fft, const int* hop, const int* win, float eps,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Filters longer than one biquad.  Replaces dasp_pytorch.signal.lfilter_via_fsm (dasp_pytorch/signal.py:95-133) for K = 4 .. 16

@@ -114,3 +114,43 @@ def test_single_resolution_stft_loss(D):
     assert abs(float(loss) - lo) < 2e-5 * abs(lo)
     g = xt.grad.cpu().numpy()                   # (sign(log P - log T) flips where the two magnitudes meet: a norm, not the largest entry)
     assert np.linalg.norm(g - go) < 1e-2 * np.linalg.norm(go)
+
+
+def _torch_mrstft(p, t, resolutions, eps=1e-8):
+    """auraloss.freq.MultiResolutionSTFTLoss with its defaults, restated on torch.stft (float64, CPU, autograd for both arguments)."""
+    total = 0.0
+    for n_fft, hop, win in resolutions:
+        w = torch.hann_window(win, dtype=p.dtype)
+        mag = lambda v: torch.sqrt(torch.clamp(torch.view_as_real(torch.stft(v.reshape(-1, v.shape[-1]), n_fft, hop, win, w, return_complex=True)).pow(2).sum(-1), min=eps))
+        P, T = mag(p), mag(t)
+        total = total + torch.norm(T - P, p="fro") / torch.norm(T, p="fro") + (torch.log(P) - torch.log(T)).abs().mean()
+    return total / len(resolutions)
+
+
+@pytest.mark.parametrize("res", [((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)), ((256, 64, 256),)])
+def test_gradient_for_both_arguments(D, res):
+    """auraloss differentiates input and target; so does this loss (dasp_mrstft_backward_target: the backward kernels with the two signals
+    swapped plus the norm term of the spectral convergence). Both gradients against torch.stft + autograd in float64 on a draw whose
+    log-magnitude differences keep their sign (prediction = 1.5 x target + a little noise), and the plain case target.requires_grad =
+    False still returns None for it."""
+    rng = np.random.default_rng(3)
+    N = 9000
+    t = (rng.standard_normal((2, 1, N)) * 0.3).astype(np.float32)
+    p = (1.5 * t + 0.003 * rng.standard_normal((2, 1, N))).astype(np.float32)
+    kw = dict(fft_sizes=[r[0] for r in res], hop_sizes=[r[1] for r in res], win_lengths=[r[2] for r in res])
+    pt, tt = dev(p).requires_grad_(True), dev(t).requires_grad_(True)
+    loss = D.losses.MultiResolutionSTFTLoss(**kw)(pt, tt)
+    loss.backward()
+    pc, tc = torch.from_numpy(p).double().requires_grad_(True), torch.from_numpy(t).double().requires_grad_(True)
+    ref = _torch_mrstft(pc, tc, res)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-5 * abs(float(ref.detach()))
+    for name, g, go in (("input", pt.grad, pc.grad), ("target", tt.grad, tc.grad)):
+        g, go = g.cpu().double(), go
+        e2 = float((g - go).norm() / go.norm())
+        print(f"mrstft gradient w.r.t. {name}: rel L2 {e2:.2e}")
+        assert e2 < 2e-3, (name, e2)
+    t2 = dev(t)
+    p2 = dev(p).requires_grad_(True)
+    D.losses.MultiResolutionSTFTLoss(**kw)(p2, t2).backward()
+    assert t2.grad is None and float((p2.grad - pt.grad).abs().max()) <= 1e-6 * float(pt.grad.abs().max())
