@@ -1,5 +1,6 @@
 // Multi-resolution STFT loss (spectral convergence + log-magnitude L1 per resolution, mean over resolutions), forward and the
-// gradient with respect to the first signal: the op directly downstream of the effect chain in the reference's training loops
+// gradients with respect to either signal (the first: the chain's output at every call site of the reference; the second - auraloss
+// differentiates both - through the same kernels with the signals swapped, see grad_bin): the op directly downstream of the effect chain in the reference's training loops
 // (auraloss.freq.MultiResolutionSTFTLoss(), call sites examples/style_transfer.py:341,363, auto_eq.py:252, virtual_analog.py:288;
 // auraloss is not vendored in the reference: the algorithm of auraloss 0.4.0 with default arguments is restated in
 // oracle/dasp_oracle.py:mrstft_loss, "parity unpinned").
