@@ -30,8 +30,13 @@ The JSON line also carries
   roofline     -- HBM roofline of the dominant kernel (the backward cascade): algorithmic bytes per launch / average launch duration,
                   measured live with HIP events on the launch stream in a separate, untimed pass directly behind the timed blocks (the
                   events need the kernels as separate entry points, which is not how the product issues them, so they stay out of the
-                  timed region; 240 back-to-back steps, events around every 4th launch of each entry point); `traffic` = HBM bytes per launch from the PMC counters, read from profiles/<round>/hbm_traffic.json
-                  only if that file was produced from the kernel sources now loaded
+                  timed region; 240 back-to-back steps, events around every 4th launch of each entry point, queued behind a backlog of
+                  graph replays sized from a probe of the host's issue rate so that the GPU never waits for the host - a waiting GPU
+                  runs these power-limited kernels faster than the timed step does; DASP_BENCH_EVENT_BLOCKER=0 turns the backlog off);
+                  `kernel_events_over_step` = the four kernels' event durations over the timed step (0.97 - 1.03 when consistent);
+                  `traffic` = HBM bytes per launch from the PMC counters, read from profiles/<round>/hbm_traffic.json only if that
+                  file was produced from the kernel sources now loaded
+  frames_per_s, step_algorithmic_GBps_per_gpu -- the same rate in frames (B N) and the whole step on its 20 B per channel-sample
   roofline_*   -- the same for the forward kernel and for forward+backward together
   cpu_baseline -- the reference itself (oracle/_ref, staged by __graft_entry__.build(); kind "reference") on the host cores on a
                   bounded sub-batch (its best-case batch size), or, when it is not staged, the numpy restatement
