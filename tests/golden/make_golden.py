@@ -312,9 +312,47 @@ def lfilter_long_case(name, B, N, seed):
     print(name, sorted(out))
 
 
+def chain_case(name, B, N, seed, noise_seed):
+    """BASELINE config 5's effect chain as the reference wires it (examples/style_transfer.py:150-154): ParametricEQ -> Compressor ->
+    NoiseShapedReverb -> Gain, each through Processor.process_normalized (dasp_pytorch/modules.py:25-51), mono input (B, 1, N) ->
+    stereo output (B, 2, N), default 65,536-sample / 1,023-tap reverb. Stored from the reference's fp32 and fp64 runs: y, grad x and the
+    gradients w.r.t. all four normalised parameter tensors (18 + 6 + 25 + 1) - these cross every stage boundary (reverb grad x ->
+    compressor grad y -> EQ) - plus the EQ -> compressor prefix output `yec` (the pin for the fused forward kernel). The reverb's noise
+    comes from the global CPU generator: `noise_seed` is set immediately before the chain runs (the reverb is its only consumer)."""
+    g = torch.Generator().manual_seed(seed)
+    mods = [dasp_pytorch.ParametricEQ(SR), dasp_pytorch.Compressor(SR), dasp_pytorch.NoiseShapedReverb(SR), dasp_pytorch.Gain(SR)]
+    x = torch.rand(B, 1, N, generator=g) * 2 - 1
+    # a slow level envelope so that the compressor's three knee regions are all visited behind the EQ
+    env_db = torch.nn.functional.interpolate(torch.rand(B, 1, N // 500 + 2, generator=g) * 40 - 40, size=N, mode="linear")
+    x = x * 10 ** (env_db / 20)
+    pn = [torch.rand(B, m.num_params, generator=g) for m in mods]
+    pn[1][:, 4] = pn[1][:, 4].clamp_min(1e-3 / 12)            # knee_db > 0 (SURVEY Appendix A Q9)
+    w = torch.randn(B, 2, N, generator=g)
+    out = dict(x=f32(x), w=f32(w), noise_seed=np.int64(noise_seed), pn_eq=f32(pn[0]), pn_comp=f32(pn[1]), pn_rev=f32(pn[2]), pn_gain=f32(pn[3]))
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        xx = x.to(dt).clone().requires_grad_(True)
+        pp = [p.to(dt).clone().requires_grad_(True) for p in pn]
+        torch.manual_seed(noise_seed)
+        y = xx.clone()
+        y = mods[0].process_normalized(y, pp[0])
+        yec = y = mods[1].process_normalized(y, pp[1])
+        y = mods[2].process_normalized(y, pp[2])
+        y = mods[3].process_normalized(y, pp[3])
+        (y * w.to(dt)).sum().backward()
+        out["y" + tag], out["gx" + tag], out["yec" + tag] = f32(y), f32(xx.grad), f32(yec)
+        for key, p in zip(("eq", "comp", "rev", "gain"), pp):
+            out[f"gpn_{key}{tag}"] = f32(p.grad)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lfilter_long":          # round 3 addition; the other files regenerate bit-identically
         lfilter_long_case("lfilter_long_b3_n9000", 3, 9000, seed=131)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":                 # round 4 addition
+        torch.set_num_threads(8)
+        chain_case("chain_b2c1_n20000", 2, 20000, seed=141, noise_seed=6141)
         sys.exit(0)
     torch.set_num_threads(8)
     eq_case("eq_b3c2_n12000", 3, 2, 12000, 3, seed=101)
@@ -336,3 +374,4 @@ if __name__ == "__main__":
     lfilter_case("lfilter_b3_n9000", 3, 9000, seed=126)
     dist_sample_case("dist_sample_b2c2_n3001", 2, 2, 3001, seed=127)
     lfilter_long_case("lfilter_long_b3_n9000", 3, 9000, seed=131)
+    chain_case("chain_b2c1_n20000", 2, 20000, seed=141, noise_seed=6141)

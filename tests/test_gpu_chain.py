@@ -150,3 +150,85 @@ def test_chain_module_takes_the_fused_path_without_grad(D, monkeypatch):
     assert float((y_ng - y_g.detach()).abs().max()) <= 1e-5 * float(y_g.detach().abs().max())
     with pytest.raises(RuntimeError):
         ops.chain_eq_compressor_forward(x.requires_grad_(True), ps[0], [1, 0, 0, 0, 0, 2], [0.0] * 18, [1.0] * 18, float(SR), torch.zeros(B, 5, device="cuda:0"))
+
+
+# ---- the composed chain against the REFERENCE: tests/golden/chain_b2c1_n20000.npz, make_golden.py chain_case ----
+
+def _chain_golden_inputs():
+    from tests.util import load_golden
+    g = load_golden("chain_b2c1_n20000")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    return g, dev
+
+
+def _run_chain_on_golden(kind, g, dev, monkeypatch=None):
+    """kind: 'chain' = chain.StyleTransferChain.process_normalized (folded gain, no-gx EQ, dasp_chain_controls, validated decay bound);
+    'sequence' = the four Processors one after the other, as the reference's model wires them (examples/style_transfer.py:150-154)."""
+    import dasp_pytorch_amd as D
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    x = dev(g["x"]).requires_grad_(True)
+    pp = [dev(g[k]).requires_grad_(True) for k in ("pn_eq", "pn_comp", "pn_rev", "pn_gain")]
+    torch.manual_seed(int(g["noise_seed"]))            # the reference's noise comes from the global CPU generator (functional.py:548)
+    if kind == "chain":
+        y = StyleTransferChain(SR).process_normalized(x, *pp)
+    else:
+        y = x
+        for mod, p in zip((D.ParametricEQ(SR), D.Compressor(SR), D.NoiseShapedReverb(SR), D.Gain(SR)), pp):
+            y = mod.process_normalized(y, p)
+    (y * dev(g["w"])).sum().backward()
+    return y.detach().cpu().numpy(), x.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in pp]
+
+
+@pytest.mark.parametrize("kind", ["chain", "sequence"])
+def test_chain_with_gradients_against_the_reference(D, kind):
+    """EQ -> compressor -> reverb -> gain WITH gradients on the reference's own numbers: y, grad x and the gradients w.r.t. the four
+    normalised parameter tensors (18 + 6 + 25 + 1) - gradients that cross every stage boundary (reverb grad x -> compressor grad y -> EQ
+    backward; the folded gain's column). Bounds: y 1e-5 and every parameter gradient 1e-4 of the tensor's largest entry against the
+    reference's fp64 run; 1e-4 against its fp32 run (the reference's fp32 run itself sits 4e-6 / 1.8e-5 from its fp64 run)."""
+    g, dev = _chain_golden_inputs()
+    y, gx, gps = _run_chain_on_golden(kind, g, dev)
+    if linf_peak(y, g["y64"]).max() > 1e-3:
+        pytest.skip("this torch build's CPU generator does not reproduce the golden's noise stream")
+    errs = {"y64": linf_peak(y, g["y64"]).max(), "y32": linf_peak(y, g["y32"]).max(),
+            "gx64": linf_peak(gx, g["gx64"]).max(), "gx32": linf_peak(gx, g["gx32"]).max()}
+    for key, gp in zip(("eq", "comp", "rev", "gain"), gps):
+        for tag in ("64", "32"):
+            ref = g[f"gpn_{key}{tag}"]
+            errs[f"gpn_{key}{tag}"] = np.abs(gp - ref).max() / np.abs(ref).max()
+    # the compressor's columns differ by orders of magnitude: each against its own largest entry too (release_ms is exactly 0)
+    ref = g["gpn_comp64"]
+    errs["gpn_comp_cols64"] = [np.abs(gps[1][:, j] - ref[:, j]).max() / max(np.abs(ref[:, j]).max(), 1e-12) for j in range(6)]
+    record(f"chain_vs_reference[{kind}]", **errs)
+    assert np.all(gps[1][:, 3] == 0)
+    assert errs["y64"] < 1e-5 and errs["y32"] < 1e-4
+    assert errs["gx64"] < 2e-5 and errs["gx32"] < 1e-4
+    for key in ("eq", "comp", "rev", "gain"):
+        assert errs[f"gpn_{key}64"] < 1e-4 and errs[f"gpn_{key}32"] < 1e-4, (key, errs)
+    assert max(errs["gpn_comp_cols64"]) < 1e-4, errs["gpn_comp_cols64"]
+
+
+def test_fused_forward_prefix_against_the_reference(D):
+    """The no-gradient fused pass (csrc/chainfwd.hip) on the golden's EQ -> compressor prefix: the reference's compressor output `yec`."""
+    g, dev = _chain_golden_inputs()
+    import dasp_pytorch_amd as DD
+    comp = DD.Compressor(SR)
+    pn = dev(g["pn_comp"])
+    lo, span = comp._affine(pn)
+    yf = fused(dev(g["x"]), dev(g["pn_eq"]), pn * span + lo).cpu().numpy()
+    e64, e32 = linf_peak(yf, g["yec64"]).max(), linf_peak(yf, g["yec32"]).max()
+    record("chain_fused_prefix_vs_reference", yec64=e64, yec32=e32)
+    assert e64 < 1e-5 and e32 < 1e-4
+
+
+def test_chain_no_grad_against_the_reference(D):
+    """StyleTransferChain under no_grad (fused EQ -> compressor forward, then the reverb with the folded gain): the reference's y."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    g, dev = _chain_golden_inputs()
+    torch.manual_seed(int(g["noise_seed"]))
+    with torch.no_grad():
+        y = StyleTransferChain(SR).process_normalized(dev(g["x"]), *[dev(g[k]) for k in ("pn_eq", "pn_comp", "pn_rev", "pn_gain")]).cpu().numpy()
+    if linf_peak(y, g["y64"]).max() > 1e-3:
+        pytest.skip("this torch build's CPU generator does not reproduce the golden's noise stream")
+    e64, e32 = linf_peak(y, g["y64"]).max(), linf_peak(y, g["y32"]).max()
+    record("chain_no_grad_vs_reference", y64=e64, y32=e32)
+    assert e64 < 1e-5 and e32 < 1e-4

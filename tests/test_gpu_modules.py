@@ -83,9 +83,10 @@ def test_process_normalized_against_reference_goldens(D):
         assert linf_peak(gx, g["gx64"]).max() < 2e-5, name
         if name.startswith("norm_comp"):     # per column: the six control gradients differ by orders of magnitude; release_ms is exactly 0
             import numpy as np
-            for j in range(6):
-                ref = g["gpn64"][:, j]
-                assert np.abs(gpn[:, j] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12), (name, j)
+            from tests.util import record
+            cols = [np.abs(gpn[:, j] - g["gpn64"][:, j]).max() / max(np.abs(g["gpn64"][:, j]).max(), 1e-12) for j in range(6)]
+            record("norm_comp_golden_param_grads", cols=cols)
+            assert max(cols) < 1e-4, (name, cols)
         else:
             assert linf_peak(gpn, g["gpn64"]).max() < tol_p, name
 
@@ -173,8 +174,12 @@ def test_style_transfer_chain_folds_the_gain(D):
     peak = float(y2.abs().max())
     assert float((y1 - y2).abs().max()) < 2e-5 * peak
     assert float((gx1 - gx2).abs().max()) < 5e-5 * float(gx2.abs().max())
-    for a, b in zip(gp1, gp2):
-        assert float((a - b).abs().max()) < 2e-3 * max(float(b.abs().max()), 1e-12)
+    from tests.util import record
+    eg = [float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) for a, b in zip(gp1, gp2)]
+    record("chain_folded_vs_sequence", y=float((y1 - y2).abs().max()) / peak, gx=float((gx1 - gx2).abs().max()) / float(gx2.abs().max()), gparams=eg)
+    # both sides are fp32 kernels with differently associated sums; each is pinned to the reference at 1e-4 by
+    # tests/test_gpu_chain.py::test_chain_with_gradients_against_the_reference, so two such paths may differ by up to 2e-4
+    assert max(eg) < 2e-4, eg
 
 
 def test_chain_controls_in_one_launch_equal_the_torch_ops(D, monkeypatch):

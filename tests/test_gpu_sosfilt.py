@@ -168,7 +168,9 @@ def test_seven_and_eight_sections_on_a_full_grid(D, S):
     x2 = dev(x[sel]).requires_grad_(True); s2 = dev(sos[sel]).requires_grad_(True)
     (D.signal.sosfilt_via_fsm(s2, x2) * dev(w[sel])).sum().backward()
     a, b = st.grad[sel].cpu().numpy(), s2.grad.cpu().numpy()
-    assert np.abs(a - b).max() < 2e-4 * np.abs(b).max()
+    from tests.util import record
+    record("sos8_full_vs_segmented_gsos", gsos=np.abs(a - b).max() / np.abs(b).max())
+    assert np.abs(a - b).max() < 1e-4 * np.abs(b).max()
     # the same call without a gradient for x (the kernel's no-gx instantiation): the coefficient gradients do not change
     s3 = dev(sos).requires_grad_(True)
     (D.signal.sosfilt_via_fsm(s3, dev(x)) * dev(w)).sum().backward()
@@ -457,7 +459,9 @@ def test_segmented_rows_equal_plain_rows(D, monkeypatch, B, C, N, bcast, tiles):
     ys, gxs, gps = run("1")
     assert np.abs(ys - yp).max() <= 2e-6 * np.abs(yp).max()
     assert np.abs(gxs - gxp).max() <= 2e-6 * np.abs(gxp).max()
-    assert np.abs(gps - gpp).max() <= 2e-4 * np.abs(gpp).max()
+    from tests.util import record
+    record(f"eq_segmented_vs_plain[{B},{C},{N},{tiles}]", gparams=np.abs(gps - gpp).max() / np.abs(gpp).max())
+    assert np.abs(gps - gpp).max() <= 1e-4 * np.abs(gpp).max()
     yo = orc.parametric_eq(x, SR, np.broadcast_to(p, (B, 18)).astype(np.float64))
     assert linf_peak(ys, yo).max() < TOL_SIG
 
