@@ -177,9 +177,9 @@ def test_style_transfer_chain_folds_the_gain(D):
     from tests.util import record
     eg = [float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) for a, b in zip(gp1, gp2)]
     record("chain_folded_vs_sequence", y=float((y1 - y2).abs().max()) / peak, gx=float((gx1 - gx2).abs().max()) / float(gx2.abs().max()), gparams=eg)
-    # both sides are fp32 kernels with differently associated sums; each is pinned to the reference at 1e-4 by
-    # tests/test_gpu_chain.py::test_chain_with_gradients_against_the_reference, so two such paths may differ by up to 2e-4
-    assert max(eg) < 2e-4, eg
+    # both sides are pinned to the reference itself by tests/test_gpu_chain.py::test_chain_with_gradients_against_the_reference;
+    # this HIP-vs-HIP comparison measured 1e-6 (profiles/r04/parity_measured.jsonl)
+    assert max(eg) < 2e-5, eg
 
 
 def test_chain_controls_in_one_launch_equal_the_torch_ops(D, monkeypatch):
