@@ -168,6 +168,39 @@ def _time_steps(fn, steps=30, warmup=10):
     return (time.perf_counter() - t0) / steps
 
 
+def graph_step_ms(step, replays=50, blocks=5, ramp_s=0.3):
+    """GPU-bound milliseconds per step, comparable across boxes: `step` (forward + backward into static .grad buffers) is captured once into
+    a HIP graph and replayed back to back - the host issues a replay in ~15 us, so the queue never runs dry, and there is no event pair
+    between kernels (events around the library calls of an eager, host-bound loop insert idle gaps after which power-limited kernels clock
+    up: round 3's `gpu_ms` of the small-batch ops differed by 36 % between boxes). Median of `blocks` blocks of `replays` replays after a
+    sustained ramp of the same replays."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                 # warm-up off the default stream: allocator pools, cached tables, lazy module state
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp_s:
+        for _ in range(25):
+            graph.replay()
+        torch.cuda.synchronize()
+    ts = []
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            graph.replay()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / replays * 1e3)
+    del graph
+    return round(float(np.median(ts)), 4)
+
+
 def secondary_traffic(name):
     """HBM bytes per fwd+bwd step of a secondary op from the newest profiles/r*/hbm_traffic_secondary.json that has it (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes, scripts/reverb_traffic.sh; null when no counter file covers the op)."""

@@ -87,9 +87,9 @@ SIGNATURES = {
     "dasp_mrstft_forward": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
     "dasp_mrstft_backward": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
     "dasp_mrstft_backward_target": (_i, [_p] * 6 + [_i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_float, _p]),
-    "dasp_lfilter_work_doubles": (_l, [_i, _l, _i]),
-    "dasp_lfilter_forward": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _l, _i, _i, _p]),
-    "dasp_lfilter_backward": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
+    "dasp_lfilter_work_doubles": (_l, [_i, _l, _i, _l]),
+    "dasp_lfilter_forward": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _i, _l, _i, _i, _l, _p]),
+    "dasp_lfilter_backward": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _l, _i, _i, _l, _p]),
     "dasp_sos64_normalize": (_i, [_p, _i, _i, _p, _p]),
     "dasp_sos64_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sos64_backward": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _l, _i, _p]),

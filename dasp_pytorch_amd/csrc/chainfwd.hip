@@ -219,9 +219,7 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
         const int item = tab_bcast ? 0 : b;
         int* cnt = reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 3;
         if (threadIdx.x == 0) {
-            const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = done == (tab_bcast ? (int)gridDim.x : G) - 1;
-            if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = handoff_arrive_is_last(cnt, tab_bcast ? (int)gridDim.x : G);
         }
         __syncthreads();
         if (s_last) {

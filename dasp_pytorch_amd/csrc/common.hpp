@@ -82,6 +82,36 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- "the last workgroup to arrive finishes the job" -----------------------------------------------------------------------------
+// Used where a few values per workgroup (segment end states, per-wave partial sums) are combined by whichever workgroup of a group
+// finishes last, instead of by a launch of its own (sosfilt.hip chain_by_last_workgroup / fused finalize, dynamics.hip dyn_last_workgroup,
+// chainfwd.hip). Protocol, in the terms of the HIP / LLVM memory model:
+//   writers   every value that crosses workgroups is stored with a relaxed AGENT-scope atomic store (no data race by construction);
+//             each wave waits for its stores (s_waitcnt vmcnt(0)), __syncthreads() orders them before thread 0 (workgroup scope),
+//   arrive    thread 0 increments the group's counter with a RELEASE read-modify-write at agent scope: cumulative over everything that
+//             happens-before it, i.e. over the whole workgroup's atomic stores; the RMWs of the group form one release sequence,
+//   complete  the thread that reads count - 1 issues an ACQUIRE fence at agent scope, resets the counter and (through the following
+//             __syncthreads()) lets its workgroup read the values with relaxed agent-scope atomic loads.
+// DASP_HANDOFF_FORMAL=0 builds the round-3 variant: the same stores, waits and loads with a RELAXED counter increment. It relies on
+// gfx950 behaviour the memory model does not promise (agent-scope atomic stores are write-through to the point of coherence and
+// acknowledged after they got there; atomic RMWs are performed at the memory side in arrival order) and skips the release's
+// buffer_wbl2, the write-back of this XCD's dirty L2 lines that the hand-off itself does not need. Kept for A/B measurements only.
+#ifndef DASP_HANDOFF_FORMAL
+#define DASP_HANDOFF_FORMAL 1
+#endif
+__device__ __forceinline__ bool handoff_arrive_is_last(int* cnt, int n_wg) {      // call from ONE thread of the workgroup
+#if DASP_HANDOFF_FORMAL
+    const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (done != n_wg - 1) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done != n_wg - 1) return false;
+#endif
+    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the counter can serve the next call
+    return true;
+}
+
 // LDS-DMA: 16 (4) bytes per active lane straight from global memory into LDS at (wave-uniform dst) + 16 (4) * lane, no staging
 // registers; completion is counted by vmcnt. Issued as inline asm on purpose: hipcc answers the builtin form with a vmcnt(0) in front
 // of every later LDS read, which would serialise the prefetch it is meant to overlap; here the waits are placed by hand

@@ -107,9 +107,7 @@ __device__ __forceinline__ bool dyn_last_workgroup(int* cnt, int n_wg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = done == n_wg - 1;
-        if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = handoff_arrive_is_last(cnt, n_wg);
     }
     __syncthreads();
     return s_last != 0;
@@ -597,6 +595,9 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
     float* start = segbuf + (size_t)B * G;
     hipStream_t st = (hipStream_t)stream;
     float* lb = lookahead > 0 ? lin_buf : nullptr;
+    // counters: 4 * B ints owned by the caller (dasp_hip.h). Every use returns its word to zero, but a word left non-zero by a call that
+    // failed half-way would keep every later count from completing (start states never written): they are zeroed per call, on the stream.
+    if (counters) { const hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4 * (size_t)B, st); if (e != hipSuccess) return (int)e; }
 #define DASP_DYN_FWD_SEG(MODE_)                                                                                                                  \
     hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 2>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, (float*)nullptr, (float*)nullptr,          \
                        (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z);               \
@@ -631,6 +632,7 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
     float* z = segbuf;
     float* start = segbuf + (size_t)B * G;
     hipStream_t st = (hipStream_t)stream;
+    if (counters) { const hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4 * (size_t)B, st); if (e != hipSuccess) return (int)e; }
 #define DASP_DYN_BWD_SEG(MODE_, DMA_)                                                                                                            \
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 2>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, (float*)nullptr, \
                        (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z);               \

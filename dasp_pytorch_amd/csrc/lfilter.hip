@@ -213,12 +213,12 @@ inline int lf_check() {
     return e == hipSuccess ? DASP_OK : (int)e;
 }
 inline int lf_mk(int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : 16); }
+inline long lf_work_doubles(int rows, int P, int M) { return P > 1 ? 2L * P * rows * M + (long)rows * M * M : 0; }
 // chunk length: 1024 samples from 16 chunks on; shorter signals in 16 chunks of at least 64 samples; one chunk below 128 samples
-inline void lf_plan(long N, long* L, int* P) {
-    if (const char* e = getenv("DASP_LFILTER_CHUNK")) {               // developer override (tests: chunk boundaries at odd places)
-        const long v = atol(e);
-        if (v >= 1) { *L = v; *P = (int)((N + v - 1) / v); return; }
-    }
+// chunk > 0: the caller's chunk length (tests: chunk boundaries at odd places). The library reads no environment variable here: the size
+// query, the forward and the backward call of one filter operation must cut time the same way, so the caller passes the same value thrice.
+inline void lf_plan(long N, long chunk, long* L, int* P) {
+    if (chunk >= 1) { *L = chunk; *P = (int)((N + chunk - 1) / chunk); return; }
     long l = 1024;
     if (N < 16 * 1024) { l = (N + 15) / 16; l = (l + 15) / 16 * 16; if (l < 64) l = 64; }
     *L = l; *P = (int)((N + l - 1) / l);
@@ -232,14 +232,14 @@ inline void lf_plan(long N, long* L, int* P) {
     } while (0)
 
 template <typename T>
-int lfilt_forward_t(const T* x, const double* bn, const double* an, T* y, double* wsave, double* work, int rows, int bcast, long N, int K,
-                    hipStream_t st) {
+int lfilt_forward_t(const T* x, const double* bn, const double* an, T* y, double* wsave, double* work, long work_doubles, int rows, int bcast,
+                    long N, int K, long chunk, hipStream_t st) {
     const int mk = lf_mk(K), M = mk - 1;
     long L; int P;
-    lf_plan(N, &L, &P);
+    lf_plan(N, chunk, &L, &P);
     double *E = nullptr, *S = nullptr, *Phi = nullptr;
     if (P > 1) {
-        if (!work) return DASP_ERR_ARG;
+        if (!work || work_doubles < lf_work_doubles(rows, P, M)) return DASP_ERR_ARG;
         E = work; S = E + (size_t)P * rows * M; Phi = S + (size_t)P * rows * M;
         dim3 grid((unsigned)(((long)rows * P + (long)rows * M + 63) / 64));
         LF_DISPATCH(lfilt_fwd_kernel, 0, x, bn, an, (T*)nullptr, (double*)nullptr, (const double*)nullptr, E, Phi, rows, bcast, N, K, L, P);
@@ -250,17 +250,17 @@ int lfilt_forward_t(const T* x, const double* bn, const double* an, T* y, double
     return lf_check();
 }
 template <typename T>
-int lfilt_backward_t(const T* gy, const double* bn, const double* an, const double* wsave, T* gx, double* gb, double* ga, double* work, int rows,
-                     int bcast, long N, int K, hipStream_t st) {
+int lfilt_backward_t(const T* gy, const double* bn, const double* an, const double* wsave, T* gx, double* gb, double* ga, double* work,
+                     long work_doubles, int rows, int bcast, long N, int K, long chunk, hipStream_t st) {
     const int mk = lf_mk(K), M = mk - 1;
     long L; int P;
-    lf_plan(N, &L, &P);
+    lf_plan(N, chunk, &L, &P);
+    if (P > 1 && (!work || work_doubles < lf_work_doubles(rows, P, M))) return DASP_ERR_ARG;
     hipError_t e = hipMemsetAsync(gb, 0, sizeof(double) * (size_t)rows * K, st);
     if (e == hipSuccess) e = hipMemsetAsync(ga, 0, sizeof(double) * (size_t)rows * K, st);
     if (e != hipSuccess) return (int)e;
     double *E = nullptr, *S = nullptr, *Phi = nullptr;
     if (P > 1) {
-        if (!work) return DASP_ERR_ARG;
         E = work; S = E + (size_t)P * rows * M; Phi = S + (size_t)P * rows * M;
         dim3 grid((unsigned)(((long)rows * P + (long)rows * M + 63) / 64));
         LF_DISPATCH(lfilt_bwd_kernel, 0, gy, bn, an, (const double*)nullptr, (T*)nullptr, (double*)nullptr, (double*)nullptr, (const double*)nullptr, E, Phi,
@@ -279,29 +279,30 @@ extern "C" {
 /* include/dasp_hip.h: filters of K = 4 .. 16 coefficients per row. x, y, gy, gx: (rows, N) float (f64 = 0) or double (f64 = 1);
  * bn, an: (Bs, K) doubles, Bs = rows or 1, normalised so that an[:, 0] = 1 (an FIR filter: an = 1, 0, ...); wsave: (N, rows) doubles or
  * NULL when no backward pass follows; work: dasp_lfilter_work_doubles(rows, N, K) doubles of scratch (chunk states);
- * gb, ga: (rows, K) doubles; gx may be NULL. */
-long dasp_lfilter_work_doubles(int rows, long N, int K) {
+ * gb, ga: (rows, K) doubles; gx may be NULL. chunk: samples per chunk of time, 0 = the library's plan - the SAME value must go into the size
+ * query, the forward and the backward call; work_doubles: the size of `work`, checked against the plan. */
+long dasp_lfilter_work_doubles(int rows, long N, int K, long chunk) {
     if (rows <= 0 || N <= 0 || K < 1 || K > 16) return -1;
     const int M = lf_mk(K) - 1;
     long L; int P;
-    lf_plan(N, &L, &P);
-    return P > 1 ? 2L * P * rows * M + (long)rows * M * M : 0;
+    lf_plan(N, chunk, &L, &P);
+    return lf_work_doubles(rows, P, M);
 }
-int dasp_lfilter_forward(const void* x, const double* bn, const double* an, int Bs, void* y, double* wsave, double* work, int rows, long N, int K,
-                         int f64, void* stream) {
+int dasp_lfilter_forward(const void* x, const double* bn, const double* an, int Bs, void* y, double* wsave, double* work, long work_doubles,
+                         int rows, long N, int K, int f64, long chunk, void* stream) {
     if (!x || !bn || !an || !y || rows <= 0 || N <= 0 || (Bs != 1 && Bs != rows)) return DASP_ERR_ARG;
     if (K < 1 || K > 16) return DASP_ERR_UNSUPPORTED;
     const int bcast = Bs == 1 && rows > 1;
-    return f64 ? lfilt_forward_t<double>((const double*)x, bn, an, (double*)y, wsave, work, rows, bcast, N, K, (hipStream_t)stream)
-               : lfilt_forward_t<float>((const float*)x, bn, an, (float*)y, wsave, work, rows, bcast, N, K, (hipStream_t)stream);
+    return f64 ? lfilt_forward_t<double>((const double*)x, bn, an, (double*)y, wsave, work, work_doubles, rows, bcast, N, K, chunk, (hipStream_t)stream)
+               : lfilt_forward_t<float>((const float*)x, bn, an, (float*)y, wsave, work, work_doubles, rows, bcast, N, K, chunk, (hipStream_t)stream);
 }
 int dasp_lfilter_backward(const void* gy, const double* bn, const double* an, int Bs, const double* wsave, void* gx, double* gb, double* ga,
-                          double* work, int rows, long N, int K, int f64, void* stream) {
+                          double* work, long work_doubles, int rows, long N, int K, int f64, long chunk, void* stream) {
     if (!gy || !bn || !an || !wsave || !gb || !ga || rows <= 0 || N <= 0 || (Bs != 1 && Bs != rows)) return DASP_ERR_ARG;
     if (K < 1 || K > 16) return DASP_ERR_UNSUPPORTED;
     const int bcast = Bs == 1 && rows > 1;
-    return f64 ? lfilt_backward_t<double>((const double*)gy, bn, an, wsave, (double*)gx, gb, ga, work, rows, bcast, N, K, (hipStream_t)stream)
-               : lfilt_backward_t<float>((const float*)gy, bn, an, wsave, (float*)gx, gb, ga, work, rows, bcast, N, K, (hipStream_t)stream);
+    return f64 ? lfilt_backward_t<double>((const double*)gy, bn, an, wsave, (double*)gx, gb, ga, work, work_doubles, rows, bcast, N, K, chunk, (hipStream_t)stream)
+               : lfilt_backward_t<float>((const float*)gy, bn, an, wsave, (float*)gx, gb, ga, work, work_doubles, rows, bcast, N, K, chunk, (hipStream_t)stream);
 }
 
 }  // extern "C"

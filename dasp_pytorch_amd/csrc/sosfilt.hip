@@ -420,9 +420,7 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = done == n_wg - 1;
-        if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the table can serve another pre-pass
+        s_last = handoff_arrive_is_last(cnt, n_wg);       // (resets the counter: the table can serve another pre-pass)
     }
     __syncthreads();
     if (!s_last) return;
@@ -1181,9 +1179,7 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         const int item = row / C;
         int* cnt = reinterpret_cast<int*>(cnt_tab + (size_t)item * LY::TOTAL + LY::CNT);
         if (threadIdx.x == 0) {
-            const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_row = done == C * G - 1;           // (G = 1 unless the rows are segmented: then every (row, segment) workgroup counts)
-            if (last_row) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the table can serve another backward pass
+            last_row = handoff_arrive_is_last(cnt, C * G);   // (G = 1 unless the rows are segmented: then every (row, segment) workgroup counts; resets the counter)
         }
         __syncthreads();
         if (!SEG) {

@@ -126,9 +126,13 @@ class Processor:
         check_unit_range(param_tensor, self.param_ranges)
 
     def _range_is_enforced(self):
-        """True when the [0, 1] contract of process_normalized holds for this call: the check is on (inside a HIP-graph capture it is only
-        deferred - the caller validated in eager mode - not waived) or the caller already ran it (chain.StyleTransferChain)."""
-        return bool(self.validate_range or getattr(_validated, "on", False))
+        """True when the [0, 1] check of process_normalized actually RAN for this call: the caller already did it (chain.StyleTransferChain),
+        or the check is on and the stream is not being captured into a HIP graph (inside a capture `_check_range` is skipped, so nothing
+        vouches for the values a replay will see: promises derived from the range - the reverb's decay bound - are then withdrawn and
+        the kernels decide per item)."""
+        if getattr(_validated, "on", False):
+            return True
+        return bool(self.validate_range) and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
     def extract_param_dict(self, param_tensor: torch.Tensor):
         if param_tensor.shape[1] != len(self.param_ranges):

@@ -407,9 +407,9 @@ _DYN_COUNTERS = {}
 
 
 def _dyn_counters(dev):
-    """The zeroed completion counters of the segmented dynamics calls (4 ints per batch item, one buffer per (device, stream); every
-    call returns them to zero). Inside a HIP-graph capture a fresh buffer is used and not kept: it belongs to the graph's pool, and its
-    captured zero-fill runs again on every replay."""
+    """The completion counters of the segmented dynamics calls (4 ints per batch item, one buffer per (device, stream): 4 * 128 ints, and
+    the segmented path is only taken up to 128 items - the size contract of dasp_hip.h; the C entry points zero the 4 * B words they use
+    at the start of every call). Inside a HIP-graph capture a fresh buffer is used and not kept: it belongs to the graph's pool."""
     capturing = torch.cuda.is_current_stream_capturing()
     key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
     t = None if capturing else _DYN_COUNTERS.get(key)
@@ -855,8 +855,12 @@ class ReverbFunction(torch.autograd.Function):
                 call("dasp_reverb_forward", ptr(x32), ptr(n32), ptr(Fspec), ptr(g32), ptr(d32), ptr(m32), ptr(y), ptr(A), ptr(H),
                      ptr(W), ptr(W2), ptr(Ah), ptr(ir), B, C, N, L_ir, taps, nb, float(decay_bound), stream())
             if need_grad:
-                ctx.save_for_backward(ir, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H)
-                ctx.cfg = (B, C, N, L_ir, taps, nb, [int(v) for v in sizes], useed, soff, float(decay_bound))
+                # the seed-offset word is read again by the backward kernels when they run: it is saved WITH the tensors, so that an in-place
+                # bump between this forward and its backward (which would regenerate a different noise stream) trips autograd's
+                # version check instead of giving silently wrong gain / decay / mix gradients (bump it after backward, or per replay)
+                ctx.save_for_backward(ir, n32 if n32 is not None else x32.new_empty(0), Fspec, g32, d32, m32, A, H,
+                                      soff if soff is not None else torch.empty(0, dtype=torch.int64, device=dev))
+                ctx.cfg = (B, C, N, L_ir, taps, nb, [int(v) for v in sizes], useed, soff is not None, float(decay_bound))
         return y.to(x.dtype)
 
     @staticmethod
@@ -866,8 +870,9 @@ class ReverbFunction(torch.autograd.Function):
         if ctx.empty:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=gy.device)
             return torch.empty(gy.shape[0], ctx.xC, gy.shape[2], dtype=xd, device=gy.device), None, None, z(gs, gd), z(ds, dd), z(ms, md), None, None, None, None
-        ir, n32, Fspec, g32, d32, m32, A, H = ctx.saved_tensors
-        B, C, N, L_ir, taps, nb, sizes, useed, soff, dbound = ctx.cfg
+        ir, n32, Fspec, g32, d32, m32, A, H, soff = ctx.saved_tensors
+        B, C, N, L_ir, taps, nb, sizes, useed, has_soff, dbound = ctx.cfg
+        soff = soff if has_soff else None
         dev = ir.device
         with torch.cuda.device(dev):
             gx = torch.empty(B, 2, N, dtype=torch.float32, device=dev)

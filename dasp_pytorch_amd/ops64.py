@@ -102,9 +102,12 @@ class LFilterFunction(torch.autograd.Function):
             y = torch.empty_like(xc)
             need = any(ctx.needs_input_grad)
             wsave = torch.empty(N * B * C, dtype=torch.float64, device=dev) if need else None
-            nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K)
+            # the chunk length is resolved ONCE per filter operation (developer override DASP_LFILTER_CHUNK, tests: chunk boundaries at odd
+            # places) and handed to the size query, the forward and - through ctx - the backward call: they must cut time the same way
+            chunk = ctx.chunk = max(int(os.environ.get("DASP_LFILTER_CHUNK", "0") or 0), 0)
+            nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K, chunk)
             work = torch.empty(nwork, dtype=torch.float64, device=dev) if nwork > 0 else None
-            call("dasp_lfilter_forward", ptr(xc), ptr(b64), ptr(a64), Bs, ptr(y), ptr(wsave), ptr(work), B * C, N, K, int(f64), stream())
+            call("dasp_lfilter_forward", ptr(xc), ptr(b64), ptr(a64), Bs, ptr(y), ptr(wsave), ptr(work), nwork, B * C, N, K, int(f64), chunk, stream())
             if need:
                 ctx.save_for_backward(b64, a64, wsave)
         return y.to(x.dtype)
@@ -125,9 +128,9 @@ class LFilterFunction(torch.autograd.Function):
             gx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
             gb = torch.empty(B * C, K, dtype=torch.float64, device=dev)
             ga = torch.empty(B * C, K, dtype=torch.float64, device=dev)
-            nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K)
+            nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K, ctx.chunk)
             work = torch.empty(nwork, dtype=torch.float64, device=dev) if nwork > 0 else None
-            call("dasp_lfilter_backward", ptr(g), ptr(b64), ptr(a64), Bs, ptr(wsave), ptr(gx), ptr(gb), ptr(ga), ptr(work), B * C, N, K, int(f64), stream())
+            call("dasp_lfilter_backward", ptr(g), ptr(b64), ptr(a64), Bs, ptr(wsave), ptr(gx), ptr(gb), ptr(ga), ptr(work), nwork, B * C, N, K, int(f64), ctx.chunk, stream())
             if Bs == 1 and B * C > 1:
                 gb, ga = gb.sum(0, keepdim=True), ga.sum(0, keepdim=True)
         return (gx.to(xdt) if gx is not None else None), gb.to(bdt), ga.to(adt)

@@ -242,9 +242,11 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
 int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
                                const float* lin_buf, float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N,
                                double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
-/* counters (may be NULL): 4 B ints that the caller keeps ZERO between calls (every call returns them to zero) - with them the item's last
- * workgroup of a pre-pass chains the segments and the last one of the adjoint pass forms the control gradients: two launches per direction
- * instead of three / four (workgroup to workgroup by device-scope atomics, as for the biquad cascade). One buffer per stream. */
+/* counters (may be NULL): a buffer of AT LEAST 4 * B ints owned by the caller, one buffer per stream (size contract: the library cannot see
+ * the allocation; it zeroes exactly 4 * B ints on the stream at the start of every call - round 4 - so a word left non-zero by a call that
+ * failed half-way cannot poison later calls). With them the item's last workgroup of a pre-pass chains the segments and the last one of
+ * the adjoint pass forms the control gradients: two launches per direction instead of three / four (workgroup to workgroup by agent-scope
+ * atomics with a release / acquire counter, csrc/common.hpp handoff_arrive_is_last, as for the biquad cascade). */
 
 /* ---------------------------------------------------------------------------------------------
  * Noise-shaped reverberation.  Replaces dasp_pytorch.functional.noise_shaped_reverberation
@@ -356,14 +358,16 @@ int dasp_mrstft_backward_target(const float* pred, const float* target, const vo
  * and are stitched by their state transition (csrc/lfilter.hip: three launches per direction).
  *   x, y, gy, gx: (rows, N) float (f64 = 0) or double (f64 = 1);  bn, an: (Bs, K) doubles, Bs = rows or 1, normalised so that
  *   an[:, 0] = 1 (FIR: an = 1, 0, ...);  wsave: (N, rows) doubles written by the forward pass for the backward pass (NULL: none follows);
- *   work: dasp_lfilter_work_doubles(rows, N, K) doubles of scratch;
+ *   work: dasp_lfilter_work_doubles(rows, N, K, chunk) doubles of scratch, its size passed as work_doubles (checked: DASP_ERR_ARG);
+ *   chunk: samples per chunk of time, 0 = the library's plan (1024 from 16 chunks on). The size query, the forward and the backward call of
+ *   one filter operation must be given the same value; the library reads no environment variable for it (round 4, advisor finding);
  *   gb, ga: (rows, K) doubles, per row (the caller adds the rows of a broadcast filter; ga[:, 0] = 0);  gx may be NULL.
  * ------------------------------------------------------------------------------------------- */
-long dasp_lfilter_work_doubles(int rows, long N, int K);
-int dasp_lfilter_forward(const void* x, const double* bn, const double* an, int Bs, void* y, double* wsave, double* work, int rows, long N,
-                         int K, int f64, void* stream);
+long dasp_lfilter_work_doubles(int rows, long N, int K, long chunk);
+int dasp_lfilter_forward(const void* x, const double* bn, const double* an, int Bs, void* y, double* wsave, double* work, long work_doubles,
+                         int rows, long N, int K, int f64, long chunk, void* stream);
 int dasp_lfilter_backward(const void* gy, const double* bn, const double* an, int Bs, const double* wsave, void* gx, double* gb,
-                          double* ga, double* work, int rows, long N, int K, int f64, void* stream);
+                          double* ga, double* work, long work_doubles, int rows, long N, int K, int f64, long chunk, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Double precision.  The reference follows the dtype of its input (`.type_as(x)`, dasp_pytorch/signal.py:113,119,
