@@ -478,9 +478,12 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # one rank started by torch.distributed.run (the driver's launch line with --nproc-per-node 1) joins a one-rank process group too:
+    # barrier and max-over-ranks then go through RCCL, which is all of the N > 1 path a 1-GPU box can exercise
+    under_launcher = world == 1 and bool(os.environ.get("TORCHELASTIC_RUN_ID"))
+    if world > 1 or under_launcher:
         import torch.distributed as dist
-        dd.init("gloo" if dry else "nccl", None if dry else dev)
+        dd.init("gloo" if dry else "nccl", None if dry else dev, force=under_launcher)
     sync = (lambda: None) if dry else torch.cuda.synchronize
     joined = dist.get_world_size() if dist is not None else 1      # ranks that actually joined the process group (RCCL / gloo)
 
@@ -614,6 +617,7 @@ def main():
             "config": {"workload": f"parametric_eq fwd+bwd (grad x + 18 controls) on ({B},{C},{N}) fp32 per GPU, sr 44100, "
                                    "controls ~ U(ParametricEQ ranges)", "global_batch": global_batch,
                        "parallelism": f"batch-shard x{world}, no collective", "launch": mode, "world_size": joined,
+                       "process_group": (dist.get_backend() if dist is not None else None),
                        "timing": f"median of {len(blocks[mode])} blocks of {args.steps} steps, product path (no timers / events in the timed region)"},
             "launch_ms_per_step": {k: per_step(v) for k, v in med.items()},
             "block_ms_per_step": {k: {"min": per_step(min(v)), "median": per_step(float(np.median(v))), "max": per_step(max(v))}

@@ -24,6 +24,13 @@ def test_shard_bounds_partition():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert dd.max_over_ranks(1.5) == 1.5 and dd.allreduce_gradients([torch.nn.Parameter(torch.ones(2))]) == 0
+    # no process group: GradientBuckets still owns the gradient storage (flat buckets, .grad views) but issues nothing
+    net = torch.nn.Linear(4, 3)
+    gb = dd.GradientBuckets(net.parameters(), bucket_bytes=16)
+    assert not gb.active and len(gb.buckets) == 2 and gb.bytes == 4 * 15
+    gb.zero_grad(); net(torch.ones(2, 4)).sum().backward()
+    assert gb.finish() == 0 and torch.equal(net.bias.grad, torch.full((3,), 2.0)) and net.bias.grad.data_ptr() == gb.buckets[0][0].data_ptr()
+    gb.remove()
 
 
 WORKER = textwrap.dedent("""
@@ -59,6 +66,27 @@ WORKER = textwrap.dedent("""
         dist.all_gather(other, g)
         assert torch.allclose(p.grad, sum(other) / world, atol=1e-6)
     assert torch.allclose(extra.grad, torch.full((3,), 2.0))
+    # the same exchange driven by post-accumulate-grad hooks (GradientBuckets: flat buckets autograd accumulates into, each all-reduced as
+    # its last gradient arrives): equals the post-backward version above, bucket by bucket, over two steps (counters re-arm), with a
+    # parameter that gets no gradient on either rank (its bucket is launched by finish()) and with .grad set to None by the caller
+    torch.manual_seed(0)
+    net2 = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    unused = torch.nn.Parameter(torch.ones(5))
+    gb = dd.GradientBuckets([unused] + list(net2.parameters()), bucket_bytes=256)       # (buckets fill in reverse order and launch in order: a parameter without a gradient in the FIRST bucket would hold every launch back until finish())
+    assert gb.active and len(gb.buckets) >= 3 and gb.bytes == 4 * (sum(p.numel() for p in net2.parameters()) + 5)
+    for it in range(2):
+        if it == 1:
+            net2[0].weight.grad = None                      # a caller's set_to_none: zero_grad() re-attaches the view
+        gb.zero_grad()
+        net2(inp).square().mean().backward()
+        assert all(p.grad.data_ptr() == v.data_ptr() for _, members in gb.buckets for p, v in members)
+        launched = gb._next                                 # buckets already in flight when backward() returned
+        n = gb.finish()
+        assert n == len(gb.buckets) and gb.launched_in_backward == launched and launched >= 1
+        for p, q in zip(net2.parameters(), net.parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-6), it
+        assert float(unused.grad.abs().max()) == 0.0
+    gb.remove()
     dist.barrier()
     dist.destroy_process_group()
     print("worker", rank, "ok")
