@@ -269,6 +269,15 @@ def secondary(dev):
         a = bytes_per_cs * cs / (gpu_ms * 1e-3) / 1e9
         res[name]["roofline"] = {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes": int(bytes_per_cs * cs), "traffic": secondary_traffic(name)}
+        if B <= 32:
+            # reference training batches: the step is launch-bound and its eager wall time is the host's. `ms_fwd_bwd_graph` is the whole step
+            # replayed as ONE HIP graph back to back (graph_step_ms): GPU-bound and comparable across boxes - the event-pair figure above
+            # (`gpu_ms_fwd_bwd`) comes from a host-bound loop whose idle gaps let the kernels clock up differently on every box (round 3:
+            # 36 % apart between two boxes); the roofline of these rows is therefore taken over the graph time
+            tg = graph_step_ms(step)
+            res[name]["ms_fwd_bwd_graph"] = tg
+            a = bytes_per_cs * cs / (tg * 1e-3) / 1e9
+            res[name]["roofline"].update(achieved=round(a, 1), frac=round(a / HBM_PEAK_GBS, 4), over="ms_fwd_bwd_graph")
         if note:
             res[name]["note"] = note
         del x, w
@@ -347,8 +356,34 @@ def secondary(dev):
         off.add_(1)
         graphed(xc, *pcs).backward(wc)
     tg = _time_steps(chain_step_graphed)
+    # box-independent GPU time: the whole training-like step as one HIP graph, replayed back to back (graph_step_ms)
+    def chain_step_static():
+        for p in pcs:
+            p.grad = None
+        chain_g.process_normalized(xc, *pcs).backward(wc)
+    t_graph = graph_step_ms(chain_step_static)
+    # eager wall time by binding: torch.ops.dasp.* (C++ autograd, csrc/torch_ext) against the ctypes autograd.Functions, and without the
+    # [0, 1] range check (one host read-back per step: the host cannot run ahead of the GPU across it)
+    from dasp_pytorch_amd import _torch_ops
+    eager = {"torch_ops" if _torch_ops.enabled() else "ctypes": round(t * 1e3, 3)}
+    for proc in (chain.equalizer, chain.compressor, chain.reverb, chain.gain):
+        proc.validate_range = False
+    eager[("torch_ops" if _torch_ops.enabled() else "ctypes") + "_no_range_check"] = round(_time_steps(chain_step) * 1e3, 3)
+    if _torch_ops.enabled():
+        os.environ["DASP_TORCH_OPS"] = "0"
+        eager["ctypes_no_range_check"] = round(_time_steps(chain_step) * 1e3, 3)
+        del os.environ["DASP_TORCH_OPS"]
+        cm = D.chain.ChainModule(SR, noise_seed=7, device=dev)
+
+        def module_step():
+            for p in pcs:
+                p.grad = None
+            cm(xc, *pcs).backward(wc)
+        eager["chain_module_torch_ops"] = round(_time_steps(module_step) * 1e3, 3)
     res["style_transfer_chain_b16"] = {"shape": [16, 1, 131072], "ms_fwd_bwd": round(t * 1e3, 3),
                                        "ms_fwd_bwd_graphed_callable": round(tg * 1e3, 3),
+                                       "ms_fwd_bwd_graph": t_graph, "eager_ms_by_binding": eager,
+                                       "eager_over_gpu": round(min(eager.values()) / t_graph, 3),
                                        "gpu_ms_fwd_bwd": round(sum(sum(v) for v in kt.values()) / 10, 4),
                                        "library_calls_per_step": sum(len(v) for v in kt.values()) // 10,
                                        "note": "EQ -> compressor -> reverb -> gain on normalised parameters, gradients for all 50 of them"}

@@ -120,7 +120,7 @@ def lib():
             raise DaspHipError(
                 f"{LIB_PATH} not found: build it with `python -m dasp_pytorch_amd.csrc.build` "
                 "(or __graft_entry__.build()). dasp_pytorch_amd has no CPU fallback.")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

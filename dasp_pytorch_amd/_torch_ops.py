@@ -1,0 +1,128 @@
+"""torch.ops.dasp.*: the PyTorch-ROCm extension (csrc/torch_ext/dasp_torch_ops.cpp -> csrc/libdasp_torch.so) over the C ABI for the four ops
+of the reference's effect chain (examples/style_transfer.py:150-154), as SURVEY 8(b) / BASELINE north_star specify the boundary: ops with
+schemas registered through TORCH_LIBRARY, forward + hand-derived adjoint as torch::autograd::Function in C++.
+
+This module loads the library, registers the fake (meta) implementations that torch.compile / AOTAutograd / torch.library.opcheck need
+(output shapes only; the work-buffer sizes come from the C ABI's own size queries), and answers `enabled()` for the call sites in
+ops.py. The ctypes binding stays: it is the binding for every other op, for float64, for bench.py's per-call HIP events, and the
+fallback when the extension is not built (DASP_TORCH_OPS=0 forces it: A/B of the two bindings)."""
+import os
+
+import torch
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+EXT_PATH = os.path.join(_HERE, "csrc", "libdasp_torch.so")
+_state = {"loaded": None}
+
+
+def _r64(n):
+    return (int(n) + 63) & ~63
+
+
+def _concrete(*vals):
+    return all(isinstance(v, int) for v in vals)
+
+
+def _n(fn, *args):
+    """A buffer size from the library's size query - or, while tracing with symbolic shapes, a fresh unbacked size (the buffers are opaque
+    work areas whose length no traced code looks at)."""
+    if _concrete(*args):
+        return int(fn(*args))
+    return torch.library.get_ctx().new_dynamic_size()
+
+
+def _register_fakes():
+    L = _lib.lib()
+    f32 = lambda t, *shape: t.new_empty(shape, dtype=torch.float32)
+
+    @torch.library.register_fake("dasp::parametric_eq_norm")
+    def _(x, param_tensor, sample_rate, types, lo, span):
+        return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+    @torch.library.register_fake("dasp::_peq_norm_forward")
+    def _(x, param_tensor, sample_rate, types, lo, span, tseg, save):
+        B, C, N = x.shape
+        Bp, S = param_tensor.shape[0], len(types)
+        n32 = _n(lambda bp, b, c, n: _r64(bp * L.dasp_sos_table_floats(S)) + (_r64(L.dasp_sos_carry_floats(b * c, n, S)) if save else 0), Bp, B, C, N)
+        n64 = _n(lambda bp: bp * L.dasp_sos_dtab_doubles(S) + (bp * L.dasp_sos_segtab_doubles(S) if tseg else 0), Bp)
+        return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, n32), x.new_empty((n64,), dtype=torch.float64)
+
+    @torch.library.register_fake("dasp::_peq_norm_backward")
+    def _(x, grad_y, work32, work64, Bp, S, tseg, need_gx, need_gp):
+        gx = torch.empty_like(x, memory_format=torch.contiguous_format) if need_gx else f32(x, 0)
+        return gx, (f32(x, Bp, 3 * S) if need_gp else f32(x, 0))
+
+    @torch.library.register_fake("dasp::dynamics_ctl")
+    def _(x, ctl, mode, sample_rate, eps, lookahead_samples):
+        return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+    @torch.library.register_fake("dasp::_dynamics_forward")
+    def _(x, ctl, mode, sample_rate, eps, lookahead_samples, tseg, save):
+        B, C, N = x.shape
+        ncar = _n(lambda b, n: L.dasp_dyn_carry_floats(b, n) if save and b * n else 0, B, N)
+        return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, ncar), (f32(x, B, N) if lookahead_samples > 0 else f32(x, 0))
+
+    @torch.library.register_fake("dasp::_dynamics_backward")
+    def _(x, ctl, grad_y, carries, lin, mode, sample_rate, eps, lookahead_samples, tseg):
+        return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, x.shape[0], 5)
+
+    @torch.library.register_fake("dasp::chain_controls")
+    def _(comp_params, reverb_params, gain_params, lo, span):
+        B = comp_params.shape[0]
+        return f32(comp_params, B, 5), f32(comp_params, B, 12), f32(comp_params, B, 12), f32(comp_params, B)
+
+    @torch.library.register_fake("dasp::_chain_controls_backward")
+    def _(gctl, ggain, gdecay, gmix, span):
+        B = gctl.shape[0]
+        return f32(gctl, B, 6), f32(gctl, B, 25), f32(gctl, B, 1)
+
+    def _rv_sizes(B, N, Lir, taps, nb):
+        import ctypes
+        sizes = (ctypes.c_long * 14)()
+        _lib.check(L.dasp_reverb_sizes(B, N, Lir, taps, nb, sizes), "dasp_reverb_sizes")
+        return sizes
+
+    @torch.library.register_fake("dasp::reverb")
+    def _(x, noise, fspec, gains, decays, mix, num_samples, taps, bands, seed, seed_offset, decay_bound):
+        return f32(x, x.shape[0], 2, x.shape[2])
+
+    @torch.library.register_fake("dasp::_reverb_forward")
+    def _(x, noise, fspec, gains, decays, mix, num_samples, taps, bands, seed, seed_offset, decay_bound, save):
+        B, _, N = x.shape
+        if _concrete(B, N):
+            s = _rv_sizes(B, N, num_samples, taps, bands) if B * N else [0] * 14
+            nA, nH, nir = (2 * s[6] if save else 0), 2 * s[7], s[8]
+        else:
+            ctx = torch.library.get_ctx()
+            nA, nH, nir = (ctx.new_dynamic_size() if save else 0), ctx.new_dynamic_size(), ctx.new_dynamic_size()
+        return f32(x, B, 2, N), f32(x, nA), f32(x, nH), f32(x, nir)
+
+    @torch.library.register_fake("dasp::_reverb_backward")
+    def _(grad_y, ir, A, H, noise, fspec, gains, decays, mix, Cx, num_samples, taps, bands, seed, seed_offset, decay_bound):
+        B, _, N = grad_y.shape
+        return f32(grad_y, B, Cx, N), f32(grad_y, B, bands), f32(grad_y, B, bands), f32(grad_y, B)
+
+
+def load():
+    """Load csrc/libdasp_torch.so (once) and register the fake implementations. Returns True when torch.ops.dasp.* is usable."""
+    if _state["loaded"] is None:
+        ok = False
+        if os.path.exists(EXT_PATH) and os.path.exists(_lib.LIB_PATH):
+            try:
+                _lib.lib()                               # libdasp_hip.so first (the extension links against it by soname)
+                torch.ops.load_library(EXT_PATH)
+                _register_fakes()
+                ok = True
+            except (OSError, RuntimeError) as e:         # a stale or foreign build: the ctypes binding still works
+                import warnings
+                warnings.warn(f"dasp_pytorch_amd: could not load {EXT_PATH} ({e}); using the ctypes binding")
+        _state["loaded"] = ok
+    return _state["loaded"]
+
+
+def enabled():
+    """True when the chain ops should go through torch.ops.dasp.* (the extension is built and loadable, DASP_TORCH_OPS is not 0, and
+    bench.py's per-call HIP-event timers - which live in the ctypes binding - are off)."""
+    return os.environ.get("DASP_TORCH_OPS", "1") != "0" and not _lib.timers.enabled and load()

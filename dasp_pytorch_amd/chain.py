@@ -71,12 +71,12 @@ class StyleTransferChain:
                  and self.gain.process_fn is _functional.gain)
         if fused:
             # every control of the three stages behind the EQ from one launch (and one back): ops.ChainControlsFunction
-            from .ops import ChainControlsFunction, DynamicsCtlFunction
+            from . import ops as _ops
             self.gain._check_range(gain_params)
             self.compressor._check_range(comp_params)
             self.reverb._check_range(reverb_params)
             lo, span = self._tables()
-            ctl, gains, decays, mix = ChainControlsFunction.apply(comp_params, reverb_params, gain_params, lo, span)
+            ctl, gains, decays, mix = _ops.chain_controls(comp_params, reverb_params, gain_params, lo, span)
             eq = self.equalizer
             no_grad = not (torch.is_grad_enabled() and (x.requires_grad or eq_params.requires_grad or ctl.requires_grad))
             if (no_grad and os.environ.get("DASP_CHAIN_FUSED_FORWARD", "1") != "0" and eq.process_fn is _functional.parametric_eq
@@ -91,7 +91,7 @@ class StyleTransferChain:
                 y = chain_eq_compressor_forward(x, eq_params, _functional._PEQ_TYPES, elo, espan, float(self.sample_rate), ctl)
             else:
                 y = eq.process_normalized(x, eq_params)                     # fused de-normalise + design; no gradient for x: the no-gx kernel
-                y = DynamicsCtlFunction.apply(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
+                y = _ops.dynamics_ctl(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
             # (mono: the reverb kernels read the one row for both output channels - no duplicated copy, functional.py:493-495)
             return _functional._reverb_from_matrices(y, self.sample_rate, gains, decays, mix, decay_bound=self.reverb._decay_bound(), **self.reverb._rev_kwargs)
         self.gain._check_range(gain_params)
@@ -110,3 +110,41 @@ class StyleTransferChain:
             kwargs["makeup_gain_db"] = kwargs["makeup_gain_db"] + gain_db[:, 0]
             y = self.compressor.process_fn(y, self.sample_rate, **kwargs)
         return self.reverb.process_normalized(y, reverb_params)
+
+
+class ChainModule(torch.nn.Module):
+    """The same chain as a torch.nn.Module built from torch.ops.dasp.* only (csrc/torch_ext): four op calls, no host read-back, no Python
+    branching on tensors - `torch.compile(module, fullgraph=True)` captures it without a graph break, and in eager mode the backward pass
+    runs entirely in C++. The reverb's noise is generated on the device from `noise_seed` plus the `seed_offset` buffer (bump it once per
+    step: `module.seed_offset.add_(1)`). The [0, 1] contract of process_normalized is the caller's here (sigmoid heads satisfy it by
+    construction; `StyleTransferChain` is the variant that checks), so no decay bound is vouched for and the filter bank decides its route
+    per item. float32 tensors on one ROCm device."""
+
+    def __init__(self, sample_rate, num_samples=65536, num_bandpass_taps=1023, noise_seed=0, device="cuda"):
+        super().__init__()
+        from . import _torch_ops, ops as _ops
+        if not _torch_ops.load():
+            raise _ops._lib.DaspHipError("ChainModule needs csrc/libdasp_torch.so (python -m dasp_pytorch_amd.csrc.build)")
+        ref = StyleTransferChain(sample_rate)
+        self.sample_rate, self.num_samples, self.taps, self.noise_seed = float(sample_rate), int(num_samples), int(num_bandpass_taps), int(noise_seed)
+        self.types = list(_functional._PEQ_TYPES)
+        self.eq_lo = [float(r[0]) for r in ref.equalizer.param_ranges.values()]
+        self.eq_span = [float(r[1]) - float(r[0]) for r in ref.equalizer.param_ranges.values()]
+        lo, span = ref._tables()
+        self.lo, self.span = [float(v) for v in lo], [float(v) for v in span]
+        dev = torch.device(device)
+        filters = _functional._device_filterbank(self.taps, self.sample_rate, dev)
+        import ctypes
+        sizes = (ctypes.c_long * 14)()
+        _ops.check(_ops._lib.lib().dasp_reverb_sizes(1, 4096, self.num_samples, self.taps, filters.shape[0], sizes), "dasp_reverb_sizes")
+        with torch.cuda.device(dev):
+            self.register_buffer("fspec", _ops._filter_spectrum(filters, filters.shape[0], self.taps, sizes[4], dev).clone(), persistent=False)
+        self.bands = int(filters.shape[0])
+        self.register_buffer("seed_offset", torch.zeros(1, dtype=torch.int64, device=dev), persistent=False)
+
+    def forward(self, x, eq_params, comp_params, reverb_params, gain_params):
+        d = torch.ops.dasp
+        ctl, gains, decays, mix = d.chain_controls(comp_params, reverb_params, gain_params, self.lo, self.span)
+        y = d.parametric_eq_norm(x, eq_params, self.sample_rate, self.types, self.eq_lo, self.eq_span)
+        y = d.dynamics_ctl(y, ctl, 0, self.sample_rate, 1e-8, 0)
+        return d.reverb(y, None, self.fspec, gains, decays, mix, self.num_samples, self.taps, self.bands, self.noise_seed, self.seed_offset, 0.0)

@@ -55,12 +55,40 @@ def build_lib(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(subprocess.check_call, jobs))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    # (soname: the torch extension libdasp_torch.so names this library as a dependency; a variant build loaded first through DASP_HIP_LIB
+    # is then the one the dynamic loader hands to it)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-soname,libdasp_hip.so", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     return LIB
 
 
+TORCH_EXT_SRC = os.path.join(HERE, "torch_ext", "dasp_torch_ops.cpp")
+TORCH_EXT = os.path.join(HERE, "libdasp_torch.so")
+
+
+def build_torch_ext(force=False, verbose=False):
+    """csrc/torch_ext/dasp_torch_ops.cpp -> csrc/libdasp_torch.so: the TORCH_LIBRARY registration of the chain ops (torch.ops.dasp.*) over the
+    C ABI. Host-only C++ (no kernels): compiled with g++ against the torch headers of the running interpreter and linked to libdasp_hip.so
+    next to it ($ORIGIN). In-tree, like the kernel library, so that it travels to the GPU box and shows up among the loaded objects."""
+    lib = build_lib()
+    if not force and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= max(os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(lib),
+                                                                                       os.path.getmtime(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dasp_hip.h"))):
+        return TORCH_EXT
+    import torch
+    from torch.utils import cpp_extension
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [f"-I{p}" for p in cpp_extension.include_paths()] + ["-I/opt/rocm/include", f"-I{os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include')}"]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + inc + [
+        TORCH_EXT_SRC, "-o", TORCH_EXT, f"-L{tlib}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{HERE}", "-ldasp_hip",
+        "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return TORCH_EXT
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,539 @@
+// torch.ops.dasp.*: the PyTorch-ROCm extension over the C ABI (include/dasp_hip.h) for the effect chain of the reference's training loop
+// (examples/style_transfer.py:150-154): parametric EQ on normalised parameters, compressor / expander on control rows, noise-shaped
+// reverb on control matrices, and the chain's fused control de-normalisation. What SURVEY 8(b) / BASELINE north_star specify: ops
+// registered with TORCH_LIBRARY (schemas visible to torch.compile / torch.library.opcheck), forward + hand-derived adjoint as
+// torch::autograd::Function in C++ (the backward pass runs on autograd's worker thread without the Python interpreter), errors as
+// TORCH_CHECK -> RuntimeError. No kernels live here: every number comes from libdasp_hip.so, launched on torch's current HIP stream.
+// The ctypes binding (dasp_pytorch_amd/_lib.py, ops.py) stays as the no-torch-extension path and for every other op.
+//
+// Layout of an op family (as torchvision's roi_align): a public differentiable op with a kernel on the dispatch key of the device
+// (inference: nothing saved) and one on Autograd (a Function whose forward calls the `_forward` op - outputs + what the adjoint needs -
+// and whose backward calls the `_backward` op). The `_forward` / `_backward` ops are ordinary functional ops with fake (meta)
+// implementations registered from Python (dasp_pytorch_amd/_torch_ops.py), so AOTAutograd traces through both directions.
+// Backward ops have no derivative formula: differentiating twice raises (the hand-written adjoints are once-differentiable).
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/autograd.h>
+#include <torch/csrc/autograd/autograd_not_implemented_fallback.h>
+#include <torch/library.h>
+
+#include <cstdlib>
+#include <vector>
+
+#include "dasp_hip.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_rc(int rc, const char* what) {
+    TORCH_CHECK(rc == 0, what, " failed: ", rc == -1 ? "DASP_ERR_ARG (bad argument)" : rc == -2 ? "DASP_ERR_UNSUPPORTED" : "HIP error ", rc);
+}
+void need_device(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda(), "dasp: `", name, "` must be on a ROCm device (there is no CPU path), got ", t.device());
+}
+void same_device(const Tensor& a, const Tensor& b, const char* name) {
+    TORCH_CHECK(a.device() == b.device(), "dasp: `", name, "` is on ", b.device(), " but x is on ", a.device());
+}
+Tensor f32c(const Tensor& t) { return t.to(at::kFloat).contiguous(); }
+float* fp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
+double* dp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<double>() : nullptr; }
+long round64(long n) { return (n + 63) & ~63L; }
+Tensor empty_f32(long n, const Tensor& like) { return at::empty({n}, like.options().dtype(at::kFloat)); }
+
+// ---- parametric EQ on the normalised (Bp, 3 S) tensor (ops.ParametricEQNormFunction; dasp_peq_forward_norm / dasp_peq_backward) ---------
+// tseg: tiles per segment of the segmented-row kernels, 0 = one workgroup per row. Decided ONCE per op call (planner, or the developer
+// overrides DASP_SOS_SEGMENT / DASP_SOS_SEGMENT_TILES) by the autograd function and handed to both directions.
+int64_t sos_segment_tiles(int64_t rows, int64_t N) {
+    const char* e = std::getenv("DASP_SOS_SEGMENT");
+    if (e && e[0] == '0' && e[1] == 0) return 0;
+    if (const char* f = std::getenv("DASP_SOS_SEGMENT_TILES")) { const long v = std::atol(f); if (v > 0) return v; }
+    return dasp_sos_segment_tiles(rows, N);
+}
+struct PeqDims { int64_t B, C, N, Bp, S; };
+PeqDims peq_check(const Tensor& x, const Tensor& pn, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
+    need_device(x, "x");
+    same_device(x, pn, "param_tensor");
+    TORCH_CHECK(x.dim() == 3, "dasp::parametric_eq_norm: x must be (bs, chs, seq_len), got ", x.sizes());
+    TORCH_CHECK(x.scalar_type() == at::kFloat, "dasp::parametric_eq_norm computes in float32; got ", x.scalar_type());
+    const int64_t S = (int64_t)types.size();
+    TORCH_CHECK(dasp_sos_supported_sections((int)S), "dasp::parametric_eq_norm: ", S, " sections are not supported (2, 4, 6, 8)");
+    TORCH_CHECK(pn.dim() == 2 && pn.size(1) == 3 * S && (pn.size(0) == 1 || pn.size(0) == x.size(0)),
+                "dasp::parametric_eq_norm: parameters must be (", x.size(0), " or 1, ", 3 * S, "), got ", pn.sizes());
+    TORCH_CHECK((int64_t)lo.size() == 3 * S && (int64_t)span.size() == 3 * S, "dasp::parametric_eq_norm: lo / span need ", 3 * S, " entries");
+    return PeqDims{x.size(0), x.size(1), x.size(2), pn.size(0), S};
+}
+// y, work32 = [tab | carries] (what the adjoint reads), work64 = [dtab | segtab]
+std::tuple<Tensor, Tensor, Tensor> peq_norm_forward(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types,
+                                                    at::ArrayRef<double> lo, at::ArrayRef<double> span, int64_t tseg, bool save) {
+    const PeqDims d = peq_check(x, pn, types, lo, span);
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous(), pn32 = f32c(pn);
+    Tensor y = at::empty_like(x32);
+    const long n_tab = round64(d.Bp * dasp_sos_table_floats((int)d.S));
+    const long n_car = save ? round64(dasp_sos_carry_floats(d.B * d.C, d.N, (int)d.S)) : 0;
+    const long n_seg = tseg ? round64(dasp_sos_seg_floats(d.B * d.C, d.N, (int)d.S, tseg)) : 0;
+    const long n_dt = d.Bp * dasp_sos_dtab_doubles((int)d.S), n_st = tseg ? d.Bp * dasp_sos_segtab_doubles((int)d.S) : 0;
+    Tensor work32 = empty_f32(n_tab + n_car, x32);
+    Tensor work64 = at::empty({n_dt + n_st}, x32.options().dtype(at::kDouble));
+    if (x32.numel() == 0) return {y, work32, work64};
+    Tensor segbuf = tseg ? empty_f32(n_seg, x32) : Tensor();              // scratch of the forward pre-pass only
+    std::vector<int> ty(types.begin(), types.end());
+    float* w = work32.data_ptr<float>();
+    double* w64 = work64.data_ptr<double>();
+    check_rc(dasp_peq_forward_norm(pn32.data_ptr<float>(), (int)d.Bp, (int)d.S, ty.data(), sample_rate, lo.data(), span.data(), nullptr, w, w64,
+                                   x32.data_ptr<float>(), y.data_ptr<float>(), save ? w + n_tab : nullptr, (int)d.B, (int)d.C, d.N, tseg,
+                                   tseg ? w64 + n_dt : nullptr, fp(segbuf), stream_of(x32)),
+             "dasp_peq_forward_norm");
+    return {y, work32, work64};
+}
+// -> (gx or empty, gp (Bp, 3 S) or empty). Reads the forward call's tables and chunk states; its own scratch (partial sums, segment
+// pre-pass buffers) is allocated here, so the op leaves its inputs as it found them (the completion counter word inside `tab` is returned
+// to zero by the kernels).
+std::tuple<Tensor, Tensor> peq_norm_backward(const Tensor& x, const Tensor& gy, const Tensor& work32, const Tensor& work64, int64_t Bp, int64_t S,
+                                             int64_t tseg, bool need_gx, bool need_gp) {
+    need_device(x, "x");
+    same_device(x, gy, "grad_output");
+    TORCH_CHECK(gy.sizes() == x.sizes(), "dasp::_peq_norm_backward: grad_output ", gy.sizes(), " does not match x ", x.sizes());
+    c10::DeviceGuard guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
+    const Tensor x32 = x.contiguous(), g32 = f32c(gy);
+    Tensor gx = need_gx ? at::empty_like(x32) : at::empty({0}, x32.options());
+    Tensor gp = need_gp ? at::empty({B, S, 3}, x32.options()) : at::empty({0}, x32.options());
+    if (x32.numel() == 0 || (!need_gx && !need_gp)) return {gx, need_gp ? gp.zero_().reshape({B, 3 * S}) : gp};
+    const long n_tab = round64(Bp * dasp_sos_table_floats((int)S));
+    const long n_dt = Bp * dasp_sos_dtab_doubles((int)S);
+    const long G = dasp_sos_segments(N, tseg);
+    TORCH_CHECK(work32.numel() >= n_tab + round64(dasp_sos_carry_floats(B * C, N, (int)S)) && work64.numel() >= n_dt + (tseg ? Bp * dasp_sos_segtab_doubles((int)S) : 0),
+                "dasp::_peq_norm_backward: work buffers do not belong to a forward call of this shape");
+    Tensor partials = need_gp ? empty_f32(round64(dasp_sos_partial_floats(B * C * G, (int)S)), x32) : Tensor();
+    Tensor segbuf = tseg ? empty_f32(round64(dasp_sos_seg_floats(B * C, N, (int)S, tseg)), x32) : Tensor();
+    float* w = work32.data_ptr<float>();
+    double* w64 = work64.data_ptr<double>();
+    // mode 1: gout (B, S, 3) = the layout of the (Bp, 3 S) parameter tensor
+    check_rc(dasp_peq_backward(w, w64, (int)Bp, x32.data_ptr<float>(), g32.data_ptr<float>(), w + n_tab, need_gx ? gx.data_ptr<float>() : nullptr,
+                               fp(partials), 1, need_gp ? gp.data_ptr<float>() : nullptr, (int)B, (int)C, N, (int)S, tseg,
+                               tseg ? w64 + n_dt : nullptr, fp(segbuf), stream_of(x32)),
+             "dasp_peq_backward");
+    if (need_gp) {
+        if (Bp == 1 && B != 1) gp = gp.sum(0, /*keepdim=*/true);             // one filter set shared by the batch (functional.py:208-220)
+        gp = gp.reshape({Bp, 3 * S});
+    }
+    return {gx, gp};
+}
+Tensor peq_norm_device(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
+    const PeqDims d = peq_check(x, pn, types, lo, span);
+    return std::get<0>(peq_norm_forward(x, pn, sample_rate, types, lo, span, sos_segment_tiles(d.B * d.C, d.N), false));
+}
+struct PeqNormFn : public torch::autograd::Function<PeqNormFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& pn, double sample_rate, std::vector<int64_t> types,
+                          std::vector<double> lo, std::vector<double> span) {
+        const PeqDims d = peq_check(x, pn, types, lo, span);
+        const int64_t tseg = sos_segment_tiles(d.B * d.C, d.N);
+        const bool need = x.requires_grad() || pn.requires_grad();
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_norm_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, double, at::IntArrayRef, at::ArrayRef<double>,
+                                                                       at::ArrayRef<double>, int64_t, bool)>();
+        auto [y, w32, w64] = op.call(x, pn, sample_rate, types, lo, span, tseg, need);
+        if (need) {
+            ctx->save_for_backward({x, w32, w64});
+            ctx->saved_data["Bp"] = d.Bp; ctx->saved_data["S"] = d.S; ctx->saved_data["tseg"] = tseg;
+            ctx->saved_data["pn_dtype"] = (int64_t)pn.scalar_type();
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_norm_backward", "")
+                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, bool, bool)>();
+        const bool need_gx = ctx->needs_input_grad(0), need_gp = ctx->needs_input_grad(1);
+        auto [gx, gp] = op.call(saved[0], grads[0], saved[1], saved[2], ctx->saved_data["Bp"].toInt(), ctx->saved_data["S"].toInt(),
+                                ctx->saved_data["tseg"].toInt(), need_gx, need_gp);
+        if (need_gp) gp = gp.to((at::ScalarType)ctx->saved_data["pn_dtype"].toInt());
+        return {need_gx ? gx : Tensor(), need_gp ? gp : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+Tensor peq_norm_autograd(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
+    return PeqNormFn::apply(x, pn, sample_rate, types.vec(), lo.vec(), span.vec());
+}
+
+// ---- compressor / expander on (bs, 5) control rows (ops.DynamicsCtlFunction; dasp_dynamics_forward(_seg) / _backward(_seg)) -------------
+int64_t dyn_segment_tiles(int64_t B, int64_t N) {
+    const char* e = std::getenv("DASP_DYN_SEGMENT");
+    if (e && e[0] == '0' && e[1] == 0) return 0;
+    if (const char* f = std::getenv("DASP_DYN_SEGMENT_TILES")) { const long v = std::atol(f); if (v > 0) return v; }
+    return dasp_dyn_segment_tiles(B, N);
+}
+void dyn_check(const Tensor& x, const Tensor& ctl, int64_t mode, int64_t lookahead) {
+    need_device(x, "x");
+    same_device(x, ctl, "ctl");
+    TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kFloat, "dasp::dynamics_ctl: x must be float32 (bs, chs, seq_len), got ", x.scalar_type(), " ", x.sizes());
+    // the kernels read five controls per batch item at ctl[b * 5 ...] (the reference does not broadcast a parameter batch of 1 either,
+    // functional.py:330-336)
+    TORCH_CHECK(ctl.dim() == 2 && ctl.size(0) == x.size(0) && ctl.size(1) == 5, "The size of tensor a (", ctl.dim() ? ctl.size(0) : 1,
+                ") must match the size of tensor b (", x.size(0), ") at non-singleton dimension 0 (ctl must be (", x.size(0), ", 5), got ", ctl.sizes(), ")");
+    TORCH_CHECK(mode == 0 || mode == 1, "dasp::dynamics_ctl: mode 0 (compressor) or 1 (expander)");
+    TORCH_CHECK(lookahead >= 0, "dasp::dynamics_ctl: lookahead_samples must be >= 0");
+}
+// -> y, carries, lin (the linear gain curve, kept only with a look-ahead delay)
+std::tuple<Tensor, Tensor, Tensor> dyn_forward(const Tensor& x, const Tensor& ctl, int64_t mode, double sample_rate, double eps, int64_t lookahead,
+                                               int64_t tseg, bool save) {
+    dyn_check(x, ctl, mode, lookahead);
+    c10::DeviceGuard guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
+    const Tensor x32 = x.contiguous(), c32 = f32c(ctl);
+    Tensor y = at::empty_like(x32);
+    Tensor carries = empty_f32(save && x32.numel() ? dasp_dyn_carry_floats(B, N) : 0, x32);
+    Tensor lin = lookahead > 0 ? at::empty({B, N}, x32.options()) : at::empty({0}, x32.options());
+    if (x32.numel() == 0) return {y, carries, lin};
+    if (tseg) {
+        Tensor segbuf = empty_f32(2 * B * dasp_dyn_segments(N, tseg), x32);
+        Tensor counters = at::empty({4 * B}, x32.options().dtype(at::kInt));       // zeroed by the call itself (dasp_hip.h)
+        check_rc(dasp_dynamics_forward_seg((int)mode, x32.data_ptr<float>(), c32.data_ptr<float>(), y.data_ptr<float>(), fp(carries), fp(lin), fp(segbuf),
+                                           (int)B, (int)C, N, sample_rate, (float)eps, (int)lookahead, tseg, counters.data_ptr<int>(), stream_of(x32)),
+                 "dasp_dynamics_forward_seg");
+    } else {
+        check_rc(dasp_dynamics_forward((int)mode, x32.data_ptr<float>(), c32.data_ptr<float>(), y.data_ptr<float>(), fp(carries), fp(lin), (int)B, (int)C, N,
+                                       sample_rate, (float)eps, (int)lookahead, stream_of(x32)),
+                 "dasp_dynamics_forward");
+    }
+    return {y, carries, lin};
+}
+std::tuple<Tensor, Tensor> dyn_backward(const Tensor& x, const Tensor& ctl, const Tensor& gy, const Tensor& carries, const Tensor& lin, int64_t mode,
+                                        double sample_rate, double eps, int64_t lookahead, int64_t tseg) {
+    dyn_check(x, ctl, mode, lookahead);
+    same_device(x, gy, "grad_output");
+    TORCH_CHECK(gy.sizes() == x.sizes(), "dasp::_dynamics_backward: grad_output ", gy.sizes(), " does not match x ", x.sizes());
+    c10::DeviceGuard guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
+    const Tensor x32 = x.contiguous(), c32 = f32c(ctl), g32 = f32c(gy);
+    Tensor gx = at::empty_like(x32), gctl = at::empty({B, 5}, x32.options());
+    if (x32.numel() == 0) return {gx, gctl.zero_()};
+    TORCH_CHECK(carries.numel() >= dasp_dyn_carry_floats(B, N), "dasp::_dynamics_backward: `carries` does not belong to a forward call of this shape");
+    const long G = dasp_dyn_segments(N, tseg);
+    Tensor partials = empty_f32(dasp_dyn_partial_floats(B * G), x32);
+    if (tseg) {
+        Tensor segbuf = empty_f32(2 * B * G, x32);
+        Tensor counters = at::empty({4 * B}, x32.options().dtype(at::kInt));
+        check_rc(dasp_dynamics_backward_seg((int)mode, x32.data_ptr<float>(), c32.data_ptr<float>(), g32.data_ptr<float>(), fp(carries), lookahead > 0 ? fp(lin) : nullptr,
+                                            gx.data_ptr<float>(), gctl.data_ptr<float>(), fp(partials), fp(segbuf), (int)B, (int)C, N, sample_rate, (float)eps,
+                                            (int)lookahead, tseg, counters.data_ptr<int>(), stream_of(x32)),
+                 "dasp_dynamics_backward_seg");
+    } else {
+        check_rc(dasp_dynamics_backward((int)mode, x32.data_ptr<float>(), c32.data_ptr<float>(), g32.data_ptr<float>(), fp(carries), lookahead > 0 ? fp(lin) : nullptr,
+                                        gx.data_ptr<float>(), gctl.data_ptr<float>(), fp(partials), (int)B, (int)C, N, sample_rate, (float)eps, (int)lookahead,
+                                        stream_of(x32)),
+                 "dasp_dynamics_backward");
+    }
+    return {gx, gctl};
+}
+Tensor dyn_device(const Tensor& x, const Tensor& ctl, int64_t mode, double sample_rate, double eps, int64_t lookahead) {
+    dyn_check(x, ctl, mode, lookahead);
+    return std::get<0>(dyn_forward(x, ctl, mode, sample_rate, eps, lookahead, dyn_segment_tiles(x.size(0), x.size(2)), false));
+}
+struct DynFn : public torch::autograd::Function<DynFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& ctl, int64_t mode, double sample_rate, double eps, int64_t lookahead) {
+        dyn_check(x, ctl, mode, lookahead);
+        const int64_t tseg = dyn_segment_tiles(x.size(0), x.size(2));
+        const bool need = x.requires_grad() || ctl.requires_grad();
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, int64_t, double, double, int64_t, int64_t, bool)>();
+        auto [y, carries, lin] = op.call(x, ctl, mode, sample_rate, eps, lookahead, tseg, need);
+        if (need) {
+            ctx->save_for_backward({x, ctl, carries, lin});
+            ctx->saved_data["mode"] = mode; ctx->saved_data["sr"] = sample_rate; ctx->saved_data["eps"] = eps;
+            ctx->saved_data["look"] = lookahead; ctx->saved_data["tseg"] = tseg; ctx->saved_data["ctl_dtype"] = (int64_t)ctl.scalar_type();
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_backward", "")
+                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, double, double,
+                                                               int64_t, int64_t)>();
+        auto [gx, gctl] = op.call(s[0], s[1], grads[0], s[2], s[3], ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
+                                  ctx->saved_data["eps"].toDouble(), ctx->saved_data["look"].toInt(), ctx->saved_data["tseg"].toInt());
+        return {ctx->needs_input_grad(0) ? gx : Tensor(),
+                ctx->needs_input_grad(1) ? gctl.to((at::ScalarType)ctx->saved_data["ctl_dtype"].toInt()) : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+Tensor dyn_autograd(const Tensor& x, const Tensor& ctl, int64_t mode, double sample_rate, double eps, int64_t lookahead) {
+    return DynFn::apply(x, ctl, mode, sample_rate, eps, lookahead);
+}
+
+// ---- the chain's control de-normalisation (ops.ChainControlsFunction; dasp_chain_controls / _backward) -------------------------------------
+// lo, span: 32 floats each (compressor 0-5, reverb 6-30, gain 31)
+std::tuple<Tensor, Tensor, Tensor, Tensor> chain_controls(const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, at::ArrayRef<double> lo,
+                                                          at::ArrayRef<double> span) {
+    need_device(comp_pn, "comp_params");
+    same_device(comp_pn, reverb_pn, "reverb_params");
+    same_device(comp_pn, gain_pn, "gain_params");
+    const int64_t B = comp_pn.size(0);
+    TORCH_CHECK(comp_pn.dim() == 2 && comp_pn.size(1) == 6 && reverb_pn.dim() == 2 && reverb_pn.size(0) == B && reverb_pn.size(1) == 25 && gain_pn.dim() == 2 &&
+                    gain_pn.size(0) == B && gain_pn.size(1) == 1,
+                "dasp::chain_controls: parameters must be (bs, 6), (bs, 25), (bs, 1), got ", comp_pn.sizes(), " ", reverb_pn.sizes(), " ", gain_pn.sizes());
+    TORCH_CHECK(lo.size() == 32 && span.size() == 32, "dasp::chain_controls: lo / span need 32 entries");
+    c10::DeviceGuard guard(comp_pn.device());
+    const auto o = comp_pn.options().dtype(at::kFloat);
+    Tensor ctl = at::empty({B, 5}, o), gains = at::empty({B, 12}, o), decays = at::empty({B, 12}, o), mix = at::empty({B}, o);
+    if (B) {
+        float lof[32], spf[32];
+        for (int i = 0; i < 32; ++i) { lof[i] = (float)lo[i]; spf[i] = (float)span[i]; }
+        const Tensor c = f32c(comp_pn), r = f32c(reverb_pn), g = f32c(gain_pn);
+        check_rc(dasp_chain_controls(c.data_ptr<float>(), r.data_ptr<float>(), g.data_ptr<float>(), lof, spf, ctl.data_ptr<float>(), gains.data_ptr<float>(),
+                                     decays.data_ptr<float>(), mix.data_ptr<float>(), (int)B, stream_of(comp_pn)),
+                 "dasp_chain_controls");
+    }
+    return {ctl, gains, decays, mix};
+}
+std::tuple<Tensor, Tensor, Tensor> chain_controls_backward(const Tensor& gctl, const Tensor& ggain, const Tensor& gdecay, const Tensor& gmix, at::ArrayRef<double> span) {
+    need_device(gctl, "grad ctl");
+    const int64_t B = gctl.size(0);
+    TORCH_CHECK(gctl.dim() == 2 && gctl.size(1) == 5 && ggain.sizes() == at::IntArrayRef({B, 12}) && gdecay.sizes() == at::IntArrayRef({B, 12}) && gmix.numel() == B,
+                "dasp::_chain_controls_backward: gradients must be (bs, 5), (bs, 12), (bs, 12), (bs)");
+    TORCH_CHECK(span.size() == 32, "dasp::_chain_controls_backward: span needs 32 entries");
+    c10::DeviceGuard guard(gctl.device());
+    const auto o = gctl.options().dtype(at::kFloat);
+    Tensor gc = at::empty({B, 6}, o), gr = at::empty({B, 25}, o), gg = at::empty({B, 1}, o);
+    if (B) {
+        float spf[32];
+        for (int i = 0; i < 32; ++i) spf[i] = (float)span[i];
+        const Tensor a = f32c(gctl), b = f32c(ggain), c = f32c(gdecay), d = f32c(gmix);
+        check_rc(dasp_chain_controls_backward(a.data_ptr<float>(), b.data_ptr<float>(), c.data_ptr<float>(), d.data_ptr<float>(), spf, gc.data_ptr<float>(),
+                                              gr.data_ptr<float>(), gg.data_ptr<float>(), (int)B, stream_of(gctl)),
+                 "dasp_chain_controls_backward");
+    }
+    return {gc, gr, gg};
+}
+struct ChainControlsFn : public torch::autograd::Function<ChainControlsFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, std::vector<double> lo,
+                                 std::vector<double> span) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::chain_controls", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, at::ArrayRef<double>, at::ArrayRef<double>)>();
+        auto [ctl, gains, decays, mix] = op.call(comp_pn, reverb_pn, gain_pn, lo, span);
+        ctx->saved_data["span"] = span;
+        ctx->saved_data["B"] = comp_pn.size(0);
+        ctx->saved_data["dt"] = std::vector<int64_t>{(int64_t)comp_pn.scalar_type(), (int64_t)reverb_pn.scalar_type(), (int64_t)gain_pn.scalar_type()};
+        return {ctl, gains, decays, mix};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        const int64_t B = ctx->saved_data["B"].toInt();
+        const auto span = ctx->saved_data["span"].toDoubleVector();
+        const auto dt = ctx->saved_data["dt"].toIntVector();
+        Tensor any;
+        for (const auto& t : g) if (t.defined()) { any = t; break; }
+        TORCH_CHECK(any.defined(), "dasp::chain_controls backward without any gradient");
+        const auto o = any.options().dtype(at::kFloat);
+        auto z = [&](const Tensor& t, at::IntArrayRef shape) { return t.defined() ? t : at::zeros(shape, o); };
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_chain_controls_backward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, at::ArrayRef<double>)>();
+        auto [gc, gr, gg] = op.call(z(g[0], {B, 5}), z(g[1], {B, 12}), z(g[2], {B, 12}), z(g[3], {B}), span);
+        return {gc.to((at::ScalarType)dt[0]), gr.to((at::ScalarType)dt[1]), gg.to((at::ScalarType)dt[2]), Tensor(), Tensor()};
+    }
+};
+std::tuple<Tensor, Tensor, Tensor, Tensor> chain_controls_autograd(const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, at::ArrayRef<double> lo,
+                                                                   at::ArrayRef<double> span) {
+    auto r = ChainControlsFn::apply(comp_pn, reverb_pn, gain_pn, lo.vec(), span.vec());
+    return {r[0], r[1], r[2], r[3]};
+}
+
+// ---- noise-shaped reverb on control matrices (ops.ReverbFunction; dasp_reverb_forward(_rng) / _backward(_rng)) ---------------------------
+// noise: (2 bs, nb, L + taps - 1) or undefined = generated inside the filter-bank kernels from `seed` (+ the device word seed_offset);
+// fspec: dasp_reverb_filter_spectrum of the (nb, taps) bank (cached by the Python side); gains / decays (bs, nb), mix (bs).
+struct RvDims { int64_t B, C, N; long sizes[14]; };
+RvDims reverb_check(const Tensor& x, const c10::optional<Tensor>& noise, const Tensor& fspec, const Tensor& gains, const Tensor& decays, const Tensor& mix, int64_t L,
+                    int64_t taps, int64_t nb, const c10::optional<Tensor>& seed_offset) {
+    need_device(x, "x");
+    same_device(x, fspec, "filter spectra");
+    same_device(x, gains, "band gains"); same_device(x, decays, "band decays"); same_device(x, mix, "mix");
+    TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kFloat, "dasp::reverb: x must be float32 (bs, chs, seq_len), got ", x.scalar_type(), " ", x.sizes());
+    TORCH_CHECK(x.size(1) == 1 || x.size(1) == 2, "noise_shaped_reverberation takes mono or stereo input, got ", x.size(1), " channels");
+    RvDims d{x.size(0), x.size(1), x.size(2), {}};
+    // the kernels index gains[b * nb + band]: a (k, nb) stack with k != bs must not be reshaped silently (functional.py:498-544)
+    TORCH_CHECK(gains.dim() == 2 && gains.size(0) == d.B && gains.size(1) == nb && decays.sizes() == gains.sizes() && mix.numel() == d.B, "shape '[", d.B, ", ", nb,
+                "]' is invalid for band gains / decays of shapes ", gains.sizes(), " / ", decays.sizes(), " and mix with ", mix.numel(), " values");
+    if (x.numel()) check_rc(dasp_reverb_sizes((int)d.B, d.N, (int)L, (int)taps, (int)nb, d.sizes), "dasp_reverb_sizes");
+    if (x.numel()) TORCH_CHECK(fspec.scalar_type() == at::kFloat && fspec.numel() >= 2 * d.sizes[4], "dasp::reverb: `fspec` is not the filter spectrum of this (nb, taps)");
+    if (noise.has_value() && noise->defined()) {
+        same_device(x, *noise, "noise");
+        TORCH_CHECK(noise->numel() == 2 * d.B * nb * (L + taps - 1), "noise must hold (2 * ", d.B, ", ", nb, ", ", L + taps - 1, ") values, got ", noise->sizes());
+        TORCH_CHECK(!(seed_offset.has_value() && seed_offset->defined()), "noise_seed_offset only applies to the generated noise");
+    }
+    if (seed_offset.has_value() && seed_offset->defined())
+        TORCH_CHECK(seed_offset->is_cuda() && seed_offset->scalar_type() == at::kLong && seed_offset->numel() == 1 && seed_offset->device() == x.device(),
+                    "noise_seed_offset must be a 1-element int64 tensor on x's device");
+    return d;
+}
+Tensor cbuf(long n_complex, const Tensor& like) { return empty_f32(2 * n_complex, like); }
+const unsigned long long* seed_ptr(const c10::optional<Tensor>& t) {
+    return t.has_value() && t->defined() ? reinterpret_cast<const unsigned long long*>(t->data_ptr<int64_t>()) : nullptr;
+}
+// -> y (bs, 2, N), A, H, ir  (A: column transforms of x, H: the impulse responses' spectra, ir: the impulse responses; kept for the adjoint)
+std::tuple<Tensor, Tensor, Tensor, Tensor> reverb_forward(const Tensor& x, const c10::optional<Tensor>& noise, const Tensor& fspec, const Tensor& gains, const Tensor& decays,
+                                                          const Tensor& mix, int64_t L, int64_t taps, int64_t nb, int64_t seed, const c10::optional<Tensor>& seed_offset,
+                                                          double decay_bound, bool save) {
+    const RvDims d = reverb_check(x, noise, fspec, gains, decays, mix, L, taps, nb, seed_offset);
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous();
+    Tensor y = at::empty({d.B, 2, d.N}, x32.options());
+    if (x32.numel() == 0) return {y, cbuf(0, x32), cbuf(0, x32), empty_f32(0, x32)};
+    const Tensor g32 = f32c(gains), d32 = f32c(decays), m32 = f32c(mix.reshape({d.B}));
+    Tensor A = cbuf(save ? d.sizes[6] : 0, x32), W2 = cbuf(save ? 0 : d.sizes[12], x32);
+    Tensor W = cbuf(d.sizes[12], x32), H = cbuf(d.sizes[7], x32), Ah = cbuf(d.sizes[13], x32), ir = empty_f32(d.sizes[8], x32);
+    if (noise.has_value() && noise->defined()) {
+        const Tensor n32 = f32c(*noise);
+        check_rc(dasp_reverb_forward(x32.data_ptr<float>(), n32.data_ptr<float>(), fspec.data_ptr<float>(), g32.data_ptr<float>(), d32.data_ptr<float>(),
+                                     m32.data_ptr<float>(), y.data_ptr<float>(), fp(A), fp(H), fp(W), fp(W2), fp(Ah), fp(ir), (int)d.B, (int)d.C, d.N, (int)L, (int)taps,
+                                     (int)nb, (float)decay_bound, stream_of(x32)),
+                 "dasp_reverb_forward");
+    } else {
+        check_rc(dasp_reverb_forward_rng(x32.data_ptr<float>(), (unsigned long long)seed, seed_ptr(seed_offset), fspec.data_ptr<float>(), g32.data_ptr<float>(),
+                                         d32.data_ptr<float>(), m32.data_ptr<float>(), y.data_ptr<float>(), fp(A), fp(H), fp(W), fp(W2), fp(Ah), fp(ir), (int)d.B, (int)d.C,
+                                         d.N, (int)L, (int)taps, (int)nb, (float)decay_bound, stream_of(x32)),
+                 "dasp_reverb_forward_rng");
+    }
+    return {y, A, H, ir};
+}
+// -> gx (bs, Cx, N), ggain (bs, nb), gdecay (bs, nb), gmix (bs)
+std::tuple<Tensor, Tensor, Tensor, Tensor> reverb_backward(const Tensor& gy, const Tensor& ir, const Tensor& A, const Tensor& H, const c10::optional<Tensor>& noise,
+                                                           const Tensor& fspec, const Tensor& gains, const Tensor& decays, const Tensor& mix, int64_t Cx, int64_t L,
+                                                           int64_t taps, int64_t nb, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+    need_device(gy, "grad_output");
+    TORCH_CHECK(gy.dim() == 3 && gy.size(1) == 2, "dasp::_reverb_backward: grad_output must be (bs, 2, seq_len), got ", gy.sizes());
+    const int64_t B = gy.size(0), N = gy.size(2);
+    c10::DeviceGuard guard(gy.device());
+    const auto o = gy.options().dtype(at::kFloat);
+    Tensor ggain = at::empty({B, nb}, o), gdecay = at::empty({B, nb}, o), gmix = at::empty({B}, o);
+    if (gy.numel() == 0) return {at::empty({B, Cx, N}, o), ggain.zero_(), gdecay.zero_(), gmix.zero_()};
+    long sizes[14];
+    check_rc(dasp_reverb_sizes((int)B, N, (int)L, (int)taps, (int)nb, sizes), "dasp_reverb_sizes");
+    TORCH_CHECK(A.numel() >= 2 * sizes[6] && H.numel() >= 2 * sizes[7] && ir.numel() >= sizes[8], "dasp::_reverb_backward: A / H / ir do not belong to a forward call of this shape");
+    const Tensor g32 = f32c(gy), ga = f32c(gains), de = f32c(decays), mi = f32c(mix.reshape({B}));
+    Tensor gx = at::empty({B, 2, N}, o);
+    Tensor Ag = cbuf(sizes[12], g32), W = cbuf(sizes[12], g32), P = cbuf(sizes[13], g32);
+    Tensor gir = empty_f32(sizes[8], g32), part = empty_f32(sizes[11], g32), mix_part = empty_f32(sizes[10], g32);
+    if (noise.has_value() && noise->defined()) {
+        const Tensor n32 = f32c(*noise);
+        check_rc(dasp_reverb_backward(ir.data_ptr<float>(), g32.data_ptr<float>(), n32.data_ptr<float>(), fspec.data_ptr<float>(), ga.data_ptr<float>(), de.data_ptr<float>(),
+                                      mi.data_ptr<float>(), A.data_ptr<float>(), H.data_ptr<float>(), gx.data_ptr<float>(), ggain.data_ptr<float>(), gdecay.data_ptr<float>(),
+                                      gmix.data_ptr<float>(), fp(Ag), fp(W), fp(P), fp(gir), fp(part), fp(mix_part), (int)B, (int)Cx, N, (int)L, (int)taps, (int)nb,
+                                      (float)decay_bound, stream_of(g32)),
+                 "dasp_reverb_backward");
+    } else {
+        check_rc(dasp_reverb_backward_rng(ir.data_ptr<float>(), g32.data_ptr<float>(), (unsigned long long)seed, seed_ptr(seed_offset), fspec.data_ptr<float>(),
+                                          ga.data_ptr<float>(), de.data_ptr<float>(), mi.data_ptr<float>(), A.data_ptr<float>(), H.data_ptr<float>(), gx.data_ptr<float>(),
+                                          ggain.data_ptr<float>(), gdecay.data_ptr<float>(), gmix.data_ptr<float>(), fp(Ag), fp(W), fp(P), fp(gir), fp(part), fp(mix_part),
+                                          (int)B, (int)Cx, N, (int)L, (int)taps, (int)nb, (float)decay_bound, stream_of(g32)),
+                 "dasp_reverb_backward_rng");
+    }
+    if (Cx == 1) gx = gx.sum(1, /*keepdim=*/true);             // the adjoint of the mono -> stereo duplication (functional.py:493-495)
+    return {gx, ggain, gdecay, gmix};
+}
+Tensor reverb_device(const Tensor& x, const c10::optional<Tensor>& noise, const Tensor& fspec, const Tensor& gains, const Tensor& decays, const Tensor& mix, int64_t L,
+                     int64_t taps, int64_t nb, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+    return std::get<0>(reverb_forward(x, noise, fspec, gains, decays, mix, L, taps, nb, seed, seed_offset, decay_bound, false));
+}
+struct ReverbFn : public torch::autograd::Function<ReverbFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const c10::optional<Tensor>& noise, const Tensor& fspec, const Tensor& gains, const Tensor& decays,
+                          const Tensor& mix, int64_t L, int64_t taps, int64_t nb, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+        TORCH_CHECK(!(noise.has_value() && noise->defined() && noise->requires_grad()) && !fspec.requires_grad(),
+                    "noise_shaped_reverberation: `noise` and the filters are not differentiable inputs (detach them)");
+        const bool need = x.requires_grad() || gains.requires_grad() || decays.requires_grad() || mix.requires_grad();
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_reverb_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&,
+                                                                               const Tensor&, int64_t, int64_t, int64_t, int64_t, const c10::optional<Tensor>&, double, bool)>();
+        auto [y, A, H, ir] = op.call(x, noise, fspec, gains, decays, mix, L, taps, nb, seed, seed_offset, decay_bound, need);
+        if (need) {
+            const bool has_noise = noise.has_value() && noise->defined(), has_off = seed_offset.has_value() && seed_offset->defined();
+            // the seed-offset word is read again by the adjoint kernels when they run: saved WITH the tensors, so that an in-place bump between
+            // forward and backward trips autograd's version check instead of regenerating different noise
+            ctx->save_for_backward({ir, A, H, fspec, gains, decays, mix, has_noise ? *noise : Tensor(), has_off ? *seed_offset : Tensor()});
+            ctx->saved_data["Cx"] = x.size(1); ctx->saved_data["L"] = L; ctx->saved_data["taps"] = taps; ctx->saved_data["nb"] = nb; ctx->saved_data["seed"] = seed;
+            ctx->saved_data["bound"] = decay_bound;
+            ctx->saved_data["has_noise"] = has_noise;
+            ctx->saved_data["dt"] = std::vector<int64_t>{(int64_t)gains.scalar_type(), (int64_t)decays.scalar_type(), (int64_t)mix.scalar_type()};
+            ctx->saved_data["mix_shape"] = mix.sizes().vec();
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_reverb_backward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const c10::optional<Tensor>&,
+                                                                               const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, int64_t,
+                                                                               int64_t, const c10::optional<Tensor>&, double)>();
+        const c10::optional<Tensor> noise = s[7].defined() ? c10::optional<Tensor>(s[7]) : c10::nullopt;
+        const c10::optional<Tensor> off = s[8].defined() ? c10::optional<Tensor>(s[8]) : c10::nullopt;
+        auto [gx, gg, gd, gm] = op.call(grads[0], s[0], s[1], s[2], noise, s[3], s[4], s[5], s[6], ctx->saved_data["Cx"].toInt(), ctx->saved_data["L"].toInt(),
+                                        ctx->saved_data["taps"].toInt(), ctx->saved_data["nb"].toInt(), ctx->saved_data["seed"].toInt(), off,
+                                        ctx->saved_data["bound"].toDouble());
+        const auto dt = ctx->saved_data["dt"].toIntVector();
+        // needs_input_grad counts the TENSOR arguments that were passed (an absent optional has no edge): x, [noise], fspec, gains, decays, mix
+        const size_t e = ctx->saved_data["has_noise"].toBool() ? 1 : 0;
+        return {ctx->needs_input_grad(0) ? gx : Tensor(), Tensor(), Tensor(), ctx->needs_input_grad(2 + e) ? gg.to((at::ScalarType)dt[0]) : Tensor(),
+                ctx->needs_input_grad(3 + e) ? gd.to((at::ScalarType)dt[1]) : Tensor(),
+                ctx->needs_input_grad(4 + e) ? gm.to((at::ScalarType)dt[2]).reshape(ctx->saved_data["mix_shape"].toIntVector()) : Tensor(),
+                Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+Tensor reverb_autograd(const Tensor& x, const c10::optional<Tensor>& noise, const Tensor& fspec, const Tensor& gains, const Tensor& decays, const Tensor& mix, int64_t L,
+                       int64_t taps, int64_t nb, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+    return ReverbFn::apply(x, noise, fspec, gains, decays, mix, L, taps, nb, seed, seed_offset, decay_bound);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(dasp, m) {
+    // public, differentiable (reference callables: Processor.process_normalized of ParametricEQ, dasp_pytorch/modules.py:124-156 +
+    // functional.py:118-272; functional.compressor / expander, functional.py:275-403; functional.noise_shaped_reverberation, :406-577)
+    m.def("parametric_eq_norm(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span) -> Tensor");
+    m.def("dynamics_ctl(Tensor x, Tensor ctl, int mode, float sample_rate, float eps, int lookahead_samples) -> Tensor");
+    m.def("chain_controls(Tensor comp_params, Tensor reverb_params, Tensor gain_params, float[] lo, float[] span) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("reverb(Tensor x, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int num_samples, int taps, int bands, int seed, Tensor? seed_offset, "
+          "float decay_bound) -> Tensor");
+    // the two directions as plain functional ops (traced by AOTAutograd; fake implementations: dasp_pytorch_amd/_torch_ops.py)
+    m.def("_peq_norm_forward(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_peq_norm_backward(Tensor x, Tensor grad_y, Tensor work32, Tensor work64, int Bp, int S, int tseg, bool need_gx, bool need_gp) -> (Tensor, Tensor)");
+    m.def("_dynamics_forward(Tensor x, Tensor ctl, int mode, float sample_rate, float eps, int lookahead_samples, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_dynamics_backward(Tensor x, Tensor ctl, Tensor grad_y, Tensor carries, Tensor lin, int mode, float sample_rate, float eps, int lookahead_samples, int tseg) "
+          "-> (Tensor, Tensor)");
+    m.def("_chain_controls_backward(Tensor gctl, Tensor ggain, Tensor gdecay, Tensor gmix, float[] span) -> (Tensor, Tensor, Tensor)");
+    m.def("_reverb_forward(Tensor x, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int num_samples, int taps, int bands, int seed, "
+          "Tensor? seed_offset, float decay_bound, bool save) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("_reverb_backward(Tensor grad_y, Tensor ir, Tensor A, Tensor H, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int Cx, int num_samples, "
+          "int taps, int bands, int seed, Tensor? seed_offset, float decay_bound) -> (Tensor, Tensor, Tensor, Tensor)");
+}
+// ROCm devices carry the CUDA dispatch key in PyTorch-ROCm builds
+TORCH_LIBRARY_IMPL(dasp, CUDA, m) {
+    m.impl("parametric_eq_norm", &peq_norm_device);
+    m.impl("dynamics_ctl", &dyn_device);
+    m.impl("chain_controls", &chain_controls);
+    m.impl("reverb", &reverb_device);
+    m.impl("_peq_norm_forward", &peq_norm_forward);
+    m.impl("_peq_norm_backward", &peq_norm_backward);
+    m.impl("_dynamics_forward", &dyn_forward);
+    m.impl("_dynamics_backward", &dyn_backward);
+    m.impl("_chain_controls_backward", &chain_controls_backward);
+    m.impl("_reverb_forward", &reverb_forward);
+    m.impl("_reverb_backward", &reverb_backward);
+}
+TORCH_LIBRARY_IMPL(dasp, Autograd, m) {
+    m.impl("parametric_eq_norm", &peq_norm_autograd);
+    m.impl("dynamics_ctl", &dyn_autograd);
+    m.impl("chain_controls", &chain_controls_autograd);
+    m.impl("reverb", &reverb_autograd);
+    // the two directions themselves carry no derivative: backpropagating through them (a double backward, or calling `_forward` on tensors
+    // that require a gradient) raises "derivative for dasp::... is not implemented" instead of treating the result as a constant
+    for (const char* name : {"_peq_norm_forward", "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_chain_controls_backward", "_reverb_forward",
+                             "_reverb_backward"})
+        m.impl(name, torch::autograd::autogradNotImplementedFallback());
+}

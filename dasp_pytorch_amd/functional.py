@@ -5,6 +5,7 @@ import torch
 from . import signal as _signal
 from .ops import (FILTER_TYPES, BusFunction, DistortionFunction, DistortionSampleFunction, DynamicsFunction, GainFunction, PannerFunction, ParametricEQFunction,
                   ReverbFunction, WidenerFunction)
+from .ops import reverb as _ops_reverb
 from .ops64 import Dynamics64Function, Elementwise64Function, ParametricEQ64Function, is_f64, require_fp32_ok
 
 _PEQ_TYPES = [FILTER_TYPES[t] for t in ("low_shelf", "peaking", "peaking", "peaking", "peaking", "high_shelf")]
@@ -293,8 +294,8 @@ def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samp
             seed = int(noise_seed) if noise_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         else:
             noise = torch.randn(bs * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
-    return ReverbFunction.apply(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed,
-                                noise_seed_offset if seed is not None else None, float(decay_bound))
+    return _ops_reverb(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed,
+                       noise_seed_offset if seed is not None else None, float(decay_bound))
 
 
 def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):

@@ -204,13 +204,13 @@ class ParametricEQ(Processor):
                  and param_tensor.is_floating_point())
         if not fused:
             return super().process_normalized(x, param_tensor)
-        from .ops import ParametricEQNormFunction
+        from .ops import parametric_eq_norm
         lo = [float(r[0]) for r in self.param_ranges.values()]
         span = [float(r[1]) - float(r[0]) for r in self.param_ranges.values()]
         # the check runs before the kernels are queued (one small reduction + read-back): the C entry point's in-kernel flag word would
         # make the host wait for the forward kernel it has just launched
         self._check_range(param_tensor)
-        return ParametricEQNormFunction.apply(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span)
+        return parametric_eq_norm(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span)
 
 
 class _Dynamics(Processor):

@@ -893,3 +893,52 @@ class ReverbFunction(torch.autograd.Function):
         if C == 1:
             gx = gx.sum(1, keepdim=True)           # the adjoint of the mono -> stereo duplication
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None, None, None
+
+
+# ---- the chain ops through torch.ops.dasp.* (csrc/torch_ext: TORCH_LIBRARY + C++ autograd) when the extension is there -----------------------
+# Same kernels, same C entry points as the autograd.Functions above; what changes is the host side: no ctypes marshalling, no Python in
+# the backward pass, schemas that torch.compile and torch.library.opcheck understand. float32 CUDA tensors only (anything else keeps the
+# path above, which also owns the dtype / device error messages).
+def _torch_ops_ok(*tensors):
+    from . import _torch_ops
+    return _torch_ops.enabled() and all(t is None or (t.is_cuda and t.dtype is torch.float32) for t in tensors)
+
+
+def parametric_eq_norm(x, pn, sample_rate, types, lo, span):
+    """ParametricEQNormFunction, or torch.ops.dasp.parametric_eq_norm."""
+    if _torch_ops_ok(x) and x.dim() == 3 and pn.is_cuda and pn.is_floating_point() and pn.device == x.device:
+        return torch.ops.dasp.parametric_eq_norm(x, pn, float(sample_rate), list(types), list(lo), list(span))
+    return ParametricEQNormFunction.apply(x, pn, float(sample_rate), types, lo, span)
+
+
+def dynamics_ctl(x, mode, sample_rate, eps, lookahead, ctl):
+    """DynamicsCtlFunction, or torch.ops.dasp.dynamics_ctl."""
+    if _torch_ops_ok(x, ctl) and x.dim() == 3 and ctl.device == x.device:
+        return torch.ops.dasp.dynamics_ctl(x, ctl, int(mode), float(sample_rate), float(eps), int(lookahead))
+    return DynamicsCtlFunction.apply(x, mode, sample_rate, eps, lookahead, ctl)
+
+
+def chain_controls(comp_pn, reverb_pn, gain_pn, lo, span):
+    """ChainControlsFunction (lo, span: ctypes float[32]), or torch.ops.dasp.chain_controls."""
+    if _torch_ops_ok(comp_pn, reverb_pn, gain_pn) and comp_pn.device == reverb_pn.device == gain_pn.device:
+        return torch.ops.dasp.chain_controls(comp_pn, reverb_pn, gain_pn, list(lo), list(span))
+    return ChainControlsFunction.apply(comp_pn, reverb_pn, gain_pn, lo, span)
+
+
+def reverb(x, noise, filters, gains, decays, mix, L_ir, seed=None, seed_offset=None, decay_bound=0.0):
+    """ReverbFunction, or torch.ops.dasp.reverb (the filter spectra stay cached on the Python side and go in as a tensor)."""
+    if (_torch_ops_ok(x, noise, gains, decays, mix) and x.dim() == 3 and x.shape[1] in (1, 2) and x.numel() and filters.is_cuda
+            and all(t.device == x.device for t in (filters, gains, decays, mix)) and (noise is None or noise.device == x.device)
+            and not filters.requires_grad and (noise is None or not noise.requires_grad)):
+        if noise is None and seed is None:
+            raise ValueError("reverb: either a noise tensor or a seed")
+        nb, taps = filters.shape
+        with torch.cuda.device(x.device):
+            sizes = (ctypes.c_long * 14)()
+            check(_lib.lib().dasp_reverb_sizes(x.shape[0], x.shape[2], int(L_ir), taps, nb, sizes), "dasp_reverb_sizes")
+            fspec = _filter_spectrum(filters, nb, taps, sizes[4], x.device)
+        s = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        s = s - (1 << 64) if s >= (1 << 63) else s                  # the op's `int` is a signed 64-bit word: same bits
+        return torch.ops.dasp.reverb(x, noise, fspec, gains, decays, mix, int(L_ir), int(taps), int(nb), s,
+                                     _seed_offset(seed_offset, x.device) if noise is None else None, float(decay_bound))
+    return ReverbFunction.apply(x, noise, filters, gains, decays, mix, L_ir, seed, seed_offset, decay_bound)

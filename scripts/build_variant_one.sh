@@ -7,5 +7,5 @@ mkdir -p tools/$name
 c=dasp_pytorch_amd/csrc
 b=$(basename $src .hip)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-inline-asm -Wno-pass-failed "$@" -c $c/$b.hip -o tools/$name/$b.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o tools/$name/libdasp_hip.so tools/$name/$b.o $(ls $c/*.o | grep -v "/$b.o")
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libdasp_hip.so -o tools/$name/libdasp_hip.so tools/$name/$b.o $(ls $c/*.o | grep -v "/$b.o")
 echo tools/$name/libdasp_hip.so

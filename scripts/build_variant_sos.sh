@@ -6,5 +6,5 @@ name=$1; shift
 mkdir -p tools/$name
 c=dasp_pytorch_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-inline-asm -Wno-pass-failed "$@" -c $c/sosfilt.hip -o tools/$name/sosfilt.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o tools/$name/libdasp_hip.so tools/$name/sosfilt.o $(ls $c/*.o | grep -v sosfilt.o)
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libdasp_hip.so -o tools/$name/libdasp_hip.so tools/$name/sosfilt.o $(ls $c/*.o | grep -v sosfilt.o)
 echo tools/$name/libdasp_hip.so
