@@ -192,14 +192,35 @@ __global__ __launch_bounds__(64) void lfilt_chain_kernel(const double* __restric
     for (int j = 0; j < 15; ++j) ph[j] = (live && j < M) ? Phi[((size_t)r * M + lane) * M + j] : 0.0;
     double s = 0.0;
     int c = dir > 0 ? 0 : P - 1;
+    const int dc = dir > 0 ? 1 : -1;
     if (live) S[((size_t)c * rows + r) * M + lane] = 0.0;
-    for (int step = 0; step < P - 1; ++step) {
-        double acc = live ? E[((size_t)c * rows + r) * M + lane] : 0.0;
+    // The chain is the one sequential part of a filter operation (P - 1 dependent steps per row). The zero-start end states E do not
+    // depend on it: eight steps' worth are requested together, so a step costs its arithmetic (15 lane exchanges, two sums of products)
+    // and not a round trip to memory as well (round 3: one load inside every step, ~1 us per step - the chain was 0.5 of the 1.2 ms of a
+    // forward + backward pass at (16, 1, 262144) and ruled out shorter chunks).
+    constexpr int PF = 8;
+    for (int step0 = 0; step0 < P - 1; step0 += PF) {
+        double e[PF];
 #pragma unroll
-        for (int j = 0; j < 15; ++j) acc = fma(ph[j], __shfl(s, j, 16), acc);
-        s = acc;
-        c += dir > 0 ? 1 : -1;
-        if (live) S[((size_t)c * rows + r) * M + lane] = s;
+        for (int u = 0; u < PF; ++u) {
+            int cu = c + u * dc;
+            cu = cu < 0 ? 0 : (cu > P - 1 ? P - 1 : cu);                       // clamped: the tail's extra loads are never used
+            e[u] = live ? E[((size_t)cu * rows + r) * M + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (step0 + u < P - 1) {                                           // uniform over the wave
+                double v[15];
+#pragma unroll
+                for (int j = 0; j < 15; ++j) v[j] = __shfl(s, j, 16);         // every exchange before the first product
+                double a0 = e[u], a1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 14; j += 2) { a0 = fma(ph[j], v[j], a0); a1 = fma(ph[j + 1], v[j + 1], a1); }
+                s = fma(ph[14], v[14], a0) + a1;
+                c += dc;
+                if (live) S[((size_t)c * rows + r) * M + lane] = s;
+            }
+        }
     }
 }
 
@@ -212,15 +233,22 @@ inline int lf_check() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
 }
+#ifndef DASP_LFILTER_CHUNK_DEFAULT
+#define DASP_LFILTER_CHUNK_DEFAULT 1024
+#endif
+constexpr long LF_CHUNK_DEFAULT = DASP_LFILTER_CHUNK_DEFAULT;
 inline int lf_mk(int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : 16); }
 inline long lf_work_doubles(int rows, int P, int M) { return P > 1 ? 2L * P * rows * M + (long)rows * M * M : 0; }
-// chunk length: 1024 samples from 16 chunks on; shorter signals in 16 chunks of at least 64 samples; one chunk below 128 samples
+// chunk length: 1024 samples (512 up to 64 rows) from 16 chunks on; shorter signals in 16 chunks of at least 64 samples; one chunk below 128 samples
 // chunk > 0: the caller's chunk length (tests: chunk boundaries at odd places). The library reads no environment variable here: the size
 // query, the forward and the backward call of one filter operation must cut time the same way, so the caller passes the same value thrice.
-inline void lf_plan(long N, long chunk, long* L, int* P) {
+inline void lf_plan(int rows, long N, long chunk, long* L, int* P) {
     if (chunk >= 1) { *L = chunk; *P = (int)((N + chunk - 1) / chunk); return; }
-    long l = 1024;
-    if (N < 16 * 1024) { l = (N + 15) / 16; l = (l + 15) / 16 * 16; if (l < 64) l = 64; }
+    // GPU time of forward + backward against the chunk length (profiles/r04/lfilter_graph_time.log, K = 5, N = 262144): 16 rows 0.85 /
+    // 0.68 / 0.81 / 1.30 ms at 256 / 512 / 1024 / 2048 samples per chunk, 256 rows 2.71 / 2.41 / 2.12 / 2.34 ms: few rows want more chunks
+    // (threads = rows x chunks), until the sequential chain over the chunks (0.3 us per step and direction) takes over
+    long l = rows <= 64 ? LF_CHUNK_DEFAULT / 2 : LF_CHUNK_DEFAULT;
+    if (N < 16 * l) { l = (N + 15) / 16; l = (l + 15) / 16 * 16; if (l < 64) l = 64; }
     *L = l; *P = (int)((N + l - 1) / l);
 }
 
@@ -236,7 +264,7 @@ int lfilt_forward_t(const T* x, const double* bn, const double* an, T* y, double
                     long N, int K, long chunk, hipStream_t st) {
     const int mk = lf_mk(K), M = mk - 1;
     long L; int P;
-    lf_plan(N, chunk, &L, &P);
+    lf_plan(rows, N, chunk, &L, &P);
     double *E = nullptr, *S = nullptr, *Phi = nullptr;
     if (P > 1) {
         if (!work || work_doubles < lf_work_doubles(rows, P, M)) return DASP_ERR_ARG;
@@ -254,7 +282,7 @@ int lfilt_backward_t(const T* gy, const double* bn, const double* an, const doub
                      long work_doubles, int rows, int bcast, long N, int K, long chunk, hipStream_t st) {
     const int mk = lf_mk(K), M = mk - 1;
     long L; int P;
-    lf_plan(N, chunk, &L, &P);
+    lf_plan(rows, N, chunk, &L, &P);
     if (P > 1 && (!work || work_doubles < lf_work_doubles(rows, P, M))) return DASP_ERR_ARG;
     hipError_t e = hipMemsetAsync(gb, 0, sizeof(double) * (size_t)rows * K, st);
     if (e == hipSuccess) e = hipMemsetAsync(ga, 0, sizeof(double) * (size_t)rows * K, st);
@@ -285,7 +313,7 @@ long dasp_lfilter_work_doubles(int rows, long N, int K, long chunk) {
     if (rows <= 0 || N <= 0 || K < 1 || K > 16) return -1;
     const int M = lf_mk(K) - 1;
     long L; int P;
-    lf_plan(N, chunk, &L, &P);
+    lf_plan(rows, N, chunk, &L, &P);
     return lf_work_doubles(rows, P, M);
 }
 int dasp_lfilter_forward(const void* x, const double* bn, const double* an, int Bs, void* y, double* wsave, double* work, long work_doubles,

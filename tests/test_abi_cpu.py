@@ -84,7 +84,8 @@ def test_argument_errors_without_gpu():
     assert L.dasp_sosfilt_forward(None, 1, None, None, None, 1, 1, 16, 6, None) == -1
     assert L.dasp_sos_prepare(None, 1, 6, None, None, None) == -1
     assert L.dasp_lfilter_forward(None, None, None, 1, None, None, None, 0, 1, 16, 5, 0, 0, None) == -1
-    assert L.dasp_lfilter_work_doubles(4, 262144, 5, 0) == 2 * 256 * 4 * 7 + 4 * 7 * 7          # 256 chunks of 1024 samples, 7 state components (K <= 8)
+    assert L.dasp_lfilter_work_doubles(4, 262144, 5, 0) == 2 * 512 * 4 * 7 + 4 * 7 * 7          # up to 64 rows: 512 chunks of 512 samples, 7 state components (K <= 8)
+    assert L.dasp_lfilter_work_doubles(100, 262144, 5, 0) == 2 * 256 * 100 * 7 + 100 * 7 * 7    # more rows: 256 chunks of 1024 samples
     assert L.dasp_lfilter_work_doubles(4, 50, 5, 0) == 0 and L.dasp_lfilter_work_doubles(4, 100, 17, 0) == -1   # one chunk (<= 64 samples): no scratch; K > 16 unsupported
     assert L.dasp_lfilter_work_doubles(4, 100, 5, 7) == 2 * 15 * 4 * 7 + 4 * 7 * 7               # the caller's chunk length: 15 chunks of 7 samples
     # a scratch buffer smaller than the plan needs is refused before anything is launched (the pointers are never dereferenced on the host)
