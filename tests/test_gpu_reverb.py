@@ -65,7 +65,9 @@ def test_reverb_seed_reproduces_reference_noise_stream(D):
 @pytest.mark.parametrize("B,C,N,L,taps", [(1, 2, 1, 64, 15), (2, 1, 100, 256, 31), (1, 2, 5000, 300, 63), (3, 2, 70000, 65536, 1023), (2, 2, 262144, 65536, 1023),
                                           (1, 2, 9000, 3000, 63), (2, 2, 21000, 5000, 255), (1, 1, 50000, 10000, 1023), (1, 2, 9000, 20000, 127),
                                           (1, 2, 300000, 100000, 63), (1, 1, 30000, 200000, 255), (1, 2, 40000, 400000, 63), (1, 2, 40000, 1000000, 63),
-                                          (1, 2, 4000, 500, 3585)])
+                                          (1, 2, 4000, 500, 3585),
+                                          # more pairs of blocks: the overlap carried across pairs, an odd block count (zero partner), mono input
+                                          (1, 2, 61000, 8000, 63), (2, 1, 110000, 8192, 127), (1, 2, 32768, 8192, 31), (1, 2, 120000, 30000, 255)])
 def test_reverb_shapes_vs_oracle(D, B, C, N, L, taps):
     rng = np.random.default_rng(N + L)
     x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
@@ -269,3 +271,34 @@ def test_chunked_passes_equal_one_pass(D, monkeypatch, C):
         assert np.abs(y1 - y0).max() <= 1e-6 * np.abs(y0).max()
         assert np.abs(gx1 - gx0).max() <= 1e-6 * np.abs(gx0).max()
         assert np.abs(gp1 - gp0).max() <= 2e-6 * np.abs(gp0).max()
+
+
+@pytest.mark.parametrize("B,C,N,L", [(2, 2, 61000, 8000), (1, 1, 110000, 8192), (2, 2, 262144, 65536), (1, 2, 30000, 8192)])
+def test_r3_frames_equal_radix2_frames(D, monkeypatch, B, C, N, L):
+    """The long convolution on frames of 3 x 2^k points (blocks of two thirds of a frame, radix-3 step around the column transforms; round 4)
+    against the same call on the 2^k frames, which are the plan (R3 frames measured slower, csrc/reverb.hip rv_dims; DASP_REVERB_RADIX3=1
+    takes them): one pair of blocks, several pairs with the overlap carried across them, an odd block count, mono input, BASELINE
+    config 4's ratio N = 4 L. y, grad x and the 25 control gradients agree to the rounding of two different transform lengths."""
+    taps = 127
+    rng = np.random.default_rng(N + L + C)
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 2, N)).astype(np.float32)
+    p = rng.random((B, 25)).astype(np.float32)
+    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DASP_REVERB_RADIX3", flag)
+        outs.append(run(D, x, p, w, noise, L, taps))
+    (y3, gx3, gp3), (y2, gx2, gp2) = outs
+    e = {"y": np.abs(y3 - y2).max() / np.abs(y2).max(), "gx": np.abs(gx3 - gx2).max() / np.abs(gx2).max(), "gctl": np.abs(gp3 - gp2).max() / np.abs(gp2).max()}
+    record(f"reverb_r3_vs_radix2[{B},{C},{N},{L}]", **e)
+    assert e["y"] < 5e-6 and e["gx"] < 5e-6 and e["gctl"] < 2e-5, e
+    from dasp_pytorch_amd import _lib
+    import ctypes
+    sizes = (ctypes.c_long * 14)()
+    monkeypatch.delenv("DASP_REVERB_RADIX3")
+    assert _lib.lib().dasp_reverb_sizes(128, 262144, 65536, 1023, 12, sizes) == 0
+    assert (sizes[0], sizes[1], sizes[2]) == (65536, 131072, 2)           # BASELINE config 4, the plan: two pairs of blocks in 2^17-point frames
+    monkeypatch.setenv("DASP_REVERB_RADIX3", "1")
+    assert _lib.lib().dasp_reverb_sizes(128, 262144, 65536, 1023, 12, sizes) == 0
+    assert (sizes[0], sizes[1], sizes[2]) == (131072, 196608, 1)          # on request: ONE 3 x 2^16-point frame per signal
