@@ -20,6 +20,67 @@ constexpr int FFT_LDS = FFT_N + FFT_N / 8;   // float2 elements of one padded ex
 // one pad slot per 8 elements: spreads the stride-8 and stride-64 scatters of the Stockham passes over the LDS banks
 __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 3); }
 
+// ---- packed complex arithmetic (round 4 experiment, OFF by default) ------------------------------------------------------------------------
+// A complex number is one f2 = one 64-bit register pair, and gfx950's packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: two fp32 operations per lane and instruction at the scalar instructions' issue rate - SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+// stays at 1.07 quad-cycles with 43 % of the instructions packed) do a complex add in ONE instruction and a complex product in TWO: their
+// op_sel / neg modifiers read a source's halves swapped and negated for free, which is what "times +-i" and the cross terms of a product
+// are. A radix-8 butterfly 54 -> 28 instructions, a twiddle product 4 -> 2; per kernel (static counts, scripts/kernel_valu.sh): filter bank
+// 1211 -> 893 / 1642 -> 1423, row passes 895 -> 644 / 1576 -> 1124, inverse columns 980 -> 768, STFT loss 768 -> 645 / 1672 -> 1466.
+// MEASURED, same box, interleaved (profiles/r04/ab_packed_fft.log): reverb (128, 2, 262144) 2.265 against 2.248 ms, (8, 2, 131072) 0.197
+// against 0.201 ms, chain step unchanged, STFT loss 0.769 against 0.730 ms. A quarter fewer vector instructions buy nothing: the counters
+// put these kernels at ~1.8 GHz of 2.4 (SQ_BUSY_CYCLES over the duration; profiles/r04/reverb_sq_counters.log) - they run at the power
+// limit, the arithmetic done per joule is the same, and the clock gives back what the issue slots gained. Kept as a
+// build-time A/B (-DDASP_FFT_PACKED=1); the scalar interfaces below (float r[8], i[8]) are the same either way.
+#ifndef DASP_FFT_PACKED
+#define DASP_FFT_PACKED 0
+#endif
+// a + rot(b), a - rot(b) with rot(b) = b * (-i) for DIR < 0 (b.y, -b.x) and b * (+i) for DIR > 0 (-b.y, b.x)
+template <int DIR> __device__ __forceinline__ f2 cx_add_rot(f2 a, f2 b) {
+    f2 o;
+    if (DIR < 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+template <int DIR> __device__ __forceinline__ f2 cx_sub_rot(f2 a, f2 b) { return cx_add_rot<-DIR>(a, b); }
+// rot(t) - t  (what w8^3 = (-1 -+ i) / sqrt 2 does to t, up to the factor 1 / sqrt 2)
+template <int DIR> __device__ __forceinline__ f2 cx_rot_minus(f2 t) {
+    f2 o;
+    if (DIR < 0) asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(o) : "v"(t));    // (t.y - t.x, -t.x - t.y)
+    else asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[0,1]" : "=v"(o) : "v"(t));          // (-t.y - t.x, t.x - t.y)
+    return o;
+}
+// z * w (DIR < 0) or z * conj(w) (DIR > 0)
+template <int DIR> __device__ __forceinline__ f2 cx_mul(f2 z, f2 w) {
+    f2 o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(o) : "v"(z), "v"(w));                                               // (z.x w.x, z.y w.x)
+    if (DIR < 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(o) : "v"(z), "v"(w));   // + (-z.y w.y, z.x w.y)
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(o) : "v"(z), "v"(w));          // + (z.y w.y, -z.x w.y)
+    return o;
+}
+template <int DIR> __device__ __forceinline__ void dft4v(f2& a, f2& b, f2& c, f2& d) {        // 4-point DFT in place, natural order
+    const f2 s0 = a + c, d0 = a - c, s1 = b + d, d1 = b - d;
+    a = s0 + s1; c = s0 - s1;
+    b = cx_add_rot<DIR>(d0, d1); d = cx_sub_rot<DIR>(d0, d1);
+}
+template <int DIR> __device__ __forceinline__ void radix8v(f2 (&z)[8]) {                      // X[q] = sum_r x[r] exp(DIR 2 pi i q r / 8)
+    constexpr float H = 0.70710678118654752440f;
+    f2 a[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = z[k] + z[k + 4]; a[k + 4] = z[k] - z[k + 4]; }
+    // odd half times w8^k: w8 = (1 -+ i) / sqrt 2 -> (t + rot t) H;  w8^2 = -+i folded into the butterflies below;  w8^3 -> (rot t - t) H
+    a[5] = cx_add_rot<DIR>(a[5], a[5]) * H;
+    a[7] = cx_rot_minus<DIR>(a[7]) * H;
+    dft4v<DIR>(a[0], a[1], a[2], a[3]);
+    {
+        const f2 s0 = cx_add_rot<DIR>(a[4], a[6]), d0 = cx_sub_rot<DIR>(a[4], a[6]), s1 = a[5] + a[7], d1 = a[5] - a[7];
+        a[4] = s0 + s1; a[6] = s0 - s1;
+        a[5] = cx_add_rot<DIR>(d0, d1); a[7] = cx_sub_rot<DIR>(d0, d1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { z[2 * k] = a[k]; z[2 * k + 1] = a[4 + k]; }
+}
+
 // z * (-i) for DIR < 0, z * (+i) for DIR > 0
 template <int DIR> __device__ __forceinline__ void rot90(float& re, float& im) {
     const float t = re;
@@ -29,6 +90,11 @@ template <int DIR> __device__ __forceinline__ void rot90(float& re, float& im) {
 // 4-point DFT of (c0..c3) in place, outputs in natural order
 template <int DIR>
 __device__ __forceinline__ void dft4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3, float& i3) {
+#if DASP_FFT_PACKED
+    f2 a = f2{r0, i0}, b = f2{r1, i1}, c = f2{r2, i2}, d = f2{r3, i3};
+    dft4v<DIR>(a, b, c, d);
+    r0 = a.x; i0 = a.y; r1 = b.x; i1 = b.y; r2 = c.x; i2 = c.y; r3 = d.x; i3 = d.y;
+#else
     const float s0r = r0 + r2, s0i = i0 + i2, d0r = r0 - r2, d0i = i0 - i2;
     const float s1r = r1 + r3, s1i = i1 + i3;
     float d1r = r1 - r3, d1i = i1 - i3;
@@ -37,10 +103,19 @@ __device__ __forceinline__ void dft4(float& r0, float& i0, float& r1, float& i1,
     r2 = s0r - s1r; i2 = s0i - s1i;
     r1 = d0r + d1r; i1 = d0i + d1i;
     r3 = d0r - d1r; i3 = d0i - d1i;
+#endif
 }
 
 // 8-point DFT, X[q] = sum_r x[r] exp(DIR 2 pi i q r / 8), natural order in and out
 template <int DIR> __device__ __forceinline__ void radix8(float (&r)[8], float (&i)[8]) {
+#if DASP_FFT_PACKED
+    f2 z[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = f2{r[k], i[k]};
+    radix8v<DIR>(z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { r[k] = z[k].x; i[k] = z[k].y; }
+#else
     constexpr float H = 0.70710678118654752440f;
     float ar[8], ai[8];
 #pragma unroll
@@ -65,30 +140,39 @@ template <int DIR> __device__ __forceinline__ void radix8(float (&r)[8], float (
         r[2 * k] = ar[k]; i[2 * k] = ai[k];
         r[2 * k + 1] = ar[4 + k]; i[2 * k + 1] = ai[4 + k];
     }
+#endif
 }
 
-// w^1..w^7 of one pass's twiddle (forward sign), powers by repeated products (each within ~2 ulp)
-struct Tw8 { float r[7], i[7]; };
+// w^1..w^7 of one pass's twiddle (forward sign), powers by repeated products (each within ~2 ulp); kept as pairs: a twiddle is one
+// 64-bit operand of the packed product
+struct Tw8 { f2 w[7]; };
 __device__ __forceinline__ Tw8 tw_powers(f2 w) {
     Tw8 t;
-    t.r[0] = w.x; t.i[0] = w.y;
-    t.r[1] = w.x * w.x - w.y * w.y;            t.i[1] = 2.f * w.x * w.y;
-    t.r[2] = t.r[1] * w.x - t.i[1] * w.y;      t.i[2] = t.r[1] * w.y + t.i[1] * w.x;
-    t.r[3] = t.r[1] * t.r[1] - t.i[1] * t.i[1]; t.i[3] = 2.f * t.r[1] * t.i[1];
-    t.r[4] = t.r[3] * w.x - t.i[3] * w.y;      t.i[4] = t.r[3] * w.y + t.i[3] * w.x;
-    t.r[5] = t.r[2] * t.r[2] - t.i[2] * t.i[2]; t.i[5] = 2.f * t.r[2] * t.i[2];
-    t.r[6] = t.r[3] * t.r[2] - t.i[3] * t.i[2]; t.i[6] = t.r[3] * t.i[2] + t.i[3] * t.r[2];
+    t.w[0] = w;
+#if DASP_FFT_PACKED
+    t.w[1] = cx_mul<-1>(w, w); t.w[2] = cx_mul<-1>(t.w[1], w); t.w[3] = cx_mul<-1>(t.w[1], t.w[1]); t.w[4] = cx_mul<-1>(t.w[3], w);
+    t.w[5] = cx_mul<-1>(t.w[2], t.w[2]); t.w[6] = cx_mul<-1>(t.w[3], t.w[2]);
+#else
+    auto mul = [](f2 a, f2 b) { return f2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; };
+    auto sqr = [](f2 a) { return f2{a.x * a.x - a.y * a.y, 2.f * a.x * a.y}; };
+    t.w[1] = sqr(w); t.w[2] = mul(t.w[1], w); t.w[3] = sqr(t.w[1]); t.w[4] = mul(t.w[3], w); t.w[5] = sqr(t.w[2]); t.w[6] = mul(t.w[3], t.w[2]);
+#endif
     return t;
 }
 // x[k] *= w^k (DIR < 0) or conj(w)^k (DIR > 0), k = 1..7
 template <int DIR> __device__ __forceinline__ void twiddle8(float (&r)[8], float (&i)[8], const Tw8& w) {
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-        const float wr = w.r[k - 1], wi = w.i[k - 1];
+#if DASP_FFT_PACKED
+        const f2 o = cx_mul<DIR>(f2{r[k], i[k]}, w.w[k - 1]);
+        r[k] = o.x; i[k] = o.y;
+#else
+        const float wr = w.w[k - 1].x, wi = w.w[k - 1].y;
         float t;
         if (DIR < 0) { t = r[k] * wr - i[k] * wi; i[k] = r[k] * wi + i[k] * wr; }
         else { t = r[k] * wr + i[k] * wi; i[k] = i[k] * wr - r[k] * wi; }
         r[k] = t;
+#endif
     }
 }
 
@@ -217,9 +301,14 @@ __device__ __forceinline__ void col_exchange(float (&r)[8], float (&i)[8], f2* l
     for (int q = 0; q < 8; ++q) { const f2 v = lds[fft_pad(g.j + q * g.T) * g.TC + g.c]; r[q] = v.x; i[q] = v.y; }
 }
 template <int DIR> __device__ __forceinline__ void cmul_dir(float& re, float& im, float wr, float wi) {
+#if DASP_FFT_PACKED
+    const f2 o = cx_mul<DIR>(f2{re, im}, f2{wr, wi});
+    re = o.x; im = o.y;
+#else
     const float t = DIR < 0 ? re * wr - im * wi : re * wr + im * wi;
     im = DIR < 0 ? re * wi + im * wr : im * wr - re * wi;
     re = t;
+#endif
 }
 // tw = the 4096-entry forward table; the twiddles of a pass are formed right before it (workgroups that run one transform per
 // thread have nothing to amortise them over, and keeping all of them live costs ~50 VGPRs)
