@@ -1,0 +1,29 @@
+#!/bin/bash
+# round 4 GPU call: full GPU test suite, smoke, the bench line at the driver's arguments and at the defaults, rocprofv3 kernel stats of the
+# bench command, HBM counters of the EQ kernels (tied to the kernel source hash) and of the reverb kernels, reverb kernel stats.
+# usage (gpurun): bash scripts/gpu_r4_final.sh [skip-tests]
+out=gpurun_out/r04; mkdir -p $out; export TMPDIR=/tmp
+if [ "$1" != "skip-tests" ]; then
+  timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8 | tee $out/smoke.log
+fi
+bash scripts/hbm_traffic.sh $out > $out/hbm_traffic.log 2>&1; tail -c 600 $out/hbm_traffic.log
+mkdir -p profiles/r04; cp $out/hbm_traffic.json profiles/r04/hbm_traffic.json       # bench.py reads the counter file from profiles/ (hash-checked)
+DASP_RV_NOISE=generated bash scripts/reverb_traffic.sh $out/hbm_traffic_secondary.json 2>&1 | tail -2
+cp $out/hbm_traffic_secondary.json profiles/r04/hbm_traffic_secondary.json           # (the reverb's roofline dict in bench.py's `secondary` quotes it)
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_args.json 2> $out/bench_driver_args.err
+timeout 600 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rprof.err )
+cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv; rm -rf $out/rprof
+( cd /tmp && DASP_RV_NOISE=generated rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/scripts/reverb_time.py 128 2 262144 > /dev/null 2>> $GRAFT_REPO_ROOT/$out/rprof.err )
+cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/reverb_kernel_stats.csv; rm -rf $out/rprof
+python - <<'PY'
+import json
+for f in ("bench_driver_args", "bench", "bench_under_rocprof"):
+    try:
+        d = json.loads(open(f"gpurun_out/r04/{f}.json").read().strip().splitlines()[-1])
+        print(f, "ms", round(d["ms_per_step"], 4), "value %.4g" % d["value"], d["launch_ms_per_step"], "bwd", d["roofline"]["ms"], d["roofline"]["frac"], "traffic", d["roofline"]["traffic"],
+              "fwd", d["roofline_fwd"]["ms"], "both", d["roofline_fwd_bwd"]["frac"])
+    except Exception as e:
+        print(f, "ERR", e)
+PY
