@@ -367,6 +367,10 @@ def secondary(dev):
     from dasp_pytorch_amd import _torch_ops
     eager = {"torch_ops" if _torch_ops.enabled() else "ctypes": round(t * 1e3, 3)}
     for proc in (chain.equalizer, chain.compressor, chain.reverb, chain.gain):
+        proc.validate_range = "deferred"              # the check stays, read one call late from pinned memory: no host wait
+    eager[("torch_ops" if _torch_ops.enabled() else "ctypes") + "_deferred_range_check"] = round(_time_steps(chain_step) * 1e3, 3)
+    chain.flush_range_check()
+    for proc in (chain.equalizer, chain.compressor, chain.reverb, chain.gain):
         proc.validate_range = False
     eager[("torch_ops" if _torch_ops.enabled() else "ctypes") + "_no_range_check"] = round(_time_steps(chain_step) * 1e3, 3)
     if _torch_ops.enabled():

@@ -38,10 +38,19 @@ class StyleTransferChain:
         if all(p.validate_range for p in procs) and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
             every = (eq_params, comp_params, reverb_params, gain_params)
             if all(t.dim() == 2 and t.shape[0] == every[0].shape[0] and t.dtype == every[0].dtype and t.device == every[0].device for t in every):
-                _modules.check_unit_range(torch.cat([t.detach() for t in every], dim=1), [n for p in procs for n in p.param_ranges])
+                names = [n for p in procs for n in p.param_ranges]
+                if all(p.validate_range == "deferred" for p in procs):      # no host wait: the previous call's numbers are looked at (modules._DeferredRangeCheck)
+                    self.equalizer._deferred().submit(torch.cat([t.detach() for t in every], dim=1), names)
+                else:
+                    _modules.check_unit_range(torch.cat([t.detach() for t in every], dim=1), names)
                 with _modules.already_validated():
                     return self._run(x, eq_params, comp_params, reverb_params, gain_params)
         return self._run(x, eq_params, comp_params, reverb_params, gain_params)
+
+    def flush_range_check(self):
+        """validate_range = "deferred": raise now if the last call's parameters were outside [0, 1]."""
+        for p in (self.equalizer, self.compressor, self.reverb, self.gain):
+            p.flush_range_check()
 
     def _tables(self):
         """lo / span of the compressor's 6, the reverb's 25 and the gain's 1 parameter as the two float[32] arrays dasp_chain_controls takes."""

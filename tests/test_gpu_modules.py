@@ -370,3 +370,35 @@ def test_chain_as_graphed_callable(D):
         if step:
             assert float((yg.detach() - y_prev).abs().max()) > 1e-3 * float(yg.detach().abs().max())       # the offset word changed the noise of the replay
         y_prev = yg.detach().clone()
+
+
+def test_deferred_range_check_raises_one_call_late(D):
+    """validate_range = "deferred": no host wait in process_normalized; a value outside [0, 1] raises the reference's ValueError (the parameter
+    named) at the next call or at flush_range_check(), and a good call after a flushed bad one runs."""
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    x = torch.rand(2, 2, 4096, device="cuda:0", generator=g) * 2 - 1
+    eq = D.ParametricEQ(SR)
+    eq.validate_range = "deferred"
+    good = torch.rand(2, 18, device="cuda:0", generator=g)
+    bad = good.clone(); bad[1, 4] = 1.25                                  # band0_cutoff_freq
+    y = eq.process_normalized(x, good)
+    assert torch.isfinite(y).all()
+    eq.process_normalized(x, bad)                                         # queued; nothing read back yet
+    with pytest.raises(ValueError, match="band0_cutoff_freq"):
+        eq.process_normalized(x, good)                                    # the previous call's numbers arrive here
+    assert torch.isfinite(eq.process_normalized(x, good)).all()
+    eq.process_normalized(x, bad)
+    with pytest.raises(ValueError, match="band0_cutoff_freq"):
+        eq.flush_range_check()
+    eq.flush_range_check()                                                # nothing pending: no-op
+    # the chain: one deferred check for all 50 parameters
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    chain = StyleTransferChain(SR, num_samples=2048, device_noise=True, noise_seed=3)
+    for p in (chain.equalizer, chain.compressor, chain.reverb, chain.gain):
+        p.validate_range = "deferred"
+    ps = [torch.rand(2, n, device="cuda:0", generator=g) for n in chain.num_params]
+    chain.process_normalized(x, *ps)
+    ps[2][0, 13] = -0.5                                                   # band1_decay
+    chain.process_normalized(x, *ps)
+    with pytest.raises(ValueError, match="band1_decay"):
+        chain.flush_range_check()

@@ -142,3 +142,22 @@ def test_reverb_module_passes_its_noise_keywords(monkeypatch):
     monkeypatch.undo()                                                        # the real function: an offset without generated noise is refused
     with pytest.raises(ValueError, match="noise_seed_offset"):
         F.noise_shaped_reverberation(torch.zeros(1, 2, 8), SR, *[torch.zeros(1)] * 25, noise_seed_offset=off)
+
+
+def test_deferred_range_check_on_cpu_tensors_is_immediate():
+    """validate_range = "deferred" exists to avoid a device read-back; CPU parameter tensors are simply checked at once (same ValueError)."""
+    import dasp_pytorch_amd as D
+
+    class Probe(D.Processor):
+        def __init__(self):
+            super().__init__()
+            self.sample_rate = 44100
+            self.process_fn = lambda x, sr, a, b: x
+            self.param_ranges = {"a": (0.0, 1.0), "b": (-1.0, 1.0)}
+    m = Probe()
+    m.validate_range = "deferred"
+    x = torch.zeros(2, 1, 8)
+    assert m.process_normalized(x, torch.tensor([[0.1, 0.9], [0.5, 0.5]])) is x
+    with pytest.raises(ValueError, match="Parameter b of is out of range"):
+        m.process_normalized(x, torch.tensor([[0.1, 0.9], [0.5, 1.5]]))
+    m.flush_range_check()                                                   # nothing pending
