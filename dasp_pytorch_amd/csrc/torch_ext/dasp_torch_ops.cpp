@@ -105,7 +105,7 @@ std::tuple<Tensor, Tensor> peq_norm_backward(const Tensor& x, const Tensor& gy, 
     const Tensor x32 = x.contiguous(), g32 = f32c(gy);
     Tensor gx = need_gx ? at::empty_like(x32) : at::empty({0}, x32.options());
     Tensor gp = need_gp ? at::empty({B, S, 3}, x32.options()) : at::empty({0}, x32.options());
-    if (x32.numel() == 0 || (!need_gx && !need_gp)) return {gx, need_gp ? gp.zero_().reshape({B, 3 * S}) : gp};
+    if (x32.numel() == 0 || (!need_gx && !need_gp)) return {gx, need_gp ? at::zeros({Bp, 3 * S}, x32.options()) : gp};
     const long n_tab = round64(Bp * dasp_sos_table_floats((int)S));
     const long n_dt = Bp * dasp_sos_dtab_doubles((int)S);
     const long G = dasp_sos_segments(N, tseg);

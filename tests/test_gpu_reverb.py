@@ -302,3 +302,28 @@ def test_r3_frames_equal_radix2_frames(D, monkeypatch, B, C, N, L):
     monkeypatch.setenv("DASP_REVERB_RADIX3", "1")
     assert _lib.lib().dasp_reverb_sizes(128, 262144, 65536, 1023, 12, sizes) == 0
     assert (sizes[0], sizes[1], sizes[2]) == (131072, 196608, 1)          # on request: ONE 3 x 2^16-point frame per signal
+
+
+@pytest.mark.parametrize("B,C,N,L,taps", [(1, 2, 61000, 8000, 63), (2, 1, 110000, 8192, 127), (1, 2, 32768, 8192, 31), (1, 2, 300000, 100000, 63), (2, 2, 262144, 65536, 1023)])
+def test_r3_frames_vs_oracle(D, monkeypatch, B, C, N, L, taps):
+    """Frames of 3 x 2^k points (DASP_REVERB_RADIX3=1: a non-power-of-two transform length, NAp = 16 ... 256 column sub-transforms) straight
+    against the oracle - y, grad x and the 25 control gradients at the bounds of test_reverb_shapes_vs_oracle - on two pairs of blocks, an
+    odd block count with mono input, N = 4 Lp exactly, a 2^17-sample block, and BASELINE config 4's sizes at a small batch."""
+    monkeypatch.setenv("DASP_REVERB_RADIX3", "1")
+    rng = np.random.default_rng(N + L + 3)
+    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
+    w = rng.standard_normal((B, 2, N)).astype(np.float32)
+    p = rng.random((B, 25)).astype(np.float32)
+    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
+    from dasp_pytorch_amd import _lib
+    import ctypes
+    sizes = (ctypes.c_long * 14)()
+    assert _lib.lib().dasp_reverb_sizes(B, N, L, taps, 12, sizes) == 0 and sizes[1] % 3 == 0 and (sizes[1] // 3) & (sizes[1] // 3 - 1) == 0
+    y, gx, gp = run(D, x, p, w, noise, L, taps)
+    pd = p.astype(np.float64)
+    yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
+    gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, w, L, taps)
+    gpo = np.concatenate([gg, gd, gm[:, None]], 1)
+    e = {"y": np.abs(y - yo).max() / max(np.abs(yo).max(), 1e-6), "gx": np.abs(gx - gxo).max() / max(np.abs(gxo).max(), 1e-6), "gctl": np.abs(gp - gpo).max() / np.abs(gpo).max()}
+    record(f"reverb_r3_vs_oracle[{B},{C},{N},{L},{taps}]", **e)
+    assert e["y"] < 3e-5 and e["gx"] < 3e-5 and e["gctl"] < CTL_TOL, e
