@@ -71,7 +71,11 @@ struct SosLayout {
     static constexpr int DF = GT + 2 * SYS;          // [S][8]: b1, b2, -a1, -a2 (normalised), zc1, zc2, 1/om, sg/om: direct-form sections
     static constexpr int MN = DF + 8 * S;            // [S][8]: b1/b0, b2/b0, g1/d, g2/d, q, q/om, q sg/om, 0 with q = 1 / (b0 of the sections before k): the
                                                      //      backward kernel's recomputation of a designed cascade runs every section with feed-through 1
-    static constexpr int CNT = MN + 8 * S;           // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
+    static constexpr int YMC = L + 16;               // columns of the output map below: L input samples, then up to 16 start-state components
+    static constexpr int YM = MN + 8 * S;            // [L][YMC]: the chunk's L outputs as a linear map of (its L inputs, its 2S start-state
+                                                     //      components): row n = (h[n], h[n-1], .., h[0], 0, .. | O[n][0..2S), 0, ..), h = impulse response
+                                                     //      of the whole cascade, O = its zero-input response per unit state (forward kernel, MFMA output path)
+    static constexpr int CNT = YM + L * YMC;         // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
                                                      //      prep kernel, reset by the workgroup that finalizes the item)
     static constexpr int TOTAL = CNT + 4;
 };

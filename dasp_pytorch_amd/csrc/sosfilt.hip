@@ -160,6 +160,9 @@ constexpr double OM_MIN = 1e-5;
 #ifndef DASP_FWD_DIRECT
 #define DASP_FWD_DIRECT 0
 #endif
+#ifndef DASP_FWD_MFMA_OUT
+#define DASP_FWD_MFMA_OUT 1      // forward kernel, one workgroup per row: the chunk's outputs on the matrix cores (y = T x + O s0) instead of the per-lane cascade
+#endif
 
 template <int S, int L>
 __global__ void __launch_bounds__(256)
@@ -172,12 +175,14 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     __shared__ double vv[2][2][S2];
     __shared__ float Gsh[2][L][S2];     // chunk-table columns v_m, written out after the recursion (no global stores inside it)
     __shared__ double Pd[S][7][2];
+    __shared__ float hsh[L];            // impulse response of the cascade over one chunk (output map, LY::YM)
     const int tid = threadIdx.x, item = blockIdx.x;
     PTRACE(40, 0);
     float* tb = tab + (size_t)item * LY::TOTAL;
     double* dt = dtab + (size_t)item * S * DT_STRIDE;
 
     if (tid < 4) tb[LY::CNT + tid] = 0.f;
+    for (int e = tid; e < L * LY::YMC; e += 256) tb[LY::YM + e] = 0.f;      // (the output map's non-zero entries are written after the barrier below)
     if (tid < 3 * S) {   // thread = (section k, control dir): values + one Jacobian column each
         const int k = tid / 3, dir = tid % 3;
         double c5[5], dc5[5] = {0, 0, 0, 0, 0}, a0 = 1.0;
@@ -297,6 +302,28 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             }
             wave_lds_sync();
         }
+    } else if (tid >= 128 && tid < 128 + 1 + S2) {
+        // Wave 2, beside the two chains above: the output map of a chunk (LY::YM; sos_fwd_kernel's matrix-core output path). Thread 0 runs
+        // the cascade on a unit impulse from zero states (h[n] -> row n holds h[n - j] at column j), thread 1 + c on zero input from the unit
+        // start state c (section c / 2, component c % 2): 16 samples of the normal-form recursion the forward kernel would run, in fp64.
+        const int ex = tid - 128, c0 = ex - 1;
+        double s1[S], s2[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) { s1[k] = (c0 == 2 * k) ? 1.0 : 0.0; s2[k] = (c0 == 2 * k + 1) ? 1.0 : 0.0; }
+        for (int n = 0; n < L; ++n) {
+            double u = (ex == 0 && n == 0) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const double sg = sec[k][0], om = sec[k][1], kom = sec[k][2], g1 = sec[k][3], g2 = sec[k][4], d = sec[k][5];
+                const double o = d * u + g1 * s1[k] + g2 * s2[k];
+                const double t1 = sg * s1[k] - kom * s2[k] + u;
+                s2[k] = om * s1[k] + sg * s2[k];
+                s1[k] = t1;
+                u = o;
+            }
+            if (ex == 0) hsh[n] = (float)u;                        // h[n]: spread over the n-th sub-diagonal after the barrier below
+            else tb[LY::YM + n * LY::YMC + L + c0] = (float)u;
+        }
     } else if (tid < 128) {
         const int l = tid - 64;
         double (*src)[NN] = T1;
@@ -346,6 +373,10 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     }
     PTRACE(43, 0); PTRACE(44, 64);
     __syncthreads();
+    for (int e = tid; e < L * L; e += 256) {            // output map, input half: T[n][j] = h[n - j] (the upper triangle stays zero)
+        const int n = e / L, j = e % L;
+        if (j <= n) tb[LY::YM + n * LY::YMC + j] = hsh[n - j];
+    }
     // chunk tables: forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
     for (int e = tid; e < 2 * L * S2; e += 256) {
         const int sys = e / (L * S2), m = (e / S2) % L, i = e % S2;
@@ -518,6 +549,20 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
     const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
+    // Matrix-core output path (round 4): a chunk's 16 outputs are a linear map of its 16 inputs and its 2S
+    // start-state components, y = T x + O s0 (LY::YM, fp64 in the prep kernel), so the cascade over the chunk - 768 of the kernel's ~890
+    // vector instructions per tile - becomes 32 v_mfma_f32_16x16x4_f32 beside the 16 of the chunk products: the B operands of T x are the
+    // input granules already in registers, those of O s0 the start states written as one more [chunk][16] image, and the D registers are
+    // granules of the output image. A operands, once per kernel: row i = lane & 15, contraction slots 4 (lane >> 4) + q.
+    constexpr bool MO = DASP_FWD_MFMA_OUT && SEG != 2 && L == 16 && S2 <= 16;      // (SEG 2 is the scan-only pre-pass: no outputs)
+    float AT[4], AO[4];
+    if (MO) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            AT[q] = tb[LY::YM + (lane & 15) * LY::YMC + 4 * (lane >> 4) + q];
+            AO[q] = tb[LY::YM + (lane & 15) * LY::YMC + L + 4 * (lane >> 4) + q];
+        }
+    }
 
     for (int t = t0 + wave; t < t1; t += W) {
         int toff = 0;
@@ -532,10 +577,11 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // issued after that request, may stay in flight.
         if (full) wait_vmcnt(stores_in_flight);
         else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
-        lds_to_chunks_swz<L>(tbx, X, lane);
+        if (!MO) lds_to_chunks_swz<L>(tbx, X, lane);
         f4 Bop[4], zacc[4];
         chunk_products_load(tbx, Bop, lane);
-        pin(X); pin(Bop);
+        if (!MO) pin(X);
+        pin(Bop);
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 16)
         if (t + W < t1 && t < W) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
 #else
@@ -590,6 +636,30 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             }
         }
 
+        if constexpr (MO) {
+            // start states -> [chunk][16] image (granule g = components 4 g .. 4 g + 3; beyond 2S: zeros), read back as B operands
+            float sc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sc[c] = c < S2 ? ((c & 1) ? st[c >> 1].y : st[c >> 1].x) : 0.f;
+            chunks_to_lds_swz<L>(tby, sc, lane);
+            f4 Bs[4], yacc[4];
+            chunk_products_load(tby, Bs, lane);
+            pin(Bs);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) yacc[c] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[q], Bop[c][q], yacc[c], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bs[c][q], yacc[c], 0, 0, 0);
+            wave_lds_sync();              // every lane has its B operands before the image is overwritten with the outputs
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(tby + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = yacc[c];
+            wave_lds_sync();
+        } else
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
         // wave-uniform but are loaded into VGPRs (opaque lane-dependent address): VALU ops with SGPR operands issue at
         // half rate on gfx950. Only one section's coefficients are live, which keeps the kernel at <= 80 VGPRs so that
@@ -632,7 +702,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         TRACE(3);
         WIDE_PRIO(DASP_SCAN_PRIO);
 
-        chunks_to_lds_swz<L>(tby, X, lane);
+        if (!MO) chunks_to_lds_swz<L>(tby, X, lane);
 #if defined(DASP_ABLATE) && (DASP_ABLATE & 4)
         if (X[0] == 123.456f) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
         stores_in_flight = -1;
