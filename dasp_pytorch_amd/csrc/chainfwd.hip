@@ -24,6 +24,10 @@ extern "C" long dasp_sos_seg_floats(long rows, long N, int S, long Tseg);
 extern "C" int dasp_sos_segment_starts(const float* tab, const double* segtab, int Bs, const float* x, float* segbuf, int B, int C, long N, int S,
                                        long Tseg, void* stream);
 
+#ifndef DASP_CHAIN_MFMA_OUT
+#define DASP_CHAIN_MFMA_OUT 1      // the EQ half's per-chunk cascade on the matrix cores (0: the per-lane recursion)
+#endif
+
 namespace dasp {
 
 // alpha^(16 m) for a per-lane m < 128, fp64 repeated squaring
@@ -95,6 +99,13 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
     int stores_in_flight = 0;
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
+    // the EQ's cascade over every chunk on the matrix cores (sos_tile.hpp cascade_outputs_mfma, as sos_fwd_kernel); the outputs come back
+    // into the chunk layout the compressor half works in
+    // (one workgroup per item only: with segmented items - few items, every launch latency-bound - the two more LDS round trips per channel
+    // cost more than the recursion they replace: (16,1,262144) 0.0647 -> 0.0708 ms, against 0.1747 -> 0.1595 ms at (256,2,131072))
+    constexpr bool MO = DASP_CHAIN_MFMA_OUT && SEG == 0 && L == 16 && S2 <= 16;
+    float AT[4], AO[4];
+    if (MO) cascade_map_operands<S, L>(tb + LY::YM, LY::YMC, AT, AO, lane);
 
     for (int t = t0 + wave; t < t1; t += W) {
         int toff = 0;
@@ -116,10 +127,11 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
             // request of channel 0's image and may stay in flight, the request of channel 1's image came after them
             if (full) wait_vmcnt(c == 0 ? stores_in_flight : 0);
             else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
-            lds_to_chunks_swz<L>(tbx, X, lane);
+            if (!MO) lds_to_chunks_swz<L>(tbx, X, lane);
             f4 Bop[4], zacc[4];
             chunk_products_load(tbx, Bop, lane);
-            pin(X); pin(Bop);
+            if (!MO) pin(X);
+            pin(Bop);
             {   // next pass: the other channel of this tile, or channel 0 of this wave's next tile
                 const int tn = c + 1 < C ? t : t + W, cn = c + 1 < C ? c + 1 : 0;
                 if (tn < t1 && tile_full<L>((long)tn * TS, N, vec)) tile_dma_issue_swz(xb + (size_t)cn * N + (size_t)tn * TS, a_x, lane);
@@ -139,6 +151,10 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
                 },
                 [&](int k, f2 Kn) { if (t + 1 < t1) mbox_publish<63>(lds, mb_out + (c * S + k) * 4, Kn.x, Kn.y, t + 1); });
             SCAN_PRIO(0);
+            if constexpr (MO) {
+                cascade_outputs_mfma<S, L>(tby, st, Bop, AT, AO, lane);
+                lds_to_chunks_swz<L>(tby, X, lane);
+            } else
             // the cascade, one section at a time in place over the chunk (sos_fwd_kernel; normal form, coefficients in VGPRs)
 #pragma unroll
             for (int k = 0; k < S; ++k) {

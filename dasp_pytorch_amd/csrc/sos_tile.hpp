@@ -234,6 +234,47 @@ __device__ __forceinline__ void chunk_products_collect(float* scratch, const f4 
     lds_to_chunks_swz<L>(scratch, Z, chunk);
 }
 
+// The cascade over every chunk of a tile on the matrix cores (round 4). From its exact start state a chunk's L = 16 outputs are a linear
+// map of its 16 inputs and its 2S start-state components, y = T x + O s0 (LY::YM: row n = (h[n], .., h[0], 0, .. | O[n][0 .. 2S), 0, ..),
+// fp64 in the prep kernel), so the per-lane recursion - 768 vector instructions per tile for six sections - is 32 v_mfma_f32_16x16x4_f32
+// with the operand geometry of the chunk products above: the B operands of T x are the input granules the chunk products already hold
+// (Bx), those of O s0 the scan's start states written as one more [chunk][16] image (granule g = components 4 g .. 4 g + 3; beyond 2S:
+// zeros) and read back the same way, and the D registers are granules of the output image: on return `img` holds the tile's outputs in the
+// swizzled image layout (what chunks_to_lds_swz would have written). AT / AO: cascade_map_operands, once per kernel.
+template <int S, int L>
+__device__ __forceinline__ void cascade_map_operands(const float* __restrict__ ym, int ymc, float (&AT)[4], float (&AO)[4], int lane) {
+    static_assert(L == 16 && 2 * S <= 16, "one 16x16 output block per 16 chunks");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        AT[q] = ym[(lane & 15) * ymc + 4 * (lane >> 4) + q];
+        AO[q] = ym[(lane & 15) * ymc + L + 4 * (lane >> 4) + q];
+    }
+}
+template <int S, int L>
+__device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[S], const f4 (&Bx)[4], const float (&AT)[4], const float (&AO)[4], int lane) {
+    float sc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sc[c] = c < 2 * S ? ((c & 1) ? st[c >> 1].y : st[c >> 1].x) : 0.f;
+    chunks_to_lds_swz<L>(img, sc, lane);
+    f4 Bs[4], yacc[4];
+    chunk_products_load(img, Bs, lane);
+    pin(Bs);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) yacc[c] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[q], Bx[c][q], yacc[c], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bs[c][q], yacc[c], 0, 0, 0);
+    wave_lds_sync();              // every lane has its B operands before the image is overwritten with the outputs
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(img + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = yacc[c];
+    wave_lds_sync();
+}
+
 // Whole-tile scan for one system (forward or adjoint tables): lane chunks X -> chunk start states st.
 //   Gs   : [S][L][2] chunk table (zero-state end state of section k = sum_n Gs[k][n] X[n]); zmap is
 //          applied to that per-lane value before the scan (identity, or the lane mirror for the adjoint)

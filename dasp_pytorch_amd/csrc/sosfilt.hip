@@ -161,7 +161,8 @@ constexpr double OM_MIN = 1e-5;
 #define DASP_FWD_DIRECT 0
 #endif
 #ifndef DASP_FWD_MFMA_OUT
-#define DASP_FWD_MFMA_OUT 1      // forward kernel, one workgroup per row: the chunk's outputs on the matrix cores (y = T x + O s0) instead of the per-lane cascade
+#define DASP_FWD_MFMA_OUT 2      // forward kernel: the chunk's outputs on the matrix cores (y = T x + O s0) instead of the per-lane cascade;
+                                 // 1 = one workgroup per row only, 2 = segmented rows as well, 0 = never
 #endif
 
 template <int S, int L>
@@ -549,20 +550,11 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
     const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
-    // Matrix-core output path (round 4): a chunk's 16 outputs are a linear map of its 16 inputs and its 2S
-    // start-state components, y = T x + O s0 (LY::YM, fp64 in the prep kernel), so the cascade over the chunk - 768 of the kernel's ~890
-    // vector instructions per tile - becomes 32 v_mfma_f32_16x16x4_f32 beside the 16 of the chunk products: the B operands of T x are the
-    // input granules already in registers, those of O s0 the start states written as one more [chunk][16] image, and the D registers are
-    // granules of the output image. A operands, once per kernel: row i = lane & 15, contraction slots 4 (lane >> 4) + q.
-    constexpr bool MO = DASP_FWD_MFMA_OUT && SEG != 2 && L == 16 && S2 <= 16;      // (SEG 2 is the scan-only pre-pass: no outputs)
+    // Matrix-core output path (round 4; sos_tile.hpp cascade_outputs_mfma): the cascade over the chunk - 768 of the kernel's ~890 vector
+    // instructions per tile - as 32 v_mfma_f32_16x16x4_f32 beside the 16 of the chunk products.
+    constexpr bool MO = (SEG == 0 ? DASP_FWD_MFMA_OUT >= 1 : SEG == 1 ? DASP_FWD_MFMA_OUT >= 2 : false) && L == 16 && S2 <= 16;   // (SEG 2: scan only, no outputs)
     float AT[4], AO[4];
-    if (MO) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            AT[q] = tb[LY::YM + (lane & 15) * LY::YMC + 4 * (lane >> 4) + q];
-            AO[q] = tb[LY::YM + (lane & 15) * LY::YMC + L + 4 * (lane >> 4) + q];
-        }
-    }
+    if (MO) cascade_map_operands<S, L>(tb + LY::YM, LY::YMC, AT, AO, lane);
 
     for (int t = t0 + wave; t < t1; t += W) {
         int toff = 0;
@@ -637,28 +629,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         }
 
         if constexpr (MO) {
-            // start states -> [chunk][16] image (granule g = components 4 g .. 4 g + 3; beyond 2S: zeros), read back as B operands
-            float sc[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) sc[c] = c < S2 ? ((c & 1) ? st[c >> 1].y : st[c >> 1].x) : 0.f;
-            chunks_to_lds_swz<L>(tby, sc, lane);
-            f4 Bs[4], yacc[4];
-            chunk_products_load(tby, Bs, lane);
-            pin(Bs);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) yacc[c] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[q], Bop[c][q], yacc[c], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bs[c][q], yacc[c], 0, 0, 0);
-            wave_lds_sync();              // every lane has its B operands before the image is overwritten with the outputs
-#pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(tby + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = yacc[c];
-            wave_lds_sync();
+            cascade_outputs_mfma<S, L>(tby, st, Bop, AT, AO, lane);
         } else
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
         // wave-uniform but are loaded into VGPRs (opaque lane-dependent address): VALU ops with SGPR operands issue at
