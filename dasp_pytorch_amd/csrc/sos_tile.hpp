@@ -75,7 +75,10 @@ struct SosLayout {
     static constexpr int YM = MN + 8 * S;            // [L][YMC]: the chunk's L outputs as a linear map of (its L inputs, its 2S start-state
                                                      //      components): row n = (h[n], h[n-1], .., h[0], 0, .. | O[n][0..2S), 0, ..), h = impulse response
                                                      //      of the whole cascade, O = its zero-input response per unit state (forward kernel, MFMA output path)
-    static constexpr int CNT = YM + L * YMC;         // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
+    static constexpr int YMA = YM + L * YMC;         // [L][YMC]: the same for the adjoint cascade, natural sample order: row n = (0, .., h[0], h[1], .., h[L-1-n] |
+                                                     //      OA[n][0..2S), 0, ..): the adjoint outputs (gx) of a chunk from its L adjoint inputs (gy) and
+                                                     //      the 2S components of the adjoint state entering it from above (sos_bwd_gram_kernel)
+    static constexpr int CNT = YMA + L * YMC;        // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
                                                      //      prep kernel, reset by the workgroup that finalizes the item)
     static constexpr int TOTAL = CNT + 4;
 };
@@ -289,11 +292,14 @@ __device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[
 // has nothing else to issue meanwhile, so they are software-pipelined by hand: each table buffer is
 // refilled for section k+1 right after its last use in section k (the scheduling barriers pin the
 // issue points), which keeps at most one section's worth (~72 SGPRs) live.
-template <int S, int L, typename FMap, typename FPre, typename FIn, typename FOut>
-__device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (&st)[S],
-                                          const float* __restrict__ MCs, const float* __restrict__ PLs,
-                                          const float* __restrict__ P64s, const f4* __restrict__ pws, int lane,
-                                          FPre&& carry_prefetch, FIn&& carry_in, FOut&& carry_out, bool trace_on = false) {
+//   hook(k, p)      : p = 0..3, four points of section k's code (start, before the coupling sum, before the in-row levels, end) where
+//          the caller may issue work that is independent of the scan - the backward kernel's matrix-core products, which then run
+//          under the scan's dependent chains instead of in a phase of their own (tile_scan_h; tile_scan = no hook)
+template <int S, int L, typename FMap, typename FPre, typename FIn, typename FOut, typename FHook>
+__device__ __forceinline__ void tile_scan_h(const float (&Z)[L], FMap&& zmap, f2 (&st)[S],
+                                            const float* __restrict__ MCs, const float* __restrict__ PLs,
+                                            const float* __restrict__ P64s, const f4* __restrict__ pws, int lane,
+                                            FPre&& carry_prefetch, FIn&& carry_in, FOut&& carry_out, FHook&& hook, bool trace_on = false) {
     (void)P64s;   // M^64 is lane 63's per-lane power
     f4 MC[S], PL[4];
 #pragma unroll
@@ -304,6 +310,7 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         __builtin_amdgcn_sched_barrier(0);
+        hook(k, 0);
         // LDS reads of the section (per-lane powers, carry mailbox) are issued first and *waited for* right after the
         // table product, before any scalar refill is in flight: LDS and SMEM share lgkmcnt and SMEM returns out of
         // order, so a later LDS wait would be an lgkmcnt(0) that also waits for the refills just issued.
@@ -314,6 +321,7 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
         { float a = pw16.x, b = pw32.x, c = pw64.x; pin(a); pin(b); pin(c); pw16.x = a; pw32.x = b; pw64.x = c; }
         TRACE2(9);
         __builtin_amdgcn_sched_barrier(0);
+        hook(k, 1);
 #if DASP_SPLIT_COUPLING
         if (k >= 3) {       // two accumulators: the coupling sum is a dependent chain of 2 k packed FMAs otherwise
             f2 fb = f2{0.f, 0.f};
@@ -328,6 +336,7 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
         }
         pin(f); TRACE2(10);
         __builtin_amdgcn_sched_barrier(0);
+        hook(k, 2);
         if (k + 1 < S) {
 #pragma unroll
             for (int j = 0; j <= k; ++j) MC[j] = TLD4(MCs + ((k + 1) * S + j) * 4);
@@ -357,7 +366,15 @@ __device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (
         carry_out(k, E);
         st[k] = f2{wave_shr1(K.x, E.x), wave_shr1(K.y, E.y)};
         pin(st[k]); TRACE2(14);
+        hook(k, 3);
     }
+}
+template <int S, int L, typename FMap, typename FPre, typename FIn, typename FOut>
+__device__ __forceinline__ void tile_scan(const float (&Z)[L], FMap&& zmap, f2 (&st)[S],
+                                          const float* __restrict__ MCs, const float* __restrict__ PLs,
+                                          const float* __restrict__ P64s, const f4* __restrict__ pws, int lane,
+                                          FPre&& carry_prefetch, FIn&& carry_in, FOut&& carry_out, bool trace_on = false) {
+    tile_scan_h<S, L>(Z, zmap, st, MCs, PLs, P64s, pws, lane, carry_prefetch, carry_in, carry_out, [](int, int) {}, trace_on);
 }
 
 }  // namespace dasp

@@ -160,6 +160,12 @@ constexpr double OM_MIN = 1e-5;
 #ifndef DASP_FWD_DIRECT
 #define DASP_FWD_DIRECT 0
 #endif
+#ifndef DASP_GRAM_INTERLEAVE
+#define DASP_GRAM_INTERLEAVE 1 // sos_bwd_gram_kernel: the products that do not depend on the adjoint scan are issued from inside it (tile_scan_h)
+#endif
+#ifndef DASP_GRAM_ABLATE
+#define DASP_GRAM_ABLATE 0     // measurement builds only (wrong results): 1 = no Gram products, 2 = no gx products, 4 = no fp64 fold, 8 = no adjoint scan
+#endif
 #ifndef DASP_FWD_MFMA_OUT
 #define DASP_FWD_MFMA_OUT 2      // forward kernel: the chunk's outputs on the matrix cores (y = T x + O s0) instead of the per-lane cascade;
                                  // 1 = one workgroup per row only, 2 = segmented rows as well, 0 = never
@@ -183,7 +189,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     double* dt = dtab + (size_t)item * S * DT_STRIDE;
 
     if (tid < 4) tb[LY::CNT + tid] = 0.f;
-    for (int e = tid; e < L * LY::YMC; e += 256) tb[LY::YM + e] = 0.f;      // (the output map's non-zero entries are written after the barrier below)
+    for (int e = tid; e < 2 * L * LY::YMC; e += 256) tb[LY::YM + e] = 0.f;  // (the output maps' non-zero entries are written after the barrier below)
     if (tid < 3 * S) {   // thread = (section k, control dir): values + one Jacobian column each
         const int k = tid / 3, dir = tid % 3;
         double c5[5], dc5[5] = {0, 0, 0, 0, 0}, a0 = 1.0;
@@ -325,6 +331,27 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             if (ex == 0) hsh[n] = (float)u;                        // h[n]: spread over the n-th sub-diagonal after the barrier below
             else tb[LY::YM + n * LY::YMC + L + c0] = (float)u;
         }
+    } else if (tid >= 192 && tid < 192 + S2) {
+        // Wave 3: the adjoint cascade's zero-input response per unit adjoint state (LY::YMA's state half): component c of the state that
+        // enters the chunk from above (adjoint section i = c / 2 <-> forward section S - 1 - i), samples L - 1 down to 0
+        const int c0 = tid - 192;
+        double l1[S], l2[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) { l1[i] = (c0 == 2 * i) ? 1.0 : 0.0; l2[i] = (c0 == 2 * i + 1) ? 1.0 : 0.0; }
+        for (int n = L - 1; n >= 0; --n) {
+            double g = 0.0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const int k = S - 1 - i;
+                const double sg = sec[k][0], om = sec[k][1], kom = sec[k][2], g1 = sec[k][3], g2 = sec[k][4], d = sec[k][5];
+                const double o = d * g + l1[i];
+                const double t1 = sg * l1[i] + om * l2[i] + g1 * g;
+                l2[i] = -kom * l1[i] + sg * l2[i] + g2 * g;
+                l1[i] = t1;
+                g = o;
+            }
+            tb[LY::YMA + n * LY::YMC + L + c0] = (float)g;
+        }
     } else if (tid < 128) {
         const int l = tid - 64;
         double (*src)[NN] = T1;
@@ -377,6 +404,8 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     for (int e = tid; e < L * L; e += 256) {            // output map, input half: T[n][j] = h[n - j] (the upper triangle stays zero)
         const int n = e / L, j = e % L;
         if (j <= n) tb[LY::YM + n * LY::YMC + j] = hsh[n - j];
+        else tb[LY::YMA + n * LY::YMC + j] = hsh[j - n];
+        if (j == n) tb[LY::YMA + n * LY::YMC + j] = hsh[0];
     }
     // chunk tables: forward GT[k][L-1-m] = v_m[2k..2k+1] ; adjoint (natural order) GAT[i][m] = v_m[2i..2i+1]
     for (int e = tid; e < 2 * L * S2; e += 256) {
@@ -722,6 +751,8 @@ __device__ __forceinline__ void finalize_section(const double* __restrict__ dtab
     }
     finish_section(dtab, tab_bcast, acc, B, S, mode, gout, item, k, fast);
 }
+__device__ __forceinline__ void emit_section_grads(const double* __restrict__ d, const double (&g5)[5], int B, int S, int mode,
+                                                   float* __restrict__ gout, int item, int k);
 // acc: the five sums of section k of the item over all its rows -> its gradients
 __device__ __forceinline__ void finish_section(const double* __restrict__ dtab, int tab_bcast, const double (&acc)[5], int B, int S, int mode,
                                                float* __restrict__ gout, int item, int k, int fast) {
@@ -755,6 +786,11 @@ __device__ __forceinline__ void finish_section(const double* __restrict__ dtab, 
     }
     const double iom = 1.0 / d[DT_OM];
     const double g5[5] = {lag[0] * iom, lag[1] * iom, lag[2] * iom, -lag[3] * iom, -lag[4] * iom};
+    emit_section_grads(d, g5, B, S, mode, gout, item, k);
+}
+// g5 = dL/d(b0, b1, b2, a1, a2) of section k of the item (normalised coefficients) -> the requested gradients (mode as in dasp_sos_grad_finalize)
+__device__ __forceinline__ void emit_section_grads(const double* __restrict__ d, const double (&g5)[5], int B, int S, int mode,
+                                                   float* __restrict__ gout, int item, int k) {
     const int idx = item * S + k;
     if (mode == 0) {
         const double a0 = d[DT_A0];
@@ -1675,6 +1711,359 @@ sos_chain_kernel(const double* __restrict__ segtab, int tab_bcast, int C, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward by Gram matrix (round 4; one workgroup per row, coefficient gradients wanted). No recomputation of the cascade at all.
+// Within a chunk every signal of the cascade is a LINEAR function of u = (the chunk's L inputs x, its 2S forward start-state components)
+// and every adjoint signal a linear function of v = (the chunk's L adjoint inputs gy, the 2S components of the adjoint state that enters
+// it from above). Every correlation the coefficient gradients are made of - sum_n g_k[n] w_k[n - j], sum_n o_k[n] w_k[n - j] over all
+// samples of the row - is therefore a bilinear form in (v, u) summed over the chunks, i.e. <C, M_kj> with
+//     C = sum over chunks of v u^T          ((L + 2S) x (L + 2S): 28 x 28 for the EQ)
+// and M_kj built from the per-chunk basis responses of the item's cascade, which depend on the item's coefficients only. The kernel
+// accumulates C on the matrix cores: the contraction index of the product is the chunk, and with the tile images read row-major (lane
+// 16 k + i: entry i of chunk 4 m + k, one ds_read_b32 per step m) the A / B operands of v_mfma_f32_16x16x4_f32 are the images as they
+// are - 64 MFMAs per tile for the four 16 x 16 blocks of C (padded to 32 x 32), fp32 within the tile, folded into fp64 sums per tile
+// (the part that needs it: C's entries are sums over the whole row of products of O(1) signals, and the gradients are differences of
+// nearly equal combinations of them at the low-frequency corner of the EQ's ranges). What is left per tile besides that:
+//   - the adjoint lane scan (as in sos_bwd_kernel: chunk products on the matrix cores, Kogge-Stone over the lanes, mailboxes between waves),
+//   - gx = TA gy + OA lam, the adjoint cascade's outputs as a linear map of v (LY::YMA, 32 MFMAs: the forward kernel's output path mirrored),
+//   - no forward scan: the forward chunk start states are the ones the forward kernel saved; they land by LDS-DMA directly in the
+//     [chunk][16] image the products read (the DMA's global addresses do the transposition: lane = (chunk, section pair)).
+// The 30 dependent VALU instructions per sample of sos_bwd_kernel (recomputation + adjoint + correlations) become ~112 MFMAs per tile
+// beside a VALU that only runs the scan. sos_gram_finalize_kernel turns sum-over-rows(C) into the gradients (fp64 basis responses).
+// Executable specification and error budget: oracle/chunkscan_model.py (gram_backward_row), tests/test_chunkscan_model.py.
+// gram: [row][16 registers][64 lanes] doubles - register 4 (2 bv + bu) + e of lane l = C[16 bv + 4 (l / 16) + e][16 bu + l % 16].
+__device__ __forceinline__ void gram_operands_load(const float* img, float (&R)[16], int lane) {
+    const int k = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) R[m] = img[64 * m + 16 * k + 4 * ((i >> 2) ^ (m & 3)) + (i & 3)];      // (swz_slot(4 m + k, i / 4), entry i % 4)
+}
+
+template <int S, int L, int W, int FLAGS>
+__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
+sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
+                    const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
+                    double* __restrict__ gram, int C, int N, int nt, int vec) {
+    using LY = SosLayout<S, L>;
+    static_assert(L == 16 && 2 * S <= 16, "one 16-wide block of state components");
+    constexpr bool GX = !(FLAGS & BWD_NOGX);
+    constexpr int TS = 64 * L, IMG = 64 * L, REGION = 4 * IMG;      // per wave: gy, x, states, scratch (chunk products / adjoint states / gx on its way out)
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4;
+    static_assert(REGION >= 2 * 1024, "a wave's region holds its 1024 fp64 sums at the end");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW];
+    const int lane = lane_id(), wave = wave_id();
+    const int row = blockIdx.x, nr = nt;
+    const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
+    const float* __restrict__ xr = x + (size_t)row * N;
+    const float* __restrict__ gr = gy + (size_t)row * N;
+    float* __restrict__ gxr = gx + (size_t)row * N;
+    const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;
+    float* pw_lds = lds + LDS_MB;
+    float* tbg = pw_lds + LDS_PW + wave * REGION;
+    float* tbx = tbg + IMG;
+    float* tsi = tbx + IMG;
+    float* tbo = tsi + IMG;
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
+    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
+    __syncthreads();
+    const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
+    f2 Kreg[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
+
+    const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
+                   a_s = __builtin_amdgcn_readfirstlane(lds_addr(tsi));
+    // states: image slot 64 q + lane is granule g = (lane % 4) ^ (lane / 16) of chunk 16 q + lane / 4 (swz_slot), granule = section pair;
+    // the pad granules (g >= S / 2) fetch pair 0 again: finite numbers in columns of C that nobody reads
+    const int sg_ = (lane & 3) ^ (lane >> 4), soff = ((sg_ < S / 2 ? sg_ : 0) * 64 + (lane >> 2)) * 4;
+    auto issue_dma = [&](int tt, bool full) {
+        if (full) {
+            tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
+            tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
+        }
+        const float* cs = carries + ((size_t)row * nt + tt) * (S * 128) + soff;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16<!DASP_STATES_CACHED>(cs + 64 * q, a_s + 1024 * q);
+    };
+    if (wave < nr) issue_dma(nt - 1 - wave, tile_full<L>((long)(nt - 1 - wave) * TS, N, vec));
+    int stores_in_flight = 0;
+    float Aop[4], AT[4], AO[4];
+    chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
+    if (GX) cascade_map_operands<S, L>(tb + LY::YMA, LY::YMC, AT, AO, lane);
+    double gsum[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gsum[i] = 0.0;
+
+    for (int r = wave; r < nr; r += W) {
+        const int t = nt - 1 - r;
+        int toff = 0;
+        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
+        const float* __restrict__ tbl = tb + toff;
+        const bool full = tile_full<L>((long)t * TS, N, vec);
+        WIDE_PRIO(DASP_SCAN_PRIO);
+        TRACE(16);
+        if (full && GX && stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!full) {
+            tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
+            tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
+        }
+        TRACE(17);
+        const int cl = 63 - lane;        // lane l scans chunk 63 - l (sos_bwd_kernel)
+        f4 Bg[4];
+        float Rg[16], Rx[16], Rs[16];
+        chunk_products_load(tbg, Bg, lane);
+        gram_operands_load(tbg, Rg, lane);
+        gram_operands_load(tbx, Rx, lane);
+        gram_operands_load(tsi, Rs, lane);
+        pin(Bg); pin(Rg); pin(Rx); pin(Rs);
+        if (r + W < nr) issue_dma(t - W, tile_full<L>((long)(t - W) * TS, N, vec));     // the three images are in registers now
+        TRACE(18);
+        f4 zacc[4];
+        float Z[L];
+        chunk_products_issue(Bg, Aop, zacc);
+        chunk_products_collect<L>(tbo, zacc, Z, lane, cl);
+        pin(Z); TRACE(25);
+        // the half of the tile's products that does not need the scan: (gy x) and (gy states) blocks of C, TA gy of gx - they run on the
+        // matrix cores while the VALU scans
+        f4 cacc[4], oacc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { cacc[c] = f4{0.f, 0.f, 0.f, 0.f}; oacc[c] = f4{0.f, 0.f, 0.f, 0.f}; }
+        // product number idx = 3 j + type of the 48: (gy x) step j, (gy states) step j, TA gy term j
+        auto early = [&](int idx) {
+            const int j = idx / 3, ty = idx % 3;
+            if (ty == 0) { if (!(DASP_GRAM_ABLATE & 1)) cacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rx[j], cacc[0], 0, 0, 0); }
+            else if (ty == 1) { if (!(DASP_GRAM_ABLATE & 1)) cacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rs[j], cacc[1], 0, 0, 0); }
+            else if (GX && !(DASP_GRAM_ABLATE & 2)) oacc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[j >> 2], Bg[j & 3][j >> 2], oacc[j & 3], 0, 0, 0);
+        };
+#if !DASP_GRAM_INTERLEAVE
+#pragma unroll
+        for (int idx = 0; idx < 48; ++idx) early(idx);
+#endif
+        TRACE(26);
+        // ---- adjoint chunk end states: the scan runs from the last chunk to the first = ascending lanes (chunk 63 - lane) ----
+        f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
+#if DASP_GRAM_ABLATE & 8
+#pragma unroll
+        for (int i = 0; i < S; ++i) lam[i] = f2{Z[2 * i], Z[2 * i + 1]};
+#else
+        {
+            MboxPeek pk;
+            SCAN_PRIO(DASP_SCAN_PRIO);
+            tile_scan_h<S, L>(Z, [](f2 v) { return v; }, lam,
+                tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
+                [&](int i) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * i); },
+                [&](int i, f2& K) {
+                    if (W == 1) K = Kreg[i];
+                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
+                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
+                },
+                [&](int i, f2 Kn) {
+                    if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
+                    else if (t > 0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                },
+                [&](int k, int p) {      // the 48 products above, dealt out over the 4 S hook points of the scan
+                    if (!DASP_GRAM_INTERLEAVE) return;
+                    constexpr int NPS = (48 + S - 1) / S, base = NPS / 4, extra = NPS % 4;
+                    const int start = k * NPS + p * base + (p < extra ? p : extra), cnt = base + (p < extra ? 1 : 0);
+#pragma unroll
+                    for (int i = 0; i < NPS; ++i)
+                        if (i < cnt && start + i < 48) early(start + i);
+                });
+        }
+#endif
+#if DASP_GRAM_INTERLEAVE && (DASP_GRAM_ABLATE & 8)
+#pragma unroll
+        for (int idx = 0; idx < 48; ++idx) early(idx);
+#endif
+        SCAN_PRIO(0);
+        pin(lam); TRACE(19);
+        // ---- the other half: the adjoint states as one more [chunk][16] image (components 2 i + c; zeros beyond 2S) ----
+        {
+            float sc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sc[c] = c < 2 * S ? ((c & 1) ? lam[c >> 1].y : lam[c >> 1].x) : 0.f;
+            chunks_to_lds_swz<L>(tbo, sc, cl);
+        }
+        {
+            float Rl[16];
+            gram_operands_load(tbo, Rl, lane);
+            pin(Rl); TRACE(27);
+#if !(DASP_GRAM_ABLATE & 1)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                cacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rx[m], cacc[2], 0, 0, 0);
+                cacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rs[m], cacc[3], 0, 0, 0);
+            }
+#endif
+        }
+        WIDE_PRIO(DASP_SCAN_PRIO);
+        TRACE(28);
+        if (GX) {
+            f4 Bl[4];
+            chunk_products_load(tbo, Bl, lane);
+            pin(Bl);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (!(DASP_GRAM_ABLATE & 2)) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bl[c][q], oacc[c], 0, 0, 0);
+            wave_lds_sync();              // every lane has its operands before the image is overwritten with the outputs
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(tbo + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = oacc[c];
+            wave_lds_sync();
+            if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
+            else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+            stores_in_flight = full ? L / 4 : 0;
+        }
+        TRACE(23);
+        // the tile's fp32 block sums -> the row's fp64 sums
+#pragma unroll
+        for (int b = 0; b < ((DASP_GRAM_ABLATE & 4) ? 1 : 4); ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gsum[4 * b + e] += (double)cacc[b][e];
+        TRACE(24);
+    }
+    // the W waves' sums -> one matrix per row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (LDS-DMA never targets an image after the last tile, but the regions change hands below)
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(pw_lds + LDS_PW);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave * (REGION / 2) + i * 64 + lane] = gsum[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 64 * W) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) s += red[w * (REGION / 2) + e];
+        gram[(size_t)row * 1024 + e] = s;
+    }
+}
+
+// C (summed over the item's rows) -> the gradients of the item's sections. One workgroup per item:
+//   1. waves 0 / 1: the per-chunk basis responses of the item's cascade in fp64, one thread per basis vector - FW[k][n][j] = w_k[n - 2]
+//      (the all-pole signal of section k, n = 0 .. L + 1) for u = e_j; FG / FO[k][n][j] = adjoint input / output of section k at sample n
+//      for v = e_j. Start states enter as the kernels define them: w[-2] = s2 / om, w[-1] = s1 + (sg / om) s2 (normal-form chunk start
+//      state); z1 = l1, z2 = -sg l1 + om l2 (adjoint state, transposed direct form II). Waves 2 / 3 meanwhile sum C over the rows.
+//   2. P[k][m] = C FW[k][m] for the S (L + 2) signal rows on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: D[i][j] in lane 16 (i % 4) + j,
+//      register i / 4 - not the f32 instruction's row order; tools/mfma64_probe.hip), then thread (which, k, n): the products of
+//      F[k][n] with P[k][n + 2 - j]: the lag sums sum g w[n], sum g w[n - 1], sum g w[n - 2], sum o w[n - 1], sum o w[n - 2] after a
+//      16-lane reduction over n.
+//   3. thread k: dL/d(b0, b1, b2, a1, a2) = (the three g sums, minus the two o sums) -> emit_section_grads.
+template <int S>
+__global__ void __launch_bounds__(256)
+sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const double* __restrict__ gram, int B, int C, int mode,
+                         float* __restrict__ gout) {
+    constexpr int L = 16, D = L + 2 * S, NW = L + 2, NP = S * NW, NPB = (NP + 15) / 16;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    __shared__ double Cm[32][33];                   // C[v][u], zero beyond D
+    __shared__ double FW[NP][D], FG[S][L][D], FO[S][L][D];
+    __shared__ double P[NP][33];                    // P[k (L + 2) + m][v] = sum_u C[v][u] FW[k][m][u]
+    __shared__ double lagsum[S][5];
+    const int tid = threadIdx.x, item = blockIdx.x;
+    const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
+    if (tid < 128) {
+        const int j = tid & 63, adj = tid >> 6;
+        if (j < D) {
+            double sig[L];
+#pragma unroll
+            for (int n = 0; n < L; ++n) sig[n] = (j == n) ? 1.0 : 0.0;
+            for (int i = 0; i < S; ++i) {
+                const int k = adj ? S - 1 - i : i;
+                const double* d = d0 + k * DT_STRIDE;
+                const double b0 = d[DT_B0], b1 = d[DT_B0 + 1], b2 = d[DT_B0 + 2], a1 = d[DT_B0 + 3], a2 = d[DT_B0 + 4];
+                const double sg = -0.5 * a1;
+                double om = sqrt(fabs(sg * sg - a2));
+                om = om < OM_MIN ? OM_MIN : om;
+                const double c1 = (j == L + 2 * i) ? 1.0 : 0.0, c2 = (j == L + 2 * i + 1) ? 1.0 : 0.0;   // the unit state component, if it is this section's
+                if (!adj) {
+                    double w2 = c2 / om, w1 = c1 + (sg / om) * c2;
+                    FW[k * NW][j] = w2; FW[k * NW + 1][j] = w1;
+#pragma unroll
+                    for (int n = 0; n < L; ++n) {
+                        const double w = sig[n] - a1 * w1 - a2 * w2;
+                        sig[n] = b0 * w + b1 * w1 + b2 * w2;
+                        FW[k * NW + n + 2][j] = w;
+                        w2 = w1; w1 = w;
+                    }
+                } else {
+                    double z1 = c1, z2 = -sg * c1 + om * c2;
+#pragma unroll
+                    for (int n = L - 1; n >= 0; --n) {
+                        const double g = sig[n];
+                        FG[k][n][j] = g;
+                        const double o = b0 * g + z1;
+                        z1 = b1 * g - a1 * o + z2;
+                        z2 = b2 * g - a2 * o;
+                        FO[k][n][j] = o;
+                        sig[n] = o;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int e = tid - 128; e < 1024; e += 128) {
+            const double* g0 = gram + (size_t)item * C * 1024 + e;
+            double s = 0.0;
+            for (int c = 0; c < C; ++c) s += g0[(size_t)c * 1024];
+            const int r = e >> 6, ln = e & 63, blk = r >> 2;
+            const int vi = 16 * (blk >> 1) + 4 * (ln >> 4) + (r & 3), uj = 16 * (blk & 1) + (ln & 15);
+            Cm[vi][uj] = (vi < D && uj < D) ? s : 0.0;       // (the pad rows / columns hold whatever the pad lanes of the images held)
+        }
+    }
+    __syncthreads();
+    {   // P^T (32 x NP) = C (32 x 32) FW^T (32 x NP): 2 x NPB blocks of 16 x 16, 8 steps of 4 each, dealt out over the four waves
+        const int wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+        for (int blk = wave; blk < 2 * NPB; blk += 4) {
+            const int v0 = 16 * (blk & 1), p0 = 16 * (blk >> 1);
+            const int pm = p0 + li < NP ? p0 + li : NP - 1;                  // (pad columns of the last block: any row - their results are not read)
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int u = 4 * st + lk;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[v0 + li][u], FW[pm][u < D ? u : D - 1], acc, 0, 0, 0);     // (C is zero there)
+            }
+            if (p0 + li < NP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[p0 + li][v0 + lk + 4 * r] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;
+        const bool on = tid < 2 * 16 * S;
+        double v3[3] = {0.0, 0.0, 0.0};
+        if (on) {
+            const double* F = which ? &FO[k][n][0] : &FG[k][n][0];
+            double f[D];
+#pragma unroll
+            for (int v = 0; v < D; ++v) f[v] = F[v];
+#pragma unroll
+            for (int jl = 0; jl < 3; ++jl) {
+                const double* pr = &P[k * NW + n + 2 - jl][0];
+                double a = 0.0;
+#pragma unroll
+                for (int v = 0; v < D; ++v) a += f[v] * pr[v];
+                v3[jl] = a;
+            }
+        }
+#pragma unroll
+        for (int jl = 0; jl < 3; ++jl) {        // sum over the 16 samples n = the 16 lanes of a DPP row
+            double a = v3[jl];
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+            v3[jl] = a;
+        }
+        if (on && n == 0) {
+            if (!which) { lagsum[k][0] = v3[0]; lagsum[k][1] = v3[1]; lagsum[k][2] = v3[2]; }
+            else { lagsum[k][3] = v3[1]; lagsum[k][4] = v3[2]; }
+        }
+    }
+    __syncthreads();
+    if (tid < S) {
+        const double g5[5] = {lagsum[tid][0], lagsum[tid][1], lagsum[tid][2], -lagsum[tid][3], -lagsum[tid][4]};
+        emit_section_grads(d0 + tid * DT_STRIDE, g5, B, S, mode, gout, item, tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stand-alone finalize (one thread per (item, section)): used when the table is shared by all items (tab_bcast) or when the caller
 // asks for the two steps separately; otherwise the backward kernel finalizes an item as soon as its last row is done.
 __global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
@@ -1789,6 +2178,19 @@ inline bool use_bwd8cp(int S) {
     return pick && S == 8;
 }
 
+// Backward by Gram matrix (sos_bwd_gram_kernel + sos_gram_finalize_kernel) for one workgroup per row with coefficient gradients;
+// DASP_BWD_GRAM=0 / 1 at run time overrides the build's default. The partial-sum buffer then holds one 32 x 32 fp64 matrix per row.
+#ifndef DASP_BWD_GRAM
+#define DASP_BWD_GRAM 1
+#endif
+inline bool use_bwd_gram() {
+    static const int pick = [] {
+        const char* e = getenv("DASP_BWD_GRAM");
+        return e ? (e[0] != '0') : (DASP_BWD_GRAM != 0);
+    }();
+    return pick != 0;
+}
+
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
@@ -1854,7 +2256,10 @@ long dasp_sos_table_floats(int S) {
 long dasp_sos_dtab_doubles(int S) { return (long)S * DT_STRIDE; }
 long dasp_sos_num_tiles(long N) { return (N + 64 * kL - 1) / (64 * kL); }
 long dasp_sos_carry_floats(long rows, long N, int S) { return rows * dasp_sos_num_tiles(N) * 2 * S * 64; }
-long dasp_sos_partial_floats(long rows, int S) { return rows * (kWB3 > kWB ? kWB3 : kWB) * S * 5; }
+long dasp_sos_partial_floats(long rows, int S) {
+    const long sums = rows * (kWB3 > kWB ? kWB3 : kWB) * S * 5, gram = rows * 2048;     // (one 32 x 32 fp64 matrix per row: sos_bwd_gram_kernel)
+    return sums > gram ? sums : gram;
+}
 
 // sos: (Bs, S, 6) fp32 rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Builds tables for Bs items.
 int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, void* stream) {
@@ -1935,6 +2340,20 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_sos_num_tiles(N);
     const int vec = (N % 4 == 0) && aligned16(gy) && (!x || aligned16(x)) && (!gx || aligned16(gx));
+    if (use_bwd_gram() && !(flags & BWD_NOGC)) {
+        if (!aligned16(partials)) return DASP_ERR_ARG;
+        const int bc = Bs == 1 && B != 1;
+        return dispatch_S(S, [&](auto s) {
+            constexpr int SS = decltype(s)::value;
+            const dim3 g(B * C), b(64 * kWB);
+            hipStream_t st = (hipStream_t)stream;
+            if (flags & BWD_NOGX)
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, reinterpret_cast<double*>(partials), C, (int)N, nt, vec);
+            else
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, reinterpret_cast<double*>(partials), C, (int)N, nt, vec);
+            return check_launch();
+        });
+    }
     if (use_bwd3w(S, designed) && !(flags & BWD_NOGC)) {
         const dim3 g(B * C), b(64 * kWB3);
         hipStream_t st = (hipStream_t)stream;
@@ -1973,10 +2392,18 @@ int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float*
 
 // mode 0: gout (B,S,6) = dL/dsos ; mode 1: gout (B,S,3) = dL/d(gain_db, cutoff_freq, q_factor); mode 2: the same as (3S, B) rows.
 // segments: rows of partial sums per (row, wave) as written by the *_seg entry points (1 for the plain ones).
-int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
-                              int designed, float* gout, void* stream) {
+static int grad_finalize_impl(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
+                              int designed, float* gout, bool plain, void* stream) {
     if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
         return DASP_ERR_ARG;
+    if (plain && use_bwd_gram()) {      // the sums of dasp_sosfilt_backward_ex: one matrix per row
+        return dispatch_S(S, [&](auto s) {
+            constexpr int SS = decltype(s)::value;
+            hipLaunchKernelGGL((sos_gram_finalize_kernel<SS>), dim3(B), dim3(256), 0, (hipStream_t)stream, dtab, Bs == 1 && B != 1,
+                               reinterpret_cast<const double*>(partials), B, C, mode, gout);
+            return check_launch();
+        });
+    }
     const int n = B * S;
     const int wb = (segments == 1 && use_bwd3w(S, designed) ? kWB3 : kWB) * segments;      // rows of sums per signal row: the waves of the kernel that wrote them
     if (C * wb > 16)      // many rows of sums per item (segmented rows): one wave per (item, section)
@@ -1986,6 +2413,11 @@ int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials,
         hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
                            Bs == 1 && B != 1, partials, B, C, S, wb, mode, gout, designed ? 1 : 0);
     return check_launch();
+}
+
+int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
+                              int designed, float* gout, void* stream) {
+    return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, designed, gout, segments == 1, stream);
 }
 
 int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S, int mode,
@@ -2143,7 +2575,7 @@ int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, co
 // dasp_sos_grad_finalize for partial sums produced by dasp_sosfilt_backward_seg with `segments` segments per row
 int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
                                float* gout, void* stream) {
-    return dasp_sos_grad_finalize_ex(dtab, Bs, partials, B, C, S, segments, mode, 0, gout, stream);
+    return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, 0, gout, false, stream);
 }
 
 // ---- one call per direction for functional.parametric_eq (functional.py:118-272) ------------------------------------------------------
@@ -2214,7 +2646,7 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
     const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, fuse ? dtab : nullptr, mode,
                                              fuse ? gout : nullptr, stream);
     if (rc != DASP_OK || !partials || fuse) return rc;
-    return dasp_sos_grad_finalize_ex(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, 1, gout, stream);
+    return grad_finalize_impl(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, 1, gout, false, stream);
 }
 
 // ---- signal.biquad (dasp_pytorch/signal.py:242-306) ------------------------------------------------------------------------------

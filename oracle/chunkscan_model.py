@@ -337,6 +337,81 @@ def _normalise_grads(r, acc, fast=False):
     return gb, ga
 
 
+# ---- backward by Gram matrix (csrc/sosfilt.hip sos_bwd_gram_kernel / sos_gram_finalize_kernel) ------------------------------------------
+# Inside a chunk every forward signal of the cascade is a linear function of u = (the chunk's L inputs, its 2S start-state components)
+# and every adjoint signal a linear function of v = (the chunk's L adjoint inputs, the 2S components of the adjoint state entering from
+# above), so each correlation sum_n g_k[n] w_k[n - j], sum_n o_k[n] w_k[n - j] over the row is <C, M> with C = sum over chunks of v u^T
+# ((L + 2S) x (L + 2S)) and M built from the per-chunk basis responses of the cascade. The kernel accumulates C (fp32 products on the
+# matrix cores inside a tile, fp64 across tiles), takes gx from the linear map of v, and the finalize step does the rest in fp64.
+
+def chunk_basis_responses(r, L):
+    """FW[k][n] (n = 0..L+1): w_k[n - 2] as a row vector over u = [x (L); start states (2S)];  FG[k][n], FO[k][n]: adjoint input /
+    output of section k at sample n as row vectors over v = [gy (L); adjoint states (2S, adjoint section order i <-> k = S-1-i)].
+    Start states enter as the kernels define them: w[-2] = s2 / om, w[-1] = s1 + (sg / om) s2;  z1 = l1, z2 = -sg l1 + om l2."""
+    S = len(r["sg"]); D = L + 2 * S
+    FW = np.zeros((S, L + 2, D)); FG = np.zeros((S, L, D)); FO = np.zeros((S, L, D))
+    for j in range(D):
+        e = np.zeros(D); e[j] = 1.0
+        sig = e[:L].copy()
+        for k in range(S):
+            b0, b1, b2 = r["b"][k]; a1, a2 = r["a"][k]
+            s1, s2 = e[L + 2 * k], e[L + 2 * k + 1]
+            w2 = s2 / r["om"][k]; w1 = s1 + (r["sg"][k] / r["om"][k]) * s2
+            FW[k, 0, j] = w2; FW[k, 1, j] = w1
+            for n in range(L):
+                w = sig[n] - a1 * w1 - a2 * w2
+                sig[n] = b0 * w + b1 * w1 + b2 * w2
+                FW[k, n + 2, j] = w
+                w2, w1 = w1, w
+        g = e[:L].copy()
+        for i in range(S):
+            k = S - 1 - i
+            b0, b1, b2 = r["b"][k]; a1, a2 = r["a"][k]
+            l1, l2 = e[L + 2 * i], e[L + 2 * i + 1]
+            z1 = l1; z2 = -r["sg"][k] * l1 + r["om"][k] * l2
+            for n in range(L - 1, -1, -1):
+                FG[k, n, j] = g[n]
+                out = b0 * g[n] + z1
+                z1 = b1 * g[n] - a1 * out + z2
+                z2 = b2 * g[n] - a2 * out
+                FO[k, n, j] = out
+                g[n] = out
+    return FW, FG, FO
+
+
+def gram_backward_row(r, x, gy, carries, L, fp32_tiles=False):
+    """backward_row's results (gx, gb, ga) the way the Gram-matrix kernels compute them. fp32_tiles: round the scanned states to fp32 and
+    form each tile's 64-chunk contribution to C in fp32 (what the matrix cores do), to measure what that costs."""
+    fs = _sections_fwd(r); ads = _sections_adj(r); S = len(fs)
+    G, M, P = chunk_tables(fs, L); Ga, Ma, Pa = chunk_tables(ads, L)
+    TS = WAVE * L; N = len(x); nt = (N + TS - 1) // TS; D = L + 2 * S
+    xp = np.zeros(nt * TS); xp[:N] = x
+    gp = np.zeros(nt * TS); gp[:N] = gy
+    FW, FG, FO = chunk_basis_responses(r, L)
+    # gx of a chunk = (adjoint output of the last adjoint section = forward section 0) as a linear map of v: LY::YMA in the kernels
+    OUT = FO[0]                                             # (L, D)
+    Cm = np.zeros((D, D)); acarry = np.zeros(2 * S); gx = np.zeros(nt * TS)
+    for t in range(nt - 1, -1, -1):
+        X = xp[t * TS:(t + 1) * TS].reshape(WAVE, L); GY = gp[t * TS:(t + 1) * TS].reshape(WAVE, L)
+        astart_r, acarry = tile_scan(GY[::-1, ::-1] @ Ga.T, Ma, Pa, acarry)
+        start, _ = tile_scan(X @ G.T, M, P, carries[t])       # (the kernel reads these from what the forward pass saved)
+        lam = astart_r[::-1]
+        if fp32_tiles:
+            start = start.astype(np.float32).astype(np.float64); lam = lam.astype(np.float32).astype(np.float64)
+        U = np.concatenate([X, start], 1); V = np.concatenate([GY, lam], 1)
+        Cm += (V.astype(np.float32).T @ U.astype(np.float32)).astype(np.float64) if fp32_tiles else V.T @ U
+        gx[t * TS:(t + 1) * TS] = (V @ OUT.T).reshape(-1)
+    gb = np.zeros((S, 3)); ga = np.zeros((S, 3))
+    for k in range(S):
+        Pk = FW[k] @ Cm.T                                    # P[m] = C FW[k][m]  (the finalize kernel's matrix product)
+        for j in range(3):
+            gb[k, j] = sum(FG[k, n] @ Pk[n + 2 - j] for n in range(L))
+        for j in (1, 2):
+            ga[k, j] = -sum(FO[k, n] @ Pk[n + 2 - j] for n in range(L))
+        ga[k, 0] = -(np.sum(gb[k] * r["b"][k]) + np.sum(ga[k, 1:] * r["a"][k]))
+    return gx[:N], gb, ga
+
+
 # ---- segmented scheme for few rows (DESIGN.md section 7: a row is one workgroup, so B*C < 512 rows leave CUs idle) --------------------
 # Every row is cut into `segments` runs of tiles that are processed independently:
 #   1. a scan-only pass over each segment from a zero state gives z(g), the cascade state its input alone leaves behind;

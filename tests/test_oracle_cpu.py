@@ -234,6 +234,33 @@ def test_chunkscan_model_designed_cascade_variant():
             assert np.abs(got - gsos_ref[b]).max() < 2e-7 * np.abs(gsos_ref[b]).max(), (b, fast)
 
 
+def test_chunkscan_model_gram_backward():
+    """The Gram-matrix backward (sos_bwd_gram_kernel / sos_gram_finalize_kernel; oracle/chunkscan_model.py gram_backward_row): in fp64 it
+    IS backward_row (same gx and coefficient gradients to rounding), against the oracle's VJP of the reference algorithm too; with the
+    matrix cores' arithmetic (fp32 states, fp32 products and sums inside a tile, fp64 across tiles) the coefficient gradients stay
+    within 2e-6 of the largest one - also on the low-frequency corner of the EQ's ranges, where they are differences of nearly equal sums."""
+    rng = np.random.default_rng(23)
+    p = np.array([[12, 300, 0.3, -15, 500, 2.0, 9, 2000, 3, -6, 8000, 1, 4, 12000, 0.7, -20, 4000, 6],
+                  [20, 20, 0.1, -20, 80, 0.1, -3, 8000, 0.1, 6, 12000, 6, -9, 21050, 0.3, 20, 21050, 0.1]], dtype=np.float64)
+    N = 16384 + 4099
+    x, w = rng.standard_normal((2, 1, N)), rng.standard_normal((2, 1, N))
+    sos = orc.peq_sos(p, 44100)
+    gsos_ref, gx_ref = orc.sosfilt_via_fsm_vjp(sos[:1], x[:1], w[:1])
+    for b in range(2):
+        r = cm.realize(sos[b])
+        _, car = cm.forward_row(r, x[b, 0], 16)
+        gx0, gb0, ga0 = cm.backward_row(r, x[b, 0], w[b, 0], car, 16)
+        gx, gb, ga = cm.gram_backward_row(r, x[b, 0], w[b, 0], car, 16)
+        sc = max(np.abs(gb0).max(), np.abs(ga0).max())
+        assert np.abs(gx - gx0).max() < 1e-11 * np.abs(gx0).max()
+        assert np.abs(gb - gb0).max() < 1e-10 * sc and np.abs(ga - ga0).max() < 1e-10 * sc
+        if b == 0:      # (the second parameter set rings for longer than N: the reference's circular method is not alias-free there)
+            assert np.abs(gx - gx_ref[0, 0]).max() < 1e-9 * np.abs(gx_ref[0, 0]).max()
+            assert np.abs(np.concatenate([gb, ga], 1) - gsos_ref[0]).max() < 2e-7 * np.abs(gsos_ref[0]).max()
+        _, gb32, ga32 = cm.gram_backward_row(r, x[b, 0], w[b, 0], car, 16, fp32_tiles=True)
+        assert np.abs(gb32 - gb0).max() < 2e-6 * sc and np.abs(ga32 - ga0).max() < 2e-6 * sc, b
+
+
 # ---- round 2 goldens: coefficient design, first-order / FIR filter boundary, normalised-parameter API ------------------------------------
 
 BIQUAD_TYPES = ["peaking", "low_shelf", "high_shelf", "low_pass", "high_pass"]
