@@ -470,11 +470,11 @@ def profiled_kernel_ms():
         try:
             out = {}
             for r in csv.DictReader(open(path)):
-                for key in ("sos_bwd_kernel<6", "sos_fwd_kernel<6"):
-                    if key in r["Name"] and key not in out:
+                for key, names in (("bwd", ("sos_bwd_gram_kernel<6", "sos_bwd_kernel<6")), ("fwd", ("sos_fwd_kernel<6",))):
+                    if any(n in r["Name"] for n in names) and key not in out:
                         out[key] = float(r["AverageNs"]) / 1e6
             if len(out) == 2:
-                return {"bwd": out["sos_bwd_kernel<6"], "fwd": out["sos_fwd_kernel<6"], "file": os.path.relpath(path, ROOT)}
+                return {"bwd": out["bwd"], "fwd": out["fwd"], "file": os.path.relpath(path, ROOT)}
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -731,7 +731,7 @@ def main():
             "launch_ms_per_step": {k: per_step(v) for k, v in med.items()},
             "block_ms_per_step": {k: {"min": per_step(min(v)), "median": per_step(float(np.median(v))), "max": per_step(max(v))}
                                   for k, v in blocks.items()},
-            "roofline": dict(roof(12, t_bwd, "bwd"), kernel="sos_bwd_kernel<6> (designed-cascade variant)", ms=round(t_bwd * 1e3, 4),
+            "roofline": dict(roof(12, t_bwd, "bwd"), kernel="sos_bwd_gram_kernel<6>", ms=round(t_bwd * 1e3, 4),
                              algorithmic_bytes=12 * units),
             "roofline_fwd": dict(roof(8, t_fwd, "fwd"), kernel="sos_fwd_kernel<6>", ms=round(t_fwd * 1e3, 4), algorithmic_bytes=8 * units),
             "roofline_fwd_bwd": dict(roof(20, t_fwd + t_bwd, "both"), ms=round((t_fwd + t_bwd) * 1e3, 4), algorithmic_bytes=20 * units),

@@ -147,6 +147,22 @@ __device__ __forceinline__ void glds16(const float* src, unsigned dst_uniform) {
                      : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
 #endif
 }
+// Four consecutive KiB of one image with one M0 set-up: the instruction's offset field moves the global address and the LDS address
+// together (LDS address = M0 base + offset + 16 lane), so instruction m lands 1 KiB further on both sides.
+template <bool STREAM = true>
+__device__ __forceinline__ void glds16x4(const float* src, unsigned dst_uniform) {
+    unsigned keep;
+    if (STREAM)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" DASP_GLDS_POLICY
+                     "\n\tglobal_load_lds_dwordx4 %1, off offset:1024" DASP_GLDS_POLICY "\n\tglobal_load_lds_dwordx4 %1, off offset:2048" DASP_GLDS_POLICY
+                     "\n\tglobal_load_lds_dwordx4 %1, off offset:3072" DASP_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                     "\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048"
+                     "\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+}
 __device__ __forceinline__ void glds4(const float* src, unsigned dst_uniform) {
 #if DASP_GLDS_CLOBBER
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst_uniform) : "memory", "m0");
@@ -190,9 +206,17 @@ __device__ __forceinline__ void chunks_to_lds_swz(float* img, const float (&X)[L
     wave_lds_sync();
 }
 // full tile, global -> image by LDS-DMA (4 wave instructions of 1 KiB, every lane active)
+#ifndef DASP_DMA_X4
+#define DASP_DMA_X4 1   // the four instructions of an image as one asm block: one M0 set-up, one lane address, instruction offsets 0 .. 3 KiB (glds16x4;
+                        // the swizzle of slot 64 m + lane does not depend on m). Backward kernel, same box: 0.218 -> 0.215 ms (profiles/r04/gram_bwd_variants.log)
+#endif
 __device__ __forceinline__ void tile_dma_issue_swz(const float* __restrict__ tile, unsigned lds_bytes, int lane) {
+#if DASP_DMA_X4
+    glds16x4(tile + 4 * swz_granule_of_slot(lane), lds_bytes);
+#else
 #pragma unroll
     for (int m = 0; m < 4; ++m) glds16(tile + 4 * swz_granule_of_slot(64 * m + lane), lds_bytes + 1024 * m);
+#endif
 }
 __device__ __forceinline__ void tile_swz_to_global_full(const float* img, float* __restrict__ row, long base, bool stream, int lane) {
 #pragma unroll

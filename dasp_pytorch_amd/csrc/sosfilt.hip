@@ -160,6 +160,9 @@ constexpr double OM_MIN = 1e-5;
 #ifndef DASP_FWD_DIRECT
 #define DASP_FWD_DIRECT 0
 #endif
+#ifndef DASP_GRAM_ZVALU
+#define DASP_GRAM_ZVALU 1      // sos_bwd_gram_kernel: the chunk table products of the adjoint scan on the VALU (SGPR table) instead of the matrix cores
+#endif
 #ifndef DASP_GRAM_INTERLEAVE
 #define DASP_GRAM_INTERLEAVE 1 // sos_bwd_gram_kernel: the products that do not depend on the adjoint scan are issued from inside it (tile_scan_h)
 #endif
@@ -1814,25 +1817,62 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         gram_operands_load(tbg, Rg, lane);
         gram_operands_load(tbx, Rx, lane);
         gram_operands_load(tsi, Rs, lane);
+#if DASP_GRAM_ZVALU
+        float GYc[L];
+        lds_to_chunks_swz<L>(tbg, GYc, cl);
+        pin(GYc);
+#endif
         pin(Bg); pin(Rg); pin(Rx); pin(Rs);
         if (r + W < nr) issue_dma(t - W, tile_full<L>((long)(t - W) * TS, N, vec));     // the three images are in registers now
         TRACE(18);
-        f4 zacc[4];
         float Z[L];
+#if DASP_GRAM_ZVALU
+        {   // zero-state chunk end states on the VALU (packed FMAs against the wave-uniform table in SGPRs, one section's 16 entries at a time,
+            // the next section's loads in flight meanwhile): the 16 matrix-core products this replaces queued behind the other wave's bulk
+            // products and came back through an LDS round trip - the longest phase of the tile after the scan
+            f2 G[L];
+#pragma unroll
+            for (int n = 0; n < L; ++n) G[n] = TLD2(tbl + LY::GAT + 2 * n);
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < L; n += 2) {
+                    const f2 xy = f2{GYc[n], GYc[n + 1]};
+                    z0 = fma2_bcast<0>(G[n], xy, z0);
+                    z1 = fma2_bcast<1>(G[n + 1], xy, z1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < S) {
+#pragma unroll
+                    for (int n = 0; n < L; ++n) G[n] = TLD2(tbl + LY::GAT + ((k + 1) * L + n) * 2);
+                }
+                const f2 z = z0 + z1;
+                Z[2 * k] = z.x; Z[2 * k + 1] = z.y;
+            }
+#pragma unroll
+            for (int c = 2 * S; c < L; ++c) Z[c] = 0.f;
+        }
+#else
+        f4 zacc[4];
         chunk_products_issue(Bg, Aop, zacc);
         chunk_products_collect<L>(tbo, zacc, Z, lane, cl);
+#endif
         pin(Z); TRACE(25);
         // the half of the tile's products that does not need the scan: (gy x) and (gy states) blocks of C, TA gy of gx - they run on the
         // matrix cores while the VALU scans
         f4 cacc[4], oacc[4];
+        const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};       // (the first product of every accumulator takes the constant: no zeroing moves)
+#if DASP_GRAM_ABLATE
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { cacc[c] = f4{0.f, 0.f, 0.f, 0.f}; oacc[c] = f4{0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c < 4; ++c) { cacc[c] = zero4; oacc[c] = zero4; }
+#endif
         // product number idx = 3 j + type of the 48: (gy x) step j, (gy states) step j, TA gy term j
         auto early = [&](int idx) {
             const int j = idx / 3, ty = idx % 3;
-            if (ty == 0) { if (!(DASP_GRAM_ABLATE & 1)) cacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rx[j], cacc[0], 0, 0, 0); }
-            else if (ty == 1) { if (!(DASP_GRAM_ABLATE & 1)) cacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rs[j], cacc[1], 0, 0, 0); }
-            else if (GX && !(DASP_GRAM_ABLATE & 2)) oacc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[j >> 2], Bg[j & 3][j >> 2], oacc[j & 3], 0, 0, 0);
+            if (ty == 0) { if (!(DASP_GRAM_ABLATE & 1)) cacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rx[j], j ? cacc[0] : zero4, 0, 0, 0); }
+            else if (ty == 1) { if (!(DASP_GRAM_ABLATE & 1)) cacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rs[j], j ? cacc[1] : zero4, 0, 0, 0); }
+            else if (GX && !(DASP_GRAM_ABLATE & 2)) oacc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[j >> 2], Bg[j & 3][j >> 2], (j >> 2) ? oacc[j & 3] : zero4, 0, 0, 0);
         };
 #if !DASP_GRAM_INTERLEAVE
 #pragma unroll
@@ -1890,8 +1930,8 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 #if !(DASP_GRAM_ABLATE & 1)
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                cacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rx[m], cacc[2], 0, 0, 0);
-                cacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rs[m], cacc[3], 0, 0, 0);
+                cacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rx[m], m ? cacc[2] : zero4, 0, 0, 0);
+                cacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rs[m], m ? cacc[3] : zero4, 0, 0, 0);
             }
 #endif
         }
@@ -1941,7 +1981,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 //   1. waves 0 / 1: the per-chunk basis responses of the item's cascade in fp64, one thread per basis vector - FW[k][n][j] = w_k[n - 2]
 //      (the all-pole signal of section k, n = 0 .. L + 1) for u = e_j; FG / FO[k][n][j] = adjoint input / output of section k at sample n
 //      for v = e_j. Start states enter as the kernels define them: w[-2] = s2 / om, w[-1] = s1 + (sg / om) s2 (normal-form chunk start
-//      state); z1 = l1, z2 = -sg l1 + om l2 (adjoint state, transposed direct form II). Waves 2 / 3 meanwhile sum C over the rows.
+//      state); z1 = l1, z2 = -sg l1 + om l2 (adjoint state, transposed direct form II). (Before that: all threads sum C over the rows.)
 //   2. P[k][m] = C FW[k][m] for the S (L + 2) signal rows on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: D[i][j] in lane 16 (i % 4) + j,
 //      register i / 4 - not the f32 instruction's row order; tools/mfma64_probe.hip), then thread (which, k, n): the products of
 //      F[k][n] with P[k][n + 2 - j]: the lag sums sum g w[n], sum g w[n - 1], sum g w[n - 2], sum o w[n - 1], sum o w[n - 2] after a
@@ -1957,8 +1997,34 @@ sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const d
     __shared__ double FW[NP][D], FG[S][L][D], FO[S][L][D];
     __shared__ double P[NP][33];                    // P[k (L + 2) + m][v] = sum_u C[v][u] FW[k][m][u]
     __shared__ double lagsum[S][5];
+    __shared__ double cf[S][8];                     // b0 b1 b2 a1 a2 (normalised), sg, om, 1 / om per section
     const int tid = threadIdx.x, item = blockIdx.x;
     const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
+    PTRACE(50, 0);
+    // every global read of the kernel up front and in flight together (one trip to L2 instead of one per section / per matrix entry)
+    if (tid < S) {
+        const double* d = d0 + tid * DT_STRIDE;
+        const double a1 = d[DT_B0 + 3], a2 = d[DT_B0 + 4], sg = -0.5 * a1;
+        double om = sqrt(fabs(sg * sg - a2));
+        om = om < OM_MIN ? OM_MIN : om;
+        cf[tid][0] = d[DT_B0]; cf[tid][1] = d[DT_B0 + 1]; cf[tid][2] = d[DT_B0 + 2]; cf[tid][3] = a1; cf[tid][4] = a2;
+        cf[tid][5] = sg; cf[tid][6] = om; cf[tid][7] = 1.0 / om;
+    }
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        const double* g0 = gram + (size_t)item * C * 1024 + tid;
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[q] += g0[(size_t)c * 1024 + 256 * q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 6, ln = e & 63, blk = r >> 2;
+        const int vi = 16 * (blk >> 1) + 4 * (ln >> 4) + (r & 3), uj = 16 * (blk & 1) + (ln & 15);
+        Cm[vi][uj] = (vi < D && uj < D) ? cs[q] : 0.0;       // (the pad rows / columns hold whatever the pad lanes of the images held)
+    }
+    __syncthreads();
+    PTRACE(51, 0);
     if (tid < 128) {
         const int j = tid & 63, adj = tid >> 6;
         if (j < D) {
@@ -1967,19 +2033,15 @@ sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const d
             for (int n = 0; n < L; ++n) sig[n] = (j == n) ? 1.0 : 0.0;
             for (int i = 0; i < S; ++i) {
                 const int k = adj ? S - 1 - i : i;
-                const double* d = d0 + k * DT_STRIDE;
-                const double b0 = d[DT_B0], b1 = d[DT_B0 + 1], b2 = d[DT_B0 + 2], a1 = d[DT_B0 + 3], a2 = d[DT_B0 + 4];
-                const double sg = -0.5 * a1;
-                double om = sqrt(fabs(sg * sg - a2));
-                om = om < OM_MIN ? OM_MIN : om;
+                const double b0 = cf[k][0], b1 = cf[k][1], b2 = cf[k][2], a1 = cf[k][3], a2 = cf[k][4], sg = cf[k][5], om = cf[k][6], iom = cf[k][7];
                 const double c1 = (j == L + 2 * i) ? 1.0 : 0.0, c2 = (j == L + 2 * i + 1) ? 1.0 : 0.0;   // the unit state component, if it is this section's
                 if (!adj) {
-                    double w2 = c2 / om, w1 = c1 + (sg / om) * c2;
+                    double w2 = c2 * iom, w1 = c1 + sg * iom * c2;
                     FW[k * NW][j] = w2; FW[k * NW + 1][j] = w1;
 #pragma unroll
                     for (int n = 0; n < L; ++n) {
-                        const double w = sig[n] - a1 * w1 - a2 * w2;
-                        sig[n] = b0 * w + b1 * w1 + b2 * w2;
+                        const double w = fma(-a1, w1, fma(-a2, w2, sig[n]));      // (one FMA on the recurrence's dependent chain)
+                        sig[n] = fma(b0, w, fma(b1, w1, b2 * w2));
                         FW[k * NW + n + 2][j] = w;
                         w2 = w1; w1 = w;
                     }
@@ -1989,44 +2051,48 @@ sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const d
                     for (int n = L - 1; n >= 0; --n) {
                         const double g = sig[n];
                         FG[k][n][j] = g;
-                        const double o = b0 * g + z1;
-                        z1 = b1 * g - a1 * o + z2;
-                        z2 = b2 * g - a2 * o;
+                        const double o = fma(b0, g, z1);
+                        z1 = fma(-a1, o, fma(b1, g, z2));
+                        z2 = fma(-a2, o, b2 * g);
                         FO[k][n][j] = o;
                         sig[n] = o;
                     }
                 }
             }
         }
-    } else {
-        for (int e = tid - 128; e < 1024; e += 128) {
-            const double* g0 = gram + (size_t)item * C * 1024 + e;
-            double s = 0.0;
-            for (int c = 0; c < C; ++c) s += g0[(size_t)c * 1024];
-            const int r = e >> 6, ln = e & 63, blk = r >> 2;
-            const int vi = 16 * (blk >> 1) + 4 * (ln >> 4) + (r & 3), uj = 16 * (blk & 1) + (ln & 15);
-            Cm[vi][uj] = (vi < D && uj < D) ? s : 0.0;       // (the pad rows / columns hold whatever the pad lanes of the images held)
-        }
     }
+    PTRACE(52, 0);
     __syncthreads();
+    PTRACE(53, 0);
     {   // P^T (32 x NP) = C (32 x 32) FW^T (32 x NP): 2 x NPB blocks of 16 x 16, 8 steps of 4 each, dealt out over the four waves
         const int wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
-        for (int blk = wave; blk < 2 * NPB; blk += 4) {
-            const int v0 = 16 * (blk & 1), p0 = 16 * (blk >> 1);
-            const int pm = p0 + li < NP ? p0 + li : NP - 1;                  // (pad columns of the last block: any row - their results are not read)
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
+        constexpr int NB = (2 * NPB + 3) / 4;            // blocks per wave; their accumulator chains run side by side
+        d4 acc[NB];
+        int pmr[NB];
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const int u = 4 * st + lk;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[v0 + li][u], FW[pm][u < D ? u : D - 1], acc, 0, 0, 0);     // (C is zero there)
-            }
-            if (p0 + li < NP) {
+        for (int q = 0; q < NB; ++q) {
+            const int p0 = 16 * ((wave + 4 * q) >> 1);
+            acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+            pmr[q] = p0 + li < NP ? p0 + li : NP - 1;    // (pad columns of the last block and blocks past the end: any row - their results are not stored)
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) P[p0 + li][v0 + lk + 4 * r] = acc[r];
+        for (int st = 0; st < 8; ++st) {
+            const int u = 4 * st + lk, uu = u < D ? u : D - 1;           // (C is zero beyond D)
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * ((wave + 4 * q) & 1) + li][u], FW[pmr[q]][uu], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int blk = wave + 4 * q, v0 = 16 * (blk & 1), p0 = 16 * (blk >> 1);
+            if (blk < 2 * NPB && p0 + li < NP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[p0 + li][v0 + lk + 4 * r] = acc[q][r];
             }
         }
     }
     __syncthreads();
+    PTRACE(54, 0);
     {
         const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;
         const bool on = tid < 2 * 16 * S;
@@ -2039,10 +2105,10 @@ sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const d
 #pragma unroll
             for (int jl = 0; jl < 3; ++jl) {
                 const double* pr = &P[k * NW + n + 2 - jl][0];
-                double a = 0.0;
+                double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                for (int v = 0; v < D; ++v) a += f[v] * pr[v];
-                v3[jl] = a;
+                for (int v = 0; v < D; v += 2) { a0 = fma(f[v], pr[v], a0); a1 = fma(f[v + 1], pr[v + 1], a1); }
+                v3[jl] = a0 + a1;
             }
         }
 #pragma unroll
@@ -2057,10 +2123,12 @@ sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const d
         }
     }
     __syncthreads();
+    PTRACE(55, 0);
     if (tid < S) {
         const double g5[5] = {lagsum[tid][0], lagsum[tid][1], lagsum[tid][2], -lagsum[tid][3], -lagsum[tid][4]};
         emit_section_grads(d0 + tid * DT_STRIDE, g5, B, S, mode, gout, item, tid);
     }
+    PTRACE(56, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,7 +38,8 @@ long dasp_sos_table_floats(int S);                /* fp32 table size per filter 
 long dasp_sos_dtab_doubles(int S);                /* fp64 side-table size per filter set */
 long dasp_sos_num_tiles(long N);
 long dasp_sos_carry_floats(long rows, long N, int S);   /* rows = B*C */
-long dasp_sos_partial_floats(long rows, int S);
+long dasp_sos_partial_floats(long rows, int S);          /* scratch between the backward kernel and the finalize step (16-byte aligned; opaque:
+                                                          * one 32 x 32 fp64 Gram matrix per row, or per-wave correlation sums for segmented rows) */
 
 /* sos: (Bs, S, 6) fp32, rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Fills tab / dtab. */
 int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, void* stream);
@@ -58,7 +59,8 @@ int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* ty
 int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries,
                          int B, int C, long N, int S, void* stream);
 
-/* gx = adjoint cascade(gy); partials receives the per-wave coefficient correlations. */
+/* gx = adjoint cascade(gy); partials receives what dasp_sos_grad_finalize turns into the coefficient gradients (per row: the matrix
+ * sum over chunks of [gy chunk; adjoint state] [x chunk; forward state]^T, accumulated on the matrix cores: csrc/sosfilt.hip sos_bwd_gram_kernel). */
 int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float* gy,
                           const float* carries, float* gx, float* partials,
                           int B, int C, long N, int S, void* stream);

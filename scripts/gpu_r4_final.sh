@@ -17,6 +17,8 @@ timeout 600 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.er
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv; rm -rf $out/rprof
 ( cd /tmp && DASP_RV_NOISE=generated rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/scripts/reverb_time.py 128 2 262144 > /dev/null 2>> $GRAFT_REPO_ROOT/$out/rprof.err )
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/reverb_kernel_stats.csv; rm -rf $out/rprof
+for g in 1 0; do echo "# DASP_BWD_GRAM=$g"; DASP_BWD_GRAM=$g timeout 300 python scripts/sections_sweep.py 2>/dev/null | grep -E "S [78] split \\((8|7),\\)"; done > $out/sections_per_call.log
+./tools/ubench5 > $out/mfma_valu_overlap.log 2>&1
 python - <<'PY'
 import json
 for f in ("bench_driver_args", "bench", "bench_under_rocprof"):

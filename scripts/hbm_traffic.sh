@@ -21,7 +21,8 @@ def counter(name):
     vals = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            k = "sos_fwd_kernel" if "sos_fwd_kernel" in r["Kernel_Name"] else "sos_bwd_kernel" if "sos_bwd_kernel" in r["Kernel_Name"] else None
+            n = r["Kernel_Name"]
+            k = "sos_fwd_kernel" if "sos_fwd_kernel" in n else "sos_bwd_kernel" if ("sos_bwd_gram_kernel" in n or "sos_bwd_kernel" in n) else None      # (the backward kernel of the build: Gram-matrix or recomputation)
             if k:
                 vals.setdefault(k, []).append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in vals.items()}      # second half of the launches (warm)
@@ -30,7 +31,7 @@ sys.path.insert(0, os.getcwd())
 from dasp_pytorch_amd.csrc.build import kernel_source_hash
 units = 256 * 2 * 131072
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes with --kernel-trace only, KB units) on tools/sosbench 256 2 131072 "
-               "(DASP_PEQ=1 DASP_DESIGNED=1: the designed-cascade backward kernel), averaged over the second half of 42 launches; FETCH_SIZE doubled "
+               "(DASP_PEQ=1 DASP_DESIGNED=1; backward = sos_bwd_gram_kernel), averaged over the second half of 42 launches; FETCH_SIZE doubled "
                "per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE as is. scripts/hbm_traffic.sh",
        "shape": [256, 2, 131072], "kernel_source_hash": kernel_source_hash()}
 for k, alg in (("sos_fwd_kernel", 8 * units), ("sos_bwd_kernel", 12 * units)):

@@ -120,6 +120,8 @@ int main(int argc, char** argv) {
                    tr[17] - tr[16], tr[18] - tr[17], tr[25] - tr[18], tr[19] - tr[25], tr[23] - tr[19], tr[24] - tr[23], tr[24] - tr[16]);
             printf("gram bwd tile: wait %lld  operands %lld  chunk products %lld  early mfma issue %lld  adj-scan %lld  lam image %lld  late mfma issue %lld  gx out %lld  fold %lld | total %lld\n",
                    tr[17] - tr[16], tr[18] - tr[17], tr[25] - tr[18], tr[26] - tr[25], tr[19] - tr[26], tr[27] - tr[19], tr[28] - tr[27], tr[23] - tr[28], tr[24] - tr[23], tr[24] - tr[16]);
+            printf("gram finalize (cycles): loads + C %lld  experiments (thread 0) %lld  barrier %lld  P = C FW %lld  lag sums %lld  emit %lld | total %lld\n",
+                   tr[51] - tr[50], tr[52] - tr[51], tr[53] - tr[52], tr[54] - tr[53], tr[55] - tr[54], tr[56] - tr[55], tr[56] - tr[50]);
             printf("section 3: lds-issue+table+zmap+wait %lld  coupling %lld  in-row %lld  bcast %lld  carry-in %lld  carry-out+apply+shift %lld\n",
                    tr[9] - tr[8], tr[10] - tr[9], tr[11] - tr[10], tr[12] - tr[11], tr[13] - tr[12], tr[14] - tr[13]);
         }
