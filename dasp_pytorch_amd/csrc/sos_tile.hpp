@@ -241,9 +241,19 @@ __device__ __forceinline__ void chunk_products_collect(float* scratch, const f4 
 // map of its 16 inputs and its 2S start-state components, y = T x + O s0 (LY::YM: row n = (h[n], .., h[0], 0, .. | O[n][0 .. 2S), 0, ..),
 // fp64 in the prep kernel), so the per-lane recursion - 768 vector instructions per tile for six sections - is 32 v_mfma_f32_16x16x4_f32
 // with the operand geometry of the chunk products above: the B operands of T x are the input granules the chunk products already hold
-// (Bx), those of O s0 the scan's start states written as one more [chunk][16] image (granule g = components 4 g .. 4 g + 3; beyond 2S:
+// (Bx), those of O s0 the scan's start states written as one more [chunk][16] image (component c at entry state_pos(c); the other entries
 // zeros) and read back the same way, and the D registers are granules of the output image: on return `img` holds the tile's outputs in the
 // swizzled image layout (what chunks_to_lds_swz would have written). AT / AO: cascade_map_operands, once per kernel.
+// Position of state component c in the [chunk][16] state images of the matrix-core maps. The contraction slot (step q, lane group k) of a
+// 16x16x4 product is entry 4 k + q of the image row, so zero entries only save a step when they fill one q for every k: with 2S <= 12
+// the components go three to a granule (entries 4 g .. 4 g + 2, entry 4 g + 3 zero) and step q = 3 of the state products is skipped.
+template <int S> __host__ __device__ constexpr bool state_packed3() { return 2 * S <= 12; }
+template <int S> __host__ __device__ constexpr int state_pos(int c) { return state_packed3<S>() ? 4 * (c / 3) + c % 3 : c; }
+template <int S> __host__ __device__ constexpr int state_comp_at(int p) {     // component at entry p of the image row, -1 = a zero
+    return state_packed3<S>() ? ((p % 4 == 3 || 3 * (p / 4) + p % 4 >= 2 * S) ? -1 : 3 * (p / 4) + p % 4) : (p < 2 * S ? p : -1);
+}
+template <int S> __host__ __device__ constexpr int state_steps() { return state_packed3<S>() ? 3 : 4; }
+
 template <int S, int L>
 __device__ __forceinline__ void cascade_map_operands(const float* __restrict__ ym, int ymc, float (&AT)[4], float (&AO)[4], int lane) {
     static_assert(L == 16 && 2 * S <= 16, "one 16x16 output block per 16 chunks");
@@ -257,7 +267,10 @@ template <int S, int L>
 __device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[S], const f4 (&Bx)[4], const float (&AT)[4], const float (&AO)[4], int lane) {
     float sc[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) sc[c] = c < 2 * S ? ((c & 1) ? st[c >> 1].y : st[c >> 1].x) : 0.f;
+    for (int p = 0; p < 16; ++p) {
+        const int c = state_comp_at<S>(p);
+        sc[p] = c >= 0 ? ((c & 1) ? st[c >> 1].y : st[c >> 1].x) : 0.f;
+    }
     chunks_to_lds_swz<L>(img, sc, lane);
     f4 Bs[4], yacc[4];
     chunk_products_load(img, Bs, lane);
@@ -269,7 +282,7 @@ __device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[
 #pragma unroll
         for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[q], Bx[c][q], yacc[c], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < state_steps<S>(); ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bs[c][q], yacc[c], 0, 0, 0);
     wave_lds_sync();              // every lane has its B operands before the image is overwritten with the outputs

@@ -332,7 +332,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
                 u = o;
             }
             if (ex == 0) hsh[n] = (float)u;                        // h[n]: spread over the n-th sub-diagonal after the barrier below
-            else tb[LY::YM + n * LY::YMC + L + c0] = (float)u;
+            else tb[LY::YM + n * LY::YMC + L + state_pos<S>(c0)] = (float)u;
         }
     } else if (tid >= 192 && tid < 192 + S2) {
         // Wave 3: the adjoint cascade's zero-input response per unit adjoint state (LY::YMA's state half): component c of the state that
@@ -353,7 +353,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
                 l1[i] = t1;
                 g = o;
             }
-            tb[LY::YMA + n * LY::YMC + L + c0] = (float)g;
+            tb[LY::YMA + n * LY::YMC + L + state_pos<S>(c0)] = (float)g;
         }
     } else if (tid < 128) {
         const int l = tid - 64;
@@ -1920,7 +1920,10 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         {
             float sc[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) sc[c] = c < 2 * S ? ((c & 1) ? lam[c >> 1].y : lam[c >> 1].x) : 0.f;
+            for (int p = 0; p < 16; ++p) {
+                const int c = state_comp_at<S>(p);
+                sc[p] = c >= 0 ? ((c & 1) ? lam[c >> 1].y : lam[c >> 1].x) : 0.f;
+            }
             chunks_to_lds_swz<L>(tbo, sc, cl);
         }
         {
@@ -1942,7 +1945,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
             chunk_products_load(tbo, Bl, lane);
             pin(Bl);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < state_steps<S>(); ++q)          // (entries 4 k + 3 of the adjoint-state image are zeros for 2S <= 12: sos_tile.hpp state_pos)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (!(DASP_GRAM_ABLATE & 2)) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bl[c][q], oacc[c], 0, 0, 0);
@@ -2010,18 +2013,26 @@ sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const d
         cf[tid][0] = d[DT_B0]; cf[tid][1] = d[DT_B0 + 1]; cf[tid][2] = d[DT_B0 + 2]; cf[tid][3] = a1; cf[tid][4] = a2;
         cf[tid][5] = sg; cf[tid][6] = om; cf[tid][7] = 1.0 / om;
     }
+    // C[v][u] (v, u < 32; zero beyond D) gathered from the kernel's register layout; rows 16.. are the entries of the adjoint-state
+    // image, component c at entry state_pos(c)
     double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    int src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, dv = e >> 5, du = e & 31;
+        const int sv = dv < 16 ? dv : 16 + state_pos<S>(dv - 16 < 2 * S ? dv - 16 : 0);
+        src[q] = (dv < D && du < D) ? (((sv >> 4) * 2 + (du >> 4)) * 4 + (sv & 3)) * 64 + ((sv & 15) >> 2) * 16 + (du & 15) : -1;
+    }
     {
-        const double* g0 = gram + (size_t)item * C * 1024 + tid;
+        const double* g0 = gram + (size_t)item * C * 1024;
         for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cs[q] += g0[(size_t)c * 1024 + 256 * q];
+            for (int q = 0; q < 4; ++q) cs[q] += src[q] >= 0 ? g0[(size_t)c * 1024 + src[q]] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, r = e >> 6, ln = e & 63, blk = r >> 2;
-        const int vi = 16 * (blk >> 1) + 4 * (ln >> 4) + (r & 3), uj = 16 * (blk & 1) + (ln & 15);
-        Cm[vi][uj] = (vi < D && uj < D) ? cs[q] : 0.0;       // (the pad rows / columns hold whatever the pad lanes of the images held)
+        const int e = tid + 256 * q;
+        Cm[e >> 5][e & 31] = cs[q];
     }
     __syncthreads();
     PTRACE(51, 0);
