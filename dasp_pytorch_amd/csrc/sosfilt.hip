@@ -1726,13 +1726,16 @@ sos_chain_kernel(const double* __restrict__ segtab, int tab_bcast, int C, const 
 // are - 64 MFMAs per tile for the four 16 x 16 blocks of C (padded to 32 x 32), fp32 within the tile, folded into fp64 sums per tile
 // (the part that needs it: C's entries are sums over the whole row of products of O(1) signals, and the gradients are differences of
 // nearly equal combinations of them at the low-frequency corner of the EQ's ranges). What is left per tile besides that:
-//   - the adjoint lane scan (as in sos_bwd_kernel: chunk products on the matrix cores, Kogge-Stone over the lanes, mailboxes between waves),
-//   - gx = TA gy + OA lam, the adjoint cascade's outputs as a linear map of v (LY::YMA, 32 MFMAs: the forward kernel's output path mirrored),
+//   - the adjoint lane scan (as in sos_bwd_kernel: Kogge-Stone over the lanes, mailboxes between waves; its table products on the VALU),
+//   - gx = TA gy + OA lam, the adjoint cascade's outputs as a linear map of v (LY::YMA, 28 MFMAs: the forward kernel's output path mirrored;
+//     the adjoint states three to a granule so that the all-zero contraction step is skipped, sos_tile.hpp state_pos),
 //   - no forward scan: the forward chunk start states are the ones the forward kernel saved; they land by LDS-DMA directly in the
 //     [chunk][16] image the products read (the DMA's global addresses do the transposition: lane = (chunk, section pair)).
-// The 30 dependent VALU instructions per sample of sos_bwd_kernel (recomputation + adjoint + correlations) become ~112 MFMAs per tile
-// beside a VALU that only runs the scan. sos_gram_finalize_kernel turns sum-over-rows(C) into the gradients (fp64 basis responses).
-// Executable specification and error budget: oracle/chunkscan_model.py (gram_backward_row), tests/test_chunkscan_model.py.
+// The 30 dependent VALU instructions per sample of sos_bwd_kernel (recomputation + adjoint + correlations) become 92 MFMAs per tile
+// next to the scan. (They do not run beside it: on gfx950 an fp32 MFMA occupies its SIMD's vector issue for its 32 cycles - tools/ubench5.hip -
+// so the kernel is bound by the sum of both; the products that do not depend on the scan are still issued from hook points
+// inside it, which measured 3 % better than one block.) sos_gram_finalize_kernel turns sum-over-rows(C) into the gradients (fp64 basis
+// responses). Executable specification and error budget: oracle/chunkscan_model.py (gram_backward_row), tests/test_oracle_cpu.py.
 // gram: [row][16 registers][64 lanes] doubles - register 4 (2 bv + bu) + e of lane l = C[16 bv + 4 (l / 16) + e][16 bu + l % 16].
 __device__ __forceinline__ void gram_operands_load(const float* img, float (&R)[16], int lane) {
     const int k = lane >> 4, i = lane & 15;
