@@ -531,7 +531,7 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
 // workgroup per (row, segment of Tseg tiles); 2 = the scan-only pre-pass from a zero state, which leaves the segment's end state in
 // zseg[row][segment][2S]; 1 = the ordinary pass from the segment's start state segstart[row][segment][2S].
 template <int S, int L, int W, int SEG = 0>
-__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
+__global__ void __launch_bounds__(64 * W, W >= 16 ? 4 : (W * 2 + 3) / 4)   // two workgroups per CU (W = 16, few rows: one)
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
                float* __restrict__ carries, int C, int N, int nt, int vec,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
@@ -1744,7 +1744,7 @@ __device__ __forceinline__ void gram_operands_load(const float* img, float (&R)[
 }
 
 template <int S, int L, int W, int FLAGS>
-__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
+__global__ void __launch_bounds__(64 * W, 2)   // two waves per SIMD: two workgroups of 4 waves per CU, or one of 8 (few rows)
 sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                     const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
                     double* __restrict__ gram, int C, int N, int nt, int vec) {
@@ -2273,6 +2273,18 @@ inline bool use_bwd_gram() {
     return pick != 0;
 }
 
+// At most one row per CU (B * C <= 256 rows, one workgroup each): twice the waves per row - the same waves per CU as two rows of the
+// ordinary width, on one row (one workgroup per CU fits: LDS 134 / 139 KiB). Rows are latency-bound there: (64..128, 2, 131072) EQ steps
+// took the same 0.23 ms as a 256-row batch, and cutting rows into segments does not pay above 128 rows (profiles/r04/seg_crossover.log).
+// DASP_SOS_WIDE=0 / 1 at run time forces the choice (developer A/B).
+inline bool wide_rows(long rows) {
+    static const int pick = [] {
+        const char* e = getenv("DASP_SOS_WIDE");
+        return e ? (e[0] != '0' ? 1 : 0) : -1;
+    }();
+    return pick < 0 ? rows <= 256 : pick != 0;
+}
+
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
@@ -2406,8 +2418,12 @@ int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, flo
     const int vec = (N % 4 == 0) && aligned16(x) && aligned16(y);
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
-        hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF>), dim3(B * C), dim3(64 * kWF), 0, (hipStream_t)stream, tab,
-                           Bs == 1 && B != 1, x, y, carries, C, (int)N, nt, vec);
+        if (wide_rows(B * C))
+            hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, 2 * kWF>), dim3(B * C), dim3(128 * kWF), 0, (hipStream_t)stream, tab,
+                               Bs == 1 && B != 1, x, y, carries, C, (int)N, nt, vec);
+        else
+            hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF>), dim3(B * C), dim3(64 * kWF), 0, (hipStream_t)stream, tab,
+                               Bs == 1 && B != 1, x, y, carries, C, (int)N, nt, vec);
         return check_launch();
     });
 }
@@ -2427,12 +2443,18 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
         const int bc = Bs == 1 && B != 1;
         return dispatch_S(S, [&](auto s) {
             constexpr int SS = decltype(s)::value;
-            const dim3 g(B * C), b(64 * kWB);
+            const dim3 g(B * C), b(64 * kWB), b2(128 * kWB);
             hipStream_t st = (hipStream_t)stream;
-            if (flags & BWD_NOGX)
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, reinterpret_cast<double*>(partials), C, (int)N, nt, vec);
+            double* gm = reinterpret_cast<double*>(partials);
+            const bool wide = wide_rows(B * C);
+            if (wide && (flags & BWD_NOGX))
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, 2 * kWB, BWD_NOGX>), g, b2, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
+            else if (wide)
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, 2 * kWB, 0>), g, b2, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
+            else if (flags & BWD_NOGX)
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
             else
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, reinterpret_cast<double*>(partials), C, (int)N, nt, vec);
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
             return check_launch();
         });
     }
@@ -2553,7 +2575,9 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
 // dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch; partials: dasp_sos_partial_floats(rows * segments, S).
 long dasp_sos_segment_tiles(long rows, long N) {
     const long nt = dasp_sos_num_tiles(N);
-    if (rows <= 0 || rows >= 128 || nt < 16) return 0;
+    // (more than 64 rows: one workgroup per row at twice the waves - wide_rows - is as fast or faster, 0.178 against 0.179..0.190 ms at
+    // (40..63, 2, 131072), and its backward pass is the Gram-matrix kernel: profiles/r04/seg_crossover.log)
+    if (rows <= 0 || rows > 64 || nt < 16) return 0;
     long T = 8;                                        // at least one tile per forward wave
     // two workgroups per CU: measured at (8 / 16 / 32, 2, 131072) forward + backward 0.107 / 0.114 / 0.142 ms with this rule against 0.106 /
     // 0.114 / 0.162 ms with up to four per CU and 0.12 / 0.12 / 0.167 with one (profiles/r02/segment_length_sweep.log)

@@ -29,10 +29,11 @@ def _pad_sections(S):
 
 def _segment_tiles(rows, N):
     """Tiles per segment for the segmented-row kernels, 0 = one workgroup per row (dasp_hip.h, "Few rows").
-    A row is one workgroup, so fewer than 128 rows (the reference's training batches are 8-32 items: examples/style_transfer.py:403,
+    A row is one workgroup, so few rows (the reference's training batches are 8-32 items: examples/style_transfer.py:403,
     auto_eq.py:231) leave most of the 256 CUs idle; the segmented path takes 2-4x less GPU time there (16 x 2 x 131072: forward
     0.078 -> 0.032 ms, backward 0.177 -> 0.047 ms) for four more kernel launches per call, all issued by the same C call. It is taken
-    whenever the library's planner proposes a cut (rows < 128 and at least 16 tiles per row), eager or captured.
+    whenever the library's planner proposes a cut (at most 64 rows and at least 16 tiles per row; above that one workgroup per row runs at
+    twice the waves per row up to 256 rows and is as fast), eager or captured.
     DASP_SOS_SEGMENT=0 never, DASP_SOS_SEGMENT_TILES=<power of two> fixes the segment length."""
     if os.environ.get("DASP_SOS_SEGMENT", "auto") == "0":
         return 0

@@ -150,7 +150,7 @@ int dasp_biquad_design(const double* gain_db, const double* cutoff_freq, const d
                        double sample_rate, double* ba, double* jac, void* stream);
 int dasp_biquad_backward(const double* jac, const double* gba, int n, double* gparams, void* stream);
 
-/* Few rows (B*C < 128): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
+/* Few rows (B*C <= 64; up to 256 rows the plain calls launch twice the waves per row instead): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
  * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, the
  * last of an item's workgroups to finish chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab; the
  * completion counter is a word of the item's table, zeroed by the prepare call and reset after use - the one place where a call

@@ -1,0 +1,28 @@
+"""Developer timing: segmented rows beyond 128 rows (forced segment lengths) against one workgroup per row, EQ fwd+bwd graph replays."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dasp_pytorch_amd as D
+from bench import graph_step_ms, PEQ_RANGES, SR
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(3)
+rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+N = 131072
+for B in (64, 80, 96, 112, 128, 160, 192):
+    cols = [(rnd(B) * (hi - lo) + lo).requires_grad_(True) for lo, hi in PEQ_RANGES]
+    x = (rnd(B, 2, N) * 2 - 1).requires_grad_(True)
+    w = torch.randn(B, 2, N, device=dev, generator=g)
+    def step():
+        x.grad = None
+        for c in cols:
+            c.grad = None
+        D.parametric_eq(x, SR, *cols).backward(w)
+    row = {"B": B, "rows": 2 * B}
+    os.environ["DASP_SOS_SEGMENT"] = "0"
+    row["plain"] = round(graph_step_ms(step, replays=200, blocks=3, ramp_s=0.3), 4)
+    os.environ["DASP_SOS_SEGMENT"] = "1"
+    for T in (16, 32, 64):
+        os.environ["DASP_SOS_SEGMENT_TILES"] = str(T)
+        row[f"T{T}"] = round(graph_step_ms(step, replays=200, blocks=3, ramp_s=0.3), 4)
+    del os.environ["DASP_SOS_SEGMENT_TILES"]
+    print(json.dumps(row), flush=True)
