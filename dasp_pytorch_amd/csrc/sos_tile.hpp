@@ -29,6 +29,9 @@
 #ifndef DASP_BWD_DIRECT_GX
 #define DASP_BWD_DIRECT_GX 0      // backward kernel: gx stored by every lane from its registers (64 contiguous bytes per lane) instead of through a staging image
 #endif
+#ifndef DASP_DIRECT_OUT
+#define DASP_DIRECT_OUT 1         // forward / Gram backward kernels, full tiles: the matrix-core output granules go straight to memory (no staging image)
+#endif
 #ifndef DASP_SPLIT_COUPLING
 #define DASP_SPLIT_COUPLING 0     // lane scan: the coupling sum of sections >= 3 on two accumulators (shorter dependent chain, one more packed
                                   // add). Measured: 0.396 -> 0.398 ms fwd + bwd, i.e. nothing (profiles/r02/ab_micro_variants.log)
@@ -263,8 +266,35 @@ __device__ __forceinline__ void cascade_map_operands(const float* __restrict__ y
         AO[q] = ym[(lane & 15) * ymc + L + 4 * (lane >> 4) + q];
     }
 }
+// _acc: the products only - yacc[c] = rows 4 (lane / 16) .. + 3 of chunk 16 c + lane % 16, i.e. one 16-byte granule of the tile per
+// register quad (`img` is used for the state image). cascade_outputs_mfma: the same, then written to `img` as the output image.
+// mfma_granules_to_global: the granules straight to memory - per instruction the wave writes 16 chunks x 64 B = 1 KiB contiguous, every
+// 64-byte chunk by four lanes - no staging image, no LDS round trip (full tiles only; ragged tiles go through the image).
+template <int S, int L>
+__device__ __forceinline__ void cascade_outputs_mfma_acc(float* img, const f2 (&st)[S], const f4 (&Bx)[4], const float (&AT)[4], const float (&AO)[4], int lane,
+                                                         f4 (&yacc)[4]);
+__device__ __forceinline__ void mfma_granules_to_image(float* img, const f4 (&acc)[4], int lane) {
+    wave_lds_sync();              // every lane has its operands before the image is overwritten with the outputs
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(img + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = acc[c];
+    wave_lds_sync();
+}
+__device__ __forceinline__ void mfma_granules_to_global(float* __restrict__ tile, const f4 (&acc)[4], bool stream, int lane) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f4* p = reinterpret_cast<f4*>(tile + (16 * c + (lane & 15)) * 16 + 4 * (lane >> 4));
+        if (stream) st_stream(p, acc[c]); else *p = acc[c];
+    }
+}
 template <int S, int L>
 __device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[S], const f4 (&Bx)[4], const float (&AT)[4], const float (&AO)[4], int lane) {
+    f4 yacc[4];
+    cascade_outputs_mfma_acc<S, L>(img, st, Bx, AT, AO, lane, yacc);
+    mfma_granules_to_image(img, yacc, lane);
+}
+template <int S, int L>
+__device__ __forceinline__ void cascade_outputs_mfma_acc(float* img, const f2 (&st)[S], const f4 (&Bx)[4], const float (&AT)[4], const float (&AO)[4], int lane,
+                                                         f4 (&yacc)[4]) {
     float sc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
@@ -272,7 +302,7 @@ __device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[
         sc[p] = c >= 0 ? ((c & 1) ? st[c >> 1].y : st[c >> 1].x) : 0.f;
     }
     chunks_to_lds_swz<L>(img, sc, lane);
-    f4 Bs[4], yacc[4];
+    f4 Bs[4];
     chunk_products_load(img, Bs, lane);
     pin(Bs);
 #pragma unroll
@@ -285,10 +315,6 @@ __device__ __forceinline__ void cascade_outputs_mfma(float* img, const f2 (&st)[
     for (int q = 0; q < state_steps<S>(); ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) yacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bs[c][q], yacc[c], 0, 0, 0);
-    wave_lds_sync();              // every lane has its B operands before the image is overwritten with the outputs
-#pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(img + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = yacc[c];
-    wave_lds_sync();
 }
 
 // Whole-tile scan for one system (forward or adjoint tables): lane chunks X -> chunk start states st.

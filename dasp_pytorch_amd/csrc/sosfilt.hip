@@ -530,6 +530,13 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
 // SEG 0: one workgroup per row. SEG 1 / 2: the segmented scheme for few rows (oracle/chunkscan_model.py forward_row_segmented): one
 // workgroup per (row, segment of Tseg tiles); 2 = the scan-only pre-pass from a zero state, which leaves the segment's end state in
 // zseg[row][segment][2S]; 1 = the ordinary pass from the segment's start state segstart[row][segment][2S].
+constexpr bool defined_ablate_4() {
+#if defined(DASP_ABLATE) && (DASP_ABLATE & 4)
+    return true;
+#else
+    return false;
+#endif
+}
 template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, W >= 16 ? 4 : (W * 2 + 3) / 4)   // two workgroups per CU (W = 16, few rows: one)
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
@@ -660,8 +667,16 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             }
         }
 
+        bool stored = false;
         if constexpr (MO) {
-            cascade_outputs_mfma<S, L>(tby, st, Bop, AT, AO, lane);
+            f4 yacc[4];
+            cascade_outputs_mfma_acc<S, L>(tby, st, Bop, AT, AO, lane, yacc);
+            if (DASP_DIRECT_OUT && full && !(defined_ablate_4())) {
+                mfma_granules_to_global(yr + (size_t)t * TS, yacc, DASP_FWD_NT & 2, lane);
+                stored = true;
+            } else {
+                mfma_granules_to_image(tby, yacc, lane);
+            }
         } else
         // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
         // wave-uniform but are loaded into VGPRs (opaque lane-dependent address): VALU ops with SGPR operands issue at
@@ -710,7 +725,8 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         if (X[0] == 123.456f) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
         stores_in_flight = -1;
 #else
-        if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
+        if (stored) {}
+        else if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
         else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
         stores_in_flight = full ? (carries ? S / 2 : 0) + L / 4 : -1;
 #endif      // -1: a ragged tile issues a data-dependent number of stores
@@ -1952,12 +1968,13 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (!(DASP_GRAM_ABLATE & 2)) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bl[c][q], oacc[c], 0, 0, 0);
-            wave_lds_sync();              // every lane has its operands before the image is overwritten with the outputs
-#pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(tbo + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = oacc[c];
-            wave_lds_sync();
-            if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
-            else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+            if (DASP_DIRECT_OUT && full) {
+                mfma_granules_to_global(gxr + (size_t)t * TS, oacc, true, lane);
+            } else {
+                mfma_granules_to_image(tbo, oacc, lane);
+                if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
+                else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+            }
             stores_in_flight = full ? L / 4 : 0;
         }
         TRACE(23);
