@@ -1759,11 +1759,13 @@ __device__ __forceinline__ void gram_operands_load(const float* img, float (&R)[
     for (int m = 0; m < 16; ++m) R[m] = img[64 * m + 16 * k + 4 * ((i >> 2) ^ (m & 3)) + (i & 3)];      // (swz_slot(4 m + k, i / 4), entry i % 4)
 }
 
-template <int S, int L, int W, int FLAGS>
+// SEG = 1: segmented rows (few rows): workgroup = (row, segment of Tseg tiles), the adjoint state entering the segment from above comes from
+// segstart[row][segment][2S] (the scan-only pre-pass of sos_bwd_kernel<SEG = 2> and its chain); one matrix per (row, segment).
+template <int S, int L, int W, int FLAGS, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, 2)   // two waves per SIMD: two workgroups of 4 waves per CU, or one of 8 (few rows)
 sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                     const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
-                    double* __restrict__ gram, int C, int N, int nt, int vec) {
+                    double* __restrict__ gram, int C, int N, int nt, int vec, int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr) {
     using LY = SosLayout<S, L>;
     static_assert(L == 16 && 2 * S <= 16, "one 16-wide block of state components");
     constexpr bool GX = !(FLAGS & BWD_NOGX);
@@ -1772,7 +1774,8 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
     static_assert(REGION >= 2 * 1024, "a wave's region holds its 1024 fp64 sums at the end");
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW];
     const int lane = lane_id(), wave = wave_id();
-    const int row = blockIdx.x, nr = nt;
+    const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // this workgroup's tiles, walked t1 - 1 .. t0
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
@@ -1783,7 +1786,17 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
     float* tbx = tbg + IMG;
     float* tsi = tbx + IMG;
     float* tbo = tsi + IMG;
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
+    // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (t1 - 1) waits for, with the adjoint state that enters
+    // from above (zero at the end of the row)
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
+        float v = 0.f;
+        if (i < S * 4) {
+            const int comp = i & 3;
+            if (comp == 2) v = __builtin_bit_cast(float, t1);
+            else if (SEG && comp < 2) v = segstart[((size_t)row * G + seg) * (2 * S) + 2 * (i >> 2) + comp];
+        }
+        lds[i] = v;
+    }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     __syncthreads();
     const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
@@ -1805,7 +1818,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) glds16<!DASP_STATES_CACHED>(cs + 64 * q, a_s + 1024 * q);
     };
-    if (wave < nr) issue_dma(nt - 1 - wave, tile_full<L>((long)(nt - 1 - wave) * TS, N, vec));
+    if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec));
     int stores_in_flight = 0;
     float Aop[4], AT[4], AO[4];
     chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
@@ -1815,7 +1828,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
     for (int i = 0; i < 16; ++i) gsum[i] = 0.0;
 
     for (int r = wave; r < nr; r += W) {
-        const int t = nt - 1 - r;
+        const int t = t1 - 1 - r;
         int toff = 0;
         asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
         const float* __restrict__ tbl = tb + toff;
@@ -1917,7 +1930,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
                 },
                 [&](int i, f2 Kn) {
                     if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
-                    else if (t > 0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                    else if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
                 },
                 [&](int k, int p) {      // the 48 products above, dealt out over the 4 S hook points of the scan
                     if (!DASP_GRAM_INTERLEAVE) return;
@@ -1996,7 +2009,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < W; ++w) s += red[w * (REGION / 2) + e];
-        gram[(size_t)row * 1024 + e] = s;
+        gram[(SEG ? (size_t)row * G + seg : (size_t)row) * 1024 + e] = s;
     }
 }
 
@@ -2282,6 +2295,15 @@ inline bool use_bwd8cp(int S) {
 #ifndef DASP_BWD_GRAM
 #define DASP_BWD_GRAM 1
 #endif
+// the same for segmented rows (sos_bwd_gram_kernel<SEG = 1> + a finalize launch instead of sos_bwd_kernel<SEG = 1> finalizing in its last
+// workgroup): DASP_SEG_GRAM=0 / 1 at run time overrides the build's default
+#ifndef DASP_SEG_GRAM
+#define DASP_SEG_GRAM 0     // measured (profiles/r04/seg_gram_ab.log): the finalize launch it needs costs more than the kernel saves at the reference's
+                            // training batches - EQ fwd+bwd (8 / 16, 2, 131072) 0.081 -> 0.090 / 0.097 -> 0.106 ms, (16, 1, 131072) without gx 0.080 -> 0.083,
+                            // (32, 2, 131072) 0.131 = 0.131. What it buys is the Gram kernel's accuracy on segmented rows (worst control gradient of the
+                            // randomized sweep 1.0e-4 -> 2e-5): opt-in.
+#endif
+inline bool use_seg_gram();
 inline bool use_bwd_gram() {
     static const int pick = [] {
         const char* e = getenv("DASP_BWD_GRAM");
@@ -2300,6 +2322,14 @@ inline bool wide_rows(long rows) {
         return e ? (e[0] != '0' ? 1 : 0) : -1;
     }();
     return pick < 0 ? rows <= 256 : pick != 0;
+}
+
+inline bool use_seg_gram() {
+    static const int pick = [] {
+        const char* e = getenv("DASP_SEG_GRAM");
+        return e ? (e[0] != '0') : (DASP_SEG_GRAM != 0);
+    }();
+    return pick != 0 && use_bwd_gram();
 }
 
 inline int check_launch() {
@@ -2517,11 +2547,11 @@ static int grad_finalize_impl(const double* dtab, int Bs, const float* partials,
                               int designed, float* gout, bool plain, void* stream) {
     if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
         return DASP_ERR_ARG;
-    if (plain && use_bwd_gram()) {      // the sums of dasp_sosfilt_backward_ex: one matrix per row
+    if (plain ? use_bwd_gram() : use_seg_gram()) {      // one matrix per row (dasp_sosfilt_backward_ex) or per (row, segment)
         return dispatch_S(S, [&](auto s) {
             constexpr int SS = decltype(s)::value;
             hipLaunchKernelGGL((sos_gram_finalize_kernel<SS>), dim3(B), dim3(256), 0, (hipStream_t)stream, dtab, Bs == 1 && B != 1,
-                               reinterpret_cast<const double*>(partials), B, C, mode, gout);
+                               reinterpret_cast<const double*>(partials), B, plain ? C : C * segments, mode, gout);
             return check_launch();
         });
     }
@@ -2676,6 +2706,16 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
         hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 2>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, (float*)nullptr,
                            (float*)nullptr, C, (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg,
                            (const float*)nullptr, z, const_cast<float*>(tab), segtab, start);
+        if (use_seg_gram() && !(flags & BWD_NOGC)) {      // (the caller finalizes: grad_finalize_impl)
+            if (!aligned16(partials)) return DASP_ERR_ARG;
+            double* gm = reinterpret_cast<double*>(partials);
+            const dim3 g(B * C * G), b(64 * kWB);
+            if (flags & BWD_NOGX)
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start);
+            else
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start);
+            return check_launch();
+        }
         const bool fuse = fin_dtab && fin_gout && !bc && !(flags & BWD_NOGC);
         launch_bwd<SS, 1>(flags, B * C * G, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec, fuse ? const_cast<float*>(tab) : (float*)nullptr,
                           fuse ? fin_dtab : (const double*)nullptr, fin_mode, fuse ? fin_gout : (float*)nullptr, B, G, (int)Tseg, (const float*)start,
@@ -2765,7 +2805,7 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
     if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 1, stream);
     // one table per item: the last (row, segment) workgroup of an item finalizes it inside the backward launch (DASP_SEG_FUSED_FINALIZE=0
     // at build time keeps the separate launch); a shared table (Bp == 1 < B) always takes the separate launch
-    const bool fuse = DASP_SEG_FUSED_FINALIZE && partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
+    const bool fuse = DASP_SEG_FUSED_FINALIZE && !use_seg_gram() && partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
     const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, fuse ? dtab : nullptr, mode,
                                              fuse ? gout : nullptr, stream);
     if (rc != DASP_OK || !partials || fuse) return rc;
