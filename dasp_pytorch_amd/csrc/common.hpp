@@ -35,6 +35,16 @@ template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
 #endif
 }
 
+// Write-through store at agent scope (16 bytes, streaming): the line does not stay dirty in this XCD's L2. For the bulk output of a kernel
+// that ends with a cross-workgroup hand-off (handoff_arrive_is_last): the hand-off's release has to write back every dirty line of the L2
+// before the counter moves - measured 2.6 - 8.4 us for the 8 - 16 MB of input gradients of a segmented EQ backward pass
+// (profiles/r05/seg_tail_trace.log) - and finds nothing to write back when the output went through. (Inline asm: there is no builtin for
+// a 16-byte agent-scope store; vmcnt counts it like any store.)
+__device__ __forceinline__ void st_through(f4* p, f4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_through(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -218,13 +228,13 @@ __device__ __forceinline__ void tile_dma_issue_swz(const float* __restrict__ til
     for (int m = 0; m < 4; ++m) glds16(tile + 4 * swz_granule_of_slot(64 * m + lane), lds_bytes + 1024 * m);
 #endif
 }
-__device__ __forceinline__ void tile_swz_to_global_full(const float* img, float* __restrict__ row, long base, bool stream, int lane) {
+__device__ __forceinline__ void tile_swz_to_global_full(const float* img, float* __restrict__ row, long base, bool stream, int lane, bool through = false) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int P = 64 * m + lane;
         f4* p = reinterpret_cast<f4*>(row + base + 4 * swz_granule_of_slot(P));
         const f4 v = *reinterpret_cast<const f4*>(img + 4 * P);
-        if (stream) st_stream(p, v); else *p = v;
+        if (through) st_through(p, v); else if (stream) st_stream(p, v); else *p = v;
     }
 }
 __device__ __forceinline__ int swz_index(int m) { return 4 * swz_granule_of_slot(m >> 2) + (m & 3); }   // float index of sample m (slot map is an involution)
@@ -235,11 +245,11 @@ __device__ __forceinline__ void tile_global_to_swz_guarded(float* img, const flo
     for (int m = lane; m < 1024; m += 64) img[swz_index(m)] = (base + m < n_valid) ? row[base + m] : 0.f;
     wave_lds_sync();
 }
-__device__ __forceinline__ void tile_swz_to_global_guarded(const float* img, float* __restrict__ row, long base, long n_valid) {
+__device__ __forceinline__ void tile_swz_to_global_guarded(const float* img, float* __restrict__ row, long base, long n_valid, bool through = false) {
     const int lane = lane_id();
 #pragma unroll 1
     for (int m = lane; m < 1024; m += 64)
-        if (base + m < n_valid) row[base + m] = img[swz_index(m)];
+        if (base + m < n_valid) { if (through) st_through(row + base + m, img[swz_index(m)]); else row[base + m] = img[swz_index(m)]; }
 }
 
 // ---- intra-workgroup mailbox: one wave hands a 2-vector carry to another wave through LDS --------

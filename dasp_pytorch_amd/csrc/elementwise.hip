@@ -138,18 +138,32 @@ dist_sample_kernel(const float* __restrict__ x, const float* __restrict__ drive_
 // As separate torch ops this is ~30 launches of 3-4 us per training step.
 struct ChainAffine { float lo[32], span[32]; };        // [0, 6) compressor, [6, 31) reverb, [31] gain
 
+// flag (may be null): bit i of *flag is set when column i of the 32 (compressor 0 - 5, reverb 6 - 30, gain 31) holds a value outside [0, 1] -
+// the reference's ValueError (modules.py:83-84), raised by the host after it has read the word back; NaN passes, as it does there
+__device__ __forceinline__ void unit_range_flag(unsigned* flag, float p, int col) {
+    if (flag && (p < 0.f || p > 1.f)) atomicOr(flag, 1u << col);
+}
 __global__ void chain_controls_kernel(const float* __restrict__ pc, const float* __restrict__ pr, const float* __restrict__ pg, ChainAffine a,
-                                      float* __restrict__ ctl, float* __restrict__ gains, float* __restrict__ decays, float* __restrict__ mix, int B) {
+                                      float* __restrict__ ctl, float* __restrict__ gains, float* __restrict__ decays, float* __restrict__ mix,
+                                      unsigned* __restrict__ flag, int B) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, b = t / 30, j = t % 30;
     if (b >= B) return;
     if (j < 5) {
         const int c = j < 3 ? j : j + 1;
-        float v = fmaf(a.span[c], pc[b * 6 + c], a.lo[c]);
-        if (j == 4) v += fmaf(a.span[31], pg[b], a.lo[31]);
+        const float p = pc[b * 6 + c];
+        unit_range_flag(flag, p, c);
+        if (j == 2) unit_range_flag(flag, pc[b * 6 + 3], 3);      // release_ms: checked like the others although nothing reads it
+        float v = fmaf(a.span[c], p, a.lo[c]);
+        if (j == 4) {
+            unit_range_flag(flag, pg[b], 31);
+            v += fmaf(a.span[31], pg[b], a.lo[31]);
+        }
         ctl[b * 5 + j] = v;
     } else {
         const int c = j - 5;                              // reverb column 0 .. 24
-        const float v = fmaf(a.span[6 + c], pr[b * 25 + c], a.lo[6 + c]);
+        const float p = pr[b * 25 + c];
+        unit_range_flag(flag, p, 6 + c);
+        const float v = fmaf(a.span[6 + c], p, a.lo[6 + c]);
         if (c < 12) gains[b * 12 + c] = v; else if (c < 24) decays[b * 12 + c - 12] = v; else mix[b] = v;
     }
 }
@@ -244,12 +258,12 @@ int dasp_distortion_sample_backward(const float* x, const float* drive_db, const
     return ew_check();
 }
 int dasp_chain_controls(const float* comp_pn, const float* reverb_pn, const float* gain_pn, const float* lo, const float* span, float* ctl,
-                        float* gains, float* decays, float* mix, int B, void* stream) {
+                        float* gains, float* decays, float* mix, unsigned* flag, int B, void* stream) {
     if (!comp_pn || !reverb_pn || !gain_pn || !lo || !span || !ctl || !gains || !decays || !mix || B <= 0) return DASP_ERR_ARG;
     ChainAffine a;
     for (int i = 0; i < 32; ++i) { a.lo[i] = lo[i]; a.span[i] = span[i]; }
     hipLaunchKernelGGL(chain_controls_kernel, dim3((B * 30 + 255) / 256), dim3(256), 0, (hipStream_t)stream, comp_pn, reverb_pn, gain_pn, a, ctl, gains,
-                       decays, mix, B);
+                       decays, mix, flag, B);
     return ew_check();
 }
 int dasp_chain_controls_backward(const float* gctl, const float* ggain, const float* gdecay, const float* gmix, const float* span,

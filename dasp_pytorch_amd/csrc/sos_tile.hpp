@@ -279,11 +279,11 @@ __device__ __forceinline__ void mfma_granules_to_image(float* img, const f4 (&ac
     for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(img + 4 * swz_slot(16 * c + (lane & 15), lane >> 4)) = acc[c];
     wave_lds_sync();
 }
-__device__ __forceinline__ void mfma_granules_to_global(float* __restrict__ tile, const f4 (&acc)[4], bool stream, int lane) {
+__device__ __forceinline__ void mfma_granules_to_global(float* __restrict__ tile, const f4 (&acc)[4], bool stream, int lane, bool through = false) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         f4* p = reinterpret_cast<f4*>(tile + (16 * c + (lane & 15)) * 16 + 4 * (lane >> 4));
-        if (stream) st_stream(p, acc[c]); else *p = acc[c];
+        if (through) st_through(p, acc[c]); else if (stream) st_stream(p, acc[c]); else *p = acc[c];
     }
 }
 template <int S, int L>

@@ -174,13 +174,32 @@ constexpr double OM_MIN = 1e-5;
                                  // 1 = one workgroup per row only, 2 = segmented rows as well, 0 = never
 #endif
 
+// The per-chunk basis responses of an item's cascade (GramFin<S>, below: what the finalize step of the Gram-matrix backward multiplies the
+// Gram matrix with). They depend on the coefficients only, and their 96-step fp64 recurrences are half of that step's time - so for
+// segmented rows, whose finalize step is the tail of the backward launch, the design kernel computes them here, beside its own chains.
+template <int S> struct GramFin;
+template <int S, bool AGENT> __device__ __forceinline__ void gram_basis_responses(const double* cf, double* bas, int tid);
+
+// 256 threads; 384 when `basis` is given: waves 4 and 5 then compute the basis responses (one thread per basis vector) while waves 0 - 3
+// run the chunk-table recursion, the squarings and the output maps.
 template <int S, int L>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(384)
 sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params, PeqSpec spec,
-                float* __restrict__ tab, double* __restrict__ dtab, int nsq_seg = 0, double* __restrict__ segtab = nullptr) {
+                float* __restrict__ tab, double* __restrict__ dtab, int nsq_seg = 0, double* __restrict__ segtab = nullptr,
+                double* __restrict__ basis = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, NN = S2 * S2;
     __shared__ double sec[S][10];       // sg, om, kom, g1, g2, d, kappa, b1, b2
+    __shared__ double cfb[S][8];        // b0 b1 b2 a1 a2 (normalised), sg, om, 1 / om: gram_fin_coefs' numbers, for the helper waves
+    if (threadIdx.x >= 256) {           // helper waves: the same barriers as everybody else, the basis responses between the second and the third
+        __syncthreads();
+        __syncthreads();
+        gram_basis_responses<S, false>(&cfb[0][0], basis + (size_t)blockIdx.x * ((S * (L + 2) + 2 * S * L) * (L + 2 * S)), (int)threadIdx.x - 256);
+        __syncthreads();
+        if (segtab)
+            for (int step = 0; step < nsq_seg; ++step) __syncthreads();
+        return;
+    }
     __shared__ double Phi[2][NN], T1[2][NN], T2[2][NN];
     __shared__ double vv[2][2][S2];
     __shared__ float Gsh[2][L][S2];     // chunk-table columns v_m, written out after the recursion (no global stores inside it)
@@ -243,6 +262,8 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             d[DT_A0] = a0; d[7] = kap;
             d[23] = 0.0;
             d[DT_SG32] = (double)(float)sg; d[DT_NF] = direct ? 0.0 : 1.0; d[27] = 0.0;
+            for (int c = 0; c < 5; ++c) cfb[k][c] = c5[c];
+            cfb[k][5] = sg; cfb[k][6] = om; cfb[k][7] = 1.0 / om;
         }
     }
     PTRACE(41, 0);
@@ -808,25 +829,41 @@ __device__ __forceinline__ void finish_section(const double* __restrict__ dtab, 
     emit_section_grads(d, g5, B, S, mode, gout, item, k);
 }
 // g5 = dL/d(b0, b1, b2, a1, a2) of section k of the item (normalised coefficients) -> the requested gradients (mode as in dasp_sos_grad_finalize)
-__device__ __forceinline__ void emit_section_grads(const double* __restrict__ d, const double (&g5)[5], int B, int S, int mode,
+struct EmitCoef { double a0, b[5], J[15]; };      // of one (item, section): a0 as given, the normalised coefficients, the design Jacobian (dtab)
+__device__ __forceinline__ EmitCoef load_emit_coef(const double* __restrict__ d) {
+    EmitCoef e;
+    e.a0 = d[DT_A0];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) e.b[i] = d[DT_B0 + i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) e.J[i] = d[DT_J + i];
+    return e;
+}
+__device__ __forceinline__ void emit_section_grads(const EmitCoef& e, const double (&g5)[5], int B, int S, int mode,
                                                    float* __restrict__ gout, int item, int k) {
     const int idx = item * S + k;
     if (mode == 0) {
-        const double a0 = d[DT_A0];
         double dot = 0.0;
-        for (int i = 0; i < 5; ++i) dot += g5[i] * d[DT_B0 + i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dot += g5[i] * e.b[i];
         float* o = gout + (size_t)idx * 6;
-        o[0] = (float)(g5[0] / a0); o[1] = (float)(g5[1] / a0); o[2] = (float)(g5[2] / a0);
-        o[3] = (float)(-dot / a0);
-        o[4] = (float)(g5[3] / a0); o[5] = (float)(g5[4] / a0);
+        o[0] = (float)(g5[0] / e.a0); o[1] = (float)(g5[1] / e.a0); o[2] = (float)(g5[2] / e.a0);
+        o[3] = (float)(-dot / e.a0);
+        o[4] = (float)(g5[3] / e.a0); o[5] = (float)(g5[4] / e.a0);
     } else {
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             double v = 0.0;
-            for (int c = 0; c < 5; ++c) v += g5[c] * d[DT_J + c * 3 + i];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) v += g5[c] * e.J[c * 3 + i];
             if (mode == 1) gout[(size_t)idx * 3 + i] = (float)v;
             else gout[(size_t)(3 * k + i) * B + item] = (float)v;
         }
     }
+}
+__device__ __forceinline__ void emit_section_grads(const double* __restrict__ d, const double (&g5)[5], int B, int S, int mode,
+                                                   float* __restrict__ gout, int item, int k) {
+    emit_section_grads(load_emit_coef(d), g5, B, S, mode, gout, item, k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1730,6 +1767,355 @@ sos_chain_kernel(const double* __restrict__ segtab, int tab_bcast, int C, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// C (summed over the item's rows, or over its (row, segment) workgroups) -> the gradients of the item's sections. The steps are shared by
+// sos_gram_finalize_kernel (one workgroup per item, a launch of its own: one workgroup per row, shared tables, the two-call C entry points)
+// and by the last workgroup of an item in the segmented Gram pass (sos_bwd_gram_kernel<SEG = 1>, gram_fused_tail):
+//   1. the per-chunk basis responses of the item's cascade in fp64, one thread per basis vector - FW[k][n][j] = w_k[n - 2] (the all-pole
+//      signal of section k, n = 0 .. L + 1) for u = e_j; FG / FO[k][n][j] = adjoint input / output of section k at sample n for v = e_j.
+//      Start states enter as the kernels define them: w[-2] = s2 / om, w[-1] = s1 + (sg / om) s2 (normal-form chunk start state);
+//      z1 = l1, z2 = -sg l1 + om l2 (adjoint state, transposed direct form II). They depend on the item's coefficients only: in the
+//      segmented pass a workgroup of its own computes them BESIDE the tile workgroups (gram_basis_responses<AGENT = true> into global
+//      scratch), so that the 96-step fp64 chain - half of the finalize step's time - is not on the tail of the launch;
+//   2. C summed over the matrices (gram_sum), P[k][m] = C FW[k][m] for the S (L + 2) signal rows on the fp64 matrix cores
+//      (v_mfma_f64_16x16x4_f64: D[i][j] in lane 16 (i % 4) + j, register i / 4 - not the f32 instruction's row order;
+//      tools/mfma64_probe.hip), then thread (which, k, n): the products of F[k][n] with P[k][n + 2 - j]: the lag sums sum g w[n],
+//      sum g w[n - 1], sum g w[n - 2], sum o w[n - 1], sum o w[n - 2] after a 16-lane reduction over n;
+//   3. thread k: dL/d(b0, b1, b2, a1, a2) = (the three g sums, minus the two o sums) -> emit_section_grads.
+// AGENT: the operands were written by other workgroups of the running launch (relaxed agent-scope accesses, common.hpp hand-off).
+// developer builds (-DDASP_TRACE): cycle stamps of the finalize steps of item 0 (tools/sosbench, scripts/seg_tail_trace.py)
+#ifdef DASP_TRACE
+#define GTRACE(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                       if (item == 0 && threadIdx.x == 0) g_trace[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GTRACE(i)
+#endif
+template <int S>
+struct GramFin {
+    static constexpr int L = 16, D = L + 2 * S, NW = L + 2, NP = S * NW, NPB = (NP + 15) / 16;
+    static constexpr int FW = 0, FG = NP * D, FO = FG + S * L * D, BASIS = FO + S * L * D;       // basis responses (doubles): FW[NP][D], FG[S][L][D], FO[S][L][D]
+    // work area in LDS (doubles): C[32][33] (C[v][u], zero beyond D), P[NP][33] (P[k (L + 2) + m][v] = sum_u C[v][u] FW[k][m][u]),
+    // lag sums [S][5], coefficients [S][8] (b0 b1 b2 a1 a2 normalised, sg, om, 1 / om)
+    static constexpr int CM = 0, P = 32 * 33, LAG = P + NP * 33, CF = LAG + S * 5 + (S * 5) % 2, WORK = CF + S * 8;
+};
+template <bool AGENT> __device__ __forceinline__ double fin_ld(const double* p) {
+    if (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool AGENT> __device__ __forceinline__ void fin_st(double* p, double v) {
+    if (AGENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int S>
+__device__ __forceinline__ void gram_fin_coefs(const double* __restrict__ d0, double* cf, int tid) {
+    if (tid < S) {
+        const double* d = d0 + tid * DT_STRIDE;
+        const double a1 = d[DT_B0 + 3], a2 = d[DT_B0 + 4], sg = -0.5 * a1;
+        double om = sqrt(fabs(sg * sg - a2));
+        om = om < OM_MIN ? OM_MIN : om;
+        double* c = cf + tid * 8;
+        c[0] = d[DT_B0]; c[1] = d[DT_B0 + 1]; c[2] = d[DT_B0 + 2]; c[3] = a1; c[4] = a2;
+        c[5] = sg; c[6] = om; c[7] = 1.0 / om;
+    }
+}
+// threads 0 .. 127 (forward basis vectors: 0 .. D - 1, adjoint ones: 64 .. 64 + D - 1); cf must be visible (barrier) before the call
+template <int S, bool AGENT>
+__device__ __forceinline__ void gram_basis_responses(const double* cf, double* bas, int tid) {
+    using GF = GramFin<S>;
+    constexpr int L = GF::L, D = GF::D, NW = GF::NW;
+    if (tid >= 128) return;
+    const int j = tid & 63, adj = tid >> 6;
+    if (j >= D) return;
+    double sig[L];
+#pragma unroll
+    for (int n = 0; n < L; ++n) sig[n] = (j == n) ? 1.0 : 0.0;
+    for (int i = 0; i < S; ++i) {
+        const int k = adj ? S - 1 - i : i;
+        const double* c = cf + k * 8;
+        const double b0 = c[0], b1 = c[1], b2 = c[2], a1 = c[3], a2 = c[4], sg = c[5], om = c[6], iom = c[7];
+        const double c1 = (j == L + 2 * i) ? 1.0 : 0.0, c2 = (j == L + 2 * i + 1) ? 1.0 : 0.0;   // the unit state component, if it is this section's
+        if (!adj) {
+            double w2 = c2 * iom, w1 = c1 + sg * iom * c2;
+            double* fw = bas + GF::FW + (size_t)(k * NW) * D + j;
+            fin_st<AGENT>(fw, w2); fin_st<AGENT>(fw + D, w1);
+#pragma unroll
+            for (int n = 0; n < L; ++n) {
+                const double w = fma(-a1, w1, fma(-a2, w2, sig[n]));      // (one FMA on the recurrence's dependent chain)
+                sig[n] = fma(b0, w, fma(b1, w1, b2 * w2));
+                fin_st<AGENT>(fw + (size_t)(n + 2) * D, w);
+                w2 = w1; w1 = w;
+            }
+        } else {
+            double z1 = c1, z2 = -sg * c1 + om * c2;
+            double* fg = bas + GF::FG + (size_t)(k * L) * D + j;
+            double* fo = bas + GF::FO + (size_t)(k * L) * D + j;
+#pragma unroll
+            for (int n = L - 1; n >= 0; --n) {
+                const double g = sig[n];
+                fin_st<AGENT>(fg + (size_t)n * D, g);
+                const double o = fma(b0, g, z1);
+                z1 = fma(-a1, o, fma(b1, g, z2));
+                z2 = fma(-a2, o, b2 * g);
+                fin_st<AGENT>(fo + (size_t)n * D, o);
+                sig[n] = o;
+            }
+        }
+    }
+}
+// C[v][u] (v, u < 32; zero beyond D) = sum of the nmat matrices at g0, gathered from the kernel's register layout; rows 16.. are the
+// entries of the adjoint-state image, component c at entry state_pos(c). 256 threads, four entries each; the matrices are fetched
+// sixteen at a time (64 independent loads per thread in flight: one trip to memory per sixteen matrices), summed in index order.
+template <int S, bool AGENT>
+__device__ __forceinline__ void gram_sum(const double* __restrict__ g0, int nmat, double* Cm, int tid) {
+    constexpr int D = GramFin<S>::D, NBATCH = AGENT ? 16 : 4;
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    int src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, dv = e >> 5, du = e & 31;
+        const int sv = dv < 16 ? dv : 16 + state_pos<S>(dv - 16 < 2 * S ? dv - 16 : 0);
+        src[q] = (dv < D && du < D) ? (((sv >> 4) * 2 + (du >> 4)) * 4 + (sv & 3)) * 64 + ((sv & 15) >> 2) * 16 + (du & 15) : -1;
+    }
+    for (int c0 = 0; c0 < nmat; c0 += NBATCH) {
+        double v[NBATCH][4];
+#pragma unroll
+        for (int j = 0; j < NBATCH; ++j) {
+            const double* g = g0 + (size_t)(c0 + j < nmat ? c0 + j : c0) * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[j][q] = src[q] >= 0 ? fin_ld<AGENT>(g + src[q]) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NBATCH; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[q] += c0 + j < nmat ? v[j][q] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        Cm[(e >> 5) * 33 + (e & 31)] = cs[q];
+    }
+}
+// A workgroup's own matrix (segmented pass with the finalize step inside the launch): the four sums of thread tid - entries tid + 256 i of
+// the kernel's register layout (register r = entry / 64 = 4 (2 bv + bu) + e of lane entry % 64 is C[16 bv + 4 (lane / 16) + e][16 bu +
+// lane % 16]) - scattered into the zero-filled C of the work area; 256 threads.
+template <int S>
+__device__ __forceinline__ void gram_scatter(const double (&s4)[4], double* Cm, int tid) {
+    constexpr int D = GramFin<S>::D;
+    for (int e = tid; e < 32 * 33; e += 256) Cm[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, reg = idx >> 6, lane = idx & 63;
+        const int sv = 16 * (reg >> 3) + 4 * (lane >> 4) + (reg & 3), du = 16 * ((reg >> 2) & 1) + (lane & 15);
+        int dv = sv;
+        if (sv >= 16) {
+            const int comp = state_comp_at<S>(sv - 16);
+            dv = comp >= 0 ? 16 + comp : -1;
+        }
+        if (dv >= 0 && dv < D && du < D) Cm[dv * 33 + du] = s4[i];
+    }
+}
+// step 2 (products, lag sums). The operands that come from the basis responses are a thread's own registers, fetched by gram_prefetch -
+// in the segmented pass before the workgroup's matrix is even reduced, so that their trip to L2 / memory (half of this step's time when
+// they were loaded where they are used: profiles/r05/seg_tail_trace.log) runs under that reduction.
+template <int S>
+struct GramOps {
+    static constexpr int NST = (GramFin<S>::D + 3) / 4, NB = (2 * GramFin<S>::NPB + 3) / 4;
+    double bop[NST][NB];            // FW entries: the B operands of this lane's matrix-core products
+    double f[GramFin<S>::D];        // F[k][n][.] of this thread's (which, k, n)
+};
+template <int S, bool AGENT>
+__device__ __forceinline__ void gram_prefetch(const double* bas, int tid, GramOps<S>& r) {
+    using GF = GramFin<S>;
+    constexpr int L = GF::L, D = GF::D, NP = GF::NP;
+    const int wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+#pragma unroll
+    for (int st = 0; st < GramOps<S>::NST; ++st) {
+        const int u = 4 * st + lk, uu = u < D ? u : D - 1;           // (C is zero beyond D)
+#pragma unroll
+        for (int q = 0; q < GramOps<S>::NB; ++q) {
+            const int p0 = 16 * ((wave + 4 * q) >> 1), pmr = p0 + li < NP ? p0 + li : NP - 1;   // (pad columns of the last block and blocks past the end: any row - their results are not stored)
+            r.bop[st][q] = fin_ld<AGENT>(bas + GF::FW + (size_t)pmr * D + uu);
+        }
+    }
+    const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;
+    const double* F = bas + ((which & 1) ? GF::FO : GF::FG) + (size_t)(k * L + n) * D;      // (threads beyond 2 x 16 S read a valid row they do not use)
+#pragma unroll
+    for (int v = 0; v < D; ++v) r.f[v] = fin_ld<AGENT>(F + v);
+}
+// wk = the LDS work area with C in place (barrier before the call) -> the 5 S lag sums in wk + LAG (barrier after the call before they are
+// read); 256 threads. `item` only serves the developer trace.
+template <int S>
+__device__ __forceinline__ void gram_lag_sums(const GramOps<S>& r, double* wk, int item, int tid) {
+    using GF = GramFin<S>;
+    constexpr int D = GF::D, NW = GF::NW, NP = GF::NP, NPB = GF::NPB;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const double* Cm = wk + GF::CM;
+    double* P = wk + GF::P;
+    double* lagsum = wk + GF::LAG;
+    {   // P^T (32 x NP) = C (32 x 32) FW^T (32 x NP): 2 x NPB blocks of 16 x 16, (D + 3) / 4 steps of 4 each (C is zero beyond D), dealt out over the four waves
+        const int wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+        constexpr int NB = GramOps<S>::NB;               // blocks per wave; their accumulator chains run side by side
+        d4 acc[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < GramOps<S>::NST; ++st) {
+            const int u = 4 * st + lk;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[(16 * ((wave + 4 * q) & 1) + li) * 33 + u], r.bop[st][q], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int blk = wave + 4 * q, v0 = 16 * (blk & 1), p0 = 16 * (blk >> 1);
+            if (blk < 2 * NPB && p0 + li < NP) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) P[(p0 + li) * 33 + v0 + lk + 4 * rr] = acc[q][rr];
+            }
+        }
+    }
+    __syncthreads();
+    GTRACE(54);
+    {
+        const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;
+        const bool on = tid < 2 * 16 * S;
+        double v3[3] = {0.0, 0.0, 0.0};
+        if (on) {
+#pragma unroll
+            for (int jl = 0; jl < 3; ++jl) {
+                const double* pr = P + (k * NW + n + 2 - jl) * 33;
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int v = 0; v < D; v += 2) { a0 = fma(r.f[v], pr[v], a0); a1 = fma(r.f[v + 1], pr[v + 1], a1); }
+                v3[jl] = a0 + a1;
+            }
+        }
+#pragma unroll
+        for (int jl = 0; jl < 3; ++jl) {        // sum over the 16 samples n = the 16 lanes of a DPP row
+            double a = v3[jl];
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+            v3[jl] = a;
+        }
+        if (on && n == 0) {
+            if (!which) { lagsum[k * 5 + 0] = v3[0]; lagsum[k * 5 + 1] = v3[1]; lagsum[k * 5 + 2] = v3[2]; }
+            else { lagsum[k * 5 + 3] = v3[1]; lagsum[k * 5 + 4] = v3[2]; }
+        }
+    }
+    GTRACE(55);
+}
+// step 3: thread k < S turns section k's lag sums (wk + LAG, visible) into its gradients. ec: the section's design numbers (EmitCoef,
+// loaded by the caller - in the segmented pass long before the hand-off that precedes this step)
+template <int S>
+__device__ __forceinline__ void gram_emit(const EmitCoef& ec, const double* wk, int B, int mode, float* __restrict__ gout, int item, int tid) {
+    const double* lagsum = wk + GramFin<S>::LAG;
+    if (tid < S) {
+        const double g5[5] = {lagsum[tid * 5 + 0], lagsum[tid * 5 + 1], lagsum[tid * 5 + 2], -lagsum[tid * 5 + 3], -lagsum[tid * 5 + 4]};
+        emit_section_grads(ec, g5, B, S, mode, gout, item, tid);
+    }
+    GTRACE(56);
+}
+
+template <int S>
+__global__ void __launch_bounds__(256)
+sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const double* __restrict__ gram, int B, int C, int mode,
+                         float* __restrict__ gout) {
+    using GF = GramFin<S>;
+    __shared__ double wk[GF::WORK];
+    __shared__ double bas[GF::BASIS];
+    const int tid = threadIdx.x, item = blockIdx.x;
+    const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
+    GTRACE(50);
+    // every global read of the kernel up front and in flight together (one trip to L2 instead of one per section / per matrix entry)
+    gram_fin_coefs<S>(d0, wk + GF::CF, tid);
+    gram_sum<S, false>(gram + (size_t)item * C * 1024, C, wk + GF::CM, tid);
+    __syncthreads();
+    GTRACE(51);
+    gram_basis_responses<S, false>(wk + GF::CF, bas, tid);
+    GTRACE(52);
+    __syncthreads();
+    GTRACE(53);
+    GramOps<S> ops;
+    gram_prefetch<S, false>(bas, tid, ops);
+    gram_lag_sums<S>(ops, wk, item, tid);
+    __syncthreads();
+    gram_emit<S>(load_emit_coef(d0 + (tid < S ? tid : 0) * DT_STRIDE), wk, B, mode, gout, item, tid);
+}
+
+// The tail of the segmented Gram pass (sos_bwd_gram_kernel<SEG = 1> with fz.on). The finalize step is LINEAR in the Gram matrix, so every
+// (row, segment) workgroup applies it to its own matrix - straight from its registers, the matrix never goes to memory - with the basis
+// responses the design kernel left in fz.basis: 5 S lag sums per workgroup (lagbuf: 32 doubles per workgroup), all workgroups side by
+// side. What is left for the workgroup that completes the item's count (common.hpp hand-off) is the sum of those few numbers over the
+// item's workgroups and the design Jacobian. (First version: the last workgroup summed the 8 KiB matrices and ran the whole step alone -
+// measured 13 - 21 us of tail at (8 .. 16, 2, 131072): profiles/r05/seg_tail_trace.log.) wk: GramFin<S>::WORK doubles of LDS, idle by now.
+struct GramFuse {
+    int on, B, mode;
+    const double* dtab;
+    float* gout;
+    const double* basis;    // [item][GramFin<S>::BASIS], written by sos_prep_kernel
+    float* cnt_tab;         // the items' tables: word LY::CNT of an item's table counts its arrivals (zeroed by the prep kernel, reset here)
+};
+// red: the four waves' 1024 sums each, [wave][red_stride] doubles in LDS (visible); it may overlap wk - it is read into registers first.
+template <int S>
+__device__ __forceinline__ void gram_fused_tail(const GramFuse& fz, int item, int nwg, int wg_in_item, double* lagbuf_item, const double* red, int red_stride, double* wk) {
+    using LY = SosLayout<S, 16>;
+    using GF = GramFin<S>;
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+#ifdef DASP_TRACE
+    long long tail_t[5];
+#define TAIL_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tail_t[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TAIL_STAMP(i)
+#endif
+    TAIL_STAMP(0);
+    // everything this workgroup will want from memory, requested before anything else: the operands of the lag sums, the design numbers
+    // of the last step (only the workgroup that ends up finalizing uses those)
+    GramOps<S> ops;
+    gram_prefetch<S, false>(fz.basis + (size_t)item * GF::BASIS, tid, ops);
+    const EmitCoef ec = load_emit_coef(fz.dtab + ((size_t)item * S + (tid < S ? tid : 0)) * DT_STRIDE);
+    double s4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += red[w * red_stride + tid + 256 * i];
+        s4[i] = a;
+    }
+    __syncthreads();        // the sums are in registers: the work area may overwrite them
+    gram_scatter<S>(s4, wk + GF::CM, tid);
+    __syncthreads();
+    TAIL_STAMP(1);
+    gram_lag_sums<S>(ops, wk, item, tid);
+    __syncthreads();
+    if (tid < 5 * S) fin_st<true>(lagbuf_item + (size_t)wg_in_item * 32 + tid, wk[GF::LAG + tid]);
+    TAIL_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = handoff_arrive_is_last(reinterpret_cast<int*>(fz.cnt_tab + (size_t)item * LY::TOTAL + LY::CNT), nwg);
+    __syncthreads();
+    if (!s_last) return;
+    TAIL_STAMP(3);
+    if (tid < 5 * S) {
+        double acc = 0.0;
+        for (int m0 = 0; m0 < nwg; m0 += 32) {         // thirty-two loads in flight (the usual count: one trip to memory); summed in index order
+            double v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = fin_ld<true>(lagbuf_item + (size_t)(m0 + j < nwg ? m0 + j : m0) * 32 + tid);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc += m0 + j < nwg ? v[j] : 0.0;
+        }
+        wk[GF::LAG + tid] = acc;
+    }
+    __syncthreads();
+    gram_emit<S>(ec, wk, fz.B, fz.mode, fz.gout, item, tid);
+    TAIL_STAMP(4);
+#ifdef DASP_TRACE
+    if (item == 0 && tid == 0)
+        for (int i = 0; i < 5; ++i) g_trace[57 + i] = tail_t[i];       // the stamps of ONE workgroup - the one that finalized item 0
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward by Gram matrix (round 4; one workgroup per row, coefficient gradients wanted). No recomputation of the cascade at all.
 // Within a chunk every signal of the cascade is a LINEAR function of u = (the chunk's L inputs x, its 2S forward start-state components)
 // and every adjoint signal a linear function of v = (the chunk's L adjoint inputs gy, the 2S components of the adjoint state that enters
@@ -1765,7 +2151,8 @@ template <int S, int L, int W, int FLAGS, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, 2)   // two waves per SIMD: two workgroups of 4 waves per CU, or one of 8 (few rows)
 sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
                     const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
-                    double* __restrict__ gram, int C, int N, int nt, int vec, int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr) {
+                    double* __restrict__ gram, int C, int N, int nt, int vec, int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr,
+                    GramFuse fz = GramFuse{}) {
     using LY = SosLayout<S, L>;
     static_assert(L == 16 && 2 * S <= 16, "one 16-wide block of state components");
     constexpr bool GX = !(FLAGS & BWD_NOGX);
@@ -1774,7 +2161,12 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
     static_assert(REGION >= 2 * 1024, "a wave's region holds its 1024 fp64 sums at the end");
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW];
     const int lane = lane_id(), wave = wave_id();
-    const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    const int wg = blockIdx.x;
+    if constexpr (SEG != 0) {
+        static_assert(W == 4, "the finalize steps are written for 256 threads");
+        static_assert(GramFin<S>::WORK * 2 <= LDS_T + LDS_MB + LDS_PW, "the finalize work area fits the tile images");
+    }
+    const int row = SEG ? wg / G : wg, seg = SEG ? wg % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // this workgroup's tiles, walked t1 - 1 .. t0
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
@@ -1981,12 +2373,13 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (!(DASP_GRAM_ABLATE & 2)) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bl[c][q], oacc[c], 0, 0, 0);
+            // (segmented rows: the launch ends with a hand-off - gx goes through the L2 so that its release finds nothing to write back)
             if (DASP_DIRECT_OUT && full) {
-                mfma_granules_to_global(gxr + (size_t)t * TS, oacc, true, lane);
+                mfma_granules_to_global(gxr + (size_t)t * TS, oacc, true, lane, SEG != 0);
             } else {
                 mfma_granules_to_image(tbo, oacc, lane);
-                if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
-                else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+                if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane, SEG != 0);
+                else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N, SEG != 0);
             }
             stores_in_flight = full ? L / 4 : 0;
         }
@@ -1998,181 +2391,26 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
             for (int e = 0; e < 4; ++e) gsum[4 * b + e] += (double)cacc[b][e];
         TRACE(24);
     }
-    // the W waves' sums -> one matrix per row
+    // the W waves' sums -> one matrix per row (per (row, segment))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (LDS-DMA never targets an image after the last tile, but the regions change hands below)
     __syncthreads();
     double* red = reinterpret_cast<double*>(pw_lds + LDS_PW);
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[wave * (REGION / 2) + i * 64 + lane] = gsum[i];
     __syncthreads();
+    if constexpr (SEG != 0) {
+        if (fz.on) {        // the finalize step inside the launch: this workgroup's lag sums from its own matrix (gram_fused_tail)
+            const int item = row / C;
+            gram_fused_tail<S>(fz, item, C * G, (row - item * C) * G + seg, gram + (size_t)item * C * G * 32, red, REGION / 2, reinterpret_cast<double*>(lds));
+            return;
+        }
+    }
     for (int e = threadIdx.x; e < 1024; e += 64 * W) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < W; ++w) s += red[w * (REGION / 2) + e];
         gram[(SEG ? (size_t)row * G + seg : (size_t)row) * 1024 + e] = s;
     }
-}
-
-// C (summed over the item's rows) -> the gradients of the item's sections. One workgroup per item:
-//   1. waves 0 / 1: the per-chunk basis responses of the item's cascade in fp64, one thread per basis vector - FW[k][n][j] = w_k[n - 2]
-//      (the all-pole signal of section k, n = 0 .. L + 1) for u = e_j; FG / FO[k][n][j] = adjoint input / output of section k at sample n
-//      for v = e_j. Start states enter as the kernels define them: w[-2] = s2 / om, w[-1] = s1 + (sg / om) s2 (normal-form chunk start
-//      state); z1 = l1, z2 = -sg l1 + om l2 (adjoint state, transposed direct form II). (Before that: all threads sum C over the rows.)
-//   2. P[k][m] = C FW[k][m] for the S (L + 2) signal rows on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: D[i][j] in lane 16 (i % 4) + j,
-//      register i / 4 - not the f32 instruction's row order; tools/mfma64_probe.hip), then thread (which, k, n): the products of
-//      F[k][n] with P[k][n + 2 - j]: the lag sums sum g w[n], sum g w[n - 1], sum g w[n - 2], sum o w[n - 1], sum o w[n - 2] after a
-//      16-lane reduction over n.
-//   3. thread k: dL/d(b0, b1, b2, a1, a2) = (the three g sums, minus the two o sums) -> emit_section_grads.
-template <int S>
-__global__ void __launch_bounds__(256)
-sos_gram_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const double* __restrict__ gram, int B, int C, int mode,
-                         float* __restrict__ gout) {
-    constexpr int L = 16, D = L + 2 * S, NW = L + 2, NP = S * NW, NPB = (NP + 15) / 16;
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    __shared__ double Cm[32][33];                   // C[v][u], zero beyond D
-    __shared__ double FW[NP][D], FG[S][L][D], FO[S][L][D];
-    __shared__ double P[NP][33];                    // P[k (L + 2) + m][v] = sum_u C[v][u] FW[k][m][u]
-    __shared__ double lagsum[S][5];
-    __shared__ double cf[S][8];                     // b0 b1 b2 a1 a2 (normalised), sg, om, 1 / om per section
-    const int tid = threadIdx.x, item = blockIdx.x;
-    const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
-    PTRACE(50, 0);
-    // every global read of the kernel up front and in flight together (one trip to L2 instead of one per section / per matrix entry)
-    if (tid < S) {
-        const double* d = d0 + tid * DT_STRIDE;
-        const double a1 = d[DT_B0 + 3], a2 = d[DT_B0 + 4], sg = -0.5 * a1;
-        double om = sqrt(fabs(sg * sg - a2));
-        om = om < OM_MIN ? OM_MIN : om;
-        cf[tid][0] = d[DT_B0]; cf[tid][1] = d[DT_B0 + 1]; cf[tid][2] = d[DT_B0 + 2]; cf[tid][3] = a1; cf[tid][4] = a2;
-        cf[tid][5] = sg; cf[tid][6] = om; cf[tid][7] = 1.0 / om;
-    }
-    // C[v][u] (v, u < 32; zero beyond D) gathered from the kernel's register layout; rows 16.. are the entries of the adjoint-state
-    // image, component c at entry state_pos(c)
-    double cs[4] = {0.0, 0.0, 0.0, 0.0};
-    int src[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, dv = e >> 5, du = e & 31;
-        const int sv = dv < 16 ? dv : 16 + state_pos<S>(dv - 16 < 2 * S ? dv - 16 : 0);
-        src[q] = (dv < D && du < D) ? (((sv >> 4) * 2 + (du >> 4)) * 4 + (sv & 3)) * 64 + ((sv & 15) >> 2) * 16 + (du & 15) : -1;
-    }
-    {
-        const double* g0 = gram + (size_t)item * C * 1024;
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cs[q] += src[q] >= 0 ? g0[(size_t)c * 1024 + src[q]] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q;
-        Cm[e >> 5][e & 31] = cs[q];
-    }
-    __syncthreads();
-    PTRACE(51, 0);
-    if (tid < 128) {
-        const int j = tid & 63, adj = tid >> 6;
-        if (j < D) {
-            double sig[L];
-#pragma unroll
-            for (int n = 0; n < L; ++n) sig[n] = (j == n) ? 1.0 : 0.0;
-            for (int i = 0; i < S; ++i) {
-                const int k = adj ? S - 1 - i : i;
-                const double b0 = cf[k][0], b1 = cf[k][1], b2 = cf[k][2], a1 = cf[k][3], a2 = cf[k][4], sg = cf[k][5], om = cf[k][6], iom = cf[k][7];
-                const double c1 = (j == L + 2 * i) ? 1.0 : 0.0, c2 = (j == L + 2 * i + 1) ? 1.0 : 0.0;   // the unit state component, if it is this section's
-                if (!adj) {
-                    double w2 = c2 * iom, w1 = c1 + sg * iom * c2;
-                    FW[k * NW][j] = w2; FW[k * NW + 1][j] = w1;
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const double w = fma(-a1, w1, fma(-a2, w2, sig[n]));      // (one FMA on the recurrence's dependent chain)
-                        sig[n] = fma(b0, w, fma(b1, w1, b2 * w2));
-                        FW[k * NW + n + 2][j] = w;
-                        w2 = w1; w1 = w;
-                    }
-                } else {
-                    double z1 = c1, z2 = -sg * c1 + om * c2;
-#pragma unroll
-                    for (int n = L - 1; n >= 0; --n) {
-                        const double g = sig[n];
-                        FG[k][n][j] = g;
-                        const double o = fma(b0, g, z1);
-                        z1 = fma(-a1, o, fma(b1, g, z2));
-                        z2 = fma(-a2, o, b2 * g);
-                        FO[k][n][j] = o;
-                        sig[n] = o;
-                    }
-                }
-            }
-        }
-    }
-    PTRACE(52, 0);
-    __syncthreads();
-    PTRACE(53, 0);
-    {   // P^T (32 x NP) = C (32 x 32) FW^T (32 x NP): 2 x NPB blocks of 16 x 16, 8 steps of 4 each, dealt out over the four waves
-        const int wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
-        constexpr int NB = (2 * NPB + 3) / 4;            // blocks per wave; their accumulator chains run side by side
-        d4 acc[NB];
-        int pmr[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int p0 = 16 * ((wave + 4 * q) >> 1);
-            acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-            pmr[q] = p0 + li < NP ? p0 + li : NP - 1;    // (pad columns of the last block and blocks past the end: any row - their results are not stored)
-        }
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const int u = 4 * st + lk, uu = u < D ? u : D - 1;           // (C is zero beyond D)
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * ((wave + 4 * q) & 1) + li][u], FW[pmr[q]][uu], acc[q], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int blk = wave + 4 * q, v0 = 16 * (blk & 1), p0 = 16 * (blk >> 1);
-            if (blk < 2 * NPB && p0 + li < NP) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) P[p0 + li][v0 + lk + 4 * r] = acc[q][r];
-            }
-        }
-    }
-    __syncthreads();
-    PTRACE(54, 0);
-    {
-        const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;
-        const bool on = tid < 2 * 16 * S;
-        double v3[3] = {0.0, 0.0, 0.0};
-        if (on) {
-            const double* F = which ? &FO[k][n][0] : &FG[k][n][0];
-            double f[D];
-#pragma unroll
-            for (int v = 0; v < D; ++v) f[v] = F[v];
-#pragma unroll
-            for (int jl = 0; jl < 3; ++jl) {
-                const double* pr = &P[k * NW + n + 2 - jl][0];
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int v = 0; v < D; v += 2) { a0 = fma(f[v], pr[v], a0); a1 = fma(f[v + 1], pr[v + 1], a1); }
-                v3[jl] = a0 + a1;
-            }
-        }
-#pragma unroll
-        for (int jl = 0; jl < 3; ++jl) {        // sum over the 16 samples n = the 16 lanes of a DPP row
-            double a = v3[jl];
-            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
-            v3[jl] = a;
-        }
-        if (on && n == 0) {
-            if (!which) { lagsum[k][0] = v3[0]; lagsum[k][1] = v3[1]; lagsum[k][2] = v3[2]; }
-            else { lagsum[k][3] = v3[1]; lagsum[k][4] = v3[2]; }
-        }
-    }
-    __syncthreads();
-    PTRACE(55, 0);
-    if (tid < S) {
-        const double g5[5] = {lagsum[tid][0], lagsum[tid][1], lagsum[tid][2], -lagsum[tid][3], -lagsum[tid][4]};
-        emit_section_grads(d0 + tid * DT_STRIDE, g5, B, S, mode, gout, item, tid);
-    }
-    PTRACE(56, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2298,7 +2536,7 @@ inline bool use_bwd8cp(int S) {
 // the same for segmented rows (sos_bwd_gram_kernel<SEG = 1> + a finalize launch instead of sos_bwd_kernel<SEG = 1> finalizing in its last
 // workgroup): DASP_SEG_GRAM=0 / 1 at run time overrides the build's default
 #ifndef DASP_SEG_GRAM
-#define DASP_SEG_GRAM 0     // measured (profiles/r04/seg_gram_ab.log): the finalize launch it needs costs more than the kernel saves at the reference's
+#define DASP_SEG_GRAM 1     // (round 4, with a finalize launch of its own:) measured (profiles/r04/seg_gram_ab.log): the finalize launch it needs costs more than the kernel saves at the reference's
                             // training batches - EQ fwd+bwd (8 / 16, 2, 131072) 0.081 -> 0.090 / 0.097 -> 0.106 ms, (16, 1, 131072) without gx 0.080 -> 0.083,
                             // (32, 2, 131072) 0.131 = 0.131. What it buys is the Gram kernel's accuracy on segmented rows (worst control gradient of the
                             // randomized sweep 1.0e-4 -> 2e-5): opt-in.
@@ -2432,8 +2670,10 @@ int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, doubl
 
 /* The same design from 3 S separate control vectors (host array of device pointers, [3 k + dir] -> Bs values): what
  * functional.parametric_eq receives (functional.py:118-139), without packing them first. */
+// want_basis (with Tseg > 0): a backward pass will follow - two more waves leave the basis responses of the Gram finalize step behind the
+// segment matrices (dasp_sos_segtab_doubles)
 static int peq_prepare_rows_impl(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
-                                 long Tseg, double* segtab, void* stream) {
+                                 long Tseg, double* segtab, int want_basis, void* stream) {
     if (!rows || !types || !tab || !dtab || Bs <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1))))) return DASP_ERR_ARG;
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
@@ -2447,14 +2687,15 @@ static int peq_prepare_rows_impl(const float* const* rows, int Bs, int S, const 
             spec.rows[i] = rows[i];
         }
         spec.sample_rate = sample_rate;
-        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bs), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab,
-                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr);
+        double* basis = Tseg > 0 && want_basis ? segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS) : nullptr;
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bs), dim3(basis ? 384 : 256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab,
+                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis);
         return check_launch();
     });
 }
 int dasp_peq_prepare_rows(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
                           void* stream) {
-    return peq_prepare_rows_impl(rows, Bs, S, types, sample_rate, tab, dtab, 0, nullptr, stream);
+    return peq_prepare_rows_impl(rows, Bs, S, types, sample_rate, tab, dtab, 0, nullptr, 0, stream);
 }
 
 int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, float* carries, int B, int C, long N,
@@ -2632,7 +2873,10 @@ long dasp_sos_segment_tiles(long rows, long N) {
     return (nt + T - 1) / T > 1 ? T : 0;
 }
 long dasp_sos_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_sos_num_tiles(N) + Tseg - 1) / Tseg : 1; }
-long dasp_sos_segtab_doubles(int S) { return 2L * (2 * S) * (2 * S); }
+// per item: the segment transition matrices of both systems; behind the Bs items' matrices, per item, the basis responses of the Gram
+// finalize step (GramFin<S>::BASIS doubles: written by the design launch of dasp_peq_forward*, read by dasp_peq_backward)
+static long sos_basis_doubles(int S) { return (long)(S * 18 + 2 * S * 16) * (16 + 2 * S); }
+long dasp_sos_segtab_doubles(int S) { return 2L * (2 * S) * (2 * S) + sos_basis_doubles(S); }
 long dasp_sos_seg_floats(long rows, long N, int S, long Tseg) { return 2 * rows * dasp_sos_segments(N, Tseg) * 2 * S; }
 
 int dasp_sos_segment_prepare(const double* dtab, int Bs, int S, long Tseg, double* segtab, void* stream) {
@@ -2706,14 +2950,24 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
         hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 2>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, (float*)nullptr,
                            (float*)nullptr, C, (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg,
                            (const float*)nullptr, z, const_cast<float*>(tab), segtab, start);
-        if (use_seg_gram() && !(flags & BWD_NOGC)) {      // (the caller finalizes: grad_finalize_impl)
+        if (use_seg_gram() && !(flags & BWD_NOGC)) {
+            // one Gram matrix per (row, segment); with one table per item and the basis responses in place (fin_dtab given: dasp_peq_backward
+            // after dasp_peq_forward*) the finalize step runs inside this launch: the last workgroup of an item to arrive maps its matrices
+            // to the gradients (gram_fused_tail) - otherwise the caller finalizes (grad_finalize_impl)
             if (!aligned16(partials)) return DASP_ERR_ARG;
+            static_assert(GramFin<SS>::BASIS == (SS * 18 + 2 * SS * 16) * (16 + 2 * SS), "sos_basis_doubles");
             double* gm = reinterpret_cast<double*>(partials);
+            GramFuse fz = {};
+            if (fin_dtab && fin_gout && !bc) {
+                fz.on = 1; fz.B = B; fz.mode = fin_mode; fz.dtab = fin_dtab; fz.gout = fin_gout;
+                fz.basis = segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS);
+                fz.cnt_tab = const_cast<float*>(tab);
+            }
             const dim3 g(B * C * G), b(64 * kWB);
             if (flags & BWD_NOGX)
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start);
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start, fz);
             else
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start);
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start, fz);
             return check_launch();
         }
         const bool fuse = fin_dtab && fin_gout && !bc && !(flags & BWD_NOGC);
@@ -2748,7 +3002,7 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
                      const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
                      void* stream) {
     // (segmented rows: the segment transition matrices come out of the design launch - no dasp_sos_segment_prepare launch)
-    const int rc = peq_prepare_rows_impl(rows, Bp, S, types, sample_rate, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, stream);
+    const int rc = peq_prepare_rows_impl(rows, Bp, S, types, sample_rate, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, carries != nullptr, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
     return dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
@@ -2760,7 +3014,7 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
 // cascade in the two launches of dasp_peq_forward. dasp_peq_backward with mode 1 then returns the gradient w.r.t. the normalised tensor.
 // dasp_peq_prepare_norm is the design step on its own (tables only).
 static int peq_prepare_norm_impl(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
-                                 unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, void* stream) {
+                                 unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, int want_basis, void* stream) {
     if (!pn || !types || !lo || !span || !tab || !dtab || Bp <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1))))) return DASP_ERR_ARG;
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
@@ -2773,24 +3027,25 @@ static int peq_prepare_norm_impl(const float* pn, int Bp, int S, const int* type
         spec.sample_rate = sample_rate;
         spec.norm = 1;
         spec.flag = flag;
-        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bp), dim3(256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab,
-                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr);
+        double* basis = Tseg > 0 && want_basis ? segtab + (size_t)Bp * 2 * (2 * SS) * (2 * SS) : nullptr;
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bp), dim3(basis ? 384 : 256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab,
+                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis);
         return check_launch();
     });
 }
 /* Tseg > 0 (a power of two) with segtab: the design launch also leaves the segment transition matrices of dasp_sos_segment_prepare. */
 int dasp_peq_prepare_norm_seg(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                               unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, void* stream) {
-    return peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg, segtab, stream);
+    return peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg, segtab, 0, stream);
 }
 int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                           unsigned* flag, float* tab, double* dtab, void* stream) {
-    return peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, 0, nullptr, stream);
+    return peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, 0, nullptr, 0, stream);
 }
 int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                           unsigned* flag, float* tab, double* dtab, const float* x, float* y, float* carries, int B, int C, long N, long Tseg,
                           double* segtab, float* segbuf, void* stream) {
-    const int rc = peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, stream);
+    const int rc = peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, carries != nullptr, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
     return dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
@@ -2805,7 +3060,7 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
     if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 1, stream);
     // one table per item: the last (row, segment) workgroup of an item finalizes it inside the backward launch (DASP_SEG_FUSED_FINALIZE=0
     // at build time keeps the separate launch); a shared table (Bp == 1 < B) always takes the separate launch
-    const bool fuse = DASP_SEG_FUSED_FINALIZE && !use_seg_gram() && partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
+    const bool fuse = DASP_SEG_FUSED_FINALIZE && partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
     const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, fuse ? dtab : nullptr, mode,
                                              fuse ? gout : nullptr, stream);
     if (rc != DASP_OK || !partials || fuse) return rc;

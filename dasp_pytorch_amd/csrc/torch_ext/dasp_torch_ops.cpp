@@ -1,6 +1,9 @@
-// torch.ops.dasp.*: the PyTorch-ROCm extension over the C ABI (include/dasp_hip.h) for the effect chain of the reference's training loop
-// (examples/style_transfer.py:150-154): parametric EQ on normalised parameters, compressor / expander on control rows, noise-shaped
-// reverb on control matrices, and the chain's fused control de-normalisation. What SURVEY 8(b) / BASELINE north_star specify: ops
+// torch.ops.dasp.*: the PyTorch-ROCm extension over the C ABI (include/dasp_hip.h). Two groups of ops:
+//   * the reference's own callables (round 5) - parametric_eq on its 3 S control tensors (dasp_pytorch/functional.py:118-139), dynamics on
+//     the six controls of compressor / expander (:275-286), gain (:10), distortion (:65), sosfilt (signal.py:136), noise_shaped_reverb on its
+//     12 + 12 + 1 control tensors (functional.py:406-436): dasp_pytorch_amd.functional routes float32 ROCm tensors through them;
+//   * the effect chain of the reference's training loop (examples/style_transfer.py:150-154) on normalised parameters (round 4):
+//     parametric_eq_norm, dynamics_ctl, reverb on control matrices, and the chain's fused control de-normalisation chain_controls. What SURVEY 8(b) / BASELINE north_star specify: ops
 // registered with TORCH_LIBRARY (schemas visible to torch.compile / torch.library.opcheck), forward + hand-derived adjoint as
 // torch::autograd::Function in C++ (the backward pass runs on autograd's worker thread without the Python interpreter), errors as
 // TORCH_CHECK -> RuntimeError. No kernels live here: every number comes from libdasp_hip.so, launched on torch's current HIP stream.
@@ -44,6 +47,14 @@ Tensor f32c(const Tensor& t) { return t.to(at::kFloat).contiguous(); }
 float* fp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
 double* dp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<double>() : nullptr; }
 long round64(long n) { return (n + 63) & ~63L; }
+// the optional range-flag word of the normalised ops: one int32 on x's device into which the kernels OR a bit per parameter column that
+// left [0, 1] (the reference's ValueError, modules.py:83-84; read back by dasp_pytorch_amd.modules when it chooses to - never cleared here)
+unsigned* flag_ptr(const c10::optional<Tensor>& f, const Tensor& x) {
+    if (!f.has_value() || !f->defined()) return nullptr;
+    TORCH_CHECK(f->is_cuda() && f->device() == x.device() && f->scalar_type() == at::kInt && f->numel() >= 1 && f->is_contiguous(),
+                "dasp: range_flag must be an int32 tensor on x's device");
+    return reinterpret_cast<unsigned*>(f->data_ptr<int>());
+}
 Tensor empty_f32(long n, const Tensor& like) { return at::empty({n}, like.options().dtype(at::kFloat)); }
 
 // ---- parametric EQ on the normalised (Bp, 3 S) tensor (ops.ParametricEQNormFunction; dasp_peq_forward_norm / dasp_peq_backward) ---------
@@ -70,7 +81,8 @@ PeqDims peq_check(const Tensor& x, const Tensor& pn, at::IntArrayRef types, at::
 }
 // y, work32 = [tab | carries] (what the adjoint reads), work64 = [dtab | segtab]
 std::tuple<Tensor, Tensor, Tensor> peq_norm_forward(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types,
-                                                    at::ArrayRef<double> lo, at::ArrayRef<double> span, int64_t tseg, bool save) {
+                                                    at::ArrayRef<double> lo, at::ArrayRef<double> span, int64_t tseg, bool save,
+                                                    const c10::optional<Tensor>& range_flag) {
     const PeqDims d = peq_check(x, pn, types, lo, span);
     c10::DeviceGuard guard(x.device());
     const Tensor x32 = x.contiguous(), pn32 = f32c(pn);
@@ -86,7 +98,7 @@ std::tuple<Tensor, Tensor, Tensor> peq_norm_forward(const Tensor& x, const Tenso
     std::vector<int> ty(types.begin(), types.end());
     float* w = work32.data_ptr<float>();
     double* w64 = work64.data_ptr<double>();
-    check_rc(dasp_peq_forward_norm(pn32.data_ptr<float>(), (int)d.Bp, (int)d.S, ty.data(), sample_rate, lo.data(), span.data(), nullptr, w, w64,
+    check_rc(dasp_peq_forward_norm(pn32.data_ptr<float>(), (int)d.Bp, (int)d.S, ty.data(), sample_rate, lo.data(), span.data(), flag_ptr(range_flag, x32), w, w64,
                                    x32.data_ptr<float>(), y.data_ptr<float>(), save ? w + n_tab : nullptr, (int)d.B, (int)d.C, d.N, tseg,
                                    tseg ? w64 + n_dt : nullptr, fp(segbuf), stream_of(x32)),
              "dasp_peq_forward_norm");
@@ -95,8 +107,9 @@ std::tuple<Tensor, Tensor, Tensor> peq_norm_forward(const Tensor& x, const Tenso
 // -> (gx or empty, gp (Bp, 3 S) or empty). Reads the forward call's tables and chunk states; its own scratch (partial sums, segment
 // pre-pass buffers) is allocated here, so the op leaves its inputs as it found them (the completion counter word inside `tab` is returned
 // to zero by the kernels).
-std::tuple<Tensor, Tensor> peq_norm_backward(const Tensor& x, const Tensor& gy, const Tensor& work32, const Tensor& work64, int64_t Bp, int64_t S,
-                                             int64_t tseg, bool need_gx, bool need_gp) {
+// mode 1: gp (Bp, 3 S), the layout of the normalised parameter tensor; mode 2: gp (3 S, Bp), one contiguous row per control tensor
+std::tuple<Tensor, Tensor> peq_backward_impl(const Tensor& x, const Tensor& gy, const Tensor& work32, const Tensor& work64, int64_t Bp, int64_t S,
+                                             int64_t tseg, bool need_gx, bool need_gp, int64_t mode) {
     need_device(x, "x");
     same_device(x, gy, "grad_output");
     TORCH_CHECK(gy.sizes() == x.sizes(), "dasp::_peq_norm_backward: grad_output ", gy.sizes(), " does not match x ", x.sizes());
@@ -104,8 +117,10 @@ std::tuple<Tensor, Tensor> peq_norm_backward(const Tensor& x, const Tensor& gy, 
     const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
     const Tensor x32 = x.contiguous(), g32 = f32c(gy);
     Tensor gx = need_gx ? at::empty_like(x32) : at::empty({0}, x32.options());
-    Tensor gp = need_gp ? at::empty({B, S, 3}, x32.options()) : at::empty({0}, x32.options());
-    if (x32.numel() == 0 || (!need_gx && !need_gp)) return {gx, need_gp ? at::zeros({Bp, 3 * S}, x32.options()) : gp};
+    TORCH_CHECK(mode == 1 || mode == 2, "dasp::_peq_backward: gradient layout 1 (Bp, 3 S) or 2 (3 S, Bp)");
+    Tensor gp = need_gp ? (mode == 1 ? at::empty({B, S, 3}, x32.options()) : at::empty({3 * S, B}, x32.options())) : at::empty({0}, x32.options());
+    if (x32.numel() == 0 || (!need_gx && !need_gp))
+        return {gx, need_gp ? (mode == 1 ? at::zeros({Bp, 3 * S}, x32.options()) : at::zeros({3 * S, Bp}, x32.options())) : gp};
     const long n_tab = round64(Bp * dasp_sos_table_floats((int)S));
     const long n_dt = Bp * dasp_sos_dtab_doubles((int)S);
     const long G = dasp_sos_segments(N, tseg);
@@ -115,32 +130,37 @@ std::tuple<Tensor, Tensor> peq_norm_backward(const Tensor& x, const Tensor& gy, 
     Tensor segbuf = tseg ? empty_f32(round64(dasp_sos_seg_floats(B * C, N, (int)S, tseg)), x32) : Tensor();
     float* w = work32.data_ptr<float>();
     double* w64 = work64.data_ptr<double>();
-    // mode 1: gout (B, S, 3) = the layout of the (Bp, 3 S) parameter tensor
+    // mode 1: gout (B, S, 3) = the layout of the (Bp, 3 S) parameter tensor; mode 2: gout (3 S, B)
     check_rc(dasp_peq_backward(w, w64, (int)Bp, x32.data_ptr<float>(), g32.data_ptr<float>(), w + n_tab, need_gx ? gx.data_ptr<float>() : nullptr,
-                               fp(partials), 1, need_gp ? gp.data_ptr<float>() : nullptr, (int)B, (int)C, N, (int)S, tseg,
+                               fp(partials), (int)mode, need_gp ? gp.data_ptr<float>() : nullptr, (int)B, (int)C, N, (int)S, tseg,
                                tseg ? w64 + n_dt : nullptr, fp(segbuf), stream_of(x32)),
              "dasp_peq_backward");
     if (need_gp) {
-        if (Bp == 1 && B != 1) gp = gp.sum(0, /*keepdim=*/true);             // one filter set shared by the batch (functional.py:208-220)
-        gp = gp.reshape({Bp, 3 * S});
+        if (Bp == 1 && B != 1) gp = gp.sum(mode == 1 ? 0 : 1, /*keepdim=*/true);   // one filter set shared by the batch (functional.py:208-220)
+        if (mode == 1) gp = gp.reshape({Bp, 3 * S});
     }
     return {gx, gp};
 }
-Tensor peq_norm_device(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
+std::tuple<Tensor, Tensor> peq_norm_backward(const Tensor& x, const Tensor& gy, const Tensor& work32, const Tensor& work64, int64_t Bp, int64_t S,
+                                             int64_t tseg, bool need_gx, bool need_gp) {
+    return peq_backward_impl(x, gy, work32, work64, Bp, S, tseg, need_gx, need_gp, 1);
+}
+Tensor peq_norm_device(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span,
+                       const c10::optional<Tensor>& range_flag) {
     const PeqDims d = peq_check(x, pn, types, lo, span);
-    return std::get<0>(peq_norm_forward(x, pn, sample_rate, types, lo, span, sos_segment_tiles(d.B * d.C, d.N), false));
+    return std::get<0>(peq_norm_forward(x, pn, sample_rate, types, lo, span, sos_segment_tiles(d.B * d.C, d.N), false, range_flag));
 }
 struct PeqNormFn : public torch::autograd::Function<PeqNormFn> {
     static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& pn, double sample_rate, std::vector<int64_t> types,
-                          std::vector<double> lo, std::vector<double> span) {
+                          std::vector<double> lo, std::vector<double> span, const c10::optional<Tensor>& range_flag) {
         const PeqDims d = peq_check(x, pn, types, lo, span);
         const int64_t tseg = sos_segment_tiles(d.B * d.C, d.N);
         const bool need = x.requires_grad() || pn.requires_grad();
         at::AutoDispatchBelowADInplaceOrView below;
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_norm_forward", "")
                              .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, double, at::IntArrayRef, at::ArrayRef<double>,
-                                                                       at::ArrayRef<double>, int64_t, bool)>();
-        auto [y, w32, w64] = op.call(x, pn, sample_rate, types, lo, span, tseg, need);
+                                                                       at::ArrayRef<double>, int64_t, bool, const c10::optional<Tensor>&)>();
+        auto [y, w32, w64] = op.call(x, pn, sample_rate, types, lo, span, tseg, need, range_flag);
         if (need) {
             ctx->save_for_backward({x, w32, w64});
             ctx->saved_data["Bp"] = d.Bp; ctx->saved_data["S"] = d.S; ctx->saved_data["tseg"] = tseg;
@@ -156,11 +176,12 @@ struct PeqNormFn : public torch::autograd::Function<PeqNormFn> {
         auto [gx, gp] = op.call(saved[0], grads[0], saved[1], saved[2], ctx->saved_data["Bp"].toInt(), ctx->saved_data["S"].toInt(),
                                 ctx->saved_data["tseg"].toInt(), need_gx, need_gp);
         if (need_gp) gp = gp.to((at::ScalarType)ctx->saved_data["pn_dtype"].toInt());
-        return {need_gx ? gx : Tensor(), need_gp ? gp : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {need_gx ? gx : Tensor(), need_gp ? gp : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
-Tensor peq_norm_autograd(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
-    return PeqNormFn::apply(x, pn, sample_rate, types.vec(), lo.vec(), span.vec());
+Tensor peq_norm_autograd(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span,
+                         const c10::optional<Tensor>& range_flag) {
+    return PeqNormFn::apply(x, pn, sample_rate, types.vec(), lo.vec(), span.vec(), range_flag);
 }
 
 // ---- compressor / expander on (bs, 5) control rows (ops.DynamicsCtlFunction; dasp_dynamics_forward(_seg) / _backward(_seg)) -------------
@@ -271,7 +292,7 @@ Tensor dyn_autograd(const Tensor& x, const Tensor& ctl, int64_t mode, double sam
 // ---- the chain's control de-normalisation (ops.ChainControlsFunction; dasp_chain_controls / _backward) -------------------------------------
 // lo, span: 32 floats each (compressor 0-5, reverb 6-30, gain 31)
 std::tuple<Tensor, Tensor, Tensor, Tensor> chain_controls(const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, at::ArrayRef<double> lo,
-                                                          at::ArrayRef<double> span) {
+                                                          at::ArrayRef<double> span, const c10::optional<Tensor>& range_flag) {
     need_device(comp_pn, "comp_params");
     same_device(comp_pn, reverb_pn, "reverb_params");
     same_device(comp_pn, gain_pn, "gain_params");
@@ -288,7 +309,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> chain_controls(const Tensor& comp_pn,
         for (int i = 0; i < 32; ++i) { lof[i] = (float)lo[i]; spf[i] = (float)span[i]; }
         const Tensor c = f32c(comp_pn), r = f32c(reverb_pn), g = f32c(gain_pn);
         check_rc(dasp_chain_controls(c.data_ptr<float>(), r.data_ptr<float>(), g.data_ptr<float>(), lof, spf, ctl.data_ptr<float>(), gains.data_ptr<float>(),
-                                     decays.data_ptr<float>(), mix.data_ptr<float>(), (int)B, stream_of(comp_pn)),
+                                     decays.data_ptr<float>(), mix.data_ptr<float>(), flag_ptr(range_flag, comp_pn), (int)B, stream_of(comp_pn)),
                  "dasp_chain_controls");
     }
     return {ctl, gains, decays, mix};
@@ -314,11 +335,12 @@ std::tuple<Tensor, Tensor, Tensor> chain_controls_backward(const Tensor& gctl, c
 }
 struct ChainControlsFn : public torch::autograd::Function<ChainControlsFn> {
     static variable_list forward(AutogradContext* ctx, const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, std::vector<double> lo,
-                                 std::vector<double> span) {
+                                 std::vector<double> span, const c10::optional<Tensor>& range_flag) {
         at::AutoDispatchBelowADInplaceOrView below;
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::chain_controls", "")
-                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, at::ArrayRef<double>, at::ArrayRef<double>)>();
-        auto [ctl, gains, decays, mix] = op.call(comp_pn, reverb_pn, gain_pn, lo, span);
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, at::ArrayRef<double>, at::ArrayRef<double>,
+                                                                               const c10::optional<Tensor>&)>();
+        auto [ctl, gains, decays, mix] = op.call(comp_pn, reverb_pn, gain_pn, lo, span, range_flag);
         ctx->saved_data["span"] = span;
         ctx->saved_data["B"] = comp_pn.size(0);
         ctx->saved_data["dt"] = std::vector<int64_t>{(int64_t)comp_pn.scalar_type(), (int64_t)reverb_pn.scalar_type(), (int64_t)gain_pn.scalar_type()};
@@ -336,12 +358,12 @@ struct ChainControlsFn : public torch::autograd::Function<ChainControlsFn> {
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_chain_controls_backward", "")
                              .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, at::ArrayRef<double>)>();
         auto [gc, gr, gg] = op.call(z(g[0], {B, 5}), z(g[1], {B, 12}), z(g[2], {B, 12}), z(g[3], {B}), span);
-        return {gc.to((at::ScalarType)dt[0]), gr.to((at::ScalarType)dt[1]), gg.to((at::ScalarType)dt[2]), Tensor(), Tensor()};
+        return {gc.to((at::ScalarType)dt[0]), gr.to((at::ScalarType)dt[1]), gg.to((at::ScalarType)dt[2]), Tensor(), Tensor(), Tensor()};
     }
 };
 std::tuple<Tensor, Tensor, Tensor, Tensor> chain_controls_autograd(const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, at::ArrayRef<double> lo,
-                                                                   at::ArrayRef<double> span) {
-    auto r = ChainControlsFn::apply(comp_pn, reverb_pn, gain_pn, lo.vec(), span.vec());
+                                                                   at::ArrayRef<double> span, const c10::optional<Tensor>& range_flag) {
+    auto r = ChainControlsFn::apply(comp_pn, reverb_pn, gain_pn, lo.vec(), span.vec(), range_flag);
     return {r[0], r[1], r[2], r[3]};
 }
 
@@ -490,18 +512,503 @@ Tensor reverb_autograd(const Tensor& x, const c10::optional<Tensor>& noise, cons
     return ReverbFn::apply(x, noise, fspec, gains, decays, mix, L, taps, nb, seed, seed_offset, decay_bound);
 }
 
+
+// =====================================================================================================================================
+// The reference's own callables (round 5): the signatures of dasp_pytorch.functional / .signal on float32 ROCm tensors.
+// =====================================================================================================================================
+
+// ---- functional.parametric_eq on its 3 S control tensors (functional.py:118-139; ops.ParametricEQFunction; dasp_peq_forward / _backward) ----
+// controls[3 k + c]: control c (0 gain_db, 1 cutoff_freq, 2 q_factor) of section k, Bp = 1 or bs values each, any shape; they are read in
+// place by the design kernel (a host array of device pointers: no packing copy) and their gradients come back as the rows of one (3 S, Bp)
+// matrix - one contiguous row per control tensor, no stack node, no 3 S copy kernels.
+struct PeqRows { int64_t B, C, N, Bp, S; };
+PeqRows peq_rows_check(const Tensor& x, at::TensorList controls, at::IntArrayRef types) {
+    need_device(x, "x");
+    TORCH_CHECK(x.dim() == 3, "dasp::parametric_eq: x must be (bs, chs, seq_len), got ", x.sizes());
+    TORCH_CHECK(x.scalar_type() == at::kFloat, "dasp::parametric_eq computes in float32; got ", x.scalar_type());
+    const int64_t S = (int64_t)types.size();
+    TORCH_CHECK(dasp_sos_supported_sections((int)S), "no kernel compiled for ", S, " sections");
+    TORCH_CHECK((int64_t)controls.size() == 3 * S, "dasp::parametric_eq: ", 3 * S, " control tensors for ", S, " sections, got ", controls.size());
+    const int64_t Bp = controls[0].numel();
+    for (const Tensor& c : controls) {
+        same_device(x, c, "control");
+        TORCH_CHECK(c.numel() == Bp && (Bp == 1 || Bp == x.size(0)), "parametric_eq controls must each hold ", x.size(0), " (or 1) values, got ", c.numel());
+    }
+    for (int64_t t : types) TORCH_CHECK(t >= 0 && t <= 4, "dasp::parametric_eq: filter type ", t, " (0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass)");
+    return PeqRows{x.size(0), x.size(1), x.size(2), Bp, S};
+}
+std::tuple<Tensor, Tensor, Tensor> peq_forward(const Tensor& x, at::TensorList controls, double sample_rate, at::IntArrayRef types, int64_t tseg, bool save) {
+    const PeqRows d = peq_rows_check(x, controls, types);
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous();
+    Tensor y = at::empty_like(x32);
+    const long n_tab = round64(d.Bp * dasp_sos_table_floats((int)d.S));
+    const long n_car = save ? round64(dasp_sos_carry_floats(d.B * d.C, d.N, (int)d.S)) : 0;
+    const long n_dt = d.Bp * dasp_sos_dtab_doubles((int)d.S), n_st = tseg ? d.Bp * dasp_sos_segtab_doubles((int)d.S) : 0;
+    Tensor work32 = empty_f32(n_tab + n_car, x32);
+    Tensor work64 = at::empty({n_dt + n_st}, x32.options().dtype(at::kDouble));
+    if (x32.numel() == 0) return {y, work32, work64};
+    Tensor segbuf = tseg ? empty_f32(round64(dasp_sos_seg_floats(d.B * d.C, d.N, (int)d.S, tseg)), x32) : Tensor();
+    std::vector<Tensor> keep;               // float32 contiguous views / copies of the controls, alive until the launch is queued
+    std::vector<const float*> rows;
+    keep.reserve(controls.size()); rows.reserve(controls.size());
+    for (const Tensor& c : controls) {
+        keep.push_back(c.scalar_type() == at::kFloat && c.is_contiguous() ? c : c.to(at::kFloat).contiguous());
+        rows.push_back(keep.back().data_ptr<float>());
+    }
+    std::vector<int> ty(types.begin(), types.end());
+    float* w = work32.data_ptr<float>();
+    double* w64 = work64.data_ptr<double>();
+    check_rc(dasp_peq_forward(rows.data(), (int)d.Bp, (int)d.S, ty.data(), sample_rate, w, w64, x32.data_ptr<float>(), y.data_ptr<float>(),
+                              save ? w + n_tab : nullptr, (int)d.B, (int)d.C, d.N, tseg, tseg ? w64 + n_dt : nullptr, fp(segbuf), stream_of(x32)),
+             "dasp_peq_forward");
+    return {y, work32, work64};
+}
+std::tuple<Tensor, Tensor> peq_backward(const Tensor& x, const Tensor& gy, const Tensor& work32, const Tensor& work64, int64_t Bp, int64_t S,
+                                        int64_t tseg, bool need_gx, bool need_gc) {
+    return peq_backward_impl(x, gy, work32, work64, Bp, S, tseg, need_gx, need_gc, 2);
+}
+Tensor peq_device(const Tensor& x, double sample_rate, at::TensorList controls, at::IntArrayRef types) {
+    const PeqRows d = peq_rows_check(x, controls, types);
+    return std::get<0>(peq_forward(x, controls, sample_rate, types, sos_segment_tiles(d.B * d.C, d.N), false));
+}
+struct PeqFn : public torch::autograd::Function<PeqFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, double sample_rate, at::TensorList controls, std::vector<int64_t> types) {
+        const PeqRows d = peq_rows_check(x, controls, types);
+        const int64_t tseg = sos_segment_tiles(d.B * d.C, d.N);
+        bool need = x.requires_grad();
+        for (const Tensor& c : controls) need = need || c.requires_grad();
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, at::TensorList, double, at::IntArrayRef, int64_t, bool)>();
+        auto [y, w32, w64] = op.call(x, controls, sample_rate, types, tseg, need);
+        if (need) {
+            ctx->save_for_backward({x, w32, w64});
+            ctx->saved_data["Bp"] = d.Bp; ctx->saved_data["S"] = d.S; ctx->saved_data["tseg"] = tseg;
+            std::vector<int64_t> dt, shapes;          // dtype and shape of every control: its gradient goes back in both
+            for (const Tensor& c : controls) {
+                dt.push_back((int64_t)c.scalar_type());
+                shapes.push_back(c.dim());
+                for (int64_t v : c.sizes()) shapes.push_back(v);
+            }
+            ctx->saved_data["dt"] = dt; ctx->saved_data["shapes"] = shapes;
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_backward", "")
+                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, bool, bool)>();
+        const int64_t S = ctx->saved_data["S"].toInt(), nc = 3 * S;
+        const bool need_gx = ctx->needs_input_grad(0);
+        bool need_gc = false;
+        for (int64_t i = 0; i < nc; ++i) need_gc = need_gc || ctx->needs_input_grad(1 + i);
+        auto [gx, gc] = op.call(saved[0], grads[0], saved[1], saved[2], ctx->saved_data["Bp"].toInt(), S, ctx->saved_data["tseg"].toInt(), need_gx, need_gc);
+        // forward arguments: x, sample_rate, the 3 S controls, types
+        variable_list out(2 + nc + 1);
+        if (need_gx) out[0] = gx;
+        if (need_gc) {
+            const auto dt = ctx->saved_data["dt"].toIntVector(), shapes = ctx->saved_data["shapes"].toIntVector();
+            size_t pos = 0;
+            for (int64_t i = 0; i < nc; ++i) {
+                const int64_t nd = shapes[pos++];
+                std::vector<int64_t> shp(shapes.begin() + pos, shapes.begin() + pos + nd);
+                pos += nd;
+                if (ctx->needs_input_grad(1 + i)) out[2 + i] = gc.select(0, i).reshape(shp).to((at::ScalarType)dt[i]);
+            }
+        }
+        return out;
+    }
+};
+Tensor peq_autograd(const Tensor& x, double sample_rate, at::TensorList controls, at::IntArrayRef types) {
+    return PeqFn::apply(x, sample_rate, controls, types.vec());
+}
+
+// ---- functional.compressor / expander on their six control tensors (functional.py:275-286; ops.DynamicsFunction) ------------------------------
+// The five controls the kernels read are stacked into the (bs, 5) rows of dasp::dynamics_ctl's entry points; release_ms has no path to the
+// output (functional.py:340,343-344): it is accepted and gets a zero gradient.
+struct Dyn6Fn : public torch::autograd::Function<Dyn6Fn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, double sample_rate, const Tensor& threshold_db, const Tensor& ratio, const Tensor& attack_ms,
+                          const Tensor& release_ms, const Tensor& knee_db, const Tensor& makeup_gain_db, double eps, int64_t lookahead, int64_t mode) {
+        need_device(x, "x");
+        const Tensor* six[6] = {&threshold_db, &ratio, &attack_ms, &release_ms, &knee_db, &makeup_gain_db};
+        bool need = x.requires_grad();
+        for (const Tensor* c : six) {
+            same_device(x, *c, "control");
+            // the reference's .view(-1, 1, 1) against a (bs, 1, seq_len) side chain: no parameter broadcasting (functional.py:330-336)
+            TORCH_CHECK(x.dim() == 3 && c->numel() == x.size(0), "The size of tensor a (", c->numel(), ") must match the size of tensor b (", x.dim() ? x.size(0) : 0,
+                        ") at non-singleton dimension 0");
+            need = need || c->requires_grad();
+        }
+        at::AutoDispatchBelowADInplaceOrView below;
+        const Tensor ctl = at::stack({threshold_db.reshape({-1}).to(at::kFloat), ratio.reshape({-1}).to(at::kFloat), attack_ms.reshape({-1}).to(at::kFloat),
+                                      knee_db.reshape({-1}).to(at::kFloat), makeup_gain_db.reshape({-1}).to(at::kFloat)}, 1);
+        dyn_check(x, ctl, mode, lookahead);
+        const int64_t tseg = dyn_segment_tiles(x.size(0), x.size(2));
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, int64_t, double, double, int64_t, int64_t, bool)>();
+        auto [y, carries, lin] = op.call(x, ctl, mode, sample_rate, eps, lookahead, tseg, need);
+        if (need) {
+            ctx->save_for_backward({x, ctl, carries, lin});
+            ctx->saved_data["mode"] = mode; ctx->saved_data["sr"] = sample_rate; ctx->saved_data["eps"] = eps;
+            ctx->saved_data["look"] = lookahead; ctx->saved_data["tseg"] = tseg;
+            std::vector<int64_t> dt, shapes;
+            for (const Tensor* c : six) {
+                dt.push_back((int64_t)c->scalar_type());
+                shapes.push_back(c->dim());
+                for (int64_t v : c->sizes()) shapes.push_back(v);
+            }
+            ctx->saved_data["dt"] = dt; ctx->saved_data["shapes"] = shapes;
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_backward", "")
+                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, double, double,
+                                                               int64_t, int64_t)>();
+        auto [gx, gctl] = op.call(s[0], s[1], grads[0], s[2], s[3], ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
+                                  ctx->saved_data["eps"].toDouble(), ctx->saved_data["look"].toInt(), ctx->saved_data["tseg"].toInt());
+        const Tensor rows = gctl.t().contiguous();             // (5, bs): threshold, ratio, attack, knee, make-up - one contiguous row each
+        const auto dt = ctx->saved_data["dt"].toIntVector(), shapes = ctx->saved_data["shapes"].toIntVector();
+        // forward arguments: x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead, mode
+        variable_list out(11);
+        if (ctx->needs_input_grad(0)) out[0] = gx;
+        static const int row_of[6] = {0, 1, 2, -1, 3, 4};
+        size_t pos = 0;
+        for (int i = 0; i < 6; ++i) {
+            const int64_t nd = shapes[pos++];
+            std::vector<int64_t> shp(shapes.begin() + pos, shapes.begin() + pos + nd);
+            pos += nd;
+            if (!ctx->needs_input_grad(1 + i)) continue;
+            out[2 + i] = row_of[i] < 0 ? at::zeros(shp, gctl.options().dtype((at::ScalarType)dt[i]))
+                                       : rows.select(0, row_of[i]).reshape(shp).to((at::ScalarType)dt[i]);
+        }
+        return out;
+    }
+};
+Tensor dyn6_device(const Tensor& x, double sample_rate, const Tensor& threshold_db, const Tensor& ratio, const Tensor& attack_ms, const Tensor& release_ms,
+                   const Tensor& knee_db, const Tensor& makeup_gain_db, double eps, int64_t lookahead, int64_t mode) {
+    need_device(x, "x");
+    for (const Tensor* c : {&threshold_db, &ratio, &attack_ms, &release_ms, &knee_db, &makeup_gain_db})
+        TORCH_CHECK(x.dim() == 3 && c->numel() == x.size(0), "The size of tensor a (", c->numel(), ") must match the size of tensor b (", x.dim() ? x.size(0) : 0,
+                    ") at non-singleton dimension 0");
+    const Tensor ctl = at::stack({threshold_db.reshape({-1}).to(at::kFloat), ratio.reshape({-1}).to(at::kFloat), attack_ms.reshape({-1}).to(at::kFloat),
+                                  knee_db.reshape({-1}).to(at::kFloat), makeup_gain_db.reshape({-1}).to(at::kFloat)}, 1);
+    return dyn_device(x, ctl, mode, sample_rate, eps, lookahead);
+}
+Tensor dyn6_autograd(const Tensor& x, double sample_rate, const Tensor& threshold_db, const Tensor& ratio, const Tensor& attack_ms, const Tensor& release_ms,
+                     const Tensor& knee_db, const Tensor& makeup_gain_db, double eps, int64_t lookahead, int64_t mode) {
+    return Dyn6Fn::apply(x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead, mode);
+}
+
+// ---- functional.gain / functional.distortion (functional.py:10-29, :65-78; ops.GainFunction / DistortionFunction) ---------------------------------
+// op 0: y = x 10^(gain_db / 20), one value per batch item; op 1: y = tanh(x 10^(drive_db / 20)), one value per (item, channel) row
+void ew_check(const Tensor& x, const Tensor& ctl, int64_t op) {
+    need_device(x, "x");
+    same_device(x, ctl, op == 0 ? "gain_db" : "drive_db");
+    TORCH_CHECK(op == 0 || op == 1, "dasp::_ew_forward: op 0 (gain) or 1 (distortion)");
+    TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kFloat, "dasp::", op == 0 ? "gain" : "distortion", ": x must be float32 (bs, chs, seq_len), got ", x.scalar_type(), " ", x.sizes());
+    const int64_t want = op == 0 ? x.size(0) : x.size(0) * x.size(1);
+    if (op == 0) {
+        TORCH_CHECK(ctl.numel() == want, "shape '[", x.size(0), ", 1, 1]' is invalid for input of size ", ctl.numel());
+    } else {
+        TORCH_CHECK(ctl.numel() == want, "shape '[", x.size(0), ", ", x.size(1), ", -1]' is invalid for input of size ", ctl.numel());
+    }
+}
+Tensor ew_forward(const Tensor& x, const Tensor& ctl, int64_t op) {
+    ew_check(x, ctl, op);
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous(), c32 = f32c(ctl.reshape({-1}));
+    Tensor y = at::empty_like(x32);
+    if (x32.numel() == 0) return y;
+    const int B = (int)x.size(0), C = (int)x.size(1);
+    const long N = x.size(2);
+    check_rc(op == 0 ? dasp_gain_forward(x32.data_ptr<float>(), c32.data_ptr<float>(), y.data_ptr<float>(), B, C, N, stream_of(x32))
+                     : dasp_distortion_forward(x32.data_ptr<float>(), c32.data_ptr<float>(), y.data_ptr<float>(), B, C, N, stream_of(x32)),
+             op == 0 ? "dasp_gain_forward" : "dasp_distortion_forward");
+    return y;
+}
+std::tuple<Tensor, Tensor> ew_backward(const Tensor& x, const Tensor& ctl, const Tensor& gy, int64_t op) {
+    ew_check(x, ctl, op);
+    same_device(x, gy, "grad_output");
+    TORCH_CHECK(gy.sizes() == x.sizes(), "dasp::_ew_backward: grad_output ", gy.sizes(), " does not match x ", x.sizes());
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous(), c32 = f32c(ctl.reshape({-1})), g32 = f32c(gy);
+    Tensor gx = at::empty_like(x32), gctl = at::empty_like(c32);
+    if (x32.numel() == 0) return {gx, gctl.zero_()};
+    const int B = (int)x.size(0), C = (int)x.size(1);
+    const long N = x.size(2);
+    Tensor partials = empty_f32(dasp_ew_partial_floats((long)B * C, N), x32);
+    check_rc(op == 0 ? dasp_gain_backward(x32.data_ptr<float>(), c32.data_ptr<float>(), g32.data_ptr<float>(), gx.data_ptr<float>(), gctl.data_ptr<float>(),
+                                          partials.data_ptr<float>(), B, C, N, stream_of(x32))
+                     : dasp_distortion_backward(x32.data_ptr<float>(), c32.data_ptr<float>(), g32.data_ptr<float>(), gx.data_ptr<float>(), gctl.data_ptr<float>(),
+                                                partials.data_ptr<float>(), B, C, N, stream_of(x32)),
+             op == 0 ? "dasp_gain_backward" : "dasp_distortion_backward");
+    return {gx, gctl};
+}
+struct EwFn : public torch::autograd::Function<EwFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& ctl, int64_t op) {
+        ew_check(x, ctl, op);
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto fop = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_ew_forward", "").typed<Tensor(const Tensor&, const Tensor&, int64_t)>();
+        Tensor y = fop.call(x, ctl, op);
+        if (x.requires_grad() || ctl.requires_grad()) {
+            ctx->save_for_backward({x, ctl});
+            ctx->saved_data["op"] = op;
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto bop = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_ew_backward", "")
+                              .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, int64_t)>();
+        auto [gx, gctl] = bop.call(s[0], s[1], grads[0], ctx->saved_data["op"].toInt());
+        return {ctx->needs_input_grad(0) ? gx : Tensor(), ctx->needs_input_grad(1) ? gctl.reshape(s[1].sizes()).to(s[1].scalar_type()) : Tensor(), Tensor()};
+    }
+};
+Tensor gain_device(const Tensor& x, const Tensor& gain_db) { return ew_forward(x, gain_db, 0); }
+Tensor gain_autograd(const Tensor& x, const Tensor& gain_db) { return EwFn::apply(x, gain_db, (int64_t)0); }
+Tensor distortion_device(const Tensor& x, const Tensor& drive_db) { return ew_forward(x, drive_db, 1); }
+Tensor distortion_autograd(const Tensor& x, const Tensor& drive_db) { return EwFn::apply(x, drive_db, (int64_t)1); }
+
+// ---- signal.sosfilt_via_fsm on at most 8 sections (signal.py:136-166; ops.SosFiltFunction) -----------------------------------------------
+// sos (Bs, S, 6) rows [b0 b1 b2 a0 a1 a2], Bs = 1 or bs; x (bs, chs, seq_len). S is padded to a compiled section count with identity
+// sections; longer cascades are the caller's successive calls (dasp_pytorch_amd.signal).
+struct SosDims { int64_t B, C, N, Bs, S, Sp; };
+SosDims sos_check(const Tensor& sos, const Tensor& x) {
+    need_device(x, "x");
+    same_device(x, sos, "sos");
+    TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kFloat, "dasp::sosfilt: x must be float32 (bs, chs, seq_len), got ", x.scalar_type(), " ", x.sizes());
+    TORCH_CHECK(sos.dim() == 3 && sos.size(2) == 6, "dasp::sosfilt: sos must be (bs, n_sections, 6), got ", sos.sizes());
+    const int64_t S = sos.size(1);
+    TORCH_CHECK(S >= 1 && S <= 8, "more than 8 sections per call: chain calls (see signal.sosfilt_via_fsm)");
+    TORCH_CHECK(sos.size(0) == 1 || sos.size(0) == x.size(0), "dasp::sosfilt: sos holds ", sos.size(0), " filter sets for a batch of ", x.size(0));
+    return SosDims{x.size(0), x.size(1), x.size(2), sos.size(0), S, (S + 1) / 2 * 2};
+}
+std::tuple<Tensor, Tensor, Tensor> sosfilt_forward(const Tensor& sos, const Tensor& x, int64_t tseg, bool save) {
+    const SosDims d = sos_check(sos, x);
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous();
+    Tensor y = at::empty_like(x32);
+    const long n_tab = round64(d.Bs * dasp_sos_table_floats((int)d.Sp));
+    const long n_car = save ? round64(dasp_sos_carry_floats(d.B * d.C, d.N, (int)d.Sp)) : 0;
+    const long n_dt = d.Bs * dasp_sos_dtab_doubles((int)d.Sp), n_st = tseg ? d.Bs * dasp_sos_segtab_doubles((int)d.Sp) : 0;
+    Tensor work32 = empty_f32(n_tab + n_car, x32);
+    Tensor work64 = at::empty({n_dt + n_st}, x32.options().dtype(at::kDouble));
+    if (x32.numel() == 0) return {y, work32, work64};
+    Tensor s32 = f32c(sos);
+    if (d.Sp != d.S) {                       // identity sections [1 0 0 1 0 0]
+        Tensor pad = at::zeros({d.Bs, d.Sp - d.S, 6}, s32.options());
+        pad.select(2, 0).fill_(1.0);
+        pad.select(2, 3).fill_(1.0);
+        s32 = at::cat({s32, pad}, 1).contiguous();
+    }
+    float* w = work32.data_ptr<float>();
+    double* w64 = work64.data_ptr<double>();
+    void* st = stream_of(x32);
+    check_rc(dasp_sos_prepare(s32.data_ptr<float>(), (int)d.Bs, (int)d.Sp, w, w64, st), "dasp_sos_prepare");
+    if (tseg) {
+        Tensor segbuf = empty_f32(round64(dasp_sos_seg_floats(d.B * d.C, d.N, (int)d.Sp, tseg)), x32);
+        check_rc(dasp_sos_segment_prepare(w64, (int)d.Bs, (int)d.Sp, tseg, w64 + n_dt, st), "dasp_sos_segment_prepare");
+        check_rc(dasp_sosfilt_forward_seg(w, w64 + n_dt, (int)d.Bs, x32.data_ptr<float>(), y.data_ptr<float>(), save ? w + n_tab : nullptr, segbuf.data_ptr<float>(),
+                                          (int)d.B, (int)d.C, d.N, (int)d.Sp, tseg, st),
+                 "dasp_sosfilt_forward_seg");
+    } else {
+        check_rc(dasp_sosfilt_forward(w, (int)d.Bs, x32.data_ptr<float>(), y.data_ptr<float>(), save ? w + n_tab : nullptr, (int)d.B, (int)d.C, d.N, (int)d.Sp, st),
+                 "dasp_sosfilt_forward");
+    }
+    return {y, work32, work64};
+}
+// -> (gx or empty, gsos (Bs, Sp, 6) or empty)
+std::tuple<Tensor, Tensor> sosfilt_backward(const Tensor& x, const Tensor& gy, const Tensor& work32, const Tensor& work64, int64_t Bs, int64_t Sp, int64_t tseg,
+                                            bool need_gx, bool need_gs) {
+    need_device(x, "x");
+    same_device(x, gy, "grad_output");
+    TORCH_CHECK(gy.sizes() == x.sizes(), "dasp::_sosfilt_backward: grad_output ", gy.sizes(), " does not match x ", x.sizes());
+    c10::DeviceGuard guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
+    const Tensor x32 = x.contiguous(), g32 = f32c(gy);
+    Tensor gx = need_gx ? at::empty_like(x32) : at::empty({0}, x32.options());
+    Tensor gs = need_gs ? at::empty({B, Sp, 6}, x32.options()) : at::empty({0}, x32.options());
+    if (x32.numel() == 0 || (!need_gx && !need_gs)) return {gx, need_gs ? at::zeros({Bs, Sp, 6}, x32.options()) : gs};
+    const long n_tab = round64(Bs * dasp_sos_table_floats((int)Sp)), n_dt = Bs * dasp_sos_dtab_doubles((int)Sp);
+    const long G = dasp_sos_segments(N, tseg);
+    TORCH_CHECK(work32.numel() >= n_tab + round64(dasp_sos_carry_floats(B * C, N, (int)Sp)) && work64.numel() >= n_dt + (tseg ? Bs * dasp_sos_segtab_doubles((int)Sp) : 0),
+                "dasp::_sosfilt_backward: work buffers do not belong to a forward call of this shape");
+    Tensor partials = need_gs ? empty_f32(round64(dasp_sos_partial_floats(B * C * G, (int)Sp)), x32) : Tensor();
+    float* w = work32.data_ptr<float>();
+    double* w64 = work64.data_ptr<double>();
+    void* st = stream_of(x32);
+    if (tseg) {
+        Tensor segbuf = empty_f32(round64(dasp_sos_seg_floats(B * C, N, (int)Sp, tseg)), x32);
+        check_rc(dasp_sosfilt_backward_seg_ex(w, w64 + n_dt, (int)Bs, x32.data_ptr<float>(), g32.data_ptr<float>(), w + n_tab, need_gx ? gx.data_ptr<float>() : nullptr,
+                                              fp(partials), segbuf.data_ptr<float>(), (int)B, (int)C, N, (int)Sp, tseg, 0, st),
+                 "dasp_sosfilt_backward_seg_ex");
+        if (need_gs) check_rc(dasp_sos_grad_finalize_ex(w64, (int)Bs, partials.data_ptr<float>(), (int)B, (int)C, (int)Sp, (int)G, 0, 0, gs.data_ptr<float>(), st), "dasp_sos_grad_finalize_ex");
+    } else {
+        check_rc(dasp_sosfilt_backward_grads_ex(w, w64, (int)Bs, x32.data_ptr<float>(), g32.data_ptr<float>(), w + n_tab, need_gx ? gx.data_ptr<float>() : nullptr, fp(partials), 0,
+                                                need_gs ? gs.data_ptr<float>() : nullptr, (int)B, (int)C, N, (int)Sp, 0, st),
+                 "dasp_sosfilt_backward_grads_ex");
+    }
+    if (need_gs && Bs == 1 && B != 1) gs = gs.sum(0, /*keepdim=*/true);
+    return {gx, gs};
+}
+Tensor sosfilt_device(const Tensor& sos, const Tensor& x) {
+    const SosDims d = sos_check(sos, x);
+    return std::get<0>(sosfilt_forward(sos, x, sos_segment_tiles(d.B * d.C, d.N), false));
+}
+struct SosFn : public torch::autograd::Function<SosFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& sos, const Tensor& x) {
+        const SosDims d = sos_check(sos, x);
+        const int64_t tseg = sos_segment_tiles(d.B * d.C, d.N);
+        const bool need = sos.requires_grad() || x.requires_grad();
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_sosfilt_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, int64_t, bool)>();
+        auto [y, w32, w64] = op.call(sos, x, tseg, need);
+        if (need) {
+            ctx->save_for_backward({x, w32, w64});
+            ctx->saved_data["Bs"] = d.Bs; ctx->saved_data["S"] = d.S; ctx->saved_data["Sp"] = d.Sp; ctx->saved_data["tseg"] = tseg;
+            ctx->saved_data["dt"] = (int64_t)sos.scalar_type();
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_sosfilt_backward", "")
+                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, bool, bool)>();
+        const bool need_gs = ctx->needs_input_grad(0), need_gx = ctx->needs_input_grad(1);
+        auto [gx, gs] = op.call(s[0], grads[0], s[1], s[2], ctx->saved_data["Bs"].toInt(), ctx->saved_data["Sp"].toInt(), ctx->saved_data["tseg"].toInt(), need_gx, need_gs);
+        return {need_gs ? gs.narrow(1, 0, ctx->saved_data["S"].toInt()).to((at::ScalarType)ctx->saved_data["dt"].toInt()) : Tensor(), need_gx ? gx : Tensor()};
+    }
+};
+Tensor sosfilt_autograd(const Tensor& sos, const Tensor& x) { return SosFn::apply(sos, x); }
+
+// ---- functional.noise_shaped_reverberation on its 12 + 12 + 1 control tensors (functional.py:406-436) -----------------------------------------
+// The band gains and decays are stacked into the (bs, bands) matrices of dasp::reverb's entry points, their gradients go back as the rows of
+// the transposed gradient matrices (one contiguous row per control; autograd's own stack backward hands out 24 strided columns, each of
+// which AccumulateGrad copies with a kernel of its own).
+struct NsrFn : public torch::autograd::Function<NsrFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, at::TensorList band_gains, at::TensorList band_decays, const Tensor& mix, const c10::optional<Tensor>& noise,
+                          const Tensor& fspec, int64_t L, int64_t taps, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+        need_device(x, "x");
+        const int64_t nb = (int64_t)band_gains.size(), B = x.dim() ? x.size(0) : 0;
+        TORCH_CHECK(nb >= 1 && (int64_t)band_decays.size() == nb, "dasp::noise_shaped_reverb: as many band decays as band gains");
+        TORCH_CHECK(!(noise.has_value() && noise->defined() && noise->requires_grad()) && !fspec.requires_grad(),
+                    "noise_shaped_reverberation: `noise` and the filters are not differentiable inputs (detach them)");
+        bool need = x.requires_grad() || mix.requires_grad();
+        std::vector<Tensor> gv, dv;
+        std::vector<int64_t> dt, shapes;
+        auto note = [&](const Tensor& c) {
+            same_device(x, c, "control");
+            // the reference's torch.stack(...).view(bs, 12) / mix.view(bs, 1, 1) (functional.py:498-544): no broadcasting
+            TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel());
+            need = need || c.requires_grad();
+            dt.push_back((int64_t)c.scalar_type());
+            shapes.push_back(c.dim());
+            for (int64_t v : c.sizes()) shapes.push_back(v);
+        };
+        for (const Tensor& c : band_gains) note(c);
+        for (const Tensor& c : band_decays) note(c);
+        note(mix);
+        at::AutoDispatchBelowADInplaceOrView below;
+        for (const Tensor& c : band_gains) gv.push_back(c.reshape({-1}).to(at::kFloat));
+        for (const Tensor& c : band_decays) dv.push_back(c.reshape({-1}).to(at::kFloat));
+        const Tensor gains = at::stack(gv, 1), decays = at::stack(dv, 1), m32 = mix.reshape({-1}).to(at::kFloat);
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_reverb_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&,
+                                                                               const Tensor&, int64_t, int64_t, int64_t, int64_t, const c10::optional<Tensor>&, double, bool)>();
+        auto [y, A, H, ir] = op.call(x, noise, fspec, gains, decays, m32, L, taps, nb, seed, seed_offset, decay_bound, need);
+        if (need) {
+            const bool has_noise = noise.has_value() && noise->defined(), has_off = seed_offset.has_value() && seed_offset->defined();
+            ctx->save_for_backward({ir, A, H, fspec, gains, decays, m32, has_noise ? *noise : Tensor(), has_off ? *seed_offset : Tensor()});
+            ctx->saved_data["Cx"] = x.size(1); ctx->saved_data["L"] = L; ctx->saved_data["taps"] = taps; ctx->saved_data["nb"] = nb; ctx->saved_data["seed"] = seed;
+            ctx->saved_data["bound"] = decay_bound; ctx->saved_data["has_noise"] = has_noise;
+            ctx->saved_data["dt"] = dt; ctx->saved_data["shapes"] = shapes;
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_reverb_backward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const c10::optional<Tensor>&,
+                                                                               const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, int64_t,
+                                                                               int64_t, const c10::optional<Tensor>&, double)>();
+        const c10::optional<Tensor> noise = s[7].defined() ? c10::optional<Tensor>(s[7]) : c10::nullopt;
+        const c10::optional<Tensor> off = s[8].defined() ? c10::optional<Tensor>(s[8]) : c10::nullopt;
+        const int64_t nb = ctx->saved_data["nb"].toInt();
+        auto [gx, gg, gd, gm] = op.call(grads[0], s[0], s[1], s[2], noise, s[3], s[4], s[5], s[6], ctx->saved_data["Cx"].toInt(), ctx->saved_data["L"].toInt(),
+                                        ctx->saved_data["taps"].toInt(), nb, ctx->saved_data["seed"].toInt(), off, ctx->saved_data["bound"].toDouble());
+        const Tensor ggr = gg.t().contiguous(), gdr = gd.t().contiguous();       // (bands, bs): one contiguous row per control tensor
+        const auto dt = ctx->saved_data["dt"].toIntVector(), shapes = ctx->saved_data["shapes"].toIntVector();
+        // forward arguments: x, the band gains, the band decays, mix, [noise], fspec, num_samples, taps, seed, [seed_offset], decay_bound.
+        // needs_input_grad counts the tensor arguments that were passed: x, 2 bands controls, mix, ...
+        variable_list out(1 + 2 * nb + 1 + 7);
+        if (ctx->needs_input_grad(0)) out[0] = gx;
+        size_t pos = 0;
+        for (int64_t i = 0; i < 2 * nb + 1; ++i) {
+            const int64_t nd = shapes[pos++];
+            std::vector<int64_t> shp(shapes.begin() + pos, shapes.begin() + pos + nd);
+            pos += nd;
+            if (!ctx->needs_input_grad(1 + i)) continue;
+            const Tensor g = i < nb ? ggr.select(0, i) : (i < 2 * nb ? gdr.select(0, i - nb) : gm);
+            out[1 + i] = g.reshape(shp).to((at::ScalarType)dt[i]);
+        }
+        return out;
+    }
+};
+Tensor nsr_device(const Tensor& x, at::TensorList band_gains, at::TensorList band_decays, const Tensor& mix, const c10::optional<Tensor>& noise, const Tensor& fspec, int64_t L,
+                  int64_t taps, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+    need_device(x, "x");
+    const int64_t nb = (int64_t)band_gains.size(), B = x.dim() ? x.size(0) : 0;
+    TORCH_CHECK(nb >= 1 && (int64_t)band_decays.size() == nb, "dasp::noise_shaped_reverb: as many band decays as band gains");
+    std::vector<Tensor> gv, dv;
+    for (const Tensor& c : band_gains) { TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel()); gv.push_back(c.reshape({-1}).to(at::kFloat)); }
+    for (const Tensor& c : band_decays) { TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel()); dv.push_back(c.reshape({-1}).to(at::kFloat)); }
+    TORCH_CHECK(mix.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * mix.numel());
+    return reverb_device(x, noise, fspec, at::stack(gv, 1), at::stack(dv, 1), mix.reshape({-1}).to(at::kFloat), L, taps, nb, seed, seed_offset, decay_bound);
+}
+Tensor nsr_autograd(const Tensor& x, at::TensorList band_gains, at::TensorList band_decays, const Tensor& mix, const c10::optional<Tensor>& noise, const Tensor& fspec, int64_t L,
+                    int64_t taps, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
+    return NsrFn::apply(x, band_gains, band_decays, mix, noise, fspec, L, taps, seed, seed_offset, decay_bound);
+}
+
 }  // namespace
 
+#ifndef DASP_ABI_HASH
+#define DASP_ABI_HASH 0
+#endif
+// the hash of include/dasp_hip.h this extension was compiled against (csrc/build.py); libdasp_hip.so carries its own (dasp_abi_hash):
+// dasp_pytorch_amd._torch_ops refuses an extension whose hash differs from the kernel library's
+int64_t abi_hash() { return (int64_t)DASP_ABI_HASH; }
+
 TORCH_LIBRARY(dasp, m) {
-    // public, differentiable (reference callables: Processor.process_normalized of ParametricEQ, dasp_pytorch/modules.py:124-156 +
-    // functional.py:118-272; functional.compressor / expander, functional.py:275-403; functional.noise_shaped_reverberation, :406-577)
-    m.def("parametric_eq_norm(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span) -> Tensor");
+    // ---- the reference's own callables (dasp_pytorch/functional.py:10, :65, :118-139, :275-286, :406-436; signal.py:136), differentiable ----
+    m.def("parametric_eq(Tensor x, float sample_rate, Tensor[] controls, int[] types) -> Tensor");
+    m.def("dynamics(Tensor x, float sample_rate, Tensor threshold_db, Tensor ratio, Tensor attack_ms, Tensor release_ms, Tensor knee_db, Tensor makeup_gain_db, "
+          "float eps, int lookahead_samples, int mode) -> Tensor");
+    m.def("gain(Tensor x, Tensor gain_db) -> Tensor");
+    m.def("distortion(Tensor x, Tensor drive_db) -> Tensor");
+    m.def("sosfilt(Tensor sos, Tensor x) -> Tensor");
+    m.def("noise_shaped_reverb(Tensor x, Tensor[] band_gains, Tensor[] band_decays, Tensor mix, Tensor? noise, Tensor fspec, int num_samples, int taps, int seed, "
+          "Tensor? seed_offset, float decay_bound) -> Tensor");
+    // ---- the chain on normalised parameters (Processor.process_normalized of ParametricEQ, dasp_pytorch/modules.py:124-156 + functional.py:118-272;
+    // compressor / expander on control rows; the reverb on control matrices), differentiable. range_flag: see flag_ptr above ----
+    m.def("parametric_eq_norm(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, Tensor(a!)? range_flag=None) -> Tensor");
     m.def("dynamics_ctl(Tensor x, Tensor ctl, int mode, float sample_rate, float eps, int lookahead_samples) -> Tensor");
-    m.def("chain_controls(Tensor comp_params, Tensor reverb_params, Tensor gain_params, float[] lo, float[] span) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("chain_controls(Tensor comp_params, Tensor reverb_params, Tensor gain_params, float[] lo, float[] span, Tensor(a!)? range_flag=None) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("reverb(Tensor x, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int num_samples, int taps, int bands, int seed, Tensor? seed_offset, "
           "float decay_bound) -> Tensor");
     // the two directions as plain functional ops (traced by AOTAutograd; fake implementations: dasp_pytorch_amd/_torch_ops.py)
-    m.def("_peq_norm_forward(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_peq_forward(Tensor x, Tensor[] controls, float sample_rate, int[] types, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_peq_backward(Tensor x, Tensor grad_y, Tensor work32, Tensor work64, int Bp, int S, int tseg, bool need_gx, bool need_gc) -> (Tensor, Tensor)");
+    m.def("_ew_forward(Tensor x, Tensor ctl, int op) -> Tensor");
+    m.def("_ew_backward(Tensor x, Tensor ctl, Tensor grad_y, int op) -> (Tensor, Tensor)");
+    m.def("_sosfilt_forward(Tensor sos, Tensor x, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_sosfilt_backward(Tensor x, Tensor grad_y, Tensor work32, Tensor work64, int Bs, int Sp, int tseg, bool need_gx, bool need_gs) -> (Tensor, Tensor)");
+    m.def("_peq_norm_forward(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, int tseg, bool save, Tensor(a!)? range_flag=None) "
+          "-> (Tensor, Tensor, Tensor)");
     m.def("_peq_norm_backward(Tensor x, Tensor grad_y, Tensor work32, Tensor work64, int Bp, int S, int tseg, bool need_gx, bool need_gp) -> (Tensor, Tensor)");
     m.def("_dynamics_forward(Tensor x, Tensor ctl, int mode, float sample_rate, float eps, int lookahead_samples, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
     m.def("_dynamics_backward(Tensor x, Tensor ctl, Tensor grad_y, Tensor carries, Tensor lin, int mode, float sample_rate, float eps, int lookahead_samples, int tseg) "
@@ -511,13 +1018,26 @@ TORCH_LIBRARY(dasp, m) {
           "Tensor? seed_offset, float decay_bound, bool save) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("_reverb_backward(Tensor grad_y, Tensor ir, Tensor A, Tensor H, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int Cx, int num_samples, "
           "int taps, int bands, int seed, Tensor? seed_offset, float decay_bound) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("_abi_hash() -> int", &abi_hash);
 }
 // ROCm devices carry the CUDA dispatch key in PyTorch-ROCm builds
 TORCH_LIBRARY_IMPL(dasp, CUDA, m) {
+    m.impl("parametric_eq", &peq_device);
+    m.impl("dynamics", &dyn6_device);
+    m.impl("gain", &gain_device);
+    m.impl("distortion", &distortion_device);
+    m.impl("sosfilt", &sosfilt_device);
+    m.impl("noise_shaped_reverb", &nsr_device);
     m.impl("parametric_eq_norm", &peq_norm_device);
     m.impl("dynamics_ctl", &dyn_device);
     m.impl("chain_controls", &chain_controls);
     m.impl("reverb", &reverb_device);
+    m.impl("_peq_forward", &peq_forward);
+    m.impl("_peq_backward", &peq_backward);
+    m.impl("_ew_forward", &ew_forward);
+    m.impl("_ew_backward", &ew_backward);
+    m.impl("_sosfilt_forward", &sosfilt_forward);
+    m.impl("_sosfilt_backward", &sosfilt_backward);
     m.impl("_peq_norm_forward", &peq_norm_forward);
     m.impl("_peq_norm_backward", &peq_norm_backward);
     m.impl("_dynamics_forward", &dyn_forward);
@@ -527,13 +1047,19 @@ TORCH_LIBRARY_IMPL(dasp, CUDA, m) {
     m.impl("_reverb_backward", &reverb_backward);
 }
 TORCH_LIBRARY_IMPL(dasp, Autograd, m) {
+    m.impl("parametric_eq", &peq_autograd);
+    m.impl("dynamics", &dyn6_autograd);
+    m.impl("gain", &gain_autograd);
+    m.impl("distortion", &distortion_autograd);
+    m.impl("sosfilt", &sosfilt_autograd);
+    m.impl("noise_shaped_reverb", &nsr_autograd);
     m.impl("parametric_eq_norm", &peq_norm_autograd);
     m.impl("dynamics_ctl", &dyn_autograd);
     m.impl("chain_controls", &chain_controls_autograd);
     m.impl("reverb", &reverb_autograd);
     // the two directions themselves carry no derivative: backpropagating through them (a double backward, or calling `_forward` on tensors
     // that require a gradient) raises "derivative for dasp::... is not implemented" instead of treating the result as a constant
-    for (const char* name : {"_peq_norm_forward", "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_chain_controls_backward", "_reverb_forward",
-                             "_reverb_backward"})
+    for (const char* name : {"_peq_forward", "_peq_backward", "_ew_forward", "_ew_backward", "_sosfilt_forward", "_sosfilt_backward", "_peq_norm_forward",
+                             "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_chain_controls_backward", "_reverb_forward", "_reverb_backward"})
         m.impl(name, torch::autograd::autogradNotImplementedFallback());
 }

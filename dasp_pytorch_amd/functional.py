@@ -3,8 +3,8 @@
 import torch
 
 from . import signal as _signal
-from .ops import (FILTER_TYPES, BusFunction, DistortionFunction, DistortionSampleFunction, DynamicsFunction, GainFunction, PannerFunction, ParametricEQFunction,
-                  ReverbFunction, WidenerFunction)
+from . import ops as _ops
+from .ops import FILTER_TYPES, BusFunction, DistortionSampleFunction, PannerFunction, WidenerFunction
 from .ops import reverb as _ops_reverb
 from .ops64 import Dynamics64Function, Elementwise64Function, ParametricEQ64Function, is_f64, require_fp32_ok
 
@@ -19,7 +19,7 @@ def gain(x: torch.Tensor, sample_rate: int, gain_db: torch.Tensor):
         raise RuntimeError(f"shape '[{bs}, 1, 1]' is invalid for input of size {gain_db.numel()}")
     if is_f64(x):            # float64 in, float64 arithmetic, as the reference (ops64.py)
         return Elementwise64Function.apply(x, gain_db, 0)
-    return GainFunction.apply(x, gain_db)
+    return _ops.gain(x, gain_db)                      # torch.ops.dasp.gain (csrc/torch_ext), or the ctypes binding
 
 
 def distortion(x: torch.Tensor, sample_rate: int, drive_db: torch.Tensor):
@@ -39,7 +39,7 @@ def distortion(x: torch.Tensor, sample_rate: int, drive_db: torch.Tensor):
         raise RuntimeError(f"The size of tensor a ({seq_len}) must match the size of tensor b ({n // (bs * chs)}) at non-singleton dimension 2")
     if is_f64(x):
         return Elementwise64Function.apply(x, drive_db, 1)
-    return DistortionFunction.apply(x, drive_db)
+    return _ops.distortion(x, drive_db)
 
 
 def stereo_bus(x: torch.Tensor, sample_rate: int, send_db: torch.Tensor):
@@ -124,7 +124,7 @@ def parametric_eq(
         raise RuntimeError(f"parametric_eq controls must each hold {bs} (or 1) values, got {[c.numel() for c in controls]}")
     if is_f64(x):
         return ParametricEQ64Function.apply(x, float(sample_rate), _PEQ_TYPES, *controls)
-    return ParametricEQFunction.apply(x, float(sample_rate), _PEQ_TYPES, *controls)
+    return _ops.parametric_eq(x, sample_rate, _PEQ_TYPES, controls)
 
 
 def _dynamics(mode, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead_samples):
@@ -133,8 +133,9 @@ def _dynamics(mode, x, sample_rate, threshold_db, ratio, attack_ms, release_ms, 
     for c in ctls:   # the reference's .view(-1, 1, 1) against a (bs, 1, seq_len) side chain: no parameter broadcasting
         if c.numel() != bs:
             raise RuntimeError(f"The size of tensor a ({c.numel()}) must match the size of tensor b ({bs}) at non-singleton dimension 0")
-    fn = Dynamics64Function if is_f64(x) else DynamicsFunction
-    return fn.apply(x, mode, float(sample_rate), float(eps), int(lookahead_samples), *ctls)
+    if is_f64(x):
+        return Dynamics64Function.apply(x, mode, float(sample_rate), float(eps), int(lookahead_samples), *ctls)
+    return _ops.dynamics(x, mode, sample_rate, eps, lookahead_samples, ctls)
 
 
 def compressor(
@@ -254,12 +255,15 @@ def noise_shaped_reverberation(
             raise RuntimeError(f"shape '[{bs}, 12]' is invalid for input of size {12 * c.numel()}")
     # (chs == 1: the reference copies mono to stereo, functional.py:493-495; the kernels read the one row for both output channels,
     # ops.ReverbFunction)
-    band_gains = _StackColumns.apply(band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain,
-                                     band8_gain, band9_gain, band10_gain, band11_gain)
-    band_decays = _StackColumns.apply(band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay,
-                                      band7_decay, band8_decay, band9_decay, band10_decay, band11_decay)
-    return _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix.view(bs), num_samples, num_bandpass_taps, noise, device_noise, noise_seed,
-                                 noise_seed_offset)
+    gains = (band0_gain, band1_gain, band2_gain, band3_gain, band4_gain, band5_gain, band6_gain, band7_gain, band8_gain, band9_gain, band10_gain, band11_gain)
+    decays = (band0_decay, band1_decay, band2_decay, band3_decay, band4_decay, band5_decay, band6_decay, band7_decay, band8_decay, band9_decay, band10_decay,
+              band11_decay)
+    if _ops.noise_shaped_reverb_ok(x, gains, decays, mix, noise):
+        # the 25 tensors as they are: torch.ops.dasp.noise_shaped_reverb stacks them and hands their gradients back in C++ (csrc/torch_ext)
+        filters, noise, seed, offset = _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset)
+        return _ops.noise_shaped_reverb(x, noise, filters, gains, decays, mix, int(num_samples), seed, offset, 0.0)
+    return _reverb_from_matrices(x, sample_rate, _StackColumns.apply(*gains), _StackColumns.apply(*decays), mix.view(bs), num_samples, num_bandpass_taps, noise,
+                                 device_noise, noise_seed, noise_seed_offset)
 
 
 class _StackColumns(torch.autograd.Function):
@@ -278,12 +282,9 @@ class _StackColumns(torch.autograd.Function):
         return tuple(r.reshape(shape) if need else None for r, shape, need in zip(rows, ctx.shapes, ctx.needs_input_grad))
 
 
-def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False,
-                          noise_seed=None, noise_seed_offset=None, decay_bound=0.0):
-    """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what the function above stacks its 24 + 1
-    arguments into, and what NoiseShapedReverb.process_normalized has as slices of its de-normalised (bs, 25) tensor. x: (bs, 1 or 2, seq_len).
-    decay_bound > 0: the caller vouches that no band decay exceeds it (a validated parameter range) - lets the filter bank skip a launch."""
-    bs = x.shape[0]
+def _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset):
+    """The filter bank on x's device and the white noise of one call, as the reference draws it (functional.py:548) or as the keywords of
+    noise_shaped_reverberation ask for it: (filters, noise tensor or None, seed or None, seed offset or None)."""
     filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
     seed = None
     if noise_seed_offset is not None and (noise is not None or not (device_noise or noise_seed is not None)):
@@ -293,9 +294,17 @@ def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samp
             # one 63-bit draw from the global CPU generator (a host-side scalar: no device work, no sync) unless the caller fixed the seed
             seed = int(noise_seed) if noise_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         else:
-            noise = torch.randn(bs * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
-    return _ops_reverb(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed,
-                       noise_seed_offset if seed is not None else None, float(decay_bound))
+            noise = torch.randn(x.shape[0] * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
+    return filters, noise, seed, (noise_seed_offset if seed is not None else None)
+
+
+def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False,
+                          noise_seed=None, noise_seed_offset=None, decay_bound=0.0):
+    """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what NoiseShapedReverb.process_normalized has
+    as slices of its de-normalised (bs, 25) tensor. x: (bs, 1 or 2, seq_len).
+    decay_bound > 0: the caller vouches that no band decay exceeds it (a validated parameter range) - lets the filter bank skip a launch."""
+    filters, noise, seed, offset = _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset)
+    return _ops_reverb(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed, offset, float(decay_bound))
 
 
 def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):

@@ -39,15 +39,16 @@ _validated = threading.local()
 
 
 @contextlib.contextmanager
-def already_validated():
+def already_validated(enforced=True):
     """Inside this block `Processor._check_range` is a no-op: for callers that checked the parameter tensors of several processors with one
-    reduction and one sync (chain.StyleTransferChain) before calling them."""
-    prev = getattr(_validated, "on", False)
-    _validated.on = True
+    reduction and one sync (chain.StyleTransferChain) before calling them. enforced=False: the caller only SUBMITTED a deferred check -
+    nothing has vouched for this call's values yet, so promises derived from the range (the reverb's decay bound) stay withdrawn."""
+    prev = (getattr(_validated, "on", False), getattr(_validated, "enforced", False))
+    _validated.on, _validated.enforced = True, bool(enforced)
     try:
         yield
     finally:
-        _validated.on = prev
+        _validated.on, _validated.enforced = prev
 
 
 def check_unit_range(param_tensor: torch.Tensor, names):
@@ -63,11 +64,12 @@ def check_unit_range(param_tensor: torch.Tensor, names):
 
 
 class _DeferredRangeCheck:
-    """validate_range = "deferred": the [0, 1] check of process_normalized without the host waiting for the device. Each call queues the
-    min / max reduction and an asynchronous copy of its two numbers into pinned host memory, and looks at the numbers of the PREVIOUS call -
-    whose reduction was queued in front of that call's kernels and is long done - so a value outside [0, 1] still raises the reference's
-    ValueError (modules.py:83-84, the parameter named), one call late, and the host keeps running ahead of the GPU (the blocking check costs
-    the chain step 0.08 ms of GPU idle time at the reference's batch). `flush()` (or the next call) collects the last one."""
+    """validate_range = "deferred": the [0, 1] check of process_normalized without the host waiting for the device. Each call queues ONE
+    per-column min / max reduction and an asynchronous copy of its 2 P numbers into pinned host memory, and looks at the numbers of the
+    PREVIOUS call - whose reduction was queued in front of that call's kernels and is long done - so a value outside [0, 1] still raises the
+    reference's ValueError (modules.py:83-84, the parameter named from the host copy), one call late, and the host keeps running ahead of the
+    GPU. Nothing of the parameter tensor is retained (round 4, advisor: the re-scan of a tensor that an optimizer had updated in place in
+    the meantime could find no offender). `flush()` (or the next call) collects the last one."""
 
     def __init__(self):
         self.pending = None
@@ -81,24 +83,71 @@ class _DeferredRangeCheck:
         if not p.is_cuda:
             check_unit_range(p, names)
             return
-        mm = torch.stack(torch.aminmax(p)).to(torch.float32)
-        if self.host is None:
-            self.host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        mm = torch.stack(torch.aminmax(p, dim=0)).to(torch.float32)         # (2, P); NaNs pass, as they do the reference's (p < 0).any()
+        if self.host is None or self.host.shape != mm.shape:
+            self.host = torch.empty(mm.shape, dtype=torch.float32, pin_memory=True)
         self.host.copy_(mm, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending = (ev, p, list(names))
+        self.pending = (ev, list(names))
 
     def flush(self):
         if self.pending is None:
             return
-        ev, p, names = self.pending
+        ev, names = self.pending
         self.pending = None
         ev.synchronize()
-        lo, hi = self.host.tolist()
-        if lo < 0 or hi > 1:
-            bad = ((p < 0) | (p > 1)).any(dim=0)
-            raise ValueError(f"Parameter {names[int(torch.nonzero(bad)[0])]} of is out of range. (found by the deferred check: in the previous call)")
+        lo, hi = self.host[0].tolist(), self.host[1].tolist()
+        for name, a, b in zip(names, lo, hi):
+            if a < 0 or b > 1:
+                raise ValueError(f"Parameter {name} of is out of range. (found by the deferred check: in the previous call)")
+
+
+class _FlagRangeCheck:
+    """validate_range = "deferred" on the fused GPU paths (round 5): the kernels that read the normalised parameters anyway - the EQ's design
+    kernel, the chain's control kernel - OR a bit per offending column into persistent device words (C ABI: the `flag` argument of
+    dasp_peq_forward_norm / dasp_chain_controls; torch.ops.dasp.*: `range_flag`), so the check costs the step no launch at all. Per call the
+    host does one asynchronous copy of the words into pinned memory and one event record, and looks at the PREVIOUS call's copy: a value
+    outside [0, 1] raises the reference's ValueError (modules.py:83-84, the first offending parameter named), one call late, exactly as
+    _DeferredRangeCheck does with its five torch ops per call. The words are sticky until an error has been reported."""
+
+    def __init__(self, nwords):
+        self.nwords = nwords
+        self.dev = None
+        self.host = None
+        self.pending = None
+
+    def words(self, device):
+        """The device words (int32, zero when created); word i as a 1-element view: words(dev)[i:i + 1]."""
+        if self.dev is None or self.dev.device != device:
+            self.flush()
+            self.dev = torch.zeros(self.nwords, dtype=torch.int32, device=device)
+            self.host = torch.zeros(self.nwords, dtype=torch.int32, pin_memory=True)
+        return self.dev
+
+    def begin(self):
+        """Before a call queues anything: raise what the previous call found."""
+        self.flush()
+
+    def end(self, names_per_word):
+        """After the call's kernels are queued: the words on their way to the host, for the next call to look at."""
+        self.host.copy_(self.dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (ev, names_per_word)
+
+    def flush(self):
+        if self.pending is None:
+            return
+        ev, names_per_word = self.pending
+        self.pending = None
+        ev.synchronize()
+        for word, names in zip(self.host.tolist(), names_per_word):
+            word &= 0xFFFFFFFF
+            if word:
+                self.dev.zero_()                      # reported: the words start afresh
+                bit = (word & -word).bit_length() - 1
+                raise ValueError(f"Parameter {names[bit]} of is out of range. (found by the deferred check: in the previous call)")
 
 
 class Processor:
@@ -174,20 +223,30 @@ class Processor:
             d = self.__dict__["_deferred_check"] = _DeferredRangeCheck()
         return d
 
+    def _flags(self, nwords=1):
+        d = self.__dict__.get("_flag_check")
+        if d is None:
+            d = self.__dict__["_flag_check"] = _FlagRangeCheck(nwords)
+        return d
+
     def flush_range_check(self):
         """validate_range = "deferred": raise now if the last call's parameters were outside [0, 1] (waits for that call's reduction)."""
-        d = self.__dict__.get("_deferred_check")
-        if d is not None:
-            d.flush()
+        for key in ("_deferred_check", "_flag_check"):
+            d = self.__dict__.get(key)
+            if d is not None:
+                d.flush()
 
     def _range_is_enforced(self):
-        """True when the [0, 1] check of process_normalized actually RAN for this call: the caller already did it (chain.StyleTransferChain),
-        or the check is on and the stream is not being captured into a HIP graph (inside a capture `_check_range` is skipped, so nothing
-        vouches for the values a replay will see: promises derived from the range - the reverb's decay bound - are then withdrawn and
-        the kernels decide per item)."""
+        """True when the [0, 1] check of process_normalized actually RAN for this call: the caller already did it (chain.StyleTransferChain
+        with the blocking check), or this processor's blocking check is on and the stream is not being captured into a HIP graph. A deferred
+        check has only been submitted - this call's values are looked at one call later - and inside a capture `_check_range` is skipped:
+        in both cases nothing vouches for the values the kernels will see, promises derived from the range (the reverb's decay bound) are
+        withdrawn and the kernels decide per item."""
         if getattr(_validated, "on", False):
-            return True
-        return bool(self.validate_range) and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+            return bool(getattr(_validated, "enforced", False))
+        if self.validate_range == "deferred" or not self.validate_range:
+            return False
+        return not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
     def extract_param_dict(self, param_tensor: torch.Tensor):
         if param_tensor.shape[1] != len(self.param_ranges):
@@ -249,23 +308,36 @@ class ParametricEQ(Processor):
         self.process_fn = F.parametric_eq
         self.param_ranges = _eq_ranges(sample_rate, (min_gain_db, max_gain_db), (min_q_factor, max_q_factor))
 
-    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor):
+    def _fused_ok(self, x, param_tensor):
+        return (self.process_fn is F.parametric_eq and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and param_tensor.dim() == 2
+                and param_tensor.shape[1] == 18 and param_tensor.shape[0] in (1, x.shape[0]) and list(self.param_ranges) == _EQ_NAMES
+                and param_tensor.is_floating_point() and param_tensor.device == x.device)
+
+    def process_normalized(self, x: torch.Tensor, param_tensor: torch.Tensor, _range_flag: torch.Tensor = None):
         """As Processor.process_normalized; float32 audio on the GPU takes the fused op (ops.ParametricEQNormFunction): de-normalisation,
         filter design inside the design kernel, gradients returned w.r.t. `param_tensor` itself. Anything else (float64,
-        a replaced process_fn, renamed ranges) goes through the generic path."""
-        names = list(self.param_ranges)
-        fused = (self.process_fn is F.parametric_eq and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and param_tensor.dim() == 2
-                 and param_tensor.shape[1] == 18 and param_tensor.shape[0] in (1, x.shape[0]) and names == _EQ_NAMES
-                 and param_tensor.is_floating_point())
-        if not fused:
+        a replaced process_fn, renamed ranges) goes through the generic path. `_range_flag` (chain.StyleTransferChain's deferred check):
+        the device word the design kernel reports out-of-range columns into."""
+        if not self._fused_ok(x, param_tensor):
+            if _range_flag is not None:               # the caller counted on the kernel's check: do the blocking one instead
+                check_unit_range(param_tensor, self.param_ranges)
             return super().process_normalized(x, param_tensor)
         from .ops import parametric_eq_norm
         lo = [float(r[0]) for r in self.param_ranges.values()]
         span = [float(r[1]) - float(r[0]) for r in self.param_ranges.values()]
-        # the check runs before the kernels are queued (one small reduction + read-back): the C entry point's in-kernel flag word would
-        # make the host wait for the forward kernel it has just launched
+        deferred = (_range_flag is None and self.validate_range == "deferred" and not getattr(_validated, "on", False)
+                    and not torch.cuda.is_current_stream_capturing())
+        if deferred:
+            # the design kernel itself flags the columns outside [0, 1]; the word is read back one call late (_FlagRangeCheck)
+            fc = self._flags()
+            fc.begin()
+            with torch.cuda.device(x.device):
+                y = parametric_eq_norm(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, fc.words(x.device))
+                fc.end([list(self.param_ranges)])
+            return y
+        # the blocking check runs before the kernels are queued (one small reduction + read-back)
         self._check_range(param_tensor)
-        return parametric_eq_norm(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span)
+        return parametric_eq_norm(x, param_tensor, float(self.sample_rate), F._PEQ_TYPES, lo, span, _range_flag)
 
 
 class _Dynamics(Processor):

@@ -258,7 +258,7 @@ class ParametricEQNormFunction(torch.autograd.Function):
     Python: reading it back would make the host wait for the forward kernel it has just queued."""
 
     @staticmethod
-    def forward(ctx, x, pn, sample_rate, types, lo, span):
+    def forward(ctx, x, pn, sample_rate, types, lo, span, range_flag=None):
         _lib.require_device(x, "x")
         _lib.require_same_device(x, param_tensor=pn)
         S = len(types)
@@ -276,7 +276,7 @@ class ParametricEQNormFunction(torch.autograd.Function):
             w = _SosWork(Bp, S, x32, need)
             y = torch.empty_like(x32)
             call("dasp_peq_forward_norm", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
-                 (ctypes.c_double * (3 * S))(*span), ptr(None), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y), ptr(w.carries), B, C, N, w.tseg,
+                 (ctypes.c_double * (3 * S))(*span), ptr(range_flag), ptr(w.tab), ptr(w.dtab), ptr(x32), ptr(y), ptr(w.carries), B, C, N, w.tseg,
                  ptr(w.segtab), ptr(w.segbuf), stream())
             if need:
                 ctx.work = w
@@ -288,12 +288,12 @@ class ParametricEQNormFunction(torch.autograd.Function):
     def backward(ctx, gy):
         xd, pd, pshape = ctx.meta
         if ctx.empty:
-            return torch.empty_like(gy), torch.zeros(pshape, dtype=pd, device=gy.device), None, None, None, None
+            return torch.empty_like(gy), torch.zeros(pshape, dtype=pd, device=gy.device), None, None, None, None, None
         (x32,) = ctx.saved_tensors
         need_gx, need_gp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         with torch.cuda.device(x32.device):
             gx, gp = ctx.work.backward(x32, _f32c(gy), 1, 1, need_gx, need_gp)       # mode 1: (Bp, S, 3) = the layout of the (Bp, 3 S) tensor
-        return (gx.to(xd) if need_gx else None, gp.reshape(pshape).to(pd) if need_gp else None, None, None, None, None)
+        return (gx.to(xd) if need_gx else None, gp.reshape(pshape).to(pd) if need_gp else None, None, None, None, None, None)
 
 
 class _ElementwiseFunction(torch.autograd.Function):
@@ -587,7 +587,7 @@ class ChainControlsFunction(torch.autograd.Function):
     lo, span: ctypes float[32] (compressor 0-5, reverb 6-30, gain 31)."""
 
     @staticmethod
-    def forward(ctx, comp_pn, reverb_pn, gain_pn, lo, span):
+    def forward(ctx, comp_pn, reverb_pn, gain_pn, lo, span, range_flag=None):
         _lib.require_device(comp_pn, "comp_params")
         _lib.require_same_device(comp_pn, reverb_params=reverb_pn, gain_params=gain_pn)
         B = comp_pn.shape[0]
@@ -600,7 +600,7 @@ class ChainControlsFunction(torch.autograd.Function):
             ctl, gains, decays, mix = flat[:5 * B].view(B, 5), flat[5 * B:17 * B].view(B, 12), flat[17 * B:29 * B].view(B, 12), flat[29 * B:]
             if B:
                 call("dasp_chain_controls", ptr(_f32c(comp_pn)), ptr(_f32c(reverb_pn)), ptr(_f32c(gain_pn)), lo, span, ptr(ctl), ptr(gains),
-                     ptr(decays), ptr(mix), B, stream())
+                     ptr(decays), ptr(mix), ptr(range_flag), B, stream())
         return ctl, gains, decays, mix
 
     @staticmethod
@@ -617,10 +617,10 @@ class ChainControlsFunction(torch.autograd.Function):
                 call("dasp_chain_controls_backward", ptr(z(gctl, B, 5)), ptr(z(ggain, B, 12)), ptr(z(gdecay, B, 12)), ptr(z(gmix, B)), ctx.span,
                      ptr(gc), ptr(gr), ptr(gg), B, stream())
         cd, rd, gd = ctx.dtypes
-        return gc.to(cd), gr.to(rd), gg.to(gd), None, None
+        return gc.to(cd), gr.to(rd), gg.to(gd), None, None, None
 
 
-def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mode=0, eps=1e-8):
+def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mode=0, eps=1e-8, range_flag=None):
     """y = compressor(parametric_eq(x)) in one pass over x (dasp_chain_forward, csrc/chainfwd.hip): the EQ designed from its normalised
     (Bp, 18) parameter tensor (dasp_peq_prepare_norm: de-normalisation + RBJ design on the device), the compressor on its (B, 5) control rows
     [threshold_db, ratio, attack_ms, knee_db, makeup_gain_db]. Forward only - no autograd node, nothing saved: the reference's target
@@ -653,7 +653,7 @@ def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mod
         dtab, segtab = f64[:n_dt], (f64[n_dt:] if tseg else None)
         y = torch.empty_like(x32)
         call("dasp_peq_prepare_norm_seg", ptr(pn32), Bp, S, (ctypes.c_int * S)(*types), float(sample_rate), (ctypes.c_double * (3 * S))(*lo),
-             (ctypes.c_double * (3 * S))(*span), ptr(None), ptr(tab), ptr(dtab), tseg, ptr(segtab), stream())      # design (+ segment matrices)
+             (ctypes.c_double * (3 * S))(*span), ptr(range_flag), ptr(tab), ptr(dtab), tseg, ptr(segtab), stream())      # design (+ segment matrices; range_flag: see parametric_eq_norm)
         call("dasp_chain_forward", ptr(tab), Bp, ptr(x32), ptr(c32), ptr(y), B, C, N, S, int(mode), float(sample_rate), float(eps), tseg,
              ptr(segtab), ptr(segbuf), stream())
     return y.to(x.dtype)
@@ -896,20 +896,63 @@ class ReverbFunction(torch.autograd.Function):
         return gx.to(xd), None, None, ggain.reshape(gs).to(gd), gdecay.reshape(ds).to(dd), gmix.reshape(ms).to(md), None, None, None, None
 
 
-# ---- the chain ops through torch.ops.dasp.* (csrc/torch_ext: TORCH_LIBRARY + C++ autograd) when the extension is there -----------------------
+# ---- the ops through torch.ops.dasp.* (csrc/torch_ext: TORCH_LIBRARY + C++ autograd) when the extension is there ---------------------------------
 # Same kernels, same C entry points as the autograd.Functions above; what changes is the host side: no ctypes marshalling, no Python in
-# the backward pass, schemas that torch.compile and torch.library.opcheck understand. float32 CUDA tensors only (anything else keeps the
-# path above, which also owns the dtype / device error messages).
+# the backward pass, schemas that torch.compile and torch.library.opcheck understand. float32 ROCm tensors on one device only (anything
+# else keeps the path above, which also owns the dtype / device error messages).
 def _torch_ops_ok(*tensors):
     from . import _torch_ops
-    return _torch_ops.enabled() and all(t is None or (t.is_cuda and t.dtype is torch.float32) for t in tensors)
+    # (under torch.compile the binding is not a choice: only the registered ops can be traced - and the environment / timer look-ups of
+    # enabled() would be graph breaks)
+    on = _torch_ops._state["loaded"] is True if torch.compiler.is_compiling() else _torch_ops.enabled()
+    return on and all(t is None or (t.is_cuda and t.dtype is torch.float32) for t in tensors)
 
 
-def parametric_eq_norm(x, pn, sample_rate, types, lo, span):
-    """ParametricEQNormFunction, or torch.ops.dasp.parametric_eq_norm."""
+def _same_device_tensors(x, tensors):
+    return all(isinstance(t, torch.Tensor) and t.device == x.device for t in tensors)
+
+
+def parametric_eq(x, sample_rate, types, controls):
+    """functional.parametric_eq's core: ParametricEQFunction, or torch.ops.dasp.parametric_eq (float32 audio and every control on its device)."""
+    if _torch_ops_ok(x) and x.dim() == 3 and _same_device_tensors(x, controls) and len(types) in (2, 4, 6, 8):
+        return torch.ops.dasp.parametric_eq(x, float(sample_rate), list(controls), list(types))
+    return ParametricEQFunction.apply(x, float(sample_rate), types, *controls)
+
+
+def dynamics(x, mode, sample_rate, eps, lookahead, controls):
+    """functional.compressor / expander's core on the six control tensors: DynamicsFunction, or torch.ops.dasp.dynamics."""
+    if _torch_ops_ok(x) and x.dim() == 3 and _same_device_tensors(x, controls):
+        return torch.ops.dasp.dynamics(x, float(sample_rate), *controls, float(eps), int(lookahead), int(mode))
+    return DynamicsFunction.apply(x, mode, float(sample_rate), float(eps), int(lookahead), *controls)
+
+
+def gain(x, gain_db):
+    """GainFunction, or torch.ops.dasp.gain."""
+    if _torch_ops_ok(x) and x.dim() == 3 and _same_device_tensors(x, (gain_db,)):
+        return torch.ops.dasp.gain(x, gain_db)
+    return GainFunction.apply(x, gain_db)
+
+
+def distortion(x, drive_db):
+    """DistortionFunction (one drive value per (item, channel) row), or torch.ops.dasp.distortion."""
+    if _torch_ops_ok(x) and x.dim() == 3 and _same_device_tensors(x, (drive_db,)):
+        return torch.ops.dasp.distortion(x, drive_db)
+    return DistortionFunction.apply(x, drive_db)
+
+
+def sosfilt(sos, x):
+    """One cascade call of at most 8 sections on x (bs, chs, seq_len): SosFiltFunction, or torch.ops.dasp.sosfilt."""
+    if _torch_ops_ok(x) and x.dim() == 3 and _same_device_tensors(x, (sos,)) and sos.dim() == 3 and 1 <= sos.shape[1] <= 8 and sos.is_floating_point():
+        return torch.ops.dasp.sosfilt(sos, x)
+    return SosFiltFunction.apply(sos, x)
+
+
+def parametric_eq_norm(x, pn, sample_rate, types, lo, span, range_flag=None):
+    """ParametricEQNormFunction, or torch.ops.dasp.parametric_eq_norm. range_flag: one int32 device word into which the design kernel ORs
+    bit i when column i of pn holds a value outside [0, 1] (modules._FlagRangeCheck reads it back one call later)."""
     if _torch_ops_ok(x) and x.dim() == 3 and pn.is_cuda and pn.is_floating_point() and pn.device == x.device:
-        return torch.ops.dasp.parametric_eq_norm(x, pn, float(sample_rate), list(types), list(lo), list(span))
-    return ParametricEQNormFunction.apply(x, pn, float(sample_rate), types, lo, span)
+        return torch.ops.dasp.parametric_eq_norm(x, pn, float(sample_rate), list(types), list(lo), list(span), range_flag)
+    return ParametricEQNormFunction.apply(x, pn, float(sample_rate), types, lo, span, range_flag)
 
 
 def dynamics_ctl(x, mode, sample_rate, eps, lookahead, ctl):
@@ -919,11 +962,25 @@ def dynamics_ctl(x, mode, sample_rate, eps, lookahead, ctl):
     return DynamicsCtlFunction.apply(x, mode, sample_rate, eps, lookahead, ctl)
 
 
-def chain_controls(comp_pn, reverb_pn, gain_pn, lo, span):
-    """ChainControlsFunction (lo, span: ctypes float[32]), or torch.ops.dasp.chain_controls."""
+def chain_controls(comp_pn, reverb_pn, gain_pn, lo, span, range_flag=None):
+    """ChainControlsFunction (lo, span: ctypes float[32]), or torch.ops.dasp.chain_controls. range_flag: as for parametric_eq_norm, bit i for
+    column i of the 32 (compressor 0-5, reverb 6-30, gain 31)."""
     if _torch_ops_ok(comp_pn, reverb_pn, gain_pn) and comp_pn.device == reverb_pn.device == gain_pn.device:
-        return torch.ops.dasp.chain_controls(comp_pn, reverb_pn, gain_pn, list(lo), list(span))
-    return ChainControlsFunction.apply(comp_pn, reverb_pn, gain_pn, lo, span)
+        return torch.ops.dasp.chain_controls(comp_pn, reverb_pn, gain_pn, list(lo), list(span), range_flag)
+    return ChainControlsFunction.apply(comp_pn, reverb_pn, gain_pn, lo, span, range_flag)
+
+
+def _reverb_fspec(x, filters, L_ir):
+    nb, taps = filters.shape
+    with torch.cuda.device(x.device):
+        sizes = (ctypes.c_long * 14)()
+        check(_lib.lib().dasp_reverb_sizes(x.shape[0], x.shape[2], int(L_ir), taps, nb, sizes), "dasp_reverb_sizes")
+        return _filter_spectrum(filters, nb, taps, sizes[4], x.device)
+
+
+def _signed64(seed):
+    s = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+    return s - (1 << 64) if s >= (1 << 63) else s                   # the op's `int` is a signed 64-bit word: same bits
 
 
 def reverb(x, noise, filters, gains, decays, mix, L_ir, seed=None, seed_offset=None, decay_bound=0.0):
@@ -934,12 +991,24 @@ def reverb(x, noise, filters, gains, decays, mix, L_ir, seed=None, seed_offset=N
         if noise is None and seed is None:
             raise ValueError("reverb: either a noise tensor or a seed")
         nb, taps = filters.shape
-        with torch.cuda.device(x.device):
-            sizes = (ctypes.c_long * 14)()
-            check(_lib.lib().dasp_reverb_sizes(x.shape[0], x.shape[2], int(L_ir), taps, nb, sizes), "dasp_reverb_sizes")
-            fspec = _filter_spectrum(filters, nb, taps, sizes[4], x.device)
-        s = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
-        s = s - (1 << 64) if s >= (1 << 63) else s                  # the op's `int` is a signed 64-bit word: same bits
-        return torch.ops.dasp.reverb(x, noise, fspec, gains, decays, mix, int(L_ir), int(taps), int(nb), s,
+        return torch.ops.dasp.reverb(x, noise, _reverb_fspec(x, filters, L_ir), gains, decays, mix, int(L_ir), int(taps), int(nb), _signed64(seed),
                                      _seed_offset(seed_offset, x.device) if noise is None else None, float(decay_bound))
     return ReverbFunction.apply(x, noise, filters, gains, decays, mix, L_ir, seed, seed_offset, decay_bound)
+
+
+def noise_shaped_reverb_ok(x, band_gains, band_decays, mix, noise):
+    """True when torch.ops.dasp.noise_shaped_reverb takes these tensors as they are (float32 audio on a ROCm device, the 25 floating-point
+    controls and an explicit noise tensor, if any, on that device)."""
+    ctls = list(band_gains) + list(band_decays) + [mix]
+    return (_torch_ops_ok(x, noise) and x.dim() == 3 and x.shape[1] in (1, 2) and x.numel() > 0 and _same_device_tensors(x, ctls)
+            and all(t.is_floating_point() for t in ctls) and (noise is None or (noise.device == x.device and not noise.requires_grad)))
+
+
+def noise_shaped_reverb(x, noise, filters, band_gains, band_decays, mix, L_ir, seed=None, seed_offset=None, decay_bound=0.0):
+    """functional.noise_shaped_reverberation's core on its 12 + 12 + 1 control tensors (each with bs values): torch.ops.dasp.noise_shaped_reverb
+    (the stacks and their backward in C++). Call it when noise_shaped_reverb_ok says so."""
+    if noise is None and seed is None:
+        raise ValueError("reverb: either a noise tensor or a seed")
+    taps = filters.shape[1]
+    return torch.ops.dasp.noise_shaped_reverb(x, list(band_gains), list(band_decays), mix, noise, _reverb_fspec(x, filters, L_ir), int(L_ir), int(taps),
+                                              _signed64(seed), _seed_offset(seed_offset, x.device) if noise is None else None, float(decay_bound))

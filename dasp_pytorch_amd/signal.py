@@ -12,6 +12,7 @@ import numpy as np
 import scipy.signal
 import torch
 
+from . import ops as _ops
 from .ops import FILTER_TYPES, BiquadFunction, SosFiltFunction
 from .ops64 import LFilterFunction, SosFilt64Function, is_f64
 
@@ -98,10 +99,9 @@ def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
     """Cascade of second-order sections along the last dim of x (reference: signal.py:136-166).
 
     sos: (bs, n_sections, 6) rows [b0 b1 b2 a0 a1 a2]; bs may be 1 (broadcast). x: (bs, ..., T).
-    Differentiable w.r.t. both. Up to 8 sections are one launch per direction (round 3: the 8-section backward is the checkpointed
-    kernel, 4 + 4 sections at two waves per SIMD - 0.61 ms forward + backward on (256, 2, 131072) against 0.67 ms as two calls of 4);
-    longer cascades are applied as successive calls of at most 6 sections (12 sections: 0.85 ms as 6 + 6 against 0.94 as 8 + 4,
-    profiles/r02/sections_per_call.log, profiles/r03/sections_per_call.log)."""
+    Differentiable w.r.t. both. Up to 8 sections are one launch per direction (the backward pass is the Gram-matrix kernel for every
+    section count: 0.46 ms forward + backward for 8 sections on (256, 2, 131072), profiles/r04/sections_per_call.log); longer cascades are
+    applied as successive calls of at most 6 sections."""
     bs, n_sections, n_coeffs = sos.size()
     assert n_coeffs == 6  # must be second order (signal.py:24)
     shape = x.shape
@@ -110,7 +110,7 @@ def sosfilt_via_fsm(sos: torch.Tensor, x: torch.Tensor):
         return SosFilt64Function.apply(sos, xx).reshape(shape)
     step = 8 if n_sections <= 8 else 6
     for s0 in range(0, n_sections, step):
-        xx = SosFiltFunction.apply(sos[:, s0:s0 + step], xx)
+        xx = _ops.sosfilt(sos[:, s0:s0 + step], xx)         # torch.ops.dasp.sosfilt (csrc/torch_ext), or the ctypes binding
     return xx.reshape(shape)
 
 

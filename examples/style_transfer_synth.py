@@ -182,8 +182,8 @@ def run(steps=10, batch=8, n=131072, sample_rate=44100, ir_samples=65536, lr=1e-
             return loss
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                         # warm-up off the capture stream (allocator, lazy tables, Adam state)
-            for _ in range(3):
+        with torch.cuda.stream(side), grads.no_sync():        # warm-up off the capture stream (allocator, lazy tables, Adam state); no
+            for _ in range(3):                                # collective from these passes: their gradients are thrown away
                 captured()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()

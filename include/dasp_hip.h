@@ -16,6 +16,10 @@
 extern "C" {
 #endif
 
+/* Hash of this header as it was when the library was built (csrc/build.py -> csrc/abi.hip). A binding compiled against the header - the
+ * torch extension csrc/torch_ext, or a maintainer's own - compares it with the hash it was built with before it trusts the argument lists. */
+unsigned long long dasp_abi_hash(void);
+
 #define DASP_OK 0
 #define DASP_ERR_ARG (-1)          /* null pointer / inconsistent sizes */
 #define DASP_ERR_UNSUPPORTED (-2)  /* e.g. section count without a compiled kernel */
@@ -203,8 +207,10 @@ int dasp_distortion_sample_backward(const float* x, const float* drive_db, const
  * param_ranges (modules.py:159-187), [6, 31) the reverb's, [31] the gain's. Out: ctl (B, 5) as dasp_dynamics_forward takes it, with the
  * gain added to the make-up gain (a per-item gain commutes with the linear reverb); gains, decays (B, 12), mix (B) as
  * dasp_reverb_forward takes them. The backward call maps the gradients of those four back to the three parameter tensors. */
+/* flag (may be NULL): one device word; bit i is OR-ed in when column i of the 32 (compressor 0-5, reverb 6-30, gain 31) holds a value outside
+ * [0, 1] (the reference's ValueError, modules.py:83-84: the host reads the word back when it chooses to; it is never cleared here). */
 int dasp_chain_controls(const float* comp_pn, const float* reverb_pn, const float* gain_pn, const float* lo, const float* span, float* ctl,
-                        float* gains, float* decays, float* mix, int B, void* stream);
+                        float* gains, float* decays, float* mix, unsigned* flag, int B, void* stream);
 int dasp_chain_controls_backward(const float* gctl, const float* ggain, const float* gdecay, const float* gmix, const float* span,
                                  float* gcomp_pn, float* greverb_pn, float* ggain_pn, int B, void* stream);
 

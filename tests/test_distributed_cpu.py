@@ -86,6 +86,81 @@ WORKER = textwrap.dedent("""
         for p, q in zip(net2.parameters(), net.parameters()):
             assert torch.allclose(p.grad, q.grad, atol=1e-6), it
         assert float(unused.grad.abs().max()) == 0.0
+    # one step = zero_grad -> backward -> finish (round 4, advisor): passes whose gradients are thrown away or only accumulated run under
+    # no_sync() - nothing is launched from their hooks and the step's count stays where it was - and the step after them still exchanges
+    # every bucket; a second backward() in one step raises from its first hook instead of all-reducing half-accumulated buckets
+    with gb.no_sync():
+        for _ in range(3):
+            gb.zero_grad()
+            net2(inp).square().mean().backward()
+    assert gb._next == 0 and not gb._handles
+    gb.zero_grad()
+    net2(inp).square().mean().backward()
+    assert gb.finish() == len(gb.buckets)
+    for p, q in zip(net2.parameters(), net.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6)
+    gb.zero_grad()
+    with gb.no_sync():                                      # gradient accumulation: two local passes, one exchange of the sum
+        net2(inp).square().mean().backward()
+    net2(inp).square().mean().backward()
+    assert gb.finish() == len(gb.buckets)
+    for p, q in zip(net2.parameters(), net.parameters()):
+        assert torch.allclose(p.grad, 2 * q.grad, atol=1e-5)
+    gb.zero_grad()
+    net2(inp).square().mean().backward()
+    try:
+        net2(inp).square().mean().backward()
+        raise AssertionError("a second backward() before finish() must raise")
+    except RuntimeError as e:
+        assert "backward() ran twice" in str(e)
+    gb.zero_grad()                                          # waits for what the aborted step left in flight, then a clean step again
+    net2(inp).square().mean().backward()
+    assert gb.finish() == len(gb.buckets)
+    for p, q in zip(net2.parameters(), net.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6)
+    gb.remove()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("worker", rank, "ok")
+""")
+
+# world 4: the ranks complete their buckets in different orders (on odd ranks a parameter of the FIRST bucket gets no gradient, so nothing can
+# be launched from a hook there, while the even ranks launch every bucket under backward; rank 3 also sleeps inside backward): the
+# collectives still pair up bucket by bucket, because every rank issues them in bucket order, and the result is the mean over the four ranks
+WORKER4 = textwrap.dedent("""
+    import os, sys, time, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from dasp_pytorch_amd import distributed as dd
+    rank, world = dd.init(backend="gloo")
+    assert world == 4
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2))
+    tail = torch.nn.Parameter(torch.ones(4))                # LAST parameter = first bucket (buckets fill in reverse order)
+    gb = dd.GradientBuckets(list(net.parameters()) + [tail], bucket_bytes=128)
+    assert gb.active and len(gb.buckets) >= 4 and id(tail) in gb._bucket_of and gb._bucket_of[id(tail)] == 0
+    if rank == 3:
+        net[2].weight.register_hook(lambda g: (time.sleep(0.3), g)[1])
+    for step in range(3):
+        inp = torch.full((3, 8), float(rank + 1 + step))
+        gb.zero_grad()
+        out = net(inp).square().mean()
+        if rank %% 2 == 0:
+            out = out + (tail * (rank + 1)).sum()           # even ranks: every bucket completes under backward
+        out.backward()
+        launched = gb._next
+        assert (launched == len(gb.buckets)) if rank %% 2 == 0 else (launched == 0), (rank, launched)
+        mine = [p.grad.clone() for p in gb.params]          # (buckets already in flight hold partial sums: compare against a plain run)
+        assert gb.finish() == len(gb.buckets)
+        ref_net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2))
+        ref_net.load_state_dict(net.state_dict())
+        acc = [torch.zeros_like(p) for p in ref_net.parameters()]
+        for r in range(world):
+            ref_net.zero_grad()
+            ref_net(torch.full((3, 8), float(r + 1 + step))).square().mean().backward()
+            acc = [a + p.grad for a, p in zip(acc, ref_net.parameters())]
+        for p, a in zip(net.parameters(), acc):
+            assert torch.allclose(p.grad, a / world, atol=1e-6), (rank, step)
+        assert torch.allclose(tail.grad, torch.full((4,), (1 + 3) / world)), tail.grad
     gb.remove()
     dist.barrier()
     dist.destroy_process_group()
@@ -105,6 +180,18 @@ def test_world2_gloo():
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=150)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"worker {rank} ok" in o, o
+
+
+@pytest.mark.timeout(240)
+def test_world4_gloo_uneven_bucket_completion():
+    port = _free_port()
+    procs = []
+    for rank in range(4):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER4 % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=200)[0] for p in procs]
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"worker {rank} ok" in o, o
 
@@ -141,6 +228,29 @@ def test_bench_rank_wiring_under_torchrun(scaling):
     assert out["config"]["global_batch"] == (12 if scaling == "weak" else 6)
     assert f"({per_gpu},2,2048)" in out["config"]["workload"]
     assert abs(out["value"] - out["config"]["global_batch"] * 2 * 2048 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_world8_as_the_driver_launches_it(scaling):
+    """The driver's 8-GPU launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 8 --steps K --warmup W) on CPU over gloo with the kernels replaced by a copy: eight ranks rendezvous, the batch is
+    sharded (weak: 8 x the per-GPU batch; strong: one batch in 8 contiguous shards, here of unequal size), the timed region is the max
+    over ranks, and rank 0 alone prints the line. No 8-GPU node has been available to any round: this is what can be verified without one."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--scaling", scaling, "--dry-run-cpu", "--batch", "20", "--samples", "1024", "--blocks", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["world_size"] == 8 and out["scaling"] == scaling and out["dry_run"]
+    assert out["config"]["global_batch"] == (160 if scaling == "weak" else 20)
+    assert abs(out["value"] - out["config"]["global_batch"] * 2 * 1024 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    if scaling == "strong":                                  # 20 items over 8 ranks: shards of 3 and 2 items, every item owned once
+        assert out["config"]["shard_items"] == [3, 3, 3, 3, 2, 2, 2, 2]
 
 
 @pytest.mark.timeout(300)

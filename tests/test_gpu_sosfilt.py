@@ -393,7 +393,9 @@ def test_needs_input_grad_selects_the_kernel_variant(D):
     assert np.array_equal(torch.stack([c.grad for c in cols], 1).cpu().numpy(), gp)
     xt = dev(x).requires_grad_(True)
     (D.parametric_eq(xt, SR, *[dev(p[:, i]) for i in range(18)]) * dev(w)).sum().backward()
-    assert np.array_equal(xt.grad.cpu().numpy(), gx)
+    # (no control gradients: the adjoint-only kernel runs the per-lane cascade, the Gram-matrix kernel takes gx from the matrix-core output
+    # map - two fp32 evaluations of the same numbers)
+    assert linf_peak(xt.grad.cpu().numpy(), gx).max() < 1e-5
     sos = dev(orc.peq_sos(p.astype(np.float64), SR).astype(np.float32))
     xt2 = dev(x).requires_grad_(True)
     (D.signal.sosfilt_via_fsm(sos, xt2) * dev(w)).sum().backward()          # fixed filter: the adjoint-only kernel

@@ -175,3 +175,152 @@ def test_inference_and_empty(T):
     assert not y.requires_grad and torch.isfinite(y).all()
     e = d.dynamics_ctl(torch.zeros(0, 2, 64, device=DEV), torch.zeros(0, 5, device=DEV), 0, float(SR), 1e-8, 0)
     assert e.shape == (0, 2, 64)
+
+
+# ---- round 5: torch.ops.dasp.* for the reference's own signatures ---------------------------------------------------------------------------
+def _ref_signature_samples():
+    from dasp_pytorch_amd import functional as F
+    g = torch.Generator(device=DEV).manual_seed(21)
+    r = lambda *s: torch.rand(*s, device=DEV, generator=g)
+    B, C, N = 3, 2, 20000
+    x = (r(B, C, N) * 2 - 1).requires_grad_(True)
+    from bench import PEQ_RANGES
+    eq = [(r(B) * (hi - lo) + lo).requires_grad_(True) for lo, hi in PEQ_RANGES]
+    comp = [(-40 + 30 * r(B)).requires_grad_(True), (1 + 8 * r(B)).requires_grad_(True), (5 + 50 * r(B)).requires_grad_(True),
+            (5 + 50 * r(B)).requires_grad_(True), (1 + 8 * r(B)).requires_grad_(True), (6 * r(B)).requires_grad_(True)]
+    rev = [r(B).requires_grad_(True) for _ in range(25)]
+    w = torch.randn(B, C, N, device=DEV, generator=g)
+    sos = torch.stack([torch.tensor([[1.0, -1.2, 0.5, 1.0, -1.5, 0.7], [0.8, 0.1, 0.2, 1.0, -0.3, 0.4], [1.1, 0.0, -0.2, 2.0, 0.4, 0.1]])] * B).to(DEV)
+    return F, x, eq, comp, rev, w, sos.requires_grad_(True)
+
+
+def _grads(y, w, leaves):
+    for t in leaves:
+        t.grad = None
+    (y * w).sum().backward()
+    return [y.detach().clone()] + [t.grad.clone() if t.grad is not None else None for t in leaves]
+
+
+@pytest.mark.parametrize("op", ["parametric_eq", "compressor", "expander", "gain", "distortion", "sosfilt", "reverb"])
+def test_reference_signatures_through_both_bindings(T, monkeypatch, op):
+    """functional.* / signal.sosfilt_via_fsm on the reference's own argument lists go through torch.ops.dasp.* (round 5: parametric_eq on its 18
+    control tensors, dynamics on six, gain, distortion, sosfilt, noise_shaped_reverb on 25) - same kernels and arguments as the ctypes
+    autograd.Functions: outputs, input gradients and every control gradient agree to the order fp32 atomics land in."""
+    import dasp_pytorch_amd as D
+    F, x, eq, comp, rev, w, sos = _ref_signature_samples()
+    calls = {
+        "parametric_eq": (lambda: F.parametric_eq(x, SR, *eq), [x] + eq, "parametric_eq"),
+        "compressor": (lambda: F.compressor(x, SR, *comp, lookahead_samples=3), [x] + comp, "dynamics"),
+        "expander": (lambda: F.expander(x, SR, *comp), [x] + comp, "dynamics"),
+        "gain": (lambda: F.gain(x, SR, eq[0]), [x, eq[0]], "gain"),
+        "distortion": (lambda: F.distortion(x, SR, torch.stack([comp[5], comp[5]], 1)), [x, comp[5]], "distortion"),
+        "sosfilt": (lambda: D.signal.sosfilt_via_fsm(sos, x), [x, sos], "sosfilt"),
+        "reverb": (lambda: F.noise_shaped_reverberation(x, SR, *rev, num_samples=4096, num_bandpass_taps=255, noise_seed=17), [x] + rev, "noise_shaped_reverb"),
+    }
+    fn, leaves, opname = calls[op]
+    seen = []
+    real = getattr(torch.ops.dasp, opname)
+
+    class Spy:                                  # counts the calls that reach the registered op
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def __call__(self, *a, **k):
+            seen.append(opname)
+            return real(*a, **k)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DASP_TORCH_OPS", flag)
+        if flag == "1":
+            monkeypatch.setattr(torch.ops.dasp, opname, Spy(), raising=False)
+        y = fn()
+        outs.append(_grads(y, w, leaves))
+        if flag == "1":
+            monkeypatch.undo()
+            assert seen, f"functional.{op} did not reach torch.ops.dasp.{opname}"
+    errs = []
+    for a, b in zip(*outs):
+        assert (a is None) == (b is None)
+        if a is not None:
+            errs.append(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30))
+    record(f"reference_signature_torch_ops_vs_ctypes[{op}]", y=errs[0], gx=errs[1], gcontrols=max(errs[2:]))
+    assert errs[0] <= 2e-6 and errs[1] <= 5e-6 and max(errs[2:]) <= 2e-5, errs
+    if op in ("compressor", "expander"):        # release_ms: accepted, zero gradient (functional.py:340,343-344)
+        assert float(outs[0][1 + 4].abs().max()) == 0.0
+
+
+def _new_op_samples():
+    F, x, eq, comp, rev, w, sos = _ref_signature_samples()
+    from dasp_pytorch_amd import ops
+    from dasp_pytorch_amd.functional import _PEQ_TYPES, _device_filterbank
+    filters = _device_filterbank(255, float(SR), torch.device(DEV))
+    xs = x[:2, :, :6000].detach().clone().requires_grad_(True)
+    cut = lambda ts: [t[:2].detach().clone().requires_grad_(True) for t in ts]
+    fspec = ops._reverb_fspec(xs, filters, 2048)
+    return {
+        "parametric_eq": (xs, float(SR), cut(eq), list(_PEQ_TYPES)),
+        "parametric_eq_shared": (xs, float(SR), [t[:1].detach().clone().requires_grad_(True) for t in eq], list(_PEQ_TYPES)),
+        "dynamics": (xs, float(SR), *cut(comp), 1e-8, 0, 0),
+        "dynamics_lookahead_expander": (xs, float(SR), *cut(comp), 1e-8, 4, 1),
+        "gain": (xs, cut([eq[0]])[0]),
+        "distortion": (xs, torch.rand(2, 2, device=DEV).requires_grad_(True)),
+        "sosfilt": (sos[:2].detach().clone().requires_grad_(True), xs),
+        "sosfilt_shared": (sos[:1].detach().clone().requires_grad_(True), xs),
+        "noise_shaped_reverb": (xs, cut(rev[:12]), cut(rev[12:24]), cut(rev[24:])[0], None, fspec, 2048, 255, 5, None, 0.0),
+    }
+
+
+@pytest.mark.parametrize("case", ["parametric_eq", "parametric_eq_shared", "dynamics", "dynamics_lookahead_expander", "gain", "distortion", "sosfilt",
+                                  "sosfilt_shared", "noise_shaped_reverb"])
+def test_opcheck_reference_signatures(T, case):
+    samples = _new_op_samples()
+    op = getattr(torch.ops.dasp, case.split("_shared")[0].split("_lookahead")[0]).default
+    res = torch.library.opcheck(op, samples[case], raise_exception=True)
+    assert all(v == "SUCCESS" for v in res.values()), res
+
+
+@pytest.mark.parametrize("backend", ["aot_eager", "inductor"])
+def test_functional_calls_compile_without_graph_breaks(T, backend):
+    """A module that calls functional.parametric_eq and functional.compressor directly - the reference's signatures - under
+    torch.compile(fullgraph=True): the functions resolve to torch.ops.dasp.parametric_eq / dynamics (round 4: every direct functional.*
+    call was a graph break). Output and all gradients equal the eager module's."""
+    import torch._dynamo
+    import dasp_pytorch_amd as D
+    torch._dynamo.reset()
+
+    class Net(torch.nn.Module):
+        def forward(self, x, eq, comp):
+            y = D.functional.parametric_eq(x, SR, *eq)
+            return D.functional.compressor(y, SR, *comp)
+    F, x, eq, comp, rev, w, sos = _ref_signature_samples()
+    m = Net()
+    outs = []
+    for fn in (m, torch.compile(m, fullgraph=True, backend=backend)):
+        leaves = [x] + eq + comp
+        y = fn(x, eq, comp)
+        outs.append(_grads(y, w, leaves))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(a.abs().max()) + 1e-12)
+
+
+def test_range_flag_words(T):
+    """The normalised ops' `range_flag`: the design kernel / the chain's control kernel OR bit i into the device word when column i leaves
+    [0, 1] (NaN passes, as in the reference); the words are sticky; modules._FlagRangeCheck turns them into the reference's ValueError."""
+    d = torch.ops.dasp
+    m, s = _op_samples()
+    x, pn = s["parametric_eq_norm"][0].detach(), s["parametric_eq_norm"][1].detach().clone()
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d.parametric_eq_norm(x, pn, float(SR), m.types, m.eq_lo, m.eq_span, flag)
+    assert int(flag) == 0
+    pn[1, 4] = 1.25; pn[0, 17] = -0.1; pn[0, 2] = float("nan")
+    d.parametric_eq_norm(x, pn, float(SR), m.types, m.eq_lo, m.eq_span, flag)
+    assert int(flag) == (1 << 4) | (1 << 17)
+    cp, rp, gp = (t.detach().clone() for t in s["chain_controls"][:3])
+    f2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d.chain_controls(cp, rp, gp, m.lo, m.span, f2)
+    assert int(f2) == 0
+    cp[0, 3] = 2.0; rp[1, 13] = -0.5; gp[1, 0] = 1.5                      # release_ms (read by nothing, checked like the others), band1_decay, gain_db
+    d.chain_controls(cp, rp, gp, m.lo, m.span, f2)
+    assert int(f2) & 0xFFFFFFFF == (1 << 3) | (1 << (6 + 13)) | (1 << 31)
+    d.chain_controls(s["chain_controls"][0].detach(), s["chain_controls"][1].detach(), s["chain_controls"][2].detach(), m.lo, m.span, f2)
+    assert int(f2) & 0xFFFFFFFF == (1 << 3) | (1 << (6 + 13)) | (1 << 31)    # sticky: nobody cleared it

@@ -144,6 +144,26 @@ def test_reverb_module_passes_its_noise_keywords(monkeypatch):
         F.noise_shaped_reverberation(torch.zeros(1, 2, 8), SR, *[torch.zeros(1)] * 25, noise_seed_offset=off)
 
 
+def test_decay_bound_is_only_vouched_for_by_a_check_that_ran():
+    """NoiseShapedReverb._decay_bound (the promise that lets the filter bank skip a launch) needs a [0, 1] check that has actually looked at
+    THIS call's values: the blocking check, or a chain that ran it (already_validated). A deferred check has only been submitted (round 4,
+    advisor), a switched-off check says nothing: the bound is then 0 = no promise."""
+    import dasp_pytorch_amd as D
+    from dasp_pytorch_amd import modules as M
+    rev = D.NoiseShapedReverb(44100)
+    assert rev._decay_bound() == 1.0
+    rev.validate_range = "deferred"
+    assert rev._decay_bound() == 0.0
+    with M.already_validated():                      # a chain's blocking check covered this call
+        assert rev._decay_bound() == 1.0
+    with M.already_validated(enforced=False):        # a chain's deferred check was only queued
+        assert rev._decay_bound() == 0.0
+    rev.validate_range = True
+    with M.already_validated(enforced=False):
+        assert rev._decay_bound() == 0.0
+    assert rev._decay_bound() == 1.0
+
+
 def test_deferred_range_check_on_cpu_tensors_is_immediate():
     """validate_range = "deferred" exists to avoid a device read-back; CPU parameter tensors are simply checked at once (same ValueError)."""
     import dasp_pytorch_amd as D
