@@ -99,6 +99,7 @@ SIGNATURES = {
     "dasp_dynamics64_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, _d, _i, _p]),
     "dasp_ew64_forward": (_i, [_i, _p, _p, _p, _i, _i, _l, _p]),
     "dasp_ew64_backward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _p]),
+    "dasp_reverb_plan": (_i, [_l, ctypes.c_float, _i]),
     "dasp_reverb_sizes": (_i, [_i, _l, _i, _i, _i, ctypes.POINTER(ctypes.c_long)]),
     "dasp_reverb_filter_spectrum": (_i, [_p, _i, _i, _p, _p]),
     "dasp_reverb_forward": (_i, [_p] * 13 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),

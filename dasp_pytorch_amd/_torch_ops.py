@@ -185,7 +185,30 @@ def load():
     return _state["loaded"]
 
 
+def _plan_from_env():
+    """The segment-plan overrides of the two scan families as the extension takes them: -1 = the library's planner, 0 = never segment,
+    > 0 = tiles per segment (developer switches DASP_SOS_SEGMENT / DASP_SOS_SEGMENT_TILES / DASP_DYN_SEGMENT / DASP_DYN_SEGMENT_TILES - the
+    same ones the ctypes binding reads in ops.py; the compiled code reads no environment)."""
+    def one(flag, tiles):
+        if os.environ.get(flag, "auto") == "0":
+            return 0
+        t = os.environ.get(tiles)
+        return int(t) if t and int(t) > 0 else -1
+    return one("DASP_SOS_SEGMENT", "DASP_SOS_SEGMENT_TILES"), one("DASP_DYN_SEGMENT", "DASP_DYN_SEGMENT_TILES")
+
+
+def sync_plan():
+    """Push the environment's plan overrides to the extension when they changed since the last push."""
+    plan = _plan_from_env()
+    if plan != _state.get("plan", (-1, -1)):
+        torch.ops.dasp._plan_override(*plan)
+        _state["plan"] = plan
+
+
 def enabled():
     """True when the chain ops should go through torch.ops.dasp.* (the extension is built and loadable, DASP_TORCH_OPS is not 0, and
     bench.py's per-call HIP-event timers - which live in the ctypes binding - are off)."""
-    return os.environ.get("DASP_TORCH_OPS", "1") != "0" and not _lib.timers.enabled and load()
+    on = os.environ.get("DASP_TORCH_OPS", "1") != "0" and not _lib.timers.enabled and load()
+    if on:
+        sync_plan()
+    return on

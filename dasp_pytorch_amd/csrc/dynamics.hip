@@ -88,12 +88,12 @@ __device__ __forceinline__ f4 load4(const float* __restrict__ p, long idx, long 
     r.w = (idx + 3 >= 0 && idx + 3 < n_valid) ? p[idx + 3] : 0.f;
     return r;
 }
-__device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_valid, bool fast, f4 v) {
-    if (fast) { st_stream(reinterpret_cast<f4*>(p + idx), v); return; }
-    if (idx + 0 < n_valid) p[idx + 0] = v.x;
-    if (idx + 1 < n_valid) p[idx + 1] = v.y;
-    if (idx + 2 < n_valid) p[idx + 2] = v.z;
-    if (idx + 3 < n_valid) p[idx + 3] = v.w;
+// through: write-through at agent scope (common.hpp st_through) - the bulk output of a launch that ends with a cross-workgroup hand-off
+__device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_valid, bool fast, f4 v, bool through = false) {
+    if (fast) { if (through) st_through(reinterpret_cast<f4*>(p + idx), v); else st_stream(reinterpret_cast<f4*>(p + idx), v); return; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (idx + i < n_valid) { if (through) st_through(p + idx + i, v[i]); else p[idx + i] = v[i]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,7 +407,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                     lin = load4(lin_buf + (size_t)b * N, p + lk, N, false);
                 }
                 const f4 g = DMA ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : load4<true>(gb + (size_t)c * N, p + lk, N, fast_in);
-                store4(gxb + (size_t)c * N, p, N, fast, g * lin + q[j]);
+                store4(gxb + (size_t)c * N, p, N, fast, g * lin + q[j], SEG == 1);      // (segmented: the launch ends with the finalize hand-off)
             }
         }
         pending_stores = fast ? C * DY_SUB : 0;       // a full tile issues exactly C * DY_SUB wave-wide stores; anything else: wait for all

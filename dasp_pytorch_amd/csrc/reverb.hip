@@ -30,7 +30,6 @@
 // d ir = first half of IFFT(sum_k GW_k conj(X_k)), with X_k recomputed from the saved column transforms A.
 #include "common.hpp"
 #include "fft_lds.hpp"
-#include <cstdlib>
 
 namespace dasp {
 
@@ -358,16 +357,10 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
 }
 
 // ---- long convolution ----------------------------------------------------------------------------------------------
-// Frames of n1 = NA x 512 points, NA = 2^logNA (radix-2 frames: blocks of Lb = n1 / 2 samples) or NA = 3 x 2^logNA (round 4, "R3"
-// frames: blocks of Lb = 2 n1 / 3 samples, i.e. one third of a frame is padding instead of one half). Where the signal is N = 4 Lp
-// samples against an impulse response of Lp = nextpow2(L) samples - BASELINE config 4 - a signal is ONE pair of blocks in one 3 Lp-point
-// frame instead of two pairs in two 2 Lp-point frames: three quarters of the frame traffic of every pass. The factor 3 lives in the
-// column transforms only, as one decimation-in-frequency step around the power-of-two col_fft:
-//   forward   u_k2[m] = w_NA^(m k2) sum_s x[m + NAp s] w_3^(s k2),  k2 = 0, 1, 2  -> three NAp-point transforms -> rows ka = 3 k1 + k2
-//   inverse   the mirror image (three NAp-point inverse transforms of the rows 3 k1 + k2, conjugate twiddle, radix-3 butterfly)
-// so the frequency index stays k = ka + NA kb with ka in natural order and the row pass (512-point transforms, products, the Hermitian
-// mirror of the paired impulse responses) does not change beyond taking its twiddles and mirror rows modulo a non-power-of-two.
-// (logNA is log2 of the power-of-two part NAp = NA / 3 for R3 frames.)
+// Frames of n1 = NA x 512 points, NA = 2^logNA: blocks of Lb = n1 / 2 samples. (Round 4 also built frames of 3 x 2^k points - one
+// decimation-in-frequency radix-3 step around the power-of-two column transforms, a signal of N = 4 Lp samples as one 3 Lp-point frame
+// instead of two 2 Lp-point frames - verified them against this path and measured the long convolution at 1.79 ms against 1.60
+// (profiles/r04/reverb_r3_kernels.log): removed in round 5, the code is in the history of this file.)
 struct ConvDims { int logNA, NA, n1, Lb, npairs; long N; };
 
 // forward twiddle w_n1^(ka (j + 64 q)), q = 0..7, as a chain from two accurate sincospi evaluations
@@ -382,30 +375,6 @@ __device__ __forceinline__ void fourstep_twiddles(int ka, int j, int n1, float (
 }
 
 
-// radix-3 butterfly term: (ar, ai) + w (br, bi) + w^2 (cr, ci) with w = exp(DIR 2 pi i K2 / 3), K2 = 1 or 2 (K2 = 0: the plain sum)
-template <int DIR, int K2>
-__device__ __forceinline__ void radix3_term(float ar, float ai, float br, float bi, float cr, float ci, float& outr, float& outi) {
-    constexpr float H = 0.86602540378443864676f;                     // sin(2 pi / 3)
-    // w^K2 = (-1/2, s H), w^(2 K2) = (-1/2, -s H), s = DIR for K2 = 1 and -DIR for K2 = 2
-    constexpr float sg = (DIR < 0 ? -1.f : 1.f) * (K2 == 1 ? 1.f : -1.f);
-    const float sr = br + cr, si = bi + ci, dr = br - cr, di = bi - ci;
-    outr = ar - 0.5f * sr - sg * H * di;
-    outi = ai - 0.5f * si + sg * H * dr;
-}
-// (sin, cos)(2 pi f) for 0 <= f < 1 with few instructions and registers (the twiddles w_NA^(m k2) of the R3 step, 16 per thread and
-// sub-transform pair: sincospif's general argument reduction costs the column kernels their registers): nearest quarter turn taken off
-// exactly, degree-9 / degree-8 polynomials on |x| <= pi / 4 (truncation 4e-9 / 3e-10), quadrant rotation. Absolute error <= 1.5e-7.
-__device__ __forceinline__ void sincos_turns(float f, float& sn, float& cs) {
-    const float k = rintf(4.f * f);                 // 0 .. 4
-    const float x = (f - 0.25f * k) * 6.283185307179586f;        // f - k / 4 is exact
-    const float x2 = x * x;
-    const float sp = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.f);
-    const float cp = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.f);
-    const int q = (int)k & 3;
-    sn = q == 0 ? sp : q == 1 ? cp : q == 2 ? -sp : -cp;
-    cs = q == 0 ? cp : q == 1 ? -sp : q == 2 ? -cp : sp;
-}
-
 // Column pass, time -> A[ka][jb]. grid (NA * 512 / 4096 column tiles, pairs, signals), 512 threads; thread (j, c): column jb = tile * TC + c,
 // elements ja = j + (NA / 8) q.   MODE 0: zero-padded blocks 2p (real) and 2p+1 (imaginary) of x (:570)
 //                                 MODE 1: overlapped windows [k Lb, k Lb + 2 Lb) of gy, k = 2p, 2p+1
@@ -414,8 +383,8 @@ __device__ __forceinline__ void sincos_turns(float f, float& sn, float& cs) {
 //                                         spectrum of the pair by its Hermitian symmetry (pair_spectrum_rows)
 // src_shift: 1 = mono input, both signals of an item read row (sig >> 1) of src (the reference duplicates a mono input to stereo,
 // functional.py:493-495: here the duplicate never exists); 0 otherwise.
-template <int MODE, bool R3 = false>
-__global__ __launch_bounds__(LoadGeom::T, R3 ? 4 : 1) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
+template <int MODE>
+__global__ __launch_bounds__(LoadGeom::T, 1) void conv_load_kernel(const float* __restrict__ src, const float* __restrict__ mix, const f2* __restrict__ tw,
                                                           f2* __restrict__ A, ConvDims d, int L, int src_shift = 0) {
     __shared__ f2 lds[LoadGeom::LDS];
     const ColCfg g = col_config<LOAD_LOG>(d.logNA, threadIdx.x);
@@ -423,81 +392,6 @@ __global__ __launch_bounds__(LoadGeom::T, R3 ? 4 : 1) void conv_load_kernel(cons
     const long sig = blockIdx.z, srow = sig >> src_shift;
     const int jb = xcd_tile(blockIdx.x, gridDim.x) * g.TC + g.c;
     (void)mix;
-    if constexpr (R3) {
-        // R3 frame: thread (j, c) holds m = j + T q of column jb for the three thirds s of the frame (time m 512 + jb + s n1 / 3)
-        const int third = d.n1 / 3;
-        f2* out = A + (sig * d.npairs + p) * (long)d.n1;
-        float xr[3][8], xi[3][8];
-        if (MODE == 2) {                  // the impulse responses (L <= third samples per row): only the first third is not padding
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int tt = (g.j + g.T * q) * CV_NB + jb;
-                xr[0][q] = src[2 * sig * L + (tt < L ? tt : L - 1)];
-                xi[0][q] = src[(2 * sig + 1) * L + (tt < L ? tt : L - 1)];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int tt = (g.j + g.T * q) * CV_NB + jb;
-                xr[0][q] = tt < L ? xr[0][q] : 0.f; xi[0][q] = tt < L ? xi[0][q] : 0.f;
-                xr[1][q] = xi[1][q] = xr[2][q] = xi[2][q] = 0.f;
-            }
-        } else {
-            // MODE 0: blocks 2p (real) and 2p + 1 (imaginary) of Lb = 2 thirds, the last third of the frame is padding
-            // MODE 1: windows [k Lb, k Lb + n1) of gy, k = 2p, 2p + 1: five thirds of signal, window 2p + 1 starts two thirds in
-            constexpr int NU = MODE == 0 ? 4 : 5;
-            float v[NU][8];
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const long n = (long)(2 * p) * d.Lb + (long)u * third + (g.j + g.T * q) * CV_NB + jb;
-                    v[u][q] = src[srow * d.N + (n < d.N ? n : d.N - 1)];
-                }
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const long n = (long)(2 * p) * d.Lb + (long)u * third + (g.j + g.T * q) * CV_NB + jb;
-                    v[u][q] = n < d.N ? v[u][q] : 0.f;
-                }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                xr[0][q] = v[0][q]; xr[1][q] = v[1][q]; xi[0][q] = v[2][q]; xi[1][q] = v[3][q];
-                xr[2][q] = MODE == 1 ? v[2][q] : 0.f;
-                xi[2][q] = MODE == 1 ? v[NU - 1][q] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 3; ++k2) {
-            // the thread coordinates pass through an opaque move once per sub-transform: otherwise the twiddles and the 24 store addresses
-            // of all three are formed up front and the kernel needs 188 registers (one workgroup per CU)
-            ColCfg gl = g;
-            { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); gl.j += z; }
-            float r[8], i[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (k2 == 0) { r[q] = xr[0][q] + xr[1][q] + xr[2][q]; i[q] = xi[0][q] + xi[1][q] + xi[2][q]; }
-                else {
-                    if (k2 == 1) radix3_term<-1, 1>(xr[0][q], xi[0][q], xr[1][q], xi[1][q], xr[2][q], xi[2][q], r[q], i[q]);
-                    else radix3_term<-1, 2>(xr[0][q], xi[0][q], xr[1][q], xi[1][q], xr[2][q], xi[2][q], r[q], i[q]);
-                    float ws, wc;
-                    sincos_turns((float)(k2 * (gl.j + gl.T * q)) / (float)d.NA, ws, wc);         // forward: exp(-i phi), phi = 2 pi m k2 / NA
-                    const float t = r[q] * wc + i[q] * ws;
-                    i[q] = i[q] * wc - r[q] * ws;
-                    r[q] = t;
-                }
-            }
-            col_fft<-1>(r, i, gl, tw, lds);
-            const int jbo = xcd_tile(blockIdx.x, gridDim.x) * gl.TC + gl.c;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f2* o = out + (long)(3 * (gl.j + gl.T * q) + k2) * CV_NB + jbo;
-                if (MODE == 2) st_stream(o, f2{r[q], i[q]}); else *o = f2{r[q], i[q]};
-            }
-            __syncthreads();              // the next transform's first exchange writes the image this one may still be reading
-        }
-        return;
-    }
     constexpr float scale = 1.f;
     // every load first, at an address that is always valid, the bounds applied to the values afterwards: a load under its own bounds
     // check is a branch with a wait in it - eight exposed round trips per thread (column loads of x / gy / the impulse responses: 196 -> 167, 248 -> 187, 96 -> 81 us)
@@ -659,130 +553,6 @@ __global__ __launch_bounds__(FFT_T, MODE == 1 ? 2 : 4) void conv_rows_kernel(con
 }
 
 // (launch bounds: 8 waves per SIMD = two workgroups per CU, <= 64 VGPRs; left to itself the forward instance took 66 and ran alone on its CU: 217 -> 250 us)
-// R3 frames (see ConvDims): the inverse of conv_load_kernel<*, true>'s decimation-in-frequency step - three NAp-point inverse column
-// transforms of the rows 3 k1 + k2, conjugate twiddle, radix-3 butterfly -> the three thirds of the frame, then the same epilogues on
-// thirds instead of halves (a block is two thirds of a frame, its convolution tail the third one). A thread carries three times the
-// elements of the radix-2 kernel's (<= 128 registers), so the workgroups are the 512-thread kind of the load kernels: two of them share a
-// CU and cover each other's barriers and round trips (as ONE 1024-thread workgroup per CU the forward instance took 331 us against the
-// radix-2 kernel's 221 at BASELINE config 4, on 0.88 of its traffic).
-template <int MODE>
-__global__ __launch_bounds__(LoadGeom::T, 4) void conv_cols_r3_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
-                                                             const float* __restrict__ gy, const float* __restrict__ mix,
-                                                             float* __restrict__ out, float* __restrict__ mix_part, ConvDims d, int L, int x_shift = 0) {
-    __shared__ f2 lds[LoadGeom::LDS];
-    __shared__ float red[LoadGeom::T / 64];
-    const ColCfg g = col_config<LOAD_LOG>(d.logNA, threadIdx.x);
-    const long sig = MODE == 1 ? (long)blockIdx.z : blockIdx.y, xrow = sig >> x_shift;          // MODE 2: sig = batch item
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int third = d.n1 / 3;
-    const float inv = 1.f / (float)d.n1;
-    const float m = mix[MODE == 2 ? sig : sig >> 1];
-    float carry[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) carry[q] = 0.f;
-    float macc = 0.f;
-    const int p_lo = MODE == 1 ? (int)blockIdx.y : 0, p_hi = MODE == 0 ? d.npairs : p_lo + 1;
-#pragma unroll 1
-    for (int p = p_lo; p < p_hi; ++p) {
-        const f2* in = W + (sig * d.npairs + p) * (long)d.n1;
-        // thirds of the frame, accumulated as the three sub-transforms arrive: y_s = (u_0 + w^s u_1 + w^(2 s) u_2) / n1, w = exp(+2 pi i / 3)
-        // (MODE 2 needs the first third only; MODE 1, overlap-save, discards the last one: the wrapped part of the correlation)
-        constexpr int NS = MODE == 2 ? 1 : MODE == 1 ? 2 : 3;
-        constexpr float H3 = 0.86602540378443864676f;
-        float yr[3][8], yi[3][8];
-#pragma unroll
-        for (int k2 = 0; k2 < 3; ++k2) {
-            ColCfg gl = g;                                    // (opaque per sub-transform, as in conv_load_kernel<*, true>)
-            { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); gl.j += z; }
-            const int jbi = tile * gl.TC + gl.c;
-            float r[8], i[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const f2 v = in[(long)(3 * (gl.j + gl.T * q) + k2) * CV_NB + jbi]; r[q] = v.x; i[q] = v.y; }
-            col_fft<1>(r, i, gl, tw, lds);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float tr = r[q] * inv, ti = i[q] * inv;
-                if (k2 > 0) {
-                    float ws, wc;
-                    sincos_turns((float)(k2 * (gl.j + gl.T * q)) / (float)d.NA, ws, wc);         // inverse: exp(+i phi)
-                    const float t = tr * wc - ti * ws;
-                    ti = tr * ws + ti * wc;
-                    tr = t;
-                }
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int e = (s * k2) % 3;               // w^e: (1, 0), (-1/2, H3), (-1/2, -H3)
-                    const float cr = e == 0 ? 1.f : -0.5f, ci = e == 0 ? 0.f : (e == 1 ? H3 : -H3);
-                    const float ar = tr * cr - ti * ci, ai = tr * ci + ti * cr;
-                    if (k2 == 0) { yr[s][q] = ar; yi[s][q] = ai; } else { yr[s][q] += ar; yi[s][q] += ai; }
-                }
-            }
-            __syncthreads();
-        }
-        ColCfg ge = g;                                        // (opaque once more: the epilogue's addresses are formed here, not up front)
-        { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); ge.j += z; }
-        const int jbe = tile * ge.TC + ge.c;
-        if (MODE == 2) {
-            float xa[8], xb[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int rr = (ge.j + ge.T * q) * CV_NB + jbe, o = rr < L ? rr : L - 1;
-                xa[q] = x[2 * sig * L + o]; xb[q] = x[(2 * sig + 1) * L + o];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int rr = (ge.j + ge.T * q) * CV_NB + jbe;
-                if (rr < L) {
-                    const float ca = yr[0][q], cb = yi[0][q];
-                    out[2 * sig * L + rr] = m * ca;
-                    out[(2 * sig + 1) * L + rr] = m * cb;
-                    macc = fmaf(xa[q], ca, fmaf(xb[q], cb, macc));
-                    if (rr == 0) macc -= ca + cb;
-                }
-            }
-        } else {
-            const float* sgn = MODE == 0 ? x + xrow * d.N : gy + sig * d.N;       // the dry signal of the wet / dry mix (forward: x, backward: gy)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float xa[8], xb[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const long na = (long)(2 * p) * d.Lb + (long)s * third + (ge.j + ge.T * q) * CV_NB + jbe, nbk = na + d.Lb;
-                    xa[q] = sgn[na < d.N ? na : d.N - 1]; xb[q] = sgn[nbk < d.N ? nbk : d.N - 1];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const long na = (long)(2 * p) * d.Lb + (long)s * third + (ge.j + ge.T * q) * CV_NB + jbe, nbk = na + d.Lb;
-                    float wa, wb;
-                    if (MODE == 0) {
-                        // block 2p: its own thirds (+ the tail of block 2p - 1 on the first); block 2p + 1: + the tail of block 2p on the first
-                        wa = s == 0 ? yr[0][q] + carry[q] : yr[1][q];
-                        wb = s == 0 ? yi[0][q] + yr[2][q] : yi[1][q];
-                    } else {
-                        wa = yr[s][q]; wb = yi[s][q];
-                    }
-                    if (na < d.N) out[sig * d.N + na] = fmaf(m, wa - xa[q], xa[q]);
-                    if (nbk < d.N) out[sig * d.N + nbk] = fmaf(m, wb - xb[q], xb[q]);
-                }
-            }
-            if (MODE == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) carry[q] = yi[2][q];
-            }
-        }
-    }
-    if (MODE == 2) {
-        const float s = wave_sum(macc);
-        if (lane_id() == 0) red[wave_id()] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float a = 0.f;
-            for (int v = 0; v < LoadGeom::T / 64; ++v) a += red[v];
-            mix_part[sig * gridDim.x + blockIdx.x] = a;
-        }
-    }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(ColsGeom::T, 8) void conv_cols_kernel(const f2* __restrict__ W, const f2* __restrict__ tw, const float* __restrict__ x,
                                                           const float* __restrict__ gy, const float* __restrict__ mix,
@@ -899,24 +669,28 @@ inline int rv_check() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DASP_OK : (int)e;
 }
-struct RvDims { ConvDims c; int nblk, VQ, nwin, ltiles, ctiles, rowgroups, chunk, r3; long R; };
+struct RvDims { ConvDims c; int nblk, VQ, nwin, ltiles, ctiles, rowgroups, chunk; long R; };
+// Plan overrides (dasp_reverb_plan, dasp_hip.h): explicit arguments of the C ABI for the three choices the planner makes, -1 = the planner's
+// own (rounds 2 - 4 read them from the environment). Process-wide; tests and developer A/Bs set them and set them back.
+long g_plan_chunk = -1;
+float g_plan_weight_limit = -1.f;
+int g_plan_band_split = -1;
 // Signals per pass of the long-convolution pipeline: all of them by default. Passes over chunks of signals that reuse chunk-sized scratch
 // buffers were built to keep the 8 B per frame point the three kernels of a pass hand to each other in the 256 MB last-level cache; measured
 // at (128, 2, 262144) it only cost time (fwd + bwd 2.85 ms in one pass, 2.91 / 2.94 / 2.98 / 3.28 ms with 128 / 64 / 32 / 16 signals per
 // pass): the passes run at the rate of their HBM traffic either way and the extra launches and partially filled waves of small grids
-// are not paid back. DASP_REVERB_CHUNK=<signals per pass> keeps the experiment reproducible.
+// are not paid back. dasp_reverb_plan(chunk = signals per pass, ..) keeps the experiment reproducible.
 inline int rv_chunk(long R, long frame_elems_per_signal) {
     (void)frame_elems_per_signal;
-    long c = R;
-    if (const char* e = getenv("DASP_REVERB_CHUNK")) c = atol(e);          // developer override; 0 = all at once
+    long c = g_plan_chunk > 0 ? g_plan_chunk : R;
     if (c <= 0 || c > R) c = R;
     c &= ~1L;                                        // the two signals of a batch item stay together (they share mix)
     return (int)(c < 2 ? 2 : c);
 }
-// largest |rho| * 4096 served with the envelope inside the transform (fb_fused_kernel); DASP_REVERB_WEIGHT_LIMIT=0 sends every item the
-// per-band way (developer A/B and the route-equality test)
+// largest |rho| * 4096 served with the envelope inside the transform (fb_fused_kernel); dasp_reverb_plan(.., weight_limit = 0, ..) sends every
+// item the per-band way (developer A/B and the route-equality test)
 inline float rv_weight_limit() {
-    if (const char* e = getenv("DASP_REVERB_WEIGHT_LIMIT")) { const float v = (float)atof(e); if (v >= 0.f && v <= 8.f) return v == 0.f ? -1.f : v; }
+    if (g_plan_weight_limit >= 0.f && g_plan_weight_limit <= 8.f) return g_plan_weight_limit == 0.f ? -1.f : g_plan_weight_limit;
     return RV_WEIGHT_LIMIT;
 }
 // decay_bound > 0: the caller vouches that no band decay exceeds it (Processor.process_normalized: the validated upper end of the parameter
@@ -928,7 +702,7 @@ inline int rv_only_route1(float decay_bound, float tstep, float limit) {
 }
 // workgroups per (item, window) of the filter-bank kernel: the bands are dealt out when B * windows would leave most of the chip idle
 inline int rv_band_split(int B, int nwin, int nb) {
-    if (const char* e = getenv("DASP_REVERB_BAND_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= nb) return v; }
+    if (g_plan_band_split >= 1 && g_plan_band_split <= nb) return g_plan_band_split;
     // every share repeats the window's inverse transform (forward) and adds its part with atomics, so the bands are only dealt out until
     // ~128 workgroups exist (measured at 131072 samples, fwd + bwd: 1 item 0.148 -> 0.113 ms, 2 items 0.155 -> 0.129, 4 items 0.164 -> 0.146,
     // 8 items and more: no split is fastest; profiles/r02/reverb_band_split.log)
@@ -937,42 +711,22 @@ inline int rv_band_split(int B, int nwin, int nb) {
     while (nb % split) ++split;             // equal shares
     return split;
 }
-// column kernels of radix-2 and of R3 frames (d.r3, st in scope)
-#define DASP_RV_LOAD(MODE_, GRID_, ...)                                                                                        \
-    do {                                                                                                                       \
-        if (d.r3) hipLaunchKernelGGL((conv_load_kernel<MODE_, true>), GRID_, dim3(LoadGeom::T), 0, st, __VA_ARGS__);            \
-        else hipLaunchKernelGGL((conv_load_kernel<MODE_, false>), GRID_, dim3(LoadGeom::T), 0, st, __VA_ARGS__);                \
-    } while (0)
-#define DASP_RV_COLS(MODE_, GRID_, ...)                                                                                        \
-    do {                                                                                                                       \
-        if (d.r3) hipLaunchKernelGGL(conv_cols_r3_kernel<MODE_>, GRID_, dim3(LoadGeom::T), 0, st, __VA_ARGS__);                 \
-        else hipLaunchKernelGGL(conv_cols_kernel<MODE_>, GRID_, dim3(ColsGeom::T), 0, st, __VA_ARGS__);                         \
-    } while (0)
+#define DASP_RV_LOAD(MODE_, GRID_, ...) hipLaunchKernelGGL((conv_load_kernel<MODE_>), GRID_, dim3(LoadGeom::T), 0, st, __VA_ARGS__)
+#define DASP_RV_COLS(MODE_, GRID_, ...) hipLaunchKernelGGL(conv_cols_kernel<MODE_>, GRID_, dim3(ColsGeom::T), 0, st, __VA_ARGS__)
 inline bool rv_dims(int B, long N, int L, int taps, RvDims* o) {
     RvDims d;
     long Lb = ColsGeom::N / 2;                       // n1 >= 8192 keeps every workgroup of the four-step kernels full
     while (Lb < L) Lb <<= 1;
     if (Lb > (1L << 20)) return false;               // NA = n1 / 512 <= 4096
-    // Frame plan. Lp = Lb as found: the impulse response padded to a power of two. Radix-2 frames: blocks of Lp samples in 2 Lp-point
-    // frames - the plan. R3 frames (round 4): blocks of 2 Lp samples in 3 Lp-point frames; where N = 4 Lp (BASELINE config 4) a signal is
-    // then one 3 Lp frame instead of two 2 Lp frames, 0.75 of the frame points. BUILT, VERIFIED (tests/test_gpu_reverb.py) AND MEASURED
-    // SLOWER, so they are only taken on request (DASP_REVERB_RADIX3=1; profiles/r04/reverb_r3_kernels.log, (128, 2, 262144), us per step,
-    // R3 against radix 2): row passes 208 + 407 against 230 + 427 (fewer rows), column loads 173 + 178 against 170 + 191, inverse columns
-    // 316 + 267 against 227 + 209, impulse-response spectra (1.5 x the frame) 73 + 70 + 96 against 39 + 48 + 62: long convolution 1.79 ms
-    // against 1.60. The column passes are not purely bound by the bytes the frames shrink: a radix-2 inverse column kernel spends 157 of
-    // its 227 us issuing vector instructions, and an R3 thread carries three sub-transforms - the same instructions per frame point plus
-    // the radix-3 step, at half the waves per SIMD (128 registers) - so the 12 % fewer bytes buy nothing there.
-    const long Lp = Lb;
-    d.r3 = 0;
-    if (const char* e = getenv("DASP_REVERB_RADIX3")) d.r3 = Lp >= ColsGeom::N && Lp <= (1L << 19) && atoi(e) != 0;      // (NAp = Lp / 512 >= 16)
-    const long napow = d.r3 ? Lp / CV_NB : 2 * Lp / CV_NB;                         // power-of-two column-transform length
-    d.c.Lb = (int)(d.r3 ? 2 * Lp : Lp); d.c.n1 = (int)(d.r3 ? 3 * Lp : 2 * Lp); d.c.NA = d.c.n1 / CV_NB;
+    // Frame plan: blocks of Lb samples (the impulse response padded to a power of two) in 2 Lb-point frames
+    d.c.Lb = (int)Lb; d.c.n1 = (int)(2 * Lb); d.c.NA = d.c.n1 / CV_NB;
+    const long napow = d.c.NA;                       // column-transform length
     d.c.logNA = 0; while ((1L << d.c.logNA) < napow) ++d.c.logNA;
     d.c.N = N;
     d.nblk = (int)((N + d.c.Lb - 1) / d.c.Lb);
     d.c.npairs = (d.nblk + 1) / 2;
     d.ltiles = (int)(napow * CV_NB / LoadGeom::N);   // column tiles of the forward / inverse column kernels
-    d.ctiles = (int)(napow * CV_NB / (d.r3 ? LoadGeom::N : ColsGeom::N));
+    d.ctiles = (int)(napow * CV_NB / ColsGeom::N);
     d.rowgroups = d.c.NA / 8;                        // 8 rows (waves) per workgroup of the row pass
     d.R = 2L * B;
     d.VQ = (FFT_N - (taps - 1)) / 512;              // valid outputs per filter-bank window = 512 VQ
@@ -993,6 +747,10 @@ extern "C" {
  * [8] = floats of ir / gir (2B * L), [9] = signals per pass of the long-convolution pipeline (chunk),
  * [10] = floats of mix_part, [11] = floats of the gain / decay partial sums,
  * [12] = complex elements of the scratch buffers W / Ag (chunk * pairs * n1, at least B * nb * 4096), [13] = complex elements of the scratch buffers Ah / P (chunk / 2 * n1: one complex frame per item of a pass) */
+int dasp_reverb_plan(long chunk, float weight_limit, int band_split) {
+    g_plan_chunk = chunk; g_plan_weight_limit = weight_limit; g_plan_band_split = band_split;
+    return DASP_OK;
+}
 int dasp_reverb_sizes(int B, long N, int L, int taps, int nb, long* sizes) {
     if (!sizes || B <= 0 || N <= 0 || L <= 0 || taps <= 0 || nb <= 0 || nb > RV_BANDS_MAX) return DASP_ERR_ARG;
     RvDims d;

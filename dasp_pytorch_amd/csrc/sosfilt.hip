@@ -145,33 +145,13 @@ __device__ void rbj_design(int type, double sample_rate, double gain_db, double 
 // ------------------------------------------------------------------------------------------------
 // Prep kernel: one workgroup per batch item. Builds the realisation and all chunk tables in fp64.
 constexpr double OM_MIN = 1e-5;
-// A section whose poles are complex and at least this far (imaginary part) from the real axis runs in direct form between the exact
-// chunk restarts (5 ops per sample against 7 in normal form): the internal signals of a direct form exceed the normal form's by
-// 1 / (2 sin(pole angle)), which is what costs digits near z = +-1 and nothing in the middle of the band.
+// A section whose poles are complex and at least this far (imaginary part) from the real axis is flagged "direct" in its coefficient row (rounds 2 - 4's
+// recomputation kernels ran such sections in direct form between the exact chunk restarts; the flag is kept in the table layout).
 #ifndef DASP_DF_OM_MIN
 #define DASP_DF_OM_MIN 0.125
 #endif
-// The backward kernel's recomputation uses the direct form (its signals only enter the coefficient correlations: parameter
-// gradients unchanged to their digits, -4.6 % kernel time). The forward kernel does not by default: there it bought 2 % and moved the
-// worst y error over 2.6k random configurations from 1.5e-6 to 8.9e-6 (scripts/fuzz_gpu.py).
 #ifndef DASP_STATES_CACHED
 #define DASP_STATES_CACHED 1   // the backward kernel reads the saved chunk states with the caches' normal policy (not streaming)
-#endif
-#ifndef DASP_FWD_DIRECT
-#define DASP_FWD_DIRECT 0
-#endif
-#ifndef DASP_GRAM_ZVALU
-#define DASP_GRAM_ZVALU 1      // sos_bwd_gram_kernel: the chunk table products of the adjoint scan on the VALU (SGPR table) instead of the matrix cores
-#endif
-#ifndef DASP_GRAM_INTERLEAVE
-#define DASP_GRAM_INTERLEAVE 1 // sos_bwd_gram_kernel: the products that do not depend on the adjoint scan are issued from inside it (tile_scan_h)
-#endif
-#ifndef DASP_GRAM_ABLATE
-#define DASP_GRAM_ABLATE 0     // measurement builds only (wrong results): 1 = no Gram products, 2 = no gx products, 4 = no fp64 fold, 8 = no adjoint scan
-#endif
-#ifndef DASP_FWD_MFMA_OUT
-#define DASP_FWD_MFMA_OUT 2      // forward kernel: the chunk's outputs on the matrix cores (y = T x + O s0) instead of the per-lane cascade;
-                                 // 1 = one workgroup per row only, 2 = segmented rows as well, 0 = never
 #endif
 
 // The per-chunk basis responses of an item's cascade (GramFin<S>, below: what the finalize step of the Gram-matrix backward multiplies the
@@ -179,6 +159,7 @@ constexpr double OM_MIN = 1e-5;
 // segmented rows, whose finalize step is the tail of the backward launch, the design kernel computes them here, beside its own chains.
 template <int S> struct GramFin;
 template <int S, bool AGENT> __device__ __forceinline__ void gram_basis_responses(const double* cf, double* bas, int tid);
+template <int S> __device__ __forceinline__ constexpr int basis_doubles();       // GramFin<S>::BASIS (defined with it)
 
 // 256 threads; 384 when `basis` is given: waves 4 and 5 then compute the basis responses (one thread per basis vector) while waves 0 - 3
 // run the chunk-table recursion, the squarings and the output maps.
@@ -194,7 +175,7 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     if (threadIdx.x >= 256) {           // helper waves: the same barriers as everybody else, the basis responses between the second and the third
         __syncthreads();
         __syncthreads();
-        gram_basis_responses<S, false>(&cfb[0][0], basis + (size_t)blockIdx.x * ((S * (L + 2) + 2 * S * L) * (L + 2 * S)), (int)threadIdx.x - 256);
+        gram_basis_responses<S, false>(&cfb[0][0], basis + (size_t)blockIdx.x * basis_doubles<S>(), (int)threadIdx.x - 256);
         __syncthreads();
         if (segtab)
             for (int step = 0; step < nsq_seg; ++step) __syncthreads();
@@ -551,13 +532,6 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
 // SEG 0: one workgroup per row. SEG 1 / 2: the segmented scheme for few rows (oracle/chunkscan_model.py forward_row_segmented): one
 // workgroup per (row, segment of Tseg tiles); 2 = the scan-only pre-pass from a zero state, which leaves the segment's end state in
 // zseg[row][segment][2S]; 1 = the ordinary pass from the segment's start state segstart[row][segment][2S].
-constexpr bool defined_ablate_4() {
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 4)
-    return true;
-#else
-    return false;
-#endif
-}
 template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, W >= 16 ? 4 : (W * 2 + 3) / 4)   // two workgroups per CU (W = 16, few rows: one)
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
@@ -566,19 +540,18 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                float* __restrict__ chain_tab = nullptr, const double* __restrict__ segtab = nullptr, float* __restrict__ chain_start = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L;        // unpadded, swizzled tile images (common.hpp)
-    constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, then DF rows
-    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
+    constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW];
     const int lane = lane_id(), wave = wave_id();
     const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt;   // this workgroup's tiles
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
     float* __restrict__ yr = y + (size_t)row * N;
-    // mailboxes, coefficients and per-lane powers first: below 64 KiB their addresses fold into the 16-bit DS offset field (behind
+    // mailboxes and per-lane powers first: below 64 KiB their addresses fold into the 16-bit DS offset field (behind
     // the tile images every slot needed an address register of its own, ~14 VGPRs that ended up spilled on the carry chain)
     const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;
-    float* cf_lds = lds + LDS_MB;
-    float* pw_lds = cf_lds + LDS_CF;
+    float* pw_lds = lds + LDS_MB;
     float* tbx = pw_lds + LDS_PW + wave * 2 * IMG;   // x image: this tile's, then (by LDS-DMA, as soon as it has been read) the next one's
     float* tby = tbx + IMG;                          // y image on its way out
     // mailboxes zeroed; wave 0's inbox holds what its first tile t0 waits for: sequence number t0 and the state the segment starts from
@@ -596,8 +569,6 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = 0.f;
     }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PW + i];
-    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
-    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
     __syncthreads();
     const f4* pws = reinterpret_cast<const f4*>(pw_lds);
 
@@ -609,19 +580,17 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     int stores_in_flight = 0;
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
-    const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
-    // Matrix-core output path (round 4; sos_tile.hpp cascade_outputs_mfma): the cascade over the chunk - 768 of the kernel's ~890 vector
-    // instructions per tile - as 32 v_mfma_f32_16x16x4_f32 beside the 16 of the chunk products.
-    constexpr bool MO = (SEG == 0 ? DASP_FWD_MFMA_OUT >= 1 : SEG == 1 ? DASP_FWD_MFMA_OUT >= 2 : false) && L == 16 && S2 <= 16;   // (SEG 2: scan only, no outputs)
+    // The cascade over the chunk on the matrix cores (round 4; sos_tile.hpp cascade_outputs_mfma: y = T x + O s0, LY::YM) - 32
+    // v_mfma_f32_16x16x4_f32 beside the 16 of the chunk products where rounds 1 - 3 ran 768 vector instructions of per-lane recursion.
+    static_assert(L == 16 && S2 <= 16, "one 16 x 16 output block per 16 chunks");
     float AT[4], AO[4];
-    if (MO) cascade_map_operands<S, L>(tb + LY::YM, LY::YMC, AT, AO, lane);
+    if (SEG != 2) cascade_map_operands<S, L>(tb + LY::YM, LY::YMC, AT, AO, lane);      // (SEG 2: scan only, no outputs)
 
     for (int t = t0 + wave; t < t1; t += W) {
         int toff = 0;
         asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
         const float* __restrict__ tbl = tb + toff;
         const bool full = tile_full<L>((long)t * TS, N, vec);
-        float X[L];
         WIDE_PRIO(DASP_SCAN_PRIO);
         TRACE(0);
         // The x image of this tile was requested one tile ago (LDS-DMA, no staging registers); with the loads exposed at the top
@@ -629,16 +598,10 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // issued after that request, may stay in flight.
         if (full) wait_vmcnt(stores_in_flight);
         else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
-        if (!MO) lds_to_chunks_swz<L>(tbx, X, lane);
         f4 Bop[4], zacc[4];
         chunk_products_load(tbx, Bop, lane);
-        if (!MO) pin(X);
         pin(Bop);
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 16)
-        if (t + W < t1 && t < W) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
-#else
         if (t + W < t1 && tile_full<L>((long)(t + W) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
-#endif
         TRACE(1);
         float Z[L];
         chunk_products_issue(Bop, Aop, zacc);
@@ -652,12 +615,8 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             [&](int k) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
             [&](int k, f2& K) {
                 if (W == 1) K = Kreg[k];
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 1)
-                else K = f2{0.f, 0.f};
-#else
                 else if (pk.seq == t) K = f2{pk.a, pk.b};   // tile 0 finds the zero-initialised inbox: sequence 0, carry 0
                 else { float a, b; mbox_wait(lds, mb_in + 4 * k, t, a, b); K = f2{a, b}; }
-#endif
             },
             [&](int k, f2 Kn) {
                 if (W == 1) Kreg[k] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
@@ -674,11 +633,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             stores_in_flight = 0;
             continue;
         }
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 8)
-        if (false) {
-#else
         if (carries) {   // chunk start states for the backward pass: [row][tile][section pair][lane] f4, 1 KiB per wave store
-#endif
             static_assert(S % 2 == 0, "states are stored in section pairs");
             f4* cs = reinterpret_cast<f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + lane;
 #pragma unroll
@@ -688,69 +643,18 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             }
         }
 
-        bool stored = false;
-        if constexpr (MO) {
-            f4 yacc[4];
-            cascade_outputs_mfma_acc<S, L>(tby, st, Bop, AT, AO, lane, yacc);
-            if (DASP_DIRECT_OUT && full && !(defined_ablate_4())) {
-                mfma_granules_to_global(yr + (size_t)t * TS, yacc, DASP_FWD_NT & 2, lane);
-                stored = true;
-            } else {
-                mfma_granules_to_image(tby, yacc, lane);
-            }
-        } else
-        // The cascade itself, one section at a time in place over the chunk. The six coefficients of a section are
-        // wave-uniform but are loaded into VGPRs (opaque lane-dependent address): VALU ops with SGPR operands issue at
-        // half rate on gfx950. Only one section's coefficients are live, which keeps the kernel at <= 80 VGPRs so that
-        // six waves per SIMD hide the dependent-issue latency of the lane scans.
-        {
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                // chained behind the previous section's first output so that the six coefficient loads are not all
-                // hoisted to the top (48 live registers)
-                const int oz = opaque_zero_after(X[0]);
-                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
-                const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
-                float s1 = st[k].x, s2 = st[k].y;
-                if (DASP_FWD_DIRECT && ((direct >> k) & 1)) {   // wave-uniform. Transposed direct form II from the exact chunk start state: y = b0 u + z1;
-                                           // z1 = b1 u - a1 y + z2; z2 = b2 u - a2 y
-                    const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
-                    const f2 cz = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 4 + oz);   // zc1, zc2
-                    float z1 = fmaf(ca.w, s1, cb.x * s2), z2 = fmaf(cz.x, s1, cz.y * s2);
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        const float o = fmaf(cb.y, u, z1);
-                        z1 = fmaf(cd.x, u, fmaf(cd.z, o, z2));
-                        z2 = fmaf(cd.y, u, cd.w * o);
-                        X[n] = o;
-                    }
-                } else {
-                    const float nk = -ca.z;
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                        s2 = fmaf(ca.y, s1, ca.x * s2);
-                        s1 = t1;
-                    }
-                }
-            }
-        }
+        f4 yacc[4];
+        cascade_outputs_mfma_acc<S, L>(tby, st, Bop, AT, AO, lane, yacc);
         TRACE(3);
         WIDE_PRIO(DASP_SCAN_PRIO);
-
-        if (!MO) chunks_to_lds_swz<L>(tby, X, lane);
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 4)
-        if (X[0] == 123.456f) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
-        stores_in_flight = -1;
-#else
-        if (stored) {}
-        else if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
-        else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
+        if (DASP_DIRECT_OUT && full) {       // the output granules straight from the matrix cores' result registers to memory
+            mfma_granules_to_global(yr + (size_t)t * TS, yacc, DASP_FWD_NT & 2, lane);
+        } else {
+            mfma_granules_to_image(tby, yacc, lane);
+            if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
+            else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
+        }
         stores_in_flight = full ? (carries ? S / 2 : 0) + L / 4 : -1;
-#endif      // -1: a ragged tile issues a data-dependent number of stores
         TRACE(4);
     }
     if (SEG == 2 && chain_tab) {      // scan-only pre-pass: the last workgroup of the item (of the call, with a shared table) chains its rows
@@ -762,72 +666,6 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Finalize, one (item, section) per call: sums the per-wave partial correlations of the item's rows in fp64 and maps them to
-// mode 0: gradient w.r.t. sos (B,S,6) as given (a0 included); mode 1: gradient w.r.t. (gain_db, cutoff_freq, q_factor) (B,S,3)
-// through the RBJ design Jacobian; mode 2: the same as 3 S rows of B values ([3 k + dir][item]: one contiguous gradient vector per
-// control tensor of parametric_eq).
-__device__ __forceinline__ void finish_section(const double* __restrict__ dtab, int tab_bcast, const double (&acc)[5], int B, int S, int mode,
-                                               float* __restrict__ gout, int item, int k, int fast);
-template <bool COHERENT>   // COHERENT: the partial sums were written by other workgroups of the running kernel (device-scope loads)
-__device__ __forceinline__ void finalize_section(const double* __restrict__ dtab, int tab_bcast, const float* partials,
-                                                 int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int item, int k, int fast) {
-    double acc[5] = {0, 0, 0, 0, 0};
-    // the item's C * Wb rows of sums are contiguous; they are fetched eight rows (40 independent loads) at a time: one rolled loop with
-    // a dependent add per load paid the L2 latency C * Wb times (5.4 us for this kernel, most of it waiting)
-    const int R = C * Wb;
-    const float* p0 = partials + ((size_t)item * R * S + k) * 5;
-    for (int r0 = 0; r0 < R; r0 += 8) {
-        float v[8][5];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* p = p0 + (size_t)(r0 + j < R ? r0 + j : r0) * S * 5;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) v[j][i] = COHERENT ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) acc[i] += r0 + j < R ? (double)v[j][i] : 0.0;
-    }
-    finish_section(dtab, tab_bcast, acc, B, S, mode, gout, item, k, fast);
-}
-__device__ __forceinline__ void emit_section_grads(const double* __restrict__ d, const double (&g5)[5], int B, int S, int mode,
-                                                   float* __restrict__ gout, int item, int k);
-// acc: the five sums of section k of the item over all its rows -> its gradients
-__device__ __forceinline__ void finish_section(const double* __restrict__ dtab, int tab_bcast, const double (&acc)[5], int B, int S, int mode,
-                                               float* __restrict__ gout, int item, int k, int fast) {
-    const double* d0 = dtab + (size_t)(tab_bcast ? 0 : item) * S * DT_STRIDE;
-    const double* d = d0 + k * DT_STRIDE;
-    // What the backward kernel summed (sos_bwd_kernel, `adjoint`): with K[n] the kept signal of the section (w[n - 2] itself for a
-    // direct-form section, om w[n - 2] for a normal-form one), g the section's adjoint input and o its adjoint output,
-    //   direct form:  [0] sum g K[n+2]   [1] sum g K[n+1]   [2] sum g K[n]   [3] sum o K[n+1]   [4] sum o K[n]
-    //   normal form:  [0] sum g D[n+1]   [1] sum g D[n]     [2] sum g K[n]   [3] sum o D[n]     [4] sum o K[n]     D[n] = K[n+1] - sg K[n]
-    // (near z = 1 the three lags of K are equal to five digits and the coefficient gradients are differences of their correlations;
-    // summed as they are, the fp32 rounding of the running sums is what is left of those differences. D is the small quantity itself.)
-    // FAST kernels leave [0] out and put T = sum (adjoint output of the last section) x (its input) there instead: for every section
-    // sum_i b_i (sum g w[n - i]) = <g, y> = T, because <adjoint input, output> is the same number at every section of a cascade.
-    const double sg = d[DT_SG32];
-    const bool nf = d[DT_NF] != 0.0;
-    double lag[5];      // sum g K[n+2], sum g K[n+1], sum g K[n], sum o K[n+1], sum o K[n]
-    lag[2] = acc[2];
-    lag[1] = nf ? acc[1] + sg * acc[2] : acc[1];
-    lag[4] = acc[4];
-    lag[3] = nf ? acc[3] + sg * acc[4] : acc[3];
-    if (fast) {
-        // the recomputed signals of section k are scaled by 1 / pk (pk = product of the b0 of the sections before it), T by 1 / pk of
-        // the last section:  b0 lag0 + b1 lag1 + b2 lag2 = T om' pk_last / pk   in the scaled units
-        const double pk = d[DT_PK], pk_last = d0[(S - 1) * DT_STRIDE + DT_PK];
-        const double rhs = acc[0] * d[DT_OM] * pk_last / pk;
-        lag[0] = (rhs - d[DT_B0 + 1] * lag[1] - d[DT_B0 + 2] * lag[2]) / d[DT_B0];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) lag[i] *= pk;
-    } else {
-        lag[0] = nf ? acc[0] + sg * lag[1] : acc[0];    // K[n+2] = D[n+1] + sg K[n+1]
-    }
-    const double iom = 1.0 / d[DT_OM];
-    const double g5[5] = {lag[0] * iom, lag[1] * iom, lag[2] * iom, -lag[3] * iom, -lag[4] * iom};
-    emit_section_grads(d, g5, B, S, mode, gout, item, k);
-}
 // g5 = dL/d(b0, b1, b2, a1, a2) of section k of the item (normalised coefficients) -> the requested gradients (mode as in dasp_sos_grad_finalize)
 struct EmitCoef { double a0, b[5], J[15]; };      // of one (item, section): a0 as given, the normalised coefficients, the design Jacobian (dtab)
 __device__ __forceinline__ EmitCoef load_emit_coef(const double* __restrict__ d) {
@@ -867,55 +705,33 @@ __device__ __forceinline__ void emit_section_grads(const double* __restrict__ d,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward. Register budget is the design constraint: the coefficient correlations pair the
-// adjoint signals of section k with its forward all-pole signal s2_k[n], so forward signals have to
-// be held while the adjoint runs. Holding all S sections (S*(L+2) registers) leaves one wave per
-// SIMD; instead the forward cascade is run once, the s2 signals of the lower half [0, H) are
-// parked in the wave's LDS region (the transposition buffers are idle at that point), the upper
-// half [H, S) keeps its own in registers, and the adjoint runs as two half-cascade passes
-// (sections S-1..H, then H-1..0 with the parked signals read back).
-// SEG as in the forward kernel (oracle/chunkscan_model.py backward_row_segmented): 2 = adjoint scan-only pre-pass from a zero adjoint
-// state, leaving the state below the segment in zseg[row][segment][2S]; 1 = the ordinary pass from segstart[row][segment][2S], the
-// adjoint state entering the segment from above; partial sums per (row, segment, wave).
-// FLAGS: what the caller asked for and what the cascade is.
-//   BWD_FAST  the cascade comes from the RBJ design (every b0 > 0): the recomputation runs each section in monic form (feed-through 1, its
-//             signals scaled by 1 / product of the earlier b0: one operation per section-sample less), the last section computes no
-//             output, and the lag-0 correlation of every section is left out - the finalize step gets it from T = <adjoint output, input>
-//             of the last section (finalize_section). Executable specification of the arithmetic: scripts/bwd_fp32_model.py.
-//   BWD_NOGX  no gradient for x is wanted (the EQ is the first effect of the reference's chain: examples/style_transfer.py:150):
-//             the adjoint output is not transposed back and not stored.
-//   BWD_NOGC  no coefficient gradients (a fixed filter): no x, no saved states, no recomputation - the adjoint cascade only.
-// Sections kept in normal form (poles on or near the real axis) take their correlations with K[n] and D[n] = K[n+1] - sg K[n] instead
-// of the three nearly equal lags of K (finalize_section undoes it in fp64): at the low-frequency corner of the EQ's ranges the lag
-// correlations agree to five digits, the control gradients are their differences, and what the running fp32 sums rounded away was
-// most of them (measured 1.5e-4 .. 1e-3 of the gradient there before; 1e-5 .. 5e-5, the level of the fp32 signals themselves, after).
-constexpr int BWD_FAST = 1, BWD_NOGX = 2, BWD_NOGC = 4;
-
-template <int S, int L, int W, int SEG = 0, int FLAGS = 0>
+// The adjoint cascade on its own (one workgroup of W waves per row; lane l on chunk 63 - l so that the adjoint lane scan, which runs from
+// the last chunk to the first, is an ordinary ascending DPP scan). Two uses:
+//   SEG 0 / 1  the backward pass of a FIXED filter (no coefficient gradients asked for: x and the saved chunk states are not read): gx by the
+//              per-lane cascade, every section in transposed direct form II from the exact chunk costate (o = b0 g + z1; z1 = b1 g - a1 o +
+//              z2; z2 = b2 g - a2 o: 5 ops against 7 in normal form; direct forms lose digits over long horizons, not over the 16 samples
+//              between two exact restarts: the chunk's entry costate comes from the normal-form lane scan and is mapped once per chunk,
+//              z1 = l1, z2 = -sg l1 + om l2). 80 % of 8 TB/s at (256, 2, 131072). SEG 1: one workgroup per (row, segment of Tseg tiles),
+//              the adjoint state entering the segment from above in segstart[row][segment][2S].
+//   SEG 2      the adjoint scan-only pre-pass of segmented rows (oracle/chunkscan_model.py backward_row_segmented): from a zero adjoint state,
+//              leaving the state below the segment in zseg[row][segment][2S]; its last workgroup per item chains the segments
+//              (chain_by_last_workgroup). The pass that follows is sos_bwd_gram_kernel<SEG = 1> (gradients) or this kernel's SEG 1.
+// With coefficient gradients the backward pass is sos_bwd_gram_kernel below; rounds 2 - 4's recomputation kernels (all six sections
+// recomputed from the saved states, five correlations per section in every lane) are in the history of this file.
+template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
-sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
-               const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
-               float* __restrict__ partials, int C, int N, int nt, int vec,
-               float* __restrict__ cnt_tab, const double* __restrict__ dtab, int mode, float* __restrict__ gout, int B,
+sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ gy, float* __restrict__ gx, int C, int N, int nt, int vec,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
                float* __restrict__ chain_tab = nullptr, const double* __restrict__ segtab = nullptr, float* __restrict__ chain_start = nullptr) {
     using LY = SosLayout<S, L>;
-    constexpr bool GC = SEG != 2 && !(FLAGS & BWD_NOGC), GX = SEG != 2 && !(FLAGS & BWD_NOGX), FAST = GC && (FLAGS & BWD_FAST);
-    constexpr int NACC = FAST ? 4 : 5;            // running correlation sums per section
-    constexpr int KEEP = FAST ? L + 1 : L + 2;    // kept samples of a section's signal per chunk
-    // S <= 6: the s2 signals of all sections stay in registers (H = 0). S = 8: the lower half is parked in LDS (H = S / 2).
-    constexpr int S2 = 2 * S, TS = 64 * L, H = (GC && S > 6) ? S / 2 : 0, SH = S - H;   // SH >= H
-    constexpr int NSTASH4 = (H * KEEP + 3) / 4;                 // float4 per lane of parked s2 signals
-    // per wave: x landing image, gy landing image, gx staging image (unpadded, swizzled: common.hpp), saved chunk states, parked signals
-    // (the adjoint-only variant has no x image and no states: two images per wave, so eight waves per workgroup fit two workgroups per CU)
-    constexpr int IMG = 64 * L, REGION = GC ? 3 * IMG + S * 128 + 64 * 4 * NSTASH4 : 2 * IMG;   // floats
-    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 24;   // COEF rows, DF rows, MN rows
+    constexpr bool GX = SEG != 2;
+    constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L, REGION = 2 * IMG;      // per wave: gy landing image, gx staging image (unpadded, swizzled: common.hpp)
+    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 16;   // COEF rows, DF rows
     __shared__ __attribute__((aligned(16))) float lds[LDS_T + LDS_MB + LDS_PW + LDS_CF];
     const int lane = lane_id(), wave = wave_id();
     const int row = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // this workgroup's tiles, walked t1 - 1 .. t0
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
-    const float* __restrict__ xr = x + (size_t)row * N;
     const float* __restrict__ gr = gy + (size_t)row * N;
     float* __restrict__ gxr = gx + (size_t)row * N;
     const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;   // small regions first (16-bit DS offsets), as in the forward kernel
@@ -923,59 +739,34 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     float* pw_lds = cf_lds + LDS_CF;
     float* tbg = pw_lds + LDS_PW + wave * REGION;  // gy image of this tile; receives the next tile's as soon as it has been read
     float* tbo = tbg + IMG;                        // gx image on its way out
-    float* tbx = tbo + IMG;                        // x image, likewise (GC)
-    float* tst = tbx + IMG;                        // chunk start states [section pair][lane] f4 (GC)
-    float* tpk = tst + S * 128;                    // parked s2 signals (S = 8 only)
     // mailboxes zeroed; wave 0's inbox carries the sequence number its first tile (t1 - 1: the row's or the segment's last) waits for,
     // with the adjoint state that enters from above (zero at the end of the row)
-    if (SEG) {
-        for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
-            float v = 0.f;
-            if (i < S * 4) {
-                const int comp = i & 3;
-                if (comp == 2) v = __builtin_bit_cast(float, t1);
-                else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
-            }
-            lds[i] = v;
+    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) {
+        float v = 0.f;
+        if (i < S * 4) {
+            const int comp = i & 3;
+            if (comp == 2) v = __builtin_bit_cast(float, t1);
+            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * S2 + 2 * (i >> 2) + comp];
         }
-    } else {
-        for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
+        lds[i] = v;
     }
     for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
     for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
-    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 16 + i] = tb[LY::MN + i];
     __syncthreads();
     const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
     f2 Kreg[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
-    float acc[S][NACC], Tacc = 0.f;     // FAST: sum g K1, sum g K0, sum o K1, sum o K0 (K1 = D for a normal-form section); else lag 0 first
-#pragma unroll
-    for (int k = 0; k < S; ++k)
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[k][i] = 0.f;
 
-    // LDS-DMA prefetch of the next tile (x, gy and the saved chunk states): issued as soon as this tile's images have been read into
-    // registers, i.e. a whole tile time before it is needed, with no staging registers (the register-staged prefetch this replaces
-    // could only be issued for the last fifth of a tile and left ~2.8k of every ~18k cycles waiting on vmcnt). vmcnt is in order on
-    // gfx9, so the wait at the top of a tile lets the previous tile's L/4 gx stores stay in flight.
-    const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
-                   a_s = __builtin_amdgcn_readfirstlane(lds_addr(tst));
-    auto issue_dma = [&](int tt) {
-        if (GC) tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
-        tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
-        if (GC) {
-            const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
-#pragma unroll
-            for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
-        }
-    };
-    if (wave < nr && tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec)) issue_dma(t1 - 1 - wave);
+    // LDS-DMA prefetch of the next tile: issued as soon as this tile's image has been read into registers, i.e. a whole tile time before it
+    // is needed, with no staging registers. vmcnt is in order on gfx9, so the wait at the top of a tile lets the previous tile's L/4 gx
+    // stores stay in flight.
+    const unsigned a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg));
+    if (wave < nr && tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec)) tile_dma_issue_swz(gr + (size_t)(t1 - 1 - wave) * TS, a_g, lane);
     int stores_in_flight = 0;
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
-    const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
 
     for (int r = wave; r < nr; r += W) {
         const int t = t1 - 1 - r;
@@ -983,41 +774,21 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
         const float* __restrict__ tbl = tb + toff;
         const bool full = tile_full<L>((long)t * TS, N, vec);
-        float X[L], GY[L];
+        float GY[L];
         WIDE_PRIO(DASP_SCAN_PRIO);
         TRACE(16);
         if (full) {
             if (GX && stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            if (GC) tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
             tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
         }
-        // Lane l works on chunk 63 - l for the whole tile: the adjoint scan runs from the last chunk to the first, and with the
-        // chunks dealt out in that order it is an ordinary ascending lane scan - no lane mirroring (ds_bpermute) of its inputs and
-        // outputs. Everything else in this kernel is per chunk and does not care which lane owns which.
         const int cl = 63 - lane;
-        if (GC) lds_to_chunks_swz<L>(tbx, X, cl);
         lds_to_chunks_swz<L>(tbg, GY, cl);
         f4 Bop[4], zacc[4];
         chunk_products_load(tbg, Bop, lane);
-        if (GC) pin(X);
         pin(GY); pin(Bop); TRACE(17);
-        // ---- forward chunk start states: saved by the forward pass (3 B/sample of extra HBM traffic each way buys
-        //      back a whole lane scan, which is issue-bound on half-rate packed FMAs: measured 27 % of this kernel) ----
-        f2 st[S];
-        if (GC) {
-#pragma unroll
-            for (int m = 0; m < S / 2; ++m) {   // [section pair][chunk] f4, as the forward kernel stored them
-                const f4 q = full ? *reinterpret_cast<const f4*>(tst + (m * 64 + cl) * 4)
-                                  : (reinterpret_cast<const f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + cl)[m * 64];
-                st[2 * m] = f2{q.x, q.y};
-                st[2 * m + 1] = f2{q.z, q.w};
-            }
-            pin(st);
-        }
-        TRACE(18);
-        if (r + W < nr) issue_dma(t - W);   // the three images are in registers now; tiles below a row's last one are always full
+        if (r + W < nr) tile_dma_issue_swz(gr + (size_t)(t - W) * TS, a_g, lane);   // the image is in registers now; tiles below a row's last one are always full
         float Z[L];
         chunk_products_issue(Bop, Aop, zacc);
         chunk_products_collect<L>(tbo, zacc, Z, lane, cl);   // the gx image is idle until the end of the tile
@@ -1032,12 +803,8 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
                 [&](int i) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * i); },
                 [&](int i, f2& K) {
                     if (W == 1) K = Kreg[i];
-#if defined(DASP_ABLATE) && (DASP_ABLATE & 2)
-                    else K = f2{0.f, 0.f};
-#else
-                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
+                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence t1, carry 0 / the segment's state
                     else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
-#endif
                 },
                 [&](int i, f2 Kn) {
                     if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
@@ -1050,229 +817,34 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
             stores_in_flight = 0;
             continue;
         }
-        if (GC) { pin(X); pin(st); }
-        pin(GY); pin(lam);   // scans done before the cascade passes start
+        pin(GY); pin(lam);   // scans done before the cascade starts
         TRACE(19);
         __builtin_amdgcn_sched_barrier(0);
-        float S2v[GC ? SH : 1][KEEP];
-        // forward section k over the chunk, in place over X, keeping K_k[n] = s2_k[n] (normal form) or w_k[n - 2] (direct form) for
-        // n = 0..KEEP-1 in S2v[slot]. FAST: monic recomputation (see the kernel header); the last section computes no output, so X
-        // still holds that section's input afterwards (T is taken from it).
-        auto forward_keep = [&](int k, int slot, int oz) {
-            float s1 = st[k].x, s2 = st[k].y;
-            const bool last = FAST && k == S - 1;
-            if ((direct >> k) & 1) {   // wave-uniform. Direct form II from the exact chunk start state; the kept signal is w[n - 2] itself
-                                       // (s2 = om w: the finalize kernel's 1 / om is 1 for these sections)
-                const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
-                if (FAST) {
-                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + oz);       // b1 / b0, b2 / b0
-                    const f4 cq = *reinterpret_cast<const f4*>(cf_lds + S * 16 + k * 8 + 4 + oz);   // q, q / om, q sg / om
-                    float w2 = cq.y * s2, w1 = fmaf(cq.z, s2, cq.x * s1);
 #pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        S2v[slot][n] = w2;
-                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
-                        if (!last) X[n] = fmaf(cm.x, w1, fmaf(cm.y, w2, w));
-                        w2 = w1;
-                        w1 = w;
-                    }
-                    S2v[slot][L] = w2;
-                } else {
-                    const float d = cf_lds[k * 8 + 5 + oz];                                         // b0
-                    const f2 cw = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 6 + oz);   // 1 / om, sg / om
-                    float w2 = cw.x * s2, w1 = fmaf(cw.y, s2, s1);
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        S2v[slot][n] = w2;
-                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
-                        X[n] = fmaf(d, w, fmaf(cd.x, w1, cd.y * w2));
-                        w2 = w1;
-                        w1 = w;
-                    }
-                    S2v[slot][L] = w2;
-                    S2v[slot][KEEP - 1] = w1;
-                }
-            } else {
-                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
-                const float nk = -ca.z;
-                if (FAST) {
-                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + 2 + oz);   // g1 / d, g2 / d
-                    const float q = cf_lds[S * 16 + k * 8 + 4 + oz];
-                    s1 *= q; s2 *= q;
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        S2v[slot][n] = s2;
-                        if (!last) X[n] = fmaf(cm.x, s1, fmaf(cm.y, s2, u));
-                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                        s2 = fmaf(ca.y, s1, ca.x * s2);
-                        s1 = t1;
-                    }
-                    S2v[slot][L] = s2;
-                } else {
-                    const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        S2v[slot][n] = s2;
-                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                        s2 = fmaf(ca.y, s1, ca.x * s2);
-                        s1 = t1;
-                    }
-                    S2v[slot][L] = s2;
-                    S2v[slot][KEEP - 1] = fmaf(ca.y, s1, ca.x * s2);   // s2 does not see the input
-                }
-            }
-        };
-        // adjoint section k (descending time) + coefficient correlations, in place over GY. The section itself runs in transposed
-        // direct form II (o = b0 g + z1; z1 = b1 g - a1 o + z2; z2 = b2 g - a2 o: 5 ops against 7 in normal form). Direct forms lose
-        // digits over long horizons, not over the 16 samples between two exact restarts: the chunk's entry costate comes from the
-        // normal-form lane scan and is mapped once per chunk, z1 = l1, z2 = -sg l1 + om l2 (same zero-input response).
-        auto adjoint = [&](int k, int slot, int oz) {
+        for (int k = S - 1; k >= 0; --k) {      // adjoint section k (descending time), in place over GY; the coefficient loads are addressed with
+            const int oz = opaque_zero_after(GY[0]);      // an opaque zero chained behind the previous section: VGPR operands, one section's set live
             const int i = S - 1 - k;
             const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);           // sg, om, kom, g1
             const float d = cf_lds[k * 8 + 5 + oz];                                     // b0
             const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);   // b1, b2, -a1, -a2
             float z1 = lam[i].x, z2 = fmaf(ca.y, lam[i].y, -ca.x * lam[i].x);
-            if (!GC) {
 #pragma unroll
-                for (int n = L - 1; n >= 0; --n) {
-                    const float g = GY[n];
-                    const float o = fmaf(d, g, z1);
-                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
-                    z2 = fmaf(cd.y, g, cd.w * o);
-                    GY[n] = o;
-                }
-                return;
+            for (int n = L - 1; n >= 0; --n) {
+                const float g = GY[n];
+                const float o = fmaf(d, g, z1);
+                z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
+                z2 = fmaf(cd.y, g, cd.w * o);
+                GY[n] = o;
             }
-            float c[NACC];
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) c[j] = acc[k][j];
-            if ((direct >> k) & 1) {        // the three lags of w as they are
-#pragma unroll
-                for (int n = L - 1; n >= 0; --n) {
-                    const float g = GY[n];
-                    if (!FAST) c[0] = fmaf(g, S2v[slot][KEEP - 1 - (L - 1 - n)], c[0]);      // K[n + 2]
-                    c[NACC - 4] = fmaf(g, S2v[slot][n + 1], c[NACC - 4]);
-                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
-                    const float o = fmaf(d, g, z1);
-                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
-                    z2 = fmaf(cd.y, g, cd.w * o);
-                    c[NACC - 2] = fmaf(o, S2v[slot][n + 1], c[NACC - 2]);
-                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
-                    GY[n] = o;
-                }
-            } else {                        // K[n] and D[n] = K[n+1] - sg K[n] (finalize_section undoes it in fp64)
-                const float nsg = -ca.x;
-#pragma unroll
-                for (int n = L - 1; n >= 0; --n) {
-                    const float g = GY[n];
-                    const float dlo = fmaf(nsg, S2v[slot][n], S2v[slot][n + 1]);              // D[n]
-                    // (D[n + 1] is computed again rather than carried from the previous step: the carried copy was the register
-                    // that made this variant spill)
-                    if (!FAST) c[0] = fmaf(g, fmaf(nsg, S2v[slot][n + 1], S2v[slot][KEEP - 1 - (L - 1 - n)]), c[0]);
-                    c[NACC - 4] = fmaf(g, dlo, c[NACC - 4]);
-                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
-                    const float o = fmaf(d, g, z1);
-                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
-                    z2 = fmaf(cd.y, g, cd.w * o);
-                    c[NACC - 2] = fmaf(o, dlo, c[NACC - 2]);
-                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
-                    GY[n] = o;
-                }
-            }
-            // pinned: otherwise the compiler defers these updates to the end of the tile and keeps all
-            // the per-tile sums live next to the running sums
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) { pin(c[j]); acc[k][j] = c[j]; }
-            if (FAST && k == S - 1) {       // T = <adjoint output of the last section, its (scaled) input>: X was left untouched by forward_keep
-                float tt = Tacc;
-#pragma unroll
-                for (int n = 0; n < L; ++n) tt = fmaf(X[n], GY[n], tt);
-                pin(tt);
-                Tacc = tt;
-            }
-        };
-        // coefficient loads addressed with an opaque zero land in VGPRs (full-rate VALU operands) and cannot be
-        // hoisted out of the tile loop
-        if (GC) {
-            {   // lower half forward, s2 signals parked in LDS ([j][lane] float4: conflict-free 1 KiB wave accesses)
-                const int oz = opaque_zero();
-#pragma unroll
-                for (int k = 0; k < H; ++k) forward_keep(k, k, oz);
-                if (H > 0) {
-                    wave_lds_sync();
-                    f4* stash = reinterpret_cast<f4*>(tpk) + lane;
-#pragma unroll
-                    for (int j = 0; j < NSTASH4; ++j) {
-                        f4 v;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int e = 4 * j + c;
-                            v[c] = e < H * KEEP ? S2v[e / KEEP][e % KEEP] : 0.f;
-                        }
-                        stash[j * 64] = v;
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {   // upper half (all sections when H = 0): forward keeping its s2 signals in registers, then its adjoint. Every section's
-                // coefficient load is chained behind the previous section's result: left free, the scheduler issues all of them up
-                // front and the S coefficient sets (8 registers each) are live on top of the s2 signals.
-#pragma unroll
-                for (int k = H; k < S; ++k) forward_keep(k, k - H, opaque_zero_after(X[0]));
-                pin(S2v); pin(GY);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = S - 1; k >= H; --k) adjoint(k, k - H, opaque_zero_after(GY[0]));
-            }
-            pin(GY);
-            __builtin_amdgcn_sched_barrier(0);
-            if (H > 0) {   // lower half adjoint with the parked signals (chained behind the upper half so that the two sets of
-                // s2 registers are not live at once)
-                const int oz = opaque_zero_after(GY[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                const f4* stash = reinterpret_cast<const f4*>(tpk + oz) + lane;
-#pragma unroll
-                for (int j = 0; j < NSTASH4; ++j) {
-                    const f4 v = stash[j * 64];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int e = 4 * j + c;
-                        if (e < H * KEEP) S2v[e / KEEP][e % KEEP] = v[c];
-                    }
-                }
-#pragma unroll
-                for (int k = H - 1; k >= 0; --k) adjoint(k, k, oz);
-            }
-        } else {
-#pragma unroll
-            for (int k = S - 1; k >= 0; --k) adjoint(k, 0, opaque_zero_after(GY[0]));
         }
         pin(GY);
         TRACE(23);
         WIDE_PRIO(DASP_SCAN_PRIO);
         __builtin_amdgcn_sched_barrier(0);
-        if (GX) {
-#if DASP_BWD_DIRECT_GX
-            if (full) {       // experiment: every lane stores its chunk (64 contiguous bytes) itself - no staging image, partial lines merge in L2
-                f4* o = reinterpret_cast<f4*>(gxr + (size_t)t * TS + cl * L);
-#pragma unroll
-                for (int k = 0; k < L / 4; ++k) o[k] = f4{GY[4 * k], GY[4 * k + 1], GY[4 * k + 2], GY[4 * k + 3]};
-            } else {
-                chunks_to_lds_swz<L>(tbo, GY, cl);
-                tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
-            }
-#else
-            chunks_to_lds_swz<L>(tbo, GY, cl);
-            if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
-            else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
-#endif
-            stores_in_flight = full ? L / 4 : 0;
-        }
+        chunks_to_lds_swz<L>(tbo, GY, cl);
+        if (full) tile_swz_to_global_full(tbo, gxr, (long)t * TS, true, lane);
+        else tile_swz_to_global_guarded(tbo, gxr, (long)t * TS, N);
+        stores_in_flight = full ? L / 4 : 0;
         TRACE(24);
     }
     if (SEG == 2 && chain_tab) {      // adjoint scan-only pre-pass: chain downwards with the adjoint system's segment matrix (word 2 of the counters)
@@ -1280,395 +852,6 @@ sos_bwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         chain_by_last_workgroup<S, W>(reinterpret_cast<int*>(chain_tab + (size_t)item * LY::TOTAL + LY::CNT) + 2, tab_bcast ? (int)gridDim.x : C * G,
                                       segtab + ((size_t)item * 2 + 1) * S2 * S2, zseg, chain_start, tab_bcast ? 0 : item * C,
                                       tab_bcast ? (int)gridDim.x / G : C, G, 1, pw_lds + LDS_PW, REGION);       // (the tile images are idle now)
-    }
-    // per-wave partial sums -> partials[row][wave][S][5]
-    if (!GC) return;
-    float* po = partials + ((SEG ? (size_t)row * G + seg : (size_t)row) * W + wave) * S * 5;
-    const float vT = FAST ? wave_sum(Tacc) : 0.f;
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        float v[5];
-        v[0] = FAST ? vT : wave_sum(acc[k][0]);
-#pragma unroll
-        for (int i = 1; i < 5; ++i) v[i] = wave_sum(acc[k][NACC - 5 + i]);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                if (cnt_tab) __hip_atomic_store(po + k * 5 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else po[k * 5 + i] = v[i];
-            }
-        }
-    }
-    // Fused finalize (cnt_tab != null: every item has its own table). The workgroup of an item's last row to finish maps the item's
-    // partial sums to the requested gradients - no separate launch (5.5 us + a launch gap per step at the north-star shape).
-    // The rows of an item run on different XCDs, whose L2s are not coherent with each other: a release fence here would write back
-    // this XCD's whole dirty L2 (the gx tiles: measured +65 us). Instead the few values that cross workgroups travel as device-scope
-    // relaxed atomics (write-through stores, L2-bypassing loads): each wave waits for its own stores to be acknowledged (vmcnt), the
-    // barrier orders that before thread 0's counter increment, and the workgroup that sees the count complete reads the sums.
-    if (cnt_tab) {
-        __shared__ int last_row;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int item = row / C;
-        int* cnt = reinterpret_cast<int*>(cnt_tab + (size_t)item * LY::TOTAL + LY::CNT);
-        if (threadIdx.x == 0) {
-            last_row = handoff_arrive_is_last(cnt, C * G);   // (G = 1 unless the rows are segmented: then every (row, segment) workgroup counts; resets the counter)
-        }
-        __syncthreads();
-        if (!SEG) {
-            if (last_row && (int)threadIdx.x < S) finalize_section<true>(dtab, 0, partials, B, C, S, W, mode, gout, item, threadIdx.x, FAST ? 1 : 0);
-        } else if (last_row) {
-            // segmented rows leave C * G * W rows of sums per item: a wave per section, its lanes across the rows (sos_finalize_wave_kernel)
-            const int R = C * G * W;
-            for (int k = wave; k < S; k += W) {
-                const float* p0 = partials + ((size_t)item * R * S + k) * 5;
-                double a5[5] = {0, 0, 0, 0, 0};
-                for (int r = lane; r < R; r += 128) {          // two rows of sums per lane and round trip
-                    float v[2][5];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int i = 0; i < 5; ++i)
-                            v[h][i] = __hip_atomic_load(p0 + (size_t)(r + 64 * h < R ? r + 64 * h : r) * S * 5 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) a5[i] += (double)v[0][i] + (r + 64 < R ? (double)v[1][i] : 0.0);
-                }
-#pragma unroll
-                for (int i = 0; i < 5; ++i) a5[i] = wave_sum(a5[i]);
-                if (lane == 0) finish_section(dtab, 0, a5, B, S, mode, gout, item, k, FAST ? 1 : 0);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Backward with checkpointed recomputation (coefficient gradients wanted, one workgroup per row). Two uses:
-//   S = 8 (sosfilt_via_fsm with 7 / 8 sections; 4 + 4 sections, kWB waves per row, two waves per SIMD): the shipped kernel - it replaces
-//         sos_bwd_kernel<8>, whose parked signals (145 KiB of LDS per workgroup) leave one wave per SIMD: 0.72 -> 0.61 ms (DASP_BWD8_CHECKPOINT);
-//   S = 6 (the EQ; 3 + 3 sections, three waves per SIMD) - an experiment that LOST against sos_bwd_kernel<6> (numbers at the dispatch switch
-//         below, DASP_BWD_3W); selectable with DASP_BWD_KERNEL=3w, covered by tests/test_gpu_sosfilt.py.
-// The description that follows is the S = 6 case.
-// sos_bwd_kernel above holds the kept signals of all six sections at once (102 registers; 255 in all) and three 4 KiB tile images per
-// wave: two waves per SIMD, and a wave issues at most one VALU instruction per ~6 cycles whatever its instruction-level parallelism
-// (tools/ubench) - a SIMD with two waves cannot use more than two thirds of its issue slots, and every lane-scan / LDS / mailbox phase of
-// one wave has only one partner to hide behind. This variant fits three waves per SIMD (<= 168 registers, ~12 KiB of LDS per wave, six
-// waves per row, two rows per CU):
-//   * checkpointed recomputation: sections 0..2 run forward once WITHOUT keeping anything (their output is the input of section 3);
-//     sections 3..5 are recomputed keeping their signals (51 registers) and their adjoints 5, 4, 3 run; then the tile's x is read from its
-//     LDS image a second time, sections 0..2 are recomputed keeping theirs in the same registers, and adjoints 2, 1, 0 run. Price: three
-//     section-passes of the cheap kind per tile (+ ~190 of ~1,600 VALU instructions);
-//   * two tile images per wave instead of three: gx leaves the registers directly (every lane stores its chunk, 64 contiguous bytes;
-//     partial lines merge in L2 - measured against the staged stores in the old kernel: +1 %), and the chunk products' D registers
-//     go through the states region (3 KiB: [row group][chunk] float4, the 12 meaningful rows only) once the states have been read;
-//   * the next tile's x is requested when the second pass over x starts (about 45 % of a tile ahead), gy at the top, the states after
-//     the lane scan.
-// Arithmetic, tables, saved states, partial sums and the finalize step are those of sos_bwd_kernel (same sums in the same order per wave,
-// except that a row's tiles are dealt to six waves instead of four).
-template <int S, int L, int W, int FLAGS>
-__global__ void __launch_bounds__(64 * W, (W * 2 + 3) / 4)   // two workgroups per CU
-sos_bwd_ckpt_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x,
-                 const float* __restrict__ gy, const float* __restrict__ carries, float* __restrict__ gx,
-                 float* __restrict__ partials, int C, int N, int nt, int vec) {
-    using LY = SosLayout<S, L>;
-    static_assert((S == 6 || S == 8) && L == 16, "checkpoint split 3 + 3 or 4 + 4, 16-sample chunks");
-    constexpr bool GX = !(FLAGS & BWD_NOGX), FAST = FLAGS & BWD_FAST;
-    constexpr int NACC = FAST ? 4 : 5, KEEP = FAST ? L + 1 : L + 2, HS = S / 2;
-    constexpr int TS = 64 * L, IMG = 64 * L, STR = S * 128, REGION = 2 * IMG + STR;      // floats per wave: gy image, x image, states
-#ifndef DASP_BWD3_PAD
-#define DASP_BWD3_PAD 0        // measurement builds: floats of unused LDS per workgroup (lowers the number of workgroups a CU holds)
-#endif
-    constexpr int LDS_T = W * REGION, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4, LDS_CF = S * 24, LDS_A = 256;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_MB + LDS_CF + LDS_A + LDS_PW + LDS_T + DASP_BWD3_PAD];
-    const int lane0 = lane_id(), lane = lane0, wave = wave_id(), row = blockIdx.x;
-    const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
-    const float* __restrict__ xr = x + (size_t)row * N;
-    const float* __restrict__ gr = gy + (size_t)row * N;
-    float* __restrict__ gxr = gx + (size_t)row * N;
-    const int mb_in = wave * S * 4, mb_out = ((wave + 1) % W) * S * 4;
-    float* cf_lds = lds + LDS_MB;
-    float* a_lds = cf_lds + LDS_CF;                // A operands of the chunk products, [lane] f4 (loop invariant: kept here, not in registers)
-    float* pw_lds = a_lds + LDS_A;
-    float* tbg = pw_lds + LDS_PW + wave * REGION;  // gy image of this tile, then scratch of the chunk products, then the next tile's gy
-    float* tbx = tbg + IMG;                        // x image: read twice per tile, then handed to the next tile's request
-    float* tst = tbx + IMG;                        // saved chunk states [section pair][chunk] f4: read three times per tile, then likewise
-    for (int i = threadIdx.x; i < LDS_MB; i += 64 * W) lds[i] = (i < S * 4 && (i & 3) == 2) ? __builtin_bit_cast(float, nt) : 0.f;
-    for (int i = threadIdx.x; i < LDS_PW; i += 64 * W) pw_lds[i] = tb[LY::PWA + i];
-    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[i] = tb[LY::COEF + i];
-    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 8 + i] = tb[LY::DF + i];
-    for (int i = threadIdx.x; i < S * 8; i += 64 * W) cf_lds[S * 16 + i] = tb[LY::MN + i];
-    if (wave == 0) {
-        float Aop[4];
-        chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
-        *reinterpret_cast<f4*>(a_lds + 4 * lane) = f4{Aop[0], Aop[1], Aop[2], Aop[3]};
-    }
-    __syncthreads();
-    const f4* pwa = reinterpret_cast<const f4*>(pw_lds);
-    float acc[S][NACC], Tacc = 0.f;
-#pragma unroll
-    for (int k = 0; k < S; ++k)
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[k][i] = 0.f;
-    const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
-                   a_s = __builtin_amdgcn_readfirstlane(lds_addr(tst));
-    auto dma_states = [&](int tt, int lane) {
-        const float* cs = carries + (((size_t)row * nt + tt) * S * 64 + lane * 2) * 2;      // 16 bytes per lane, 1 KiB per instruction
-#pragma unroll
-        for (int m = 0; m < S / 2; ++m) glds16<!DASP_STATES_CACHED>(cs + m * 256, a_s + 1024 * m);
-    };
-    if (wave < nt && tile_full<L>((long)(nt - 1 - wave) * TS, N, vec)) {
-        tile_dma_issue_swz(gr + (size_t)(nt - 1 - wave) * TS, a_g, lane);
-        tile_dma_issue_swz(xr + (size_t)(nt - 1 - wave) * TS, a_x, lane);
-        dma_states(nt - 1 - wave, lane);
-    }
-    int stores_in_flight = 0;
-    const unsigned direct = direct_form_mask<S>(tb + LY::COEF);
-
-    for (int r = wave; r < nt; r += W) {
-        const int t = nt - 1 - r;
-        int toff = 0;
-        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop
-        const float* __restrict__ tbl = tb + toff;
-        const bool full = tile_full<L>((long)t * TS, N, vec);
-        const bool more = r + W < nt;                      // (tiles below a row's last one are always full)
-        // the lane index passes through an opaque move once per tile: left visible, every LDS / global address of the loop body (swizzled
-        // granule offsets of three images, DMA sources, store pointers) is hoisted out of the loop, and at 168 registers those ~20
-        // loop invariants are spilled and reloaded - scratch loads in between the DMA requests, whose vmcnt waits then expose them
-        const int lane = lane0 + opaque_zero();
-        const int cl = 63 - lane;        // lane l works on chunk 63 - l: the adjoint lane scan is an ordinary ascending scan
-        float GY[L];
-        WIDE_PRIO(DASP_SCAN_PRIO);
-        if (full) {
-            if (GX && stores_in_flight == L / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(L / 4) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {      // ragged last tile of the row (cold): images and states by plain loads
-            tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
-            tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
-            const f4* cs = reinterpret_cast<const f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + lane;
-#pragma unroll 1
-            for (int m = 0; m < S / 2; ++m) *reinterpret_cast<f4*>(tst + (m * 64 + lane) * 4) = cs[m * 64];
-            wave_lds_sync();
-        }
-        lds_to_chunks_swz<L>(tbg, GY, cl);
-        f4 Bop[4], zacc[4];
-        chunk_products_load(tbg, Bop, lane);
-        float Z[L];
-        {
-            const f4 av = *reinterpret_cast<const f4*>(a_lds + 4 * (lane + opaque_zero()));
-            const float Aop[4] = {av.x, av.y, av.z, av.w};
-            pin(GY); pin(Bop);
-            chunk_products_issue(Bop, Aop, zacc);
-        }
-        chunk_products_collect<L>(tbg, zacc, Z, lane, cl);      // the gy image is free until the next tile is requested into it
-        pin(Z);
-        if (more) tile_dma_issue_swz(gr + (size_t)(t - W) * TS, a_g, lane);
-        f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
-        {
-            MboxPeek pk;
-            SCAN_PRIO(DASP_SCAN_PRIO);
-            tile_scan<S, L>(Z, [](f2 v) { return v; }, lam,
-                tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
-                [&](int i) { pk = mbox_peek(lds, mb_in + 4 * i); },
-                [&](int i, f2& K) {
-                    if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
-                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
-                },
-                [&](int i, f2 Kn) { if (t > 0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t); });
-        }
-        SCAN_PRIO(0);
-        pin(GY); pin(lam);
-        __builtin_amdgcn_sched_barrier(0);
-        float X[L];
-        float S2v[HS][KEEP];
-        // chunk start state of section k from the states region ([section pair][chunk] f4)
-        auto start_state = [&](int k, int oz) {
-            const f2 q = *reinterpret_cast<const f2*>(tst + ((k >> 1) * 64 + cl) * 4 + 2 * (k & 1) + oz);
-            return q;
-        };
-        // forward section k over the chunk in place over X; keep: K_k[n] (normal form: s2, direct form: w[n - 2]) into S2v[slot]
-        auto forward_sec = [&](int k, int slot, int oz, bool keep) {
-            const f2 st = start_state(k, oz);
-            float s1 = st.x, s2 = st.y;
-            const bool last = FAST && k == S - 1;
-            if ((direct >> k) & 1) {
-                const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);       // b1, b2, -a1, -a2
-                if (FAST) {
-                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + oz);       // b1 / b0, b2 / b0
-                    const f4 cq = *reinterpret_cast<const f4*>(cf_lds + S * 16 + k * 8 + 4 + oz);   // q, q / om, q sg / om
-                    float w2 = cq.y * s2, w1 = fmaf(cq.z, s2, cq.x * s1);
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        if (keep) S2v[slot][n] = w2;
-                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
-                        if (!last) X[n] = fmaf(cm.x, w1, fmaf(cm.y, w2, w));
-                        w2 = w1;
-                        w1 = w;
-                    }
-                    if (keep) S2v[slot][L] = w2;
-                } else {
-                    const float d = cf_lds[k * 8 + 5 + oz];                                         // b0
-                    const f2 cw = *reinterpret_cast<const f2*>(cf_lds + S * 8 + k * 8 + 6 + oz);   // 1 / om, sg / om
-                    float w2 = cw.x * s2, w1 = fmaf(cw.y, s2, s1);
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        if (keep) S2v[slot][n] = w2;
-                        const float w = fmaf(cd.z, w1, fmaf(cd.w, w2, u));
-                        X[n] = fmaf(d, w, fmaf(cd.x, w1, cd.y * w2));
-                        w2 = w1;
-                        w1 = w;
-                    }
-                    if (keep) { S2v[slot][L] = w2; S2v[slot][KEEP - 1] = w1; }
-                }
-            } else {
-                const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);       // sg, om, kom, g1
-                const float nk = -ca.z;
-                if (FAST) {
-                    const f2 cm = *reinterpret_cast<const f2*>(cf_lds + S * 16 + k * 8 + 2 + oz);   // g1 / d, g2 / d
-                    const float q = cf_lds[S * 16 + k * 8 + 4 + oz];
-                    s1 *= q; s2 *= q;
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        if (keep) S2v[slot][n] = s2;
-                        if (!last) X[n] = fmaf(cm.x, s1, fmaf(cm.y, s2, u));
-                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                        s2 = fmaf(ca.y, s1, ca.x * s2);
-                        s1 = t1;
-                    }
-                    if (keep) S2v[slot][L] = s2;
-                } else {
-                    const f4 cb = *reinterpret_cast<const f4*>(cf_lds + k * 8 + 4 + oz);   // g2, d, kappa, -
-#pragma unroll
-                    for (int n = 0; n < L; ++n) {
-                        const float u = X[n];
-                        if (keep) S2v[slot][n] = s2;
-                        X[n] = fmaf(ca.w, s1, fmaf(cb.x, s2, cb.y * u));
-                        const float t1 = fmaf(ca.x, s1, fmaf(nk, s2, u));
-                        s2 = fmaf(ca.y, s1, ca.x * s2);
-                        s1 = t1;
-                    }
-                    if (keep) { S2v[slot][L] = s2; S2v[slot][KEEP - 1] = fmaf(ca.y, s1, ca.x * s2); }
-                }
-            }
-        };
-        // adjoint section k (descending time) + coefficient correlations, in place over GY (sos_bwd_kernel::adjoint)
-        auto adjoint = [&](int k, int slot, int oz) {
-            const int i = S - 1 - k;
-            const f4 ca = *reinterpret_cast<const f4*>(cf_lds + k * 8 + oz);           // sg, om, kom, g1
-            const float d = cf_lds[k * 8 + 5 + oz];                                     // b0
-            const f4 cd = *reinterpret_cast<const f4*>(cf_lds + S * 8 + k * 8 + oz);   // b1, b2, -a1, -a2
-            float z1 = lam[i].x, z2 = fmaf(ca.y, lam[i].y, -ca.x * lam[i].x);
-            float c[NACC];
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) c[j] = acc[k][j];
-            if ((direct >> k) & 1) {
-#pragma unroll
-                for (int n = L - 1; n >= 0; --n) {
-                    const float g = GY[n];
-                    if (!FAST) c[0] = fmaf(g, S2v[slot][KEEP - 1 - (L - 1 - n)], c[0]);      // K[n + 2]
-                    c[NACC - 4] = fmaf(g, S2v[slot][n + 1], c[NACC - 4]);
-                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
-                    const float o = fmaf(d, g, z1);
-                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
-                    z2 = fmaf(cd.y, g, cd.w * o);
-                    c[NACC - 2] = fmaf(o, S2v[slot][n + 1], c[NACC - 2]);
-                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
-                    GY[n] = o;
-                }
-            } else {
-                const float nsg = -ca.x;
-#pragma unroll
-                for (int n = L - 1; n >= 0; --n) {
-                    const float g = GY[n];
-                    const float dlo = fmaf(nsg, S2v[slot][n], S2v[slot][n + 1]);              // D[n]
-                    if (!FAST) c[0] = fmaf(g, fmaf(nsg, S2v[slot][n + 1], S2v[slot][KEEP - 1 - (L - 1 - n)]), c[0]);
-                    c[NACC - 4] = fmaf(g, dlo, c[NACC - 4]);
-                    c[NACC - 3] = fmaf(g, S2v[slot][n], c[NACC - 3]);
-                    const float o = fmaf(d, g, z1);
-                    z1 = fmaf(cd.x, g, fmaf(cd.z, o, z2));
-                    z2 = fmaf(cd.y, g, cd.w * o);
-                    c[NACC - 2] = fmaf(o, dlo, c[NACC - 2]);
-                    c[NACC - 1] = fmaf(o, S2v[slot][n], c[NACC - 1]);
-                    GY[n] = o;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) { pin(c[j]); acc[k][j] = c[j]; }
-        };
-        // phase A: sections 0..2 forward, nothing kept: X becomes the input of section 3
-        lds_to_chunks_swz<L>(tbx + opaque_zero_after(GY[0]), X, cl);
-        pin(X);
-#pragma unroll
-        for (int k = 0; k < HS; ++k) forward_sec(k, 0, opaque_zero_after(X[0]), false);
-        pin(X);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase B: sections 3..5 kept, adjoints 5, 4, 3 (X is dead once section 5 has been recomputed: T is taken in phase C)
-#pragma unroll
-        for (int k = HS; k < S; ++k) forward_sec(k, k - HS, opaque_zero_after(X[0]), true);
-        pin(S2v); pin(GY);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = S - 1; k >= HS; --k) adjoint(k, k - HS, opaque_zero_after(GY[0]));
-        pin(GY);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase C: the tile's x once more, sections 0..2 kept, adjoints 2, 1, 0
-        lds_to_chunks_swz<L>(tbx + opaque_zero_after(GY[0]), X, cl);
-        pin(X);
-#pragma unroll
-        for (int k = 0; k < HS; ++k) forward_sec(k, k, opaque_zero_after(X[0]), true);
-        pin(S2v); pin(GY); pin(X);
-        // the x image and the states have been read for the last time: the next tile's request (about 40 % of a tile ahead of its use)
-        if (more) {
-            tile_dma_issue_swz(xr + (size_t)(t - W) * TS, a_x, lane);
-            dma_states(t - W, lane);
-        }
-        if (FAST) {
-            // T = <adjoint input of section 2, its output> = sum GY X, X being the input of section 3 again, in units of 1 / (b0 of
-            // sections 0..2): <adjoint input, output> is the same number at every section boundary of a cascade (sos_bwd_kernel takes it
-            // at the last section, where its X would have to stay alive through phase B; rescaled to that convention after the loop)
-            float tt = Tacc;
-#pragma unroll
-            for (int n = 0; n < L; ++n) tt = fmaf(X[n], GY[n], tt);
-            pin(tt);
-            Tacc = tt;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = HS - 1; k >= 0; --k) adjoint(k, k, opaque_zero_after(GY[0]));
-        pin(GY);
-        WIDE_PRIO(DASP_SCAN_PRIO);
-        __builtin_amdgcn_sched_barrier(0);
-        if (GX) {
-            if (full) {       // every lane stores its chunk (64 contiguous bytes); the partial lines of a wave instruction merge in L2
-                f4* o = reinterpret_cast<f4*>(gxr + (size_t)t * TS + cl * L);
-#pragma unroll
-                for (int k = 0; k < L / 4; ++k) o[k] = f4{GY[4 * k], GY[4 * k + 1], GY[4 * k + 2], GY[4 * k + 3]};
-            } else {
-#pragma unroll 1
-                for (int n = 0; n < L; ++n)
-                    if ((long)t * TS + cl * L + n < N) gxr[(size_t)t * TS + cl * L + n] = GY[n];
-            }
-            stores_in_flight = full ? L / 4 : 0;
-        }
-    }
-    // per-wave partial sums -> partials[row][wave][S][5]
-    float* po = partials + ((size_t)row * W + wave) * S * 5;
-    float vT = 0.f;
-    if (FAST) {       // T was taken at the input of section 3 (scale q_3 = 1 / (b0_0 b0_1 b0_2)); the finalize step expects the last section's scale
-        const float q3 = tb[LY::MN + HS * 8 + 4], ql = tb[LY::MN + (S - 1) * 8 + 4];
-        vT = wave_sum(Tacc) * (ql / q3);
-    }
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        float v[5];
-        v[0] = FAST ? vT : wave_sum(acc[k][0]);
-#pragma unroll
-        for (int i = 1; i < 5; ++i) v[i] = wave_sum(acc[k][NACC - 5 + i]);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) po[k * 5 + i] = v[i];
-        }
     }
 }
 
@@ -1792,11 +975,22 @@ sos_chain_kernel(const double* __restrict__ segtab, int tab_bcast, int C, const 
 template <int S>
 struct GramFin {
     static constexpr int L = 16, D = L + 2 * S, NW = L + 2, NP = S * NW, NPB = (NP + 15) / 16;
-    static constexpr int FW = 0, FG = NP * D, FO = FG + S * L * D, BASIS = FO + S * L * D;       // basis responses (doubles): FW[NP][D], FG[S][L][D], FO[S][L][D]
+    // Basis responses (doubles), laid out as the finalize step reads them, so that every load of a wave is one contiguous 512 bytes (the
+    // natural [row][column] layouts are strided gathers for it: 84 such loads took a wave 5k cycles just to issue,
+    // profiles/r05/seg_tail_trace.log):
+    //   FW[p][u], p = k (L + 2) + n < NP, u < D  at fw(p, u):  [u / 4][p / 16][u % 4][p % 16] - the B operands of one matrix-core step
+    //                                                          (lane = 16 (u % 4) + p % 16) of one 16-row block are 64 consecutive doubles
+    //   FG / FO[k][n][v]                          at fg(k, n, v), fo(..): [v][k L + n] - thread (k, n) of the lag sums reads column v
+    static constexpr int FW = 0, FG = (D / 4) * NPB * 64, FO = FG + D * S * L, BASIS = FO + D * S * L;
+    static_assert(D % 4 == 0, "whole matrix-core steps");
+    __host__ __device__ static constexpr int fw(int p, int u) { return FW + (((u >> 2) * NPB + (p >> 4)) * 4 + (u & 3)) * 16 + (p & 15); }
+    __host__ __device__ static constexpr int fg(int k, int n, int v) { return FG + v * (S * L) + k * L + n; }
+    __host__ __device__ static constexpr int fo(int k, int n, int v) { return FO + v * (S * L) + k * L + n; }
     // work area in LDS (doubles): C[32][33] (C[v][u], zero beyond D), P[NP][33] (P[k (L + 2) + m][v] = sum_u C[v][u] FW[k][m][u]),
     // lag sums [S][5], coefficients [S][8] (b0 b1 b2 a1 a2 normalised, sg, om, 1 / om)
     static constexpr int CM = 0, P = 32 * 33, LAG = P + NP * 33, CF = LAG + S * 5 + (S * 5) % 2, WORK = CF + S * 8;
 };
+template <int S> __device__ __forceinline__ constexpr int basis_doubles() { return GramFin<S>::BASIS; }
 template <bool AGENT> __device__ __forceinline__ double fin_ld(const double* p) {
     if (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
@@ -1821,7 +1015,7 @@ __device__ __forceinline__ void gram_fin_coefs(const double* __restrict__ d0, do
 template <int S, bool AGENT>
 __device__ __forceinline__ void gram_basis_responses(const double* cf, double* bas, int tid) {
     using GF = GramFin<S>;
-    constexpr int L = GF::L, D = GF::D, NW = GF::NW;
+    constexpr int L = GF::L, NW = GF::NW, D = GF::D;
     if (tid >= 128) return;
     const int j = tid & 63, adj = tid >> 6;
     if (j >= D) return;
@@ -1835,27 +1029,24 @@ __device__ __forceinline__ void gram_basis_responses(const double* cf, double* b
         const double c1 = (j == L + 2 * i) ? 1.0 : 0.0, c2 = (j == L + 2 * i + 1) ? 1.0 : 0.0;   // the unit state component, if it is this section's
         if (!adj) {
             double w2 = c2 * iom, w1 = c1 + sg * iom * c2;
-            double* fw = bas + GF::FW + (size_t)(k * NW) * D + j;
-            fin_st<AGENT>(fw, w2); fin_st<AGENT>(fw + D, w1);
+            fin_st<AGENT>(bas + GF::fw(k * NW, j), w2); fin_st<AGENT>(bas + GF::fw(k * NW + 1, j), w1);
 #pragma unroll
             for (int n = 0; n < L; ++n) {
                 const double w = fma(-a1, w1, fma(-a2, w2, sig[n]));      // (one FMA on the recurrence's dependent chain)
                 sig[n] = fma(b0, w, fma(b1, w1, b2 * w2));
-                fin_st<AGENT>(fw + (size_t)(n + 2) * D, w);
+                fin_st<AGENT>(bas + GF::fw(k * NW + n + 2, j), w);
                 w2 = w1; w1 = w;
             }
         } else {
             double z1 = c1, z2 = -sg * c1 + om * c2;
-            double* fg = bas + GF::FG + (size_t)(k * L) * D + j;
-            double* fo = bas + GF::FO + (size_t)(k * L) * D + j;
 #pragma unroll
             for (int n = L - 1; n >= 0; --n) {
                 const double g = sig[n];
-                fin_st<AGENT>(fg + (size_t)n * D, g);
+                fin_st<AGENT>(bas + GF::fg(k, n, j), g);
                 const double o = fma(b0, g, z1);
                 z1 = fma(-a1, o, fma(b1, g, z2));
                 z2 = fma(-a2, o, b2 * g);
-                fin_st<AGENT>(fo + (size_t)n * D, o);
+                fin_st<AGENT>(bas + GF::fo(k, n, j), o);
                 sig[n] = o;
             }
         }
@@ -1934,13 +1125,12 @@ __device__ __forceinline__ void gram_prefetch(const double* bas, int tid, GramOp
 #pragma unroll
         for (int q = 0; q < GramOps<S>::NB; ++q) {
             const int p0 = 16 * ((wave + 4 * q) >> 1), pmr = p0 + li < NP ? p0 + li : NP - 1;   // (pad columns of the last block and blocks past the end: any row - their results are not stored)
-            r.bop[st][q] = fin_ld<AGENT>(bas + GF::FW + (size_t)pmr * D + uu);
+            r.bop[st][q] = fin_ld<AGENT>(bas + GF::fw(pmr, uu));
         }
     }
-    const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;
-    const double* F = bas + ((which & 1) ? GF::FO : GF::FG) + (size_t)(k * L + n) * D;      // (threads beyond 2 x 16 S read a valid row they do not use)
+    const int which = tid / (16 * S), k = (tid / 16) % S, n = tid & 15;      // (threads beyond 2 x 16 S read a valid row they do not use)
 #pragma unroll
-    for (int v = 0; v < D; ++v) r.f[v] = fin_ld<AGENT>(F + v);
+    for (int v = 0; v < D; ++v) r.f[v] = fin_ld<AGENT>(bas + ((which & 1) ? GF::fo(k, n, v) : GF::fg(k, n, v)));
 }
 // wk = the LDS work area with C in place (barrier before the call) -> the 5 S lag sums in wk + LAG (barrier after the call before they are
 // read); 256 threads. `item` only serves the developer trace.
@@ -2145,6 +1335,9 @@ __device__ __forceinline__ void gram_operands_load(const float* img, float (&R)[
     for (int m = 0; m < 16; ++m) R[m] = img[64 * m + 16 * k + 4 * ((i >> 2) ^ (m & 3)) + (i & 3)];      // (swz_slot(4 m + k, i / 4), entry i % 4)
 }
 
+// FLAGS & BWD_NOGX: no gradient for x is wanted (the EQ is the first effect of the reference's chain: examples/style_transfer.py:150) - no
+// output map, 4 B per sample less.
+constexpr int BWD_NOGX = 2;
 // SEG = 1: segmented rows (few rows): workgroup = (row, segment of Tseg tiles), the adjoint state entering the segment from above comes from
 // segstart[row][segment][2S] (the scan-only pre-pass of sos_bwd_kernel<SEG = 2> and its chain); one matrix per (row, segment).
 template <int S, int L, int W, int FLAGS, int SEG = 0>
@@ -2241,16 +1434,13 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         gram_operands_load(tbg, Rg, lane);
         gram_operands_load(tbx, Rx, lane);
         gram_operands_load(tsi, Rs, lane);
-#if DASP_GRAM_ZVALU
         float GYc[L];
         lds_to_chunks_swz<L>(tbg, GYc, cl);
         pin(GYc);
-#endif
         pin(Bg); pin(Rg); pin(Rx); pin(Rs);
         if (r + W < nr) issue_dma(t - W, tile_full<L>((long)(t - W) * TS, N, vec));     // the three images are in registers now
         TRACE(18);
         float Z[L];
-#if DASP_GRAM_ZVALU
         {   // zero-state chunk end states on the VALU (packed FMAs against the wave-uniform table in SGPRs, one section's 16 entries at a time,
             // the next section's loads in flight meanwhile): the 16 matrix-core products this replaces queued behind the other wave's bulk
             // products and came back through an LDS round trip - the longest phase of the tile after the scan
@@ -2277,38 +1467,21 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 #pragma unroll
             for (int c = 2 * S; c < L; ++c) Z[c] = 0.f;
         }
-#else
-        f4 zacc[4];
-        chunk_products_issue(Bg, Aop, zacc);
-        chunk_products_collect<L>(tbo, zacc, Z, lane, cl);
-#endif
         pin(Z); TRACE(25);
         // the half of the tile's products that does not need the scan: (gy x) and (gy states) blocks of C, TA gy of gx - they run on the
         // matrix cores while the VALU scans
         f4 cacc[4], oacc[4];
         const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};       // (the first product of every accumulator takes the constant: no zeroing moves)
-#if DASP_GRAM_ABLATE
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { cacc[c] = zero4; oacc[c] = zero4; }
-#endif
         // product number idx = 3 j + type of the 48: (gy x) step j, (gy states) step j, TA gy term j
         auto early = [&](int idx) {
             const int j = idx / 3, ty = idx % 3;
-            if (ty == 0) { if (!(DASP_GRAM_ABLATE & 1)) cacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rx[j], j ? cacc[0] : zero4, 0, 0, 0); }
-            else if (ty == 1) { if (!(DASP_GRAM_ABLATE & 1)) cacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rs[j], j ? cacc[1] : zero4, 0, 0, 0); }
-            else if (GX && !(DASP_GRAM_ABLATE & 2)) oacc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[j >> 2], Bg[j & 3][j >> 2], (j >> 2) ? oacc[j & 3] : zero4, 0, 0, 0);
+            if (ty == 0) { cacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rx[j], j ? cacc[0] : zero4, 0, 0, 0); }
+            else if (ty == 1) { cacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rg[j], Rs[j], j ? cacc[1] : zero4, 0, 0, 0); }
+            else if (GX) oacc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AT[j >> 2], Bg[j & 3][j >> 2], (j >> 2) ? oacc[j & 3] : zero4, 0, 0, 0);
         };
-#if !DASP_GRAM_INTERLEAVE
-#pragma unroll
-        for (int idx = 0; idx < 48; ++idx) early(idx);
-#endif
         TRACE(26);
         // ---- adjoint chunk end states: the scan runs from the last chunk to the first = ascending lanes (chunk 63 - lane) ----
         f2 lam[S];  // adjoint section order: i <-> forward section S-1-i
-#if DASP_GRAM_ABLATE & 8
-#pragma unroll
-        for (int i = 0; i < S; ++i) lam[i] = f2{Z[2 * i], Z[2 * i + 1]};
-#else
         {
             MboxPeek pk;
             SCAN_PRIO(DASP_SCAN_PRIO);
@@ -2325,7 +1498,6 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
                     else if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
                 },
                 [&](int k, int p) {      // the 48 products above, dealt out over the 4 S hook points of the scan
-                    if (!DASP_GRAM_INTERLEAVE) return;
                     constexpr int NPS = (48 + S - 1) / S, base = NPS / 4, extra = NPS % 4;
                     const int start = k * NPS + p * base + (p < extra ? p : extra), cnt = base + (p < extra ? 1 : 0);
 #pragma unroll
@@ -2333,11 +1505,6 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
                         if (i < cnt && start + i < 48) early(start + i);
                 });
         }
-#endif
-#if DASP_GRAM_INTERLEAVE && (DASP_GRAM_ABLATE & 8)
-#pragma unroll
-        for (int idx = 0; idx < 48; ++idx) early(idx);
-#endif
         SCAN_PRIO(0);
         pin(lam); TRACE(19);
         // ---- the other half: the adjoint states as one more [chunk][16] image (components 2 i + c; zeros beyond 2S) ----
@@ -2354,13 +1521,11 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
             float Rl[16];
             gram_operands_load(tbo, Rl, lane);
             pin(Rl); TRACE(27);
-#if !(DASP_GRAM_ABLATE & 1)
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 cacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rx[m], m ? cacc[2] : zero4, 0, 0, 0);
                 cacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rl[m], Rs[m], m ? cacc[3] : zero4, 0, 0, 0);
             }
-#endif
         }
         WIDE_PRIO(DASP_SCAN_PRIO);
         TRACE(28);
@@ -2372,7 +1537,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
             for (int q = 0; q < state_steps<S>(); ++q)          // (entries 4 k + 3 of the adjoint-state image are zeros for 2S <= 12: sos_tile.hpp state_pos)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (!(DASP_GRAM_ABLATE & 2)) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bl[c][q], oacc[c], 0, 0, 0);
+                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(AO[q], Bl[c][q], oacc[c], 0, 0, 0);
             // (segmented rows: the launch ends with a hand-off - gx goes through the L2 so that its release finds nothing to write back)
             if (DASP_DIRECT_OUT && full) {
                 mfma_granules_to_global(gxr + (size_t)t * TS, oacc, true, lane, SEG != 0);
@@ -2386,7 +1551,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         TRACE(23);
         // the tile's fp32 block sums -> the row's fp64 sums
 #pragma unroll
-        for (int b = 0; b < ((DASP_GRAM_ABLATE & 4) ? 1 : 4); ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gsum[4 * b + e] += (double)cacc[b][e];
         TRACE(24);
@@ -2411,34 +1576,6 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         for (int w = 0; w < W; ++w) s += red[w * (REGION / 2) + e];
         gram[(SEG ? (size_t)row * G + seg : (size_t)row) * 1024 + e] = s;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stand-alone finalize (one thread per (item, section)): used when the table is shared by all items (tab_bcast) or when the caller
-// asks for the two steps separately; otherwise the backward kernel finalizes an item as soon as its last row is done.
-__global__ void sos_finalize_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
-                                    int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int fast) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * S) return;
-    finalize_section<false>(dtab, tab_bcast, partials, B, C, S, Wb, mode, gout, idx / S, idx % S, fast);
-}
-// The same with one wave per (item, section), its lanes across the item's rows of sums: segmented rows leave C * 4 * segments rows per
-// item (64 at 16 x 2 x 131072), which one thread fetches in C * Wb / 8 dependent rounds (12 us); a wave needs one.
-__global__ void __launch_bounds__(256) sos_finalize_wave_kernel(const double* __restrict__ dtab, int tab_bcast, const float* __restrict__ partials,
-                                                                int B, int C, int S, int Wb, int mode, float* __restrict__ gout, int fast) {
-    const int idx = blockIdx.x * (blockDim.x / 64) + wave_id(), l = lane_id();
-    if (idx >= B * S) return;
-    const int item = idx / S, k = idx % S, R = C * Wb;
-    const float* p0 = partials + ((size_t)item * R * S + k) * 5;
-    double acc[5] = {0, 0, 0, 0, 0};
-    for (int r = l; r < R; r += 64) {
-        const float* p = p0 + (size_t)r * S * 5;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] += (double)p[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
-    if (l == 0) finish_section(dtab, tab_bcast, acc, B, S, mode, gout, item, k, fast);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2484,91 +1621,17 @@ constexpr int kWF = DASP_FWD_W;    // waves per row, forward (2 rows per CU -> 4
 #ifndef DASP_BWD_W
 #define DASP_BWD_W 4
 #endif
-constexpr int kWB = DASP_BWD_W;    // waves per row, backward (2 rows per CU -> 2 waves per SIMD; measured faster than 6 waves at 168 registers)
+constexpr int kWB = DASP_BWD_W;    // waves per row, Gram-matrix backward (2 rows per CU -> 2 waves per SIMD)
 #ifndef DASP_BWD_W_ADJ
 #define DASP_BWD_W_ADJ 8
 #endif
-constexpr int kWBA = DASP_BWD_W_ADJ;
-// The three-waves-per-SIMD backward kernel (sos_bwd_ckpt_kernel: S = 6, coefficient gradients, one workgroup of kWB3 waves per row).
-// DASP_BWD_KERNEL=2w / 3w at run time overrides the build's default (developer A/B in one library).
-// MEASURED NEGATIVE (profiles/r03/ab_bwd3w*.log, same box, bwd + finalize at (256, 2, 131072)): two-wave kernel 0.256 ms; this one with six-wave
-// workgroups 0.349 - 0.361, with four-wave workgroups (three per CU) 0.284, and the same four-wave build with its LDS padded so that only
-// two workgroups fit a CU - two waves per SIMD again - 0.286: occupancy changes nothing, the + 11 % is the price of the extra recomputation.
-// The backward kernel is bound by VALU throughput (115.8 M VALU instructions per launch over 1024 SIMDs = 4.6 SIMD cycles per instruction
-// at 86 % VALU-busy, profiles/r01/v14_sq_counters.json), not by the latency a third wave would hide. Off by default; kept selectable.
-#ifndef DASP_BWD_3W
-#define DASP_BWD_3W 0
-#endif
-#ifndef DASP_BWD3_W
-#define DASP_BWD3_W 4
-#endif
-constexpr int kWB3 = DASP_BWD3_W;
-inline bool use_bwd3w(int S, int designed) {     // designed cascades only: the generic variant (five correlations per section) does not fit 168 registers without spills
-    static const int pick = [] {
-        const char* e = getenv("DASP_BWD_KERNEL");
-        if (e && e[0] == '2') return 0;
-        if (e && e[0] == '3') return 1;
-        return DASP_BWD_3W;
-    }();
-    return pick && S == 6 && designed;
-}   // ... of the adjoint-only variant (no coefficient gradients: ~100 registers, 8 KiB of LDS per wave - the
-                                       // forward kernel's shape; with kWB waves it ran at 2 waves per SIMD and was latency-bound, 0.159 ms)
-
-// Eight sections: sos_bwd_kernel<8> parks half of its kept signals in LDS (145 KiB per workgroup: one wave per SIMD). The checkpointed
-// kernel instantiated for 4 + 4 sections keeps 4 x 18 registers, 12 KiB of LDS per wave and runs two waves per SIMD like the six-section
-// kernel (kWB waves per row: the partial sums keep their layout). DASP_BWD8_CHECKPOINT=0 / 1 at run time overrides the build's default.
-#ifndef DASP_BWD8_CHECKPOINT
-#define DASP_BWD8_CHECKPOINT 1
-#endif
-inline bool use_bwd8cp(int S) {
-    static const int pick = [] {
-        const char* e = getenv("DASP_BWD8_CHECKPOINT");
-        return e ? (e[0] != '0') : (DASP_BWD8_CHECKPOINT != 0);
-    }();
-    return pick && S == 8;
-}
-
-// Backward by Gram matrix (sos_bwd_gram_kernel + sos_gram_finalize_kernel) for one workgroup per row with coefficient gradients;
-// DASP_BWD_GRAM=0 / 1 at run time overrides the build's default. The partial-sum buffer then holds one 32 x 32 fp64 matrix per row.
-#ifndef DASP_BWD_GRAM
-#define DASP_BWD_GRAM 1
-#endif
-// the same for segmented rows (sos_bwd_gram_kernel<SEG = 1> + a finalize launch instead of sos_bwd_kernel<SEG = 1> finalizing in its last
-// workgroup): DASP_SEG_GRAM=0 / 1 at run time overrides the build's default
-#ifndef DASP_SEG_GRAM
-#define DASP_SEG_GRAM 1     // (round 4, with a finalize launch of its own:) measured (profiles/r04/seg_gram_ab.log): the finalize launch it needs costs more than the kernel saves at the reference's
-                            // training batches - EQ fwd+bwd (8 / 16, 2, 131072) 0.081 -> 0.090 / 0.097 -> 0.106 ms, (16, 1, 131072) without gx 0.080 -> 0.083,
-                            // (32, 2, 131072) 0.131 = 0.131. What it buys is the Gram kernel's accuracy on segmented rows (worst control gradient of the
-                            // randomized sweep 1.0e-4 -> 2e-5): opt-in.
-#endif
-inline bool use_seg_gram();
-inline bool use_bwd_gram() {
-    static const int pick = [] {
-        const char* e = getenv("DASP_BWD_GRAM");
-        return e ? (e[0] != '0') : (DASP_BWD_GRAM != 0);
-    }();
-    return pick != 0;
-}
+constexpr int kWBA = DASP_BWD_W_ADJ;   // ... of the adjoint-only kernel (~100 registers, 8 KiB of LDS per wave - the forward kernel's shape; with kWB waves it
+                                       // ran at 2 waves per SIMD and was latency-bound)
 
 // At most one row per CU (B * C <= 256 rows, one workgroup each): twice the waves per row - the same waves per CU as two rows of the
 // ordinary width, on one row (one workgroup per CU fits: LDS 134 / 139 KiB). Rows are latency-bound there: (64..128, 2, 131072) EQ steps
-// took the same 0.23 ms as a 256-row batch, and cutting rows into segments does not pay above 128 rows (profiles/r04/seg_crossover.log).
-// DASP_SOS_WIDE=0 / 1 at run time forces the choice (developer A/B).
-inline bool wide_rows(long rows) {
-    static const int pick = [] {
-        const char* e = getenv("DASP_SOS_WIDE");
-        return e ? (e[0] != '0' ? 1 : 0) : -1;
-    }();
-    return pick < 0 ? rows <= 256 : pick != 0;
-}
-
-inline bool use_seg_gram() {
-    static const int pick = [] {
-        const char* e = getenv("DASP_SEG_GRAM");
-        return e ? (e[0] != '0') : (DASP_SEG_GRAM != 0);
-    }();
-    return pick != 0 && use_bwd_gram();
-}
+// took the same 0.23 ms as a 256-row batch, and cutting rows into segments does not pay above 64 rows (profiles/r04/seg_crossover.log).
+inline bool wide_rows(long rows) { return rows <= 256; }
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
@@ -2593,27 +1656,6 @@ int dispatch_S(int S, F&& f) {
         default: return DASP_ERR_UNSUPPORTED;
     }
 }
-
-// kernel flags of a backward call: `designed` = the tables come from dasp_peq_prepare* (BWD_FAST is valid), gx == null -> BWD_NOGX,
-// partials == null -> BWD_NOGC; -1 = nothing to compute
-inline int bwd_flags(int designed, const void* gx, const void* partials) {
-    if (!gx && !partials) return -1;
-    if (!partials) return BWD_NOGC;
-    return (designed ? BWD_FAST : 0) | (gx ? 0 : BWD_NOGX);
-}
-
-// one launch of sos_bwd_kernel<S, kL, kWB, SEG, flags>
-template <int SS, int SEG, typename... A>
-void launch_bwd(int flags, int blocks, hipStream_t st, A... a) {
-    const dim3 g(blocks), b(64 * kWB);
-    switch (flags) {
-        case 0: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, 0>), g, b, 0, st, a...); break;
-        case BWD_FAST: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_FAST>), g, b, 0, st, a...); break;
-        case BWD_NOGX: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_NOGX>), g, b, 0, st, a...); break;
-        case BWD_FAST | BWD_NOGX: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, SEG, BWD_FAST | BWD_NOGX>), g, b, 0, st, a...); break;
-        default: hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWBA, SEG, BWD_NOGC>), g, dim3(64 * kWBA), 0, st, a...); break;
-    }
-}
 }  // namespace
 
 extern "C" {
@@ -2635,10 +1677,7 @@ long dasp_sos_table_floats(int S) {
 long dasp_sos_dtab_doubles(int S) { return (long)S * DT_STRIDE; }
 long dasp_sos_num_tiles(long N) { return (N + 64 * kL - 1) / (64 * kL); }
 long dasp_sos_carry_floats(long rows, long N, int S) { return rows * dasp_sos_num_tiles(N) * 2 * S * 64; }
-long dasp_sos_partial_floats(long rows, int S) {
-    const long sums = rows * (kWB3 > kWB ? kWB3 : kWB) * S * 5, gram = rows * 2048;     // (one 32 x 32 fp64 matrix per row: sos_bwd_gram_kernel)
-    return sums > gram ? sums : gram;
-}
+long dasp_sos_partial_floats(long rows, int S) { (void)S; return rows * 2048; }     // one 32 x 32 fp64 Gram matrix per row (per (row, segment))
 
 // sos: (Bs, S, 6) fp32 rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Builds tables for Bs items.
 int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, void* stream) {
@@ -2716,62 +1755,35 @@ int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, flo
     });
 }
 
-// gx == null: no input gradient (BWD_NOGX); partials == null: no coefficient gradients (BWD_NOGC; x and carries are not read);
-// designed != 0: tab was filled by dasp_peq_prepare / dasp_peq_prepare_rows (the monic / identity kernel; finalize with the same flag)
+// gx == null: no input gradient; partials == null: no coefficient gradients (the adjoint-only kernel: x and carries are not read).
+// With coefficient gradients the pass is sos_bwd_gram_kernel and leaves one Gram matrix per row in `partials`. `designed` is accepted for
+// source compatibility and ignored (rounds 2 - 4 had a monic recomputation kernel for designed cascades).
 int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
                              float* partials, int B, int C, long N, int S, int designed, void* stream) {
-    const int flags = bwd_flags(designed, gx, partials);
-    if (!tab || !gy || flags < 0 || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B)) return DASP_ERR_ARG;
-    if (!(flags & BWD_NOGC) && (!x || !carries)) return DASP_ERR_ARG;
+    (void)designed;
+    if (!tab || !gy || (!gx && !partials) || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B)) return DASP_ERR_ARG;
+    if (partials && (!x || !carries || !aligned16(partials))) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
-    const int nt = (int)dasp_sos_num_tiles(N);
+    const int nt = (int)dasp_sos_num_tiles(N), bc = Bs == 1 && B != 1;
     const int vec = (N % 4 == 0) && aligned16(gy) && (!x || aligned16(x)) && (!gx || aligned16(gx));
-    if (use_bwd_gram() && !(flags & BWD_NOGC)) {
-        if (!aligned16(partials)) return DASP_ERR_ARG;
-        const int bc = Bs == 1 && B != 1;
-        return dispatch_S(S, [&](auto s) {
-            constexpr int SS = decltype(s)::value;
-            const dim3 g(B * C), b(64 * kWB), b2(128 * kWB);
-            hipStream_t st = (hipStream_t)stream;
-            double* gm = reinterpret_cast<double*>(partials);
-            const bool wide = wide_rows(B * C);
-            if (wide && (flags & BWD_NOGX))
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, 2 * kWB, BWD_NOGX>), g, b2, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
-            else if (wide)
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, 2 * kWB, 0>), g, b2, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
-            else if (flags & BWD_NOGX)
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
-            else
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
-            return check_launch();
-        });
-    }
-    if (use_bwd3w(S, designed) && !(flags & BWD_NOGC)) {
-        const dim3 g(B * C), b(64 * kWB3);
-        hipStream_t st = (hipStream_t)stream;
-        const int bc = Bs == 1 && B != 1;
-        if (flags & BWD_NOGX)
-            hipLaunchKernelGGL((sos_bwd_ckpt_kernel<6, kL, kWB3, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
-        else
-            hipLaunchKernelGGL((sos_bwd_ckpt_kernel<6, kL, kWB3, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec);
-        return check_launch();
-    }
-    if (use_bwd8cp(S) && !(flags & BWD_NOGC)) {
-        const dim3 g(B * C), b(64 * kWB);
-        hipStream_t st = (hipStream_t)stream;
-        const int bc = Bs == 1 && B != 1;
-        switch (flags) {
-            case 0: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-            case BWD_NOGX: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-            case BWD_FAST: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, BWD_FAST>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-            default: hipLaunchKernelGGL((sos_bwd_ckpt_kernel<8, kL, kWB, BWD_FAST | BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec); break;
-        }
-        return check_launch();
-    }
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
-        launch_bwd<SS, 0>(flags, B * C, (hipStream_t)stream, tab, Bs == 1 && B != 1, x, gy, carries, gx, partials, C, (int)N, nt, vec,
-                          (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, 1, 0, (const float*)nullptr, (float*)nullptr);
+        hipStream_t st = (hipStream_t)stream;
+        if (!partials) {
+            hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWBA, 0>), dim3(B * C), dim3(64 * kWBA), 0, st, tab, bc, gy, gx, C, (int)N, nt, vec);
+            return check_launch();
+        }
+        const dim3 g(B * C), b(64 * kWB), b2(128 * kWB);
+        double* gm = reinterpret_cast<double*>(partials);
+        const bool wide = wide_rows(B * C);
+        if (wide && !gx)
+            hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, 2 * kWB, BWD_NOGX>), g, b2, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
+        else if (wide)
+            hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, 2 * kWB, 0>), g, b2, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
+        else if (!gx)
+            hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
+        else
+            hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec);
         return check_launch();
     });
 }
@@ -2783,71 +1795,39 @@ int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float*
 }
 
 // mode 0: gout (B,S,6) = dL/dsos ; mode 1: gout (B,S,3) = dL/d(gain_db, cutoff_freq, q_factor); mode 2: the same as (3S, B) rows.
-// segments: rows of partial sums per (row, wave) as written by the *_seg entry points (1 for the plain ones).
-static int grad_finalize_impl(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
-                              int designed, float* gout, bool plain, void* stream) {
+// partials: one Gram matrix per (row, segment) - `segments` of them per row as written by the *_seg entry points, 1 for the plain ones.
+static int grad_finalize_impl(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode, float* gout, void* stream) {
     if (!dtab || !partials || !gout || B <= 0 || C <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2 || segments <= 0)
         return DASP_ERR_ARG;
-    if (plain ? use_bwd_gram() : use_seg_gram()) {      // one matrix per row (dasp_sosfilt_backward_ex) or per (row, segment)
-        return dispatch_S(S, [&](auto s) {
-            constexpr int SS = decltype(s)::value;
-            hipLaunchKernelGGL((sos_gram_finalize_kernel<SS>), dim3(B), dim3(256), 0, (hipStream_t)stream, dtab, Bs == 1 && B != 1,
-                               reinterpret_cast<const double*>(partials), B, plain ? C : C * segments, mode, gout);
-            return check_launch();
-        });
-    }
-    const int n = B * S;
-    const int wb = (segments == 1 && use_bwd3w(S, designed) ? kWB3 : kWB) * segments;      // rows of sums per signal row: the waves of the kernel that wrote them
-    if (C * wb > 16)      // many rows of sums per item (segmented rows): one wave per (item, section)
-        hipLaunchKernelGGL(sos_finalize_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dtab,
-                           Bs == 1 && B != 1, partials, B, C, S, wb, mode, gout, designed ? 1 : 0);
-    else
-        hipLaunchKernelGGL(sos_finalize_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dtab,
-                           Bs == 1 && B != 1, partials, B, C, S, wb, mode, gout, designed ? 1 : 0);
-    return check_launch();
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        hipLaunchKernelGGL((sos_gram_finalize_kernel<SS>), dim3(B), dim3(256), 0, (hipStream_t)stream, dtab, Bs == 1 && B != 1,
+                           reinterpret_cast<const double*>(partials), B, C * segments, mode, gout);
+        return check_launch();
+    });
 }
 
 int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
                               int designed, float* gout, void* stream) {
-    return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, designed, gout, segments == 1, stream);
+    (void)designed;
+    return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, gout, stream);
 }
 
 int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, int B, int C, int S, int mode,
                            float* gout, void* stream) {
-    return dasp_sos_grad_finalize_ex(dtab, Bs, partials, B, C, S, 1, mode, 0, gout, stream);
+    return grad_finalize_impl(dtab, Bs, partials, B, C, S, 1, mode, gout, stream);
 }
 
-// dasp_sosfilt_backward followed by dasp_sos_grad_finalize (same mode / gout) as one call. Built with -DDASP_FUSED_FINALIZE=1 and
-// given one table per item (Bs == B) it is also one launch: the backward kernel finalizes every item as its last row completes, using
-// the completion counter in the item's table (hence the non-const tab). Measured at the north-star shape: 2-3 us of 425 per step
-// (the finalize work becomes a tail of the big kernel); left off by default - the gain does not pay for a cross-XCD hand-off that
-// only the hardware's memory model keeps correct. Otherwise, and with a shared table (Bs == 1 < B), it launches the two kernels.
-#ifndef DASP_FUSED_FINALIZE
-#define DASP_FUSED_FINALIZE 0
-#endif
-#ifndef DASP_SEG_FUSED_FINALIZE
-#define DASP_SEG_FUSED_FINALIZE 1     // segmented rows (few rows: the step is launch-bound): finalize inside the backward launch (dasp_peq_backward)
-#endif
+// dasp_sosfilt_backward followed by dasp_sos_grad_finalize (same mode / gout) as one call (two launches: fusing the finalize step into the
+// backward kernel of one-workgroup-per-row launches was measured at 2 - 3 us of 425 and is not built; segmented rows - dasp_peq_backward -
+// do finalize inside their launch).
 int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
                                    float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, int designed,
                                    void* stream) {
-    const int flags = bwd_flags(designed, gx, partials);
-    if (!tab || !gy || flags < 0 || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || mode < 0 || mode > 2) return DASP_ERR_ARG;
-    if (!(flags & BWD_NOGC) && (!dtab || !x || !carries || !gout)) return DASP_ERR_ARG;
-    if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
-    if (!DASP_FUSED_FINALIZE || (flags & BWD_NOGC) || (Bs == 1 && B != 1)) {
-        const int rc = dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, designed, stream);
-        if (rc != DASP_OK || (flags & BWD_NOGC)) return rc;
-        return dasp_sos_grad_finalize_ex(dtab, Bs, partials, B, C, S, 1, mode, designed, gout, stream);
-    }
-    const int nt = (int)dasp_sos_num_tiles(N);
-    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(gy) && (!gx || aligned16(gx));
-    return dispatch_S(S, [&](auto s) {
-        constexpr int SS = decltype(s)::value;
-        launch_bwd<SS, 0>(flags, B * C, (hipStream_t)stream, (const float*)tab, 0, x, gy, carries, gx, partials, C, (int)N, nt, vec, tab, dtab,
-                          mode, gout, B, 1, 0, (const float*)nullptr, (float*)nullptr);
-        return check_launch();
-    });
+    if (mode < 0 || mode > 2 || (partials && (!dtab || !gout))) return DASP_ERR_ARG;
+    const int rc = dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, designed, stream);
+    if (rc != DASP_OK || !partials) return rc;
+    return grad_finalize_impl(dtab, Bs, partials, B, C, S, 1, mode, gout, stream);
 }
 
 int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
@@ -2875,7 +1855,10 @@ long dasp_sos_segment_tiles(long rows, long N) {
 long dasp_sos_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_sos_num_tiles(N) + Tseg - 1) / Tseg : 1; }
 // per item: the segment transition matrices of both systems; behind the Bs items' matrices, per item, the basis responses of the Gram
 // finalize step (GramFin<S>::BASIS doubles: written by the design launch of dasp_peq_forward*, read by dasp_peq_backward)
-static long sos_basis_doubles(int S) { return (long)(S * 18 + 2 * S * 16) * (16 + 2 * S); }
+static long sos_basis_doubles(int S) {      // = GramFin<S>::BASIS: FW in whole 16-row blocks, FG, FO
+    const long D = 16 + 2 * S, NPB = (S * 18 + 15) / 16;
+    return (D / 4) * NPB * 64 + 2 * D * S * 16;
+}
 long dasp_sos_segtab_doubles(int S) { return 2L * (2 * S) * (2 * S) + sos_basis_doubles(S); }
 long dasp_sos_seg_floats(long rows, long N, int S, long Tseg) { return 2 * rows * dasp_sos_segments(N, Tseg) * 2 * S; }
 
@@ -2930,15 +1913,15 @@ int dasp_sos_segment_starts(const float* tab, const double* segtab, int Bs, cons
     });
 }
 
-// gx / partials / designed as in dasp_sosfilt_backward_ex
-// fin_dtab != null (with one table per item and coefficient gradients asked for): the workgroup that completes an item's count maps its
-// partial sums to the gradients gout (mode as in dasp_sos_grad_finalize_ex) - no finalize launch
+// gx / partials as in dasp_sosfilt_backward_ex
+// fin_dtab != null (with one table per item, the basis responses behind segtab's matrices - dasp_peq_forward* - and coefficient gradients
+// asked for): every (row, segment) workgroup turns its Gram matrix into lag sums and the one that completes an item's count maps their sum
+// to the gradients gout (mode as in dasp_sos_grad_finalize_ex) - no finalize launch (gram_fused_tail)
 static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
-                                     float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
+                                     float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg,
                                      const double* fin_dtab, int fin_mode, float* fin_gout, void* stream) {
-    const int flags = bwd_flags(designed, gx, partials);
-    if (!tab || !segtab || !gy || flags < 0 || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0) return DASP_ERR_ARG;
-    if (!(flags & BWD_NOGC) && (!x || !carries)) return DASP_ERR_ARG;
+    if (!tab || !segtab || !gy || (!gx && !partials) || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0) return DASP_ERR_ARG;
+    if (partials && (!x || !carries || !aligned16(partials))) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_sos_num_tiles(N), G = (int)dasp_sos_segments(N, Tseg), bc = Bs == 1 && B != 1;
     const int vec = (N % 4 == 0) && aligned16(gy) && (!x || aligned16(x)) && (!gx || aligned16(gx));
@@ -2947,40 +1930,36 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         hipStream_t st = (hipStream_t)stream;
-        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWB, 2>), dim3(B * C * G), dim3(64 * kWB), 0, st, tab, bc, x, gy, carries, (float*)nullptr,
-                           (float*)nullptr, C, (int)N, nt, vec, (float*)nullptr, (const double*)nullptr, 0, (float*)nullptr, B, G, (int)Tseg,
+        // adjoint scan-only pre-pass; its last workgroup per item chains the segments (chain_by_last_workgroup: the counter word lives in the table)
+        // (kWBA waves: a segment of eight tiles is one tile per wave - the scan-only pass is a latency chain, not a throughput loop)
+        hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWBA, 2>), dim3(B * C * G), dim3(64 * kWBA), 0, st, tab, bc, gy, (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg,
                            (const float*)nullptr, z, const_cast<float*>(tab), segtab, start);
-        if (use_seg_gram() && !(flags & BWD_NOGC)) {
-            // one Gram matrix per (row, segment); with one table per item and the basis responses in place (fin_dtab given: dasp_peq_backward
-            // after dasp_peq_forward*) the finalize step runs inside this launch: the last workgroup of an item to arrive maps its matrices
-            // to the gradients (gram_fused_tail) - otherwise the caller finalizes (grad_finalize_impl)
-            if (!aligned16(partials)) return DASP_ERR_ARG;
-            static_assert(GramFin<SS>::BASIS == (SS * 18 + 2 * SS * 16) * (16 + 2 * SS), "sos_basis_doubles");
-            double* gm = reinterpret_cast<double*>(partials);
-            GramFuse fz = {};
-            if (fin_dtab && fin_gout && !bc) {
-                fz.on = 1; fz.B = B; fz.mode = fin_mode; fz.dtab = fin_dtab; fz.gout = fin_gout;
-                fz.basis = segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS);
-                fz.cnt_tab = const_cast<float*>(tab);
-            }
-            const dim3 g(B * C * G), b(64 * kWB);
-            if (flags & BWD_NOGX)
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start, fz);
-            else
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start, fz);
+        if (!partials) {
+            hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWBA, 1>), dim3(B * C * G), dim3(64 * kWBA), 0, st, tab, bc, gy, gx, C, (int)N, nt, vec, G, (int)Tseg,
+                               (const float*)start, (float*)nullptr);
             return check_launch();
         }
-        const bool fuse = fin_dtab && fin_gout && !bc && !(flags & BWD_NOGC);
-        launch_bwd<SS, 1>(flags, B * C * G, st, tab, bc, x, gy, carries, gx, partials, C, (int)N, nt, vec, fuse ? const_cast<float*>(tab) : (float*)nullptr,
-                          fuse ? fin_dtab : (const double*)nullptr, fin_mode, fuse ? fin_gout : (float*)nullptr, B, G, (int)Tseg, (const float*)start,
-                          (float*)nullptr);
+        if (GramFin<SS>::BASIS != sos_basis_doubles(SS)) return DASP_ERR_UNSUPPORTED;        // (the size query and the layout are two statements of one number)
+        double* gm = reinterpret_cast<double*>(partials);
+        GramFuse fz = {};
+        if (fin_dtab && fin_gout && !bc) {
+            fz.on = 1; fz.B = B; fz.mode = fin_mode; fz.dtab = fin_dtab; fz.gout = fin_gout;
+            fz.basis = segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS);
+            fz.cnt_tab = const_cast<float*>(tab);
+        }
+        const dim3 g(B * C * G), b(64 * kWB);
+        if (!gx)
+            hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start, fz);
+        else
+            hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 1>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)start, fz);
         return check_launch();
     });
 }
 int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
                                  float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
                                  void* stream) {
-    return sosfilt_backward_seg_impl(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, designed, nullptr, 0, nullptr, stream);
+    (void)designed;
+    return sosfilt_backward_seg_impl(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, nullptr, 0, nullptr, stream);
 }
 
 int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
@@ -2992,7 +1971,7 @@ int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, co
 // dasp_sos_grad_finalize for partial sums produced by dasp_sosfilt_backward_seg with `segments` segments per row
 int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
                                float* gout, void* stream) {
-    return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, 0, gout, false, stream);
+    return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, gout, stream);
 }
 
 // ---- one call per direction for functional.parametric_eq (functional.py:118-272) ------------------------------------------------------
@@ -3058,13 +2037,12 @@ int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, co
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream) {
     if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 1, stream);
-    // one table per item: the last (row, segment) workgroup of an item finalizes it inside the backward launch (DASP_SEG_FUSED_FINALIZE=0
-    // at build time keeps the separate launch); a shared table (Bp == 1 < B) always takes the separate launch
-    const bool fuse = DASP_SEG_FUSED_FINALIZE && partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
-    const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 1, fuse ? dtab : nullptr, mode,
+    // one table per item: the finalize step runs inside the Gram pass (gram_fused_tail); a shared table (Bp == 1 < B) takes the separate launch
+    const bool fuse = partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
+    const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, fuse ? dtab : nullptr, mode,
                                              fuse ? gout : nullptr, stream);
     if (rc != DASP_OK || !partials || fuse) return rc;
-    return grad_finalize_impl(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, 1, gout, false, stream);
+    return grad_finalize_impl(dtab, Bp, partials, B, C, S, (int)dasp_sos_segments(N, Tseg), mode, gout, stream);
 }
 
 // ---- signal.biquad (dasp_pytorch/signal.py:242-306) ------------------------------------------------------------------------------

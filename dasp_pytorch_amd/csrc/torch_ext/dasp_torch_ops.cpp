@@ -21,7 +21,6 @@
 #include <torch/csrc/autograd/autograd_not_implemented_fallback.h>
 #include <torch/library.h>
 
-#include <cstdlib>
 #include <vector>
 
 #include "dasp_hip.h"
@@ -44,6 +43,21 @@ void same_device(const Tensor& a, const Tensor& b, const char* name) {
     TORCH_CHECK(a.device() == b.device(), "dasp: `", name, "` is on ", b.device(), " but x is on ", a.device());
 }
 Tensor f32c(const Tensor& t) { return t.to(at::kFloat).contiguous(); }
+// For the autograd functions (which run ABOVE the Python dispatch key, where a composite op that hands its input back unchanged - reshape of
+// a flat tensor, to() of the right dtype - is seen as "an operator returning its input" by torch.library.opcheck's schema test): numel
+// through the symbolic interface (AOT tracing with dynamic shapes), and a flat float32 view / copy that only calls what changes something.
+int64_t nel(const Tensor& t) { return t.sym_numel().guard_int(__FILE__, __LINE__); }
+// a gradient row in the shape and dtype of the control tensor it belongs to
+Tensor like_control(const Tensor& g, const Tensor& c) {
+    Tensor r = g.reshape_as(c);
+    return r.scalar_type() == c.scalar_type() ? r : r.to(c.scalar_type());
+}
+Tensor flat32(const Tensor& c) {
+    Tensor t = c;
+    if (t.dim() != 1) t = t.reshape({-1});
+    if (t.scalar_type() != at::kFloat) t = t.to(at::kFloat);
+    return t;
+}
 float* fp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
 double* dp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<double>() : nullptr; }
 long round64(long n) { return (n + 63) & ~63L; }
@@ -60,11 +74,13 @@ Tensor empty_f32(long n, const Tensor& like) { return at::empty({n}, like.option
 // ---- parametric EQ on the normalised (Bp, 3 S) tensor (ops.ParametricEQNormFunction; dasp_peq_forward_norm / dasp_peq_backward) ---------
 // tseg: tiles per segment of the segmented-row kernels, 0 = one workgroup per row. Decided ONCE per op call (planner, or the developer
 // overrides DASP_SOS_SEGMENT / DASP_SOS_SEGMENT_TILES) by the autograd function and handed to both directions.
+// The planner's proposal, or the developer override dasp_pytorch_amd._torch_ops pushes in (dasp::_plan_override: -1 = the planner, 0 = never
+// segment, > 0 = that many tiles per segment; the Python layer reads DASP_SOS_SEGMENT / DASP_SOS_SEGMENT_TILES / DASP_DYN_SEGMENT / _TILES -
+// this file reads no environment).
+int64_t g_sos_tiles_override = -1, g_dyn_tiles_override = -1;
+void plan_override(int64_t sos_tiles, int64_t dyn_tiles) { g_sos_tiles_override = sos_tiles; g_dyn_tiles_override = dyn_tiles; }
 int64_t sos_segment_tiles(int64_t rows, int64_t N) {
-    const char* e = std::getenv("DASP_SOS_SEGMENT");
-    if (e && e[0] == '0' && e[1] == 0) return 0;
-    if (const char* f = std::getenv("DASP_SOS_SEGMENT_TILES")) { const long v = std::atol(f); if (v > 0) return v; }
-    return dasp_sos_segment_tiles(rows, N);
+    return g_sos_tiles_override >= 0 ? g_sos_tiles_override : dasp_sos_segment_tiles(rows, N);
 }
 struct PeqDims { int64_t B, C, N, Bp, S; };
 PeqDims peq_check(const Tensor& x, const Tensor& pn, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
@@ -186,10 +202,7 @@ Tensor peq_norm_autograd(const Tensor& x, const Tensor& pn, double sample_rate, 
 
 // ---- compressor / expander on (bs, 5) control rows (ops.DynamicsCtlFunction; dasp_dynamics_forward(_seg) / _backward(_seg)) -------------
 int64_t dyn_segment_tiles(int64_t B, int64_t N) {
-    const char* e = std::getenv("DASP_DYN_SEGMENT");
-    if (e && e[0] == '0' && e[1] == 0) return 0;
-    if (const char* f = std::getenv("DASP_DYN_SEGMENT_TILES")) { const long v = std::atol(f); if (v > 0) return v; }
-    return dasp_dyn_segment_tiles(B, N);
+    return g_dyn_tiles_override >= 0 ? g_dyn_tiles_override : dasp_dyn_segment_tiles(B, N);
 }
 void dyn_check(const Tensor& x, const Tensor& ctl, int64_t mode, int64_t lookahead) {
     need_device(x, "x");
@@ -529,10 +542,10 @@ PeqRows peq_rows_check(const Tensor& x, at::TensorList controls, at::IntArrayRef
     const int64_t S = (int64_t)types.size();
     TORCH_CHECK(dasp_sos_supported_sections((int)S), "no kernel compiled for ", S, " sections");
     TORCH_CHECK((int64_t)controls.size() == 3 * S, "dasp::parametric_eq: ", 3 * S, " control tensors for ", S, " sections, got ", controls.size());
-    const int64_t Bp = controls[0].numel();
+    const int64_t Bp = nel(controls[0]);
     for (const Tensor& c : controls) {
         same_device(x, c, "control");
-        TORCH_CHECK(c.numel() == Bp && (Bp == 1 || Bp == x.size(0)), "parametric_eq controls must each hold ", x.size(0), " (or 1) values, got ", c.numel());
+        TORCH_CHECK(nel(c) == Bp && (Bp == 1 || Bp == x.size(0)), "parametric_eq controls must each hold ", x.size(0), " (or 1) values, got ", nel(c));
     }
     for (int64_t t : types) TORCH_CHECK(t >= 0 && t <= 4, "dasp::parametric_eq: filter type ", t, " (0 peaking, 1 low_shelf, 2 high_shelf, 3 low_pass, 4 high_pass)");
     return PeqRows{x.size(0), x.size(1), x.size(2), Bp, S};
@@ -583,15 +596,10 @@ struct PeqFn : public torch::autograd::Function<PeqFn> {
                              .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, at::TensorList, double, at::IntArrayRef, int64_t, bool)>();
         auto [y, w32, w64] = op.call(x, controls, sample_rate, types, tseg, need);
         if (need) {
-            ctx->save_for_backward({x, w32, w64});
+            variable_list keep = {x, w32, w64};
+            for (const Tensor& c : controls) keep.push_back(c);       // (a few values each: their gradients go back in their shape and dtype)
+            ctx->save_for_backward(keep);
             ctx->saved_data["Bp"] = d.Bp; ctx->saved_data["S"] = d.S; ctx->saved_data["tseg"] = tseg;
-            std::vector<int64_t> dt, shapes;          // dtype and shape of every control: its gradient goes back in both
-            for (const Tensor& c : controls) {
-                dt.push_back((int64_t)c.scalar_type());
-                shapes.push_back(c.dim());
-                for (int64_t v : c.sizes()) shapes.push_back(v);
-            }
-            ctx->saved_data["dt"] = dt; ctx->saved_data["shapes"] = shapes;
         }
         return y;
     }
@@ -608,14 +616,8 @@ struct PeqFn : public torch::autograd::Function<PeqFn> {
         variable_list out(2 + nc + 1);
         if (need_gx) out[0] = gx;
         if (need_gc) {
-            const auto dt = ctx->saved_data["dt"].toIntVector(), shapes = ctx->saved_data["shapes"].toIntVector();
-            size_t pos = 0;
-            for (int64_t i = 0; i < nc; ++i) {
-                const int64_t nd = shapes[pos++];
-                std::vector<int64_t> shp(shapes.begin() + pos, shapes.begin() + pos + nd);
-                pos += nd;
-                if (ctx->needs_input_grad(1 + i)) out[2 + i] = gc.select(0, i).reshape(shp).to((at::ScalarType)dt[i]);
-            }
+            for (int64_t i = 0; i < nc; ++i)
+                if (ctx->needs_input_grad(1 + i)) out[2 + i] = like_control(gc.select(0, i), saved[3 + i]);
         }
         return out;
     }
@@ -636,29 +638,21 @@ struct Dyn6Fn : public torch::autograd::Function<Dyn6Fn> {
         for (const Tensor* c : six) {
             same_device(x, *c, "control");
             // the reference's .view(-1, 1, 1) against a (bs, 1, seq_len) side chain: no parameter broadcasting (functional.py:330-336)
-            TORCH_CHECK(x.dim() == 3 && c->numel() == x.size(0), "The size of tensor a (", c->numel(), ") must match the size of tensor b (", x.dim() ? x.size(0) : 0,
+            TORCH_CHECK(x.dim() == 3 && nel(*c) == x.size(0), "The size of tensor a (", nel(*c), ") must match the size of tensor b (", x.dim() ? x.size(0) : 0,
                         ") at non-singleton dimension 0");
             need = need || c->requires_grad();
         }
         at::AutoDispatchBelowADInplaceOrView below;
-        const Tensor ctl = at::stack({threshold_db.reshape({-1}).to(at::kFloat), ratio.reshape({-1}).to(at::kFloat), attack_ms.reshape({-1}).to(at::kFloat),
-                                      knee_db.reshape({-1}).to(at::kFloat), makeup_gain_db.reshape({-1}).to(at::kFloat)}, 1);
+        const Tensor ctl = at::stack({flat32(threshold_db), flat32(ratio), flat32(attack_ms), flat32(knee_db), flat32(makeup_gain_db)}, 1);
         dyn_check(x, ctl, mode, lookahead);
         const int64_t tseg = dyn_segment_tiles(x.size(0), x.size(2));
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_forward", "")
                              .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, int64_t, double, double, int64_t, int64_t, bool)>();
         auto [y, carries, lin] = op.call(x, ctl, mode, sample_rate, eps, lookahead, tseg, need);
         if (need) {
-            ctx->save_for_backward({x, ctl, carries, lin});
+            ctx->save_for_backward({x, ctl, carries, lin, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db});
             ctx->saved_data["mode"] = mode; ctx->saved_data["sr"] = sample_rate; ctx->saved_data["eps"] = eps;
             ctx->saved_data["look"] = lookahead; ctx->saved_data["tseg"] = tseg;
-            std::vector<int64_t> dt, shapes;
-            for (const Tensor* c : six) {
-                dt.push_back((int64_t)c->scalar_type());
-                shapes.push_back(c->dim());
-                for (int64_t v : c->sizes()) shapes.push_back(v);
-            }
-            ctx->saved_data["dt"] = dt; ctx->saved_data["shapes"] = shapes;
         }
         return y;
     }
@@ -670,19 +664,13 @@ struct Dyn6Fn : public torch::autograd::Function<Dyn6Fn> {
         auto [gx, gctl] = op.call(s[0], s[1], grads[0], s[2], s[3], ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
                                   ctx->saved_data["eps"].toDouble(), ctx->saved_data["look"].toInt(), ctx->saved_data["tseg"].toInt());
         const Tensor rows = gctl.t().contiguous();             // (5, bs): threshold, ratio, attack, knee, make-up - one contiguous row each
-        const auto dt = ctx->saved_data["dt"].toIntVector(), shapes = ctx->saved_data["shapes"].toIntVector();
         // forward arguments: x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead, mode
         variable_list out(11);
         if (ctx->needs_input_grad(0)) out[0] = gx;
         static const int row_of[6] = {0, 1, 2, -1, 3, 4};
-        size_t pos = 0;
         for (int i = 0; i < 6; ++i) {
-            const int64_t nd = shapes[pos++];
-            std::vector<int64_t> shp(shapes.begin() + pos, shapes.begin() + pos + nd);
-            pos += nd;
             if (!ctx->needs_input_grad(1 + i)) continue;
-            out[2 + i] = row_of[i] < 0 ? at::zeros(shp, gctl.options().dtype((at::ScalarType)dt[i]))
-                                       : rows.select(0, row_of[i]).reshape(shp).to((at::ScalarType)dt[i]);
+            out[2 + i] = row_of[i] < 0 ? at::zeros_like(s[4 + i]) : like_control(rows.select(0, row_of[i]), s[4 + i]);
         }
         return out;
     }
@@ -693,8 +681,7 @@ Tensor dyn6_device(const Tensor& x, double sample_rate, const Tensor& threshold_
     for (const Tensor* c : {&threshold_db, &ratio, &attack_ms, &release_ms, &knee_db, &makeup_gain_db})
         TORCH_CHECK(x.dim() == 3 && c->numel() == x.size(0), "The size of tensor a (", c->numel(), ") must match the size of tensor b (", x.dim() ? x.size(0) : 0,
                     ") at non-singleton dimension 0");
-    const Tensor ctl = at::stack({threshold_db.reshape({-1}).to(at::kFloat), ratio.reshape({-1}).to(at::kFloat), attack_ms.reshape({-1}).to(at::kFloat),
-                                  knee_db.reshape({-1}).to(at::kFloat), makeup_gain_db.reshape({-1}).to(at::kFloat)}, 1);
+    const Tensor ctl = at::stack({flat32(threshold_db), flat32(ratio), flat32(attack_ms), flat32(knee_db), flat32(makeup_gain_db)}, 1);
     return dyn_device(x, ctl, mode, sample_rate, eps, lookahead);
 }
 Tensor dyn6_autograd(const Tensor& x, double sample_rate, const Tensor& threshold_db, const Tensor& ratio, const Tensor& attack_ms, const Tensor& release_ms,
@@ -711,9 +698,9 @@ void ew_check(const Tensor& x, const Tensor& ctl, int64_t op) {
     TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kFloat, "dasp::", op == 0 ? "gain" : "distortion", ": x must be float32 (bs, chs, seq_len), got ", x.scalar_type(), " ", x.sizes());
     const int64_t want = op == 0 ? x.size(0) : x.size(0) * x.size(1);
     if (op == 0) {
-        TORCH_CHECK(ctl.numel() == want, "shape '[", x.size(0), ", 1, 1]' is invalid for input of size ", ctl.numel());
+        TORCH_CHECK(nel(ctl) == want, "shape '[", x.size(0), ", 1, 1]' is invalid for input of size ", nel(ctl));
     } else {
-        TORCH_CHECK(ctl.numel() == want, "shape '[", x.size(0), ", ", x.size(1), ", -1]' is invalid for input of size ", ctl.numel());
+        TORCH_CHECK(nel(ctl) == want, "shape '[", x.size(0), ", ", x.size(1), ", -1]' is invalid for input of size ", nel(ctl));
     }
 }
 Tensor ew_forward(const Tensor& x, const Tensor& ctl, int64_t op) {
@@ -899,33 +886,32 @@ struct NsrFn : public torch::autograd::Function<NsrFn> {
                     "noise_shaped_reverberation: `noise` and the filters are not differentiable inputs (detach them)");
         bool need = x.requires_grad() || mix.requires_grad();
         std::vector<Tensor> gv, dv;
-        std::vector<int64_t> dt, shapes;
+        variable_list ctls;
         auto note = [&](const Tensor& c) {
             same_device(x, c, "control");
             // the reference's torch.stack(...).view(bs, 12) / mix.view(bs, 1, 1) (functional.py:498-544): no broadcasting
-            TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel());
+            TORCH_CHECK(nel(c) == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * nel(c));
             need = need || c.requires_grad();
-            dt.push_back((int64_t)c.scalar_type());
-            shapes.push_back(c.dim());
-            for (int64_t v : c.sizes()) shapes.push_back(v);
+            ctls.push_back(c);
         };
         for (const Tensor& c : band_gains) note(c);
         for (const Tensor& c : band_decays) note(c);
         note(mix);
         at::AutoDispatchBelowADInplaceOrView below;
-        for (const Tensor& c : band_gains) gv.push_back(c.reshape({-1}).to(at::kFloat));
-        for (const Tensor& c : band_decays) dv.push_back(c.reshape({-1}).to(at::kFloat));
-        const Tensor gains = at::stack(gv, 1), decays = at::stack(dv, 1), m32 = mix.reshape({-1}).to(at::kFloat);
+        for (const Tensor& c : band_gains) gv.push_back(flat32(c));
+        for (const Tensor& c : band_decays) dv.push_back(flat32(c));
+        const Tensor gains = at::stack(gv, 1), decays = at::stack(dv, 1), m32 = flat32(mix);
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_reverb_forward", "")
                              .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const c10::optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&,
                                                                                const Tensor&, int64_t, int64_t, int64_t, int64_t, const c10::optional<Tensor>&, double, bool)>();
         auto [y, A, H, ir] = op.call(x, noise, fspec, gains, decays, m32, L, taps, nb, seed, seed_offset, decay_bound, need);
         if (need) {
             const bool has_noise = noise.has_value() && noise->defined(), has_off = seed_offset.has_value() && seed_offset->defined();
-            ctx->save_for_backward({ir, A, H, fspec, gains, decays, m32, has_noise ? *noise : Tensor(), has_off ? *seed_offset : Tensor()});
+            variable_list keep = {ir, A, H, fspec, gains, decays, m32, has_noise ? *noise : Tensor(), has_off ? *seed_offset : Tensor()};
+            keep.insert(keep.end(), ctls.begin(), ctls.end());       // (a few values each: their gradients go back in their shape and dtype)
+            ctx->save_for_backward(keep);
             ctx->saved_data["Cx"] = x.size(1); ctx->saved_data["L"] = L; ctx->saved_data["taps"] = taps; ctx->saved_data["nb"] = nb; ctx->saved_data["seed"] = seed;
             ctx->saved_data["bound"] = decay_bound; ctx->saved_data["has_noise"] = has_noise;
-            ctx->saved_data["dt"] = dt; ctx->saved_data["shapes"] = shapes;
         }
         return y;
     }
@@ -941,19 +927,14 @@ struct NsrFn : public torch::autograd::Function<NsrFn> {
         auto [gx, gg, gd, gm] = op.call(grads[0], s[0], s[1], s[2], noise, s[3], s[4], s[5], s[6], ctx->saved_data["Cx"].toInt(), ctx->saved_data["L"].toInt(),
                                         ctx->saved_data["taps"].toInt(), nb, ctx->saved_data["seed"].toInt(), off, ctx->saved_data["bound"].toDouble());
         const Tensor ggr = gg.t().contiguous(), gdr = gd.t().contiguous();       // (bands, bs): one contiguous row per control tensor
-        const auto dt = ctx->saved_data["dt"].toIntVector(), shapes = ctx->saved_data["shapes"].toIntVector();
         // forward arguments: x, the band gains, the band decays, mix, [noise], fspec, num_samples, taps, seed, [seed_offset], decay_bound.
         // needs_input_grad counts the tensor arguments that were passed: x, 2 bands controls, mix, ...
         variable_list out(1 + 2 * nb + 1 + 7);
         if (ctx->needs_input_grad(0)) out[0] = gx;
-        size_t pos = 0;
         for (int64_t i = 0; i < 2 * nb + 1; ++i) {
-            const int64_t nd = shapes[pos++];
-            std::vector<int64_t> shp(shapes.begin() + pos, shapes.begin() + pos + nd);
-            pos += nd;
             if (!ctx->needs_input_grad(1 + i)) continue;
             const Tensor g = i < nb ? ggr.select(0, i) : (i < 2 * nb ? gdr.select(0, i - nb) : gm);
-            out[1 + i] = g.reshape(shp).to((at::ScalarType)dt[i]);
+            out[1 + i] = like_control(g, s[9 + i]);
         }
         return out;
     }
@@ -964,10 +945,10 @@ Tensor nsr_device(const Tensor& x, at::TensorList band_gains, at::TensorList ban
     const int64_t nb = (int64_t)band_gains.size(), B = x.dim() ? x.size(0) : 0;
     TORCH_CHECK(nb >= 1 && (int64_t)band_decays.size() == nb, "dasp::noise_shaped_reverb: as many band decays as band gains");
     std::vector<Tensor> gv, dv;
-    for (const Tensor& c : band_gains) { TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel()); gv.push_back(c.reshape({-1}).to(at::kFloat)); }
-    for (const Tensor& c : band_decays) { TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel()); dv.push_back(c.reshape({-1}).to(at::kFloat)); }
+    for (const Tensor& c : band_gains) { TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel()); gv.push_back(flat32(c)); }
+    for (const Tensor& c : band_decays) { TORCH_CHECK(c.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * c.numel()); dv.push_back(flat32(c)); }
     TORCH_CHECK(mix.numel() == B, "shape '[", B, ", ", nb, "]' is invalid for input of size ", nb * mix.numel());
-    return reverb_device(x, noise, fspec, at::stack(gv, 1), at::stack(dv, 1), mix.reshape({-1}).to(at::kFloat), L, taps, nb, seed, seed_offset, decay_bound);
+    return reverb_device(x, noise, fspec, at::stack(gv, 1), at::stack(dv, 1), flat32(mix), L, taps, nb, seed, seed_offset, decay_bound);
 }
 Tensor nsr_autograd(const Tensor& x, at::TensorList band_gains, at::TensorList band_decays, const Tensor& mix, const c10::optional<Tensor>& noise, const Tensor& fspec, int64_t L,
                     int64_t taps, int64_t seed, const c10::optional<Tensor>& seed_offset, double decay_bound) {
@@ -1019,6 +1000,7 @@ TORCH_LIBRARY(dasp, m) {
     m.def("_reverb_backward(Tensor grad_y, Tensor ir, Tensor A, Tensor H, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int Cx, int num_samples, "
           "int taps, int bands, int seed, Tensor? seed_offset, float decay_bound) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("_abi_hash() -> int", &abi_hash);
+    m.def("_plan_override(int sos_tiles, int dyn_tiles) -> ()", &plan_override);
 }
 // ROCm devices carry the CUDA dispatch key in PyTorch-ROCm builds
 TORCH_LIBRARY_IMPL(dasp, CUDA, m) {

@@ -271,6 +271,13 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
  * x, y, gy, gx: (B, 2, N) fp32.  noise: (2B, nb, L + taps - 1).  gains, decays: (B, nb).  mix: (B).
  * nb <= 16 bands, L = IR length, taps = FIR length.  All buffer sizes come from dasp_reverb_sizes.
  * ------------------------------------------------------------------------------------------- */
+/* Plan overrides of the reverb - explicit arguments for the three choices its planner makes (rounds 2 - 4 read them from the environment;
+ * a library should not): chunk = signals per pass of the long-convolution pipeline (<= 0: all at once, the default), weight_limit = largest
+ * |rho| * 4096 served with the envelope inside the filter bank's transform (0: every item the per-band way; < 0: the default),
+ * band_split = workgroups per (item, window) of the filter bank (< 1: the planner's rule). Process-wide: set before dasp_reverb_sizes and
+ * the calls that use its numbers, set back to (-1, -1, -1) afterwards. Developer A/Bs and the tests of the alternative routes. */
+int dasp_reverb_plan(long chunk, float weight_limit, int band_split);
+
 /* sizes[0] = block length Lb, [1] = transform length n1, [2] = pairs of blocks per signal, [3] = blocks per signal,
  * [4] = complex (2 x fp32) elements of Fspec, [5] = filter-bank windows per batch item,
  * [6] = complex elements of A (2B * pairs * n1), [7] = complex elements of H (B * n1: the two impulse responses of an item are one complex

@@ -55,8 +55,9 @@ def test_segment_planning():
         assert t >= 8 and t & (t - 1) == 0 and g == -(-128 // t) and g > 1 and rows * g <= 1024
         assert L.dasp_sos_seg_floats(rows, N, 6, t) == 2 * rows * g * 12
     assert L.dasp_sos_segments(N + 1, 8) == 17 and L.dasp_sos_segments(N, 0) == 1                # ragged last segment; 0 = not segmented
-    # per item: the two segment transition matrices + the basis responses of the Gram finalize step (28 columns x (6 x 18 + 2 x 6 x 16) rows)
-    assert L.dasp_sos_segtab_doubles(6) == 2 * 12 * 12 + 28 * (6 * 18 + 2 * 6 * 16)
+    # per item: the two segment transition matrices + the basis responses of the Gram finalize step (28 columns: 7 blocks of 16 signal rows
+    # for the matrix-core products + 2 x 6 x 16 adjoint rows)
+    assert L.dasp_sos_segtab_doubles(6) == 2 * 12 * 12 + 28 * (7 * 16 + 2 * 6 * 16)
     assert L.dasp_sos_partial_floats(4 * L.dasp_sos_segments(N, 8), 6) == 16 * L.dasp_sos_partial_floats(4, 6)
 
 

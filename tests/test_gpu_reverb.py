@@ -10,6 +10,22 @@ from tests.test_oracle_cpu import _reverb_noise
 from tests.util import linf_peak, load_golden, record
 
 pytestmark = pytest.mark.gpu
+
+
+class reverb_plan:
+    """dasp_reverb_plan(chunk, weight_limit, band_split) for the duration of a block (-1 = the planner's own choice): the explicit C-ABI
+    arguments that replaced rounds 2 - 4's DASP_REVERB_* environment switches."""
+
+    def __init__(self, chunk=-1, weight_limit=-1.0, band_split=-1):
+        self.args = (chunk, weight_limit, band_split)
+
+    def __enter__(self):
+        from dasp_pytorch_amd import _lib
+        assert _lib.lib().dasp_reverb_plan(*self.args) == 0
+
+    def __exit__(self, *exc):
+        from dasp_pytorch_amd import _lib
+        _lib.lib().dasp_reverb_plan(-1, -1.0, -1)
 SR = 44100
 CTL_TOL = 1e-4      # the 25 control gradients, of the largest entry: the north_star bar (measured 3e-9 .. 1.9e-6, profiles/r03/parity_measured.jsonl)
 
@@ -160,11 +176,11 @@ def test_band_split_filter_bank_equals_one_workgroup_per_window(D, monkeypatch):
     w = rng.standard_normal((B, 2, N)).astype(np.float32)
     p = rng.random((B, 25)).astype(np.float32)
     noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
-    monkeypatch.setenv("DASP_REVERB_BAND_SPLIT", "1")
-    y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
-    for split in ("4", "12"):
-        monkeypatch.setenv("DASP_REVERB_BAND_SPLIT", split)
-        y2, gx2, gp2 = run(D, x, p, w, noise, L, taps)
+    with reverb_plan(band_split=1):
+        y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
+    for split in (4, 12):
+        with reverb_plan(band_split=split):
+            y2, gx2, gp2 = run(D, x, p, w, noise, L, taps)
         assert np.abs(y2 - y1).max() <= 2e-6 * np.abs(y1).max() and np.abs(gx2 - gx1).max() <= 2e-6 * np.abs(gx1).max()
         assert np.abs(gp2 - gp1).max() <= 1e-5 * np.abs(gp1).max()
 
@@ -182,11 +198,10 @@ def test_envelope_inside_the_transform_equals_per_band_route(D, monkeypatch):
     p[0, 12:24] *= 0.5
     p[1, 12:24] *= 0.5; p[1, 17] = 0.95
     noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
-    monkeypatch.setenv("DASP_REVERB_BAND_SPLIT", "1")            # no float atomics: an item that keeps its route is bit-identical
-    y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
-    monkeypatch.setenv("DASP_REVERB_WEIGHT_LIMIT", "0")
-    y0, gx0, gp0 = run(D, x, p, w, noise, L, taps)
-    monkeypatch.delenv("DASP_REVERB_WEIGHT_LIMIT")
+    with reverb_plan(band_split=1):                              # no float atomics: an item that keeps its route is bit-identical
+        y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
+    with reverb_plan(band_split=1, weight_limit=0.0):            # every item the per-band way
+        y0, gx0, gp0 = run(D, x, p, w, noise, L, taps)
     pd = p.astype(np.float64)
     yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
     gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, w, L, taps)
@@ -251,7 +266,7 @@ def test_generated_noise_equals_the_explicit_noise_path(D):
 
 @pytest.mark.parametrize("C", [2, 1])
 def test_chunked_passes_equal_one_pass(D, monkeypatch, C):
-    """DASP_REVERB_CHUNK (a developer switch kept for the measurement in DESIGN 3.3): the long-convolution pipeline run in passes over 2 and
+    """dasp_reverb_plan(chunk = ..) (a developer argument kept for the measurement in DESIGN 3.3): the long-convolution pipeline run in passes over 2 and
     4 signals with chunk-sized scratch buffers - every per-chunk pointer offset (A per item for mono input, the items' paired spectra, the
     mix partial sums) - gives what the single pass gives, and that is held to the oracle."""
     B, N, L, taps = 5, 30000, 9000, 255
@@ -265,65 +280,10 @@ def test_chunked_passes_equal_one_pass(D, monkeypatch, C):
     yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
     assert np.abs(y0 - yo).max() < 3e-5 * np.abs(yo).max()
     for chunk in (2, 4):
-        monkeypatch.setenv("DASP_REVERB_CHUNK", str(chunk))
-        y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
-        monkeypatch.delenv("DASP_REVERB_CHUNK")
+        with reverb_plan(chunk=chunk):
+            y1, gx1, gp1 = run(D, x, p, w, noise, L, taps)
         assert np.abs(y1 - y0).max() <= 1e-6 * np.abs(y0).max()
         assert np.abs(gx1 - gx0).max() <= 1e-6 * np.abs(gx0).max()
         assert np.abs(gp1 - gp0).max() <= 2e-6 * np.abs(gp0).max()
 
 
-@pytest.mark.parametrize("B,C,N,L", [(2, 2, 61000, 8000), (1, 1, 110000, 8192), (2, 2, 262144, 65536), (1, 2, 30000, 8192)])
-def test_r3_frames_equal_radix2_frames(D, monkeypatch, B, C, N, L):
-    """The long convolution on frames of 3 x 2^k points (blocks of two thirds of a frame, radix-3 step around the column transforms; round 4)
-    against the same call on the 2^k frames, which are the plan (R3 frames measured slower, csrc/reverb.hip rv_dims; DASP_REVERB_RADIX3=1
-    takes them): one pair of blocks, several pairs with the overlap carried across them, an odd block count, mono input, BASELINE
-    config 4's ratio N = 4 L. y, grad x and the 25 control gradients agree to the rounding of two different transform lengths."""
-    taps = 127
-    rng = np.random.default_rng(N + L + C)
-    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
-    w = rng.standard_normal((B, 2, N)).astype(np.float32)
-    p = rng.random((B, 25)).astype(np.float32)
-    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
-    outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("DASP_REVERB_RADIX3", flag)
-        outs.append(run(D, x, p, w, noise, L, taps))
-    (y3, gx3, gp3), (y2, gx2, gp2) = outs
-    e = {"y": np.abs(y3 - y2).max() / np.abs(y2).max(), "gx": np.abs(gx3 - gx2).max() / np.abs(gx2).max(), "gctl": np.abs(gp3 - gp2).max() / np.abs(gp2).max()}
-    record(f"reverb_r3_vs_radix2[{B},{C},{N},{L}]", **e)
-    assert e["y"] < 5e-6 and e["gx"] < 5e-6 and e["gctl"] < 2e-5, e
-    from dasp_pytorch_amd import _lib
-    import ctypes
-    sizes = (ctypes.c_long * 14)()
-    monkeypatch.delenv("DASP_REVERB_RADIX3")
-    assert _lib.lib().dasp_reverb_sizes(128, 262144, 65536, 1023, 12, sizes) == 0
-    assert (sizes[0], sizes[1], sizes[2]) == (65536, 131072, 2)           # BASELINE config 4, the plan: two pairs of blocks in 2^17-point frames
-    monkeypatch.setenv("DASP_REVERB_RADIX3", "1")
-    assert _lib.lib().dasp_reverb_sizes(128, 262144, 65536, 1023, 12, sizes) == 0
-    assert (sizes[0], sizes[1], sizes[2]) == (131072, 196608, 1)          # on request: ONE 3 x 2^16-point frame per signal
-
-
-@pytest.mark.parametrize("B,C,N,L,taps", [(1, 2, 61000, 8000, 63), (2, 1, 110000, 8192, 127), (1, 2, 32768, 8192, 31), (1, 2, 300000, 100000, 63), (2, 2, 262144, 65536, 1023)])
-def test_r3_frames_vs_oracle(D, monkeypatch, B, C, N, L, taps):
-    """Frames of 3 x 2^k points (DASP_REVERB_RADIX3=1: a non-power-of-two transform length, NAp = 16 ... 256 column sub-transforms) straight
-    against the oracle - y, grad x and the 25 control gradients at the bounds of test_reverb_shapes_vs_oracle - on two pairs of blocks, an
-    odd block count with mono input, N = 4 Lp exactly, a 2^17-sample block, and BASELINE config 4's sizes at a small batch."""
-    monkeypatch.setenv("DASP_REVERB_RADIX3", "1")
-    rng = np.random.default_rng(N + L + 3)
-    x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32)
-    w = rng.standard_normal((B, 2, N)).astype(np.float32)
-    p = rng.random((B, 25)).astype(np.float32)
-    noise = rng.standard_normal((2 * B, 12, L + taps - 1)).astype(np.float32)
-    from dasp_pytorch_amd import _lib
-    import ctypes
-    sizes = (ctypes.c_long * 14)()
-    assert _lib.lib().dasp_reverb_sizes(B, N, L, taps, 12, sizes) == 0 and sizes[1] % 3 == 0 and (sizes[1] // 3) & (sizes[1] // 3 - 1) == 0
-    y, gx, gp = run(D, x, p, w, noise, L, taps)
-    pd = p.astype(np.float64)
-    yo = orc.noise_shaped_reverberation(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, L, taps)
-    gxo, gg, gd, gm = orc.noise_shaped_reverberation_vjp(x, SR, pd[:, :12], pd[:, 12:24], pd[:, 24], noise, w, L, taps)
-    gpo = np.concatenate([gg, gd, gm[:, None]], 1)
-    e = {"y": np.abs(y - yo).max() / max(np.abs(yo).max(), 1e-6), "gx": np.abs(gx - gxo).max() / max(np.abs(gxo).max(), 1e-6), "gctl": np.abs(gp - gpo).max() / np.abs(gpo).max()}
-    record(f"reverb_r3_vs_oracle[{B},{C},{N},{L},{taps}]", **e)
-    assert e["y"] < 3e-5 and e["gx"] < 3e-5 and e["gctl"] < CTL_TOL, e
