@@ -40,10 +40,26 @@ template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
 // before the counter moves - measured 2.6 - 8.4 us for the 8 - 16 MB of input gradients of a segmented EQ backward pass
 // (profiles/r05/seg_tail_trace.log) - and finds nothing to write back when the output went through. (Inline asm: there is no builtin for
 // a 16-byte agent-scope store; vmcnt counts it like any store.)
+#ifndef DASP_THROUGH
+#define DASP_THROUGH 1      // 0 (developer A/B): streaming stores that stay dirty in the L2 until the hand-off's release writes them back
+#endif
 __device__ __forceinline__ void st_through(f4* p, f4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+#if DASP_THROUGH
+    // s_nop: a store of more than 8 bytes reads its data registers a cycle after it issues, and a vector instruction that overwrites them
+    // in the very next slot corrupts the data (gfx9 "VMEM store data hazard", 1 wait state). The compiler inserts the wait for stores it
+    // knows; it does not look inside an asm statement (found by the segmented sosfilt test: 2- and 4-section kernels wrote garbage gx).
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
 }
-__device__ __forceinline__ void st_through(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_through(float* p, float v) {
+#if DASP_THROUGH
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
