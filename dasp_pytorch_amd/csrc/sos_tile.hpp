@@ -72,18 +72,19 @@ struct SosLayout {
     static constexpr int P64A = P64 + SYS;
     static constexpr int PWA = PW + SYS;
     static constexpr int DF = GT + 2 * SYS;          // [S][8]: b1, b2, -a1, -a2 (normalised), zc1, zc2, 1/om, sg/om: direct-form sections
-    static constexpr int MN = DF + 8 * S;            // [S][8]: b1/b0, b2/b0, g1/d, g2/d, q, q/om, q sg/om, 0 with q = 1 / (b0 of the sections before k): the
-                                                     //      backward kernel's recomputation of a designed cascade runs every section with feed-through 1
     static constexpr int YMC = L + 16;               // columns of the output map below: L input samples, then up to 16 start-state components
-    static constexpr int YM = MN + 8 * S;            // [L][YMC]: the chunk's L outputs as a linear map of (its L inputs, its 2S start-state
+    static constexpr int YM = DF + 8 * S;            // [L][YMC]: the chunk's L outputs as a linear map of (its L inputs, its 2S start-state
                                                      //      components): row n = (h[n], h[n-1], .., h[0], 0, .. | O[n][0..2S), 0, ..), h = impulse response
                                                      //      of the whole cascade, O = its zero-input response per unit state (forward kernel, MFMA output path)
     static constexpr int YMA = YM + L * YMC;         // [L][YMC]: the same for the adjoint cascade, natural sample order: row n = (0, .., h[0], h[1], .., h[L-1-n] |
                                                      //      OA[n][0..2S), 0, ..): the adjoint outputs (gx) of a chunk from its L adjoint inputs (gy) and
                                                      //      the 2S components of the adjoint state entering it from above (sos_bwd_gram_kernel)
-    static constexpr int CNT = YMA + L * YMC;        // [4]: word 0 = rows of this item whose backward partial sums are complete (int; zeroed by the
-                                                     //      prep kernel, reset by the workgroup that finalizes the item)
-    static constexpr int TOTAL = CNT + 4;
+    static constexpr int CNT = YMA + L * YMC;        // [8]: the item's counter words (ints; zeroed by the prep kernel, returned to zero by whoever completes a count):
+                                                     //      0 backward finalize (gram_fused_tail), 1 forward chain, 2 adjoint chain (chain_by_last_workgroup), 3 the
+                                                     //      fused forward chain's (chainfwd.hip); word TAG: the tag of this call's look-back words (sosfilt.hip
+                                                     //      lookback_publish), drawn by the prep kernel
+    static constexpr int TAG = CNT + 4;
+    static constexpr int TOTAL = CNT + 8;
 };
 // fp64 side table for the finalize kernel, per (item, section)
 // [DT_OM] om (1 for a direct-form section: its correlations are taken with w itself), [DT_B0..+4] b0 b1 b2 a1 a2 (normalised), [DT_A0] a0 as

@@ -154,6 +154,37 @@ constexpr double OM_MIN = 1e-5;
 #define DASP_STATES_CACHED 1   // the backward kernel reads the saved chunk states with the caches' normal policy (not streaming)
 #endif
 
+// Normalised coefficients (b0, b1, b2, a1, a2) of section k of `item` and their derivative w.r.t. control `dir` - from the normalised /
+// physical control tensors through the RBJ design, or from a row [b0 b1 b2 a0 a1 a2] as given (then a0 is returned and dc5 is zero).
+template <int S>
+__device__ __forceinline__ void section_coefs(const float* __restrict__ sos, const float* __restrict__ params, const PeqSpec& spec, int item, int k, int dir,
+                                              bool report_range, double (&c5)[5], double (&dc5)[5], double& a0) {
+    a0 = 1.0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) dc5[c] = 0.0;
+    if (params && spec.norm) {
+        const float* p = params + ((size_t)item * S + k) * 3;
+        double v[3];
+        for (int c = 0; c < 3; ++c) {
+            const double pc = (double)p[c];
+            if (report_range && spec.flag && (pc < 0.0 || pc > 1.0) && dir == 0) atomicOr(spec.flag, 1u << (3 * k + c));   // (NaN passes, as in the reference)
+            v[c] = spec.lo[3 * k + c] + spec.span[3 * k + c] * pc;
+        }
+        rbj_design(spec.types[k], spec.sample_rate, v[0], v[1], v[2], dir, c5, dc5);
+        for (int c = 0; c < 5; ++c) dc5[c] *= spec.span[3 * k + dir];          // d/d(normalised control)
+    } else if (params) {
+        const float* p = params + ((size_t)item * S + k) * 3;
+        rbj_design(spec.types[k], spec.sample_rate, (double)p[0], (double)p[1], (double)p[2], dir, c5, dc5);
+    } else if (!sos) {
+        rbj_design(spec.types[k], spec.sample_rate, (double)spec.rows[3 * k][item], (double)spec.rows[3 * k + 1][item],
+                   (double)spec.rows[3 * k + 2][item], dir, c5, dc5);
+    } else {
+        const float* sr = sos + ((size_t)item * S + k) * 6;
+        a0 = (double)sr[3];
+        c5[0] = sr[0] / a0; c5[1] = sr[1] / a0; c5[2] = sr[2] / a0; c5[3] = sr[4] / a0; c5[4] = sr[5] / a0;
+    }
+}
+
 // The per-chunk basis responses of an item's cascade (GramFin<S>, below: what the finalize step of the Gram-matrix backward multiplies the
 // Gram matrix with). They depend on the coefficients only, and their 96-step fp64 recurrences are half of that step's time - so for
 // segmented rows, whose finalize step is the tail of the backward launch, the design kernel computes them here, beside its own chains.
@@ -161,28 +192,46 @@ template <int S> struct GramFin;
 template <int S, bool AGENT> __device__ __forceinline__ void gram_basis_responses(const double* cf, double* bas, int tid);
 template <int S> __device__ __forceinline__ constexpr int basis_doubles();       // GramFin<S>::BASIS (defined with it)
 
-// 256 threads; 384 when `basis` is given: waves 4 and 5 then compute the basis responses (one thread per basis vector) while waves 0 - 3
-// run the chunk-table recursion, the squarings and the output maps.
+// One workgroup per item. With `basis` (segmented rows whose backward pass will follow) the grid is twice the items: workgroup nitems + i
+// designs item i's sections once more and computes its basis responses (one thread per basis vector) - beside the table workgroups, not
+// inside them: the 96-step fp64 recurrences are the longest chain of the launch, and as two more waves of the table workgroups (the first
+// version) they held those up at the barriers (design launch 14.3 -> 16.0 us at 16 items; the launch has 16 workgroups on 256 CUs).
 template <int S, int L>
-__global__ void __launch_bounds__(384)
+__global__ void __launch_bounds__(256)
 sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params, PeqSpec spec,
                 float* __restrict__ tab, double* __restrict__ dtab, int nsq_seg = 0, double* __restrict__ segtab = nullptr,
-                double* __restrict__ basis = nullptr) {
+                double* __restrict__ basis = nullptr, int nitems = 0) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, NN = S2 * S2;
     __shared__ double sec[S][10];       // sg, om, kom, g1, g2, d, kappa, b1, b2
-    __shared__ double cfb[S][8];        // b0 b1 b2 a1 a2 (normalised), sg, om, 1 / om: gram_fin_coefs' numbers, for the helper waves
-    if (threadIdx.x >= 256) {           // helper waves: the same barriers as everybody else, the basis responses between the second and the third
-        __syncthreads();
-        __syncthreads();
-        gram_basis_responses<S, false>(&cfb[0][0], basis + (size_t)blockIdx.x * basis_doubles<S>(), (int)threadIdx.x - 256);
-        __syncthreads();
-        if (segtab)
-            for (int step = 0; step < nsq_seg; ++step) __syncthreads();
-        return;
-    }
+    __shared__ double cfb[S][8];        // b0 b1 b2 a1 a2 (normalised), sg, om, 1 / om: gram_fin_coefs' numbers (basis workgroups)
     __shared__ double Phi[2][NN], T1[2][NN], T2[2][NN];
     __shared__ double vv[2][2][S2];
+    if (basis && (int)blockIdx.x >= nitems) {
+        const int it = blockIdx.x - nitems;
+#ifdef DASP_TRACE
+        if (it == 0 && threadIdx.x == 0) g_trace[48] = clock64();
+#endif
+        if (threadIdx.x < S) {
+            double c5[5], dc5[5], a0;
+            section_coefs<S>(sos, params, spec, it, threadIdx.x, 0, false, c5, dc5, a0);
+            const double sg = -0.5 * c5[3];
+            double om = sqrt(fabs(sg * sg - c5[4]));
+            om = om < OM_MIN ? OM_MIN : om;
+            for (int c = 0; c < 5; ++c) cfb[threadIdx.x][c] = c5[c];
+            cfb[threadIdx.x][5] = sg; cfb[threadIdx.x][6] = om; cfb[threadIdx.x][7] = 1.0 / om;
+        }
+        __syncthreads();
+#ifdef DASP_TRACE
+        if (it == 0 && threadIdx.x == 0) g_trace[49] = clock64();
+#endif
+        gram_basis_responses<S, false>(&cfb[0][0], basis + (size_t)it * basis_doubles<S>(), threadIdx.x);
+#ifdef DASP_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (it == 0 && threadIdx.x == 0) g_trace[50] = clock64();
+#endif
+        return;
+    }
     __shared__ float Gsh[2][L][S2];     // chunk-table columns v_m, written out after the recursion (no global stores inside it)
     __shared__ double Pd[S][7][2];
     __shared__ float hsh[L];            // impulse response of the cascade over one chunk (output map, LY::YM)
@@ -192,31 +241,15 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
     double* dt = dtab + (size_t)item * S * DT_STRIDE;
 
     if (tid < 4) tb[LY::CNT + tid] = 0.f;
+    if (tid == 4) {     // the tag of this call's look-back words (lookback_publish): odd, different for every launch and item
+        const unsigned tg = ((unsigned)wall_clock64() * 2654435761u) ^ ((unsigned)item * 0x9E3779B1u);
+        tb[LY::TAG] = __builtin_bit_cast(float, tg | 1u);
+    }
     for (int e = tid; e < 2 * L * LY::YMC; e += 256) tb[LY::YM + e] = 0.f;  // (the output maps' non-zero entries are written after the barrier below)
     if (tid < 3 * S) {   // thread = (section k, control dir): values + one Jacobian column each
         const int k = tid / 3, dir = tid % 3;
-        double c5[5], dc5[5] = {0, 0, 0, 0, 0}, a0 = 1.0;
-        if (params && spec.norm) {
-            const float* p = params + ((size_t)item * S + k) * 3;
-            double v[3];
-            for (int c = 0; c < 3; ++c) {
-                const double pc = (double)p[c];
-                if (spec.flag && (pc < 0.0 || pc > 1.0) && dir == 0) atomicOr(spec.flag, 1u << (3 * k + c));   // (NaN passes, as in the reference)
-                v[c] = spec.lo[3 * k + c] + spec.span[3 * k + c] * pc;
-            }
-            rbj_design(spec.types[k], spec.sample_rate, v[0], v[1], v[2], dir, c5, dc5);
-            for (int c = 0; c < 5; ++c) dc5[c] *= spec.span[3 * k + dir];          // d/d(normalised control)
-        } else if (params) {
-            const float* p = params + ((size_t)item * S + k) * 3;
-            rbj_design(spec.types[k], spec.sample_rate, (double)p[0], (double)p[1], (double)p[2], dir, c5, dc5);
-        } else if (!sos) {
-            rbj_design(spec.types[k], spec.sample_rate, (double)spec.rows[3 * k][item], (double)spec.rows[3 * k + 1][item],
-                       (double)spec.rows[3 * k + 2][item], dir, c5, dc5);
-        } else {
-            const float* s = sos + ((size_t)item * S + k) * 6;
-            a0 = (double)s[3];
-            c5[0] = s[0] / a0; c5[1] = s[1] / a0; c5[2] = s[2] / a0; c5[3] = s[4] / a0; c5[4] = s[5] / a0;
-        }
+        double c5[5], dc5[5], a0;
+        section_coefs<S>(sos, params, spec, item, k, dir, true, c5, dc5, a0);
         double* d = dt + k * DT_STRIDE;
         for (int c = 0; c < 5; ++c) d[DT_J + c * 3 + dir] = dc5[c];
         if (dir == 0) {
@@ -243,26 +276,11 @@ sos_prep_kernel(const float* __restrict__ sos, const float* __restrict__ params,
             d[DT_A0] = a0; d[7] = kap;
             d[23] = 0.0;
             d[DT_SG32] = (double)(float)sg; d[DT_NF] = direct ? 0.0 : 1.0; d[27] = 0.0;
-            for (int c = 0; c < 5; ++c) cfb[k][c] = c5[c];
-            cfb[k][5] = sg; cfb[k][6] = om; cfb[k][7] = 1.0 / om;
         }
     }
     PTRACE(41, 0);
     __syncthreads();
     PTRACE(47, 0);
-    if (tid < S) {   // monic rows (sos_bwd_kernel, FAST): feed-through 1 per section, the inputs of section k scaled by q = 1 / prod_{j<k} b0_j
-        const int k = tid;
-        double pk = 1.0;
-        for (int m = 0; m < k; ++m) pk *= sec[m][5];
-        const double b0 = sec[k][5], om = sec[k][1], sg = sec[k][0];
-        const double ib0 = b0 != 0.0 ? 1.0 / b0 : 0.0, q = pk != 0.0 ? 1.0 / pk : 0.0;   // (a cascade with a zero b0 never takes the FAST kernels)
-        float* mn = tb + LY::MN + k * 8;
-        mn[0] = (float)(sec[k][7] * ib0); mn[1] = (float)(sec[k][8] * ib0);
-        mn[2] = (float)(sec[k][3] * ib0); mn[3] = (float)(sec[k][4] * ib0);
-        mn[4] = (float)q; mn[5] = (float)(q / om); mn[6] = (float)(q * sg / om); mn[7] = 0.f;
-        dt[k * DT_STRIDE + DT_PK] = pk;
-    }
-
     // Phi for the forward system (sys 0) and the adjoint system (sys 1: sections reversed, A^T, B<->C). Written without branches on
     // purpose: a kernel starts with a cold instruction cache, and in its divergent if / else form this loop's ~50 taken branches
     // each paid an instruction fetch miss (measured 25-50k cycles for ~350 instructions; straight-line code streams through).
@@ -532,6 +550,64 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
 // SEG 0: one workgroup per row. SEG 1 / 2: the segmented scheme for few rows (oracle/chunkscan_model.py forward_row_segmented): one
 // workgroup per (row, segment of Tseg tiles); 2 = the scan-only pre-pass from a zero state, which leaves the segment's end state in
 // zseg[row][segment][2S]; 1 = the ordinary pass from the segment's start state segstart[row][segment][2S].
+// SEG 3 (round 5): both in ONE launch - the workgroup sweeps its segment scan-only, publishes the end state, takes its start state from the
+// end states of the row's earlier segments (lookback_start: a decoupled look-back - it only ever waits for workgroups with smaller indices,
+// which were dispatched before it) and sweeps again for the outputs (the second read of its 32 KiB of x hits the L2). One launch boundary
+// and the last-workgroup hand-off of the pre-pass less per direction.
+
+// A segment's end state on its way to the segments behind it: every component is a 64-bit word (tag << 32 | float bits), one agent-scope
+// atomic store - the reader polls the word until the tag is the launch's, so data and "it is there" arrive together and no fence is needed.
+// The tag is drawn by the design launch that precedes every use (sos_prep_kernel: the item's table word LY::TAG), so stale words of an
+// earlier call - the scratch buffer is whatever the allocator hands out, a graph replay reuses it - never match.
+__device__ __forceinline__ void lookback_publish(unsigned long long* w, float v, unsigned tag) {
+    __hip_atomic_store(w, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (The reader - lookback_start - polls until a word carries the launch's tag; it gives up after ~0.5 s: a workgroup it waits for has a
+// smaller index and is running or done, the bound only keeps a corrupted buffer from hanging the device; the outputs then show NaN.)
+// start(seg) = sum_{j < seg} Phi^(seg - 1 - j) z(j) by Horner, fp64 (chain_by_last_workgroup's arithmetic, the same order: the same bits), by
+// ONE wave: z64 = the row's words [segment][2S]; order +1: segments 0 .. seg - 1 ascending (forward system), -1: G - 1 .. seg + 1 descending
+// (adjoint system). The result goes into the inbox of the wave that owns the segment's first tile: slots [k][4] = (state, sequence number).
+template <int S>
+__device__ __forceinline__ void lookback_start(const unsigned long long* z64, int seg, int G, int order, const double* __restrict__ Phi, unsigned tag,
+                                               float* inbox, int seq, float* zs /* LDS, >= 64 * 2S floats */, double (*st)[2 * S] /* LDS [2][2S] */) {
+    constexpr int S2 = 2 * S, GB = 64;
+    const int l = lane_id();
+    const int npred = order > 0 ? seg : G - 1 - seg, first = order > 0 ? 0 : G - 1;
+    double prow[S2];
+#pragma unroll
+    for (int j = 0; j < S2; ++j) prow[j] = l < S2 && npred > 0 ? Phi[l * S2 + j] : 0.0;
+    if (l < S2) st[0][l] = 0.0;
+    int cur = 0;
+    for (int n0 = 0; n0 < npred; n0 += GB) {
+        const int nblk = npred - n0 < GB ? npred - n0 : GB;
+        wave_lds_sync();
+        for (int e = l; e < nblk * S2; e += 64) {
+            const unsigned long long* wp = z64 + (size_t)(first + order * (n0 + e / S2)) * S2 + e % S2;
+            float v = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                const unsigned long long w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == tag) { v = __builtin_bit_cast(float, (unsigned)w); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            zs[e] = v;
+        }
+        wave_lds_sync();
+        for (int i = 0; i < nblk; ++i) {
+            if (l < S2) {
+                double acc = (double)zs[i * S2 + l];
+#pragma unroll
+                for (int j = 0; j < S2; ++j) acc += prow[j] * st[cur][j];
+                st[cur ^ 1][l] = acc;
+            }
+            wave_lds_sync();
+            cur ^= 1;
+        }
+    }
+    wave_lds_sync();
+    if (l < S2) inbox[4 * (l >> 1) + (l & 1)] = (float)st[cur][l];
+    if (l < S) inbox[4 * l + 2] = __builtin_bit_cast(float, seq);
+}
+
 template <int S, int L, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W, W >= 16 ? 4 : (W * 2 + 3) / 4)   // two workgroups per CU (W = 16, few rows: one)
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
@@ -576,8 +652,6 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 #pragma unroll
     for (int k = 0; k < S; ++k) Kreg[k] = f2{0.f, 0.f};
     const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx));
-    if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
-    int stores_in_flight = 0;
     float Aop[4];
     chunk_table_operands<S, L>(tb + LY::GT, Aop, lane);
     // The cascade over the chunk on the matrix cores (round 4; sos_tile.hpp cascade_outputs_mfma: y = T x + O s0, LY::YM) - 32
@@ -585,77 +659,106 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
     static_assert(L == 16 && S2 <= 16, "one 16 x 16 output block per 16 chunks");
     float AT[4], AO[4];
     if (SEG != 2) cascade_map_operands<S, L>(tb + LY::YM, LY::YMC, AT, AO, lane);      // (SEG 2: scan only, no outputs)
+    // look-back launches: the launch's tag and the row's words
+    const unsigned tag = SEG == 3 ? __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, tb[LY::TAG])) : 0u;
+    unsigned long long* z64 = reinterpret_cast<unsigned long long*>(zseg) + (size_t)row * G * S2;
 
-    for (int t = t0 + wave; t < t1; t += W) {
-        int toff = 0;
-        asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
-        const float* __restrict__ tbl = tb + toff;
-        const bool full = tile_full<L>((long)t * TS, N, vec);
-        WIDE_PRIO(DASP_SCAN_PRIO);
-        TRACE(0);
-        // The x image of this tile was requested one tile ago (LDS-DMA, no staging registers); with the loads exposed at the top
-        // of every tile the kernel ran 24 % above its compute-only time. vmcnt is in order: the previous tile's state and y stores,
-        // issued after that request, may stay in flight.
-        if (full) wait_vmcnt(stores_in_flight);
-        else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
-        f4 Bop[4], zacc[4];
-        chunk_products_load(tbx, Bop, lane);
-        pin(Bop);
-        if (t + W < t1 && tile_full<L>((long)(t + W) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
-        TRACE(1);
-        float Z[L];
-        chunk_products_issue(Bop, Aop, zacc);
-        chunk_products_collect<L>(tby, zacc, Z, lane, lane);   // the y image is idle until the end of the tile
-        pin(Z); TRACE(5);
+    // One sweep over the workgroup's tiles. SCAN: the lane scans only (a pre-pass: nothing is stored but the segment's end state);
+    // seq0: added to the mailboxes' sequence numbers (a second sweep must not mistake the first one's entries for its own).
+    auto sweep = [&](auto scan_tag, const int seq0) {
+        constexpr bool SCAN = decltype(scan_tag)::value;
+        if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
+        int stores_in_flight = 0;
+        for (int t = t0 + wave; t < t1; t += W) {
+            int toff = 0;
+            asm volatile("" : "+s"(toff));   // opaque uniform 0: keeps the scalar table loads inside the tile loop (no SGPR spills)
+            const float* __restrict__ tbl = tb + toff;
+            const bool full = tile_full<L>((long)t * TS, N, vec);
+            WIDE_PRIO(DASP_SCAN_PRIO);
+            TRACE(0);
+            // The x image of this tile was requested one tile ago (LDS-DMA, no staging registers); with the loads exposed at the top
+            // of every tile the kernel ran 24 % above its compute-only time. vmcnt is in order: the previous tile's state and y stores,
+            // issued after that request, may stay in flight.
+            if (full) wait_vmcnt(stores_in_flight);
+            else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
+            f4 Bop[4], zacc[4];
+            chunk_products_load(tbx, Bop, lane);
+            pin(Bop);
+            if (t + W < t1 && tile_full<L>((long)(t + W) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t + W) * TS, a_x, lane);
+            TRACE(1);
+            float Z[L];
+            chunk_products_issue(Bop, Aop, zacc);
+            chunk_products_collect<L>(tby, zacc, Z, lane, lane);   // the y image is idle until the end of the tile
+            pin(Z); TRACE(5);
 
-        f2 st[S];
-        MboxPeek pk;
-        SCAN_PRIO(DASP_SCAN_PRIO);
-        tile_scan<S, L>(Z, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
-            [&](int k) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
-            [&](int k, f2& K) {
-                if (W == 1) K = Kreg[k];
-                else if (pk.seq == t) K = f2{pk.a, pk.b};   // tile 0 finds the zero-initialised inbox: sequence 0, carry 0
-                else { float a, b; mbox_wait(lds, mb_in + 4 * k, t, a, b); K = f2{a, b}; }
-            },
-            [&](int k, f2 Kn) {
-                if (W == 1) Kreg[k] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
-                else if (t + 1 < t1) mbox_publish<63>(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1);
-                else if (SEG == 2 && lane == 63) seg_state_store(zseg + ((size_t)row * G + seg) * S2 + 2 * k, Kn);   // the segment's end state
-            }
+            f2 st[S];
+            MboxPeek pk;
+            SCAN_PRIO(DASP_SCAN_PRIO);
+            tile_scan<S, L>(Z, [](f2 v) { return v; }, st, tbl + LY::MC, tbl + LY::PL, tbl + LY::P64, pws, lane,
+                [&](int k) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * k); },   // waited for with the per-lane powers (same lgkmcnt(0))
+                [&](int k, f2& K) {
+                    if (W == 1) K = Kreg[k];
+                    else if (pk.seq == t + seq0) K = f2{pk.a, pk.b};   // tile 0 finds the zero-initialised inbox: sequence 0, carry 0
+                    else { float a, b; mbox_wait(lds, mb_in + 4 * k, t + seq0, a, b); K = f2{a, b}; }
+                },
+                [&](int k, f2 Kn) {
+                    if (W == 1) Kreg[k] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
+                    else if (t + 1 < t1) mbox_publish<63>(lds, mb_out + 4 * k, Kn.x, Kn.y, t + 1 + seq0);
+                    else if (SCAN && lane == 63) {       // the segment's end state
+                        if (SEG == 3) { lookback_publish(z64 + (size_t)seg * S2 + 2 * k, Kn.x, tag); lookback_publish(z64 + (size_t)seg * S2 + 2 * k + 1, Kn.y, tag); }
+                        else seg_state_store(zseg + ((size_t)row * G + seg) * S2 + 2 * k, Kn);
+                    }
+                }
 #ifdef DASP_TRACE
-            , blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W
+                , blockIdx.x == 7 && threadIdx.x == 64 && t >= 40 && t < 40 + W
 #endif
-            );
-        SCAN_PRIO(0);
-        TRACE(2);
-        if (SEG == 2) {          // scan-only pre-pass: the carries are all this pass is for; nothing was stored
-            stores_in_flight = 0;
-            continue;
-        }
-        if (carries) {   // chunk start states for the backward pass: [row][tile][section pair][lane] f4, 1 KiB per wave store
-            static_assert(S % 2 == 0, "states are stored in section pairs");
-            f4* cs = reinterpret_cast<f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + lane;
-#pragma unroll
-            for (int m = 0; m < S / 2; ++m) {
-                const f4 v = f4{st[2 * m].x, st[2 * m].y, st[2 * m + 1].x, st[2 * m + 1].y};
-                if (DASP_FWD_NT & 4) st_stream(cs + m * 64, v); else cs[m * 64] = v;
+                );
+            SCAN_PRIO(0);
+            TRACE(2);
+            if (SCAN) {              // scan-only: the carries are all this sweep is for; nothing was stored
+                stores_in_flight = 0;
+                continue;
             }
-        }
+            if (carries) {   // chunk start states for the backward pass: [row][tile][section pair][lane] f4, 1 KiB per wave store
+                static_assert(S % 2 == 0, "states are stored in section pairs");
+                f4* cs = reinterpret_cast<f4*>(carries) + ((size_t)row * nt + t) * (S / 2) * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < S / 2; ++m) {
+                    const f4 v = f4{st[2 * m].x, st[2 * m].y, st[2 * m + 1].x, st[2 * m + 1].y};
+                    if (DASP_FWD_NT & 4) st_stream(cs + m * 64, v); else cs[m * 64] = v;
+                }
+            }
 
-        f4 yacc[4];
-        cascade_outputs_mfma_acc<S, L>(tby, st, Bop, AT, AO, lane, yacc);
-        TRACE(3);
-        WIDE_PRIO(DASP_SCAN_PRIO);
-        if (DASP_DIRECT_OUT && full) {       // the output granules straight from the matrix cores' result registers to memory
-            mfma_granules_to_global(yr + (size_t)t * TS, yacc, DASP_FWD_NT & 2, lane);
-        } else {
-            mfma_granules_to_image(tby, yacc, lane);
-            if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
-            else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
+            f4 yacc[4];
+            cascade_outputs_mfma_acc<S, L>(tby, st, Bop, AT, AO, lane, yacc);
+            TRACE(3);
+            WIDE_PRIO(DASP_SCAN_PRIO);
+            if (DASP_DIRECT_OUT && full) {       // the output granules straight from the matrix cores' result registers to memory
+                mfma_granules_to_global(yr + (size_t)t * TS, yacc, DASP_FWD_NT & 2, lane);
+            } else {
+                mfma_granules_to_image(tby, yacc, lane);
+                if (full) tile_swz_to_global_full(tby, yr, (long)t * TS, DASP_FWD_NT & 2, lane);
+                else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
+            }
+            stores_in_flight = full ? (carries ? S / 2 : 0) + L / 4 : -1;
+            TRACE(4);
         }
-        stores_in_flight = full ? (carries ? S / 2 : 0) + L / 4 : -1;
-        TRACE(4);
+    };
+    if (SEG == 3) {
+        sweep(std::true_type{}, 0);
+        // the start state from the end states of the segments in front of this one -> wave 0's inbox, sequence t0 + SEQ2
+        constexpr int SEQ2 = 1 << 28;
+        __shared__ double lb_st[2][S2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (no LDS-DMA in flight into the images the look-back stages its loads in)
+        __syncthreads();
+        if (wave == 0)
+            lookback_start<S>(z64, seg, G, 1, segtab + (size_t)(tab_bcast ? 0 : row / C) * 2 * S2 * S2, tag, lds, t0 + SEQ2, tbx, lb_st);
+        __syncthreads();
+        sweep(std::false_type{}, SEQ2);
+    } else if (SEG == 2) {
+        sweep(std::true_type{}, 0);
+    } else {
+        sweep(std::false_type{}, 0);
     }
     if (SEG == 2 && chain_tab) {      // scan-only pre-pass: the last workgroup of the item (of the call, with a shared table) chains its rows
         const int item = tab_bcast ? 0 : row / C;
@@ -1243,6 +1346,8 @@ struct GramFuse {
     float* gout;
     const double* basis;    // [item][GramFin<S>::BASIS], written by sos_prep_kernel
     float* cnt_tab;         // the items' tables: word LY::CNT of an item's table counts its arrivals (zeroed by the prep kernel, reset here)
+    const double* segtab_adj;       // look-back launches (SEG 3): the adjoint system's segment matrix of item 0 (stride 2 (2S)^2 doubles per item)
+    unsigned long long* lb_words;   // ... and their words [row][segment][2S]: the workgroup that finalizes an item invalidates the item's
 };
 // red: the four waves' 1024 sums each, [wave][red_stride] doubles in LDS (visible); it may overlap wk - it is read into registers first.
 template <int S>
@@ -1298,6 +1403,10 @@ __device__ __forceinline__ void gram_fused_tail(const GramFuse& fz, int item, in
     }
     __syncthreads();
     gram_emit<S>(ec, wk, fz.B, fz.mode, fz.gout, item, tid);
+    if (fz.lb_words) {      // every workgroup of the item has taken what it needed: a second backward pass over the same tables (same tag) must not
+        for (int e = tid; e < nwg * 2 * S; e += 256)      // find this one's adjoint states
+            __hip_atomic_store(fz.lb_words + (size_t)item * nwg * 2 * S + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     TAIL_STAMP(4);
 #ifdef DASP_TRACE
     if (item == 0 && tid == 0)
@@ -1359,6 +1468,15 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         static_assert(W == 4, "the finalize steps are written for 256 threads");
         static_assert(GramFin<S>::WORK * 2 <= LDS_T + LDS_MB + LDS_PW, "the finalize work area fits the tile images");
     }
+    // SEG 3 (round 5, with fz.on): the adjoint scan-only pre-pass inside this launch - the workgroup sweeps its segment's gy scan-only,
+    // publishes the adjoint state below the segment, takes the state entering from above from the segments above it (lookback_start, the
+    // forward kernel's scheme mirrored) and then runs the pass. segstart then points at the row-major 64-bit words. The workgroup -> segment
+    // map is the forward kernel's: a workgroup (row, seg) sits on XCD (row G + seg) % 8 in both directions, so the x tiles and saved states
+    // it reads were last touched through the same L2 (measured, profiles/r05/bwd_lookback_ab.log: with the row reversed - which would make
+    // every wait point at a smaller workgroup index - this kernel AND the next step's forward kernel lose ~3 us each). A workgroup therefore
+    // waits for workgroups of its own row with LARGER indices: they are running or about to, because the dispatcher hands out workgroups
+    // in index order and a row's G workgroups fit the device together (the host checks G against the CU count and takes the two-launch
+    // path otherwise) - the lowest unfinished row is always resident as a whole, and its last segment waits for nobody.
     const int row = SEG ? wg / G : wg, seg = SEG ? wg % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // this workgroup's tiles, walked t1 - 1 .. t0
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
@@ -1378,7 +1496,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         if (i < S * 4) {
             const int comp = i & 3;
             if (comp == 2) v = __builtin_bit_cast(float, t1);
-            else if (SEG && comp < 2) v = segstart[((size_t)row * G + seg) * (2 * S) + 2 * (i >> 2) + comp];
+            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * (2 * S) + 2 * (i >> 2) + comp];
         }
         lds[i] = v;
     }
@@ -1391,19 +1509,76 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
 
     const unsigned a_x = __builtin_amdgcn_readfirstlane(lds_addr(tbx)), a_g = __builtin_amdgcn_readfirstlane(lds_addr(tbg)),
                    a_s = __builtin_amdgcn_readfirstlane(lds_addr(tsi));
+    constexpr int SEQ2 = SEG == 3 ? 1 << 28 : 0;        // added to the mailboxes' sequence numbers of the pass (the pre-pass sweep used the plain ones)
     // states: image slot 64 q + lane is granule g = (lane % 4) ^ (lane / 16) of chunk 16 q + lane / 4 (swz_slot), granule = section pair;
     // the pad granules (g >= S / 2) fetch pair 0 again: finite numbers in columns of C that nobody reads
     const int sg_ = (lane & 3) ^ (lane >> 4), soff = ((sg_ < S / 2 ? sg_ : 0) * 64 + (lane >> 2)) * 4;
-    auto issue_dma = [&](int tt, bool full) {
-        if (full) {
-            tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
-            tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
-        }
-        const float* cs = carries + ((size_t)row * nt + tt) * (S * 128) + soff;
+    auto issue_dma = [&](int tt, bool full, int parts = 7) {     // parts: 1 x, 2 gy, 4 saved states
+        if (full && (parts & 1)) tile_dma_issue_swz(xr + (size_t)tt * TS, a_x, lane);
+        if (full && (parts & 2)) tile_dma_issue_swz(gr + (size_t)tt * TS, a_g, lane);
+        if (parts & 4) {
+            const float* cs = carries + ((size_t)row * nt + tt) * (S * 128) + soff;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16<!DASP_STATES_CACHED>(cs + 64 * q, a_s + 1024 * q);
+            for (int q = 0; q < 4; ++q) glds16<!DASP_STATES_CACHED>(cs + 64 * q, a_s + 1024 * q);
+        }
     };
-    if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec));
+    if constexpr (SEG == 3) {
+        // (the pass's first x tile and saved states are on their way while the sweep and the look-back run: their images are not the sweep's)
+        if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec), 5);
+        // ---- the adjoint scan-only sweep over the segment's gy (sos_bwd_kernel<SEG = 2>'s loop with this kernel's table products), the
+        //      look-back, and wave 0's inbox for the pass ----
+        const unsigned tag = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, tb[LY::TAG])) ^ 0x5A5A0000u;     // (the forward pass's words carry the plain tag)
+        unsigned long long* z64 = reinterpret_cast<unsigned long long*>(const_cast<float*>(segstart)) + (size_t)row * G * (2 * S);
+        if (wave < nr && tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec)) tile_dma_issue_swz(gr + (size_t)(t1 - 1 - wave) * TS, a_g, lane);
+        for (int r = wave; r < nr; r += W) {
+            const int t = t1 - 1 - r;
+            int toff = 0;
+            asm volatile("" : "+s"(toff));
+            const float* __restrict__ tbl = tb + toff;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!tile_full<L>((long)t * TS, N, vec)) tile_global_to_swz_guarded(tbg, gr, (long)t * TS, N);
+            float GYc[L], Z[L];
+            lds_to_chunks_swz<L>(tbg, GYc, 63 - lane);
+            pin(GYc);
+            if (r + W < nr) tile_dma_issue_swz(gr + (size_t)(t - W) * TS, a_g, lane);      // (tiles below a row's last one are always full)
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                f2 z0 = f2{0.f, 0.f}, z1 = f2{0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < L; n += 2) {
+                    const f2 xy = f2{GYc[n], GYc[n + 1]};
+                    z0 = fma2_bcast<0>(TLD2(tbl + LY::GAT + (k * L + n) * 2), xy, z0);
+                    z1 = fma2_bcast<1>(TLD2(tbl + LY::GAT + (k * L + n + 1) * 2), xy, z1);
+                }
+                const f2 z = z0 + z1;
+                Z[2 * k] = z.x; Z[2 * k + 1] = z.y;
+            }
+#pragma unroll
+            for (int c = 2 * S; c < L; ++c) Z[c] = 0.f;
+            pin(Z);
+            f2 lam0[S];
+            MboxPeek pk;
+            SCAN_PRIO(DASP_SCAN_PRIO);
+            tile_scan<S, L>(Z, [](f2 v) { return v; }, lam0, tbl + LY::MCA, tbl + LY::PLA, tbl + LY::P64A, pwa, lane,
+                [&](int i) { pk = mbox_peek(lds, mb_in + 4 * i); },
+                [&](int i, f2& K) {
+                    if (pk.seq == t + 1) K = f2{pk.a, pk.b};
+                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
+                },
+                [&](int i, f2 Kn) {
+                    if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                    else if (lane == 63) { lookback_publish(z64 + (size_t)seg * (2 * S) + 2 * i, Kn.x, tag); lookback_publish(z64 + (size_t)seg * (2 * S) + 2 * i + 1, Kn.y, tag); }
+                });
+            SCAN_PRIO(0);
+        }
+        __shared__ double lb_st[2][2 * S];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (no LDS-DMA in flight into the image the look-back stages its loads in)
+        __syncthreads();
+        if (wave == 0)
+            lookback_start<S>(z64, seg, G, -1, fz.segtab_adj + (size_t)(row / C) * 2 * (2 * S) * (2 * S), tag, lds, t1 + SEQ2, tbg, lb_st);
+        __syncthreads();
+    }
+    if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec), SEG == 3 ? 2 : 7);
     int stores_in_flight = 0;
     float Aop[4], AT[4], AO[4];
     chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);
@@ -1490,12 +1665,12 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
                 [&](int i) { if (W > 1) pk = mbox_peek(lds, mb_in + 4 * i); },
                 [&](int i, f2& K) {
                     if (W == 1) K = Kreg[i];
-                    else if (pk.seq == t + 1) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
-                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1, a, b); K = f2{a, b}; }
+                    else if (pk.seq == t + 1 + SEQ2) K = f2{pk.a, pk.b};   // the last tile finds wave 0's inbox as initialised: sequence nt, carry 0
+                    else { float a, b; mbox_wait(lds, mb_in + 4 * i, t + 1 + SEQ2, a, b); K = f2{a, b}; }
                 },
                 [&](int i, f2 Kn) {
                     if (W == 1) Kreg[i] = f2{read_lane(Kn.x, 63), read_lane(Kn.y, 63)};
-                    else if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t);
+                    else if (t > t0) mbox_publish<63>(lds, mb_out + 4 * i, Kn.x, Kn.y, t + SEQ2);
                 },
                 [&](int k, int p) {      // the 48 products above, dealt out over the 4 S hook points of the scan
                     constexpr int NPS = (48 + S - 1) / S, base = NPS / 4, extra = NPS % 4;
@@ -1727,8 +1902,8 @@ static int peq_prepare_rows_impl(const float* const* rows, int Bs, int S, const 
         }
         spec.sample_rate = sample_rate;
         double* basis = Tseg > 0 && want_basis ? segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS) : nullptr;
-        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bs), dim3(basis ? 384 : 256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab,
-                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis);
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(basis ? 2 * Bs : Bs), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab,
+                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis, Bs);
         return check_launch();
     });
 }
@@ -1893,6 +2068,39 @@ int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, con
     });
 }
 
+// The segmented forward pass of dasp_peq_forward* as ONE launch (sos_fwd_kernel<SEG = 3>: scan-only sweep, look-back over the row's earlier
+// segments, output sweep). Only behind a design launch of the same call - that launch draws the tag the look-back words are validated
+// with (LY::TAG); dasp_sosfilt_forward_seg, whose tables may serve many calls, keeps the two launches. segbuf: dasp_sos_seg_floats
+// floats, used as rows x segments x 2S 64-bit words. -DDASP_FWD_LOOKBACK=0 builds the two-launch path here as well (developer A/B).
+#ifndef DASP_FWD_LOOKBACK
+#define DASP_FWD_LOOKBACK 1
+#endif
+#ifndef DASP_BWD_LOOKBACK
+#define DASP_BWD_LOOKBACK 1      // the same for the backward pass of dasp_peq_backward (sos_bwd_gram_kernel<SEG = 3>); 0: pre-pass launch + pass
+#endif
+// compute units of the current device (the backward look-back needs a row's G workgroups resident together: one per CU is always possible)
+static int device_compute_units() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
+    return cus[dev];
+}
+static int sosfilt_forward_lookback(const float* tab, const double* segtab, int Bs, const float* x, float* y, float* carries, float* segbuf,
+                                    int B, int C, long N, int S, long Tseg, void* stream) {
+    if (!DASP_FWD_LOOKBACK) return dasp_sosfilt_forward_seg(tab, segtab, Bs, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    if (!tab || !segtab || !x || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0 || (reinterpret_cast<uintptr_t>(segbuf) & 7)) return DASP_ERR_ARG;
+    if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_sos_num_tiles(N), G = (int)dasp_sos_segments(N, Tseg), bc = Bs == 1 && B != 1;
+    const int vec = (N % 4 == 0) && aligned16(x) && aligned16(y);
+    return dispatch_S(S, [&](auto s) {
+        constexpr int SS = decltype(s)::value;
+        hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 3>), dim3(B * C * G), dim3(64 * kWF), 0, (hipStream_t)stream, tab, bc, x, y, carries, C, (int)N, nt,
+                           vec, G, (int)Tseg, (const float*)nullptr, segbuf, (float*)nullptr, segtab, (float*)nullptr);
+        return check_launch();
+    });
+}
+
 // The first two launches of dasp_sosfilt_forward_seg on their own: scan-only pre-pass + chain. segbuf (dasp_sos_seg_floats floats) then
 // holds, in its second half, the state every (row, segment) starts from, [row][segment][2S] - for callers that run their own per-segment
 // pass from those states (chainfwd.hip: the fused EQ -> compressor forward).
@@ -1930,6 +2138,24 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         hipStream_t st = (hipStream_t)stream;
+        const bool fuse = partials && fin_dtab && fin_gout && !bc;
+        if (fuse && DASP_BWD_LOOKBACK && G <= device_compute_units()) {
+            // one launch: adjoint scan-only sweep, look-back over the segments above, Gram pass, finalize (sos_bwd_gram_kernel<SEG = 3>)
+            if (GramFin<SS>::BASIS != sos_basis_doubles(SS) || (reinterpret_cast<uintptr_t>(segbuf) & 7)) return DASP_ERR_UNSUPPORTED;
+            GramFuse fz = {};
+            fz.on = 1; fz.B = B; fz.mode = fin_mode; fz.dtab = fin_dtab; fz.gout = fin_gout;
+            fz.basis = segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS);
+            fz.cnt_tab = const_cast<float*>(tab);
+            fz.segtab_adj = segtab + (2 * SS) * (2 * SS);
+            fz.lb_words = reinterpret_cast<unsigned long long*>(segbuf);
+            const dim3 g(B * C * G), b(64 * kWB);
+            double* gm = reinterpret_cast<double*>(partials);
+            if (!gx)
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 3>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)segbuf, fz);
+            else
+                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 3>), g, b, 0, st, tab, bc, x, gy, carries, gx, gm, C, (int)N, nt, vec, G, (int)Tseg, (const float*)segbuf, fz);
+            return check_launch();
+        }
         // adjoint scan-only pre-pass; its last workgroup per item chains the segments (chain_by_last_workgroup: the counter word lives in the table)
         // (kWBA waves: a segment of eight tiles is one tile per wave - the scan-only pass is a latency chain, not a throughput loop)
         hipLaunchKernelGGL((sos_bwd_kernel<SS, kL, kWBA, 2>), dim3(B * C * G), dim3(64 * kWBA), 0, st, tab, bc, gy, (float*)nullptr, C, (int)N, nt, vec, G, (int)Tseg,
@@ -1942,7 +2168,7 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
         if (GramFin<SS>::BASIS != sos_basis_doubles(SS)) return DASP_ERR_UNSUPPORTED;        // (the size query and the layout are two statements of one number)
         double* gm = reinterpret_cast<double*>(partials);
         GramFuse fz = {};
-        if (fin_dtab && fin_gout && !bc) {
+        if (fuse) {
             fz.on = 1; fz.B = B; fz.mode = fin_mode; fz.dtab = fin_dtab; fz.gout = fin_gout;
             fz.basis = segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS);
             fz.cnt_tab = const_cast<float*>(tab);
@@ -1984,7 +2210,7 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
     const int rc = peq_prepare_rows_impl(rows, Bp, S, types, sample_rate, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, carries != nullptr, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
-    return dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    return sosfilt_forward_lookback(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
 }
 
 // The same from the normalised (Bp, 3 S) parameter tensor of Processor.process_normalized (dasp_pytorch/modules.py:25-91): de-normalisation
@@ -2007,8 +2233,8 @@ static int peq_prepare_norm_impl(const float* pn, int Bp, int S, const int* type
         spec.norm = 1;
         spec.flag = flag;
         double* basis = Tseg > 0 && want_basis ? segtab + (size_t)Bp * 2 * (2 * SS) * (2 * SS) : nullptr;
-        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(Bp), dim3(basis ? 384 : 256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab,
-                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis);
+        hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(basis ? 2 * Bp : Bp), dim3(256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab,
+                           Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis, Bp);
         return check_launch();
     });
 }
@@ -2027,7 +2253,7 @@ int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, doub
     const int rc = peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, carries != nullptr, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
-    return dasp_sosfilt_forward_seg(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    return sosfilt_forward_lookback(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
 }
 
 // Backward of the same call: adjoint cascade + control gradients (mode as in dasp_sos_grad_finalize), the tables being the ones
