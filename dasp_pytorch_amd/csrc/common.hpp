@@ -305,4 +305,17 @@ __device__ __forceinline__ void mbox_wait(float* lds, int slot, int seq, float& 
     b = __hip_atomic_load(&lds[slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Zeroing on the stream as a KERNEL. Not hipMemsetAsync: inside a captured graph the memset node was not ordered before the kernel node
+// behind it when a replay started on an idle device (found with the compressor's completion counters, scripts/debug_dyn_graph.py:
+// eager calls and back-to-back replays were fine, a replay after a synchronize was not) - a kernel node is.
+static __global__ void __launch_bounds__(256) zero_kernel(unsigned* __restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {     // bytes: a multiple of 4 (every caller zeroes floats, ints or doubles)
+    if (!bytes) return hipSuccess;
+    const size_t words = bytes / 4, blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, static_cast<unsigned*>(p), words);
+    return hipGetLastError();
+}
+
 }  // namespace dasp

@@ -16,6 +16,8 @@
 // HBM-bound: forward 8 B per channel-sample (read x, write y), backward 12 B (x, gy, gx).
 #include "common.hpp"
 #include "dyn_common.hpp"
+#include <atomic>
+#include <cstdint>
 
 // s_setprio of a wave from the top of its tile until its carry has been handed on (loads, gain computer, lane scans, mailbox):
 // see the same switch in sosfilt.hip
@@ -23,6 +25,11 @@
 #define DASP_DYN_PRIO 1     // compressor backward -2 %, forward unchanged
 #endif
 #define DYN_PRIO(p) do { if (DASP_DYN_PRIO) __builtin_amdgcn_s_setprio(p); } while (0)
+
+// 0 (developer A/B): segmented forward passes keep the pre-pass launch + pass instead of dyn_fwd_lookback_kernel
+#ifndef DASP_DYN_LOOKBACK
+#define DASP_DYN_LOOKBACK 1
+#endif
 
 namespace dasp {
 
@@ -224,6 +231,137 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
 }
 
 // ------------------------------------------------------------------------------------------------
+// Segmented items in ONE forward launch (round 5). The smoothing state is one float and enters everything linearly, so nothing has to
+// be swept twice: a workgroup runs its segment from a ZERO state keeping each tile's gain-computer output, lane scans and zero-start
+// carry in registers (TPW tiles per wave), publishes the segment's end state as a tagged 64-bit word, takes its true start state from
+// the words of the item's earlier segments - start = sum_j a^(seg - 1 - j) z(j), a = alpha^(samples per segment), one lane per
+// predecessor, fp64 - corrects every tile carry by alpha^(samples since the segment start) * start and only then computes the gains
+// and outputs. A workgroup waits for workgroups with smaller indices only (dispatched before it). The words are validated by `tag`
+// (the host draws a new one per call) and returned to zero by the last wave of the item that has read them (count in `counter`, which
+// returns to zero as well), so a captured graph - whose replays all carry the capture's tag - starts every replay from clean words.
+template <int MODE, int W, int TPW>
+__global__ void __launch_bounds__(64 * W)
+dyn_fwd_lookback_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y, float* __restrict__ carries,
+                        float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps, int G,
+                        unsigned long long* __restrict__ words, int* __restrict__ counters, unsigned tag) {
+    constexpr int Tseg = W * TPW;
+    __shared__ float lds[W * 4];
+    __shared__ int s_read;
+    if (threadIdx.x == 0) s_read = 0;
+    const int lane = lane_id(), wave = wave_id(), b = blockIdx.x / G, seg = blockIdx.x % G;
+    const int t0 = seg * Tseg, t1 = t0 + Tseg < nt ? t0 + Tseg : nt;
+    const DynItem it = load_item(ctl, b, sample_rate, eps);
+    const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
+    const float* __restrict__ xb = x + (size_t)b * C * N;
+    float* __restrict__ yb = y + (size_t)b * C * N;
+    unsigned long long* wb = words + (size_t)b * G;
+    const int mb_in = wave * 4, mb_out = ((wave + 1) % W) * 4;
+    for (int i = threadIdx.x; i < W * 4; i += 64 * W) lds[i] = 0.f;
+    __syncthreads();
+    f4 s[TPW][DY_SUB];
+    float E[TPW][DY_SUB], Kz[TPW];
+    // ---- zero-start sweep: side chain, gain computer, lane scans, the tile carries through the mailboxes ----
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+        const int t = t0 + wave + r * W;
+        Kz[r] = 0.f;
+        if (t >= t1) continue;
+        const long base = (long)t * DY_TS;
+        const bool fast = vec && base + DY_TS <= N;
+        DYN_PRIO(1);
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) s[r][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) s[r][j] += load4(xb + (size_t)c * N, base + dy_pos(j, lane, 0), N, fast);
+        }
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            float d0, d1, d2, d3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x_db = DB_PER_LOG2 * log2f(fmaxf(fabsf(s[r][j][i]), it.eps));
+                s[r][j][i] = gain_computer<MODE, false>(x_db, it, d0, d1, d2, d3);
+            }
+            const float e = it.beta * fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, s[r][j].x, s[r][j].y), s[r][j].z), s[r][j].w);
+            E[r][j] = lane_scan(e, it, pw16, pw32);
+        }
+        float K = 0.f;
+        if (t != t0) { float dummy; mbox_wait(lds, mb_in, t, K, dummy); }
+        Kz[r] = K;
+        float Kn = K;
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) Kn = fmaf(it.a256, Kn, read_lane(E[r][j], 63));
+        if (t + 1 < t1) mbox_publish(lds, mb_out, Kn, 0.f, t + 1);
+        else if (lane == 0)
+            __hip_atomic_store(wb + seg, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, Kn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DYN_PRIO(0);
+    }
+    // ---- look-back (every wave on its own: at most G - 1 words, no barrier) ----
+    const double rate = -2.1972245773362196 / (sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3));       // ln alpha (load_item)
+    double start = 0.0;
+    if (seg > 0) {
+        double acc = 0.0;
+        for (int j = lane; j < seg; j += 64) {
+            float z = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                const unsigned long long w = __hip_atomic_load(wb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == tag) { z = __builtin_bit_cast(float, (unsigned)w); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            acc += (double)z * exp(rate * (double)((long)Tseg * DY_TS) * (double)(seg - 1 - j));
+        }
+        start = __shfl(wave_sum(acc), 0, 64);
+    }
+    // this wave has read (and, if it owns the segment's last tile, published: the store is acknowledged before the count moves). The
+    // workgroup's waves count themselves in LDS; the one that completes that count adds the workgroup to the item's counter once its own
+    // outputs are out (one device-scope atomic per workgroup, off everybody's critical path: one per wave, each waiting for its return
+    // value, was a chain of G * W serialized atomics on one address - +20 us at (8, 2, 262144))
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int wg_last = 0;
+    if (lane == 0) wg_last = __hip_atomic_fetch_add(&s_read, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == W - 1;
+    wg_last = __builtin_amdgcn_readfirstlane(wg_last);
+    // ---- true carries, smoothed gains, outputs ----
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+        const int t = t0 + wave + r * W;
+        if (t >= t1) continue;
+        const long base = (long)t * DY_TS;
+        const bool fast = vec && base + DY_TS <= N;
+        float K = (float)((double)Kz[r] + exp(rate * (double)DY_TS * (double)(t - t0)) * start);
+        if (carries && lane == 0) carries[(size_t)b * nt + t] = K;
+#pragma unroll
+        for (int j = 0; j < DY_SUB; ++j) {
+            float g = fmaf(pws, K, dshr1(E[r][j]));
+            K = fmaf(it.a256, K, read_lane(E[r][j], 63));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g = fmaf(it.alpha, g, it.beta * s[r][j][i]);
+                s[r][j][i] = exp2f((g + it.makeup) * LOG2_PER_DB);
+            }
+            if (lin_buf) store4(lin_buf + (size_t)b * N, base + dy_pos(j, lane, 0), N, fast, s[r][j]);
+        }
+        const bool fast_in = fast && look == 0;
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < DY_SUB; ++j) {
+                const long p = base + dy_pos(j, lane, 0);
+                const f4 xv = load4<true>(xb + (size_t)c * N, p - look, N, fast_in);
+                store4(yb + (size_t)c * N, p, N, fast, xv * s[r][j]);
+            }
+        }
+    }
+    if (wg_last) {      // the workgroup that completes the item's count returns the words and the counter to zero
+        int last = 0;
+        if (lane == 0) last = __hip_atomic_fetch_add(counters + 4 * b + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+        if (__builtin_amdgcn_readfirstlane(last)) {
+            for (int g = lane; g < G; g += 64) __hip_atomic_store(wb + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(counters + 4 * b + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward. Walks the tiles in reverse; recomputes the forward gain from the saved tile carries,
 // runs the adjoint one-pole scan on lane-mirrored data, accumulates the control gradients.
 // partials: (B, W, 5) = d/d threshold, ratio, alpha, knee, makeup (per wave, fp32).
@@ -242,7 +380,8 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                const float* __restrict__ carries, const float* __restrict__ lin_buf, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
-               int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr, float* __restrict__ gctl = nullptr) {
+               int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr, float* __restrict__ gctl = nullptr,
+               unsigned tag = 0) {
     __shared__ float lds[W * 4];
     __shared__ float ring[DMA ? W * DY_RING : 1];
     const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
@@ -276,18 +415,17 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             }
         }
     };
+    // One tile in two steps: everything that does not depend on the adjoint state entering the tile (loads, forward recompute, the adjoint
+    // lane scans) and everything that does (gradient sums, gx). SEG 0 / 1 run them back to back per tile; SEG 3 keeps the first step's
+    // registers of its tiles across the look-back.
+    struct Tile { f4 s[DY_SUB], q[DY_SUB], gc[DY_SUB], gs[DY_SUB]; float Er[DY_SUB], gprev[DY_SUB]; };
     int pending_stores = 0;
-    if (DMA && wave < nr) prefetch(t1 - 1 - wave, 0);
-    int slot = 0;
-    for (int r = wave; r < nr; r += W, slot ^= 1) {
+    auto tile_scans = [&](int r, int slot, Tile& T, bool prefetch_next) {
         const int t = t1 - 1 - r;
         const long base = (long)t * DY_TS;
-        const bool fast = vec && base + DY_TS <= N, fast_in = fast && lk == 0;
-        DYN_PRIO(1);
-        DTRACE(0);
-        f4 s[DY_SUB], q[DY_SUB];
+        const bool fast = vec && base + DY_TS <= N;
 #pragma unroll
-        for (int j = 0; j < DY_SUB; ++j) { s[j] = f4{0.f, 0.f, 0.f, 0.f}; q[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < DY_SUB; ++j) { T.s[j] = f4{0.f, 0.f, 0.f, 0.f}; T.q[j] = f4{0.f, 0.f, 0.f, 0.f}; }
         float Kcur = 0.f;
         const float* cur = myring + slot * DY_SLOT;
         if (DMA) {
@@ -296,7 +434,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             else if (pending_stores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             Kcur = cur[4 * DY_TS];
-            if (r + W < nr) prefetch(t - W, slot ^ 1);
+            if (prefetch_next && r + W < nr) prefetch(t - W, slot ^ 1);
             for (int c = 0; c < C; ++c) {
 #pragma unroll
                 for (int j = 0; j < DY_SUB; ++j) {
@@ -304,8 +442,8 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                     const f4 z = f4{0.f, 0.f, 0.f, 0.f};
                     const f4 xv = in ? *reinterpret_cast<const f4*>(cur + c * DY_TS + dy_pos(j, lane, 0)) : z;
                     const f4 gv = in ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : z;
-                    s[j] += xv;
-                    q[j] += gv * xv;
+                    T.s[j] += xv;
+                    T.q[j] += gv * xv;
                 }
             }
         } else {
@@ -314,84 +452,78 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                 for (int j = 0; j < DY_SUB; ++j) {
                     const long p = base + dy_pos(j, lane, 0);
                     const f4 xv = load4(xb + (size_t)c * N, p, N, fast);
-                    s[j] += xv;
+                    T.s[j] += xv;
                     const f4 xd = lk == 0 ? xv : load4(xb + (size_t)c * N, p - lk, N, false);
-                    q[j] += load4(gb + (size_t)c * N, p, N, fast) * xd;            // sum_c gy * x_d
+                    T.q[j] += load4(gb + (size_t)c * N, p, N, fast) * xd;            // sum_c gy * x_d
                 }
             }
         }
         DTRACE(1);
-        // forward recompute: g_c, lane scan, exact g and lin; keep x_db (in s) and g_c
-        f4 gc[DY_SUB], gs[DY_SUB];   // gc = gain computer output, gs = smoothed gain g[n]
+        // forward recompute: g_c, lane scan, exact g and lin; keep x_db (in s) and g_c (gc = gain computer output, gs = smoothed gain g[n])
         float E[DY_SUB];
 #pragma unroll
         for (int j = 0; j < DY_SUB; ++j) {
             float d0, d1, d2, d3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gc[j][i] = gain_computer<MODE, false>(DB_PER_LOG2 * log2f(fmaxf(fabsf(s[j][i]), it.eps)), it, d0, d1, d2, d3);
-            const float e = it.beta * fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, gc[j].x, gc[j].y), gc[j].z), gc[j].w);
+            for (int i = 0; i < 4; ++i) T.gc[j][i] = gain_computer<MODE, false>(DB_PER_LOG2 * log2f(fmaxf(fabsf(T.s[j][i]), it.eps)), it, d0, d1, d2, d3);
+            const float e = it.beta * fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, T.gc[j].x, T.gc[j].y), T.gc[j].z), T.gc[j].w);
             E[j] = lane_scan(e, it, pw16, pw32);
         }
         DTRACE(2);
         float K = DMA ? Kcur : carries[(size_t)b * nt + t];
-        float gprev[DY_SUB];          // g[n-1] for the first sample of each lane's group
 #pragma unroll
         for (int j = 0; j < DY_SUB; ++j) {
             float g = fmaf(pws, K, dshr1(E[j]));
-            gprev[j] = g;
+            T.gprev[j] = g;                     // g[n-1] for the first sample of each lane's group
             K = fmaf(it.a256, K, read_lane(E[j], 63));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                g = fmaf(it.alpha, g, it.beta * gc[j][i]);
-                gs[j][i] = g;
+                g = fmaf(it.alpha, g, it.beta * T.gc[j][i]);
+                T.gs[j][i] = g;
                 const float lin = exp2f((g + it.makeup) * LOG2_PER_DB);
-                q[j][i] *= LN10_20 * lin;                       // q = dL/d(g + makeup)
-                acc_m += q[j][i];
+                T.q[j][i] *= LN10_20 * lin;                       // q = dL/d(g + makeup)
+                acc_m += T.q[j][i];
             }
         }
         // adjoint one-pole r[n] = q[n] + alpha r[n+1]: mirrored lanes, sub-tiles in reverse
-        float Er[DY_SUB];
 #pragma unroll
         for (int j = 0; j < DY_SUB; ++j) {
-            const float e = fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, q[j].w, q[j].z), q[j].y), q[j].x);   // value leaving towards n-1
-            Er[j] = lane_scan(dmirror(e), it, pw16, pw32);     // mirrored lane m = 63 - l; scan direction = decreasing time
+            const float e = fmaf(it.alpha, fmaf(it.alpha, fmaf(it.alpha, T.q[j].w, T.q[j].z), T.q[j].y), T.q[j].x);   // value leaving towards n-1
+            T.Er[j] = lane_scan(dmirror(e), it, pw16, pw32);     // mirrored lane m = 63 - l; scan direction = decreasing time
         }
         DTRACE(3);
-        float R;
-        if (W == 1 || r == 0) R = Rreg;                   // (only wave 0 sees r == 0: its Rreg is the adjoint state entering from above)
-        else { float dummy; mbox_wait(lds, mb_in, t + 1, R, dummy); }
-        DTRACE(4);
-        {
-            float Rn = R;
+    };
+    // the adjoint state leaving the tile downwards, from the one entering it
+    auto tile_carry = [&](const Tile& T, float R) {
 #pragma unroll
-            for (int j = DY_SUB - 1; j >= 0; --j) Rn = fmaf(it.a256, Rn, read_lane(Er[j], 63));
-            if (W == 1) Rreg = Rn;
-            else if (t > t0) mbox_publish(lds, mb_out, Rn, 0.f, t);
-            if (SEG == 2 && t == t0 && lane == 0) __hip_atomic_store(zseg + (size_t)b * G + seg, Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the adjoint state below the segment
-        }
-        DYN_PRIO(0);
-        if (SEG == 2) { pending_stores = 0; continue; }    // adjoint scan-only pre-pass
-        DTRACE(5);
+        for (int j = DY_SUB - 1; j >= 0; --j) R = fmaf(it.a256, R, read_lane(T.Er[j], 63));
+        return R;
+    };
+    auto tile_grads = [&](int r, int slot, Tile& T, float R) {
+        const int t = t1 - 1 - r;
+        const long base = (long)t * DY_TS;
+        const bool fast = vec && base + DY_TS <= N, fast_in = fast && lk == 0;
+        const float* cur = myring + slot * DY_SLOT;
 #pragma unroll
         for (int j = DY_SUB - 1; j >= 0; --j) {
             // r[n+1] for this lane's last sample: in mirrored space, the inclusive scan of the previous mirrored lane
-            float rn = dmirror(fmaf(pws, R, dshr1(Er[j])));
-            R = fmaf(it.a256, R, read_lane(Er[j], 63));
+            float rn = dmirror(fmaf(pws, R, dshr1(T.Er[j])));
+            R = fmaf(it.a256, R, read_lane(T.Er[j], 63));
             f4 gside;
 #pragma unroll
             for (int i = 3; i >= 0; --i) {
-                rn = fmaf(it.alpha, rn, q[j][i]);                                  // r[n]
-                const float glast = i == 0 ? gprev[j] : gs[j][i - 1];
-                acc_a = fmaf(rn, glast - gc[j][i], acc_a);                         // dL/dalpha
+                rn = fmaf(it.alpha, rn, T.q[j][i]);                                  // r[n]
+                const float glast = i == 0 ? T.gprev[j] : T.gs[j][i - 1];
+                acc_a = fmaf(rn, glast - T.gc[j][i], acc_a);                         // dL/dalpha
                 const float p = it.beta * rn;                                      // dL/dg_c[n]
-                const float mag = fabsf(s[j][i]);
+                const float mag = fabsf(T.s[j][i]);
                 const float x_db = DB_PER_LOG2 * log2f(fmaxf(mag, it.eps));
                 float d_x, d_t, d_r, d_w;
                 gain_computer<MODE, true>(x_db, it, d_x, d_t, d_r, d_w);
                 acc_t = fmaf(p, d_t, acc_t); acc_r = fmaf(p, d_r, acc_r); acc_w = fmaf(p, d_w, acc_w);
-                gside[i] = mag >= it.eps ? p * d_x * DB_SLOPE * __builtin_copysignf(1.f, s[j][i]) / mag : 0.f;
+                gside[i] = mag >= it.eps ? p * d_x * DB_SLOPE * __builtin_copysignf(1.f, T.s[j][i]) / mag : 0.f;
             }
-            q[j] = gside;    // dL/d(side chain sample)
+            T.q[j] = gside;    // dL/d(side chain sample)
         }
         DTRACE(6);
         // gx = gy[n + look] * lin[n + look] + dL/ds  (functional.py:383-394 transposed)
@@ -402,16 +534,91 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                 f4 lin;
                 if (lk == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lin[i] = exp2f((gs[j][i] + it.makeup) * LOG2_PER_DB);
+                    for (int i = 0; i < 4; ++i) lin[i] = exp2f((T.gs[j][i] + it.makeup) * LOG2_PER_DB);
                 } else {
                     lin = load4(lin_buf + (size_t)b * N, p + lk, N, false);
                 }
                 const f4 g = DMA ? *reinterpret_cast<const f4*>(cur + (2 + c) * DY_TS + dy_pos(j, lane, 0)) : load4<true>(gb + (size_t)c * N, p + lk, N, fast_in);
-                store4(gxb + (size_t)c * N, p, N, fast, g * lin + q[j], SEG == 1);      // (segmented: the launch ends with the finalize hand-off)
+                store4(gxb + (size_t)c * N, p, N, fast, g * lin + T.q[j], SEG == 1 || SEG == 3);      // (segmented: the launch ends with the finalize hand-off)
             }
         }
         pending_stores = fast ? C * DY_SUB : 0;       // a full tile issues exactly C * DY_SUB wave-wide stores; anything else: wait for all
         DTRACE(7);
+    };
+    if constexpr (SEG == 3) {
+        // ---- one launch (round 5, as dyn_fwd_lookback_kernel): the adjoint state enters everything below linearly, so the segment's tiles
+        //      run their first step from a ZERO state entering the segment, the state below the segment travels as a tagged word, the true
+        //      state entering from above comes from the words of the segments above (one lane per segment, fp64), every tile's entering
+        //      state is corrected by alpha^(samples above it in the segment) * that, and only then the second step runs. Two tiles per wave
+        //      (Tseg = 2 W): both ring slots are loaded up front and kept. ----
+        static_assert(DMA, "the look-back variant keeps its tiles in the LDS ring");
+        constexpr int TPW = 2;
+        unsigned long long* wb = reinterpret_cast<unsigned long long*>(zseg) + (size_t)b * G;
+        Tile T[TPW];
+        float Rz[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) if (wave + i * W < nr) prefetch(t1 - 1 - (wave + i * W), i);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int r = wave + i * W, t = t1 - 1 - r;
+            Rz[i] = 0.f;
+            if (r >= nr) continue;
+            DYN_PRIO(1);
+            tile_scans(r, i, T[i], false);
+            float R = 0.f;
+            if (r != 0) { float dummy; mbox_wait(lds, mb_in, t + 1, R, dummy); }
+            Rz[i] = R;
+            const float Rn = tile_carry(T[i], R);
+            if (t > t0) mbox_publish(lds, mb_out, Rn, 0.f, t);
+            else if (lane == 0)
+                __hip_atomic_store(wb + seg, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, Rn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DYN_PRIO(0);
+        }
+        const double rate = -2.1972245773362196 / (sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3));       // ln alpha (load_item)
+        double above = 0.0;
+        if (seg + 1 < G) {
+            double acc = 0.0;
+            for (int j = seg + 1 + lane; j < G; j += 64) {
+                float z = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
+                for (int spin = 0; spin < (1 << 22); ++spin) {
+                    const unsigned long long w = __hip_atomic_load(wb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w >> 32) == tag) { z = __builtin_bit_cast(float, (unsigned)w); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                acc += (double)z * exp(rate * (double)((long)Tseg * DY_TS) * (double)(j - seg - 1));
+            }
+            above = __shfl(wave_sum(acc), 0, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int r = wave + i * W;
+            if (r >= nr) continue;
+            tile_grads(r, i, T[i], (float)((double)Rz[i] + exp(rate * (double)DY_TS * (double)r) * above));
+        }
+    } else {
+    if (DMA && wave < nr) prefetch(t1 - 1 - wave, 0);
+    int slot = 0;
+    for (int r = wave; r < nr; r += W, slot ^= 1) {
+        const int t = t1 - 1 - r;
+        DYN_PRIO(1);
+        DTRACE(0);
+        Tile T;
+        tile_scans(r, slot, T, true);
+        float R;
+        if (W == 1 || r == 0) R = Rreg;                   // (only wave 0 sees r == 0: its Rreg is the adjoint state entering from above)
+        else { float dummy; mbox_wait(lds, mb_in, t + 1, R, dummy); }
+        DTRACE(4);
+        {
+            const float Rn = tile_carry(T, R);
+            if (W == 1) Rreg = Rn;
+            else if (t > t0) mbox_publish(lds, mb_out, Rn, 0.f, t);
+            if (SEG == 2 && t == t0 && lane == 0) __hip_atomic_store(zseg + (size_t)b * G + seg, Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the adjoint state below the segment
+        }
+        DYN_PRIO(0);
+        if (SEG == 2) { pending_stores = 0; continue; }    // adjoint scan-only pre-pass
+        DTRACE(5);
+        tile_grads(r, slot, T, R);
+    }
     }
     if (SEG == 2) {                   // adjoint scan-only pre-pass: the item's last workgroup chains its segments downwards
         if (counters && dyn_last_workgroup(counters + 4 * b + 1, G)) dyn_chain_item(ctl, zseg, chain_start, b, G, (long)Tseg * DY_TS, sample_rate, 1);
@@ -419,7 +626,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
     }
     float* po = partials + (((size_t)b * G + seg) * W + wave) * 5;
     const float v0 = wave_sum(acc_t), v1 = wave_sum(acc_r), v2 = wave_sum(acc_a), v3 = wave_sum(acc_w), v4 = wave_sum(acc_m);
-    if (SEG == 1 && counters) {
+    if ((SEG == 1 || SEG == 3) && counters) {
         // the item's last workgroup maps its G * W rows of partial sums to the control gradients (dyn_finalize_kernel's arithmetic) - no
         // finalize launch; the sums cross workgroups as device-scope atomics
         if (lane == 0) {
@@ -428,6 +635,9 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
             for (int i = 0; i < 5; ++i) __hip_atomic_store(po + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (dyn_last_workgroup(counters + 4 * b + 2, G) && wave == 0) {
+            if (SEG == 3)       // every workgroup of the item has read its look-back words: return them to zero (a graph replay carries the same tag)
+                for (int g = lane; g < G; g += 64)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(zseg) + (size_t)b * G + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int Wn = G * W;
             double a[5] = {0, 0, 0, 0, 0};
             for (int w = lane; w < Wn; w += 64) {
@@ -582,6 +792,14 @@ long dasp_dyn_segment_tiles(long B, long N) {
     while (B * ((nt + T - 1) / T) > 256 && T < nt) T *= 2;
     return (nt + T - 1) / T > 1 ? T : 0;
 }
+// compute units of the current device (the backward look-back needs an item's G workgroups resident together: one per CU is always possible)
+static int dyn_compute_units() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
+    return cus[dev];
+}
 long dasp_dyn_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_dyn_num_tiles(N) + Tseg - 1) / Tseg : 1; }
 
 int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
@@ -595,9 +813,10 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
     float* start = segbuf + (size_t)B * G;
     hipStream_t st = (hipStream_t)stream;
     float* lb = lookahead > 0 ? lin_buf : nullptr;
-    // counters: 4 * B ints owned by the caller (dasp_hip.h). Every use returns its word to zero, but a word left non-zero by a call that
-    // failed half-way would keep every later count from completing (start states never written): they are zeroed per call, on the stream.
-    if (counters) { const hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4 * (size_t)B, st); if (e != hipSuccess) return (int)e; }
+    // counters: 4 * B ints owned by the caller (dasp_hip.h), zero before their first use; every use returns its word to zero. (Rounds 3 - 4
+    // zeroed them here with hipMemsetAsync on the stream; inside a captured graph that memset node was not ordered before the kernel node
+    // behind it when the replay started on an idle device - the count was wiped half-way, no workgroup ever saw it complete, outputs
+    // and control gradients of the replay were garbage: scripts/debug_dyn_graph.py.)
 #define DASP_DYN_FWD_SEG(MODE_)                                                                                                                  \
     hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 2>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, (float*)nullptr, (float*)nullptr,          \
                        (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z);               \
@@ -611,7 +830,20 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
                        (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z, counters, start); \
     hipLaunchKernelGGL((dyn_fwd_kernel<MODE_, kDWF, 1>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, y, carries, lb, C, (int)N, nt, vec,        \
                        lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
-    if (counters && G <= DY_GMAX) { if (mode == 0) { DASP_DYN_FWD_SEG2(0); } else { DASP_DYN_FWD_SEG2(1); } }
+    /* one launch (dyn_fwd_lookback_kernel): Tseg = 1, 2 or 4 tiles per forward wave - what the planner proposes up to (32, c, 262144) */
+    const long tpw = Tseg % kDWF == 0 ? Tseg / kDWF : 0;
+    if (DASP_DYN_LOOKBACK && counters && (tpw == 1 || tpw == 2 || tpw == 4) && !(reinterpret_cast<uintptr_t>(segbuf) & 7)) {
+        static std::atomic<unsigned> calls{0x2545F491u};
+        unsigned tag = calls.fetch_add(0x9E3779B1u) | 1u;                 // never 0 (= a returned word)
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(segbuf);
+#define DASP_DYN_FWD_LB(MODE_, TPW_)                                                                                                            \
+        hipLaunchKernelGGL((dyn_fwd_lookback_kernel<MODE_, kDWF, TPW_>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, y, carries, lb, C, (int)N,  \
+                           nt, vec, lookahead, sample_rate, eps, G, words, counters, tag)
+        if (mode == 0) { if (tpw == 1) { DASP_DYN_FWD_LB(0, 1); } else if (tpw == 2) { DASP_DYN_FWD_LB(0, 2); } else { DASP_DYN_FWD_LB(0, 4); } }
+        else { if (tpw == 1) { DASP_DYN_FWD_LB(1, 1); } else if (tpw == 2) { DASP_DYN_FWD_LB(1, 2); } else { DASP_DYN_FWD_LB(1, 4); } }
+#undef DASP_DYN_FWD_LB
+    }
+    else if (counters && G <= DY_GMAX) { if (mode == 0) { DASP_DYN_FWD_SEG2(0); } else { DASP_DYN_FWD_SEG2(1); } }
     else if (mode == 0) { DASP_DYN_FWD_SEG(0); } else { DASP_DYN_FWD_SEG(1); }
 #undef DASP_DYN_FWD_SEG2
 #undef DASP_DYN_FWD_SEG
@@ -632,7 +864,6 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
     float* z = segbuf;
     float* start = segbuf + (size_t)B * G;
     hipStream_t st = (hipStream_t)stream;
-    if (counters) { const hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4 * (size_t)B, st); if (e != hipSuccess) return (int)e; }
 #define DASP_DYN_BWD_SEG(MODE_, DMA_)                                                                                                            \
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 2>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, (float*)nullptr, \
                        (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z);               \
@@ -648,6 +879,19 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 1>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials,    \
                        C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr, counters,           \
                        (float*)nullptr, gctl)
+    /* one launch (dyn_bwd_kernel<SEG = 3>): two tiles per backward wave, the LDS-ring variant; a workgroup waits for the item's LATER
+       segments, which are running or about to: the dispatcher hands out workgroups in index order and an item's G fit the device */
+    if (DASP_DYN_LOOKBACK && counters && dma && Tseg == 2 * kDW && G <= DY_GMAX && G <= dyn_compute_units() && !(reinterpret_cast<uintptr_t>(segbuf) & 7)) {
+        static std::atomic<unsigned> calls{0x6C8E9CF5u};
+        const unsigned tag = calls.fetch_add(0x9E3779B1u) | 1u;
+        if (mode == 0)
+            hipLaunchKernelGGL((dyn_bwd_kernel<0, kDW, true, 3>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials, C, (int)N, nt,
+                               vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, segbuf, counters, (float*)nullptr, gctl, tag);
+        else
+            hipLaunchKernelGGL((dyn_bwd_kernel<1, kDW, true, 3>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials, C, (int)N, nt,
+                               vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, segbuf, counters, (float*)nullptr, gctl, tag);
+        return dy_check();
+    }
     if (counters && G <= DY_GMAX) {
         if (mode == 0) { if (dma) { DASP_DYN_BWD_SEG2(0, true); } else { DASP_DYN_BWD_SEG2(0, false); } }
         else { if (dma) { DASP_DYN_BWD_SEG2(1, true); } else { DASP_DYN_BWD_SEG2(1, false); } }

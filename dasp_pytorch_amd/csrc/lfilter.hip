@@ -284,8 +284,8 @@ int lfilt_backward_t(const T* gy, const double* bn, const double* an, const doub
     long L; int P;
     lf_plan(rows, N, chunk, &L, &P);
     if (P > 1 && (!work || work_doubles < lf_work_doubles(rows, P, M))) return DASP_ERR_ARG;
-    hipError_t e = hipMemsetAsync(gb, 0, sizeof(double) * (size_t)rows * K, st);
-    if (e == hipSuccess) e = hipMemsetAsync(ga, 0, sizeof(double) * (size_t)rows * K, st);
+    hipError_t e = zero_async(gb, sizeof(double) * (size_t)rows * K, st);
+    if (e == hipSuccess) e = zero_async(ga, sizeof(double) * (size_t)rows * K, st);
     if (e != hipSuccess) return (int)e;
     double *E = nullptr, *S = nullptr, *Phi = nullptr;
     if (P > 1) {

@@ -284,7 +284,7 @@ int dasp_sos64_backward(const double* c5, int Bs, const double* gy, const double
     if (!c5 || !gy || !gx || B <= 0 || C <= 0 || N <= 0 || S <= 0 || (Bs != 1 && Bs != B) || (gc5 && !wsave)) return DASP_ERR_ARG;
     const int rows = B * C;
     if (gc5) {
-        const hipError_t e = hipMemsetAsync(gc5, 0, sizeof(double) * (size_t)Bs * S * 5, (hipStream_t)stream);
+        const hipError_t e = zero_async(gc5, sizeof(double) * (size_t)Bs * S * 5, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(sos64_bwd_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, c5, Bs == 1 && B != 1, gy, gc5 ? wsave : nullptr, gx,
@@ -326,7 +326,7 @@ int dasp_ew64_forward(int op, const double* x, const double* ctl, double* y, int
 }
 int dasp_ew64_backward(int op, const double* x, const double* ctl, const double* gy, double* gx, double* gctl, int B, int C, long N, void* stream) {
     if (!x || !ctl || !gy || !gx || !gctl || B <= 0 || C <= 0 || N <= 0 || (op != 0 && op != 1)) return DASP_ERR_ARG;
-    const hipError_t e = hipMemsetAsync(gctl, 0, sizeof(double) * (size_t)(op == 0 ? B : B * C), (hipStream_t)stream);
+    const hipError_t e = zero_async(gctl, sizeof(double) * (size_t)(op == 0 ? B : B * C), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     if (op == 0) hipLaunchKernelGGL((ew64_kernel<0, true>), dim3(B * C), dim3(256), 0, (hipStream_t)stream, x, ctl, gy, gx, gctl, C, N);
     else hipLaunchKernelGGL((ew64_kernel<1, true>), dim3(B * C), dim3(256), 0, (hipStream_t)stream, x, ctl, gy, gx, gctl, C, N);

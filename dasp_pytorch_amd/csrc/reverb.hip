@@ -795,7 +795,7 @@ static int reverb_forward_impl(const float* x, const float* noise, unsigned long
     // 1. filter bank, envelope, gains, mean over bands -> impulse responses (functional.py:551-567)
     const int bsplit = rv_band_split(B, d.nwin, nb);
     if (bsplit > 1) {
-        const hipError_t e = hipMemsetAsync(ir, 0, sizeof(float) * (size_t)d.R * L, st);
+        const hipError_t e = zero_async(ir, sizeof(float) * (size_t)d.R * L, st);
         if (e != hipSuccess) return (int)e;
     }
     const float* taps_f = reinterpret_cast<const float*>(tw + (long)(nb + 1) * FFT_N);

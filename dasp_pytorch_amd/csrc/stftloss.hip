@@ -478,7 +478,7 @@ static int mrstft_backward_impl(const float* first, const float* second, const v
     StftSpec s;
     if (!sl_spec(N, nres, fft, hop, win, eps, &s)) return DASP_ERR_UNSUPPORTED;
     if (rows > 65535) return DASP_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(gfirst, 0, (size_t)rows * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return sl_check();
+    if (zero_async(gfirst, (size_t)rows * N * sizeof(float), (hipStream_t)stream) != hipSuccess) return sl_check();
     for (int r = 0; r < nres; ++r) {
         const int TC = FFT_N >> s.r[r].logF;
         const dim3 grid((unsigned)((s.r[r].frames + TC - 1) / TC), (unsigned)rows);

@@ -21,7 +21,11 @@
 #include <torch/csrc/autograd/autograd_not_implemented_fallback.h>
 #include <torch/library.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
+#include <hip/hip_runtime_api.h>
 
 #include "dasp_hip.h"
 
@@ -32,6 +36,26 @@ using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// The completion counters of the segmented compressor calls (dasp_hip.h: 4 ints per item, zero before their first use, every use returns
+// them to zero): one buffer per (device, stream), as ops._dyn_counters. Inside a graph capture a fresh zeroed buffer from the graph's
+// pool (a fill KERNEL node; the library no longer zeroes them with a memset node - csrc/dynamics.hip).
+Tensor dyn_counters(const Tensor& like, int64_t B) {
+    const auto opts = like.options().dtype(at::kInt);
+    hipStream_t st = (hipStream_t)stream_of(like);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone || B > 128) return at::zeros({4 * B}, opts);
+    static std::mutex mu;
+    static std::map<std::pair<int, void*>, Tensor> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair((int)like.device().index(), (void*)st);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() >= 64) cache.clear();
+        it = cache.emplace(key, at::zeros({4 * 128}, opts)).first;
+    }
+    return it->second;
+}
 
 void check_rc(int rc, const char* what) {
     TORCH_CHECK(rc == 0, what, " failed: ", rc == -1 ? "DASP_ERR_ARG (bad argument)" : rc == -2 ? "DASP_ERR_UNSUPPORTED" : "HIP error ", rc);
@@ -228,7 +252,7 @@ std::tuple<Tensor, Tensor, Tensor> dyn_forward(const Tensor& x, const Tensor& ct
     if (x32.numel() == 0) return {y, carries, lin};
     if (tseg) {
         Tensor segbuf = empty_f32(2 * B * dasp_dyn_segments(N, tseg), x32);
-        Tensor counters = at::empty({4 * B}, x32.options().dtype(at::kInt));       // zeroed by the call itself (dasp_hip.h)
+        Tensor counters = dyn_counters(x32, B);
         check_rc(dasp_dynamics_forward_seg((int)mode, x32.data_ptr<float>(), c32.data_ptr<float>(), y.data_ptr<float>(), fp(carries), fp(lin), fp(segbuf),
                                            (int)B, (int)C, N, sample_rate, (float)eps, (int)lookahead, tseg, counters.data_ptr<int>(), stream_of(x32)),
                  "dasp_dynamics_forward_seg");
@@ -254,7 +278,7 @@ std::tuple<Tensor, Tensor> dyn_backward(const Tensor& x, const Tensor& ctl, cons
     Tensor partials = empty_f32(dasp_dyn_partial_floats(B * G), x32);
     if (tseg) {
         Tensor segbuf = empty_f32(2 * B * G, x32);
-        Tensor counters = at::empty({4 * B}, x32.options().dtype(at::kInt));
+        Tensor counters = dyn_counters(x32, B);
         check_rc(dasp_dynamics_backward_seg((int)mode, x32.data_ptr<float>(), c32.data_ptr<float>(), g32.data_ptr<float>(), fp(carries), lookahead > 0 ? fp(lin) : nullptr,
                                             gx.data_ptr<float>(), gctl.data_ptr<float>(), fp(partials), fp(segbuf), (int)B, (int)C, N, sample_rate, (float)eps,
                                             (int)lookahead, tseg, counters.data_ptr<int>(), stream_of(x32)),

@@ -409,8 +409,8 @@ _DYN_COUNTERS = {}
 
 def _dyn_counters(dev):
     """The completion counters of the segmented dynamics calls (4 ints per batch item, one buffer per (device, stream): 4 * 128 ints, and
-    the segmented path is only taken up to 128 items - the size contract of dasp_hip.h; the C entry points zero the 4 * B words they use
-    at the start of every call). Inside a HIP-graph capture a fresh buffer is used and not kept: it belongs to the graph's pool."""
+    the segmented path is only taken up to 128 items - the size contract of dasp_hip.h: zero before the first use, every call returns
+    the words it used to zero). Inside a HIP-graph capture a fresh zeroed buffer is used and not kept: it belongs to the graph's pool."""
     capturing = torch.cuda.is_current_stream_capturing()
     key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
     t = None if capturing else _DYN_COUNTERS.get(key)

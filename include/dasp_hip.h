@@ -250,11 +250,16 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
 int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
                                const float* lin_buf, float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N,
                                double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
-/* counters (may be NULL): a buffer of AT LEAST 4 * B ints owned by the caller, one buffer per stream (size contract: the library cannot see
- * the allocation; it zeroes exactly 4 * B ints on the stream at the start of every call - round 4 - so a word left non-zero by a call that
- * failed half-way cannot poison later calls). With them the item's last workgroup of a pre-pass chains the segments and the last one of
- * the adjoint pass forms the control gradients: two launches per direction instead of three / four (workgroup to workgroup by agent-scope
- * atomics with a release / acquire counter, csrc/common.hpp handoff_arrive_is_last, as for the biquad cascade). */
+/* counters (may be NULL): a buffer of AT LEAST 4 * B ints owned by the caller, one buffer per stream, ZERO before its first use; every
+ * call returns the words it used to zero. (Rounds 3 - 4 zeroed them with hipMemsetAsync at the start of every call; inside a captured
+ * graph that memset node was not ordered before the kernel behind it when a replay started on an idle device, so the library zeroes
+ * nothing with memset nodes any more - csrc/common.hpp zero_async.) With them the forward pass is ONE launch when Tseg is 1, 2 or 4
+ * tiles per forward wave (16, 32, 64: every workgroup runs its segment from a zero state, hands the segment's end state on as a tagged
+ * 64-bit word in segbuf - 8-byte aligned - and corrects its tile carries by the look-back sum over the item's earlier segments; the
+ * smoothing state is one float that enters linearly) and the backward pass is one launch when Tseg is two tiles per backward wave (16)
+ * with lookahead 0, C <= 2 and 16-byte aligned rows; otherwise the item's last workgroup of a pre-pass chains the segments and the last
+ * one of the adjoint pass forms the control gradients: two launches per direction instead of three / four (workgroup to workgroup by
+ * agent-scope atomics, csrc/common.hpp handoff_arrive_is_last, as for the biquad cascade). */
 
 /* ---------------------------------------------------------------------------------------------
  * Noise-shaped reverberation.  Replaces dasp_pytorch.functional.noise_shaped_reverberation

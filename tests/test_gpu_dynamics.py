@@ -200,10 +200,12 @@ def test_config3_full_size_properties(D, monkeypatch):
 
 
 @pytest.mark.parametrize("B,C,N,look,tiles,mode", [(2, 2, 40000, 0, None, "compressor"), (3, 1, 65536, 0, 32, "compressor"), (1, 2, 262144, 0, None, "compressor"),
-                                                   (2, 2, 33333, 5, 16, "compressor"), (2, 1, 16384 + 512 + 3, 0, 16, "expander"), (8, 2, 262144, 0, None, "compressor")])
+                                                   (2, 2, 33333, 5, 16, "compressor"), (2, 1, 16384 + 512 + 3, 0, 16, "expander"), (8, 2, 262144, 0, None, "compressor"),
+                                                   (2, 1, 131072 + 100, 0, 64, "expander"), (2, 2, 100000, 3, 64, "compressor")])
 def test_segmented_items_equal_plain_items(D, monkeypatch, B, C, N, look, tiles, mode):
-    """Few batch items: the segmented kernels (scan-only pre-pass, scalar chain through alpha^(samples per segment), per-segment pass;
-    dasp_hip.h "Few batch items") give what one workgroup per item gives - outputs, input gradients and control gradients to fp32
+    """Few batch items: the segmented kernels (forward: one launch, zero-start sweep + look-back over the earlier segments' end states with
+    1 / 2 / 4 tiles per wave, dyn_fwd_lookback_kernel; backward: scan-only pre-pass, scalar chain through alpha^(samples per segment),
+    per-segment pass; dasp_hip.h "Few batch items") give what one workgroup per item gives - outputs, input gradients and control gradients to fp32
     rounding of the chained state - on full and ragged lengths, with look-ahead (the register-staged backward variant), for the
     expander, and with a last segment shorter than the others; and the segmented path agrees with the oracle."""
     rng = np.random.default_rng(B * 1000 + N)
@@ -233,3 +235,46 @@ def test_segmented_items_equal_plain_items(D, monkeypatch, B, C, N, look, tiles,
         pd = p.astype(np.float64)
         yo = orc.compressor(x, SR, *[pd[:, i] for i in range(6)], lookahead_samples=look)
         assert linf_peak(ys, yo).max() < 2e-5
+
+
+def test_segmented_forward_look_back_survives_graph_replay(D):
+    """The one-launch segmented forward pass hands segment end states on as tagged words that the item's last reader returns to zero; a
+    captured graph replays with the capture's tag, so every replay must find clean words: three replays with new inputs in the same buffers
+    give what eager calls give."""
+    from dasp_pytorch_amd import _lib
+    B, C, N = 4, 2, 65536
+    assert _lib.lib().dasp_dyn_segment_tiles(B, N) > 0
+    rng = np.random.default_rng(11)
+    p = rand_params(rng, B)
+    p[:, 2] = 100.0
+    cols = [dev(p[:, i].copy()).requires_grad_(True) for i in range(6)]
+    xs = dev(speechlike(rng, B, C, N)).requires_grad_(True)
+    ws = dev(rng.standard_normal((B, C, N)).astype(np.float32))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            D.compressor(xs, SR, *cols).backward(ws)
+    torch.cuda.current_stream().wait_stream(s)
+    xs.grad = None
+    for c in cols:
+        c.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ys = D.compressor(xs, SR, *cols)
+        ys.backward(ws)
+    for k in range(3):
+        xn = dev(speechlike(rng, B, C, N)); wn = dev(rng.standard_normal((B, C, N)).astype(np.float32))
+        with torch.no_grad():
+            xs.copy_(xn); ws.copy_(wn)
+        xs.grad.zero_()
+        for c in cols:
+            c.grad.zero_()
+        graph.replay()
+        xe = xn.clone().requires_grad_(True)
+        ce = [c.detach().clone().requires_grad_(True) for c in cols]
+        ye = D.compressor(xe, SR, *ce)
+        ye.backward(wn)
+        assert torch.equal(ys, ye) and torch.equal(xs.grad, xe.grad)
+        errs = [(float((a.grad - b.grad).abs().max()), float(b.grad.abs().max())) for a, b in zip(cols, ce)]
+        assert all(e <= 1e-4 * m for e, m in errs), (k, errs)         # (fp32 partial sums: the order is not fixed)
