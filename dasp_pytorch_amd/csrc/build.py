@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libdasp_hip.so")
 ARCH = "gfx950"
 
 
-def kernel_source_hash(files=("sosfilt.hip", "sos_tile.hpp", "common.hpp"), root=HERE):
+def kernel_source_hash(files=("sosfilt.hip", "sos_tile.hpp", "sos_gram_fin.hpp", "common.hpp"), root=HERE):
     """sha256 (16 hex digits) over the code of the cascaded-biquad kernels - comments stripped, whitespace collapsed - so that off-line
     measurements (profiles/rNN/hbm_traffic.json) can be tied to the kernels they were taken from without breaking on a reworded comment."""
     import hashlib

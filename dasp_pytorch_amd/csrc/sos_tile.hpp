@@ -26,15 +26,8 @@
 #define DASP_PRIO_WIDE 1     // 1: also the load / transposition and store phases of a tile, i.e. everything but the cascade
 #endif
 #define WIDE_PRIO(p) do { if (DASP_SCAN_PRIO && DASP_PRIO_WIDE) __builtin_amdgcn_s_setprio(p); } while (0)
-#ifndef DASP_BWD_DIRECT_GX
-#define DASP_BWD_DIRECT_GX 0      // backward kernel: gx stored by every lane from its registers (64 contiguous bytes per lane) instead of through a staging image
-#endif
 #ifndef DASP_DIRECT_OUT
 #define DASP_DIRECT_OUT 1         // forward / Gram backward kernels, full tiles: the matrix-core output granules go straight to memory (no staging image)
-#endif
-#ifndef DASP_SPLIT_COUPLING
-#define DASP_SPLIT_COUPLING 0     // lane scan: the coupling sum of sections >= 3 on two accumulators (shorter dependent chain, one more packed
-                                  // add). Measured: 0.396 -> 0.398 ms fwd + bwd, i.e. nothing (profiles/r02/ab_micro_variants.log)
 #endif
 
 namespace dasp {
@@ -362,18 +355,9 @@ __device__ __forceinline__ void tile_scan_h(const float (&Z)[L], FMap&& zmap, f2
         TRACE2(9);
         __builtin_amdgcn_sched_barrier(0);
         hook(k, 1);
-#if DASP_SPLIT_COUPLING
-        if (k >= 3) {       // two accumulators: the coupling sum is a dependent chain of 2 k packed FMAs otherwise
-            f2 fb = f2{0.f, 0.f};
+        // (the coupling sum on two accumulators - a shorter dependent chain, one more packed add - measured nothing: profiles/r02/ab_micro_variants.log)
 #pragma unroll
-            for (int j = 0; j < k; ++j) { if (j & 1) fb = blk_apply_s(MC[j], st[j], fb); else f = blk_apply_s(MC[j], st[j], f); }
-            f = f + fb;
-        } else
-#endif
-        {
-#pragma unroll
-            for (int j = 0; j < k; ++j) f = blk_apply_s(MC[j], st[j], f);
-        }
+        for (int j = 0; j < k; ++j) f = blk_apply_s(MC[j], st[j], f);
         pin(f); TRACE2(10);
         __builtin_amdgcn_sched_barrier(0);
         hook(k, 2);
