@@ -337,8 +337,9 @@ def secondary(dev):
                      "note": "default (reference-compatible) noise: torch.randn on the global CPU generator + H2D copy per call; device_noise=True "
                              "(the rows above) generates the same statistics inside the filter-bank kernels and removes both"}
         del x, w, noise
-    default_noise_wall("noise_shaped_reverberation_default_noise", 128, 262144, 2)
-    default_noise_wall("noise_shaped_reverberation_default_noise_b8", 8, 131072, 5)
+    if not os.environ.get("DASP_BENCH_SKIP_DEFAULT_NOISE"):        # (developer A/B: does this row disturb the rows behind it?)
+        default_noise_wall("noise_shaped_reverberation_default_noise", 128, 262144, 2)
+        default_noise_wall("noise_shaped_reverberation_default_noise_b8", 8, 131072, 5)
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
     # the boundary's long tail: lfilter_via_fsm with more than three coefficients (signal.py:95-133; csrc/lfilter.hip: double arithmetic,

@@ -43,7 +43,7 @@ long dasp_sos_dtab_doubles(int S);                /* fp64 side-table size per fi
 long dasp_sos_num_tiles(long N);
 long dasp_sos_carry_floats(long rows, long N, int S);   /* rows = B*C */
 long dasp_sos_partial_floats(long rows, int S);          /* scratch between the backward kernel and the finalize step (16-byte aligned; opaque:
-                                                          * one 32 x 32 fp64 Gram matrix per row, or per-wave correlation sums for segmented rows) */
+                                                          * one 32 x 32 fp64 Gram matrix per row or per (row, segment)) */
 
 /* sos: (Bs, S, 6) fp32, rows [b0 b1 b2 a0 a1 a2] (signal.py:141). Fills tab / dtab. */
 int dasp_sos_prepare(const float* sos, int Bs, int S, float* tab, double* dtab, void* stream);
@@ -87,11 +87,8 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
  *   gx == NULL        no input gradient: the adjoint output is neither transposed back nor stored (parametric_eq is the first effect of
  *                     the reference's chain, examples/style_transfer.py:150 - its input never needs one);
  *   partials == NULL  no coefficient gradients (a fixed filter): x and carries are not read, only the adjoint cascade runs;
- *   designed != 0     tab / dtab were filled by dasp_peq_prepare / dasp_peq_prepare_rows (RBJ design: every b0 > 0). The kernel then
- *                     recomputes the sections in monic form, drops the lag-0 correlation of every section and hands the finalize step
- *                     T = <adjoint output, input> of the last section instead (sum_i b_i dL/db_i = T for every section of a cascade);
- *                     the matching finalize call must carry the same flag. designed == 0 (tables from dasp_sos_prepare: any b0) keeps
- *                     all five correlations.
+ *   designed          accepted and ignored since round 5 (rounds 3 - 4: the recomputation kernels ran designed cascades in monic form;
+ *                     the Gram-matrix backward treats every cascade alike). Kept in the signatures for callers built against them.
  * dasp_sos_grad_finalize_ex: segments = rows of partial sums per (row, wave) (1 after dasp_sosfilt_backward*, dasp_sos_segments(N, Tseg)
  * after the *_seg calls); mode 2 = mode 1 written as 3*S rows of B values ([3 k + c][item]: one contiguous vector per control tensor). */
 int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
@@ -154,17 +151,23 @@ int dasp_biquad_design(const double* gain_db, const double* cutoff_freq, const d
                        double sample_rate, double* ba, double* jac, void* stream);
 int dasp_biquad_backward(const double* jac, const double* gba, int n, double* gparams, void* stream);
 
-/* Few rows (B*C <= 64; up to 256 rows the plain calls launch twice the waves per row instead): a row is one workgroup, so the calls above would leave most of the chip idle. The *_seg entry points cut
- * every row into segments of Tseg tiles that run as independent workgroups - a scan-only pre-pass gives every segment's end state, the
- * last of an item's workgroups to finish chains them through Phi^(samples per segment) (dasp_sos_segment_prepare, from dtab; the
- * completion counter is a word of the item's table, zeroed by the prepare call and reset after use - the one place where a call
- * writes into `tab`), then the ordinary pass runs per segment from its start state; same results (oracle/chunkscan_model.py
- * forward_row_segmented / backward_row_segmented). Launches per direction: pre-pass, pass (dasp_peq_forward / dasp_peq_backward: the
- * design launch also produces segtab and the last workgroup of the adjoint pass finalizes the gradients - five launches per step).
+/* Few rows (B*C <= 64; up to 256 rows the plain calls launch twice the waves per row instead): a row is one workgroup, so the calls above
+ * would leave most of the chip idle. The *_seg entry points cut every row into segments of Tseg tiles that run as independent workgroups;
+ * same results (oracle/chunkscan_model.py forward_row_segmented / backward_row_segmented).
+ *   dasp_sosfilt_forward_seg / dasp_sosfilt_backward_seg[_ex] (tables that may serve many calls): per direction a scan-only pre-pass gives
+ *     every segment's end state, the last of an item's workgroups to finish chains them through Phi^(samples per segment)
+ *     (dasp_sos_segment_prepare, from dtab; the completion counters are words of the item's table, zeroed by the prepare call and reset
+ *     after use - the one place where a call writes into `tab`), then the ordinary pass runs per segment from its start state.
+ *   dasp_peq_forward* / dasp_peq_backward (a design launch per call): ONE launch per direction - every workgroup sweeps its segment
+ *     scan-only, hands the end state on as tagged 64-bit words in segbuf (8-byte aligned) and takes its start state from the words of the
+ *     row's other segments (a decoupled look-back; the tag is drawn by the call's design launch, so dasp_peq_backward needs tables filled
+ *     by dasp_peq_forward* of the same step), then runs the pass; the backward launch also finalizes the control gradients. Three
+ *     launches per step: design, forward, backward.
  *   Tseg   = dasp_sos_segment_tiles(rows, N): proposed tiles per segment (a power of two), 0 = use the plain calls
- *   segtab = dasp_sos_segtab_doubles(S) doubles per item (Bs items);  segbuf = dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch
+ *   segtab = dasp_sos_segtab_doubles(S) doubles per item (Bs items): the two segment transition matrices + the basis responses of the Gram
+ *            finalize step (filled by the design launch of dasp_peq_forward*);  segbuf = dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch
  *   partials of the backward pass: dasp_sos_partial_floats(rows * dasp_sos_segments(N, Tseg), S) floats, finalized by
- *   dasp_sos_grad_finalize_seg(..., segments = dasp_sos_segments(N, Tseg), ...). */
+ *   dasp_sos_grad_finalize_seg(..., segments = dasp_sos_segments(N, Tseg), ...) after dasp_sosfilt_backward_seg*. */
 long dasp_sos_segment_tiles(long rows, long N);
 long dasp_sos_segments(long N, long Tseg);
 long dasp_sos_segtab_doubles(int S);
