@@ -84,27 +84,56 @@ TORCH_EXT_SRC = os.path.join(HERE, "torch_ext", "dasp_torch_ops.cpp")
 TORCH_EXT = os.path.join(HERE, "libdasp_torch.so")
 
 
-def build_torch_ext(force=False, verbose=False):
-    """csrc/torch_ext/dasp_torch_ops.cpp -> csrc/libdasp_torch.so: the TORCH_LIBRARY registration of the chain ops (torch.ops.dasp.*) over the
-    C ABI. Host-only C++ (no kernels): compiled with g++ against the torch headers of the running interpreter and linked to libdasp_hip.so
-    next to it ($ORIGIN). In-tree, like the kernel library, so that it travels to the GPU box and shows up among the loaded objects."""
-    lib = build_lib()
-    if not force and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= max(os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(lib), os.path.getmtime(HEADER)):
-        return TORCH_EXT
+TORCH_EXT_OBJ = os.path.join(HERE, "torch_ext", "dasp_torch_ops.o")
+
+
+def _torch_ext_cmds():
     import torch
     from torch.utils import cpp_extension
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = [f"-I{p}" for p in cpp_extension.include_paths()] + ["-I/opt/rocm/include", f"-I{os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include')}"]
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
-           f"-DDASP_ABI_HASH={abi_hash()}LL"] + inc + [
-        TORCH_EXT_SRC, "-o", TORCH_EXT, f"-L{tlib}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{HERE}", "-ldasp_hip",
-        "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    compile_cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+                   f"-DDASP_ABI_HASH={abi_hash()}LL"] + inc + ["-c", TORCH_EXT_SRC, "-o", TORCH_EXT_OBJ]
+    link_cmd = ["g++", "-shared", "-fPIC", TORCH_EXT_OBJ, "-o", TORCH_EXT, f"-L{tlib}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{HERE}", "-ldasp_hip",
+                "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    return compile_cmd, link_cmd
+
+
+def _compile_torch_ext_obj(force=False, verbose=False):
+    """The extension's one translation unit (needs the torch headers and include/dasp_hip.h only - not the kernel library)."""
+    if not force and os.path.exists(TORCH_EXT_OBJ) and os.path.getmtime(TORCH_EXT_OBJ) >= max(os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(HEADER)):
+        return False
+    cmd = _torch_ext_cmds()[0]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return True
+
+
+def build_torch_ext(force=False, verbose=False):
+    """csrc/torch_ext/dasp_torch_ops.cpp -> csrc/libdasp_torch.so: the TORCH_LIBRARY registration of torch.ops.dasp.* over the C ABI.
+    Host-only C++ (no kernels): compiled with g++ against the torch headers of the running interpreter and linked to libdasp_hip.so
+    next to it ($ORIGIN). In-tree, like the kernel library, so that it travels to the GPU box and shows up among the loaded objects."""
+    lib = build_lib()
+    recompiled = _compile_torch_ext_obj(force, verbose)
+    if not recompiled and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= max(os.path.getmtime(TORCH_EXT_OBJ), os.path.getmtime(lib)):
+        return TORCH_EXT
+    cmd = _torch_ext_cmds()[1]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     return TORCH_EXT
 
 
+def build_all(force=False, verbose=False):
+    """Kernel library and torch extension; the extension's g++ compile (~20 s of torch headers) runs beside the hipcc jobs."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        obj = pool.submit(_compile_torch_ext_obj, force, verbose)
+        lib = build_lib(force, verbose)
+        obj.result()
+    return lib, build_torch_ext(verbose=verbose)
+
+
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
-    print(build_torch_ext(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))
