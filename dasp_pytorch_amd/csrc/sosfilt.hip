@@ -564,48 +564,56 @@ __device__ __forceinline__ void lookback_publish(unsigned long long* w, float v,
 }
 // (The reader - lookback_start - polls until a word carries the launch's tag; it gives up after ~0.5 s: a workgroup it waits for has a
 // smaller index and is running or done, the bound only keeps a corrupted buffer from hanging the device; the outputs then show NaN.)
-// start(seg) = sum_{j < seg} Phi^(seg - 1 - j) z(j) by Horner, fp64 (chain_by_last_workgroup's arithmetic, the same order: the same bits), by
-// ONE wave: z64 = the row's words [segment][2S]; order +1: segments 0 .. seg - 1 ascending (forward system), -1: G - 1 .. seg + 1 descending
+// start(seg) = sum_{j < seg} Phi^(seg - 1 - j) z(j) by Horner, fp64 (chain_by_last_workgroup's arithmetic, the same order: the same bits).
+// Called by the WHOLE workgroup (it contains barriers): every thread polls one word per round - a lane that walked its three words one
+// after the other paid three memory round trips, ~1 us each, on the critical path of the row's last segment - then wave 0 runs the chain.
+// z64 = the row's words [segment][2S]; order +1: segments 0 .. seg - 1 ascending (forward system), -1: G - 1 .. seg + 1 descending
 // (adjoint system). The result goes into the inbox of the wave that owns the segment's first tile: slots [k][4] = (state, sequence number).
-template <int S>
+template <int S, int W>
 __device__ __forceinline__ void lookback_start(const unsigned long long* z64, int seg, int G, int order, const double* __restrict__ Phi, unsigned tag,
-                                               float* inbox, int seq, float* zs /* LDS, >= 64 * 2S floats */, double (*st)[2 * S] /* LDS [2][2S] */) {
+                                               float* inbox, int seq, float* zs /* LDS, >= 64 * 2S floats, no wave's private data */,
+                                               double (*st)[2 * S] /* LDS [2][2S] */) {
     constexpr int S2 = 2 * S, GB = 64;
-    const int l = lane_id();
+    const int l = lane_id(), w = wave_id();
     const int npred = order > 0 ? seg : G - 1 - seg, first = order > 0 ? 0 : G - 1;
     double prow[S2];
 #pragma unroll
-    for (int j = 0; j < S2; ++j) prow[j] = l < S2 && npred > 0 ? Phi[l * S2 + j] : 0.0;
-    if (l < S2) st[0][l] = 0.0;
+    for (int j = 0; j < S2; ++j) prow[j] = w == 0 && l < S2 && npred > 0 ? Phi[l * S2 + j] : 0.0;
+    if (w == 0 && l < S2) st[0][l] = 0.0;
     int cur = 0;
-    for (int n0 = 0; n0 < npred; n0 += GB) {
+    __syncthreads();                                   // every wave is through its sweep: zs and the mailboxes are free
+    for (int n0 = 0; n0 < npred; n0 += GB) {           // (uniform over the workgroup: the barriers below are reached by every thread)
         const int nblk = npred - n0 < GB ? npred - n0 : GB;
-        wave_lds_sync();
-        for (int e = l; e < nblk * S2; e += 64) {
+        if (n0) __syncthreads();                       // the previous block's chain has read zs
+        for (int e = threadIdx.x; e < nblk * S2; e += 64 * W) {
             const unsigned long long* wp = z64 + (size_t)(first + order * (n0 + e / S2)) * S2 + e % S2;
             float v = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
             for (int spin = 0; spin < (1 << 22); ++spin) {
-                const unsigned long long w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(w >> 32) == tag) { v = __builtin_bit_cast(float, (unsigned)w); break; }
+                const unsigned long long wd = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(wd >> 32) == tag) { v = __builtin_bit_cast(float, (unsigned)wd); break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             zs[e] = v;
         }
-        wave_lds_sync();
-        for (int i = 0; i < nblk; ++i) {
-            if (l < S2) {
-                double acc = (double)zs[i * S2 + l];
+        __syncthreads();
+        if (w == 0) {
+            for (int i = 0; i < nblk; ++i) {
+                if (l < S2) {
+                    double acc = (double)zs[i * S2 + l];
 #pragma unroll
-                for (int j = 0; j < S2; ++j) acc += prow[j] * st[cur][j];
-                st[cur ^ 1][l] = acc;
+                    for (int j = 0; j < S2; ++j) acc += prow[j] * st[cur][j];
+                    st[cur ^ 1][l] = acc;
+                }
+                wave_lds_sync();
+                cur ^= 1;
             }
-            wave_lds_sync();
-            cur ^= 1;
         }
     }
-    wave_lds_sync();
-    if (l < S2) inbox[4 * (l >> 1) + (l & 1)] = (float)st[cur][l];
-    if (l < S) inbox[4 * l + 2] = __builtin_bit_cast(float, seq);
+    if (w == 0) {
+        wave_lds_sync();
+        if (l < S2) inbox[4 * (l >> 1) + (l & 1)] = (float)st[cur][l];
+        if (l < S) inbox[4 * l + 2] = __builtin_bit_cast(float, seq);
+    }
 }
 
 template <int S, int L, int W, int SEG = 0>
@@ -665,9 +673,9 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
 
     // One sweep over the workgroup's tiles. SCAN: the lane scans only (a pre-pass: nothing is stored but the segment's end state);
     // seq0: added to the mailboxes' sequence numbers (a second sweep must not mistake the first one's entries for its own).
-    auto sweep = [&](auto scan_tag, const int seq0) {
+    auto sweep = [&](auto scan_tag, const int seq0, const bool first_tile_requested = false) {
         constexpr bool SCAN = decltype(scan_tag)::value;
-        if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
+        if (!first_tile_requested && t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
         int stores_in_flight = 0;
         for (int t = t0 + wave; t < t1; t += W) {
             int toff = 0;
@@ -749,12 +757,12 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // the start state from the end states of the segments in front of this one -> wave 0's inbox, sequence t0 + SEQ2
         constexpr int SEQ2 = 1 << 28;
         __shared__ double lb_st[2][S2];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (no LDS-DMA in flight into the images the look-back stages its loads in)
+        // the output sweep's first x tile is on its way while the look-back runs (the look-back stages its words in wave 0's y image, idle
+        // between the sweeps; the x images are the waves' own)
+        if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
+        lookback_start<S, W>(z64, seg, G, 1, segtab + (size_t)(tab_bcast ? 0 : row / C) * 2 * S2 * S2, tag, lds, t0 + SEQ2, pw_lds + LDS_PW + IMG, lb_st);
         __syncthreads();
-        if (wave == 0)
-            lookback_start<S>(z64, seg, G, 1, segtab + (size_t)(tab_bcast ? 0 : row / C) * 2 * S2 * S2, tag, lds, t0 + SEQ2, tbx, lb_st);
-        __syncthreads();
-        sweep(std::false_type{}, SEQ2);
+        sweep(std::false_type{}, SEQ2, true);
     } else if (SEG == 2) {
         sweep(std::true_type{}, 0);
     } else {
@@ -1173,13 +1181,13 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
             SCAN_PRIO(0);
         }
         __shared__ double lb_st[2][2 * S];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (no LDS-DMA in flight into the image the look-back stages its loads in)
-        __syncthreads();
-        if (wave == 0)
-            lookback_start<S>(z64, seg, G, -1, fz.segtab_adj + (size_t)(row / C) * 2 * (2 * S) * (2 * S), tag, lds, t1 + SEQ2, tbg, lb_st);
+        // the pass's first gy tile is on its way as well now (x and the saved states since before the sweep); the look-back stages its words
+        // in wave 0's scratch image, idle between tiles
+        if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec), 2);
+        lookback_start<S, W>(z64, seg, G, -1, fz.segtab_adj + (size_t)(row / C) * 2 * (2 * S) * (2 * S), tag, lds, t1 + SEQ2, pw_lds + LDS_PW + 3 * IMG, lb_st);
         __syncthreads();
     }
-    if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec), SEG == 3 ? 2 : 7);
+    if (SEG != 3 && wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec));
     int stores_in_flight = 0;
     float Aop[4], AT[4], AO[4];
     chunk_table_operands<S, L>(tb + LY::GAT, Aop, lane);

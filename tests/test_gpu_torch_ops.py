@@ -275,7 +275,15 @@ def _new_op_samples():
 def test_opcheck_reference_signatures(T, case):
     samples = _new_op_samples()
     op = getattr(torch.ops.dasp, case.split("_shared")[0].split("_lookahead")[0]).default
-    res = torch.library.opcheck(op, samples[case], raise_exception=True)
+    if case == "noise_shaped_reverb":
+        # few items: the filter bank deals its bands out over workgroups that add into the impulse responses with float atomics - the order
+        # is not fixed, and opcheck compares eager gradients with AOTDispatcher's at a tight tolerance (one run in ~10 differed); one
+        # workgroup per window makes the op deterministic for the comparison
+        from tests.test_gpu_reverb import reverb_plan
+        with reverb_plan(band_split=1):
+            res = torch.library.opcheck(op, samples[case], raise_exception=True)
+    else:
+        res = torch.library.opcheck(op, samples[case], raise_exception=True)
     assert all(v == "SUCCESS" for v in res.values()), res
 
 
