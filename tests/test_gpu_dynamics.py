@@ -201,7 +201,8 @@ def test_config3_full_size_properties(D, monkeypatch):
 
 @pytest.mark.parametrize("B,C,N,look,tiles,mode", [(2, 2, 40000, 0, None, "compressor"), (3, 1, 65536, 0, 32, "compressor"), (1, 2, 262144, 0, None, "compressor"),
                                                    (2, 2, 33333, 5, 16, "compressor"), (2, 1, 16384 + 512 + 3, 0, 16, "expander"), (8, 2, 262144, 0, None, "compressor"),
-                                                   (2, 1, 131072 + 100, 0, 64, "expander"), (2, 2, 100000, 3, 64, "compressor")])
+                                                   (2, 1, 131072 + 100, 0, 64, "expander"), (2, 2, 100000, 3, 64, "compressor"),
+                                                   (24, 1, 262144, 0, 16, "compressor")])       # 24 x 32 = 768 workgroups: three rounds of the look-back launches
 def test_segmented_items_equal_plain_items(D, monkeypatch, B, C, N, look, tiles, mode):
     """Few batch items: the segmented kernels (forward: one launch, zero-start sweep + look-back over the earlier segments' end states with
     1 / 2 / 4 tiles per wave, dyn_fwd_lookback_kernel; backward: scan-only pre-pass, scalar chain through alpha^(samples per segment),

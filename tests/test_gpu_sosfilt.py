@@ -439,7 +439,8 @@ def test_backward_grads_entry_equals_two_calls(D, Bs_shared):
 
 
 @pytest.mark.parametrize("B,C,N,bcast,tiles", [(2, 2, 40000, False, None), (3, 1, 65536, False, 16), (1, 2, 131072, False, None),
-                                               (4, 2, 33333, True, 8), (2, 1, 16385, False, 8)])
+                                               (4, 2, 33333, True, 8), (2, 1, 16385, False, 8),
+                                               (32, 2, 131072, False, None)])      # 64 rows x 16 segments = 1024 workgroups: two rounds of the look-back launches
 def test_segmented_rows_equal_plain_rows(D, monkeypatch, B, C, N, bcast, tiles):
     """Few rows: the segmented-row kernels (scan-only pre-pass, chained segment start states, per-segment pass; dasp_hip.h) give what
     one workgroup per row gives - outputs to the last bits, input gradients to fp32 rounding, parameter gradients to summation order - on full and
