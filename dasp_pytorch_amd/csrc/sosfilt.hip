@@ -1414,7 +1414,7 @@ constexpr int kWBA = DASP_BWD_W_ADJ;   // ... of the adjoint-only kernel (~100 r
 
 // At most one row per CU (B * C <= 256 rows, one workgroup each): twice the waves per row - the same waves per CU as two rows of the
 // ordinary width, on one row (one workgroup per CU fits: LDS 134 / 139 KiB). Rows are latency-bound there: (64..128, 2, 131072) EQ steps
-// took the same 0.23 ms as a 256-row batch, and cutting rows into segments does not pay above 64 rows (profiles/r04/seg_crossover.log).
+// took the same 0.23 ms as a 256-row batch; cutting rows into segments pays up to 128 rows (dasp_sos_segment_tiles), not above.
 inline bool wide_rows(long rows) { return rows <= 256; }
 
 inline int check_launch() {
@@ -1627,9 +1627,10 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
 // dasp_sos_seg_floats(rows, N, S, Tseg) floats of scratch; partials: dasp_sos_partial_floats(rows * segments, S).
 long dasp_sos_segment_tiles(long rows, long N) {
     const long nt = dasp_sos_num_tiles(N);
-    // (more than 64 rows: one workgroup per row at twice the waves - wide_rows - is as fast or faster, 0.178 against 0.179..0.190 ms at
-    // (40..63, 2, 131072), and its backward pass is the Gram-matrix kernel: profiles/r04/seg_crossover.log)
-    if (rows <= 0 || rows > 64 || nt < 16) return 0;
+    // (more than 128 rows: one workgroup per row at twice the waves - wide_rows - is faster. Round 4 drew the line at 64 rows, when a
+    // segmented step was five launches; with three (round 5) segments pay up to 128 rows: (40 / 48 / 64, 2, 131072) 0.173 -> 0.158 /
+    // 0.159 / 0.170 ms, and lose beyond: (96, 2, 131072) 0.180 -> 0.259 - profiles/r05/seg_crossover.log)
+    if (rows <= 0 || rows > 128 || nt < 16) return 0;
     long T = 8;                                        // at least one tile per forward wave
     // two workgroups per CU: measured at (8 / 16 / 32, 2, 131072) forward + backward 0.107 / 0.114 / 0.142 ms with this rule against 0.106 /
     // 0.114 / 0.162 ms with up to four per CU and 0.12 / 0.12 / 0.167 with one (profiles/r02/segment_length_sweep.log)

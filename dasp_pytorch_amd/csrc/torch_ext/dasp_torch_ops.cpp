@@ -103,8 +103,12 @@ Tensor empty_f32(long n, const Tensor& like) { return at::empty({n}, like.option
 // this file reads no environment).
 int64_t g_sos_tiles_override = -1, g_dyn_tiles_override = -1;
 void plan_override(int64_t sos_tiles, int64_t dyn_tiles) { g_sos_tiles_override = sos_tiles; g_dyn_tiles_override = dyn_tiles; }
-int64_t sos_segment_tiles(int64_t rows, int64_t N) {
-    return g_sos_tiles_override >= 0 ? g_sos_tiles_override : dasp_sos_segment_tiles(rows, N);
+// generic: a cascade given by its coefficients (sosfilt: no design launch per call, so its segmented rows keep the pre-pass launches, five
+// launches per step) - there segments stop paying above 64 rows (profiles/r04/seg_crossover.log); the designed paths (three launches) go
+// up to the planner's 128 (profiles/r05/seg_crossover.log)
+int64_t sos_segment_tiles(int64_t rows, int64_t N, bool generic = false) {
+    if (g_sos_tiles_override >= 0) return g_sos_tiles_override;
+    return generic && rows > 64 ? 0 : dasp_sos_segment_tiles(rows, N);
 }
 struct PeqDims { int64_t B, C, N, Bp, S; };
 PeqDims peq_check(const Tensor& x, const Tensor& pn, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span) {
@@ -867,12 +871,12 @@ std::tuple<Tensor, Tensor> sosfilt_backward(const Tensor& x, const Tensor& gy, c
 }
 Tensor sosfilt_device(const Tensor& sos, const Tensor& x) {
     const SosDims d = sos_check(sos, x);
-    return std::get<0>(sosfilt_forward(sos, x, sos_segment_tiles(d.B * d.C, d.N), false));
+    return std::get<0>(sosfilt_forward(sos, x, sos_segment_tiles(d.B * d.C, d.N, true), false));
 }
 struct SosFn : public torch::autograd::Function<SosFn> {
     static Tensor forward(AutogradContext* ctx, const Tensor& sos, const Tensor& x) {
         const SosDims d = sos_check(sos, x);
-        const int64_t tseg = sos_segment_tiles(d.B * d.C, d.N);
+        const int64_t tseg = sos_segment_tiles(d.B * d.C, d.N, true);
         const bool need = sos.requires_grad() || x.requires_grad();
         at::AutoDispatchBelowADInplaceOrView below;
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_sosfilt_forward", "")

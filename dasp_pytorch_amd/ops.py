@@ -27,18 +27,22 @@ def _pad_sections(S):
     raise ValueError("more than 8 sections per call: chain calls (see signal.sosfilt_via_fsm)")
 
 
-def _segment_tiles(rows, N):
+def _segment_tiles(rows, N, generic=False):
     """Tiles per segment for the segmented-row kernels, 0 = one workgroup per row (dasp_hip.h, "Few rows").
     A row is one workgroup, so few rows (the reference's training batches are 8-32 items: examples/style_transfer.py:403,
     auto_eq.py:231) leave most of the 256 CUs idle; the segmented path takes 2-4x less GPU time there (16 x 2 x 131072: forward
     0.078 -> 0.032 ms, backward 0.177 -> 0.047 ms) for four more kernel launches per call, all issued by the same C call. It is taken
-    whenever the library's planner proposes a cut (at most 64 rows and at least 16 tiles per row; above that one workgroup per row runs at
-    twice the waves per row up to 256 rows and is as fast), eager or captured.
+    whenever the library's planner proposes a cut (at most 128 rows and at least 16 tiles per row; above that one workgroup per row runs at
+    twice the waves per row up to 256 rows and is faster), eager or captured.
     DASP_SOS_SEGMENT=0 never, DASP_SOS_SEGMENT_TILES=<power of two> fixes the segment length."""
     if os.environ.get("DASP_SOS_SEGMENT", "auto") == "0":
         return 0
     fixed = os.environ.get("DASP_SOS_SEGMENT_TILES")
-    return int(fixed) if fixed else int(_lib.lib().dasp_sos_segment_tiles(rows, N))
+    if fixed:
+        return int(fixed)
+    # generic: a cascade given by its coefficients (no design launch per call: its segmented rows keep the pre-pass launches, five launches
+    # per step) - there segments stop paying above 64 rows (profiles/r04/seg_crossover.log); the designed paths go up to the planner's 128
+    return 0 if generic and rows > 64 else int(_lib.lib().dasp_sos_segment_tiles(rows, N))
 
 
 def _round64(n):
@@ -49,11 +53,11 @@ class _SosWork:
     """Device work buffers of one filter application: one fp32 block (tables, saved chunk states, partial sums, segment scratch) and
     one fp64 block (design side table, segment transition matrices) - two allocations per call instead of one per buffer."""
 
-    def __init__(self, Bs, S, x, need_grad):
+    def __init__(self, Bs, S, x, need_grad, generic=False):
         L = _lib.lib()
         B, C, N = x.shape
         self.Bs, self.S = Bs, S
-        self.tseg = _segment_tiles(B * C, N)
+        self.tseg = _segment_tiles(B * C, N, generic)
         self.G = int(L.dasp_sos_segments(N, self.tseg))
         n_tab = _round64(Bs * L.dasp_sos_table_floats(S))
         n_car = _round64(L.dasp_sos_carry_floats(B * C, N, S)) if need_grad else 0
@@ -134,7 +138,7 @@ class SosFiltFunction(torch.autograd.Function):
                 sos32 = torch.cat([sos32, pad], 1).contiguous()
             x32 = _f32c(x)
             need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-            w = _SosWork(Bs, Sp, x32, need)
+            w = _SosWork(Bs, Sp, x32, need, generic=True)
             call("dasp_sos_prepare", ptr(sos32), Bs, Sp, ptr(w.tab), ptr(w.dtab), stream())
             y = w.forward(x32)
             if need:

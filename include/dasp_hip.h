@@ -151,7 +151,7 @@ int dasp_biquad_design(const double* gain_db, const double* cutoff_freq, const d
                        double sample_rate, double* ba, double* jac, void* stream);
 int dasp_biquad_backward(const double* jac, const double* gba, int n, double* gparams, void* stream);
 
-/* Few rows (B*C <= 64; up to 256 rows the plain calls launch twice the waves per row instead): a row is one workgroup, so the calls above
+/* Few rows (B*C <= 128; from there up to 256 rows the plain calls launch twice the waves per row instead): a row is one workgroup, so the calls above
  * would leave most of the chip idle. The *_seg entry points cut every row into segments of Tseg tiles that run as independent workgroups;
  * same results (oracle/chunkscan_model.py forward_row_segmented / backward_row_segmented).
  *   dasp_sosfilt_forward_seg / dasp_sosfilt_backward_seg[_ex] (tables that may serve many calls): per direction a scan-only pre-pass gives

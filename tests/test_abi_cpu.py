@@ -47,9 +47,9 @@ def test_segment_planning():
     L = _lib.lib()
     T = L.dasp_sos_tile()
     N = 128 * T
-    assert L.dasp_sos_segment_tiles(512, N) == 0 and L.dasp_sos_segment_tiles(65, N) == 0       # enough rows (65 .. 256: twice the waves per row instead)
+    assert L.dasp_sos_segment_tiles(512, N) == 0 and L.dasp_sos_segment_tiles(129, N) == 0      # enough rows (129 .. 256: twice the waves per row instead)
     assert L.dasp_sos_segment_tiles(8, 15 * T) == 0                                             # too short to cut
-    for rows in (1, 2, 16, 32, 64):
+    for rows in (1, 2, 16, 32, 64, 65, 96, 128):
         t = L.dasp_sos_segment_tiles(rows, N)
         g = L.dasp_sos_segments(N, t)
         assert t >= 8 and t & (t - 1) == 0 and g == -(-128 // t) and g > 1 and rows * g <= 1024

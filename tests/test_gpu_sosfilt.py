@@ -653,7 +653,7 @@ def test_sixteen_million_samples(D):
 
 def test_launch_shapes_agree(D):
     """The same items through the three launch shapes of a parametric_eq step - more than 256 rows (one workgroup of 8 + 4 waves per row),
-    65 .. 256 rows (twice the waves per row), at most 64 rows (rows cut into segments: scan-only pre-passes, chained segment states, the
+    129 .. 256 rows (twice the waves per row), at most 128 rows (rows cut into segments: one look-back launch per direction, the
     Gram-matrix pass per (row, segment) with its finalize step inside the launch) - by padding the batch with copies of itself: outputs
     bit for bit, input gradients to the rounding of one product (plain and wide rows: bit for bit), control gradients to the order in
     which fp64 sums are taken. With and without a gradient for x, full and ragged last tile. (Rounds 2 - 4 compared kernel generations
@@ -664,7 +664,7 @@ def test_launch_shapes_agree(D):
         x0 = (g.random((B, C, N)) * 2 - 1).astype(np.float32); w0 = g.standard_normal((B, C, N)).astype(np.float32)
         p0 = random_params(B, 3)
         outs = {}
-        for name, reps in (("segmented", 1), ("wide", -(-65 // (B * C))), ("plain", -(-257 // (B * C)))):
+        for name, reps in (("segmented", 1), ("wide", -(-129 // (B * C))), ("plain", -(-257 // (B * C)))):
             from dasp_pytorch_amd import _lib
             rows = reps * B * C
             assert (_lib.lib().dasp_sos_segment_tiles(rows, N) > 0) == (name == "segmented") and (rows <= 256) == (name != "plain")
