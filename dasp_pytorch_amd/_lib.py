@@ -76,6 +76,8 @@ SIGNATURES = {
     "dasp_dyn_segments": (_l, [_l, _l]),
     "dasp_dynamics_forward_seg": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p, _p]),
     "dasp_dynamics_backward_seg": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p, _p]),
+    "dasp_dynamics_forward_rows": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p, _p]),
+    "dasp_dynamics_backward_rows": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _l, _p, _p]),
     "dasp_stereo_partial_floats": (_l, [_i, _l, _i, _l]),
     "dasp_widener_forward": (_i, [_p, _p, _p, _i, _l, _p]),
     "dasp_widener_backward": (_i, [_p] * 6 + [_i, _l, _p]),

@@ -125,6 +125,16 @@ def _register_fakes():
     def _(x, ctl, grad_y, carries, lin, mode, sample_rate, eps, lookahead_samples, tseg):
         return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, x.shape[0], 5)
 
+    @torch.library.register_fake("dasp::_dynamics6_forward")
+    def _(x, five, mode, sample_rate, eps, lookahead_samples, tseg, save):
+        B, C, N = x.shape
+        ncar = _n(lambda b, n: L.dasp_dyn_carry_floats(b, n) if save and b * n else 0, B, N)
+        return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, ncar), (f32(x, B, N) if lookahead_samples > 0 else f32(x, 0))
+
+    @torch.library.register_fake("dasp::_dynamics6_backward")
+    def _(x, five, grad_y, carries, lin, mode, sample_rate, eps, lookahead_samples, tseg):
+        return torch.empty_like(x, memory_format=torch.contiguous_format), f32(x, 6, x.shape[0])
+
     @torch.library.register_fake("dasp::chain_controls")
     def _(comp_params, reverb_params, gain_params, lo, span, range_flag=None):
         B = comp_params.shape[0]

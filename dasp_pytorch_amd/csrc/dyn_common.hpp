@@ -46,9 +46,28 @@ __device__ __forceinline__ float gain_computer(float x_db, const DynItem& it, fl
     return g;
 }
 
-__device__ __forceinline__ DynItem load_item(const float* __restrict__ ctl, int b, double sample_rate, float eps) {
-    // ctl rows: threshold_db, ratio, attack_ms, knee_db, makeup_gain_db
-    const float* c = ctl + (size_t)b * 5;
+// Where the five controls the kernels read live - threshold_db, ratio, attack_ms, knee_db, makeup_gain_db: control i of item b is
+// p[i][b * s]. (B, 5) rows (the C ABI's `ctl`): p[i] = ctl + i, s = 5; five separate vectors of B values (the reference's own
+// signature, functional.py:275-286 - no stacking launch in front of the kernels): s = 1. Passed to the kernels by value.
+struct DynCtl {
+    const float* p[5];
+    int s;
+    __host__ __device__ float at(int i, int b) const { return p[i][(size_t)b * s]; }
+};
+inline DynCtl dyn_ctl_rows(const float* ctl) { return DynCtl{{ctl, ctl + 1, ctl + 2, ctl + 3, ctl + 4}, 5}; }
+// ... and where the five control gradients go (same order); `zero` (may be null): B more values that are set to zero - the gradient of
+// release_ms, which has no path to the output (functional.py:340,343-344)
+struct DynGrad {
+    float* p[5];
+    int s;
+    float* zero;
+};
+inline DynGrad dyn_grad_rows(float* gctl) { return DynGrad{{gctl, gctl + 1, gctl + 2, gctl + 3, gctl + 4}, 5, nullptr}; }
+
+__device__ __forceinline__ DynItem load_item(const DynCtl& ctl, int b, double sample_rate, float eps) {
+    float c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = ctl.at(i, b);
     DynItem it;
     it.thr = c[0]; it.ratio = c[1]; it.inv_ratio = 1.f / c[1]; it.knee = c[3]; it.makeup = c[4]; it.eps = eps;
     const double nat = sample_rate * ((double)c[2] / 1e3);                    // functional.py:339
@@ -58,6 +77,9 @@ __device__ __forceinline__ DynItem load_item(const float* __restrict__ ctl, int 
     it.alpha = (float)a; it.beta = (float)(1.0 - a);
     it.a4 = (float)a4; it.a8 = (float)a8; it.a16 = (float)a16; it.a32 = (float)a32; it.a256 = (float)a256; it.a1024 = (float)(a512 * a512);
     return it;
+}
+__device__ __forceinline__ DynItem load_item(const float* __restrict__ ctl, int b, double sample_rate, float eps) {      // (B, 5) rows
+    return load_item(DynCtl{{ctl, ctl + 1, ctl + 2, ctl + 3, ctl + 4}, 5}, b, sample_rate, eps);
 }
 
 }  // namespace dasp

@@ -108,6 +108,16 @@ __device__ __forceinline__ void store4(float* __restrict__ p, long idx, long n_v
 // a counter word that the caller keeps zeroed between calls (every use returns it to zero); the values that cross workgroups travel as
 // device-scope relaxed atomics, each wave waits for the acknowledgement of its own stores (vmcnt) before the barrier that precedes
 // thread 0's increment. Returns true (uniformly) in the workgroup that completed the count.
+// the item's five control gradients from its summed partials (threshold, ratio, alpha, knee, make-up) -> where the caller wants them
+__device__ __forceinline__ void dyn_emit_grads(const DynGrad& g, int b, const double (&a)[5], double alpha, double nat, double sample_rate) {
+    const size_t o = (size_t)b * g.s;
+    g.p[0][o] = (float)a[0];
+    g.p[1][o] = (float)a[1];
+    g.p[2][o] = (float)(a[2] * alpha * 2.1972245773362196 / (nat * nat) * (sample_rate / 1e3));   // d alpha / d attack_ms
+    g.p[3][o] = (float)a[3];
+    g.p[4][o] = (float)a[4];
+    if (g.zero) g.zero[b] = 0.f;
+}
 constexpr int DY_GMAX = 256;       // segments per item the in-kernel chain stages in LDS (the planner proposes <= 256 workgroups in all)
 __device__ __forceinline__ bool dyn_last_workgroup(int* cnt, int n_wg) {
     __shared__ int s_last;
@@ -121,13 +131,13 @@ __device__ __forceinline__ bool dyn_last_workgroup(int* cnt, int n_wg) {
 }
 // start(g + 1) = a start(g) + z(g) upwards (adjoint = 0) or aend(g - 1) = a aend(g) + za(g) downwards, a = alpha^(samples per segment),
 // fp64 (dyn_chain_kernel's arithmetic) for item b, by the calling workgroup: z staged in LDS with all loads in flight together
-__device__ __forceinline__ void dyn_chain_item(const float* __restrict__ ctl, const float* z, float* __restrict__ start, int b, int G,
+__device__ __forceinline__ void dyn_chain_item(const DynCtl& ctl, const float* z, float* __restrict__ start, int b, int G,
                                                long seg_samples, double sample_rate, int adjoint) {
     __shared__ float s_z[DY_GMAX];
     for (int g = threadIdx.x; g < G; g += blockDim.x) s_z[g] = __hip_atomic_load(z + (size_t)b * G + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
+        const double nat = sample_rate * ((double)ctl.at(2, b) / 1e3);
         const double a = exp(-2.1972245773362196 / nat * (double)seg_samples);
         double s = 0.0;
         if (!adjoint) {
@@ -148,7 +158,7 @@ __device__ __forceinline__ void dyn_chain_item(const float* __restrict__ ctl, co
 // from the z of the segments before it (the smoothing state is one float per item: start(g+1) = alpha^(samples per segment) start(g) + z(g)).
 template <int MODE, int W, int SEG = 0>
 __global__ void __launch_bounds__(64 * W)
-dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y, float* __restrict__ carries,
+dyn_fwd_kernel(const float* __restrict__ x, const DynCtl ctl, float* __restrict__ y, float* __restrict__ carries,
                float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
                int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr) {
@@ -241,7 +251,7 @@ dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float
 // returns to zero as well), so a captured graph - whose replays all carry the capture's tag - starts every replay from clean words.
 template <int MODE, int W, int TPW>
 __global__ void __launch_bounds__(64 * W)
-dyn_fwd_lookback_kernel(const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y, float* __restrict__ carries,
+dyn_fwd_lookback_kernel(const float* __restrict__ x, const DynCtl ctl, float* __restrict__ y, float* __restrict__ carries,
                         float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps, int G,
                         unsigned long long* __restrict__ words, int* __restrict__ counters, unsigned tag) {
     constexpr int Tseg = W * TPW;
@@ -298,7 +308,7 @@ dyn_fwd_lookback_kernel(const float* __restrict__ x, const float* __restrict__ c
         DYN_PRIO(0);
     }
     // ---- look-back (every wave on its own: at most G - 1 words, no barrier) ----
-    const double rate = -2.1972245773362196 / (sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3));       // ln alpha (load_item)
+    const double rate = -2.1972245773362196 / (sample_rate * ((double)ctl.at(2, b) / 1e3));       // ln alpha (load_item)
     double start = 0.0;
     if (seg > 0) {
         double acc = 0.0;
@@ -376,11 +386,11 @@ dyn_fwd_lookback_kernel(const float* __restrict__ x, const float* __restrict__ c
 // segstart[item][segment], the adjoint state entering the segment from above; partial sums per (item, segment, wave).
 template <int MODE, int W, bool DMA, int SEG = 0>
 __global__ void __launch_bounds__(64 * W)
-dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const float* __restrict__ gy,
+dyn_bwd_kernel(const float* __restrict__ x, const DynCtl ctl, const float* __restrict__ gy,
                const float* __restrict__ carries, const float* __restrict__ lin_buf, float* __restrict__ gx,
                float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
-               int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr, float* __restrict__ gctl = nullptr,
+               int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr, const DynGrad gctl = DynGrad{},
                unsigned tag = 0) {
     __shared__ float lds[W * 4];
     __shared__ float ring[DMA ? W * DY_RING : 1];
@@ -574,7 +584,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
                 __hip_atomic_store(wb + seg, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, Rn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             DYN_PRIO(0);
         }
-        const double rate = -2.1972245773362196 / (sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3));       // ln alpha (load_item)
+        const double rate = -2.1972245773362196 / (sample_rate * ((double)ctl.at(2, b) / 1e3));       // ln alpha (load_item)
         double above = 0.0;
         if (seg + 1 < G) {
             double acc = 0.0;
@@ -648,13 +658,8 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
 #pragma unroll
             for (int i = 0; i < 5; ++i) a[i] = wave_sum(a[i]);
             if (lane == 0) {
-                const double atk = (double)ctl[(size_t)b * 5 + 2], nat = sample_rate * (atk / 1e3), alpha = exp(-2.1972245773362196 / nat);
-                float* o = gctl + (size_t)b * 5;
-                o[0] = (float)a[0];
-                o[1] = (float)a[1];
-                o[2] = (float)(a[2] * alpha * 2.1972245773362196 / (nat * nat) * (sample_rate / 1e3));   // d alpha / d attack_ms
-                o[3] = (float)a[3];
-                o[4] = (float)a[4];
+                const double atk = (double)ctl.at(2, b), nat = sample_rate * (atk / 1e3), alpha = exp(-2.1972245773362196 / nat);
+                dyn_emit_grads(gctl, b, a, alpha, nat, sample_rate);
             }
         }
         return;
@@ -664,11 +669,11 @@ dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ctl, const
 
 // Chains the segments of an item: start(g + 1) = a start(g) + z(g) upwards (adjoint = 0), aend(g - 1) = a aend(g) + za(g) downwards
 // (adjoint = 1), a = alpha^(samples per segment) in fp64. One thread per item.
-__global__ void dyn_chain_kernel(const float* __restrict__ ctl, const float* __restrict__ z, float* __restrict__ start, int B, int G,
+__global__ void dyn_chain_kernel(const DynCtl ctl, const float* __restrict__ z, float* __restrict__ start, int B, int G,
                                  long seg_samples, double sample_rate, int adjoint) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const double nat = sample_rate * ((double)ctl[(size_t)b * 5 + 2] / 1e3);
+    const double nat = sample_rate * ((double)ctl.at(2, b) / 1e3);
     const double a = exp(-2.1972245773362196 / nat * (double)seg_samples);
     double s = 0.0;
     if (!adjoint) {
@@ -686,8 +691,8 @@ __global__ void dyn_chain_kernel(const float* __restrict__ ctl, const float* __r
 
 // gctl (B, 5): dL/d threshold_db, ratio, attack_ms, knee_db, makeup_gain_db. One wave per batch item, its lanes across the item's Wn rows
 // of partial sums (one thread per item walked them alone, one memory round trip per row: 14 us at 8 rows, more with segmented items)
-__global__ void __launch_bounds__(256) dyn_finalize_kernel(const float* __restrict__ partials, const float* __restrict__ ctl, int B, int Wn,
-                                                           double sample_rate, float* __restrict__ gctl) {
+__global__ void __launch_bounds__(256) dyn_finalize_kernel(const float* __restrict__ partials, const DynCtl ctl, int B, int Wn,
+                                                           double sample_rate, const DynGrad gctl) {
     const int b = blockIdx.x * (blockDim.x / 64) + wave_id(), l = lane_id();
     if (b >= B) return;
     double a[5] = {0, 0, 0, 0, 0};
@@ -699,13 +704,8 @@ __global__ void __launch_bounds__(256) dyn_finalize_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 5; ++i) a[i] = wave_sum(a[i]);
     if (l != 0) return;
-    const double atk = (double)ctl[(size_t)b * 5 + 2], nat = sample_rate * (atk / 1e3), alpha = exp(-2.1972245773362196 / nat);
-    float* o = gctl + (size_t)b * 5;
-    o[0] = (float)a[0];
-    o[1] = (float)a[1];
-    o[2] = (float)(a[2] * alpha * 2.1972245773362196 / (nat * nat) * (sample_rate / 1e3));   // d alpha / d attack_ms
-    o[3] = (float)a[3];
-    o[4] = (float)a[4];
+    const double atk = (double)ctl.at(2, b), nat = sample_rate * (atk / 1e3), alpha = exp(-2.1972245773362196 / nat);
+    dyn_emit_grads(gctl, b, a, alpha, nat, sample_rate);
 }
 
 }  // namespace dasp
@@ -739,9 +739,9 @@ long dasp_dyn_num_tiles(long N) { return (N + DY_TS - 1) / DY_TS; }
 long dasp_dyn_carry_floats(long B, long N) { return B * dasp_dyn_num_tiles(N); }
 long dasp_dyn_partial_floats(long B) { return B * kDW * 5; }
 
-int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, int B, int C, long N,
+static int dynamics_forward_impl(int mode, const float* x, const DynCtl ctl, float* y, float* carries, float* lin_buf, int B, int C, long N,
                           double sample_rate, float eps, int lookahead, void* stream) {
-    if (!x || !ctl || !y || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1)) return DASP_ERR_ARG;
+    if (!x || !ctl.p[0] || !y || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1)) return DASP_ERR_ARG;
     if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
     if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_dyn_num_tiles(N), vec = (N % 4 == 0) && dy_al16(x) && dy_al16(y) && (!lin_buf || dy_al16(lin_buf));
@@ -754,10 +754,10 @@ int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, 
     return dy_check();
 }
 
-int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
-                           float* gx, float* gctl, float* partials, int B, int C, long N, double sample_rate, float eps, int lookahead,
-                           void* stream) {
-    if (!x || !ctl || !gy || !carries || !gx || !gctl || !partials || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
+static int dynamics_backward_impl(int mode, const float* x, const DynCtl ctl, const float* gy, const float* carries, const float* lin_buf,
+                                  float* gx, const DynGrad gctl, float* partials, int B, int C, long N, double sample_rate, float eps, int lookahead,
+                                  void* stream) {
+    if (!x || !ctl.p[0] || !gy || !carries || !gx || !gctl.p[0] || !partials || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
         (mode != 0 && mode != 1))
         return DASP_ERR_ARG;
     if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
@@ -802,9 +802,9 @@ static int dyn_compute_units() {
 }
 long dasp_dyn_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_dyn_num_tiles(N) + Tseg - 1) / Tseg : 1; }
 
-int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
-                              int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream) {
-    if (!x || !ctl || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1) || Tseg <= 0) return DASP_ERR_ARG;
+static int dynamics_forward_seg_impl(int mode, const float* x, const DynCtl ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
+                                     int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream) {
+    if (!x || !ctl.p[0] || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 || (mode != 0 && mode != 1) || Tseg <= 0) return DASP_ERR_ARG;
     if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
     if (N > 0x7fffffffL - DY_TS) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_dyn_num_tiles(N), G = (int)dasp_dyn_segments(N, Tseg);
@@ -850,10 +850,10 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
     return dy_check();
 }
 
-int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
-                               float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N, double sample_rate, float eps,
-                               int lookahead, long Tseg, int* counters, void* stream) {
-    if (!x || !ctl || !gy || !carries || !gx || !gctl || !partials || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
+static int dynamics_backward_seg_impl(int mode, const float* x, const DynCtl ctl, const float* gy, const float* carries, const float* lin_buf,
+                                      float* gx, const DynGrad gctl, float* partials, float* segbuf, int B, int C, long N, double sample_rate, float eps,
+                                      int lookahead, long Tseg, int* counters, void* stream) {
+    if (!x || !ctl.p[0] || !gy || !carries || !gx || !gctl.p[0] || !partials || !segbuf || B <= 0 || C <= 0 || N <= 0 || lookahead < 0 ||
         (mode != 0 && mode != 1) || Tseg <= 0)
         return DASP_ERR_ARG;
     if (lookahead > 0 && !lin_buf) return DASP_ERR_ARG;
@@ -875,7 +875,7 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
 #define DASP_DYN_BWD_SEG2(MODE_, DMA_)                                                                                                           \
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 2>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, (float*)nullptr, \
                        (float*)nullptr, C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, z, counters, start,\
-                       (float*)nullptr);                                                                                                        \
+                       DynGrad{});                                                                                                              \
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 1>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials,    \
                        C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr, counters,           \
                        (float*)nullptr, gctl)
@@ -905,6 +905,56 @@ int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const
     if (rc != DASP_OK) return rc;
     hipLaunchKernelGGL(dyn_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, partials, ctl, B, kDW * G, sample_rate, gctl);
     return dy_check();
+}
+
+int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, int B, int C, long N,
+                          double sample_rate, float eps, int lookahead, void* stream) {
+    if (!ctl) return DASP_ERR_ARG;
+    return dynamics_forward_impl(mode, x, dyn_ctl_rows(ctl), y, carries, lin_buf, B, C, N, sample_rate, eps, lookahead, stream);
+}
+int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
+                           float* gx, float* gctl, float* partials, int B, int C, long N, double sample_rate, float eps, int lookahead,
+                           void* stream) {
+    if (!ctl || !gctl) return DASP_ERR_ARG;
+    return dynamics_backward_impl(mode, x, dyn_ctl_rows(ctl), gy, carries, lin_buf, gx, dyn_grad_rows(gctl), partials, B, C, N, sample_rate, eps, lookahead, stream);
+}
+int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
+                              int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream) {
+    if (!ctl) return DASP_ERR_ARG;
+    return dynamics_forward_seg_impl(mode, x, dyn_ctl_rows(ctl), y, carries, lin_buf, segbuf, B, C, N, sample_rate, eps, lookahead, Tseg, counters, stream);
+}
+int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries, const float* lin_buf,
+                               float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N, double sample_rate, float eps,
+                               int lookahead, long Tseg, int* counters, void* stream) {
+    if (!ctl || !gctl) return DASP_ERR_ARG;
+    return dynamics_backward_seg_impl(mode, x, dyn_ctl_rows(ctl), gy, carries, lin_buf, gx, dyn_grad_rows(gctl), partials, segbuf, B, C, N, sample_rate, eps,
+                                      lookahead, Tseg, counters, stream);
+}
+
+/* functional.compressor / expander on the reference's own six control tensors (functional.py:275-286), no stacking launch in front of the
+ * kernels and no transposition behind them: rows = 5 device vectors of B floats (threshold_db, ratio, attack_ms, knee_db, makeup_gain_db);
+ * grows = 6 device vectors of B floats for the gradients in the reference's argument order (threshold_db, ratio, attack_ms, release_ms -
+ * set to zero: it has no path to the output -, knee_db, makeup_gain_db). Tseg = 0: one workgroup per item (segbuf / counters unused),
+ * else as dasp_dynamics_forward_seg / _backward_seg. */
+int dasp_dynamics_forward_rows(int mode, const float* x, const float* const* rows, float* y, float* carries, float* lin_buf, float* segbuf,
+                               int B, int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream) {
+    if (!rows) return DASP_ERR_ARG;
+    for (int i = 0; i < 5; ++i) if (!rows[i]) return DASP_ERR_ARG;
+    const DynCtl ctl = DynCtl{{rows[0], rows[1], rows[2], rows[3], rows[4]}, 1};
+    if (Tseg > 0) return dynamics_forward_seg_impl(mode, x, ctl, y, carries, lin_buf, segbuf, B, C, N, sample_rate, eps, lookahead, Tseg, counters, stream);
+    return dynamics_forward_impl(mode, x, ctl, y, carries, lin_buf, B, C, N, sample_rate, eps, lookahead, stream);
+}
+int dasp_dynamics_backward_rows(int mode, const float* x, const float* const* rows, const float* gy, const float* carries, const float* lin_buf,
+                                float* gx, float* const* grows, float* partials, float* segbuf, int B, int C, long N, double sample_rate,
+                                float eps, int lookahead, long Tseg, int* counters, void* stream) {
+    if (!rows || !grows) return DASP_ERR_ARG;
+    for (int i = 0; i < 5; ++i) if (!rows[i]) return DASP_ERR_ARG;
+    for (int i = 0; i < 6; ++i) if (!grows[i]) return DASP_ERR_ARG;
+    const DynCtl ctl = DynCtl{{rows[0], rows[1], rows[2], rows[3], rows[4]}, 1};
+    const DynGrad g = DynGrad{{grows[0], grows[1], grows[2], grows[4], grows[5]}, 1, grows[3]};
+    if (Tseg > 0)
+        return dynamics_backward_seg_impl(mode, x, ctl, gy, carries, lin_buf, gx, g, partials, segbuf, B, C, N, sample_rate, eps, lookahead, Tseg, counters, stream);
+    return dynamics_backward_impl(mode, x, ctl, gy, carries, lin_buf, gx, g, partials, B, C, N, sample_rate, eps, lookahead, stream);
 }
 
 }  // extern "C"

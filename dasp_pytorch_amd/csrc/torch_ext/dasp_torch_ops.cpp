@@ -295,6 +295,65 @@ std::tuple<Tensor, Tensor> dyn_backward(const Tensor& x, const Tensor& ctl, cons
     }
     return {gx, gctl};
 }
+// The same on the reference's own six control tensors (functional.py:275-286), straight from where they lie: five device vectors in,
+// the six gradients as the rows of one (6, bs) tensor out (release_ms: zeros, written by the kernel) - no stacking launch in front of the
+// kernels, no transposition or fill behind them (dasp_dynamics_forward_rows / _backward_rows).
+void dyn6_check(const Tensor& x, at::TensorList five, int64_t mode, int64_t lookahead) {
+    need_device(x, "x");
+    TORCH_CHECK(x.dim() == 3 && x.scalar_type() == at::kFloat, "dasp::dynamics: x must be float32 (bs, chs, seq_len), got ", x.scalar_type(), " ", x.sizes());
+    TORCH_CHECK(five.size() == 5, "dasp::_dynamics6: five control vectors (threshold_db, ratio, attack_ms, knee_db, makeup_gain_db), got ", five.size());
+    for (const Tensor& c : five) {
+        same_device(x, c, "control");
+        TORCH_CHECK(c.dim() == 1 && c.scalar_type() == at::kFloat && c.is_contiguous() && c.sym_numel().guard_int(__FILE__, __LINE__) == x.size(0),
+                    "dasp::_dynamics6: every control is a contiguous float32 vector of bs = ", x.size(0), " values, got ", c.scalar_type(), " ", c.sizes());
+    }
+    TORCH_CHECK(mode == 0 || mode == 1, "dasp::dynamics: mode 0 (compressor) or 1 (expander)");
+    TORCH_CHECK(lookahead >= 0, "dasp::dynamics: lookahead_samples must be >= 0");
+}
+std::tuple<Tensor, Tensor, Tensor> dyn6_forward(const Tensor& x, at::TensorList five, int64_t mode, double sample_rate, double eps, int64_t lookahead,
+                                                int64_t tseg, bool save) {
+    dyn6_check(x, five, mode, lookahead);
+    c10::DeviceGuard guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
+    const Tensor x32 = x.contiguous();
+    Tensor y = at::empty_like(x32);
+    Tensor carries = empty_f32(save && x32.numel() ? dasp_dyn_carry_floats(B, N) : 0, x32);
+    Tensor lin = lookahead > 0 ? at::empty({B, N}, x32.options()) : at::empty({0}, x32.options());
+    if (x32.numel() == 0) return {y, carries, lin};
+    const float* rows[5];
+    for (int i = 0; i < 5; ++i) rows[i] = five[i].data_ptr<float>();
+    Tensor segbuf = tseg ? empty_f32(2 * B * dasp_dyn_segments(N, tseg), x32) : Tensor();
+    Tensor counters = tseg ? dyn_counters(x32, B) : Tensor();
+    check_rc(dasp_dynamics_forward_rows((int)mode, x32.data_ptr<float>(), rows, y.data_ptr<float>(), fp(carries), fp(lin), tseg ? fp(segbuf) : nullptr, (int)B, (int)C, N,
+                                        sample_rate, (float)eps, (int)lookahead, tseg, tseg ? counters.data_ptr<int>() : nullptr, stream_of(x32)),
+             "dasp_dynamics_forward_rows");
+    return {y, carries, lin};
+}
+std::tuple<Tensor, Tensor> dyn6_backward(const Tensor& x, at::TensorList five, const Tensor& gy, const Tensor& carries, const Tensor& lin, int64_t mode,
+                                         double sample_rate, double eps, int64_t lookahead, int64_t tseg) {
+    dyn6_check(x, five, mode, lookahead);
+    same_device(x, gy, "grad_output");
+    TORCH_CHECK(gy.sizes() == x.sizes(), "dasp::_dynamics6_backward: grad_output ", gy.sizes(), " does not match x ", x.sizes());
+    c10::DeviceGuard guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), N = x.size(2);
+    const Tensor x32 = x.contiguous(), g32 = f32c(gy);
+    Tensor gx = at::empty_like(x32), g6 = at::empty({6, B}, x32.options());
+    if (x32.numel() == 0) return {gx, g6.zero_()};
+    TORCH_CHECK(carries.numel() >= dasp_dyn_carry_floats(B, N), "dasp::_dynamics6_backward: `carries` does not belong to a forward call of this shape");
+    const long G = dasp_dyn_segments(N, tseg);
+    Tensor partials = empty_f32(dasp_dyn_partial_floats(B * G), x32);
+    const float* rows[5];
+    for (int i = 0; i < 5; ++i) rows[i] = five[i].data_ptr<float>();
+    float* grows[6];
+    for (int i = 0; i < 6; ++i) grows[i] = g6.data_ptr<float>() + i * B;
+    Tensor segbuf = tseg ? empty_f32(2 * B * G, x32) : Tensor();
+    Tensor counters = tseg ? dyn_counters(x32, B) : Tensor();
+    check_rc(dasp_dynamics_backward_rows((int)mode, x32.data_ptr<float>(), rows, g32.data_ptr<float>(), fp(carries), lookahead > 0 ? fp(lin) : nullptr, gx.data_ptr<float>(),
+                                         grows, fp(partials), tseg ? fp(segbuf) : nullptr, (int)B, (int)C, N, sample_rate, (float)eps, (int)lookahead, tseg,
+                                         tseg ? counters.data_ptr<int>() : nullptr, stream_of(x32)),
+             "dasp_dynamics_backward_rows");
+    return {gx, g6};
+}
 Tensor dyn_device(const Tensor& x, const Tensor& ctl, int64_t mode, double sample_rate, double eps, int64_t lookahead) {
     dyn_check(x, ctl, mode, lookahead);
     return std::get<0>(dyn_forward(x, ctl, mode, sample_rate, eps, lookahead, dyn_segment_tiles(x.size(0), x.size(2)), false));
@@ -671,14 +730,16 @@ struct Dyn6Fn : public torch::autograd::Function<Dyn6Fn> {
             need = need || c->requires_grad();
         }
         at::AutoDispatchBelowADInplaceOrView below;
-        const Tensor ctl = at::stack({flat32(threshold_db), flat32(ratio), flat32(attack_ms), flat32(knee_db), flat32(makeup_gain_db)}, 1);
-        dyn_check(x, ctl, mode, lookahead);
+        // the five controls the kernels read, as contiguous float32 vectors (no-ops for float32 controls of bs values: nothing is launched)
+        const std::vector<Tensor> five = {flat32(threshold_db).contiguous(), flat32(ratio).contiguous(), flat32(attack_ms).contiguous(),
+                                          flat32(knee_db).contiguous(), flat32(makeup_gain_db).contiguous()};
+        dyn6_check(x, five, mode, lookahead);
         const int64_t tseg = dyn_segment_tiles(x.size(0), x.size(2));
-        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_forward", "")
-                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, int64_t, double, double, int64_t, int64_t, bool)>();
-        auto [y, carries, lin] = op.call(x, ctl, mode, sample_rate, eps, lookahead, tseg, need);
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics6_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, at::TensorList, int64_t, double, double, int64_t, int64_t, bool)>();
+        auto [y, carries, lin] = op.call(x, five, mode, sample_rate, eps, lookahead, tseg, need);
         if (need) {
-            ctx->save_for_backward({x, ctl, carries, lin, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db});
+            ctx->save_for_backward({x, carries, lin, five[0], five[1], five[2], five[3], five[4], threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db});
             ctx->saved_data["mode"] = mode; ctx->saved_data["sr"] = sample_rate; ctx->saved_data["eps"] = eps;
             ctx->saved_data["look"] = lookahead; ctx->saved_data["tseg"] = tseg;
         }
@@ -686,20 +747,18 @@ struct Dyn6Fn : public torch::autograd::Function<Dyn6Fn> {
     }
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const auto s = ctx->get_saved_variables();
-        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_backward", "")
-                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, double, double,
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics6_backward", "")
+                             .typed<std::tuple<Tensor, Tensor>(const Tensor&, at::TensorList, const Tensor&, const Tensor&, const Tensor&, int64_t, double, double,
                                                                int64_t, int64_t)>();
-        auto [gx, gctl] = op.call(s[0], s[1], grads[0], s[2], s[3], ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
-                                  ctx->saved_data["eps"].toDouble(), ctx->saved_data["look"].toInt(), ctx->saved_data["tseg"].toInt());
-        const Tensor rows = gctl.t().contiguous();             // (5, bs): threshold, ratio, attack, knee, make-up - one contiguous row each
-        // forward arguments: x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead, mode
+        const std::vector<Tensor> five = {s[3], s[4], s[5], s[6], s[7]};
+        auto [gx, g6] = op.call(s[0], five, grads[0], s[1], s[2], ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
+                                ctx->saved_data["eps"].toDouble(), ctx->saved_data["look"].toInt(), ctx->saved_data["tseg"].toInt());
+        // forward arguments: x, sample_rate, threshold_db, ratio, attack_ms, release_ms, knee_db, makeup_gain_db, eps, lookahead, mode; row i
+        // of g6 is the gradient of control i in that order (release_ms: zeros), a contiguous vector each: AccumulateGrad takes them as they are
         variable_list out(11);
         if (ctx->needs_input_grad(0)) out[0] = gx;
-        static const int row_of[6] = {0, 1, 2, -1, 3, 4};
-        for (int i = 0; i < 6; ++i) {
-            if (!ctx->needs_input_grad(1 + i)) continue;
-            out[2 + i] = row_of[i] < 0 ? at::zeros_like(s[4 + i]) : like_control(rows.select(0, row_of[i]), s[4 + i]);
-        }
+        for (int i = 0; i < 6; ++i)
+            if (ctx->needs_input_grad(1 + i)) out[2 + i] = like_control(g6.select(0, i), s[8 + i]);       // (needs_input_grad counts tensor inputs only)
         return out;
     }
 };
@@ -709,8 +768,9 @@ Tensor dyn6_device(const Tensor& x, double sample_rate, const Tensor& threshold_
     for (const Tensor* c : {&threshold_db, &ratio, &attack_ms, &release_ms, &knee_db, &makeup_gain_db})
         TORCH_CHECK(x.dim() == 3 && c->numel() == x.size(0), "The size of tensor a (", c->numel(), ") must match the size of tensor b (", x.dim() ? x.size(0) : 0,
                     ") at non-singleton dimension 0");
-    const Tensor ctl = at::stack({flat32(threshold_db), flat32(ratio), flat32(attack_ms), flat32(knee_db), flat32(makeup_gain_db)}, 1);
-    return dyn_device(x, ctl, mode, sample_rate, eps, lookahead);
+    const std::vector<Tensor> five = {flat32(threshold_db).contiguous(), flat32(ratio).contiguous(), flat32(attack_ms).contiguous(), flat32(knee_db).contiguous(),
+                                      flat32(makeup_gain_db).contiguous()};
+    return std::get<0>(dyn6_forward(x, five, mode, sample_rate, eps, lookahead, dyn_segment_tiles(x.size(0), x.size(2)), false));
 }
 Tensor dyn6_autograd(const Tensor& x, double sample_rate, const Tensor& threshold_db, const Tensor& ratio, const Tensor& attack_ms, const Tensor& release_ms,
                      const Tensor& knee_db, const Tensor& makeup_gain_db, double eps, int64_t lookahead, int64_t mode) {
@@ -1020,6 +1080,9 @@ TORCH_LIBRARY(dasp, m) {
           "-> (Tensor, Tensor, Tensor)");
     m.def("_peq_norm_backward(Tensor x, Tensor grad_y, Tensor work32, Tensor work64, int Bp, int S, int tseg, bool need_gx, bool need_gp) -> (Tensor, Tensor)");
     m.def("_dynamics_forward(Tensor x, Tensor ctl, int mode, float sample_rate, float eps, int lookahead_samples, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_dynamics6_forward(Tensor x, Tensor[] five, int mode, float sample_rate, float eps, int lookahead_samples, int tseg, bool save) -> (Tensor, Tensor, Tensor)");
+    m.def("_dynamics6_backward(Tensor x, Tensor[] five, Tensor grad_y, Tensor carries, Tensor lin, int mode, float sample_rate, float eps, int lookahead_samples, int tseg) "
+          "-> (Tensor, Tensor)");
     m.def("_dynamics_backward(Tensor x, Tensor ctl, Tensor grad_y, Tensor carries, Tensor lin, int mode, float sample_rate, float eps, int lookahead_samples, int tseg) "
           "-> (Tensor, Tensor)");
     m.def("_chain_controls_backward(Tensor gctl, Tensor ggain, Tensor gdecay, Tensor gmix, float[] span) -> (Tensor, Tensor, Tensor)");
@@ -1051,6 +1114,8 @@ TORCH_LIBRARY_IMPL(dasp, CUDA, m) {
     m.impl("_peq_norm_forward", &peq_norm_forward);
     m.impl("_peq_norm_backward", &peq_norm_backward);
     m.impl("_dynamics_forward", &dyn_forward);
+    m.impl("_dynamics6_forward", &dyn6_forward);
+    m.impl("_dynamics6_backward", &dyn6_backward);
     m.impl("_dynamics_backward", &dyn_backward);
     m.impl("_chain_controls_backward", &chain_controls_backward);
     m.impl("_reverb_forward", &reverb_forward);
@@ -1070,6 +1135,7 @@ TORCH_LIBRARY_IMPL(dasp, Autograd, m) {
     // the two directions themselves carry no derivative: backpropagating through them (a double backward, or calling `_forward` on tensors
     // that require a gradient) raises "derivative for dasp::... is not implemented" instead of treating the result as a constant
     for (const char* name : {"_peq_forward", "_peq_backward", "_ew_forward", "_ew_backward", "_sosfilt_forward", "_sosfilt_backward", "_peq_norm_forward",
-                             "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_chain_controls_backward", "_reverb_forward", "_reverb_backward"})
+                             "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_dynamics6_forward", "_dynamics6_backward", "_chain_controls_backward", "_reverb_forward",
+                             "_reverb_backward"})
         m.impl(name, torch::autograd::autogradNotImplementedFallback());
 }

@@ -253,6 +253,17 @@ int dasp_dynamics_forward_seg(int mode, const float* x, const float* ctl, float*
 int dasp_dynamics_backward_seg(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
                                const float* lin_buf, float* gx, float* gctl, float* partials, float* segbuf, int B, int C, long N,
                                double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
+/* functional.compressor / expander on the reference's own six control tensors (dasp_pytorch/functional.py:275-286), without a stacking
+ * launch in front of the kernels or a transposition behind them: rows = 5 device vectors of B floats (threshold_db, ratio, attack_ms,
+ * knee_db, makeup_gain_db; the array of pointers itself is host memory), grows = 6 device vectors of B floats that receive the gradients
+ * in the reference's argument order (threshold_db, ratio, attack_ms, release_ms - set to zero: it has no path to the output,
+ * functional.py:340,343-344 -, knee_db, makeup_gain_db). Tseg = 0: one workgroup per item (segbuf / counters unused), otherwise as the
+ * *_seg calls above. Everything else as dasp_dynamics_forward / _backward. */
+int dasp_dynamics_forward_rows(int mode, const float* x, const float* const* rows, float* y, float* carries, float* lin_buf, float* segbuf,
+                               int B, int C, long N, double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
+int dasp_dynamics_backward_rows(int mode, const float* x, const float* const* rows, const float* gy, const float* carries,
+                                const float* lin_buf, float* gx, float* const* grows, float* partials, float* segbuf, int B, int C, long N,
+                                double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
 /* counters (may be NULL): a buffer of AT LEAST 4 * B ints owned by the caller, one buffer per stream, ZERO before its first use; every
  * call returns the words it used to zero. (Rounds 3 - 4 zeroed them with hipMemsetAsync at the start of every call; inside a captured
  * graph that memset node was not ordered before the kernel behind it when a replay started on an idle device, so the library zeroes
