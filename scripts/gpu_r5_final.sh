@@ -18,7 +18,7 @@ cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/small_eq_kernel_s
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/scripts/chain_kernel_count.py > /dev/null 2>> $GRAFT_REPO_ROOT/$out/rprof.err )
 python scripts/kernel_count_report.py $out/rprof 50 > $out/chain_kernel_count.log; rm -rf $out/rprof
 DASP_TORCH_OPS=0 timeout 300 python scripts/seg_gram_ab.py 2>/dev/null | tail -1 | sed 's/"DASP_SEG_GRAM": "default"/"what": "parametric_eq fwd+bwd, graph step ms"/' > $out/small_batch_steps.log
-DASP_TORCH_OPS=0 timeout 300 python scripts/dyn_small_ab.py 2>/dev/null | tail -1 | sed 's/"lib": "in-tree"/"what": "compressor fwd+bwd, graph step ms"/' >> $out/small_batch_steps.log
+timeout 300 python scripts/dyn_small_ab.py 2>/dev/null | tail -1 | sed 's/"lib": "in-tree"/"what": "compressor fwd+bwd, graph step ms"/' >> $out/small_batch_steps.log
 if [ "$1" != "skip-tests" ]; then
   FUZZ_SECONDS=150 timeout 600 python scripts/fuzz_gpu.py 7 > $out/fuzz_all_ops.log 2>&1; tail -25 $out/fuzz_all_ops.log | cut -c1-200
   FUZZ_EQ_ONLY=1 FUZZ_SECONDS=60 timeout 300 python scripts/fuzz_gpu.py 9 > $out/fuzz_eq.log 2>&1; tail -3 $out/fuzz_eq.log | cut -c1-300
