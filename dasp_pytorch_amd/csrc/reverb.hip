@@ -709,7 +709,23 @@ inline int rv_band_split(int B, int nwin, int nb) {
     int split = 1;
     while (split < nb && (long)B * nwin * split < 128) ++split;
     while (nb % split) ++split;             // equal shares
-    return split;
+    if ((long)B * nwin < 128) return split;
+    // From 128 workgroups on (round 5): a workgroup is compute-bound and 256 CUs take them in rounds, so 264 .. 511 workgroups (12 .. 23
+    // items at the default sizes) leave most CUs idle in the second round. Rounds of 256 workgroups per unit of work, with 8 % per extra
+    // share for the repeated inverse transform and the atomics: (12 / 16, c, 131072) fwd + bwd 0.269 / 0.296 -> 0.260 / 0.288 ms with two
+    // shares, (20 / 24 / 32 items) stay at one or tie (profiles/r05/fb_split_sweep.log).
+    // Only below 512 workgroups and only for a predicted gain of 10 % (beyond that one share per window was measured fastest or tied).
+    if ((long)B * nwin >= 512) return 1;
+    const double one = (double)(((long)B * nwin + 255) / 256);
+    int best = 1;
+    double best_cost = 0.9 * one;
+    for (int s = 2; s <= 4 && s <= nb; ++s) {
+        if (nb % s) continue;
+        const long wg = (long)B * nwin * s;
+        const double cost = (double)((wg + 255) / 256) / s * (1.0 + 0.08 * (s - 1));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 #define DASP_RV_LOAD(MODE_, GRID_, ...) hipLaunchKernelGGL((conv_load_kernel<MODE_>), GRID_, dim3(LoadGeom::T), 0, st, __VA_ARGS__)
 #define DASP_RV_COLS(MODE_, GRID_, ...) hipLaunchKernelGGL(conv_cols_kernel<MODE_>, GRID_, dim3(ColsGeom::T), 0, st, __VA_ARGS__)
