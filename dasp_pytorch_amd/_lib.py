@@ -109,6 +109,10 @@ SIGNATURES = {
     "dasp_reverb_forward_rng": (_i, [_p, ctypes.c_ulonglong, _p] + [_p] * 11 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
     "dasp_reverb_backward_rng": (_i, [_p, _p, ctypes.c_ulonglong, _p] + [_p] * 16 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
     "dasp_reverb_noise": (_i, [ctypes.c_ulonglong, _p, _p, _i, _i, _l, _p]),
+    "dasp_mt_layout": (_i, [ctypes.POINTER(ctypes.c_int)]),
+    "dasp_mt_max_values": (ctypes.c_longlong, []),
+    "dasp_mt_scratch_words": (_l, [_i, ctypes.c_longlong]),
+    "dasp_mt_randn": (_i, [_p, _i, _p, ctypes.c_longlong, _p, _p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_long), _p]),
 }
 
 

@@ -132,6 +132,10 @@ def build_all(force=False, verbose=False):
         obj = pool.submit(_compile_torch_ext_obj, force, verbose)
         lib = build_lib(force, verbose)
         obj.result()
+    # the jump-ahead table of csrc/mtrand.hip (a few seconds of integer arithmetic; cached next to the library, rebuilt on first use if absent)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from dasp_pytorch_amd import _mt19937
+    _mt19937.build_table(force=force)
     return lib, build_torch_ext(verbose=verbose)
 
 

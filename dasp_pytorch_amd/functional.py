@@ -3,6 +3,7 @@
 import torch
 
 from . import signal as _signal
+from . import _mt19937
 from . import ops as _ops
 from .ops import FILTER_TYPES, BusFunction, DistortionSampleFunction, PannerFunction, WidenerFunction
 from .ops import reverb as _ops_reverb
@@ -234,9 +235,11 @@ def noise_shaped_reverberation(
     """Artificial reverberation from frequency-band noise shaping (reference: dasp_pytorch/functional.py:406-577).
     Mono input is duplicated to stereo and the output always has 2 channels, as in the reference.
 
-    White noise: by default it is drawn exactly like the reference does -- torch.randn(bs*2, 12, num_samples +
-    num_bandpass_taps - 1) from the global *CPU* generator (functional.py:548) and copied to x's device -- so the same
-    torch.manual_seed gives the same impulse responses as the reference. `device_noise=True` generates it on x's device
+    White noise: by default it is what the reference draws -- torch.randn(bs*2, 12, num_samples + num_bandpass_taps - 1) from the
+    global *CPU* generator (functional.py:548) -- so the same torch.manual_seed gives the same impulse responses as the reference,
+    and the CPU generator is left in the state that call leaves it in; the values are computed on x's device from the generator's
+    state (csrc/mtrand.hip, _mt19937.py: the twister run in parallel by jump-ahead, torch's float and Box-Muller layout), not drawn
+    on the host and copied (0.56 s + 0.8 GB at (128,2,262144)). `device_noise=True` generates it on x's device
     instead, inside the filter-bank kernels (a counter-based stream, csrc/reverb.hip: the noise tensor - 0.8 GB at the default sizes
     and 128 items - never exists, forward and backward recompute it); its 63-bit seed is `noise_seed` (giving a seed selects this
     mode by itself), or, when that is None, one draw
@@ -294,7 +297,9 @@ def _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_
             # one 63-bit draw from the global CPU generator (a host-side scalar: no device work, no sync) unless the caller fixed the seed
             seed = int(noise_seed) if noise_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         else:
-            noise = torch.randn(x.shape[0] * 2, 12, num_samples + num_bandpass_taps - 1).to(x.device)
+            # the reference's draw (functional.py:548), made where it is used: the values and the CPU generator's state afterwards are
+            # those of torch.randn(bs*2, 12, ...) on the global CPU generator, computed by csrc/mtrand.hip from that generator's state
+            noise = _mt19937.randn_cpu_stream(x.shape[0] * 2, 12, num_samples + num_bandpass_taps - 1, device=x.device)
     return filters, noise, seed, (noise_seed_offset if seed is not None else None)
 
 

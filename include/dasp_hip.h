@@ -428,6 +428,24 @@ int dasp_ew64_forward(int op, const double* x, const double* ctl, double* y, int
 int dasp_ew64_backward(int op, const double* x, const double* ctl, const double* gy, double* gx, double* gctl, int B, int C, long N,
                        void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The reverb's white noise as the reference draws it.  Replaces `torch.randn(bs*2, 12, num_samples + num_bandpass_taps - 1)`
+ * on the global CPU generator (dasp_pytorch/functional.py:548) by the same stream generated on the device: at::mt19937 run from
+ * the state the host hands over, one 24-bit float per word, torch's 16-wide Box-Muller layout with its tail rule
+ * (csrc/mtrand.hip; host side - state parsing, jump-ahead table - dasp_pytorch_amd/_mt19937.py).
+ *   state_host: the 624 words of the generator (host memory, read during the call);  left: its `left` field (1..624);
+ *   out: n >= 16 floats (device);  table: the (262, row stride) uint16 jump table on the device, laid out as dasp_mt_layout says
+ *   (out8 = {blocks per chunk, baby polynomials, giant polynomials, list slot, row stride, pad exponent, max chunks per call, 0});
+ *   scratch: dasp_mt_scratch_words(left, n) 32-bit words (device); after the stream has run, words [*final_state_offset_words, + 624)
+ *   hold the generator's words after the draw (when *regenerated != 0; else they are unchanged and not written) and *left_after its
+ *   `left`. One call takes at most dasp_mt_max_values() values (a caller with more loops over pieces that are multiples of 16).
+ * ------------------------------------------------------------------------------------------- */
+int dasp_mt_layout(int* out8);
+long long dasp_mt_max_values(void);
+long dasp_mt_scratch_words(int left, long long n);
+int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n, const unsigned short* table, unsigned* scratch,
+                  int* left_after, int* regenerated, long* final_state_offset_words, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
