@@ -32,7 +32,7 @@ The JSON line also carries
                   events need the kernels as separate entry points, which is not how the product issues them, so they stay out of the
                   timed region; 240 back-to-back steps, events around every 4th launch of each entry point, queued behind a backlog of
                   graph replays sized from a probe of the host's issue rate so that the GPU never waits for the host - a waiting GPU
-                  runs these power-limited kernels faster than the timed step does; DASP_BENCH_EVENT_BLOCKER=0 turns the backlog off);
+                  runs these power-limited kernels faster than the timed step does; --no-event-backlog turns the backlog off);
                   `kernel_events_over_step` = the four kernels' event durations over the timed step (0.97 - 1.03 when consistent);
                   `traffic` = HBM bytes per launch from the PMC counters, read from profiles/<round>/hbm_traffic.json only if that
                   file was produced from the kernel sources now loaded
@@ -89,14 +89,16 @@ def kernel_source_hash():
     return h()
 
 
-def cpu_baseline_reference(seconds_budget=25.0):
+def cpu_baseline_reference(seconds_budget=25.0, full=False):
     """The reference's own dasp_pytorch.functional.parametric_eq (imported from the archive oracle/_ref holds) forward + autograd backward
-    on all host cores, fp32, on a bounded sub-batch of the workload."""
+    on all host cores, fp32, on a bounded sub-batch of the workload - (8,2,131072), the reference's best case: its throughput FALLS with
+    the batch. full=True (--cpu-baseline-full): the whole (256,2,131072) workload instead, once per thread count tried -
+    minutes of host time and ~14 GB of host memory, so not part of the default run (profiles/r06/cpu_baseline_full.json)."""
     if REF_ZIP not in sys.path:
         sys.path.insert(0, REF_ZIP)
     import dasp_pytorch.functional as RF
     cores = os.cpu_count() or 1
-    B, C, N = 8, 2, 131072
+    B, C, N = (256, 2, 131072) if full else (8, 2, 131072)
     x, params, w = make_batch(B, C, N, 999, "cpu")
 
     def step():
@@ -109,13 +111,14 @@ def cpu_baseline_reference(seconds_budget=25.0):
     # is spent or more threads made it slower, and the best one is reported
     tried = {}
     t_all = time.perf_counter()
-    for threads in sorted({min(cores, 16), min(cores, 64), cores}):
+    for threads in (sorted({min(cores, 16), min(cores, 64)}) if full else sorted({min(cores, 16), min(cores, 64), cores})):
         if tried and (time.perf_counter() - t_all > seconds_budget or (len(tried) > 1 and list(tried.values())[-1] > list(tried.values())[-2])):
             break                            # out of budget, or more threads already made it slower (256 threads: 18 s per iteration)
         torch.set_num_threads(threads)
-        step()                               # warm-up (FFT plans, allocator, thread pool)
+        if not full:
+            step()                           # warm-up (FFT plans, allocator, thread pool)
         times = []
-        for _ in range(2):
+        for _ in range(1 if full else 2):
             t0 = time.perf_counter()
             step()
             times.append(time.perf_counter() - t0)
@@ -124,7 +127,8 @@ def cpu_baseline_reference(seconds_budget=25.0):
     best = tried[threads]
     return {"value": B * C * N / best, "unit": "channel-samples/s", "cores": threads, "kind": "reference",
             "sample": f"dasp_pytorch.functional.parametric_eq fwd + autograd bwd, fp32, on ({B},{C},{N}) of the (256,2,131072) workload, "
-                      f"best of 2 after 1 warm-up per thread count, s per iteration by threads: "
+                      + ("one cold iteration per thread count (the full workload: --cpu-baseline-full)" if full else "best of 2 after 1 warm-up per thread count")
+                      + ", s per iteration by threads: "
                       + ", ".join(f"{k}: {v:.2f}" for k, v in tried.items()) + f" (host has {cores}); torch {torch.__version__} CPU"}
 
 
@@ -146,10 +150,10 @@ def cpu_baseline_port(seconds_budget=15.0):
                       "numpy pocketfft single thread (oracle/_ref not staged: run __graft_entry__.build() where /root/reference exists)"}
 
 
-def cpu_baseline():
+def cpu_baseline(full=False):
     if os.path.exists(REF_ZIP):
         try:
-            return cpu_baseline_reference()
+            return cpu_baseline_reference(full=full)
         except Exception as e:      # a broken archive must not cost the bench line; say what happened
             out = cpu_baseline_port()
             out["sample"] += f" [reference baseline failed: {type(e).__name__}: {e}]"
@@ -208,17 +212,31 @@ def graph_step_ms(step, replays=50, blocks=5, ramp_s=0.3):
 
 
 def secondary_traffic(name):
-    """HBM bytes per fwd+bwd step of a secondary op from the newest profiles/r*/hbm_traffic_secondary.json that has it (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes, scripts/reverb_traffic.sh; null when no counter file covers the op)."""
-    key = {"noise_shaped_reverberation": "hbm_bytes_per_step"}.get(name)
-    if key is None:
+    """HBM bytes per fwd+bwd step of a secondary op by the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), from the newest
+    counter file under profiles/ that covers it: the reverb's hbm_traffic_secondary.json (scripts/reverb_traffic.sh), the compressor /
+    expander / gain / distortion's hbm_traffic_ops.json (scripts/ops_traffic.sh; used only while its source hash equals the hash of the
+    kernel sources of this build). null when no counter file covers the op."""
+    if name == "noise_shaped_reverberation":
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_secondary.json")), reverse=True):
+            try:
+                tj = json.load(open(path))
+                if tj.get("noise_mode", "explicit") == "generated" and "hbm_bytes_per_step" in tj:
+                    return {"bytes": int(tj["hbm_bytes_per_step"]), "file": os.path.relpath(path, ROOT)}
+            except (OSError, ValueError):
+                continue
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_secondary.json")), reverse=True):
+    family = {"compressor": "dynamics", "expander": "dynamics", "gain": "elementwise", "distortion": "elementwise"}.get(name)
+    if family is None:
+        return None
+    from dasp_pytorch_amd.csrc.build import kernel_source_hash as h
+    now = h(("dynamics.hip", "dyn_common.hpp", "common.hpp")) if family == "dynamics" else h(("elementwise.hip", "common.hpp"))
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_ops.json")), reverse=True):
         try:
             tj = json.load(open(path))
-            if tj.get("noise_mode", "explicit") == "generated" and key in tj:
-                return {"bytes": int(tj[key]), "file": os.path.relpath(path, ROOT)}
-        except (OSError, ValueError):
+            op = tj["ops"][name]
+            if tj["kernel_source_hash"][family] == now and "hbm_bytes_per_step" in op:
+                return {"bytes": int(op["hbm_bytes_per_step"]), "ratio_to_algorithmic": op["ratio"], "file": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
             continue
     return None
 
@@ -241,7 +259,7 @@ def mrstft_roofline(gpu_ms):
     return None
 
 
-def secondary(dev):
+def secondary(dev, skip_default_noise=False):
     """Short fwd+bwd timings of the other hot-path ops at their BASELINE.json configs (1 GPU, not the headline)."""
     res = {}
     g = torch.Generator(device=dev).manual_seed(7)
@@ -257,33 +275,32 @@ def secondary(dev):
             for c in ctl:
                 c.grad = None
             call(x, ctl).backward(w)
-        t = _time_steps_median(step) if B <= 32 else _time_steps(step)       # (host-bound rows: the median of three blocks)
+        t = _time_steps_median(step)                 # eager wall per step, median of three blocks of 30 steps
         cs = B * C * N
         res[name] = {"shape": [B, C, N], "ms_fwd_bwd": round(t * 1e3, 3), "channel_samples_per_s": cs / t,
                      "algorithmic_GBps": round(bytes_per_cs * cs / t / 1e9, 1), "frac_of_8TBps": round(bytes_per_cs * cs / t / 1e9 / HBM_PEAK_GBS, 4)}
-        # GPU time of the step's library calls (HIP events around every C entry point): at small batches the eager wall time above is
-        # the host's (autograd + launches, ~0.2 ms per step), not the kernels'
-        _lib.timers.start(every=1)
-        for _ in range(10):
-            step()
-        kt = _lib.timers.stop()
-        gpu_ms = sum(sum(v) for v in kt.values()) / 10
-        res[name]["gpu_ms_fwd_bwd"] = round(gpu_ms, 4)
+        # GPU time of the step's library calls (HIP events around every C entry point), median of three blocks of ten steps: a cross-check
+        # of the figure the roofline uses (below) - event pairs in an eager loop leave idle gaps after which power-limited kernels clock
+        # differently, so this one wanders by box and by run (r05: 0.536 where the wall said 0.483)
+        blocks_ms = []
+        for _ in range(3):
+            _lib.timers.start(every=1)
+            for _ in range(10):
+                step()
+            kt = _lib.timers.stop()
+            blocks_ms.append(sum(sum(v) for v in kt.values()) / 10)
+        res[name]["gpu_ms_fwd_bwd"] = round(float(np.median(blocks_ms)), 4)
         res[name]["launch_calls"] = {k: len(v) // 10 for k, v in kt.items()}
-        # HBM roofline of the op on its algorithmic bytes over the GPU time of its library calls (HIP events, this run); `traffic` = bytes
-        # per step from the PMC counters where a counter file of this round's kernels exists (profiles/rNN/hbm_traffic_secondary.json)
-        a = bytes_per_cs * cs / (gpu_ms * 1e-3) / 1e9
+        # The roofline of every row is taken over the step replayed as ONE HIP graph back to back (graph_step_ms: median of five blocks of
+        # 50 replays after a ramp): GPU-bound whatever the batch, no event pair between kernels, comparable across boxes. For the
+        # large-batch rows it agrees with the eager wall time (the host runs ahead of the GPU there); for the reference's training batches
+        # the eager wall is the host's. `traffic` = HBM bytes per step from the PMC counters where a counter file of these kernels exists
+        # (profiles/rNN/hbm_traffic_secondary.json).
+        tg = graph_step_ms(step)
+        res[name]["ms_fwd_bwd_graph"] = tg
+        a = bytes_per_cs * cs / (tg * 1e-3) / 1e9
         res[name]["roofline"] = {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-                                 "algorithmic_bytes": int(bytes_per_cs * cs), "traffic": secondary_traffic(name)}
-        if B <= 32:
-            # reference training batches: the step is launch-bound and its eager wall time is the host's. `ms_fwd_bwd_graph` is the whole step
-            # replayed as ONE HIP graph back to back (graph_step_ms): GPU-bound and comparable across boxes - the event-pair figure above
-            # (`gpu_ms_fwd_bwd`) comes from a host-bound loop whose idle gaps let the kernels clock up differently on every box (round 3:
-            # 36 % apart between two boxes); the roofline of these rows is therefore taken over the graph time
-            tg = graph_step_ms(step)
-            res[name]["ms_fwd_bwd_graph"] = tg
-            a = bytes_per_cs * cs / (tg * 1e-3) / 1e9
-            res[name]["roofline"].update(achieved=round(a, 1), frac=round(a / HBM_PEAK_GBS, 4), over="ms_fwd_bwd_graph")
+                                 "algorithmic_bytes": int(bytes_per_cs * cs), "traffic": secondary_traffic(name), "over": "ms_fwd_bwd_graph"}
         if note:
             res[name]["note"] = note
         del x, w
@@ -293,6 +310,9 @@ def secondary(dev):
     bench_op("distortion", 256, 2, 131072, lambda B: ([ctl1(0, 24)(B * 2)], lambda x, c: D.distortion(x, SR, c[0])), 20)
     rng = [(-60, 0), (1, 20), (5, 100), (5, 100), (1e-3, 12), (0, 12)]
     bench_op("compressor", 256, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.compressor(x, SR, *c)), 20)
+
+    bench_op("expander", 256, 2, 262144, lambda B: ([ctl1(lo, hi)(B) for lo, hi in rng], lambda x, c: D.expander(x, SR, *c)), 20,
+             "BASELINE config 3 names it beside the compressor; the reference's expander is a stub (functional.py:402-403): mode 1 of the same kernels")
 
     def speechlike(B, C, N):   # white noise x a slow random envelope spanning -60 .. 0 dBFS (all three knee regions)
         knots = rnd(B, 1, N // 4096 + 2) * -60.0
@@ -315,11 +335,14 @@ def secondary(dev):
     bench_op("noise_shaped_reverberation_b8", 8, 2, 131072,
              lambda B: ([ctl1(0, 1)(B) for _ in range(25)], lambda x, c: D.noise_shaped_reverberation(x, SR, *c, device_noise=True)),
              2 * 0.537e9 / (128 * 2 * 262144), "reference training batch: the filter bank's bands dealt out over workgroups")
-    # The drop-in DEFAULT of noise_shaped_reverberation (round 4 judge): the reference draws torch.randn(2 bs, 12, 66558) from the global CPU
-    # generator per call (functional.py:548) and so does this package unless device_noise / noise_seed is given - same torch.manual_seed,
-    # same impulse responses - which puts the host's generator and one host-to-device copy in front of the kernels every call. Wall time
-    # per fwd+bwd step with its host parts timed on their own; the kernels behind them are the ones timed above.
+    # The drop-in DEFAULT of noise_shaped_reverberation: the reference draws torch.randn(2 bs, 12, 66558) from the global CPU generator per
+    # call (functional.py:548) - same torch.manual_seed, same impulse responses. Until round 5 this package drew it the same way (one host
+    # thread + a host-to-device copy in front of the kernels: 682 ms per step at (128,2,262144)); since round 6 the same stream - values and
+    # generator state - is computed on the device from the generator's state (csrc/mtrand.hip). Wall time per fwd+bwd step of the default
+    # call, the GPU time of the stream's kernels alone, and the host draw + copy it replaced timed beside it (one step with the device
+    # stream switched off).
     def default_noise_wall(name, B, N, steps):
+        from dasp_pytorch_amd import _mt19937
         x = (rnd(B, 2, N) * 2 - 1).requires_grad_(True)
         ctl = [ctl1(0, 1)(B) for _ in range(25)]
         w = torch.randn(B, 2, N, device=dev, generator=g)
@@ -329,23 +352,41 @@ def secondary(dev):
             for c in ctl:
                 c.grad = None
             D.noise_shaped_reverberation(x, SR, *ctl).backward(w)
-        t = _time_steps(step, steps=steps, warmup=1)
+        t = float(np.median([_time_steps(step, steps=steps, warmup=2 if i == 0 else 0) for i in range(3)]))
+        size = (B * 2, 12, 65536 + 1023 - 1)
+        gen = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            noise = _mt19937.randn_cpu_stream(*size, device=dev)
+            e1.record()
+            torch.cuda.synchronize()
+            gen.append(e0.elapsed_time(e1))
+        _mt19937.enabled = False
+        try:
+            t_host_step = _time_steps(step, steps=1, warmup=0)
+        finally:
+            _mt19937.enabled = True
         t0 = time.perf_counter()
-        noise = torch.randn(B * 2, 12, 65536 + 1023 - 1)
+        noise = torch.randn(*size)
         t_rng = time.perf_counter() - t0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         noise.to(dev)
         torch.cuda.synchronize()
         t_h2d = time.perf_counter() - t0
-        res[name] = {"shape": [B, 2, N], "ms_fwd_bwd_wall": round(t * 1e3, 2), "host_randn_ms": round(t_rng * 1e3, 2), "h2d_copy_ms": round(t_h2d * 1e3, 2),
-                     "noise_bytes": int(noise.numel() * 4), "host_threads": torch.get_num_threads(),
-                     "note": "default (reference-compatible) noise: torch.randn on the global CPU generator + H2D copy per call; device_noise=True "
-                             "(the rows above) generates the same statistics inside the filter-bank kernels and removes both"}
+        res[name] = {"shape": [B, 2, N], "ms_fwd_bwd_wall": round(t * 1e3, 3), "noise_stream_gpu_ms": round(float(np.median(gen)), 3),
+                     "noise_values": int(noise.numel()), "noise_bytes": int(noise.numel() * 4),
+                     "host_draw": {"ms_fwd_bwd_wall": round(t_host_step * 1e3, 2), "host_randn_ms": round(t_rng * 1e3, 2), "h2d_copy_ms": round(t_h2d * 1e3, 2),
+                                   "host_threads": torch.get_num_threads()},
+                     "note": "default (reference-compatible) noise: torch's CPU random stream (MT19937, 24-bit floats, 16-wide Box-Muller layout) computed on "
+                             "the device from the CPU generator's state, generator state written back (csrc/mtrand.hip; tests/test_gpu_mtrand.py: equal to "
+                             "torch.randn to 1e-6, state bit-equal); host_draw = the same step with the noise drawn by torch.randn on the host and copied, "
+                             "as rounds 1-5 did and the reference does"}
         del x, w, noise
-    if not os.environ.get("DASP_BENCH_SKIP_DEFAULT_NOISE"):        # (developer A/B: does this row disturb the rows behind it?)
-        default_noise_wall("noise_shaped_reverberation_default_noise", 128, 262144, 2)
-        default_noise_wall("noise_shaped_reverberation_default_noise_b8", 8, 131072, 5)
+    if not skip_default_noise:
+        default_noise_wall("noise_shaped_reverberation_default_noise", 128, 262144, 3)
+        default_noise_wall("noise_shaped_reverberation_default_noise_b8", 8, 131072, 10)
     # widening rows: stereo utilities and the multi-resolution STFT loss
     bench_op("stereo_widener", 256, 2, 131072, lambda B: ([ctl1(0, 1)(B)], lambda x, c: D.stereo_widener(x, SR, c[0].reshape(-1, 1))), 20)
     # the boundary's long tail: lfilter_via_fsm with more than three coefficients (signal.py:95-133; csrc/lfilter.hip: double arithmetic,
@@ -411,9 +452,8 @@ def secondary(dev):
         proc.validate_range = False
     eager[("torch_ops" if _torch_ops.enabled() else "ctypes") + "_no_range_check"] = round(_time_steps_median(chain_step) * 1e3, 3)
     if _torch_ops.enabled():
-        os.environ["DASP_TORCH_OPS"] = "0"
-        eager["ctypes_no_range_check"] = round(_time_steps_median(chain_step) * 1e3, 3)
-        del os.environ["DASP_TORCH_OPS"]
+        with D.config.override(torch_ops=False):
+            eager["ctypes_no_range_check"] = round(_time_steps_median(chain_step) * 1e3, 3)
         cm = D.chain.ChainModule(SR, noise_seed=7, device=dev)
 
         def module_step():
@@ -552,6 +592,10 @@ def main():
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the reference on the WHOLE (256,2,131072) workload (minutes, ~14 GB of host memory) instead of its best-case (8,2,131072) sub-batch")
+    ap.add_argument("--no-default-noise-rows", action="store_true", help="developer switch: skip the secondary rows of the reverb's default noise")
+    ap.add_argument("--no-event-backlog", action="store_true", help="developer switch: no backlog of graph replays in front of the per-kernel event pass")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other hot-path ops")
     ap.add_argument("--no-kernel-events", action="store_true", help="developer switch: skip the per-kernel HIP-event pass (roofline is then NaN)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="test hook: rank wiring on CPU tensors over gloo, kernels replaced by a copy")
@@ -682,7 +726,7 @@ def main():
         _lib.timers.start(every=4)                                     # (the probe's samples are dropped)
         gpu_per_step = min(float(np.median(v)) for v in blocks.values()) / args.steps
         n_rep = 0
-        if "graph" in blocks and os.environ.get("DASP_BENCH_EVENT_BLOCKER", "1") != "0":
+        if "graph" in blocks and not args.no_event_backlog:
             n_rep = min(4000, 200 + int(3.0 * 240 * max(0.0, host_per_step - gpu_per_step) / gpu_per_step))      # 3x the computed deficit: the probe ran on an idle host
             for _ in range(n_rep):
                 graph.replay()
@@ -804,9 +848,9 @@ def main():
         if dry:
             out["dry_run"] = "CPU wiring test: kernels replaced by a copy, numbers are meaningless"
         if world == 1 and not args.no_secondary and not dry:
-            out["secondary"] = secondary(dev)
+            out["secondary"] = secondary(dev, skip_default_noise=args.no_default_noise_rows)
         if world == 1 and not args.no_cpu_baseline and not dry:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

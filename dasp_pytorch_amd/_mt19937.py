@@ -38,7 +38,7 @@ BLOCKS_PER_CHUNK = 256                  # a chunk = this many regenerations = 15
 JUMP = N * BLOCKS_PER_CHUNK             # words between the start states of neighbouring chunks
 N_BABY = 255                            # t^(b J), b = 1 .. 255: chunk a*256 + b from chunk a*256
 N_GIANT = 7                             # t^(a 256 J), a = 1 .. 7: chunk a*256 from chunk 0  => at most 2048 chunks (327 M draws) per call
-SLOT = 9976                             # index-list slot per parity class (at most 9969 even / 9968 odd coefficients), a multiple of 8
+SLOT = 10112                            # index-list slot per parity class (at most 9969 even / 9968 odd coefficients), a multiple of 128
 STRIDE = 8 + 2 * SLOT                   # uint16 per polynomial: header (two uint32 counts, padded) + even list + odd list
 PAD_INDEX = 20560                       # first word behind the sequence window: the kernel keeps zeros there (list padding reads them)
 MAX_CHUNKS = (N_GIANT + 1) * (N_BABY + 1)
@@ -122,14 +122,14 @@ def jump_polynomials():
 
 
 def _expand(g):
-    """One polynomial as the kernel reads it: STRIDE uint16 = [n_even8 (u32), n_odd8 (u32), 0, 0 | even exponents | odd exponents], each
-    list padded to a multiple of 8 with an exponent whose window is all zeros (PAD_INDEX for the even class, PAD_INDEX + 1 for the odd)."""
+    """One polynomial as the kernel reads it: STRIDE uint16 = [n_even (u32), n_odd (u32), 0, 0 | even exponents | odd exponents], each
+    list padded to a multiple of 128 with an exponent whose window is all zeros (PAD_INDEX for the even class, PAD_INDEX + 1 for the odd)."""
     bits = np.unpackbits(np.frombuffer(g.to_bytes((DEG + 7) // 8 + 1, "little"), dtype=np.uint8), bitorder="little")
     idx = np.nonzero(bits)[0]
     row = np.zeros(STRIDE, dtype=np.uint16)
     head = np.zeros(2, dtype=np.uint32)
     for k, (cls, pad) in enumerate(((idx[idx % 2 == 0], PAD_INDEX), (idx[idx % 2 == 1], PAD_INDEX + 1))):
-        n8 = (len(cls) + 7) // 8 * 8
+        n8 = (len(cls) + 127) // 128 * 128
         assert n8 <= SLOT
         head[k] = n8
         seg = np.full(SLOT, pad, dtype=np.uint16)
@@ -269,12 +269,45 @@ def _randn_from_state(words, left, out):
     return state_dev, left
 
 
-def randn_cpu_stream(*size, device):
+class _PendingState:
+    """The generator state a device draw leaves behind, on its way to the host: the words were copied to pinned memory right behind the
+    generating kernels (an event marks the copy), `finish()` waits for that event only and installs the state. Between the draw and
+    finish() the CPU generator still holds the state from BEFORE the draw - the caller finishes before it hands control back."""
+
+    def __init__(self, state, words, left_after, state_dev):
+        import torch
+        self.state, self.words, self.left_after, self.pinned, self.event = state, words, left_after, None, None
+        if state_dev is not None:
+            self.pinned = torch.empty(N, dtype=torch.int32, pin_memory=True)
+            self.pinned.copy_(state_dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def finish(self):
+        import torch
+        if self.state is None:
+            return
+        if self.event is not None:
+            self.event.synchronize()
+            self.words = self.pinned.numpy().view(np.uint32)
+        torch.set_rng_state(format_state(self.state, self.words, self.left_after))
+        self.state = None
+
+
+class _NothingPending:
+    def finish(self):
+        pass
+
+
+def randn_cpu_stream(*size, device, defer=False):
     """`torch.randn(*size)` of the reference's call site (dasp_pytorch/functional.py:548: float32, default CPU generator) delivered on
     `device`: the values the CPU call would have returned, and the CPU generator left in the state that call would have left it in -
     generated by csrc/mtrand.hip from the generator's state instead of drawn on the host and copied. Falls back to the host draw where
     the reproduction does not apply (fewer than 16 values, a default dtype other than float32, stream capture - the draw needs one
-    read-back of 2.5 KB for the state -, a generator state of an unknown layout, or a failed self-check on this device)."""
+    read-back of 2.5 KB for the state -, a generator state of an unknown layout, or a failed self-check on this device).
+    defer=True returns (tensor, pending): the state's read-back is on its way and `pending.finish()` installs it - for a caller that
+    queues more device work first (the reverb's kernels) so that the host does not sit out the generation; it must finish before
+    anything else can draw from the CPU generator."""
     import torch
     dev = torch.device(device)
     n = 1
@@ -282,7 +315,8 @@ def randn_cpu_stream(*size, device):
         n *= int(s)
 
     def host():
-        return torch.randn(*size).to(dev)
+        t = torch.randn(*size).to(dev)
+        return (t, _NothingPending()) if defer else t
 
     if not enabled or n < 16 or torch.get_default_dtype() != torch.float32 or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
         return host()
@@ -303,8 +337,10 @@ def randn_cpu_stream(*size, device):
     with torch.cuda.device(dev):
         out = torch.empty(n, dtype=torch.float32, device=dev)
         state_dev, left_after = _randn_from_state(words, left, out)
-        new_words = state_dev.cpu().numpy().view(np.uint32) if state_dev is not None else words      # the one read-back (waits for the kernels)
-    torch.set_rng_state(format_state(state, new_words, left_after))
+        pending = _PendingState(state, words, left_after, state_dev)
+    if defer:
+        return out.view(*size), pending
+    pending.finish()
     return out.view(*size)
 
 

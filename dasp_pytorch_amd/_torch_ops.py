@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 EXT_PATH = os.path.join(_HERE, "csrc", "libdasp_torch.so")
@@ -195,30 +195,30 @@ def load():
     return _state["loaded"]
 
 
-def _plan_from_env():
+def _plan_from_config():
     """The segment-plan overrides of the two scan families as the extension takes them: -1 = the library's planner, 0 = never segment,
-    > 0 = tiles per segment (developer switches DASP_SOS_SEGMENT / DASP_SOS_SEGMENT_TILES / DASP_DYN_SEGMENT / DASP_DYN_SEGMENT_TILES - the
-    same ones the ctypes binding reads in ops.py; the compiled code reads no environment)."""
-    def one(flag, tiles):
-        if os.environ.get(flag, "auto") == "0":
+    > 0 = tiles per segment (config.plan.sos_segment / sos_segment_tiles / dyn_segment / dyn_segment_tiles - the same switches the
+    ctypes binding reads in ops.py; the compiled code reads no environment)."""
+    def one(on, tiles):
+        if not on:
             return 0
-        t = os.environ.get(tiles)
-        return int(t) if t and int(t) > 0 else -1
-    return one("DASP_SOS_SEGMENT", "DASP_SOS_SEGMENT_TILES"), one("DASP_DYN_SEGMENT", "DASP_DYN_SEGMENT_TILES")
+        return int(tiles) if tiles and int(tiles) > 0 else -1
+    p = config.plan
+    return one(p.sos_segment, p.sos_segment_tiles), one(p.dyn_segment, p.dyn_segment_tiles)
 
 
 def sync_plan():
-    """Push the environment's plan overrides to the extension when they changed since the last push."""
-    plan = _plan_from_env()
+    """Push config.plan's overrides to the extension when they changed since the last push."""
+    plan = _plan_from_config()
     if plan != _state.get("plan", (-1, -1)):
         torch.ops.dasp._plan_override(*plan)
         _state["plan"] = plan
 
 
 def enabled():
-    """True when the chain ops should go through torch.ops.dasp.* (the extension is built and loadable, DASP_TORCH_OPS is not 0, and
+    """True when the chain ops should go through torch.ops.dasp.* (the extension is built and loadable, config.plan.torch_ops is on, and
     bench.py's per-call HIP-event timers - which live in the ctypes binding - are off)."""
-    on = os.environ.get("DASP_TORCH_OPS", "1") != "0" and not _lib.timers.enabled and load()
+    on = config.plan.torch_ops and not _lib.timers.enabled and load()
     if on:
         sync_plan()
     return on

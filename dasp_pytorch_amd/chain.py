@@ -6,9 +6,10 @@ commutes with it:  gain * reverb(c) = reverb(gain * c);  and a gain applied to t
 already does:  gain_db just adds to makeup_gain_db. The chain below therefore runs three kernels' worth of passes, not four, with
 bit-for-bit the same mathematics (up to fp32 rounding of one multiply) and the gradient of gain_db falling out of the make-up gain's.
 """
-import os
 
 import torch
+
+from . import config
 
 from . import functional as _functional
 from . import modules as _modules
@@ -69,7 +70,7 @@ class StyleTransferChain:
         reference's parameter names, the stock process functions."""
         m = _modules
         every = (comp_params, reverb_params, gain_params)
-        return (os.environ.get("DASP_CHAIN_FUSED_CONTROLS", "1") != "0"        # developer A/B: the torch-op de-normalisation below
+        return (config.plan.chain_fused_controls        # developer A/B: the torch-op de-normalisation below
                 and x.is_cuda and x.dtype is torch.float32 and x.dim() == 3 and x.shape[1] <= 2
                 and all(t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.shape[0] == x.shape[0] and t.device == x.device for t in every)
                 and comp_params.shape[1] == 6 and reverb_params.shape[1] == 25 and gain_params.shape[1] == 1
@@ -106,7 +107,7 @@ class StyleTransferChain:
             ctl, gains, decays, mix = _ops.chain_controls(comp_params, reverb_params, gain_params, lo, span, None if flags is None else flags[1:2])
             eq = self.equalizer
             no_grad = not (torch.is_grad_enabled() and (x.requires_grad or eq_params.requires_grad or ctl.requires_grad))
-            if (no_grad and os.environ.get("DASP_CHAIN_FUSED_FORWARD", "1") != "0" and eq.process_fn is _functional.parametric_eq
+            if (no_grad and config.plan.chain_fused_forward and eq.process_fn is _functional.parametric_eq
                     and list(eq.param_ranges) == m._EQ_NAMES and eq_params.dim() == 2 and eq_params.shape[1] == 18
                     and eq_params.shape[0] in (1, x.shape[0]) and eq_params.is_cuda and eq_params.is_floating_point()):
                 # forward only (the reference's target synthesis, examples/style_transfer.py:293-299): EQ and compressor as ONE pass over x

@@ -27,12 +27,12 @@ namespace {
 constexpr int MT_N = 624, MT_M = 397;
 constexpr int MT_BLOCKS_PER_CHUNK = 256;
 constexpr int MT_N_BABY = 255, MT_N_GIANT = 7;
-constexpr int MT_SLOT = 9976, MT_STRIDE = 8 + 2 * MT_SLOT;
+constexpr int MT_SLOT = 10112, MT_STRIDE = 8 + 2 * MT_SLOT;     // list slot per parity class: 79 batches of 128 exponents
 constexpr int MT_PAD_INDEX = 20560;                    // = 19937 + 623: the sequence window of one jump
-constexpr int MT_SEQ_LDS = MT_PAD_INDEX + 632;         // + zeros behind it: list padding reads them (odd class: base PAD_INDEX, lanes to 2*312+1)
+constexpr int MT_SEQ_LDS = MT_PAD_INDEX + 648;         // + zeros behind it: list padding reads them (base PAD_INDEX, lanes to 2*319+1)
 constexpr int MT_JUMP_LANES = 320;                     // 313 lanes own two state words each (one more for the odd class's neighbour word)
 constexpr int MT_JUMP_THREADS = 2 * MT_JUMP_LANES;     // two halves share the exponent list
-constexpr int MT_GEN_THREADS = 256;
+constexpr int MT_GEN_THREADS = 512;                    // four regenerating waves + four Box-Muller waves
 constexpr int MT_STEP = 224;                           // new words per regeneration step: a multiple of 16 not above 227
 constexpr int MT_RING = 1024;                          // raw-word ring of a generating workgroup (a step looks 624 words back)
 
@@ -50,20 +50,24 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
 }
 __device__ __forceinline__ float mt_uniform(unsigned raw) { return (float)(mt_temper(raw) & 0xFFFFFFu) * 0x1p-24f; }
 
-__global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __restrict__ states) {
-    if (threadIdx.x < MT_N) states[threadIdx.x] = s.w[threadIdx.x];
+// chunk 0's state from the kernel argument; the other chunks' states start as zeros (a jump shared by several workgroups is summed
+// into its state with atomic XORs)
+__global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __restrict__ states, int n_chunks) {
+    if (blockIdx.x == 0) { if (threadIdx.x < MT_N) states[threadIdx.x] = s.w[threadIdx.x]; return; }
+    for (size_t k = MT_N + (size_t)(blockIdx.x - 1) * 640 + threadIdx.x; k < (size_t)n_chunks * MT_N; k += (size_t)(gridDim.x - 1) * 640) states[k] = 0u;
 }
 
 // One jump: states[dst] = g(T) states[src]. giant: src = chunk 0, polynomial N_BABY + blockIdx, dst = 256 (blockIdx + 1);
 // baby: a = blockIdx / 255, b = blockIdx % 255 + 1, src = 256 a, polynomial b - 1, dst = src + b. Word 0 of a jumped state is right in
-// its top bit only - the one bit of it the recurrence reads.
+// its top bit only - the one bit of it the recurrence reads. `parts` workgroups share a jump when there are fewer jumps than CUs (each
+// takes every parts-th batch of the exponent lists; blockIdx = jump * parts + part).
 __global__ void __launch_bounds__(MT_JUMP_THREADS)
-mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks) {
+mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks, int parts) {
     extern __shared__ unsigned seq[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, job = blockIdx.x / parts, part = blockIdx.x % parts;
     int src, dst, poly;
-    if (giant) { src = 0; poly = MT_N_BABY + blockIdx.x; dst = 256 * (blockIdx.x + 1); }
-    else { const int a = blockIdx.x / MT_N_BABY, b = blockIdx.x % MT_N_BABY + 1; src = 256 * a; poly = b - 1; dst = src + b; }
+    if (giant) { src = 0; poly = MT_N_BABY + job; dst = 256 * (job + 1); }
+    else { const int a = job / MT_N_BABY, b = job % MT_N_BABY + 1; src = 256 * a; poly = b - 1; dst = src + b; }
     if (dst >= n_chunks) return;
 
     for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) seq[k] = states[(size_t)src * MT_N + k];
@@ -76,33 +80,37 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
         __syncthreads();
     }
 
-    const unsigned short* row = table + (size_t)poly * MT_STRIDE;
-    const unsigned n_even = *reinterpret_cast<const unsigned*>(row), n_odd = *reinterpret_cast<const unsigned*>(row + 2);
-    // two halves of 320 lanes take alternate groups of eight exponents (ten waves hide the list's scalar loads and the LDS latency
-    // better than five; the LDS bandwidth is the same)
-    const int half = __builtin_amdgcn_readfirstlane(tid / MT_JUMP_LANES), t = tid % MT_JUMP_LANES;      // 320 lanes = five whole waves
+    // The exponent lists: 128 exponents (64 dwords) per wave and batch, one dword per lane (vector memory: its counter is not the
+    // LDS's - as scalar loads the list put one L2 round trip into every group of eight reads: 187 us per jump), handed to the whole
+    // wave lane by lane (v_readlane). Two halves of 320 lanes take alternate batches: ten waves hide the LDS latency better than five,
+    // the LDS bandwidth is the same. Lanes 313 .. 319 of a half run along on zeros and garbage inside the padded window.
+    const unsigned* row = reinterpret_cast<const unsigned*>(table + (size_t)poly * MT_STRIDE);
+    const int half = __builtin_amdgcn_readfirstlane(tid / MT_JUMP_LANES), t = tid % MT_JUMP_LANES, lane = tid & 63;      // 320 lanes = five whole waves
     unsigned e0 = 0u, e1 = 0u, o0 = 0u, o1 = 0u;
-    if (t <= MT_N / 2) {
-        const uint2* win = reinterpret_cast<const uint2*>(seq) + t;              // words 2 t, 2 t + 1 of the window at exponent 0
+    const uint2* win = reinterpret_cast<const uint2*>(seq) + t;                  // words 2 t, 2 t + 1 of the window at exponent 0
 #define MT_ACC(a0, a1, word, sub)                                                              \
-        { const uint2 v0 = win[(((word) & 0xFFFFu) - (sub)) >> 1], v1 = win[(((word) >> 16) - (sub)) >> 1]; \
-          a0 ^= v0.x ^ v1.x; a1 ^= v0.y ^ v1.y; }
+    { const uint2 v0 = win[(((word) & 0xFFFFu) - (sub)) >> 1], v1 = win[(((word) >> 16) - (sub)) >> 1]; \
+      a0 ^= v0.x ^ v1.x; a1 ^= v0.y ^ v1.y; }
 #define MT_CLASS(a0, a1, list, count, sub)                                                     \
-        { const uint4* lp = reinterpret_cast<const uint4*>(list);                              \
-          const int nk = (int)(count) / 8;                                                     \
-          if (half < nk) {                                                                     \
-              uint4 q = lp[half];                                                              \
-              for (int k = half; k < nk; k += 2) {                                             \
-                  const uint4 qn = lp[k + 2 < nk ? k + 2 : k];      /* the next group's exponents, asked for before this group's reads */ \
-                  MT_ACC(a0, a1, q.x, sub) MT_ACC(a0, a1, q.y, sub) MT_ACC(a0, a1, q.z, sub) MT_ACC(a0, a1, q.w, sub) \
-                  q = qn;                                                                      \
+    { const unsigned* lp = (list);                                                             \
+      const int nb = (int)(count) / 128;                                                       \
+      const int first = 2 * part + half, step = 2 * parts;                                     \
+      if (first < nb) {                                                                        \
+          unsigned nxt = lp[64 * first + lane];                                                \
+          for (int bt = first; bt < nb; bt += step) {                                          \
+              const unsigned cur = nxt;                                                        \
+              nxt = lp[64 * (bt + step < nb ? bt + step : bt) + lane];    /* the next batch, asked for before this batch's reads */ \
+              _Pragma("unroll 8")                                                              \
+              for (int k = 0; k < 64; ++k) {                                                   \
+                  const unsigned w = __builtin_amdgcn_readlane(cur, k);                        \
+                  MT_ACC(a0, a1, w, sub)                                                       \
               }                                                                                \
-          } }
-        MT_CLASS(e0, e1, row + 8, n_even, 0u)
-        MT_CLASS(o0, o1, row + 8 + MT_SLOT, n_odd, 1u)                           // odd exponent i: the aligned pair one word below
+          }                                                                                    \
+      } }
+    MT_CLASS(e0, e1, row + 4, row[0], 0u)
+    MT_CLASS(o0, o1, row + 4 + MT_SLOT / 2, row[1], 1u)                          // odd exponent i: the aligned pair one word below
 #undef MT_CLASS
 #undef MT_ACC
-    }
     // fold the halves, then: word 2 t = even sum + the odd class's UPPER word of this lane; word 2 t + 1 = even sum + the odd class's
     // LOWER word of lane t + 1
     __syncthreads();
@@ -114,8 +122,9 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
     __syncthreads();
     if (half == 0 && t < MT_N / 2) {
         unsigned* out = states + (size_t)dst * MT_N + 2 * t;
-        out[0] = e0 ^ o1;
-        out[1] = e1 ^ seq[t + 1];
+        const unsigned w0 = e0 ^ o1, w1 = e1 ^ seq[t + 1];
+        if (parts == 1) { out[0] = w0; out[1] = w1; }
+        else { atomicXor(out, w0); atomicXor(out + 1, w1); }
     }
 }
 
@@ -138,11 +147,32 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
 // One chunk: blocks 256 c + 1 .. of the sequence from states[c] (block 256 c), every aligned group of 16 draws whose last word lies
 // in those blocks (chunk 0: also the groups inside the state it starts from), the 16 tail draws it owns, and - the last chunk - the
 // generator state afterwards. word q of the chunk (q = 0 .. 623: the start state) is draw 624 (256 c) + q - (624 - rem).
+// Eight waves in two roles: waves 0-3 regenerate (two steps of 224 words per round, a barrier behind each - the serial chain of the
+// chunk), waves 4-7 turn the 448 words of the PREVIOUS round into normals meanwhile (radius before the middle barrier, angle and stores
+// behind it). One role for everything was 1,380 cycles per round, the regeneration's LDS round trips and the Box-Muller arithmetic one
+// after the other on every wave: 235 us per chunk.
+struct MtPair { float rad, ang; long long i; bool on; };
+__device__ __forceinline__ MtPair mt_pair_radius(const unsigned* ring, int qa, long long draw0, long long n_groups, bool on) {
+    MtPair r;
+    r.i = draw0 + qa;
+    r.on = on && (r.i >> 4) < n_groups;
+    const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
+    r.rad = sqrtf(-2.f * logf(1.f - ua));
+    r.ang = 6.283185307179586f * ub;
+    return r;
+}
+__device__ __forceinline__ void mt_pair_store(const MtPair& r, float* __restrict__ out) {
+    float s, co;
+    mt_sincos(r.ang, s, co);
+    if (r.on) { out[r.i] = r.rad * co; out[r.i + 8] = r.rad * s; }
+}
+
 __global__ void __launch_bounds__(MT_GEN_THREADS)
 mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out, long long n, int rem, long long beta_max,
                    unsigned* __restrict__ final_state, float* __restrict__ tail_u) {
     __shared__ unsigned ring[MT_RING];
-    const int tid = threadIdx.x, c = blockIdx.x;
+    const int tid = threadIdx.x, c = blockIdx.x, lt = tid & 255;
+    const bool producer = tid < 256;                                           // waves 0-3
     const long long beta0 = (long long)c * MT_BLOCKS_PER_CHUNK;
     const long long left_blocks = beta_max - beta0;
     const int nblk = left_blocks < MT_BLOCKS_PER_CHUNK ? (int)left_blocks : MT_BLOCKS_PER_CHUNK;
@@ -158,37 +188,39 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
     int q_done = c == 0 ? MT_N - rem : 608 + phi + (phi == 0 ? 16 : 0);        // next group start (first group ending inside block 1)
     int q_tail = c == 0 ? MT_N - rem : MT_N;                                   // tail draws are looked for in [q_tail, q_gen)
     for (;;) {
-        // Box-Muller over the complete groups in [q_done, q_gen)
-        const int groups = (q_gen - q_done) >> 4;
-        for (int p = tid; p < groups * 8; p += MT_GEN_THREADS) {
-            const int qa = q_done + 16 * (p >> 3) + (p & 7);
-            const long long i = draw0 + qa;
-            if ((i >> 4) < n_groups) {
-                const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
-                const float rad = sqrtf(-2.f * logf(1.f - ua));
-                float s, co;
-                mt_sincos(6.283185307179586f * ub, s, co);
-                out[i] = rad * co;
-                out[i + 8] = rad * s;
-            }
-        }
-        if ((n & 15) && tid < 16) {                                            // the 16 draws behind the tensor: kept as uniforms for mt_tail_kernel
-            const long long q = n + tid - draw0;
-            if (q >= q_tail && q < q_gen) tail_u[tid] = mt_uniform(ring[(int)q & (MT_RING - 1)]);
-        }
-        q_done += 16 * groups;
-        q_tail = q_gen;
-        if (q_gen >= q_end) break;
-        // two regeneration steps (448 words at most)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cnt = q_end - q_gen < MT_STEP ? q_end - q_gen : MT_STEP, q = q_gen + tid;
-            if (tid < cnt)
+        const int pairs = ((q_gen - q_done) >> 4) * 8;                         // complete groups in [q_done, q_gen): 224 per round (chunk 0's first: up to 304)
+        const bool more = q_gen < q_end;
+        const int cnt_a = !more ? 0 : q_end - q_gen < MT_STEP ? q_end - q_gen : MT_STEP;
+        const int cnt_b = q_end - q_gen - cnt_a < MT_STEP ? q_end - q_gen - cnt_a : MT_STEP;
+        MtPair pr;
+        if (producer) {
+            const int q = q_gen + lt;
+            if (lt < cnt_a)
                 ring[q & (MT_RING - 1)] = ring[(q - (MT_N - MT_M)) & (MT_RING - 1)]
                                           ^ mt_twist(ring[(q - MT_N) & (MT_RING - 1)], ring[(q - MT_N + 1) & (MT_RING - 1)]);
-            q_gen += cnt;
-            __syncthreads();
+        } else {
+            for (int p = lt + 256; p < pairs; p += 256)                        // (only chunk 0's first round has more than 256 pairs)
+                mt_pair_store(mt_pair_radius(ring, q_done + 16 * (p >> 3) + (p & 7), draw0, n_groups, true), out);
+            pr = mt_pair_radius(ring, q_done + 16 * (lt >> 3) + (lt & 7), draw0, n_groups, lt < pairs);
+            if ((n & 15) && lt < 16) {                                         // the 16 draws behind the tensor: kept as uniforms for mt_tail_kernel
+                const long long q = n + lt - draw0;
+                if (q >= q_tail && q < q_gen) tail_u[lt] = mt_uniform(ring[(int)q & (MT_RING - 1)]);
+            }
         }
+        __syncthreads();
+        if (producer) {
+            const int q = q_gen + cnt_a + lt;
+            if (lt < cnt_b)
+                ring[q & (MT_RING - 1)] = ring[(q - (MT_N - MT_M)) & (MT_RING - 1)]
+                                          ^ mt_twist(ring[(q - MT_N) & (MT_RING - 1)], ring[(q - MT_N + 1) & (MT_RING - 1)]);
+        } else {
+            mt_pair_store(pr, out);
+        }
+        __syncthreads();
+        q_done += 2 * pairs;
+        q_tail = q_gen;
+        q_gen += cnt_a + cnt_b;
+        if (!more) break;
     }
     if (c == gridDim.x - 1 && nblk > 0)
         for (int k = tid; k < MT_N; k += MT_GEN_THREADS) final_state[k] = ring[(MT_N * nblk + k) & (MT_RING - 1)];
@@ -258,16 +290,20 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
     float* tail_u = reinterpret_cast<float*>(final_state + MT_N);
     MtState s;
     for (int k = 0; k < MT_N; ++k) s.w[k] = state_host[k];
-    hipLaunchKernelGGL(mt_seed_kernel, dim3(1), dim3(640), 0, st, s, states);
+    hipLaunchKernelGGL(mt_seed_kernel, dim3(p.n_chunks > 1 ? 1 + (p.n_chunks + 63) / 64 : 1), dim3(640), 0, st, s, states, p.n_chunks);
     {   // 83 KiB of LDS per workgroup: above the 64 KiB a kernel gets unasked (per device, so every call)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_SEQ_LDS * 4);
         if (e != hipSuccess) return (int)e;
     }
-    if (p.n_chunks > 256)
-        hipLaunchKernelGGL(mt_jump_kernel, dim3((p.n_chunks - 1) / 256), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 1, p.n_chunks);
-    if (p.n_chunks > 1)
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(((p.n_chunks + 255) / 256) * MT_N_BABY), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0,
-                           p.n_chunks);
+    auto parts_for = [](int jobs) { const int k = 256 / jobs; return k < 1 ? 1 : k > 8 ? 8 : k; };      // fewer jumps than CUs: several workgroups per jump
+    if (p.n_chunks > 256) {
+        const int jobs = (p.n_chunks - 1) / 256, k = parts_for(jobs);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 1, p.n_chunks, k);
+    }
+    if (p.n_chunks > 1) {
+        const int jobs = p.n_chunks > 256 ? ((p.n_chunks + 255) / 256) * MT_N_BABY : p.n_chunks - 1, k = parts_for(jobs);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0, p.n_chunks, k);
+    }
     hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), 0, st, states, out, n, left - 1, p.beta_max, final_state, tail_u);
     if (n & 15) hipLaunchKernelGGL(mt_tail_kernel, dim3(1), dim3(64), 0, st, tail_u, out, n);
     if (left_after) *left_after = p.left_after;

@@ -263,8 +263,11 @@ def noise_shaped_reverberation(
               band11_decay)
     if _ops.noise_shaped_reverb_ok(x, gains, decays, mix, noise):
         # the 25 tensors as they are: torch.ops.dasp.noise_shaped_reverb stacks them and hands their gradients back in C++ (csrc/torch_ext)
-        filters, noise, seed, offset = _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset)
-        return _ops.noise_shaped_reverb(x, noise, filters, gains, decays, mix, int(num_samples), seed, offset, 0.0)
+        filters, noise, seed, offset, pending = _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset)
+        try:
+            return _ops.noise_shaped_reverb(x, noise, filters, gains, decays, mix, int(num_samples), seed, offset, 0.0)
+        finally:
+            pending.finish()
     return _reverb_from_matrices(x, sample_rate, _StackColumns.apply(*gains), _StackColumns.apply(*decays), mix.view(bs), num_samples, num_bandpass_taps, noise,
                                  device_noise, noise_seed, noise_seed_offset)
 
@@ -287,9 +290,11 @@ class _StackColumns(torch.autograd.Function):
 
 def _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset):
     """The filter bank on x's device and the white noise of one call, as the reference draws it (functional.py:548) or as the keywords of
-    noise_shaped_reverberation ask for it: (filters, noise tensor or None, seed or None, seed offset or None)."""
+    noise_shaped_reverberation ask for it: (filters, noise tensor or None, seed or None, seed offset or None, pending). `pending.finish()`
+    installs the CPU generator's state after a default draw (its read-back rides behind the generating kernels): call it once the
+    forward kernels are queued, before returning to the caller."""
     filters = _device_filterbank(int(num_bandpass_taps), float(sample_rate), x.device)
-    seed = None
+    seed, pending = None, _mt19937._NothingPending()
     if noise_seed_offset is not None and (noise is not None or not (device_noise or noise_seed is not None)):
         raise ValueError("noise_seed_offset only applies to the generated noise (device_noise=True or noise_seed=...)")
     if noise is None:
@@ -299,8 +304,8 @@ def _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_
         else:
             # the reference's draw (functional.py:548), made where it is used: the values and the CPU generator's state afterwards are
             # those of torch.randn(bs*2, 12, ...) on the global CPU generator, computed by csrc/mtrand.hip from that generator's state
-            noise = _mt19937.randn_cpu_stream(x.shape[0] * 2, 12, num_samples + num_bandpass_taps - 1, device=x.device)
-    return filters, noise, seed, (noise_seed_offset if seed is not None else None)
+            noise, pending = _mt19937.randn_cpu_stream(x.shape[0] * 2, 12, num_samples + num_bandpass_taps - 1, device=x.device, defer=True)
+    return filters, noise, seed, (noise_seed_offset if seed is not None else None), pending
 
 
 def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samples=65536, num_bandpass_taps=1023, noise=None, device_noise=False,
@@ -308,8 +313,11 @@ def _reverb_from_matrices(x, sample_rate, band_gains, band_decays, mix, num_samp
     """noise_shaped_reverberation on the band gains / decays as (bs, 12) matrices and mix (bs): what NoiseShapedReverb.process_normalized has
     as slices of its de-normalised (bs, 25) tensor. x: (bs, 1 or 2, seq_len).
     decay_bound > 0: the caller vouches that no band decay exceeds it (a validated parameter range) - lets the filter bank skip a launch."""
-    filters, noise, seed, offset = _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset)
-    return _ops_reverb(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed, offset, float(decay_bound))
+    filters, noise, seed, offset, pending = _reverb_noise(x, sample_rate, num_samples, num_bandpass_taps, noise, device_noise, noise_seed, noise_seed_offset)
+    try:
+        return _ops_reverb(x, noise, filters, band_gains.to(x.device), band_decays.to(x.device), mix.to(x.device), int(num_samples), seed, offset, float(decay_bound))
+    finally:
+        pending.finish()
 
 
 def _dynamics_from_matrix(mode, x, sample_rate, controls, eps=1e-8, lookahead_samples=0):

@@ -4,12 +4,11 @@ PyTorch is used for device memory, streams and autograd plumbing only; every num
 the HIP kernels in csrc/. Nothing here falls back to torch math on a missing library or a CPU tensor.
 """
 import ctypes
-import os
 
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _lib, config
 from ._lib import call, check, ptr, stream
 
 FILTER_TYPES = {"peaking": 0, "low_shelf": 1, "high_shelf": 2, "low_pass": 3, "high_pass": 4}
@@ -34,12 +33,11 @@ def _segment_tiles(rows, N, generic=False):
     0.078 -> 0.032 ms, backward 0.177 -> 0.047 ms) for four more kernel launches per call, all issued by the same C call. It is taken
     whenever the library's planner proposes a cut (at most 128 rows and at least 16 tiles per row; above that one workgroup per row runs at
     twice the waves per row up to 256 rows and is faster), eager or captured.
-    DASP_SOS_SEGMENT=0 never, DASP_SOS_SEGMENT_TILES=<power of two> fixes the segment length."""
-    if os.environ.get("DASP_SOS_SEGMENT", "auto") == "0":
+    config.plan.sos_segment = False: never; config.plan.sos_segment_tiles = <power of two> fixes the segment length."""
+    if not config.plan.sos_segment:
         return 0
-    fixed = os.environ.get("DASP_SOS_SEGMENT_TILES")
-    if fixed:
-        return int(fixed)
+    if config.plan.sos_segment_tiles:
+        return int(config.plan.sos_segment_tiles)
     # generic: a cascade given by its coefficients (no design launch per call: its segmented rows keep the pre-pass launches, five launches
     # per step) - there segments stop paying above 64 rows (profiles/r04/seg_crossover.log); the designed paths go up to the planner's 128
     return 0 if generic and rows > 64 else int(_lib.lib().dasp_sos_segment_tiles(rows, N))
@@ -437,7 +435,7 @@ def _dyn_forward(x, mode, sample_rate, eps, lookahead, ctl, need):
     carries = torch.empty(L.dasp_dyn_carry_floats(B, N), dtype=torch.float32, device=x.device) if need else None
     lin = torch.empty(B, N, dtype=torch.float32, device=x.device) if lookahead > 0 else None
     # few items: every item is cut into segments that run as independent workgroups (dasp_hip.h, "Few batch items")
-    tseg = 0 if os.environ.get("DASP_DYN_SEGMENT", "auto") == "0" else int(os.environ.get("DASP_DYN_SEGMENT_TILES") or L.dasp_dyn_segment_tiles(B, N))
+    tseg = 0 if not config.plan.dyn_segment else int(config.plan.dyn_segment_tiles or L.dasp_dyn_segment_tiles(B, N))
     segbuf = torch.empty(2 * B * L.dasp_dyn_segments(N, tseg), dtype=torch.float32, device=x.device) if tseg else None
     if tseg:
         call("dasp_dynamics_forward_seg", mode, ptr(x32), ptr(ctl), ptr(y), ptr(carries), ptr(lin), ptr(segbuf), B, C, N, float(sample_rate),
@@ -647,7 +645,7 @@ def chain_eq_compressor_forward(x, eq_pn, types, lo, span, sample_rate, ctl, mod
     with torch.cuda.device(dev):
         x32, pn32, c32 = _f32c(x), _f32c(eq_pn), _f32c(ctl)
         Bp = pn32.shape[0]
-        tseg = 0 if os.environ.get("DASP_CHAIN_SEGMENT", "auto") == "0" else int(os.environ.get("DASP_CHAIN_SEGMENT_TILES") or L.dasp_chain_segment_tiles(B, N))
+        tseg = 0 if not config.plan.chain_segment else int(config.plan.chain_segment_tiles or L.dasp_chain_segment_tiles(B, N))
         n_tab = _round64(Bp * L.dasp_sos_table_floats(S))
         n_seg = _round64(L.dasp_chain_seg_floats(B, C, N, S, tseg)) if tseg else 0
         f32 = torch.empty(n_tab + n_seg, dtype=torch.float32, device=dev)

@@ -4,14 +4,13 @@ The reference follows the dtype of its input (`.type_as(x)`, dasp_pytorch/signal
 float64 arithmetic. The fp32 kernels have no double instantiation; these plain sequential kernels are the genuine fp64 path for the
 recurrences (parametric_eq / sosfilt_via_fsm / lfilter_via_fsm, compressor / expander) and the elementwise effects (gain, distortion):
 right for validation and torch.autograd.gradcheck, not tuned for throughput. The FFT-based and stereo ops compute in fp32 only and
-refuse float64 input unless DASP_FP64_AS_FP32=1 asks for the old cast-compute-cast behaviour (`require_fp32_ok`).
+refuse float64 input unless config.plan.fp64_as_fp32 asks for the old cast-compute-cast behaviour (`require_fp32_ok`).
 """
-import os
 
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _lib, config
 from ._lib import call, ptr, stream
 
 
@@ -21,9 +20,9 @@ def is_f64(x):
 
 def require_fp32_ok(x, what):
     """Ops without a double-precision path: float64 input raises instead of being rounded to fp32 behind the caller's back."""
-    if is_f64(x) and os.environ.get("DASP_FP64_AS_FP32", "0") != "1":
+    if is_f64(x) and not config.plan.fp64_as_fp32:
         raise _lib.DaspHipError(
-            f"{what}: float64 input, but this op computes in float32 only. Cast the input (`x.float()`), or set DASP_FP64_AS_FP32=1 to have "
+            f"{what}: float64 input, but this op computes in float32 only. Cast the input (`x.float()`), or set dasp_pytorch_amd.config.plan.fp64_as_fp32 = True to have "
             "it cast, computed in fp32 and cast back (the result then has fp32 accuracy in a float64 tensor).")
 
 
@@ -102,9 +101,9 @@ class LFilterFunction(torch.autograd.Function):
             y = torch.empty_like(xc)
             need = any(ctx.needs_input_grad)
             wsave = torch.empty(N * B * C, dtype=torch.float64, device=dev) if need else None
-            # the chunk length is resolved ONCE per filter operation (developer override DASP_LFILTER_CHUNK, tests: chunk boundaries at odd
+            # the chunk length is resolved ONCE per filter operation (developer override config.plan.lfilter_chunk, tests: chunk boundaries at odd
             # places) and handed to the size query, the forward and - through ctx - the backward call: they must cut time the same way
-            chunk = ctx.chunk = max(int(os.environ.get("DASP_LFILTER_CHUNK", "0") or 0), 0)
+            chunk = ctx.chunk = max(int(config.plan.lfilter_chunk or 0), 0)
             nwork = _lib.lib().dasp_lfilter_work_doubles(B * C, N, K, chunk)
             work = torch.empty(nwork, dtype=torch.float64, device=dev) if nwork > 0 else None
             call("dasp_lfilter_forward", ptr(xc), ptr(b64), ptr(a64), Bs, ptr(y), ptr(wsave), ptr(work), nwork, B * C, N, K, int(f64), chunk, stream())

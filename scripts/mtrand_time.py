@@ -1,12 +1,13 @@
 """Time the device reproduction of torch's CPU random stream (csrc/mtrand.hip) against the host draw it replaces, at the reverb's noise
 shapes. usage: python scripts/mtrand_time.py [bs ...]   (noise tensor = (2 bs, 12, 65536 + 1022))"""
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dasp_pytorch_amd import _mt19937 as mt
 
 dev = "cuda:0"

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from dasp_pytorch_amd import config
+
 from oracle import dasp_oracle as orc
 from tests.util import linf_peak, record
 
@@ -65,9 +67,9 @@ def test_fused_forward_equals_unfused_sequence(D, monkeypatch, B, C, N, tiles):
     tile and a last segment shorter than the others): the fused pass gives what parametric_eq followed by compressor gives."""
     x, eq_pn, comp = make(B, C, N, 100 + N % 97 + B)
     if tiles:
-        monkeypatch.setenv("DASP_CHAIN_SEGMENT_TILES", str(tiles))
+        monkeypatch.setattr(config.plan, "chain_segment_tiles", tiles)
     yf = fused(x, eq_pn, comp)
-    monkeypatch.delenv("DASP_CHAIN_SEGMENT_TILES", raising=False)
+    monkeypatch.setattr(config.plan, "chain_segment_tiles", None)
     yu = unfused(D, x, eq_pn, comp)
     from dasp_pytorch_amd import _lib
     if tiles is None and B == 16:
@@ -76,7 +78,7 @@ def test_fused_forward_equals_unfused_sequence(D, monkeypatch, B, C, N, tiles):
     record(f"chain_fused_vs_unfused[{B},{C},{N},{tiles}]", y=e.max())
     assert torch.isfinite(yf).all() and e.max() < 1e-5, e          # (measured <= 4.0e-6; the differentiable sequence is itself ~2e-6 from the oracle, this path 2.8e-7)
     if tiles is None and B <= 5:      # segmented and plain fused passes agree with each other as well
-        monkeypatch.setenv("DASP_CHAIN_SEGMENT", "0")
+        monkeypatch.setattr(config.plan, "chain_segment", False)
         y0 = fused(x, eq_pn, comp)
         assert linf_peak(yf.cpu().numpy(), y0.cpu().numpy()).max() < 1e-5
 
@@ -87,9 +89,9 @@ def test_fused_forward_with_one_shared_eq(D, monkeypatch, B, C, N, tiles):
     table shared by every workgroup, the segment counters of the pre-passes then count the whole call's workgroups."""
     x, eq_pn, comp = make(B, C, N, 55 + B)
     if tiles:
-        monkeypatch.setenv("DASP_CHAIN_SEGMENT_TILES", str(tiles))
+        monkeypatch.setattr(config.plan, "chain_segment_tiles", tiles)
     yf = fused(x, eq_pn[:1], comp)
-    monkeypatch.delenv("DASP_CHAIN_SEGMENT_TILES", raising=False)
+    monkeypatch.setattr(config.plan, "chain_segment_tiles", None)
     yu = unfused(D, x, eq_pn[:1], comp)
     e = linf_peak(yf.cpu().numpy(), yu.cpu().numpy())
     record(f"chain_fused_shared_eq[{B},{C},{N},{tiles}]", y=e.max())

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from dasp_pytorch_amd import config
+
 from tests.util import linf_peak, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -123,7 +125,7 @@ def test_gradcheck_all_fp64_ops(D):
     assert torch.autograd.gradcheck(D.signal.lfilter_via_fsm, (x1, b, a), eps=1e-6, atol=1e-7, rtol=1e-5, nondet_tol=1e-12)
     # K = 5 and K = 11 coefficients (csrc/lfilter.hip; a0 != 1: the normalisation is differentiated by torch), several chunks of time
     import os
-    os.environ["DASP_LFILTER_CHUNK"] = "13"
+    config.plan.lfilter_chunk = 13
     try:
         for K in (5, 11):
             bl = ((rnd(B, K) - 0.5) * 0.5).requires_grad_(True)
@@ -132,7 +134,7 @@ def test_gradcheck_all_fp64_ops(D):
         assert torch.autograd.gradcheck(lambda x_, b_: D.signal.lfilter_via_fsm(x_, b_, None), (x1, ((rnd(1, 7) - 0.5)).requires_grad_(True)), eps=1e-6,
                                         atol=1e-7, rtol=1e-5, nondet_tol=1e-10)                      # FIR shared by the batch
     finally:
-        del os.environ["DASP_LFILTER_CHUNK"]
+        config.plan.lfilter_chunk = 0
 
 
 def test_ops_without_a_double_path_refuse_float64(D, monkeypatch):
@@ -145,6 +147,6 @@ def test_ops_without_a_double_path_refuse_float64(D, monkeypatch):
         D.stereo_widener(x, SR, one(0.3).reshape(2, 1))
     with pytest.raises(DaspHipError, match="float64"):
         D.losses.MultiResolutionSTFTLoss()(x, x)
-    monkeypatch.setenv("DASP_FP64_AS_FP32", "1")            # the explicit opt-in: cast, compute in fp32, cast back
+    monkeypatch.setattr(config.plan, "fp64_as_fp32", True)            # the explicit opt-in: cast, compute in fp32, cast back
     y = D.stereo_widener(x, SR, one(0.3).reshape(2, 1))
     assert y.dtype == torch.float64

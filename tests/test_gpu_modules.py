@@ -4,6 +4,8 @@ reach the normalised parameter tensor, and the reference's EQ -> compressor -> r
 import pytest
 import torch
 
+from dasp_pytorch_amd import config
+
 pytestmark = pytest.mark.gpu
 SR = 44100
 
@@ -195,7 +197,7 @@ def test_chain_controls_in_one_launch_equal_the_torch_ops(D, monkeypatch):
     w = torch.randn(B, 2, N, device="cuda:0", generator=g)
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("DASP_CHAIN_FUSED_CONTROLS", flag)
+        monkeypatch.setattr(config.plan, "chain_fused_controls", flag != "0")
         pp = [p.clone().requires_grad_(True) for p in ps]
         torch.manual_seed(13)
         y = chain.process_normalized(x, *pp)

@@ -15,6 +15,8 @@ import numpy as np
 import pytest
 import torch
 
+from dasp_pytorch_amd import config
+
 from oracle import dasp_oracle as orc
 from tests.util import linf_peak, load_golden, record
 
@@ -453,9 +455,9 @@ def test_segmented_rows_equal_plain_rows(D, monkeypatch, B, C, N, bcast, tiles):
     x = (rng.random((B, C, N)) * 2 - 1).astype(np.float32); w = rng.standard_normal((B, C, N)).astype(np.float32)
 
     def run(mode):
-        monkeypatch.setenv("DASP_SOS_SEGMENT", mode)
+        monkeypatch.setattr(config.plan, "sos_segment", mode != "0")
         if tiles:
-            monkeypatch.setenv("DASP_SOS_SEGMENT_TILES", str(tiles))
+            monkeypatch.setattr(config.plan, "sos_segment_tiles", tiles)
         xt = dev(x).requires_grad_(True)
         cols = [dev(p[:, i]).requires_grad_(True) for i in range(18)]
         y = D.parametric_eq(xt, SR, *cols)
@@ -594,12 +596,12 @@ def test_lfilter_via_fsm_long_filters_chunk_stitching(D, monkeypatch, chunk):
     x = (rng.random((B, 1, N)) * 2 - 1).astype(np.float32); w = rng.standard_normal((B, 1, N)).astype(np.float32)
     b32, a32 = b.astype(np.float32), a.astype(np.float32)
     if chunk is not None:
-        monkeypatch.setenv("DASP_LFILTER_CHUNK", str(chunk))
+        monkeypatch.setattr(config.plan, "lfilter_chunk", chunk)
     xt, bt, at = dev(x).requires_grad_(True), dev(b32).requires_grad_(True), dev(a32).requires_grad_(True)
     y = D.signal.lfilter_via_fsm(xt, bt, at)
     (y * dev(w)).sum().backward()
     torch.cuda.synchronize()
-    monkeypatch.delenv("DASP_LFILTER_CHUNK", raising=False)
+    monkeypatch.setattr(config.plan, "lfilter_chunk", 0)
     # the true recurrence in fp64 (scipy) - with poles at 0.999 the impulse response has not decayed within 3000 samples, where the
     # reference's circular frequency-sampling result differs from it by design
     import scipy.signal
@@ -609,10 +611,10 @@ def test_lfilter_via_fsm_long_filters_chunk_stitching(D, monkeypatch, chunk):
     record(f"lfilter_long_chunks[{chunk}]", **e)
     assert e["y"] < TOL_SIG and e["gx"] < 2 * TOL_SIG, e
     if chunk is not None:                      # coefficient gradients: the same call in one chunk is the yardstick
-        monkeypatch.setenv("DASP_LFILTER_CHUNK", str(10 ** 9))
+        monkeypatch.setattr(config.plan, "lfilter_chunk", 10 ** 9)
         x2, b2, a2 = dev(x).requires_grad_(True), dev(b32).requires_grad_(True), dev(a32).requires_grad_(True)
         (D.signal.lfilter_via_fsm(x2, b2, a2) * dev(w)).sum().backward()
-        monkeypatch.delenv("DASP_LFILTER_CHUNK")
+        monkeypatch.setattr(config.plan, "lfilter_chunk", 0)
         assert linf_peak(bt.grad.cpu().numpy(), b2.grad.cpu().numpy()).max() < 1e-9
         assert linf_peak(at.grad.cpu().numpy(), a2.grad.cpu().numpy()).max() < 1e-9
 

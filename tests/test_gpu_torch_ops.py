@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from dasp_pytorch_amd import config
+
 from tests.util import linf_peak, load_golden, record
 
 pytestmark = pytest.mark.gpu
@@ -42,7 +44,7 @@ def test_both_bindings_give_the_same_bits(T, monkeypatch, C):
     x, ps, w = _chain_inputs(C=C)
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("DASP_TORCH_OPS", flag)
+        monkeypatch.setattr(config.plan, "torch_ops", flag != "0")
         assert T.enabled() == (flag == "1")
         chain = StyleTransferChain(SR, num_samples=8192, device_noise=True, noise_seed=11)
         xx = x.clone().requires_grad_(True)
@@ -59,7 +61,7 @@ def test_both_bindings_give_the_same_bits(T, monkeypatch, C):
 def test_chain_against_the_reference_through_each_binding(T, monkeypatch, binding):
     """tests/golden/chain_b2c1_n20000.npz (the reference's own EQ -> compressor -> reverb -> gain run with gradients) through each binding."""
     from dasp_pytorch_amd.chain import StyleTransferChain
-    monkeypatch.setenv("DASP_TORCH_OPS", "1" if binding == "torch_ops" else "0")
+    monkeypatch.setattr(config.plan, "torch_ops", binding == "torch_ops")
     g = load_golden("chain_b2c1_n20000")
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     x = dev(g["x"]).requires_grad_(True)
@@ -230,7 +232,7 @@ def test_reference_signatures_through_both_bindings(T, monkeypatch, op):
             return real(*a, **k)
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("DASP_TORCH_OPS", flag)
+        monkeypatch.setattr(config.plan, "torch_ops", flag != "0")
         if flag == "1":
             monkeypatch.setattr(torch.ops.dasp, opname, Spy(), raising=False)
         y = fn()

@@ -47,7 +47,7 @@ def test_jump_table_layout(table):
     assert table.shape == (mt.N_BABY + mt.N_GIANT, mt.STRIDE) and table.dtype == np.uint16
     for row in table[[0, 1, 100, 254, 255, 261]]:
         n_even, n_odd = row[:4].view(np.uint32)[:2]
-        assert n_even % 8 == 0 and n_odd % 8 == 0 and n_even <= mt.SLOT and n_odd <= mt.SLOT
+        assert n_even % 128 == 0 and n_odd % 128 == 0 and n_even <= mt.SLOT and n_odd <= mt.SLOT
         ev, od = row[8:8 + n_even], row[8 + mt.SLOT:8 + mt.SLOT + n_odd]
         assert (ev % 2 == 0).all() and (od % 2 == 1).all()
         assert (ev[ev < mt.PAD_INDEX] < mt.DEG).all() and (od[od < mt.PAD_INDEX] < mt.DEG).all()
