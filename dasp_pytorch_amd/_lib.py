@@ -33,9 +33,9 @@ SIGNATURES = {
     "dasp_sosfilt_backward": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
     "dasp_sos_grad_finalize": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "dasp_sosfilt_backward_grads": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _p]),
-    "dasp_sosfilt_backward_ex": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p]),
-    "dasp_sos_grad_finalize_ex": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "dasp_sosfilt_backward_grads_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _i, _p]),
+    "dasp_sosfilt_backward_ex": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p]),
+    "dasp_sos_grad_finalize_ex": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "dasp_sosfilt_backward_grads_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _p]),
     "dasp_peq_forward": (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, ctypes.POINTER(ctypes.c_int), _d, _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
     "dasp_peq_forward_norm": (_i, [_p, _i, _i, ctypes.POINTER(ctypes.c_int), _d, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _p,
                                    _p, _p, _p, _p, _p, _i, _i, _l, _l, _p, _p, _p]),
@@ -47,7 +47,7 @@ SIGNATURES = {
     "dasp_chain_seg_floats": (_l, [_l, _l, _l, _i, _l]),
     "dasp_chain_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _d, ctypes.c_float, _l, _p, _p, _p]),
     "dasp_peq_backward": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _l, _p, _p, _p]),
-    "dasp_sosfilt_backward_seg_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _i, _p]),
+    "dasp_sosfilt_backward_seg_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _p]),
     "dasp_biquad_design": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p]),
     "dasp_biquad_backward": (_i, [_p, _p, _i, _p, _p]),
     "dasp_sos_segment_tiles": (_l, [_l, _l]),
@@ -109,6 +109,14 @@ SIGNATURES = {
     "dasp_reverb_forward_rng": (_i, [_p, ctypes.c_ulonglong, _p] + [_p] * 11 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
     "dasp_reverb_backward_rng": (_i, [_p, _p, ctypes.c_ulonglong, _p] + [_p] * 16 + [_i, _i, _l, _i, _i, _i, ctypes.c_float, _p]),
     "dasp_reverb_noise": (_i, [ctypes.c_ulonglong, _p, _p, _i, _i, _l, _p]),
+    "dasp_device_error": (_i, []),
+    "dasp_device_error_clear": (None, []),
+    "dasp_plan_lookback": (_i, [_i]),
+    "dasp_test_lookback_timeout": (_i, [_i]),
+    "dasp_test_lookback_stall": (_i, [_p, _p, _p]),
+    "dasp_test_spin": (_i, [_i, _i, _d, _p]),
+    "dasp_test_stream_with_cus": (_i, [_i, ctypes.POINTER(ctypes.c_void_p)]),
+    "dasp_test_stream_destroy": (_i, [_p]),
     "dasp_mt_layout": (_i, [ctypes.POINTER(ctypes.c_int)]),
     "dasp_mt_max_values": (ctypes.c_longlong, []),
     "dasp_mt_scratch_words": (_l, [_i, ctypes.c_longlong]),
@@ -134,13 +142,19 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        if torch.cuda.is_available():
+            L.dasp_device_error()           # allocates the current device's error words now - not under some later stream capture
     return _lib
 
 
 
 def check(status, what):
     if status != 0:
-        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(status, f"hipError {status}")
+        kind = {-1: "invalid argument", -2: "unsupported configuration",
+                -3: "DASP_ERR_DEVICE: a kernel of an EARLIER segmented call on this device gave up waiting for a look-back word and wrote NaN "
+                    f"(family bits {lib().dasp_device_error():#x}: 1 EQ forward, 2 EQ backward, 4 dynamics forward, 8 dynamics backward); results since then "
+                    "are not to be trusted. dasp_pytorch_amd.config.plan.lookback = False selects the two-launch forms; _lib.lib().dasp_device_error_clear() re-arms"
+                }.get(status, f"hipError {status}")
         raise DaspHipError(f"{what} failed: {kind}")
 
 

@@ -8,7 +8,10 @@ to be known before anything is imported. Tests set these with `monkeypatch.setat
     torch_ops                                     False: the ctypes autograd binding (ops.py) instead of torch.ops.dasp.* (csrc/torch_ext)
     chain_fused_controls / chain_fused_forward    False: StyleTransferChain without its fused control launch / fused no-grad EQ + compressor pass
     fp64_as_fp32                                  True: ops without a double-precision path cast float64 input instead of raising
-    lfilter_chunk                                 samples per chunk of time of csrc/lfilter.hip (0 = the library's plan)"""
+    lfilter_chunk                                 samples per chunk of time of csrc/lfilter.hip (0 = the library's plan)
+    lookback                                      False: the segmented launches in their two-launch forms (pre-pass + pass: no workgroup ever
+                                                  waits for another) instead of the one-launch look-back forms; kept in the kernel library
+                                                  (dasp_plan_lookback), so it holds for both bindings"""
 import contextlib
 
 
@@ -24,6 +27,16 @@ class _Plan:
     chain_fused_forward = True
     fp64_as_fp32 = False
     lfilter_chunk = 0
+
+    @property
+    def lookback(self):
+        from . import _lib
+        return bool(_lib.lib().dasp_plan_lookback(-1))
+
+    @lookback.setter
+    def lookback(self, on):
+        from . import _lib
+        _lib.lib().dasp_plan_lookback(1 if on else 0)
 
 
 plan = _Plan()

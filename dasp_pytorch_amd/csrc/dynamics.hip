@@ -253,7 +253,7 @@ template <int MODE, int W, int TPW>
 __global__ void __launch_bounds__(64 * W)
 dyn_fwd_lookback_kernel(const float* __restrict__ x, const DynCtl ctl, float* __restrict__ y, float* __restrict__ carries,
                         float* __restrict__ lin_buf, int C, int N, int nt, int vec, int look, double sample_rate, float eps, int G,
-                        unsigned long long* __restrict__ words, int* __restrict__ counters, unsigned tag) {
+                        unsigned long long* __restrict__ words, int* __restrict__ counters, unsigned tag, unsigned* __restrict__ err) {
     constexpr int Tseg = W * TPW;
     __shared__ float lds[W * 4];
     __shared__ int s_read;
@@ -313,12 +313,7 @@ dyn_fwd_lookback_kernel(const float* __restrict__ x, const DynCtl ctl, float* __
     if (seg > 0) {
         double acc = 0.0;
         for (int j = lane; j < seg; j += 64) {
-            float z = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                const unsigned long long w = __hip_atomic_load(wb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(w >> 32) == tag) { z = __builtin_bit_cast(float, (unsigned)w); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
+            const float z = lookback_poll(wb + j, tag, err, DASP_DEVERR_DYN_FWD);        // (common.hpp: a word that never arrives sets the device error word)
             acc += (double)z * exp(rate * (double)((long)Tseg * DY_TS) * (double)(seg - 1 - j));
         }
         start = __shfl(wave_sum(acc), 0, 64);
@@ -391,10 +386,13 @@ dyn_bwd_kernel(const float* __restrict__ x, const DynCtl ctl, const float* __res
                float* __restrict__ partials, int C, int N, int nt, int vec, int look, double sample_rate, float eps,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
                int* __restrict__ counters = nullptr, float* __restrict__ chain_start = nullptr, const DynGrad gctl = DynGrad{},
-               unsigned tag = 0) {
+               unsigned tag = 0, unsigned* __restrict__ err = nullptr) {
     __shared__ float lds[W * 4];
     __shared__ float ring[DMA ? W * DY_RING : 1];
-    const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x, seg = SEG ? blockIdx.x % G : 0;
+    // (SEG 3: the segments of an item in groups of eight, the highest group first - common.hpp lookback_bwd_segment: the segments above a
+    // workgroup's own belong to workgroups with smaller indices or to the up to seven right behind it)
+    const int lane = lane_id(), wave = wave_id(), b = SEG ? blockIdx.x / G : blockIdx.x,
+              seg = SEG == 3 ? lookback_bwd_segment(blockIdx.x % G, G) : SEG ? blockIdx.x % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // tiles t1 - 1 .. t0
     const DynItem it = load_item(ctl, b, sample_rate, eps);
     const float pw16 = alpha_pow4(it.alpha, (lane & 15) + 1), pw32 = alpha_pow4(it.alpha, (lane & 31) + 1), pws = alpha_pow4(it.alpha, lane);
@@ -589,12 +587,7 @@ dyn_bwd_kernel(const float* __restrict__ x, const DynCtl ctl, const float* __res
         if (seg + 1 < G) {
             double acc = 0.0;
             for (int j = seg + 1 + lane; j < G; j += 64) {
-                float z = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
-                for (int spin = 0; spin < (1 << 22); ++spin) {
-                    const unsigned long long w = __hip_atomic_load(wb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(w >> 32) == tag) { z = __builtin_bit_cast(float, (unsigned)w); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+                const float z = lookback_poll(wb + j, tag, err, DASP_DEVERR_DYN_BWD);
                 acc += (double)z * exp(rate * (double)((long)Tseg * DY_TS) * (double)(j - seg - 1));
             }
             above = __shfl(wave_sum(acc), 0, 64);
@@ -792,14 +785,6 @@ long dasp_dyn_segment_tiles(long B, long N) {
     while (B * ((nt + T - 1) / T) > 256 && T < nt) T *= 2;
     return (nt + T - 1) / T > 1 ? T : 0;
 }
-// compute units of the current device (the backward look-back needs an item's G workgroups resident together: one per CU is always possible)
-static int dyn_compute_units() {
-    static int cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
-    return cus[dev];
-}
 long dasp_dyn_segments(long N, long Tseg) { return Tseg > 0 ? (dasp_dyn_num_tiles(N) + Tseg - 1) / Tseg : 1; }
 
 static int dynamics_forward_seg_impl(int mode, const float* x, const DynCtl ctl, float* y, float* carries, float* lin_buf, float* segbuf, int B,
@@ -832,13 +817,15 @@ static int dynamics_forward_seg_impl(int mode, const float* x, const DynCtl ctl,
                        lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr)
     /* one launch (dyn_fwd_lookback_kernel): Tseg = 1, 2 or 4 tiles per forward wave - what the planner proposes up to (32, c, 262144) */
     const long tpw = Tseg % kDWF == 0 ? Tseg / kDWF : 0;
-    if (DASP_DYN_LOOKBACK && counters && (tpw == 1 || tpw == 2 || tpw == 4) && !(reinterpret_cast<uintptr_t>(segbuf) & 7)) {
+    if (DASP_DYN_LOOKBACK && lookback_enabled() && counters && (tpw == 1 || tpw == 2 || tpw == 4) && !(reinterpret_cast<uintptr_t>(segbuf) & 7)) {
+        if (error_pending()) return DASP_ERR_DEVICE;
+        unsigned* err = error_words_device();
         static std::atomic<unsigned> calls{0x2545F491u};
         unsigned tag = calls.fetch_add(0x9E3779B1u) | 1u;                 // never 0 (= a returned word)
         unsigned long long* words = reinterpret_cast<unsigned long long*>(segbuf);
 #define DASP_DYN_FWD_LB(MODE_, TPW_)                                                                                                            \
         hipLaunchKernelGGL((dyn_fwd_lookback_kernel<MODE_, kDWF, TPW_>), dim3(B * G), dim3(64 * kDWF), 0, st, x, ctl, y, carries, lb, C, (int)N,  \
-                           nt, vec, lookahead, sample_rate, eps, G, words, counters, tag)
+                           nt, vec, lookahead, sample_rate, eps, G, words, counters, tag, err)
         if (mode == 0) { if (tpw == 1) { DASP_DYN_FWD_LB(0, 1); } else if (tpw == 2) { DASP_DYN_FWD_LB(0, 2); } else { DASP_DYN_FWD_LB(0, 4); } }
         else { if (tpw == 1) { DASP_DYN_FWD_LB(1, 1); } else if (tpw == 2) { DASP_DYN_FWD_LB(1, 2); } else { DASP_DYN_FWD_LB(1, 4); } }
 #undef DASP_DYN_FWD_LB
@@ -879,17 +866,21 @@ static int dynamics_backward_seg_impl(int mode, const float* x, const DynCtl ctl
     hipLaunchKernelGGL((dyn_bwd_kernel<MODE_, kDW, DMA_, 1>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials,    \
                        C, (int)N, nt, vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)start, (float*)nullptr, counters,           \
                        (float*)nullptr, gctl)
-    /* one launch (dyn_bwd_kernel<SEG = 3>): two tiles per backward wave, the LDS-ring variant; a workgroup waits for the item's LATER
-       segments, which are running or about to: the dispatcher hands out workgroups in index order and an item's G fit the device */
-    if (DASP_DYN_LOOKBACK && counters && dma && Tseg == 2 * kDW && G <= DY_GMAX && G <= dyn_compute_units() && !(reinterpret_cast<uintptr_t>(segbuf) & 7)) {
+    /* one launch (dyn_bwd_kernel<SEG = 3>): two tiles per backward wave, the LDS-ring variant; a workgroup needs the item's segments ABOVE
+       its own - workgroups with smaller indices or the up to seven right behind it (common.hpp lookback_bwd_segment) */
+    const void* lb_kernel = mode == 0 ? reinterpret_cast<const void*>(dyn_bwd_kernel<0, kDW, true, 3>) : reinterpret_cast<const void*>(dyn_bwd_kernel<1, kDW, true, 3>);
+    if (DASP_DYN_LOOKBACK && lookback_enabled() && counters && dma && Tseg == 2 * kDW && G <= DY_GMAX && !(reinterpret_cast<uintptr_t>(segbuf) & 7) &&
+        lookback_has_room(lb_kernel, 64 * kDW)) {
+        if (error_pending()) return DASP_ERR_DEVICE;
+        unsigned* err = error_words_device();
         static std::atomic<unsigned> calls{0x6C8E9CF5u};
         const unsigned tag = calls.fetch_add(0x9E3779B1u) | 1u;
         if (mode == 0)
             hipLaunchKernelGGL((dyn_bwd_kernel<0, kDW, true, 3>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials, C, (int)N, nt,
-                               vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, segbuf, counters, (float*)nullptr, gctl, tag);
+                               vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, segbuf, counters, (float*)nullptr, gctl, tag, err);
         else
             hipLaunchKernelGGL((dyn_bwd_kernel<1, kDW, true, 3>), dim3(B * G), dim3(64 * kDW), 0, st, x, ctl, gy, carries, lin_buf, gx, partials, C, (int)N, nt,
-                               vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, segbuf, counters, (float*)nullptr, gctl, tag);
+                               vec, lookahead, sample_rate, eps, G, (int)Tseg, (const float*)nullptr, segbuf, counters, (float*)nullptr, gctl, tag, err);
         return dy_check();
     }
     if (counters && G <= DY_GMAX) {

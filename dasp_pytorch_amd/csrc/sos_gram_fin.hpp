@@ -340,6 +340,7 @@ struct GramFuse {
     float* cnt_tab;         // the items' tables: word LY::CNT of an item's table counts its arrivals (zeroed by the prep kernel, reset here)
     const double* segtab_adj;       // look-back launches (SEG 3): the adjoint system's segment matrix of item 0 (stride 2 (2S)^2 doubles per item)
     unsigned long long* lb_words;   // ... and their words [row][segment][2S]: the workgroup that finalizes an item invalidates the item's
+    unsigned* err;                  // ... and the device error words a reader reports a word to that never arrived (common.hpp lookback_poll)
 };
 // red: the four waves' 1024 sums each, [wave][red_stride] doubles in LDS (visible); it may overlap wk - it is read into registers first.
 template <int S>

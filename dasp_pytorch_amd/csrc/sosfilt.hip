@@ -562,8 +562,8 @@ __device__ __forceinline__ void chain_by_last_workgroup(int* __restrict__ cnt, i
 __device__ __forceinline__ void lookback_publish(unsigned long long* w, float v, unsigned tag) {
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// (The reader - lookback_start - polls until a word carries the launch's tag; it gives up after ~0.5 s: a workgroup it waits for has a
-// smaller index and is running or done, the bound only keeps a corrupted buffer from hanging the device; the outputs then show NaN.)
+// (The reader - lookback_start - polls until a word carries the launch's tag, common.hpp lookback_poll: who may wait for whom, and what
+// happens to a word that never arrives - the device error word `err[family]` - is written up there.)
 // start(seg) = sum_{j < seg} Phi^(seg - 1 - j) z(j) by Horner, fp64 (chain_by_last_workgroup's arithmetic, the same order: the same bits).
 // Called by the WHOLE workgroup (it contains barriers): every thread polls one word per round - a lane that walked its three words one
 // after the other paid three memory round trips, ~1 us each, on the critical path of the row's last segment - then wave 0 runs the chain.
@@ -572,7 +572,7 @@ __device__ __forceinline__ void lookback_publish(unsigned long long* w, float v,
 template <int S, int W>
 __device__ __forceinline__ void lookback_start(const unsigned long long* z64, int seg, int G, int order, const double* __restrict__ Phi, unsigned tag,
                                                float* inbox, int seq, float* zs /* LDS, >= 64 * 2S floats, no wave's private data */,
-                                               double (*st)[2 * S] /* LDS [2][2S] */) {
+                                               double (*st)[2 * S] /* LDS [2][2S] */, unsigned* err, int family) {
     constexpr int S2 = 2 * S, GB = 64;
     const int l = lane_id(), w = wave_id();
     const int npred = order > 0 ? seg : G - 1 - seg, first = order > 0 ? 0 : G - 1;
@@ -587,13 +587,7 @@ __device__ __forceinline__ void lookback_start(const unsigned long long* z64, in
         if (n0) __syncthreads();                       // the previous block's chain has read zs
         for (int e = threadIdx.x; e < nblk * S2; e += 64 * W) {
             const unsigned long long* wp = z64 + (size_t)(first + order * (n0 + e / S2)) * S2 + e % S2;
-            float v = __builtin_nanf("");                 // (gave up after ~0.5 s: the outputs will show it)
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                const unsigned long long wd = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(wd >> 32) == tag) { v = __builtin_bit_cast(float, (unsigned)wd); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            zs[e] = v;
+            zs[e] = lookback_poll(wp, tag, err, family);
         }
         __syncthreads();
         if (w == 0) {
@@ -621,7 +615,8 @@ __global__ void __launch_bounds__(64 * W, W >= 16 ? 4 : (W * 2 + 3) / 4)   // tw
 sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, float* __restrict__ y,
                float* __restrict__ carries, int C, int N, int nt, int vec,
                int G = 1, int Tseg = 0, const float* __restrict__ segstart = nullptr, float* __restrict__ zseg = nullptr,
-               float* __restrict__ chain_tab = nullptr, const double* __restrict__ segtab = nullptr, float* __restrict__ chain_start = nullptr) {
+               float* __restrict__ chain_tab = nullptr, const double* __restrict__ segtab = nullptr, float* __restrict__ chain_start = nullptr,
+               unsigned* __restrict__ err = nullptr) {
     using LY = SosLayout<S, L>;
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L;        // unpadded, swizzled tile images (common.hpp)
     constexpr int LDS_T = W * 2 * IMG, LDS_MB = W * S * 4, LDS_PW = S * 64 * 4;
@@ -760,7 +755,7 @@ sos_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __rest
         // the output sweep's first x tile is on its way while the look-back runs (the look-back stages its words in wave 0's y image, idle
         // between the sweeps; the x images are the waves' own)
         if (t0 + wave < t1 && tile_full<L>((long)(t0 + wave) * TS, N, vec)) tile_dma_issue_swz(xr + (size_t)(t0 + wave) * TS, a_x, lane);
-        lookback_start<S, W>(z64, seg, G, 1, segtab + (size_t)(tab_bcast ? 0 : row / C) * 2 * S2 * S2, tag, lds, t0 + SEQ2, pw_lds + LDS_PW + IMG, lb_st);
+        lookback_start<S, W>(z64, seg, G, 1, segtab + (size_t)(tab_bcast ? 0 : row / C) * 2 * S2 * S2, tag, lds, t0 + SEQ2, pw_lds + LDS_PW + IMG, lb_st, err, DASP_DEVERR_SOS_FWD);
         __syncthreads();
         sweep(std::false_type{}, SEQ2, true);
     } else if (SEG == 2) {
@@ -1080,13 +1075,12 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
     // SEG 3 (round 5, with fz.on): the adjoint scan-only pre-pass inside this launch - the workgroup sweeps its segment's gy scan-only,
     // publishes the adjoint state below the segment, takes the state entering from above from the segments above it (lookback_start, the
     // forward kernel's scheme mirrored) and then runs the pass. segstart then points at the row-major 64-bit words. The workgroup -> segment
-    // map is the forward kernel's: a workgroup (row, seg) sits on XCD (row G + seg) % 8 in both directions, so the x tiles and saved states
-    // it reads were last touched through the same L2 (measured, profiles/r05/bwd_lookback_ab.log: with the row reversed - which would make
-    // every wait point at a smaller workgroup index - this kernel AND the next step's forward kernel lose ~3 us each). A workgroup therefore
-    // waits for workgroups of its own row with LARGER indices: they are running or about to, because the dispatcher hands out workgroups
-    // in index order and a row's G workgroups fit the device together (the host checks G against the CU count and takes the two-launch
-    // path otherwise) - the lowest unfinished row is always resident as a whole, and its last segment waits for nobody.
-    const int row = SEG ? wg / G : wg, seg = SEG ? wg % G : 0;
+    // map (common.hpp lookback_bwd_segment, round 6): groups of eight segments, the highest group first - the segments above a workgroup's
+    // own belong to workgroups with smaller indices or to the up to seven right behind it, and with G a multiple of eight a (row, seg) sits
+    // on XCD (row G + seg) % 8 as in the forward launch, so the x tiles and saved states it reads were last touched through the same L2
+    // (profiles/r05/bwd_lookback_ab.log: a plainly reversed row cost this kernel AND the next step's forward kernel ~3 us each; round 5
+    // kept the forward map and waited for ALL later workgroups of the row, which needs the row resident at once).
+    const int row = SEG ? wg / G : wg, seg = SEG == 3 ? lookback_bwd_segment(wg % G, G) : SEG ? wg % G : 0;
     const int t0 = SEG ? seg * Tseg : 0, t1 = SEG ? (t0 + Tseg < nt ? t0 + Tseg : nt) : nt, nr = t1 - t0;   // this workgroup's tiles, walked t1 - 1 .. t0
     const float* __restrict__ tb = tab + (size_t)(tab_bcast ? 0 : row / C) * LY::TOTAL;
     const float* __restrict__ xr = x + (size_t)row * N;
@@ -1184,7 +1178,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         // the pass's first gy tile is on its way as well now (x and the saved states since before the sweep); the look-back stages its words
         // in wave 0's scratch image, idle between tiles
         if (wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec), 2);
-        lookback_start<S, W>(z64, seg, G, -1, fz.segtab_adj + (size_t)(row / C) * 2 * (2 * S) * (2 * S), tag, lds, t1 + SEQ2, pw_lds + LDS_PW + 3 * IMG, lb_st);
+        lookback_start<S, W>(z64, seg, G, -1, fz.segtab_adj + (size_t)(row / C) * 2 * (2 * S) * (2 * S), tag, lds, t1 + SEQ2, pw_lds + LDS_PW + 3 * IMG, lb_st, fz.err, DASP_DEVERR_SOS_BWD);
         __syncthreads();
     }
     if (SEG != 3 && wave < nr) issue_dma(t1 - 1 - wave, tile_full<L>((long)(t1 - 1 - wave) * TS, N, vec));
@@ -1540,11 +1534,9 @@ int dasp_sosfilt_forward(const float* tab, int Bs, const float* x, float* y, flo
 }
 
 // gx == null: no input gradient; partials == null: no coefficient gradients (the adjoint-only kernel: x and carries are not read).
-// With coefficient gradients the pass is sos_bwd_gram_kernel and leaves one Gram matrix per row in `partials`. `designed` is accepted for
-// source compatibility and ignored (rounds 2 - 4 had a monic recomputation kernel for designed cascades).
+// With coefficient gradients the pass is sos_bwd_gram_kernel and leaves one Gram matrix per row in `partials`.
 int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
-                             float* partials, int B, int C, long N, int S, int designed, void* stream) {
-    (void)designed;
+                             float* partials, int B, int C, long N, int S, void* stream) {
     if (!tab || !gy || (!gx && !partials) || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B)) return DASP_ERR_ARG;
     if (partials && (!x || !carries || !aligned16(partials))) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
@@ -1575,7 +1567,7 @@ int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const flo
 int dasp_sosfilt_backward(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
                           float* partials, int B, int C, long N, int S, void* stream) {
     if (!x || !carries || !gx || !partials) return DASP_ERR_ARG;
-    return dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, 0, stream);
+    return dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, stream);
 }
 
 // mode 0: gout (B,S,6) = dL/dsos ; mode 1: gout (B,S,3) = dL/d(gain_db, cutoff_freq, q_factor); mode 2: the same as (3S, B) rows.
@@ -1592,8 +1584,7 @@ static int grad_finalize_impl(const double* dtab, int Bs, const float* partials,
 }
 
 int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
-                              int designed, float* gout, void* stream) {
-    (void)designed;
+                              float* gout, void* stream) {
     return grad_finalize_impl(dtab, Bs, partials, B, C, S, segments, mode, gout, stream);
 }
 
@@ -1606,10 +1597,9 @@ int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, in
 // backward kernel of one-workgroup-per-row launches was measured at 2 - 3 us of 425 and is not built; segmented rows - dasp_peq_backward -
 // do finalize inside their launch).
 int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
-                                   float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, int designed,
-                                   void* stream) {
+                                   float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, void* stream) {
     if (mode < 0 || mode > 2 || (partials && (!dtab || !gout))) return DASP_ERR_ARG;
-    const int rc = dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, designed, stream);
+    const int rc = dasp_sosfilt_backward_ex(tab, Bs, x, gy, carries, gx, partials, B, C, N, S, stream);
     if (rc != DASP_OK || !partials) return rc;
     return grad_finalize_impl(dtab, Bs, partials, B, C, S, 1, mode, gout, stream);
 }
@@ -1617,7 +1607,7 @@ int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const
 int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
                                 float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, void* stream) {
     if (!gx || !partials) return DASP_ERR_ARG;
-    return dasp_sosfilt_backward_grads_ex(tab, dtab, Bs, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 0, stream);
+    return dasp_sosfilt_backward_grads_ex(tab, dtab, Bs, x, gy, carries, gx, partials, mode, gout, B, C, N, S, stream);
 }
 
 // ---- segmented rows -------------------------------------------------------------------------------------------------------------
@@ -1688,17 +1678,11 @@ int dasp_sosfilt_forward_seg(const float* tab, const double* segtab, int Bs, con
 #ifndef DASP_BWD_LOOKBACK
 #define DASP_BWD_LOOKBACK 1      // the same for the backward pass of dasp_peq_backward (sos_bwd_gram_kernel<SEG = 3>); 0: pre-pass launch + pass
 #endif
-// compute units of the current device (the backward look-back needs a row's G workgroups resident together: one per CU is always possible)
-static int device_compute_units() {
-    static int cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
-    return cus[dev];
-}
 static int sosfilt_forward_lookback(const float* tab, const double* segtab, int Bs, const float* x, float* y, float* carries, float* segbuf,
                                     int B, int C, long N, int S, long Tseg, void* stream) {
-    if (!DASP_FWD_LOOKBACK) return dasp_sosfilt_forward_seg(tab, segtab, Bs, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    if (!DASP_FWD_LOOKBACK || !lookback_enabled()) return dasp_sosfilt_forward_seg(tab, segtab, Bs, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
+    if (error_pending()) return DASP_ERR_DEVICE;
+    unsigned* err = error_words_device();
     if (!tab || !segtab || !x || !y || !segbuf || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || Tseg <= 0 || (reinterpret_cast<uintptr_t>(segbuf) & 7)) return DASP_ERR_ARG;
     if (N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
     const int nt = (int)dasp_sos_num_tiles(N), G = (int)dasp_sos_segments(N, Tseg), bc = Bs == 1 && B != 1;
@@ -1706,7 +1690,7 @@ static int sosfilt_forward_lookback(const float* tab, const double* segtab, int 
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         hipLaunchKernelGGL((sos_fwd_kernel<SS, kL, kWF, 3>), dim3(B * C * G), dim3(64 * kWF), 0, (hipStream_t)stream, tab, bc, x, y, carries, C, (int)N, nt,
-                           vec, G, (int)Tseg, (const float*)nullptr, segbuf, (float*)nullptr, segtab, (float*)nullptr);
+                           vec, G, (int)Tseg, (const float*)nullptr, segbuf, (float*)nullptr, segtab, (float*)nullptr, err);
         return check_launch();
     });
 }
@@ -1749,7 +1733,9 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
         constexpr int SS = decltype(s)::value;
         hipStream_t st = (hipStream_t)stream;
         const bool fuse = partials && fin_dtab && fin_gout && !bc;
-        if (fuse && DASP_BWD_LOOKBACK && G <= device_compute_units()) {
+        const void* lb_kernel = !gx ? reinterpret_cast<const void*>(sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 3>) : reinterpret_cast<const void*>(sos_bwd_gram_kernel<SS, kL, kWB, 0, 3>);
+        if (fuse && DASP_BWD_LOOKBACK && lookback_enabled() && lookback_has_room(lb_kernel, 64 * kWB)) {
+            if (error_pending()) return DASP_ERR_DEVICE;
             // one launch: adjoint scan-only sweep, look-back over the segments above, Gram pass, finalize (sos_bwd_gram_kernel<SEG = 3>)
             if (GramFin<SS>::BASIS != sos_basis_doubles(SS) || (reinterpret_cast<uintptr_t>(segbuf) & 7)) return DASP_ERR_UNSUPPORTED;
             GramFuse fz = {};
@@ -1758,6 +1744,7 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
             fz.cnt_tab = const_cast<float*>(tab);
             fz.segtab_adj = segtab + (2 * SS) * (2 * SS);
             fz.lb_words = reinterpret_cast<unsigned long long*>(segbuf);
+            fz.err = error_words_device();
             const dim3 g(B * C * G), b(64 * kWB);
             double* gm = reinterpret_cast<double*>(partials);
             if (!gx)
@@ -1792,16 +1779,14 @@ static int sosfilt_backward_seg_impl(const float* tab, const double* segtab, int
     });
 }
 int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
-                                 float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, int designed,
-                                 void* stream) {
-    (void)designed;
+                                 float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, void* stream) {
     return sosfilt_backward_seg_impl(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, nullptr, 0, nullptr, stream);
 }
 
 int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, const float* x, const float* gy, const float* carries,
                               float* gx, float* partials, float* segbuf, int B, int C, long N, int S, long Tseg, void* stream) {
     if (!x || !carries || !gx || !partials) return DASP_ERR_ARG;
-    return dasp_sosfilt_backward_seg_ex(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, 0, stream);
+    return dasp_sosfilt_backward_seg_ex(tab, segtab, Bs, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, stream);
 }
 
 // dasp_sos_grad_finalize for partial sums produced by dasp_sosfilt_backward_seg with `segments` segments per row
@@ -1872,7 +1857,7 @@ int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, doub
 int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, const float* gy, const float* carries, float* gx,
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream) {
-    if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, 1, stream);
+    if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, stream);
     // one table per item: the finalize step runs inside the Gram pass (gram_fused_tail); a shared table (Bp == 1 < B) takes the separate launch
     const bool fuse = partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;
     const int rc = sosfilt_backward_seg_impl(tab, segtab, Bp, x, gy, carries, gx, partials, segbuf, B, C, N, S, Tseg, fuse ? dtab : nullptr, mode,

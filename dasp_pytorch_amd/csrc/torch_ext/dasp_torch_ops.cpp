@@ -58,7 +58,9 @@ Tensor dyn_counters(const Tensor& like, int64_t B) {
 }
 
 void check_rc(int rc, const char* what) {
-    TORCH_CHECK(rc == 0, what, " failed: ", rc == -1 ? "DASP_ERR_ARG (bad argument)" : rc == -2 ? "DASP_ERR_UNSUPPORTED" : "HIP error ", rc);
+    TORCH_CHECK(rc == 0, what, " failed: ", rc == -1 ? "DASP_ERR_ARG (bad argument)" : rc == -2 ? "DASP_ERR_UNSUPPORTED" : rc == -3 ?
+                "DASP_ERR_DEVICE (a kernel of an EARLIER segmented call gave up waiting for a look-back word and wrote NaN: family bits of dasp_device_error(); "
+                "dasp_pytorch_amd.config.plan.lookback = False selects the two-launch forms, dasp_device_error_clear() re-arms) " : "HIP error ", rc);
 }
 void need_device(const Tensor& t, const char* name) {
     TORCH_CHECK(t.is_cuda(), "dasp: `", name, "` must be on a ROCm device (there is no CPU path), got ", t.device());
@@ -918,12 +920,12 @@ std::tuple<Tensor, Tensor> sosfilt_backward(const Tensor& x, const Tensor& gy, c
     if (tseg) {
         Tensor segbuf = empty_f32(round64(dasp_sos_seg_floats(B * C, N, (int)Sp, tseg)), x32);
         check_rc(dasp_sosfilt_backward_seg_ex(w, w64 + n_dt, (int)Bs, x32.data_ptr<float>(), g32.data_ptr<float>(), w + n_tab, need_gx ? gx.data_ptr<float>() : nullptr,
-                                              fp(partials), segbuf.data_ptr<float>(), (int)B, (int)C, N, (int)Sp, tseg, 0, st),
+                                              fp(partials), segbuf.data_ptr<float>(), (int)B, (int)C, N, (int)Sp, tseg, st),
                  "dasp_sosfilt_backward_seg_ex");
-        if (need_gs) check_rc(dasp_sos_grad_finalize_ex(w64, (int)Bs, partials.data_ptr<float>(), (int)B, (int)C, (int)Sp, (int)G, 0, 0, gs.data_ptr<float>(), st), "dasp_sos_grad_finalize_ex");
+        if (need_gs) check_rc(dasp_sos_grad_finalize_ex(w64, (int)Bs, partials.data_ptr<float>(), (int)B, (int)C, (int)Sp, (int)G, 0, gs.data_ptr<float>(), st), "dasp_sos_grad_finalize_ex");
     } else {
         check_rc(dasp_sosfilt_backward_grads_ex(w, w64, (int)Bs, x32.data_ptr<float>(), g32.data_ptr<float>(), w + n_tab, need_gx ? gx.data_ptr<float>() : nullptr, fp(partials), 0,
-                                                need_gs ? gs.data_ptr<float>() : nullptr, (int)B, (int)C, N, (int)Sp, 0, st),
+                                                need_gs ? gs.data_ptr<float>() : nullptr, (int)B, (int)C, N, (int)Sp, st),
                  "dasp_sosfilt_backward_grads_ex");
     }
     if (need_gs && Bs == 1 && B != 1) gs = gs.sum(0, /*keepdim=*/true);

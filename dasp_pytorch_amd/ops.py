@@ -91,22 +91,21 @@ class _SosWork:
             gout = torch.empty(shape, dtype=torch.float32, device=x.device)
         part = self.partials if need_gc else None
         if _lib.timers.enabled and not self.tseg:      # bench.py's per-kernel HIP events: the two launches as separate entry points
-            call("dasp_sosfilt_backward_ex", ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(part), B, C, N, self.S,
-                 designed, stream())
+            call("dasp_sosfilt_backward_ex", ptr(self.tab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(part), B, C, N, self.S, stream())
             if need_gc:
-                call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, 1, mode, designed, ptr(gout), stream())
+                call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, 1, mode, ptr(gout), stream())
         elif self.tseg and designed:
             # segmented rows of a designed cascade: pre-pass (+ chain), adjoint pass (+ finalize in its last workgroup per item) - two launches
             call("dasp_peq_backward", ptr(self.tab), ptr(self.dtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx), ptr(part), mode,
                  ptr(gout), B, C, N, self.S, self.tseg, ptr(self.segtab), ptr(self.segbuf), stream())
         elif self.tseg:
             call("dasp_sosfilt_backward_seg_ex", ptr(self.tab), ptr(self.segtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx),
-                 ptr(part), ptr(self.segbuf), B, C, N, self.S, self.tseg, designed, stream())
+                 ptr(part), ptr(self.segbuf), B, C, N, self.S, self.tseg, stream())
             if need_gc:
-                call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, self.G, mode, designed, ptr(gout), stream())
+                call("dasp_sos_grad_finalize_ex", ptr(self.dtab), self.Bs, ptr(part), B, C, self.S, self.G, mode, ptr(gout), stream())
         else:
             call("dasp_sosfilt_backward_grads_ex", ptr(self.tab), ptr(self.dtab), self.Bs, ptr(x), ptr(gy), ptr(self.carries), ptr(gx),
-                 ptr(part), mode, ptr(gout), B, C, N, self.S, designed, stream())
+                 ptr(part), mode, ptr(gout), B, C, N, self.S, stream())
         if need_gc and self.Bs == 1 and B != 1:
             gout = gout.sum(1 if mode == 2 else 0, keepdim=True)
         return gx, gout

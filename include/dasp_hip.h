@@ -23,6 +23,31 @@ unsigned long long dasp_abi_hash(void);
 #define DASP_OK 0
 #define DASP_ERR_ARG (-1)          /* null pointer / inconsistent sizes */
 #define DASP_ERR_UNSUPPORTED (-2)  /* e.g. section count without a compiled kernel */
+#define DASP_ERR_DEVICE (-3)       /* a kernel of an EARLIER call on this device reported a broken protocol: see dasp_device_error below */
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-side errors and the look-back plan.  The segmented launches ("Few rows", "Few batch items") hand segment states between the
+ * workgroups of ONE launch as tagged 64-bit words; a reader that waits for a word longer than 2 s of wall clock (a scratch buffer
+ * overwritten under the launch, a workgroup that died) stores into a sticky error word of its kernel family and carries on with NaN.
+ * The words live in 64 bytes of host-mapped memory per device (one allocation, made by the first call of dasp_device_error() or of a
+ * segmented entry point on that device - call dasp_device_error() once before capturing a graph); nothing is copied or polled on the
+ * fast path. While a bit is set every segmented entry point returns DASP_ERR_DEVICE instead of launching.
+ *   dasp_device_error()        bits of the current device: 1 EQ forward, 2 EQ backward, 4 compressor/expander forward, 8 backward, 16 test
+ *   dasp_device_error_clear()  re-arm
+ *   dasp_plan_lookback(on)     1 (default): the one-launch look-back forms where they apply; 0: the two-launch forms (pre-pass + pass) -
+ *                              no workgroup ever waits for another; < 0: query. Returns the setting.
+ * Test support (tests/test_gpu_lookback.py): dasp_test_lookback_timeout(ms) sets the time-out (0 = 2 s); dasp_test_lookback_stall polls a
+ * word that never arrives (zero_word: 8 zero bytes on the device; out: 1 float or NULL); dasp_test_spin keeps `workgroups` x `threads`
+ * busy for `milliseconds`; dasp_test_stream_with_cus makes a stream confined to the first n_cus compute units (hipExtStreamCreateWithCUMask).
+ * ------------------------------------------------------------------------------------------- */
+int  dasp_device_error(void);
+void dasp_device_error_clear(void);
+int  dasp_plan_lookback(int on);
+int  dasp_test_lookback_timeout(int milliseconds);
+int  dasp_test_lookback_stall(const unsigned long long* zero_word, float* out, void* stream);
+int  dasp_test_spin(int workgroups, int threads, double milliseconds, void* stream);
+int  dasp_test_stream_with_cus(int n_cus, void** stream);
+int  dasp_test_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Cascaded biquads.  Replaces dasp_pytorch.signal.sosfilt_via_fsm (dasp_pytorch/signal.py:136-166,
@@ -76,9 +101,8 @@ int dasp_sos_grad_finalize(const double* dtab, int Bs, const float* partials, in
 
 /* dasp_sosfilt_backward followed by dasp_sos_grad_finalize (same mode / gout) as one call - the autograd of
  * signal.sosfilt_via_fsm (dasp_pytorch/signal.py:136-166) / functional.parametric_eq (functional.py:118-272) in one step.
- * A library built with -DDASP_FUSED_FINALIZE=1 also makes it one launch when every item has its own table (Bs == B): the
- * backward kernel then finalizes an item when its last row completes, counting rows in the item's table (hence the non-const
- * tab; the count is left at zero). */
+ * Two launches at one workgroup per row (the segmented forms - dasp_peq_backward - finalize inside their launch and count an item's
+ * workgroups in the item's table: hence the non-const tab; the count is left at zero). */
 int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const float* x, const float* gy,
                                 const float* carries, float* gx, float* partials, int mode, float* gout,
                                 int B, int C, long N, int S, void* stream);
@@ -86,18 +110,17 @@ int dasp_sosfilt_backward_grads(float* tab, const double* dtab, int Bs, const fl
 /* The backward pass as asked for (torch.autograd's needs_input_grad) and for the cascade it is:
  *   gx == NULL        no input gradient: the adjoint output is neither transposed back nor stored (parametric_eq is the first effect of
  *                     the reference's chain, examples/style_transfer.py:150 - its input never needs one);
- *   partials == NULL  no coefficient gradients (a fixed filter): x and carries are not read, only the adjoint cascade runs;
- *   designed          accepted and ignored since round 5 (rounds 3 - 4: the recomputation kernels ran designed cascades in monic form;
- *                     the Gram-matrix backward treats every cascade alike). Kept in the signatures for callers built against them.
+ *   partials == NULL  no coefficient gradients (a fixed filter): x and carries are not read, only the adjoint cascade runs.
+ * (Rounds 3 - 5 carried an `int designed` in these signatures that had been ignored since the Gram-matrix backward; round 6 dropped it -
+ * the ABI hash changed with it.)
  * dasp_sos_grad_finalize_ex: segments = rows of partial sums per (row, wave) (1 after dasp_sosfilt_backward*, dasp_sos_segments(N, Tseg)
  * after the *_seg calls); mode 2 = mode 1 written as 3*S rows of B values ([3 k + c][item]: one contiguous vector per control tensor). */
 int dasp_sosfilt_backward_ex(const float* tab, int Bs, const float* x, const float* gy, const float* carries, float* gx,
-                             float* partials, int B, int C, long N, int S, int designed, void* stream);
+                             float* partials, int B, int C, long N, int S, void* stream);
 int dasp_sos_grad_finalize_ex(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments, int mode,
-                              int designed, float* gout, void* stream);
+                              float* gout, void* stream);
 int dasp_sosfilt_backward_grads_ex(float* tab, const double* dtab, int Bs, const float* x, const float* gy, const float* carries,
-                                   float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, int designed,
-                                   void* stream);
+                                   float* gx, float* partials, int mode, float* gout, int B, int C, long N, int S, void* stream);
 
 /* functional.parametric_eq (dasp_pytorch/functional.py:118-272) as one call per direction. Forward = dasp_peq_prepare_rows +
  * dasp_sosfilt_forward (Tseg == 0) or + dasp_sos_segment_prepare + dasp_sosfilt_forward_seg (Tseg = dasp_sos_segment_tiles(B*C, N) > 0;
@@ -180,7 +203,7 @@ int dasp_sosfilt_backward_seg(const float* tab, const double* segtab, int Bs, co
                               int B, int C, long N, int S, long Tseg, void* stream);
 int dasp_sosfilt_backward_seg_ex(const float* tab, const double* segtab, int Bs, const float* x, const float* gy,
                                  const float* carries, float* gx, float* partials, float* segbuf,
-                                 int B, int C, long N, int S, long Tseg, int designed, void* stream);
+                                 int B, int C, long N, int S, long Tseg, void* stream);
 int dasp_sos_grad_finalize_seg(const double* dtab, int Bs, const float* partials, int B, int C, int S, int segments,
                                int mode, float* gout, void* stream);
 

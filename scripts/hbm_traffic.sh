@@ -10,7 +10,7 @@ mkdir -p "$out" gpurun_out/pmc_r2
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_r2/$c
-  DASP_PEQ=1 DASP_DESIGNED=1 DASP_SPLIT_FINALIZE=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_r2/$c -o p -- \
+  DASP_PEQ=1 DASP_SPLIT_FINALIZE=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_r2/$c -o p -- \
       ./tools/sosbench 256 2 131072 40 > gpurun_out/pmc_r2/$c.log 2>&1 || true
 done
 python3 - "$out" <<'PY'
@@ -31,7 +31,7 @@ sys.path.insert(0, os.getcwd())
 from dasp_pytorch_amd.csrc.build import kernel_source_hash
 units = 256 * 2 * 131072
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes with --kernel-trace only, KB units) on tools/sosbench 256 2 131072 "
-               "(DASP_PEQ=1 DASP_DESIGNED=1; backward = sos_bwd_gram_kernel), averaged over the second half of 42 launches; FETCH_SIZE doubled "
+               "(DASP_PEQ=1; backward = sos_bwd_gram_kernel), averaged over the second half of 42 launches; FETCH_SIZE doubled "
                "per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE as is. scripts/hbm_traffic.sh",
        "shape": [256, 2, 131072], "kernel_source_hash": kernel_source_hash()}
 for k, alg in (("sos_fwd_kernel", 8 * units), ("sos_bwd_kernel", 12 * units)):

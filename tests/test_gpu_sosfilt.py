@@ -344,7 +344,7 @@ def _raw_setup(B, C, N, S, seed, Bs=None):
 @pytest.mark.parametrize("Bs_shared", [False, True])
 def test_backward_kernel_variants_agree(D, Bs_shared):
     """The backward kernel variants of dasp_sosfilt_backward_ex through the raw C ABI: designed and generic cascades give the same input
-    gradient bit for bit and the same control gradients (one kernel: `designed` is ignored since the Gram-matrix backward); gx == NULL
+    gradient bit for bit and the same control gradients (one kernel since the Gram-matrix backward; repeated calls are bit-identical); gx == NULL
     leaves the control gradients bit-identical; partials == NULL (the adjoint-only kernel:
     per-lane cascade instead of the matrix-core output map) gives gx to fp32 rounding; ragged length."""
     from dasp_pytorch_amd._lib import call, ptr, stream
@@ -355,10 +355,9 @@ def test_backward_kernel_variants_agree(D, Bs_shared):
         part = torch.full((L.dasp_sos_partial_floats(B * C, S),), float("nan"), dtype=torch.float32, device="cuda:0")
         gx = torch.full_like(x, float("nan")) if want_gx else None
         g = torch.zeros(B, S, 3, device="cuda:0")
-        call("dasp_sosfilt_backward_ex", ptr(tab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx), ptr(part if want_gc else None), B, C, N, S,
-             designed, stream())
+        call("dasp_sosfilt_backward_ex", ptr(tab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx), ptr(part if want_gc else None), B, C, N, S, stream())
         if want_gc:
-            call("dasp_sos_grad_finalize_ex", ptr(dtab), Bs, ptr(part), B, C, S, 1, 1, designed, ptr(g), stream())
+            call("dasp_sos_grad_finalize_ex", ptr(dtab), Bs, ptr(part), B, C, S, 1, 1, ptr(g), stream())
         return gx, g
     gx0, g0 = run(0)
     gx1, g1 = run(1)
@@ -378,7 +377,7 @@ def test_backward_kernel_variants_agree(D, Bs_shared):
         part = torch.empty(L.dasp_sos_partial_floats(B * C, S), dtype=torch.float32, device="cuda:0")
         gx2, g2 = torch.empty_like(x), torch.zeros(B, S, 3, device="cuda:0")
         call("dasp_sosfilt_backward_grads_ex", ptr(tab), ptr(dtab), Bs, ptr(x), ptr(gy), ptr(car), ptr(gx2), ptr(part), 1, ptr(g2),
-             B, C, N, S, designed, stream())
+             B, C, N, S, stream())
         assert torch.equal(gx2, gx0) and torch.equal(g2, gref)
 
 

@@ -83,15 +83,14 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e[1]));
         DK(dasp_sosfilt_forward(dtab, B, dx, dy, dcar, B, C, N, S, nullptr));
         CK(hipEventRecord(e[2]));
-        // DASP_DESIGNED=1 (with DASP_PEQ=1): the kernel variant for designed cascades; DASP_NOGX / DASP_NOGC: the reduced backward variants
-        const int designed = peq && getenv("DASP_DESIGNED") ? 1 : 0;
+        // DASP_NOGX / DASP_NOGC: the reduced backward variants
         float* pgx = getenv("DASP_NOGX") ? nullptr : dgx;
         float* ppart = getenv("DASP_NOGC") ? nullptr : dpart;
         if (getenv("DASP_SPLIT_FINALIZE")) {
-            DK(dasp_sosfilt_backward_ex(dtab, B, dx, dgy, dcar, pgx, ppart, B, C, N, S, designed, nullptr));
-            if (ppart) DK(dasp_sos_grad_finalize_ex(ddtab, B, dpart, B, C, S, 1, 0, designed, dgout, nullptr));
+            DK(dasp_sosfilt_backward_ex(dtab, B, dx, dgy, dcar, pgx, ppart, B, C, N, S, nullptr));
+            if (ppart) DK(dasp_sos_grad_finalize_ex(ddtab, B, dpart, B, C, S, 1, 0, dgout, nullptr));
         } else {
-            DK(dasp_sosfilt_backward_grads_ex(dtab, ddtab, B, dx, dgy, dcar, pgx, ppart, 0, dgout, B, C, N, S, designed, nullptr));
+            DK(dasp_sosfilt_backward_grads_ex(dtab, ddtab, B, dx, dgy, dcar, pgx, ppart, 0, dgout, B, C, N, S, nullptr));
         }
         CK(hipEventRecord(e[3]));
         CK(hipEventSynchronize(e[3]));
