@@ -1099,7 +1099,7 @@ sos_bwd_gram_kernel(const float* __restrict__ tab, int tab_bcast, const float* _
         if (i < S * 4) {
             const int comp = i & 3;
             if (comp == 2) v = __builtin_bit_cast(float, t1);
-            else if (SEG == 1 && comp < 2) v = segstart ? segstart[((size_t)row * G + seg) * (2 * S) + 2 * (i >> 2) + comp] : 0.f;    // (null: a whole row, nothing above it)
+            else if (SEG == 1 && comp < 2) v = segstart[((size_t)row * G + seg) * (2 * S) + 2 * (i >> 2) + comp];
         }
         lds[i] = v;
     }
@@ -1491,7 +1491,7 @@ int dasp_peq_prepare(const float* params, int Bs, int S, const int* types, doubl
 // segment matrices (dasp_sos_segtab_doubles)
 static int peq_prepare_rows_impl(const float* const* rows, int Bs, int S, const int* types, double sample_rate, float* tab, double* dtab,
                                  long Tseg, double* segtab, int want_basis, void* stream) {
-    if (!rows || !types || !tab || !dtab || Bs <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1)))) || (Tseg == -1 && !segtab)) return DASP_ERR_ARG;
+    if (!rows || !types || !tab || !dtab || Bs <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1))))) return DASP_ERR_ARG;
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         PeqSpec spec = {};
@@ -1504,8 +1504,7 @@ static int peq_prepare_rows_impl(const float* const* rows, int Bs, int S, const 
             spec.rows[i] = rows[i];
         }
         spec.sample_rate = sample_rate;
-        // (Tseg == -1: whole rows whose backward launch finalizes - the basis responses, no segment matrices)
-        double* basis = (Tseg > 0 || Tseg == -1) && want_basis ? segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS) : nullptr;
+        double* basis = Tseg > 0 && want_basis ? segtab + (size_t)Bs * 2 * (2 * SS) * (2 * SS) : nullptr;
         hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(basis ? 2 * Bs : Bs), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, spec, tab, dtab,
                            Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis, Bs);
         return check_launch();
@@ -1803,7 +1802,7 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
                      const float* x, float* y, float* carries, int B, int C, long N, long Tseg, double* segtab, float* segbuf,
                      void* stream) {
     // (segmented rows: the segment transition matrices come out of the design launch - no dasp_sos_segment_prepare launch)
-    const int rc = peq_prepare_rows_impl(rows, Bp, S, types, sample_rate, tab, dtab, Tseg > 0 || Tseg == -1 ? Tseg : 0, segtab, carries != nullptr, stream);
+    const int rc = peq_prepare_rows_impl(rows, Bp, S, types, sample_rate, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, carries != nullptr, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
     return sosfilt_forward_lookback(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
@@ -1816,7 +1815,7 @@ int dasp_peq_forward(const float* const* rows, int Bp, int S, const int* types, 
 // dasp_peq_prepare_norm is the design step on its own (tables only).
 static int peq_prepare_norm_impl(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                                  unsigned* flag, float* tab, double* dtab, long Tseg, double* segtab, int want_basis, void* stream) {
-    if (!pn || !types || !lo || !span || !tab || !dtab || Bp <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1)))) || (Tseg == -1 && !segtab)) return DASP_ERR_ARG;
+    if (!pn || !types || !lo || !span || !tab || !dtab || Bp <= 0 || S > 8 || S <= 0 || (Tseg > 0 && (!segtab || (Tseg & (Tseg - 1))))) return DASP_ERR_ARG;
     return dispatch_S(S, [&](auto s) {
         constexpr int SS = decltype(s)::value;
         PeqSpec spec = {};
@@ -1828,7 +1827,7 @@ static int peq_prepare_norm_impl(const float* pn, int Bp, int S, const int* type
         spec.sample_rate = sample_rate;
         spec.norm = 1;
         spec.flag = flag;
-        double* basis = (Tseg > 0 || Tseg == -1) && want_basis ? segtab + (size_t)Bp * 2 * (2 * SS) * (2 * SS) : nullptr;
+        double* basis = Tseg > 0 && want_basis ? segtab + (size_t)Bp * 2 * (2 * SS) * (2 * SS) : nullptr;
         hipLaunchKernelGGL((sos_prep_kernel<SS, kL>), dim3(basis ? 2 * Bp : Bp), dim3(256), 0, (hipStream_t)stream, nullptr, pn, spec, tab, dtab,
                            Tseg > 0 ? seg_extra_squarings(Tseg) : 0, Tseg > 0 ? segtab : nullptr, basis, Bp);
         return check_launch();
@@ -1846,7 +1845,7 @@ int dasp_peq_prepare_norm(const float* pn, int Bp, int S, const int* types, doub
 int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, double sample_rate, const double* lo, const double* span,
                           unsigned* flag, float* tab, double* dtab, const float* x, float* y, float* carries, int B, int C, long N, long Tseg,
                           double* segtab, float* segbuf, void* stream) {
-    const int rc = peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg > 0 || Tseg == -1 ? Tseg : 0, segtab, carries != nullptr, stream);
+    const int rc = peq_prepare_norm_impl(pn, Bp, S, types, sample_rate, lo, span, flag, tab, dtab, Tseg > 0 ? Tseg : 0, segtab, carries != nullptr, stream);
     if (rc != DASP_OK) return rc;
     if (Tseg <= 0) return dasp_sosfilt_forward(tab, Bp, x, y, carries, B, C, N, S, stream);
     return sosfilt_forward_lookback(tab, segtab, Bp, x, y, carries, segbuf, B, C, N, S, Tseg, stream);
@@ -1858,28 +1857,6 @@ int dasp_peq_forward_norm(const float* pn, int Bp, int S, const int* types, doub
 int dasp_peq_backward(float* tab, const double* dtab, int Bp, const float* x, const float* gy, const float* carries, float* gx,
                       float* partials, int mode, float* gout, int B, int C, long N, int S, long Tseg, const double* segtab,
                       float* segbuf, void* stream) {
-    if (Tseg == -1 && partials && dtab && gout && segtab && Bp == B && mode >= 0 && mode <= 2 && x && gy && carries && tab && aligned16(partials) && N > 0 && N <= 0x7fffffffL) {
-        // whole rows (one workgroup per row) whose launch finalizes: the Gram kernel's segmented form with ONE segment per row and no state
-        // above it - every workgroup turns its matrix into lag sums, the one that completes the item's count maps their sum to the
-        // gradients (gram_fused_tail); the basis responses came out of the design launch (dasp_peq_forward* with Tseg == -1)
-        const int nt = (int)dasp_sos_num_tiles(N);
-        const int vec = (N % 4 == 0) && aligned16(gy) && aligned16(x) && (!gx || aligned16(gx));
-        return dispatch_S(S, [&](auto s) {
-            constexpr int SS = decltype(s)::value;
-            if (GramFin<SS>::BASIS != sos_basis_doubles(SS)) return DASP_ERR_UNSUPPORTED;
-            GramFuse fz = {};
-            fz.on = 1; fz.B = B; fz.mode = mode; fz.dtab = dtab; fz.gout = gout;
-            fz.basis = segtab + (size_t)Bp * 2 * (2 * SS) * (2 * SS);
-            fz.cnt_tab = tab;
-            const dim3 g(B * C), b(64 * kWB);
-            double* gm = reinterpret_cast<double*>(partials);
-            if (!gx)
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, BWD_NOGX, 1>), g, b, 0, (hipStream_t)stream, tab, 0, x, gy, carries, gx, gm, C, (int)N, nt, vec, 1, nt, (const float*)nullptr, fz);
-            else
-                hipLaunchKernelGGL((sos_bwd_gram_kernel<SS, kL, kWB, 0, 1>), g, b, 0, (hipStream_t)stream, tab, 0, x, gy, carries, gx, gm, C, (int)N, nt, vec, 1, nt, (const float*)nullptr, fz);
-            return check_launch();
-        });
-    }
     if (Tseg <= 0) return dasp_sosfilt_backward_grads_ex(tab, dtab, Bp, x, gy, carries, gx, partials, mode, gout, B, C, N, S, stream);
     // one table per item: the finalize step runs inside the Gram pass (gram_fused_tail); a shared table (Bp == 1 < B) takes the separate launch
     const bool fuse = partials && dtab && gout && Bp == B && mode >= 0 && mode <= 2;

@@ -2,7 +2,8 @@
 four launches) against the step whose backward launch finalizes (dasp_peq_forward / dasp_peq_backward with Tseg = -1: the basis responses
 come out of the design launch, every row's workgroup turns its Gram matrix into lag sums and the last one of an item maps them to the 18
 control gradients - three launches). Both as captured graphs of the two C calls, blocks interleaved; outputs compared.
-usage: python scripts/fused_finalize_ab.py [B C N]"""
+The Tseg = -1 path was measured and dropped (profiles/r06/fused_finalize_ab.log: +13 us, bit-identical results): it exists at commit 3fe6843 only -
+check that commit out to run this script.   usage: python scripts/fused_finalize_ab.py [B C N]"""
 import ctypes
 import json
 import os
