@@ -11,7 +11,7 @@
 //   chunk = L consecutive samples of a tile                         -> one lane
 // Each biquad is realised in a *normal* state-space form (rotation/symmetric 2x2 state matrix,
 // see prep kernel) which is ~1000x less noisy in fp32 than direct forms for low-frequency poles.
-// Per tile: (1) the tile arrives by LDS-DMA (requested a tile ahead) in a swizzled 4 KiB image -> L samples per lane;
+// Forward kernel (sos_fwd_kernel), per tile: (1) the tile arrives by LDS-DMA (requested a tile ahead) in a swizzled 4 KiB image;
 // (2) z = G x : zero-state end state of every chunk, a [2S x L] x [L x 64] product on the matrix cores
 //     (16 v_mfma_f32_16x16x4_f32 per tile; its left factor comes from the prep kernel);
 // (3) per section k: forcing f = z_k + sum_{j<k} M_kj s_j (block-lower-triangular coupling), then an
@@ -21,15 +21,30 @@
 // (4) the tile carry K_k is handed from the wave that owns tile t-1 through an LDS mailbox; only
 //     K' = e_63 + M_kk^64 K sits on that serial chain (it is lane 63's end state and that lane writes the mailbox),
 //     the per-lane fix-up M_kk^(lane+1) K is off it;
-// (5) every lane runs the S-section cascade over its L samples from its exact start state with the
-//     section coefficients held in VGPRs (VALU ops with SGPR operands issue at 2/3 rate on gfx950);
-// (6) LDS transpose back -> coalesced float4 stores.
-// The backward kernel walks the tiles in reverse with lane l on chunk 63 - l (so that the adjoint lane scan, which runs from
-// the last chunk to the first, is an ordinary ascending DPP scan): the next tile's x, gy and the chunk start states the forward
-// pass saved arrive by LDS-DMA while the current tile is processed; it recomputes s2_k[n] (= om_k * w_k[n-2], the all-pole
-// signal; w_k itself where a section may run in direct form) of every section into registers, runs the adjoint cascade (sections
-// reversed, each in transposed direct form II from the exact chunk costate) and accumulates the five coefficient correlations per
-// section; a finalize kernel reduces them in fp64.
+// (5) the chunk's 16 outputs from its exact start state are a LINEAR map of its 16 inputs and its 2S start-state components,
+//     y = T x + O s0 (T: lower-triangular Toeplitz matrix of the cascade's impulse response, O: its zero-input response per unit
+//     state; LY::YM, built in fp64 by the prep kernel): 32 more MFMAs whose B operands are the input granules already in
+//     registers and the scan's start states - no recursion runs inside a chunk;
+// (6) the result granules go from the matrix cores' D registers straight to memory (full tiles), 1 KiB contiguous per wave instruction.
+//     The chunk start states are saved for the backward pass (3 B per sample).
+//
+// Backward with coefficient gradients (sos_bwd_gram_kernel + sos_gram_finalize_kernel, round 4): inside a chunk every forward signal of
+// the cascade is linear in u = (the chunk's 16 inputs, its 2S start-state components) and every adjoint signal linear in v = (its 16
+// adjoint inputs, the 2S components of the adjoint state entering from above), so every correlation the coefficient gradients are made
+// of is <C, M_kj> with C = sum over chunks of v u^T (28 x 28 for six sections) and M_kj depending on the item's coefficients only. The
+// kernel walks the tiles in reverse with lane l on chunk 63 - l (the adjoint lane scan is then an ordinary ascending DPP scan); x, gy and
+// the saved chunk states of the next tile arrive by LDS-DMA meanwhile; per tile it scans the adjoint system over the lanes, accumulates C
+// with 64 MFMAs straight from the landed images (fp32 inside a tile, fp64 across tiles) and takes gx = T^a gy + O^a lambda from the
+// mirror image of the forward output map (28 MFMAs). One 32 x 32 fp64 matrix per row leaves the kernel; the finalize kernel (one
+// workgroup per item) forms P = C FW on the fp64 matrix cores, the lag sums and - through the design Jacobian - the 18 control
+// gradients. No forward signal is recomputed and no correlation is summed per sample (rounds 2 - 3 did both; deleted in round 5).
+// Without coefficient gradients (a fixed filter): sos_bwd_kernel, the adjoint cascade alone.
+//
+// Few rows (the reference trains with 8 - 32 items): every row is cut into segments that run as workgroups of their own; the segment
+// states travel between the workgroups of ONE launch as tagged 64-bit words (decoupled look-back; common.hpp "look-back words and the
+// sticky device error" says who may wait for whom and what a time-out does), and the Gram finalize runs inside the backward launch
+// (per-workgroup lag sums, the last arriver of an item maps their sum to the gradients: sos_gram_fin.hpp). A segmented EQ step is
+// three launches: design, forward, backward. DESIGN.md section 3.1 has the measurements behind each of these choices.
 #include "common.hpp"
 #include <type_traits>
 
