@@ -44,12 +44,12 @@ __device__ __forceinline__ float alpha_pow16(double alpha, int m) {
 // MODE: 0 compressor, 1 expander (dyn_common.hpp). SEG: 0 = one workgroup per item; 1 = one workgroup per (item, segment), EQ from
 // segstart_eq[row][segment][2S], smoothing state from segstart_dyn[item][segment]; 2 = the same EQ pass with the compressor scan-only:
 // nothing stored, the zero-state end of the segment's smoothing state goes to zseg_dyn[item][segment].
-template <int S, int L, int W, int MODE, int SEG, bool SAVE = false>
+template <int S, int L, int W, int MODE, int SEG>
 __global__ void __launch_bounds__(64 * W, (W + 3) / 4)   // one workgroup of W = 16 waves per CU: four waves per SIMD, <= 128 registers
 chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y,
                  int C, int N, int nt, int vec, double sample_rate, float eps, int G, int Tseg, const float* __restrict__ segstart_eq,
                  const float* __restrict__ segstart_dyn, float* __restrict__ zseg_dyn, float* __restrict__ chain_tab = nullptr,
-                 float* __restrict__ chain_start = nullptr, float* __restrict__ yeq = nullptr, float* __restrict__ carries = nullptr) {
+                 float* __restrict__ chain_start = nullptr) {
     using LY = SosLayout<S, L>;
     static_assert(L == 16, "chunk layout of the smoothing scan");
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L, CH = 2;
@@ -125,8 +125,7 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
             WIDE_PRIO(DASP_SCAN_PRIO);
             // the image of this pass was requested one pass ago; vmcnt is in order: the previous tile's y stores were issued before the
             // request of channel 0's image and may stay in flight, the request of channel 1's image came after them
-            // (SAVE: the previous pass's seven state / EQ-output stores were issued behind this image's request as well)
-            if (full) wait_vmcnt(SAVE ? (c == 0 ? (stores_in_flight < 0 ? 0 : stores_in_flight) : 7) : c == 0 ? stores_in_flight : 0);
+            if (full) wait_vmcnt(c == 0 ? stores_in_flight : 0);
             else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
             if (!MO) lds_to_chunks_swz<L>(tbx, X, lane);
             f4 Bop[4], zacc[4];
@@ -152,11 +151,6 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
                 },
                 [&](int k, f2 Kn) { if (t + 1 < t1) mbox_publish<63>(lds, mb_out + (c * S + k) * 4, Kn.x, Kn.y, t + 1); });
             SCAN_PRIO(0);
-            if constexpr (SAVE) {        // (prototype, round 6 A/B) the chunk start states as sos_fwd_kernel saves them for the EQ's backward pass
-                f4* cs = reinterpret_cast<f4*>(carries) + (((size_t)b * C + c) * nt + t) * (S / 2) * 64 + lane;
-#pragma unroll
-                for (int m = 0; m < S / 2; ++m) st_stream(cs + m * 64, f4{st[2 * m].x, st[2 * m].y, st[2 * m + 1].x, st[2 * m + 1].y});
-            }
             if constexpr (MO) {
                 cascade_outputs_mfma<S, L>(tby, st, Bop, AT, AO, lane);
                 lds_to_chunks_swz<L>(tby, X, lane);
@@ -181,12 +175,6 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
 #pragma unroll
             for (int n = 0; n < L; ++n) Y[c][n] = X[n];
             pin(Y[c]);
-            if constexpr (SAVE) {        // ... and the EQ's output, which the compressor's backward pass recomputes its gain from
-                float* __restrict__ er = yeq + ((size_t)b * C + c) * N;
-                chunks_to_lds_swz<L>(tby, Y[c], lane);
-                if (full) tile_swz_to_global_full(tby, er, (long)t * TS, true, lane);
-                else tile_swz_to_global_guarded(tby, er, (long)t * TS, N);
-            }
         }
         // ---- compressor on the tile while it is in registers (functional.py:325-399) ----
         WIDE_PRIO(DASP_SCAN_PRIO);
@@ -234,7 +222,7 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
             else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
             nst += L / 4;
         }
-        stores_in_flight = full ? nst + (SAVE ? 7 : 0) : -1;
+        stores_in_flight = full ? nst : -1;
         WIDE_PRIO(0);
     }
     if (SEG == 2 && chain_tab) {
@@ -349,21 +337,6 @@ int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ct
     if (mode == 0) DASP_CHAIN_LAUNCH(0, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
     else DASP_CHAIN_LAUNCH(1, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
 #undef DASP_CHAIN_LAUNCH
-    return chk();
-}
-
-
-/* PROTOTYPE for the round-6 A/B (profiles/r06/chain_fwd_saving_ab.log): dasp_chain_forward that also writes what the two backward passes
- * read - the EQ's output yeq (B, C, N) and the EQ's chunk start states carries (dasp_sos_carry_floats(B*C, N, S) floats) - 15 B per
- * channel-sample instead of 8. One workgroup per item only (Tseg = 0). */
-int dasp_chain_forward_saving(const float* tab, int Bs, const float* x, const float* ctl, float* y, float* yeq, float* carries, int B, int C, long N,
-                              int S, int mode, double sample_rate, float eps, void* stream) {
-    if (!tab || !x || !ctl || !y || !yeq || !carries || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || mode != 0) return DASP_ERR_ARG;
-    if (C > 2 || S != kS || N > 0x7fffffffL) return DASP_ERR_UNSUPPORTED;
-    const int nt = (int)dasp_sos_num_tiles(N), bc = Bs == 1 && B != 1;
-    const int vec = (N % 4 == 0) && al16(x) && al16(y) && al16(yeq);
-    hipLaunchKernelGGL((chain_fwd_kernel<kS, kL, kWC, 0, 0, true>), dim3(B), dim3(64 * kWC), 0, (hipStream_t)stream, tab, bc, x, ctl, y, C, (int)N, nt, vec,
-                       sample_rate, eps, 1, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, yeq, carries);
     return chk();
 }
 

@@ -1,7 +1,8 @@
 """Round-6 A/B for SURVEY 8(f2) on the pass that carries gradients: EQ -> compressor forward as the training step runs it (two launches
 that save what their backward passes read: 4 + 4 + 3 and 4 + 4 B per channel-sample = 19 B) against ONE fused pass that saves the same
 (dasp_chain_forward_saving, a prototype: x in, y out, the EQ's output for the compressor's backward recompute, the EQ's chunk states =
-15 B). Graph replays, blocks interleaved, outputs compared. The prototype exists at the commit named in profiles/r06/README.md only.
+15 B). Graph replays, blocks interleaved, outputs compared. Measured and closed (profiles/r06/chain_fwd_saving_ab.log): the prototype entry point
+exists at commit e745b07 only - check that commit out to run this script.
 usage: python scripts/chain_fwd_saving_ab.py [B C N]"""
 import ctypes
 import json
