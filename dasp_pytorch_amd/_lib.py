@@ -70,6 +70,7 @@ SIGNATURES = {
     "dasp_dyn_num_tiles": (_l, [_l]),
     "dasp_dyn_carry_floats": (_l, [_l, _l]),
     "dasp_dyn_partial_floats": (_l, [_l]),
+    "dasp_dyn_counters_reset": (_i, [_p, _i, _p]),
     "dasp_dynamics_forward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
     "dasp_dynamics_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _d, ctypes.c_float, _i, _p]),
     "dasp_dyn_segment_tiles": (_l, [_l, _l]),
@@ -148,8 +149,13 @@ def lib():
 
 
 
+on_failure = []          # callables run when an entry point fails (ops.py: the cached completion counters may hold a count - drop them)
+
+
 def check(status, what):
     if status != 0:
+        for hook in on_failure:
+            hook()
         kind = {-1: "invalid argument", -2: "unsupported configuration",
                 -3: "DASP_ERR_DEVICE: a kernel of an EARLIER segmented call on this device gave up waiting for a look-back word and wrote NaN "
                     f"(family bits {lib().dasp_device_error():#x}: 1 EQ forward, 2 EQ backward, 4 dynamics forward, 8 dynamics backward); results since then "

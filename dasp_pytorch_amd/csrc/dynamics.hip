@@ -731,6 +731,11 @@ int dasp_debug_dyn_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, 
 long dasp_dyn_num_tiles(long N) { return (N + DY_TS - 1) / DY_TS; }
 long dasp_dyn_carry_floats(long B, long N) { return B * dasp_dyn_num_tiles(N); }
 long dasp_dyn_partial_floats(long B) { return B * kDW * 5; }
+// the completion counters of the segmented calls back to zero: after allocating them, and after a call that failed (dasp_hip.h)
+int dasp_dyn_counters_reset(int* counters, int B, void* stream) {
+    if (!counters || B <= 0) return DASP_ERR_ARG;
+    return (int)zero_async(counters, sizeof(int) * 4 * (size_t)B, (hipStream_t)stream);
+}
 
 static int dynamics_forward_impl(int mode, const float* x, const DynCtl ctl, float* y, float* carries, float* lin_buf, int B, int C, long N,
                           double sample_rate, float eps, int lookahead, void* stream) {

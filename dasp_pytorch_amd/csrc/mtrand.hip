@@ -25,7 +25,7 @@ namespace dasp {
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
-constexpr int MT_BLOCKS_PER_CHUNK = 256;
+constexpr int MT_BLOCKS_PER_CHUNK = 256;               // ... or twice that for large draws (mt_plan: `stride` = 2), from the same table
 constexpr int MT_N_BABY = 255, MT_N_GIANT = 7;
 constexpr int MT_SLOT = 10112, MT_STRIDE = 8 + 2 * MT_SLOT;     // list slot per parity class: 79 batches of 128 exponents
 constexpr int MT_PAD_INDEX = 20560;                    // = 19937 + 623: the sequence window of one jump
@@ -62,12 +62,15 @@ __global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __res
 // its top bit only - the one bit of it the recurrence reads. `parts` workgroups share a jump when there are fewer jumps than CUs (each
 // takes every parts-th batch of the exponent lists; blockIdx = jump * parts + part).
 __global__ void __launch_bounds__(MT_JUMP_THREADS)
-mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks, int parts) {
+mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks, int parts, int stride) {
     extern __shared__ unsigned seq[];
     const int tid = threadIdx.x, job = blockIdx.x / parts, part = blockIdx.x % parts;
     int src, dst, poly;
-    if (giant) { src = 0; poly = MT_N_BABY + job; dst = 256 * (job + 1); }
-    else { const int a = job / MT_N_BABY, b = job % MT_N_BABY + 1; src = 256 * a; poly = b - 1; dst = src + b; }
+    // (stride 2: chunks of 512 regenerations - a group is 128 chunks, chunk a * 128 + b lies a * 256 J + 2 b J words on: the same giant
+    // polynomials, every other baby polynomial)
+    const int gs = 256 / stride;
+    if (giant) { src = 0; poly = MT_N_BABY + job; dst = gs * (job + 1); }
+    else { const int a = job / (gs - 1), b = job % (gs - 1) + 1; src = gs * a; poly = stride * b - 1; dst = src + b; }
     if (dst >= n_chunks) return;
 
     for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) seq[k] = states[(size_t)src * MT_N + k];
@@ -169,13 +172,13 @@ __device__ __forceinline__ void mt_pair_store(const MtPair& r, float* __restrict
 
 __global__ void __launch_bounds__(MT_GEN_THREADS)
 mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out, long long n, int rem, long long beta_max,
-                   unsigned* __restrict__ final_state, float* __restrict__ tail_u) {
+                   unsigned* __restrict__ final_state, float* __restrict__ tail_u, int bpc) {
     __shared__ unsigned ring[MT_RING];
     const int tid = threadIdx.x, c = blockIdx.x, lt = tid & 255;
     const bool producer = tid < 256;                                           // waves 0-3
-    const long long beta0 = (long long)c * MT_BLOCKS_PER_CHUNK;
+    const long long beta0 = (long long)c * bpc;
     const long long left_blocks = beta_max - beta0;
-    const int nblk = left_blocks < MT_BLOCKS_PER_CHUNK ? (int)left_blocks : MT_BLOCKS_PER_CHUNK;
+    const int nblk = left_blocks < bpc ? (int)left_blocks : bpc;
     const long long draw0 = beta0 * MT_N - (MT_N - rem);                       // draw index of the chunk's word 0
     const long long n_groups = n / 16;
     const int phi = (16 - rem % 16) % 16;                                      // group starts: q = phi (mod 16)
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(64) mt_tail_kernel(const float* __restrict__ t
     }
 }
 
-struct MtPlan { long long total, beta_max; int n_chunks, left_after; };
+struct MtPlan { long long total, beta_max; int n_chunks, left_after, stride; };
 MtPlan mt_plan(int left, long long n) {
     MtPlan p;
     const int rem = left - 1;
@@ -245,7 +248,13 @@ MtPlan mt_plan(int left, long long n) {
     const long long last_word = MT_N - rem + p.total - 1;
     p.beta_max = last_word / MT_N;
     p.left_after = (int)(MT_N * (p.beta_max + 1) - last_word);
-    p.n_chunks = p.beta_max == 0 ? 1 : (int)((p.beta_max + MT_BLOCKS_PER_CHUNK - 1) / MT_BLOCKS_PER_CHUNK);
+    // chunks of 256 regenerations; twice that from 512 chunks on: a jump costs ~170 us of a CU whatever the chunk, the generation of a
+    // chunk ~190 us per 256 regenerations - at (128,2,262144) (327,670 regenerations) 1,279 jumps are five rounds of the device, 639 are three
+    // (measured: jumps 0.89 -> 0.47 ms at an unchanged 0.47 ms of generation, profiles/r06/mtrand_kernel_stats_b128.csv)
+    const long long w256 = (p.beta_max + MT_BLOCKS_PER_CHUNK - 1) / MT_BLOCKS_PER_CHUNK;
+    p.stride = w256 > 512 ? 2 : 1;
+    const long long bpc = (long long)MT_BLOCKS_PER_CHUNK * p.stride;
+    p.n_chunks = p.beta_max == 0 ? 1 : (int)((p.beta_max + bpc - 1) / bpc);
     return p;
 }
 
@@ -265,13 +274,13 @@ int dasp_mt_layout(int* out8) {
 }
 
 // Largest n one call takes from any generator position (the loop over pieces is the caller's: pieces are multiples of 16).
-long long dasp_mt_max_values(void) { return (long long)((MT_N_GIANT + 1) * (MT_N_BABY + 1) - 1) * MT_BLOCKS_PER_CHUNK * MT_N; }
+long long dasp_mt_max_values(void) { return (long long)((MT_N_GIANT + 1) * (MT_N_BABY + 1) / 2 - 1) * 2 * MT_BLOCKS_PER_CHUNK * MT_N; }
 
 // 32-bit words of device scratch for n values from a generator with `left`: chunk start states | state afterwards (624) | tail draws (16)
 long dasp_mt_scratch_words(int left, long long n) {
     if (left < 1 || left > MT_N || n < 16) return -1;
     const MtPlan p = mt_plan(left, n);
-    if (p.n_chunks > (MT_N_GIANT + 1) * (MT_N_BABY + 1)) return -1;
+    if (p.n_chunks > (MT_N_GIANT + 1) * (MT_N_BABY + 1) / p.stride) return -1;
     return (long)p.n_chunks * MT_N + MT_N + 16;
 }
 
@@ -283,7 +292,7 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
                   int* left_after, int* regenerated, long* final_state_offset_words, void* stream) {
     if (!state_host || !out || !table || !scratch || left < 1 || left > MT_N || n < 16) return DASP_ERR_ARG;
     const MtPlan p = mt_plan(left, n);
-    if (p.n_chunks > (MT_N_GIANT + 1) * (MT_N_BABY + 1)) return DASP_ERR_UNSUPPORTED;
+    if (p.n_chunks > (MT_N_GIANT + 1) * (MT_N_BABY + 1) / p.stride) return DASP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     unsigned* states = scratch;
     unsigned* final_state = scratch + (size_t)p.n_chunks * MT_N;
@@ -296,15 +305,17 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
         if (e != hipSuccess) return (int)e;
     }
     auto parts_for = [](int jobs) { const int k = 256 / jobs; return k < 1 ? 1 : k > 8 ? 8 : k; };      // fewer jumps than CUs: several workgroups per jump
-    if (p.n_chunks > 256) {
-        const int jobs = (p.n_chunks - 1) / 256, k = parts_for(jobs);
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 1, p.n_chunks, k);
+    const int gs = 256 / p.stride;                  // chunks per group (one giant jump each)
+    if (p.n_chunks > gs) {
+        const int jobs = (p.n_chunks - 1) / gs, k = parts_for(jobs);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 1, p.n_chunks, k, p.stride);
     }
     if (p.n_chunks > 1) {
-        const int jobs = p.n_chunks > 256 ? ((p.n_chunks + 255) / 256) * MT_N_BABY : p.n_chunks - 1, k = parts_for(jobs);
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0, p.n_chunks, k);
+        const int jobs = p.n_chunks > gs ? ((p.n_chunks + gs - 1) / gs) * (gs - 1) : p.n_chunks - 1, k = parts_for(jobs);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0, p.n_chunks, k, p.stride);
     }
-    hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), 0, st, states, out, n, left - 1, p.beta_max, final_state, tail_u);
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), 0, st, states, out, n, left - 1, p.beta_max, final_state, tail_u,
+                       MT_BLOCKS_PER_CHUNK * p.stride);
     if (n & 15) hipLaunchKernelGGL(mt_tail_kernel, dim3(1), dim3(64), 0, st, tail_u, out, n);
     if (left_after) *left_after = p.left_after;
     if (regenerated) *regenerated = p.beta_max > 0;

@@ -40,13 +40,16 @@ void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t
 // The completion counters of the segmented compressor calls (dasp_hip.h: 4 ints per item, zero before their first use, every use returns
 // them to zero): one buffer per (device, stream), as ops._dyn_counters. Inside a graph capture a fresh zeroed buffer from the graph's
 // pool (a fill KERNEL node; the library no longer zeroes them with a memset node - csrc/dynamics.hip).
+// (A call that fails may leave a count behind: check_rc drops the cached buffers, the next call starts from fresh zeros - advisor, r05.)
+std::mutex g_counters_mu;
+std::map<std::pair<int, void*>, Tensor> g_counters_cache;
 Tensor dyn_counters(const Tensor& like, int64_t B) {
     const auto opts = like.options().dtype(at::kInt);
     hipStream_t st = (hipStream_t)stream_of(like);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone || B > 128) return at::zeros({4 * B}, opts);
-    static std::mutex mu;
-    static std::map<std::pair<int, void*>, Tensor> cache;
+    auto& mu = g_counters_mu;
+    auto& cache = g_counters_cache;
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_pair((int)like.device().index(), (void*)st);
     auto it = cache.find(key);
@@ -58,6 +61,10 @@ Tensor dyn_counters(const Tensor& like, int64_t B) {
 }
 
 void check_rc(int rc, const char* what) {
+    if (rc != 0) {
+        std::lock_guard<std::mutex> lock(g_counters_mu);
+        g_counters_cache.clear();
+    }
     TORCH_CHECK(rc == 0, what, " failed: ", rc == -1 ? "DASP_ERR_ARG (bad argument)" : rc == -2 ? "DASP_ERR_UNSUPPORTED" : rc == -3 ?
                 "DASP_ERR_DEVICE (a kernel of an EARLIER segmented call gave up waiting for a look-back word and wrote NaN: family bits of dasp_device_error(); "
                 "dasp_pytorch_amd.config.plan.lookback = False selects the two-launch forms, dasp_device_error_clear() re-arms) " : "HIP error ", rc);

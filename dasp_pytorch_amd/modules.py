@@ -18,9 +18,12 @@ columns of the parameter tensor), `num_params`, `process`, `process_normalized`,
 """
 from typing import Dict
 
+import atexit
 import contextlib
 import functools
+import sys
 import threading
+import weakref
 
 import torch
 
@@ -57,10 +60,35 @@ def check_unit_range(param_tensor: torch.Tensor, names):
     p = param_tensor.detach()
     if p.numel() == 0:
         return
-    lo, hi = torch.stack(torch.aminmax(p)).tolist()            # NaNs pass, as they do the reference's (p < 0).any() / (p > 1).any()
+    # NaNs pass, as they do the reference's (p < 0).any() / (p > 1).any() - but they must not hide an out-of-range value beside them
+    lo, hi = torch.stack(torch.aminmax(torch.nan_to_num(p, nan=0.5))).tolist()
     if lo < 0 or hi > 1:
         bad = ((p < 0) | (p > 1)).any(dim=0)
         raise ValueError(f"Parameter {list(names)[int(torch.nonzero(bad)[0])]} of is out of range.")
+
+
+# Deferred checks look at a call's numbers one call late; the LAST call of a run has no next call. Every checker with something pending is
+# looked at once more when the interpreter exits (an offence found there is written to stderr - an exception cannot unwind into user code
+# any more), and a call that starts under a stream capture - where nothing may wait - looks at a pending result only if it has already
+# arrived (round 5, advisor).
+_PENDING_CHECKERS = weakref.WeakSet()
+
+
+def _flush_pending_at_exit():
+    for chk in list(_PENDING_CHECKERS):
+        try:
+            chk.flush()
+        except ValueError as e:
+            sys.stderr.write(f"dasp_pytorch_amd: {e} [found at interpreter exit: the offending call was the last one of the run]\n")
+        except Exception:
+            pass                                   # (the device may be gone already)
+
+
+atexit.register(_flush_pending_at_exit)
+
+
+def _may_wait():
+    return not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
 
 class _DeferredRangeCheck:
@@ -83,18 +111,23 @@ class _DeferredRangeCheck:
         if not p.is_cuda:
             check_unit_range(p, names)
             return
-        mm = torch.stack(torch.aminmax(p, dim=0)).to(torch.float32)         # (2, P); NaNs pass, as they do the reference's (p < 0).any()
+        # (2, P) min / max per column with NaNs set aside: a NaN passes the reference's (p < 0).any() / (p > 1).any(), but a column that holds
+        # a NaN AND an out-of-range value must still raise - aminmax alone would return NaN for it (round 5, advisor)
+        mm = torch.stack((torch.nan_to_num(p, nan=0.5).amin(dim=0), torch.nan_to_num(p, nan=0.5).amax(dim=0))).to(torch.float32)
         if self.host is None or self.host.shape != mm.shape:
             self.host = torch.empty(mm.shape, dtype=torch.float32, pin_memory=True)
         self.host.copy_(mm, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending = (ev, list(names))
+        _PENDING_CHECKERS.add(self)
 
     def flush(self):
         if self.pending is None:
             return
         ev, names = self.pending
+        if not _may_wait() and not ev.query():
+            return                                 # under a capture: looked at when it has arrived
         self.pending = None
         ev.synchronize()
         lo, hi = self.host[0].tolist(), self.host[1].tolist()
@@ -135,11 +168,14 @@ class _FlagRangeCheck:
         ev = torch.cuda.Event()
         ev.record()
         self.pending = (ev, names_per_word)
+        _PENDING_CHECKERS.add(self)
 
     def flush(self):
         if self.pending is None:
             return
         ev, names_per_word = self.pending
+        if not _may_wait() and not ev.query():
+            return                                 # under a capture: looked at when it has arrived
         self.pending = None
         ev.synchronize()
         for word, names in zip(self.host.tolist(), names_per_word):

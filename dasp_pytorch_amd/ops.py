@@ -406,6 +406,7 @@ def _require_rows(x, t, ncols, name):
 
 
 _DYN_COUNTERS = {}
+_lib.on_failure.append(_DYN_COUNTERS.clear)          # a failed call may leave a count behind: the next call gets fresh zeros (advisor, r05)
 
 
 def _dyn_counters(dev):

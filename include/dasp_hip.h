@@ -258,6 +258,7 @@ int dasp_chain_controls_backward(const float* gctl, const float* ggain, const fl
 long dasp_dyn_num_tiles(long N);
 long dasp_dyn_carry_floats(long B, long N);
 long dasp_dyn_partial_floats(long B);
+int dasp_dyn_counters_reset(int* counters, int B, void* stream);
 int dasp_dynamics_forward(int mode, const float* x, const float* ctl, float* y, float* carries, float* lin_buf,
                           int B, int C, long N, double sample_rate, float eps, int lookahead, void* stream);
 int dasp_dynamics_backward(int mode, const float* x, const float* ctl, const float* gy, const float* carries,
@@ -288,7 +289,10 @@ int dasp_dynamics_backward_rows(int mode, const float* x, const float* const* ro
                                 const float* lin_buf, float* gx, float* const* grows, float* partials, float* segbuf, int B, int C, long N,
                                 double sample_rate, float eps, int lookahead, long Tseg, int* counters, void* stream);
 /* counters (may be NULL): a buffer of AT LEAST 4 * B ints owned by the caller, one buffer per stream, ZERO before its first use; every
- * call returns the words it used to zero. (Rounds 3 - 4 zeroed them with hipMemsetAsync at the start of every call; inside a captured
+ * call returns the words it used to zero. dasp_dyn_counters_reset(counters, B, stream) zeroes them on the stream (a kernel): call it after
+ * allocating the buffer and after any segmented call that returned an error - a launch that did not complete may leave a count behind,
+ * and a count that never completes means wrong start states and gradients for every later call (both bindings of this repo drop their
+ * cached buffer when a call fails). (Rounds 3 - 4 zeroed them with hipMemsetAsync at the start of every call; inside a captured
  * graph that memset node was not ordered before the kernel behind it when a replay started on an idle device, so the library zeroes
  * nothing with memset nodes any more - csrc/common.hpp zero_async.) With them the forward pass is ONE launch when Tseg is 1, 2 or 4
  * tiles per forward wave (16, 32, 64: every workgroup runs its segment from a zero state, hands the segment's end state on as a tagged

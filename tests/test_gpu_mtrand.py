@@ -62,6 +62,18 @@ def test_many_chunks_with_giant_jumps(mt):
     assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref)
 
 
+def test_chunks_of_512_regenerations(mt):
+    """From 512 chunks of 256 regenerations on (82 M values) a chunk is 512 regenerations and the jumps use every other polynomial of the
+    table (mt_plan, stride 2): slices around the chunk and group borders, the whole tensor, and the generator state."""
+    n = 513 * 159744 + 77
+    ref, s_ref, after_ref, got, s_got, after_got = _both(mt, 3, 5, (n,))
+    g = got.cpu()
+    for lo in (0, 2 * 159744 - 100, 128 * 2 * 159744 - 300, 129 * 2 * 159744 + 17, 256 * 2 * 159744 - 50, n - 3000):
+        assert float((g[lo:lo + 3000] - ref[lo:lo + 3000]).abs().max()) <= 4e-6
+    assert float((g - ref).abs().max() / ref.abs().max()) <= 1e-6
+    assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref)
+
+
 def test_successive_draws_continue_the_stream(mt):
     torch.manual_seed(5)
     a_ref, b_ref, c_ref = torch.randn(1000), torch.rand(7), torch.randn(2, 12, 300)

@@ -181,3 +181,18 @@ def test_deferred_range_check_on_cpu_tensors_is_immediate():
     with pytest.raises(ValueError, match="Parameter b of is out of range"):
         m.process_normalized(x, torch.tensor([[0.1, 0.9], [0.5, 1.5]]))
     m.flush_range_check()                                                   # nothing pending
+
+
+def test_range_check_is_not_blinded_by_a_nan():
+    """The reference's check is (p < 0).any() or (p > 1).any() per parameter (modules.py:83-84): a NaN passes it, an out-of-range value beside
+    a NaN does not. A min / max reduction returns NaN for such a column - the check sets NaNs aside first (round 5, advisor)."""
+    import torch
+    from dasp_pytorch_amd import modules as m
+    names = ["a", "b", "c"]
+    m.check_unit_range(torch.tensor([[0.5, float("nan"), 1.0], [0.0, 0.3, 0.2]]), names)            # a NaN alone passes
+    with pytest.raises(ValueError, match="Parameter b of is out of range"):
+        m.check_unit_range(torch.tensor([[0.5, float("nan"), 1.0], [0.0, 1.5, 0.2]]), names)
+    with pytest.raises(ValueError, match="Parameter c of is out of range"):
+        m.check_unit_range(torch.tensor([[0.5, float("nan"), 1.0], [0.0, float("nan"), -0.1]]), names)
+    with pytest.raises(ValueError, match="Parameter c of is out of range"):
+        m._DeferredRangeCheck().submit(torch.tensor([[0.5, float("nan"), 2.0]]), names)              # CPU tensors: checked at once
