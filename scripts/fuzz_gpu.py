@@ -90,12 +90,11 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", "120")):
         pn = rng.random((B, 18)).astype(np.float32)
         pq = (pn.astype(np.float64) * (hi - lo) + lo)
         tiles = rng.choice([0, 0, 16, 32])
-        if tiles: os.environ["DASP_CHAIN_SEGMENT_TILES"] = str(int(tiles))
-        else: os.environ.pop("DASP_CHAIN_SEGMENT_TILES", None)
+        D.config.plan.chain_segment_tiles = int(tiles) if tiles else None
         ctl = np.stack([pc[:, 0], pc[:, 1], pc[:, 2], pc[:, 4], pc[:, 5]], 1).astype(np.float32)
         with torch.no_grad():
             yf = _ops.chain_eq_compressor_forward(T(x), T(pn), _PEQ_TYPES, [float(v) for v in lo], [float(v) for v in hi - lo], float(SR), T(ctl))
-        os.environ.pop("DASP_CHAIN_SEGMENT_TILES", None)
+        D.config.plan.chain_segment_tiles = None
         y1 = sosfilt_ref(orc.peq_sos(pq, SR), x)
         c2 = orc._compressor_core(y1, SR, pd[:, 0], pd[:, 1], pd[:, 2], pd[:, 4], pd[:, 5], 1e-8, 0, np.float64)
         g2 = one_pole_ref(c2["g_c"][:, 0], c2["alpha"][:, 0, 0])[:, None]

@@ -7,7 +7,7 @@ from bench import graph_step_ms, PEQ_RANGES, SR
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(3)
 rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
-out = {"DASP_SEG_GRAM": os.environ.get("DASP_SEG_GRAM", "default")}
+out = {"what": "parametric_eq fwd+bwd, graph step ms"}
 for B, C, N, gx in ((8, 2, 131072, True), (16, 2, 131072, True), (16, 1, 131072, False), (32, 2, 131072, True), (16, 2, 262144, True)):
     cols = [(rnd(B) * (hi - lo) + lo).requires_grad_(True) for lo, hi in PEQ_RANGES]
     x = (rnd(B, C, N) * 2 - 1).requires_grad_(gx)
