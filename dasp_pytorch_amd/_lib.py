@@ -45,6 +45,7 @@ SIGNATURES = {
     "dasp_sos_segment_starts": (_i, [_p, _p, _i, _p, _p, _i, _i, _l, _i, _l, _p]),
     "dasp_chain_segment_tiles": (_l, [_l, _l]),
     "dasp_chain_seg_floats": (_l, [_l, _l, _l, _i, _l]),
+    "dasp_chain_forward_saving": (_i, [_p] * 8 + [_i, _i, _l, _i, _i, _d, ctypes.c_float, _p]),
     "dasp_chain_forward": (_i, [_p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _d, ctypes.c_float, _l, _p, _p, _p]),
     "dasp_peq_backward": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _l, _p, _p, _p]),
     "dasp_sosfilt_backward_seg_ex": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _l, _p]),

@@ -115,6 +115,16 @@ def _register_fakes():
     def _(x, ctl, mode, sample_rate, eps, lookahead_samples):
         return torch.empty_like(x, memory_format=torch.contiguous_format)
 
+    @torch.library.register_fake("dasp::eq_dyn_norm")
+    def _(x, param_tensor, sample_rate, types, lo, span, ctl, mode, eps, range_flag=None):
+        return like(x)
+
+    @torch.library.register_fake("dasp::_eq_dyn_norm_forward")
+    def _(x, param_tensor, sample_rate, types, lo, span, ctl, mode, eps, range_flag=None):
+        B, C, N = x.shape
+        ncar = _n(lambda b, n: L.dasp_dyn_carry_floats(b, n) if b * n else 0, B, N)
+        return (like(x), like(x)) + sos_work(x, param_tensor.shape[0], len(types), 0, True) + (f32(x, ncar),)
+
     @torch.library.register_fake("dasp::_dynamics_forward")
     def _(x, ctl, mode, sample_rate, eps, lookahead_samples, tseg, save):
         B, C, N = x.shape

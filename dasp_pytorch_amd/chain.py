@@ -118,6 +118,15 @@ class StyleTransferChain:
                 espan = [float(r[1]) - float(r[0]) for r in eq.param_ranges.values()]
                 y = chain_eq_compressor_forward(x, eq_params, _functional._PEQ_TYPES, elo, espan, float(self.sample_rate), ctl,
                                                 range_flag=None if flags is None else flags[0:1])
+            elif (not no_grad and eq.process_fn is _functional.parametric_eq and list(eq.param_ranges) == m._EQ_NAMES
+                  and _ops.eq_dynamics_norm_ok(x, eq_params, ctl)):
+                # the pass with gradients at 192 items and more: EQ and compressor as ONE forward pass that writes what the two backward passes
+                # read (the EQ's output, its chunk states, the compressor's tile carries) - 15 B per channel-sample instead of 19
+                eq._check_range(eq_params)
+                elo = [float(r[0]) for r in eq.param_ranges.values()]
+                espan = [float(r[1]) - float(r[0]) for r in eq.param_ranges.values()]
+                y = _ops.eq_dynamics_norm(x, eq_params, _functional._PEQ_TYPES, elo, espan, float(self.sample_rate), ctl, 0, 1e-8,
+                                          None if flags is None else flags[0:1])
             else:
                 # fused de-normalise + design; no gradient for x: the no-gx kernel
                 y = eq.process_normalized(x, eq_params) if flags is None else eq.process_normalized(x, eq_params, _range_flag=flags[0:1])

@@ -10,7 +10,8 @@
 // from wave to wave through LDS mailboxes), forms the side chain in registers, runs the gain computer (dyn_common.hpp), the one-pole
 // smoothing as a per-lane recursion + lane scan in the EQ's chunk layout (16 consecutive samples per lane: factor alpha^16 between lanes,
 // alpha^1024 between tiles, a third mailbox chain), multiplies both channels and stores: 8 B per channel-sample, no saved states
-// (forward only: the chunk states and tile carries the backward kernels need are not written).
+// (the no-gradient pass: the chunk states and tile carries the backward kernels need are not written; SAVE = true - dasp_chain_forward_saving,
+// the training pass from ~200 items on - writes them and the EQ's output: 15 B per channel-sample).
 // Few batch items: every item is cut into segments of Tseg tiles that run as independent workgroups, as in sosfilt.hip / dynamics.hip;
 // the compressor's segment start state depends on the EQ's output, so the order is: EQ scan-only pre-pass + chain (sosfilt.hip,
 // dasp_sos_segment_starts), this kernel with the compressor scan-only (SEG 2: EQ from its segment start state, nothing stored), the
@@ -44,12 +45,13 @@ __device__ __forceinline__ float alpha_pow16(double alpha, int m) {
 // MODE: 0 compressor, 1 expander (dyn_common.hpp). SEG: 0 = one workgroup per item; 1 = one workgroup per (item, segment), EQ from
 // segstart_eq[row][segment][2S], smoothing state from segstart_dyn[item][segment]; 2 = the same EQ pass with the compressor scan-only:
 // nothing stored, the zero-state end of the segment's smoothing state goes to zseg_dyn[item][segment].
-template <int S, int L, int W, int MODE, int SEG>
+template <int S, int L, int W, int MODE, int SEG, bool SAVE = false>
 __global__ void __launch_bounds__(64 * W, (W + 3) / 4)   // one workgroup of W = 16 waves per CU: four waves per SIMD, <= 128 registers
 chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __restrict__ x, const float* __restrict__ ctl, float* __restrict__ y,
                  int C, int N, int nt, int vec, double sample_rate, float eps, int G, int Tseg, const float* __restrict__ segstart_eq,
                  const float* __restrict__ segstart_dyn, float* __restrict__ zseg_dyn, float* __restrict__ chain_tab = nullptr,
-                 float* __restrict__ chain_start = nullptr) {
+                 float* __restrict__ chain_start = nullptr, float* __restrict__ yeq = nullptr, float* __restrict__ carries = nullptr,
+                 float* __restrict__ dyn_carries = nullptr, int nt_dyn = 0) {
     using LY = SosLayout<S, L>;
     static_assert(L == 16, "chunk layout of the smoothing scan");
     constexpr int S2 = 2 * S, TS = 64 * L, IMG = 64 * L, CH = 2;
@@ -125,7 +127,8 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
             WIDE_PRIO(DASP_SCAN_PRIO);
             // the image of this pass was requested one pass ago; vmcnt is in order: the previous tile's y stores were issued before the
             // request of channel 0's image and may stay in flight, the request of channel 1's image came after them
-            if (full) wait_vmcnt(c == 0 ? stores_in_flight : 0);
+            // (SAVE: the previous pass's seven state / EQ-output stores were issued behind this image's request as well)
+            if (full) wait_vmcnt(SAVE ? (c == 0 ? (stores_in_flight < 0 ? 0 : stores_in_flight) : 7) : c == 0 ? stores_in_flight : 0);
             else tile_global_to_swz_guarded(tbx, xr, (long)t * TS, N);
             if (!MO) lds_to_chunks_swz<L>(tbx, X, lane);
             f4 Bop[4], zacc[4];
@@ -151,6 +154,11 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
                 },
                 [&](int k, f2 Kn) { if (t + 1 < t1) mbox_publish<63>(lds, mb_out + (c * S + k) * 4, Kn.x, Kn.y, t + 1); });
             SCAN_PRIO(0);
+            if constexpr (SAVE) {        // the chunk start states as sos_fwd_kernel saves them for the EQ's backward pass
+                f4* cs = reinterpret_cast<f4*>(carries) + (((size_t)b * C + c) * nt + t) * (S / 2) * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < S / 2; ++m) st_stream(cs + m * 64, f4{st[2 * m].x, st[2 * m].y, st[2 * m + 1].x, st[2 * m + 1].y});
+            }
             if constexpr (MO) {
                 cascade_outputs_mfma<S, L>(tby, st, Bop, AT, AO, lane);
                 lds_to_chunks_swz<L>(tby, X, lane);
@@ -175,6 +183,12 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
 #pragma unroll
             for (int n = 0; n < L; ++n) Y[c][n] = X[n];
             pin(Y[c]);
+            if constexpr (SAVE) {        // ... and the EQ's output, which the compressor's backward pass recomputes its gain from
+                float* __restrict__ er = yeq + ((size_t)b * C + c) * N;
+                chunks_to_lds_swz<L>(tby, Y[c], lane);
+                if (full) tile_swz_to_global_full(tby, er, (long)t * TS, true, lane);
+                else tile_swz_to_global_guarded(tby, er, (long)t * TS, N);
+            }
         }
         // ---- compressor on the tile while it is in registers (functional.py:325-399) ----
         WIDE_PRIO(DASP_SCAN_PRIO);
@@ -205,6 +219,11 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
         }
         if (SEG == 2) { WIDE_PRIO(0); continue; }
         float g = fmaf(dpws, K, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x138, 0xf, 0xf, true)));
+        if constexpr (SAVE) {
+            // the smoothing state entering the compressor kernels' own tiles (512 samples: lanes 0 and 32 of this 1024-sample tile), which
+            // dyn_bwd_kernel recomputes the gain curve from (dynamics.hip: carries[item][tile])
+            if ((lane & 31) == 0 && 2 * t + (lane >> 5) < nt_dyn) dyn_carries[(size_t)b * nt_dyn + 2 * t + (lane >> 5)] = g;
+        }
 #pragma unroll
         for (int n = 0; n < L; ++n) {
             g = fmaf(it.alpha, g, gc[n]);                                                  // :372-380 as a recursion
@@ -222,7 +241,7 @@ chain_fwd_kernel(const float* __restrict__ tab, int tab_bcast, const float* __re
             else tile_swz_to_global_guarded(tby, yr, (long)t * TS, N);
             nst += L / 4;
         }
-        stores_in_flight = full ? nst : -1;
+        stores_in_flight = full ? nst + (SAVE ? 8 : 0) : -1;      // (SAVE: + the last channel's seven saves and the compressor carry)
         WIDE_PRIO(0);
     }
     if (SEG == 2 && chain_tab) {
@@ -337,6 +356,30 @@ int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ct
     if (mode == 0) DASP_CHAIN_LAUNCH(0, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
     else DASP_CHAIN_LAUNCH(1, 1, B * G, start_eq, (const float*)start_dyn, (float*)nullptr);
 #undef DASP_CHAIN_LAUNCH
+    return chk();
+}
+
+
+/* dasp_chain_forward for the pass that carries gradients (examples/style_transfer.py:150-154): the same ONE pass over x that also writes
+ * what the two backward passes read - the EQ's output yeq (B, C, N), which dasp_dynamics_backward takes as its input and recomputes the gain
+ * curve from; the EQ's chunk start states eq_carries (dasp_sos_carry_floats(B * C, N, S) floats, as dasp_sosfilt_forward saves them) for
+ * dasp_peq_backward; and the smoothing state entering every 512-sample compressor tile, dyn_carries (dasp_dyn_carry_floats(B, N) floats).
+ * 15 B per channel-sample against 19 for the two forward calls. One workgroup per item (no segments): it pays from ~200 items on
+ * ((256,2,131072) 0.272 -> 0.207 ms, (128,2,131072) 0.176 -> 0.183: profiles/r06/chain_fwd_saving_ab.log); the callers take it from 192. */
+int dasp_chain_forward_saving(const float* tab, int Bs, const float* x, const float* ctl, float* y, float* yeq, float* eq_carries, float* dyn_carries,
+                              int B, int C, long N, int S, int mode, double sample_rate, float eps, void* stream) {
+    if (!tab || !x || !ctl || !y || !yeq || !eq_carries || !dyn_carries || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || (mode != 0 && mode != 1))
+        return DASP_ERR_ARG;
+    if (C > 2 || S != kS || N > 0x7fffffffL - 1024) return DASP_ERR_UNSUPPORTED;
+    const int nt = (int)dasp_sos_num_tiles(N), bc = Bs == 1 && B != 1, ntd = (int)((N + 511) / 512);
+    const int vec = (N % 4 == 0) && al16(x) && al16(y) && al16(yeq);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0)
+        hipLaunchKernelGGL((chain_fwd_kernel<kS, kL, kWC, 0, 0, true>), dim3(B), dim3(64 * kWC), 0, st, tab, bc, x, ctl, y, C, (int)N, nt, vec, sample_rate, eps, 1, 0,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, yeq, eq_carries, dyn_carries, ntd);
+    else
+        hipLaunchKernelGGL((chain_fwd_kernel<kS, kL, kWC, 1, 0, true>), dim3(B), dim3(64 * kWC), 0, st, tab, bc, x, ctl, y, C, (int)N, nt, vec, sample_rate, eps, 1, 0,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, yeq, eq_carries, dyn_carries, ntd);
     return chk();
 }
 

@@ -166,7 +166,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }

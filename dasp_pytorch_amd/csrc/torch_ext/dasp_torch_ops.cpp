@@ -398,6 +398,84 @@ Tensor dyn_autograd(const Tensor& x, const Tensor& ctl, int64_t mode, double sam
     return DynFn::apply(x, ctl, mode, sample_rate, eps, lookahead);
 }
 
+// ---- EQ -> compressor as ONE forward pass that saves for both backward passes (csrc/chainfwd.hip dasp_chain_forward_saving; SURVEY 8(f2) on
+// the pass that carries gradients, examples/style_transfer.py:150-154). Forward: the EQ's design launch + one pass over x writing y, the
+// EQ's output (the compressor's input), the EQ's chunk states and the compressor's tile carries. Backward: the two existing backward
+// passes, the compressor's on the saved EQ output, the EQ's on what that returns. One workgroup per item: the callers take it from 192
+// items on (profiles/r06/chain_fwd_saving_ab.log), below that the two segmented forward launches are faster.
+// -> y, yeq, work32 = [tab | eq carries], work64 = [dtab], dyn carries
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> eq_dyn_norm_forward(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types,
+                                                                       at::ArrayRef<double> lo, at::ArrayRef<double> span, const Tensor& ctl, int64_t mode,
+                                                                       double eps, const c10::optional<Tensor>& range_flag) {
+    const PeqDims d = peq_check(x, pn, types, lo, span);
+    dyn_check(x, ctl, mode, 0);
+    TORCH_CHECK(d.S == 6 && d.C <= 2, "dasp::eq_dyn_norm: six sections and at most two channels (got ", d.S, ", ", d.C, ")");
+    c10::DeviceGuard guard(x.device());
+    const Tensor x32 = x.contiguous(), pn32 = f32c(pn), c32 = f32c(ctl);
+    Tensor y = at::empty_like(x32), yeq = at::empty_like(x32);
+    const long n_tab = round64(d.Bp * dasp_sos_table_floats((int)d.S));
+    const long n_car = round64(dasp_sos_carry_floats(d.B * d.C, d.N, (int)d.S));
+    Tensor work32 = empty_f32(n_tab + n_car, x32);
+    Tensor work64 = at::empty({d.Bp * dasp_sos_dtab_doubles((int)d.S)}, x32.options().dtype(at::kDouble));
+    Tensor dcar = empty_f32(x32.numel() ? dasp_dyn_carry_floats(d.B, d.N) : 0, x32);
+    if (x32.numel() == 0) return {y, yeq, work32, work64, dcar};
+    std::vector<int> ty(types.begin(), types.end());
+    float* w = work32.data_ptr<float>();
+    check_rc(dasp_peq_prepare_norm(pn32.data_ptr<float>(), (int)d.Bp, (int)d.S, ty.data(), sample_rate, lo.data(), span.data(), flag_ptr(range_flag, x32), w,
+                                   work64.data_ptr<double>(), stream_of(x32)),
+             "dasp_peq_prepare_norm");
+    check_rc(dasp_chain_forward_saving(w, (int)d.Bp, x32.data_ptr<float>(), c32.data_ptr<float>(), y.data_ptr<float>(), yeq.data_ptr<float>(), w + n_tab,
+                                       dcar.data_ptr<float>(), (int)d.B, (int)d.C, d.N, (int)d.S, (int)mode, sample_rate, (float)eps, stream_of(x32)),
+             "dasp_chain_forward_saving");
+    return {y, yeq, work32, work64, dcar};
+}
+Tensor eq_dyn_norm_device(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span,
+                          const Tensor& ctl, int64_t mode, double eps, const c10::optional<Tensor>& range_flag) {
+    return std::get<0>(eq_dyn_norm_forward(x, pn, sample_rate, types, lo, span, ctl, mode, eps, range_flag));
+}
+struct EqDynNormFn : public torch::autograd::Function<EqDynNormFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& pn, double sample_rate, std::vector<int64_t> types, std::vector<double> lo,
+                          std::vector<double> span, const Tensor& ctl, int64_t mode, double eps, const c10::optional<Tensor>& range_flag) {
+        const PeqDims d = peq_check(x, pn, types, lo, span);
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_eq_dyn_norm_forward", "")
+                             .typed<std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, double, at::IntArrayRef, at::ArrayRef<double>,
+                                                                                       at::ArrayRef<double>, const Tensor&, int64_t, double,
+                                                                                       const c10::optional<Tensor>&)>();
+        auto [y, yeq, w32, w64, dcar] = op.call(x, pn, sample_rate, types, lo, span, ctl, mode, eps, range_flag);
+        if (x.requires_grad() || pn.requires_grad() || ctl.requires_grad()) {
+            ctx->save_for_backward({x, yeq, w32, w64, dcar, ctl});
+            ctx->saved_data["Bp"] = d.Bp; ctx->saved_data["S"] = d.S; ctx->saved_data["mode"] = mode; ctx->saved_data["sr"] = sample_rate;
+            ctx->saved_data["eps"] = eps; ctx->saved_data["pn_dtype"] = (int64_t)pn.scalar_type(); ctx->saved_data["ctl_dtype"] = (int64_t)ctl.scalar_type();
+        }
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto s = ctx->get_saved_variables();
+        static auto dyn_op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_dynamics_backward", "")
+                                 .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, double, double,
+                                                                   int64_t, int64_t)>();
+        static auto peq_op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_norm_backward", "")
+                                 .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, bool, bool)>();
+        const bool need_gx = ctx->needs_input_grad(0), need_gp = ctx->needs_input_grad(1), need_gc = ctx->needs_input_grad(6);
+        // compressor backward on the saved EQ output (its input), one workgroup per item as the forward pass ran
+        auto [geq, gctl] = dyn_op.call(s[1], s[5], grads[0], s[4], at::empty({0}, s[1].options()), ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
+                                       ctx->saved_data["eps"].toDouble(), 0, 0);
+        Tensor gx, gp;
+        if (need_gx || need_gp) {
+            auto r = peq_op.call(s[0], geq, s[2], s[3], ctx->saved_data["Bp"].toInt(), ctx->saved_data["S"].toInt(), 0, need_gx, need_gp);
+            gx = std::get<0>(r); gp = std::get<1>(r);
+            if (need_gp) gp = gp.to((at::ScalarType)ctx->saved_data["pn_dtype"].toInt());
+        }
+        return {need_gx ? gx : Tensor(), need_gp ? gp : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                need_gc ? gctl.to((at::ScalarType)ctx->saved_data["ctl_dtype"].toInt()) : Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+Tensor eq_dyn_norm_autograd(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types, at::ArrayRef<double> lo, at::ArrayRef<double> span,
+                            const Tensor& ctl, int64_t mode, double eps, const c10::optional<Tensor>& range_flag) {
+    return EqDynNormFn::apply(x, pn, sample_rate, types.vec(), lo.vec(), span.vec(), ctl, mode, eps, range_flag);
+}
+
 // ---- the chain's control de-normalisation (ops.ChainControlsFunction; dasp_chain_controls / _backward) -------------------------------------
 // lo, span: 32 floats each (compressor 0-5, reverb 6-30, gain 31)
 std::tuple<Tensor, Tensor, Tensor, Tensor> chain_controls(const Tensor& comp_pn, const Tensor& reverb_pn, const Tensor& gain_pn, at::ArrayRef<double> lo,
@@ -1075,6 +1153,10 @@ TORCH_LIBRARY(dasp, m) {
     // compressor / expander on control rows; the reverb on control matrices), differentiable. range_flag: see flag_ptr above ----
     m.def("parametric_eq_norm(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, Tensor(a!)? range_flag=None) -> Tensor");
     m.def("dynamics_ctl(Tensor x, Tensor ctl, int mode, float sample_rate, float eps, int lookahead_samples) -> Tensor");
+    m.def("eq_dyn_norm(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, Tensor ctl, int mode, float eps, "
+          "Tensor(a!)? range_flag=None) -> Tensor");
+    m.def("_eq_dyn_norm_forward(Tensor x, Tensor param_tensor, float sample_rate, int[] types, float[] lo, float[] span, Tensor ctl, int mode, float eps, "
+          "Tensor(a!)? range_flag=None) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("chain_controls(Tensor comp_params, Tensor reverb_params, Tensor gain_params, float[] lo, float[] span, Tensor(a!)? range_flag=None) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("reverb(Tensor x, Tensor? noise, Tensor fspec, Tensor gains, Tensor decays, Tensor mix, int num_samples, int taps, int bands, int seed, Tensor? seed_offset, "
           "float decay_bound) -> Tensor");
@@ -1112,6 +1194,8 @@ TORCH_LIBRARY_IMPL(dasp, CUDA, m) {
     m.impl("noise_shaped_reverb", &nsr_device);
     m.impl("parametric_eq_norm", &peq_norm_device);
     m.impl("dynamics_ctl", &dyn_device);
+    m.impl("eq_dyn_norm", &eq_dyn_norm_device);
+    m.impl("_eq_dyn_norm_forward", &eq_dyn_norm_forward);
     m.impl("chain_controls", &chain_controls);
     m.impl("reverb", &reverb_device);
     m.impl("_peq_forward", &peq_forward);
@@ -1139,12 +1223,13 @@ TORCH_LIBRARY_IMPL(dasp, Autograd, m) {
     m.impl("noise_shaped_reverb", &nsr_autograd);
     m.impl("parametric_eq_norm", &peq_norm_autograd);
     m.impl("dynamics_ctl", &dyn_autograd);
+    m.impl("eq_dyn_norm", &eq_dyn_norm_autograd);
     m.impl("chain_controls", &chain_controls_autograd);
     m.impl("reverb", &reverb_autograd);
     // the two directions themselves carry no derivative: backpropagating through them (a double backward, or calling `_forward` on tensors
     // that require a gradient) raises "derivative for dasp::... is not implemented" instead of treating the result as a constant
     for (const char* name : {"_peq_forward", "_peq_backward", "_ew_forward", "_ew_backward", "_sosfilt_forward", "_sosfilt_backward", "_peq_norm_forward",
-                             "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_dynamics6_forward", "_dynamics6_backward", "_chain_controls_backward", "_reverb_forward",
+                             "_peq_norm_backward", "_dynamics_forward", "_dynamics_backward", "_dynamics6_forward", "_dynamics6_backward", "_chain_controls_backward", "_reverb_forward", "_eq_dyn_norm_forward",
                              "_reverb_backward"})
         m.impl(name, torch::autograd::autogradNotImplementedFallback());
 }

@@ -964,6 +964,28 @@ def dynamics_ctl(x, mode, sample_rate, eps, lookahead, ctl):
     return DynamicsCtlFunction.apply(x, mode, sample_rate, eps, lookahead, ctl)
 
 
+EQ_DYN_FUSED_MIN_ITEMS = 192     # one workgroup per item: (256,2,131072) 0.272 -> 0.207 ms, (128,2,131072) 0.176 -> 0.183 (profiles/r06/chain_fwd_saving_ab.log)
+
+
+def eq_dynamics_norm_ok(x, pn, ctl):
+    """True when EQ -> compressor should run as ONE forward pass that saves for both backward passes (torch.ops.dasp.eq_dyn_norm,
+    csrc/chainfwd.hip dasp_chain_forward_saving): the torch extension's binding, six sections, one or two channels, and enough items for one
+    workgroup per item to fill the device (config.plan.chain_fused_grad: None = from EQ_DYN_FUSED_MIN_ITEMS items on, True = always,
+    False = never)."""
+    mode = config.plan.chain_fused_grad
+    if mode is False or not (_torch_ops_ok(x, pn, ctl) and x.dim() == 3 and x.shape[1] <= 2 and x.numel() and pn.dim() == 2 and pn.shape[1] == 18
+                             and pn.shape[0] in (1, x.shape[0]) and ctl.dim() == 2 and ctl.shape == (x.shape[0], 5) and pn.device == x.device == ctl.device):
+        return False
+    return bool(mode) or x.shape[0] >= EQ_DYN_FUSED_MIN_ITEMS
+
+
+def eq_dynamics_norm(x, pn, types, lo, span, sample_rate, ctl, mode=0, eps=1e-8, range_flag=None):
+    """compressor(parametric_eq(x)) from the normalised (bs, 18) EQ tensor and the (bs, 5) compressor rows, with gradients for x, pn and
+    ctl: one forward pass (15 B per channel-sample instead of 19), the two existing backward passes. Call when eq_dynamics_norm_ok."""
+    return torch.ops.dasp.eq_dyn_norm(x, pn, float(sample_rate), [int(t) for t in types], [float(v) for v in lo], [float(v) for v in span], ctl,
+                                      int(mode), float(eps), range_flag)
+
+
 def chain_controls(comp_pn, reverb_pn, gain_pn, lo, span, range_flag=None):
     """ChainControlsFunction (lo, span: ctypes float[32]), or torch.ops.dasp.chain_controls. range_flag: as for parametric_eq_norm, bit i for
     column i of the 32 (compressor 0-5, reverb 6-30, gain 31)."""

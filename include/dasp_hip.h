@@ -165,6 +165,12 @@ long dasp_chain_segment_tiles(long B, long N);
 long dasp_chain_seg_floats(long B, long C, long N, int S, long Tseg);
 int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ctl, float* y, int B, int C, long N, int S, int mode,
                        double sample_rate, float eps, long Tseg, const double* segtab, float* segbuf, void* stream);
+/* The same pass for the step that carries gradients: also writes the EQ's output yeq (B, C, N) - the input of dasp_dynamics_backward -, the
+ * EQ's chunk start states eq_carries (dasp_sos_carry_floats(B * C, N, S) floats, for dasp_peq_backward / dasp_sosfilt_backward*) and the
+ * smoothing state entering every compressor tile dyn_carries (dasp_dyn_carry_floats(B, N) floats): 15 B per channel-sample instead of 19
+ * for the two forward calls. One workgroup per item (no segments); pays from ~200 items on (profiles/r06/chain_fwd_saving_ab.log). */
+int dasp_chain_forward_saving(const float* tab, int Bs, const float* x, const float* ctl, float* y, float* yeq, float* eq_carries,
+                              float* dyn_carries, int B, int C, long N, int S, int mode, double sample_rate, float eps, void* stream);
 
 /* dasp_pytorch.signal.biquad (dasp_pytorch/signal.py:242-306) as a call of its own: the fp64 RBJ design the prepare calls run, for n
  * (gain_db, cutoff_freq, q_factor) triples of one filter type. ba: (n, 6) fp64 rows [b0 b1 b2 1 a1 a2] (normalised by a0, as the

@@ -181,14 +181,21 @@ def _run_chain_on_golden(kind, g, dev, monkeypatch=None):
     return y.detach().cpu().numpy(), x.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in pp]
 
 
-@pytest.mark.parametrize("kind", ["chain", "sequence"])
-def test_chain_with_gradients_against_the_reference(D, kind):
+@pytest.mark.parametrize("kind", ["chain", "sequence", "chain_fused_training_forward"])
+def test_chain_with_gradients_against_the_reference(D, kind, monkeypatch):
     """EQ -> compressor -> reverb -> gain WITH gradients on the reference's own numbers: y, grad x and the gradients w.r.t. the four
     normalised parameter tensors (18 + 6 + 25 + 1) - gradients that cross every stage boundary (reverb grad x -> compressor grad y -> EQ
     backward; the folded gain's column). Bounds: y 1e-5 and every parameter gradient 1e-4 of the tensor's largest entry against the
     reference's fp64 run; 1e-4 against its fp32 run (the reference's fp32 run itself sits 4e-6 / 1.8e-5 from its fp64 run)."""
     g, dev = _chain_golden_inputs()
-    y, gx, gps = _run_chain_on_golden(kind, g, dev)
+    if kind == "chain_fused_training_forward":
+        # (r06, SURVEY 8(f2) on the pass with gradients) EQ -> compressor as ONE forward launch that saves for both backward passes
+        # (torch.ops.dasp.eq_dyn_norm): taken from 192 items on by itself, forced here on the golden's two items
+        monkeypatch.setattr(config.plan, "chain_fused_grad", True)
+        seen = _spy_on(monkeypatch, "eq_dyn_norm")
+    y, gx, gps = _run_chain_on_golden("chain" if kind == "chain_fused_training_forward" else kind, g, dev)
+    if kind == "chain_fused_training_forward":
+        assert seen == ["eq_dyn_norm"]
     if linf_peak(y, g["y64"]).max() > 1e-3:
         pytest.skip("this torch build's CPU generator does not reproduce the golden's noise stream")
     errs = {"y64": linf_peak(y, g["y64"]).max(), "y32": linf_peak(y, g["y32"]).max(),
@@ -207,6 +214,51 @@ def test_chain_with_gradients_against_the_reference(D, kind):
     for key in ("eq", "comp", "rev", "gain"):
         assert errs[f"gpn_{key}64"] < 1e-4 and errs[f"gpn_{key}32"] < 1e-4, (key, errs)
     assert max(errs["gpn_comp_cols64"]) < 1e-4, errs["gpn_comp_cols64"]
+
+
+def _spy_on(monkeypatch, opname):
+    """Record calls of torch.ops.dasp.<opname> (the packet is replaced by a forwarding object for the duration of the test)."""
+    seen = []
+    real = getattr(torch.ops.dasp, opname)
+
+    class Spy:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def __call__(self, *a, **k):
+            seen.append(opname)
+            return real(*a, **k)
+    monkeypatch.setattr(torch.ops.dasp, opname, Spy(), raising=False)
+    return seen
+
+
+@pytest.mark.parametrize("B,C,N", [(200, 2, 20000), (192, 1, 16385), (3, 2, 9000)])
+def test_fused_training_forward_equals_the_two_launches(D, monkeypatch, B, C, N):
+    """StyleTransferChain with gradients: the EQ -> compressor forward as one launch that saves for both backward passes (from 192 items on;
+    forced for the small case) against the two launches - outputs to the fp32 rounding of two orders of the same arithmetic, input and
+    parameter gradients through the same backward kernels fed with the fused pass's saved EQ output, states and carries; ragged lengths
+    (a last EQ tile without a second compressor tile)."""
+    from dasp_pytorch_amd.chain import StyleTransferChain
+    gen = torch.Generator().manual_seed(B + N)
+    x = (torch.rand(B, C, N, generator=gen) * 2 - 1).to("cuda:0")
+    w = torch.randn(B, 2, N, generator=gen).to("cuda:0")
+    ps = [torch.rand(B, k, generator=gen).to("cuda:0") for k in (18, 6, 25, 1)]
+
+    def run(fused_grad):
+        monkeypatch.setattr(config.plan, "chain_fused_grad", fused_grad)
+        seen = _spy_on(monkeypatch, "eq_dyn_norm")
+        xt = x.clone().requires_grad_(True)
+        pp = [p.clone().requires_grad_(True) for p in ps]
+        y = StyleTransferChain(SR, num_samples=2048, num_bandpass_taps=127, noise_seed=5).process_normalized(xt, *pp)
+        y.backward(w)
+        return seen, [y.detach(), xt.grad] + [p.grad for p in pp]
+    seen_f, f = run(None if B >= 192 else True)
+    seen_s, s = run(False)
+    assert seen_f == ["eq_dyn_norm"] and seen_s == []
+    errs = [float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(f, s)]
+    record(f"chain_fused_training_forward_vs_two_launches[{B},{C},{N}]", y=errs[0], gx=errs[1], gparams=errs[2:])
+    assert errs[0] < 1e-5 and errs[1] < 2e-5 and max(errs[2:]) < 1e-4, errs
+    assert all(torch.isfinite(t).all() for t in f)
 
 
 def test_fused_forward_prefix_against_the_reference(D):
