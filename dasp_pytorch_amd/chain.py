@@ -120,7 +120,7 @@ class StyleTransferChain:
                                                 range_flag=None if flags is None else flags[0:1])
             elif (not no_grad and eq.process_fn is _functional.parametric_eq and list(eq.param_ranges) == m._EQ_NAMES
                   and _ops.eq_dynamics_norm_ok(x, eq_params, ctl)):
-                # the pass with gradients at 192 items and more: EQ and compressor as ONE forward pass that writes what the two backward passes
+                # the pass with gradients at 384 rows (192 stereo items) and more: EQ and compressor as ONE forward pass that writes what the two backward passes
                 # read (the EQ's output, its chunk states, the compressor's tile carries) - 15 B per channel-sample instead of 19
                 eq._check_range(eq_params)
                 elo = [float(r[0]) for r in eq.param_ranges.values()]

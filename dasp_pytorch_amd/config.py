@@ -8,7 +8,7 @@ to be known before anything is imported. Tests set these with `monkeypatch.setat
     torch_ops                                     False: the ctypes autograd binding (ops.py) instead of torch.ops.dasp.* (csrc/torch_ext)
     chain_fused_controls / chain_fused_forward    False: StyleTransferChain without its fused control launch / fused no-grad EQ + compressor pass
     chain_fused_grad                              the EQ -> compressor forward of the pass WITH gradients as one launch that saves for both
-                                                  backward passes: None = from 192 items on (where it wins), True = always, False = never
+                                                  backward passes: None = from 384 rows (192 stereo items) on, where it wins, True = always, False = never
     fp64_as_fp32                                  True: ops without a double-precision path cast float64 input instead of raising
     lfilter_chunk                                 samples per chunk of time of csrc/lfilter.hip (0 = the library's plan)
     lookback                                      False: the segmented launches in their two-launch forms (pre-pass + pass: no workgroup ever

@@ -365,7 +365,7 @@ int dasp_chain_forward(const float* tab, int Bs, const float* x, const float* ct
  * curve from; the EQ's chunk start states eq_carries (dasp_sos_carry_floats(B * C, N, S) floats, as dasp_sosfilt_forward saves them) for
  * dasp_peq_backward; and the smoothing state entering every 512-sample compressor tile, dyn_carries (dasp_dyn_carry_floats(B, N) floats).
  * 15 B per channel-sample against 19 for the two forward calls. One workgroup per item (no segments): it pays from ~200 items on
- * ((256,2,131072) 0.272 -> 0.207 ms, (128,2,131072) 0.176 -> 0.183: profiles/r06/chain_fwd_saving_ab.log); the callers take it from 192. */
+ * ((256,2,131072) 0.272 -> 0.207 ms, (128,2,131072) 0.176 -> 0.183: profiles/r06/chain_fwd_saving_ab.log); the callers take it from 384 rows (inside the whole chain step the gain is 0.4 %: chain_step_ab.log). */
 int dasp_chain_forward_saving(const float* tab, int Bs, const float* x, const float* ctl, float* y, float* yeq, float* eq_carries, float* dyn_carries,
                               int B, int C, long N, int S, int mode, double sample_rate, float eps, void* stream) {
     if (!tab || !x || !ctl || !y || !yeq || !eq_carries || !dyn_carries || B <= 0 || C <= 0 || N <= 0 || (Bs != 1 && Bs != B) || (mode != 0 && mode != 1))

@@ -401,8 +401,8 @@ Tensor dyn_autograd(const Tensor& x, const Tensor& ctl, int64_t mode, double sam
 // ---- EQ -> compressor as ONE forward pass that saves for both backward passes (csrc/chainfwd.hip dasp_chain_forward_saving; SURVEY 8(f2) on
 // the pass that carries gradients, examples/style_transfer.py:150-154). Forward: the EQ's design launch + one pass over x writing y, the
 // EQ's output (the compressor's input), the EQ's chunk states and the compressor's tile carries. Backward: the two existing backward
-// passes, the compressor's on the saved EQ output, the EQ's on what that returns. One workgroup per item: the callers take it from 192
-// items on (profiles/r06/chain_fwd_saving_ab.log), below that the two segmented forward launches are faster.
+// passes, the compressor's on the saved EQ output, the EQ's on what that returns. One workgroup per item: the callers take it from 384
+// rows on (profiles/r06/chain_fwd_saving_ab.log, chain_step_ab.log), below that the two forward launches are as fast or faster.
 // -> y, yeq, work32 = [tab | eq carries], work64 = [dtab], dyn carries
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> eq_dyn_norm_forward(const Tensor& x, const Tensor& pn, double sample_rate, at::IntArrayRef types,
                                                                        at::ArrayRef<double> lo, at::ArrayRef<double> span, const Tensor& ctl, int64_t mode,
@@ -457,7 +457,7 @@ struct EqDynNormFn : public torch::autograd::Function<EqDynNormFn> {
                                                                    int64_t, int64_t)>();
         static auto peq_op = c10::Dispatcher::singleton().findSchemaOrThrow("dasp::_peq_norm_backward", "")
                                  .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, bool, bool)>();
-        const bool need_gx = ctx->needs_input_grad(0), need_gp = ctx->needs_input_grad(1), need_gc = ctx->needs_input_grad(6);
+        const bool need_gx = ctx->needs_input_grad(0), need_gp = ctx->needs_input_grad(1), need_gc = ctx->needs_input_grad(2);       // (edges are counted over the tensor arguments: x, param_tensor, ctl)
         // compressor backward on the saved EQ output (its input), one workgroup per item as the forward pass ran
         auto [geq, gctl] = dyn_op.call(s[1], s[5], grads[0], s[4], at::empty({0}, s[1].options()), ctx->saved_data["mode"].toInt(), ctx->saved_data["sr"].toDouble(),
                                        ctx->saved_data["eps"].toDouble(), 0, 0);

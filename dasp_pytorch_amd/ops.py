@@ -964,19 +964,22 @@ def dynamics_ctl(x, mode, sample_rate, eps, lookahead, ctl):
     return DynamicsCtlFunction.apply(x, mode, sample_rate, eps, lookahead, ctl)
 
 
-EQ_DYN_FUSED_MIN_ITEMS = 192     # one workgroup per item: (256,2,131072) 0.272 -> 0.207 ms, (128,2,131072) 0.176 -> 0.183 (profiles/r06/chain_fwd_saving_ab.log)
+# one workgroup per item: the forward pair alone (256,2,131072) 0.272 -> 0.207 ms, (256,1,131072) 0.144 -> 0.133, (128,2,131072) 0.176 -> 0.183
+# (profiles/r06/chain_fwd_saving_ab.log); inside the whole chain step, whose reverb is 3 ms at these sizes: (256,2) 3.666 -> 3.651,
+# (192,2) 2.868 -> 2.851, (256,1) 3.378 -> 3.389, (128,2) 1.980 -> 1.999 (chain_step_ab.log) - taken from 384 rows on
+EQ_DYN_FUSED_MIN_ROWS = 384
 
 
 def eq_dynamics_norm_ok(x, pn, ctl):
     """True when EQ -> compressor should run as ONE forward pass that saves for both backward passes (torch.ops.dasp.eq_dyn_norm,
     csrc/chainfwd.hip dasp_chain_forward_saving): the torch extension's binding, six sections, one or two channels, and enough items for one
-    workgroup per item to fill the device (config.plan.chain_fused_grad: None = from EQ_DYN_FUSED_MIN_ITEMS items on, True = always,
-    False = never)."""
+    workgroup per item to fill the device (config.plan.chain_fused_grad: None = from EQ_DYN_FUSED_MIN_ROWS rows = items x channels on,
+    True = always, False = never)."""
     mode = config.plan.chain_fused_grad
     if mode is False or not (_torch_ops_ok(x, pn, ctl) and x.dim() == 3 and x.shape[1] <= 2 and x.numel() and pn.dim() == 2 and pn.shape[1] == 18
                              and pn.shape[0] in (1, x.shape[0]) and ctl.dim() == 2 and ctl.shape == (x.shape[0], 5) and pn.device == x.device == ctl.device):
         return False
-    return bool(mode) or x.shape[0] >= EQ_DYN_FUSED_MIN_ITEMS
+    return bool(mode) or x.shape[0] * x.shape[1] >= EQ_DYN_FUSED_MIN_ROWS
 
 
 def eq_dynamics_norm(x, pn, types, lo, span, sample_rate, ctl, mode=0, eps=1e-8, range_flag=None):
