@@ -5,6 +5,9 @@
 
 #include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace dasp {
 namespace {
@@ -59,11 +62,20 @@ int error_pending() {
 }
 int lookback_enabled() { return g_lookback.load(std::memory_order_relaxed); }
 bool lookback_has_room(const void* kernel, int threads) {
-    int per_cu = 0, cus = 0, dev = current_device();
+    // (asked once per kernel and device: the occupancy query is a runtime call on the small-batch path, where host time is the step)
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, bool> seen;
+    const int dev = current_device();
     if (dev < 0) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return (long)per_cu * cus >= 64;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(kernel, dev);
+    const auto it = seen.find(key);
+    if (it != seen.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) == hipSuccess &&
+              hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && (long)per_cu * cus >= 64;
+    seen[key] = ok;
+    return ok;
 }
 }  // namespace dasp
 
