@@ -237,9 +237,11 @@ def _check_layout():
         _layout_checked = True
 
 
-def _randn_from_state(words, left, out):
+def _randn_from_state(words, left, out, max_piece=None):
     """Fill the flat float32 device tensor `out` from (words, left); returns (words afterwards as a device tensor or None when the draw
-    stayed inside the current block, left afterwards). Asynchronous on the current stream."""
+    stayed inside the current block, left afterwards). Asynchronous on the current stream - except beyond one call's capacity (327 M
+    values; `max_piece`: a smaller bound, for the tests): the draw is then made in pieces, each starting from the state the previous one
+    left, which is read back in between."""
     import ctypes
 
     import torch
@@ -247,7 +249,7 @@ def _randn_from_state(words, left, out):
     from . import _lib
     _check_layout()
     n = out.numel()
-    max_n = int(_lib.lib().dasp_mt_max_values()) // 16 * 16
+    max_n = min(int(_lib.lib().dasp_mt_max_values()), int(max_piece) if max_piece else 1 << 62) // 16 * 16
     tab = table(out.device)
     state_dev, done = None, 0
     host_words = np.ascontiguousarray(words, dtype=np.uint32)

@@ -74,6 +74,23 @@ def test_chunks_of_512_regenerations(mt):
     assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref)
 
 
+@pytest.mark.parametrize("n,piece", [(100003, 40000), (65536, 16384), (5000, 4992)])
+def test_draws_beyond_one_call_are_made_in_pieces(mt, n, piece):
+    """More values than one call of dasp_mt_randn takes (327 M) are drawn in pieces that are multiples of 16, each from the state the last
+    one left (read back in between), the tail rule applied to the last piece only and never to fewer than 16 values - forced here with a
+    small piece size."""
+    torch.manual_seed(11)
+    torch.rand(3)
+    s0 = torch.get_rng_state()
+    ref = torch.randn(n)
+    s_ref = torch.get_rng_state()
+    words, left = mt.parse_state(s0)
+    out = torch.empty(n, device=DEV)
+    state_dev, left_after = mt._randn_from_state(words, left, out, max_piece=piece)
+    assert float((out.cpu() - ref).abs().max()) <= 4e-6
+    assert torch.equal(mt.format_state(s0, state_dev.cpu().numpy().view(np.uint32), left_after), s_ref)
+
+
 def test_successive_draws_continue_the_stream(mt):
     torch.manual_seed(5)
     a_ref, b_ref, c_ref = torch.randn(1000), torch.rand(7), torch.randn(2, 12, 300)
