@@ -31,7 +31,11 @@ constexpr int MT_SLOT = 10112, MT_STRIDE = 8 + 2 * MT_SLOT;     // list slot per
 constexpr int MT_PAD_INDEX = 20560;                    // = 19937 + 623: the sequence window of one jump
 constexpr int MT_SEQ_LDS = MT_PAD_INDEX + 648;         // + zeros behind it: list padding reads them (base PAD_INDEX, lanes to 2*319+1)
 constexpr int MT_JUMP_LANES = 320;                     // 313 lanes own two state words each (one more for the odd class's neighbour word)
-constexpr int MT_JUMP_THREADS = 2 * MT_JUMP_LANES;     // two halves share the exponent list
+#ifndef DASP_MT_SLICES
+#define DASP_MT_SLICES 3
+#endif
+constexpr int MT_JUMP_SLICES = DASP_MT_SLICES;         // slices of 320 lanes share the exponent lists (batch b goes to slice b % SLICES)
+constexpr int MT_JUMP_THREADS = MT_JUMP_SLICES * MT_JUMP_LANES;
 constexpr int MT_GEN_THREADS = 512;                    // four regenerating waves + four Box-Muller waves
 constexpr int MT_STEP = 224;                           // new words per regeneration step: a multiple of 16 not above 227
 constexpr int MT_RING = 1024;                          // raw-word ring of a generating workgroup (a step looks 624 words back)
@@ -97,7 +101,7 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
 #define MT_CLASS(a0, a1, list, count, sub)                                                     \
     { const unsigned* lp = (list);                                                             \
       const int nb = (int)(count) / 128;                                                       \
-      const int first = 2 * part + half, step = 2 * parts;                                     \
+      const int first = MT_JUMP_SLICES * part + half, step = MT_JUMP_SLICES * parts;           \
       if (first < nb) {                                                                        \
           unsigned nxt = lp[64 * first + lane];                                                \
           for (int bt = first; bt < nb; bt += step) {                                          \
@@ -117,9 +121,13 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
     // fold the halves, then: word 2 t = even sum + the odd class's UPPER word of this lane; word 2 t + 1 = even sum + the odd class's
     // LOWER word of lane t + 1
     __syncthreads();
-    if (half == 1) { seq[4 * t] = e0; seq[4 * t + 1] = e1; seq[4 * t + 2] = o0; seq[4 * t + 3] = o1; }
+    if (half > 0) { unsigned* d = seq + 4 * ((half - 1) * MT_JUMP_LANES + t); d[0] = e0; d[1] = e1; d[2] = o0; d[3] = o1; }
     __syncthreads();
-    if (half == 0) { e0 ^= seq[4 * t]; e1 ^= seq[4 * t + 1]; o0 ^= seq[4 * t + 2]; o1 ^= seq[4 * t + 3]; }
+    if (half == 0)
+        for (int h = 1; h < MT_JUMP_SLICES; ++h) {
+            const unsigned* d = seq + 4 * ((h - 1) * MT_JUMP_LANES + t);
+            e0 ^= d[0]; e1 ^= d[1]; o0 ^= d[2]; o1 ^= d[3];
+        }
     __syncthreads();
     if (half == 0) seq[t] = o0;
     __syncthreads();
@@ -129,6 +137,16 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
         if (parts == 1) { out[0] = w0; out[1] = w1; }
         else { atomicXor(out, w0); atomicXor(out + 1, w1); }
     }
+}
+
+// sqrt(-2 ln(1 - u)) for u = k 2^-24, k < 2^24: the argument of the logarithm lies in [2^-24, 1] - no denormals, infinities or NaNs - so
+// the library routines' range handling (scaling by 2^32, class tests, the square root's last-bit correction) is left out: v_log_f32
+// (log2, 1 ulp) times ln 2 in two pieces as the library does it, v_sqrt_f32 (1 ulp). 13 vector instructions less per pair of values.
+__device__ __forceinline__ float mt_radius(float u) {
+    const float l2 = __builtin_amdgcn_logf(1.f - u);
+    const float hi = l2 * 0x1.62e42ep-1f;
+    const float ln = fmaf(l2, 0x1.62e42ep-1f, -hi) + fmaf(l2, 0x1.efa39ep-25f, hi);        // ln 2 = 0x1.62e42e p-1 + 0x1.efa39e p-25
+    return __builtin_amdgcn_sqrtf(-2.f * ln);
 }
 
 // cosine and sine of a in [0, 2 pi): quadrant by Cody-Waite, Cephes' single-precision kernels on [-pi/4, pi/4] (the arithmetic torch's
@@ -160,7 +178,7 @@ __device__ __forceinline__ MtPair mt_pair_radius(const unsigned* ring, int qa, l
     r.i = draw0 + qa;
     r.on = on && (r.i >> 4) < n_groups;
     const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
-    r.rad = sqrtf(-2.f * logf(1.f - ua));
+    r.rad = mt_radius(ua);
     r.ang = 6.283185307179586f * ub;
     return r;
 }
@@ -232,7 +250,7 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
 __global__ void __launch_bounds__(64) mt_tail_kernel(const float* __restrict__ tail_u, float* __restrict__ out, long long n) {
     const int j = threadIdx.x;
     if (j < 8) {
-        const float rad = sqrtf(-2.f * logf(1.f - tail_u[j]));
+        const float rad = mt_radius(tail_u[j]);
         float s, co;
         mt_sincos(6.283185307179586f * tail_u[j + 8], s, co);
         out[n - 16 + j] = rad * co;
