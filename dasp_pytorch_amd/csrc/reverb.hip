@@ -64,7 +64,18 @@ __device__ __forceinline__ NoiseKey noise_key(unsigned long long seed, unsigned 
     const unsigned k2 = lowbias32(k1 ^ (unsigned)(seed >> 32) ^ 0x85EBCA6BU);
     return NoiseKey{(k1 & 0xFFFFFFU) | 1U, k2};
 }
+// Developer bounds for the round-6 filter-bank decision (profiles/r06/fb_bounds.log; timing only - the results are meaningless):
+//   -DDASP_FB_BOUND=1  the noise costs nothing (no hash, no Box-Muller): what ANY cheaper Gaussian could save at most
+//   -DDASP_FB_BOUND=2  ... and the 12 forward transforms per window are skipped: what synthesising the bands in the frequency domain
+//                      could save at most (it would still have to generate one complex Gaussian per bin - not counted here)
+#ifndef DASP_FB_BOUND
+#define DASP_FB_BOUND 0
+#endif
 __device__ __forceinline__ void noise_pair(NoiseKey k, unsigned m, float& re, float& im) {
+#if DASP_FB_BOUND
+    re = __builtin_bit_cast(float, 0x3f800000u | (m & 0x7fffffu)) - 1.5f; im = re * 0.5f + __builtin_bit_cast(float, 0x3f000000u | (k.c & 0xffffu));
+    return;
+#endif
     const unsigned h = lowbias32(__umul24(m, k.a) + k.c);
     const float u1 = ((float)(h >> 16) + 0.5f) * (1.f / 65536.f);
     const float t = (float)(h & 0xFFFFU) * (1.f / 65536.f);
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(FFT_T, 4) void fb_fused_kernel(const float* __restr
         // spectra): the transform variant with 6 twiddle registers (fft_lds.hpp) leaves room to have a band's 16 noise loads and 8
         // spectrum loads in flight together. The one inverse transform of MODE 0 builds its twiddles after the loop.
         const SplitTwLean tw = split_twiddles_lean(j, spec);
-        auto fwd = [&](float (&rr_)[8], float (&ii_)[8], f2* buf) { fft4096_split_fwd_lean(rr_, ii_, j, tw, buf); };
+        auto fwd = [&](float (&rr_)[8], float (&ii_)[8], f2* buf) { if (DASP_FB_BOUND != 2) fft4096_split_fwd_lean(rr_, ii_, j, tw, buf); };
         float g2r[8], g2i[8];
         if (MODE == 1) {                             // G1 = FFT(gir), G2 = FFT(window time * gir); zero outside the valid range
 #pragma unroll
