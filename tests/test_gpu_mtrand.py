@@ -50,6 +50,22 @@ def test_device_stream_equals_torch_randn(mt, burn, size):
     assert torch.equal(after_got, after_ref)
 
 
+def test_random_positions_and_sizes(mt):
+    """40 random (seed, draws already taken, numel) triples - sizes up to five chunks, every alignment of the generator position against
+    the 16-element groups and the 624-word blocks left to chance: values and generator state as torch.randn leaves them."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for _ in range(40):
+        seed, burn = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 3000))
+        n = int(rng.choice([rng.integers(16, 2000), rng.integers(2000, 200000), rng.integers(200000, 800000)]))
+        ref, s_ref, after_ref, got, s_got, after_got = _both(mt, seed, burn, (n,))
+        err = float((got.cpu() - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err <= 1e-6, (seed, burn, n, err)
+        assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref), (seed, burn, n)
+    record("mtrand_random_positions_and_sizes[40]", values=worst)
+
+
 def test_many_chunks_with_giant_jumps(mt):
     """> 256 chunks (41 M values): the two-phase jump. Compared on slices (the host draw of the whole tensor is the slow thing this
     replaces: ~0.1 s here) and on the generator state."""
