@@ -309,7 +309,9 @@ def randn_cpu_stream(*size, device, defer=False):
     read-back of 2.5 KB for the state -, a generator state of an unknown layout, or a failed self-check on this device).
     defer=True returns (tensor, pending): the state's read-back is on its way and `pending.finish()` installs it - for a caller that
     queues more device work first (the reverb's kernels) so that the host does not sit out the generation; it must finish before
-    anything else can draw from the CPU generator."""
+    anything else can draw from the CPU generator. (torch.randn holds the generator's mutex for the whole fill; between this function's
+    get_rng_state and set_rng_state another host THREAD drawing from the global generator would be overwritten - as racy as two threads
+    sharing one seeded stream are in the reference, but with a wider window.)"""
     import torch
     dev = torch.device(device)
     n = 1

@@ -20,8 +20,10 @@ int current_device() {
     int dev = 0;
     return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEV ? dev : -1;
 }
+std::mutex g_err_mu;
 bool ensure(int dev) {
     if (dev < 0) return false;
+    std::lock_guard<std::mutex> lock(g_err_mu);          // (two host threads may make their first call on a device together)
     if (g_err_host[dev]) return true;
     // 64 bytes of host memory the device writes straight into: nothing is copied and nothing is polled on the fast path - a kernel
     // touches it only when it gives a word up, the host reads plain memory. (One allocation per device and process, made on the first
