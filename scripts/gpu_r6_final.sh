@@ -4,7 +4,7 @@
 out=gpurun_out/r06; mkdir -p $out; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -9 | tee $out/smoke.log
-t0=$(date +%s.%N); timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_args.json 2> $out/bench_driver_args.err; echo "bench.py --gpus 1 --steps 20 --warmup 5: $(echo "$(date +%s.%N) - $t0" | bc) s of wall time" | tee $out/bench_wall.log
+SECONDS=0; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_args.json 2> $out/bench_driver_args.err; echo "bench.py --gpus 1 --steps 20 --warmup 5: $SECONDS s of wall time (process start to exit)" | tee $out/bench_wall.log
 timeout 900 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rprof.err )
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv; rm -rf $out/rprof
