@@ -36,9 +36,13 @@ constexpr int MT_JUMP_LANES = 320;                     // 313 lanes own two stat
 #endif
 constexpr int MT_JUMP_SLICES = DASP_MT_SLICES;         // slices of 320 lanes share the exponent lists (batch b goes to slice b % SLICES)
 constexpr int MT_JUMP_THREADS = MT_JUMP_SLICES * MT_JUMP_LANES;
-constexpr int MT_GEN_THREADS = 512;                    // four regenerating waves + four Box-Muller waves
+constexpr int MT_GEN_THREADS = 512;                    // one regenerating wave + seven Box-Muller waves
 constexpr int MT_STEP = 224;                           // new words per regeneration step: a multiple of 16 not above 227
-constexpr int MT_RING = 1024;                          // raw-word ring of a generating workgroup (a step looks 624 words back)
+constexpr int MT_RING = 8192;                          // raw-word ring of a generating workgroup: 36 steps of 224 words
+#ifndef DASP_MT_UNIT
+#define DASP_MT_UNIT 4
+#endif
+constexpr int MT_UNIT = DASP_MT_UNIT;                  // steps a Box-Muller wave claims at a time: 4 steps = 448 pairs = seven passes of 64 lanes
 
 struct MtState { unsigned w[MT_N]; };                  // 2,496 bytes: travels as a kernel argument, no host-to-device copy
 
@@ -168,81 +172,155 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
 // One chunk: blocks 256 c + 1 .. of the sequence from states[c] (block 256 c), every aligned group of 16 draws whose last word lies
 // in those blocks (chunk 0: also the groups inside the state it starts from), the 16 tail draws it owns, and - the last chunk - the
 // generator state afterwards. word q of the chunk (q = 0 .. 623: the start state) is draw 624 (256 c) + q - (624 - rem).
-// Eight waves in two roles: waves 0-3 regenerate (two steps of 224 words per round, a barrier behind each - the serial chain of the
-// chunk), waves 4-7 turn the 448 words of the PREVIOUS round into normals meanwhile (radius before the middle barrier, angle and stores
-// behind it). One role for everything was 1,380 cycles per round, the regeneration's LDS round trips and the Box-Muller arithmetic one
-// after the other on every wave: 235 us per chunk.
-struct MtPair { float rad, ang; long long i; bool on; };
-__device__ __forceinline__ MtPair mt_pair_radius(const unsigned* ring, int qa, long long draw0, long long n_groups, bool on) {
-    MtPair r;
-    r.i = draw0 + qa;
-    r.on = on && (r.i >> 4) < n_groups;
-    const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
-    r.rad = mt_radius(ua);
-    r.ang = 6.283185307179586f * ub;
-    return r;
+//
+// A pipeline inside the workgroup, no barrier in the loop. Wave 0 regenerates: steps of 224 words (any 227 consecutive new words are
+// independent), four consecutive words per lane through 16-byte LDS accesses, into a ring of 8192 words; the steps follow each other
+// in ONE wave's LDS program order (the LDS executes a wave's accesses in issue order), so the serial chain of the chunk is an LDS round
+// trip and a handful of vector instructions per step. After every unit of MT_UNIT steps it publishes how far the sequence reaches
+// (`avail`). Waves 1-7 turn units into normals: each claims the next unit from a counter (the wave that shares its SIMD with the
+// regenerating one simply claims fewer), waits for `avail`, reads the unit's words (two per pair: 448 pairs = seven full passes of the
+// wave), Box-Muller, stores, and publishes the unit it is at (`cur`); the regenerating wave stays at most MT_LEAD steps ahead of the
+// slowest of them. It also runs up to MT_UNIT - 1 steps past the chunk's end: valid words nobody reads.
+// History (profiles/r06/README.md): every wave doing everything between barriers 235 us per chunk of 256 blocks; four regenerating and
+// four Box-Muller waves with two barriers per 448 words 165 us, of which the regeneration chain with its barriers alone was 125 us (733
+// cycles per round); this pipeline with steps dealt out in turn 136 us (the SIMD of the regenerating wave the slowest); claimed units: see there.
+// Every wait is bounded: a wave that polls 2^22 times gives up and the output starts with a NaN (it cannot happen: the eight waves of a
+// workgroup are resident together).
+typedef unsigned mt_u32x4 __attribute__((ext_vector_type(4)));
+// LDS accesses of the regenerating wave, written out: their order on the LDS queue and the waits are the algorithm there. (The compiler
+// does not know that a register is in flight between a read and its wait: every use sits behind the wait through the "+v" operands.)
+__device__ __forceinline__ mt_u32x4 mt_lds_read128(unsigned addr) { mt_u32x4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory"); return r; }
+__device__ __forceinline__ void mt_lds_write128(unsigned addr, mt_u32x4 w) { asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
+__device__ __forceinline__ void mt_lds_write32(unsigned addr, unsigned w) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
+template <int OUTSTANDING> __device__ __forceinline__ void mt_lds_wait(mt_u32x4& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(OUTSTANDING) : "memory");
 }
-__device__ __forceinline__ void mt_pair_store(const MtPair& r, float* __restrict__ out) {
-    float s, co;
-    mt_sincos(r.ang, s, co);
-    if (r.on) { out[r.i] = r.rad * co; out[r.i + 8] = r.rad * s; }
+// twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first
+__device__ __forceinline__ mt_u32x4 mt_twist4(mt_u32x4 a) {
+    const unsigned a4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane l reads lane l + 1
+    mt_u32x4 t;
+    t.x = mt_twist(a.x, a.y); t.y = mt_twist(a.y, a.z); t.z = mt_twist(a.z, a.w); t.w = mt_twist(a.w, a4);
+    return t;
 }
+
+constexpr int MT_CONSUMERS = MT_GEN_THREADS / 64 - 1;
+constexpr int MT_LEAD = 35;                            // steps the regenerating wave may be ahead of the slowest reader
+// step v writes words 624 + 224 (v - 1) .. + 255 (all 64 lanes store): slots of words MT_RING below those; the readers of steps > v - MT_LEAD
+// read from 624 + 224 (v - MT_LEAD) - 15 on
+static_assert(MT_RING >= MT_LEAD * MT_STEP + 32 + 15 && MT_RING >= MT_N + MT_STEP + 32 && (MT_RING & (MT_RING - 1)) == 0, "ring size");
+static_assert(MT_UNIT * MT_CONSUMERS + MT_UNIT <= MT_LEAD, "every Box-Muller wave at a unit of its own, the regenerating one a unit ahead");
+
+__device__ __forceinline__ int mt_step_end(int v, int q_end) { const int e = MT_N + MT_STEP * v; return e < q_end ? e : q_end; }   // words [0, e) of the chunk exist after step v
 
 __global__ void __launch_bounds__(MT_GEN_THREADS)
 mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out, long long n, int rem, long long beta_max,
                    unsigned* __restrict__ final_state, float* __restrict__ tail_u, int bpc) {
-    __shared__ unsigned ring[MT_RING];
-    const int tid = threadIdx.x, c = blockIdx.x, lt = tid & 255;
-    const bool producer = tid < 256;                                           // waves 0-3
+    __shared__ __attribute__((aligned(16))) unsigned ring[MT_RING];
+    __shared__ int avail;                               // words [0, avail) of the chunk exist
+    __shared__ int next_unit;                           // the next unit to claim
+    __shared__ int cur[8];                              // cur[j]: the unit wave 1 + j is at (everything below it of that wave's is read)
+    __shared__ int gave_up;
+    const int tid = threadIdx.x, c = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long beta0 = (long long)c * bpc;
     const long long left_blocks = beta_max - beta0;
     const int nblk = left_blocks < bpc ? (int)left_blocks : bpc;
     const long long draw0 = beta0 * MT_N - (MT_N - rem);                       // draw index of the chunk's word 0
     const long long n_groups = n / 16;
     const int phi = (16 - rem % 16) % 16;                                      // group starts: q = phi (mod 16)
+    const int q_end = MT_N * (nblk + 1);
+    const int n_steps = (q_end - MT_N + MT_STEP - 1) / MT_STEP;                // regeneration steps 1 .. n_steps
+    const int n_regen = (n_steps + MT_UNIT - 1) / MT_UNIT;                     // units the regenerating wave runs
+    const int n_units = n_regen > 0 ? n_regen : 1;                             // unit u: steps MT_UNIT u + 1 .. MT_UNIT (u + 1); unit 0 also the start state's groups
 
     for (int k = tid; k < MT_N; k += MT_GEN_THREADS) ring[k] = states[(size_t)c * MT_N + k];
+    if (tid < 8) cur[tid] = tid < MT_CONSUMERS ? 0 : (1 << 28);
+    if (tid == 0) { avail = MT_N; next_unit = 0; gave_up = 0; }
     __syncthreads();
 
-    const int q_end = MT_N * (nblk + 1);
-    int q_gen = MT_N;                                                          // words [0, q_gen) exist
-    int q_done = c == 0 ? MT_N - rem : 608 + phi + (phi == 0 ? 16 : 0);        // next group start (first group ending inside block 1)
-    int q_tail = c == 0 ? MT_N - rem : MT_N;                                   // tail draws are looked for in [q_tail, q_gen)
-    for (;;) {
-        const int pairs = ((q_gen - q_done) >> 4) * 8;                         // complete groups in [q_done, q_gen): 224 per round (chunk 0's first: up to 304)
-        const bool more = q_gen < q_end;
-        const int cnt_a = !more ? 0 : q_end - q_gen < MT_STEP ? q_end - q_gen : MT_STEP;
-        const int cnt_b = q_end - q_gen - cnt_a < MT_STEP ? q_end - q_gen - cnt_a : MT_STEP;
-        MtPair pr;
-        if (producer) {
-            const int q = q_gen + lt;
-            if (lt < cnt_a)
-                ring[q & (MT_RING - 1)] = ring[(q - (MT_N - MT_M)) & (MT_RING - 1)]
-                                          ^ mt_twist(ring[(q - MT_N) & (MT_RING - 1)], ring[(q - MT_N + 1) & (MT_RING - 1)]);
-        } else {
-            for (int p = lt + 256; p < pairs; p += 256)                        // (only chunk 0's first round has more than 256 pairs)
-                mt_pair_store(mt_pair_radius(ring, q_done + 16 * (p >> 3) + (p & 7), draw0, n_groups, true), out);
-            pr = mt_pair_radius(ring, q_done + 16 * (lt >> 3) + (lt & 7), draw0, n_groups, lt < pairs);
-            if ((n & 15) && lt < 16) {                                         // the 16 draws behind the tensor: kept as uniforms for mt_tail_kernel
-                const long long q = n + lt - draw0;
-                if (q >= q_tail && q < q_gen) tail_u[lt] = mt_uniform(ring[(int)q & (MT_RING - 1)]);
+    if (wave == 0) {
+        // ---- regeneration: lane l owns words q0 + 4 l .. q0 + 4 l + 3 of every step (lanes 56-63: the first 32 words of the next step's
+        // slots, overwritten by that step); x[k] = x[k - 227] ^ twist(x[k - 624], x[k - 623]) ----
+        // The x[k - 624] side of step v + 1 is complete once step v - 1 is written: it is read behind step v - 1's write and twisted while
+        // step v's x[k - 227] words (step v - 1's output) are on their way: a step's own chain is one LDS read, four XORs and the write.
+        __builtin_amdgcn_s_setprio(3);                                         // the chain goes first on the SIMD it shares with a Box-Muller wave
+        const unsigned ring_b = (unsigned)(unsigned long long)ring, mask_b = 4 * MT_RING - 1;
+        unsigned q_b = 4u * (MT_N + 4 * lane);                                 // byte offset (unwrapped) of the lane's first word of the step
+        mt_u32x4 a = mt_lds_read128(ring_b + ((q_b - 4 * MT_N) & mask_b));    // step 1: x[4 l .. 4 l + 3]
+        mt_lds_wait<0>(a);
+        mt_u32x4 tw = mt_twist4(a);
+        mt_u32x4 a_next = mt_lds_read128(ring_b + ((q_b + 4 * MT_STEP - 4 * MT_N) & mask_b));        // step 2's
+        int cleared = 0;                                                       // every step <= cleared has been read
+        for (int u = 0; u < n_regen; ++u) {
+            for (int spin = 0; MT_UNIT * (u + 1) - MT_LEAD > cleared; ++spin) {                      // (asked for once per few units)
+                int lowest = 1 << 28;
+#pragma unroll
+                for (int j = 0; j < MT_CONSUMERS; ++j) {
+                    const int r = __hip_atomic_load(&cur[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lowest = r < lowest ? r : lowest;
+                }
+                cleared = lowest >= (1 << 20) ? (1 << 28) : MT_UNIT * lowest;  // units are claimed in order: every unit below the lowest is finished
+                if (MT_UNIT * (u + 1) - MT_LEAD > cleared) __builtin_amdgcn_s_sleep(2);
+                if (spin > (1 << 22)) { gave_up = 1; break; }
             }
+#pragma unroll
+            for (int sub = 0; sub < MT_UNIT; ++sub) {
+                mt_u32x4 cw = mt_lds_read128(ring_b + ((q_b - 4 * 228) & mask_b));                   // x[q - 228 .. q - 225]; x[q - 224] is the next lane's first
+                mt_lds_wait<1>(a_next);
+                mt_u32x4 tw_next = mt_twist4(a_next);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw), "+v"(tw_next) :: "memory");         // (the twists in front of the wait, the XORs behind it)
+                const unsigned c4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)cw.x, 0x130, 0xf, 0xf, true);
+                mt_u32x4 w;
+                w.x = tw.x ^ cw.y; w.y = tw.y ^ cw.z; w.z = tw.z ^ cw.w; w.w = tw.w ^ c4;
+                mt_lds_write128(ring_b + (q_b & mask_b), w);
+                q_b += 4 * MT_STEP;
+                a_next = mt_lds_read128(ring_b + ((q_b + 4 * MT_STEP - 4 * MT_N) & mask_b));         // step v + 2's: complete with the write above
+                tw = tw_next;
+            }
+            if (lane == 0) mt_lds_write32((unsigned)(unsigned long long)&avail, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
         }
-        __syncthreads();
-        if (producer) {
-            const int q = q_gen + cnt_a + lt;
-            if (lt < cnt_b)
-                ring[q & (MT_RING - 1)] = ring[(q - (MT_N - MT_M)) & (MT_RING - 1)]
-                                          ^ mt_twist(ring[(q - MT_N) & (MT_RING - 1)], ring[(q - MT_N + 1) & (MT_RING - 1)]);
-        } else {
-            mt_pair_store(pr, out);
+        mt_lds_wait<0>(a_next);
+    } else {
+        // ---- Box-Muller ----
+        const int cj = wave - 1;
+        for (;;) {
+            int u = 0;
+            if (lane == 0) u = __hip_atomic_fetch_add(&next_unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (lane == 0) __hip_atomic_store(&cur[cj], u < n_units ? u : (1 << 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (u >= n_units) break;
+            const int s_hi = MT_UNIT * (u + 1) < n_steps ? MT_UNIT * (u + 1) : n_steps;
+            const int hi = mt_step_end(s_hi, q_end);
+            const int lo = u > 0 ? mt_step_end(MT_UNIT * u, q_end) : c == 0 ? MT_N - rem : MT_N;    // words [lo, hi) are this unit's
+            int spin = 0;
+            while (__hip_atomic_load(&avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hi) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > (1 << 22)) { gave_up = 1; break; }
+            }
+            asm volatile("" ::: "memory");
+            // the groups whose last word lies in this unit (their first may lie up to 15 words back)
+            const int qs0 = u == 0 && c == 0 ? MT_N - rem : lo + (phi ? phi - 16 : 0);
+            const int pairs = hi >= qs0 + 16 ? ((hi - qs0) >> 4) * 8 : 0;
+            for (int p = lane; p < pairs; p += 64) {
+                const int qa = qs0 + 16 * (p >> 3) + (p & 7);
+                const long long i = draw0 + qa;
+                if ((i >> 4) < n_groups) {
+                    const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
+                    const float rad = mt_radius(ua);
+                    float sn, co;
+                    mt_sincos(6.283185307179586f * ub, sn, co);
+                    out[i] = rad * co;
+                    out[i + 8] = rad * sn;
+                }
+            }
+            if ((n & 15) && lane < 16) {                                       // the 16 draws behind the tensor: kept as uniforms for mt_tail_kernel
+                const long long q = n + lane - draw0;
+                if (q >= lo && q < hi) tail_u[lane] = mt_uniform(ring[(int)q & (MT_RING - 1)]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's ring reads have returned before it says so (the next claim)
         }
-        __syncthreads();
-        q_done += 2 * pairs;
-        q_tail = q_gen;
-        q_gen += cnt_a + cnt_b;
-        if (!more) break;
     }
+    __syncthreads();
+    if (gave_up && tid == 0) out[0] = __builtin_nanf("");
     if (c == gridDim.x - 1 && nblk > 0)
         for (int k = tid; k < MT_N; k += MT_GEN_THREADS) final_state[k] = ring[(MT_N * nblk + k) & (MT_RING - 1)];
 }
