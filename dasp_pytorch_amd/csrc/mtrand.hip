@@ -36,9 +36,15 @@ constexpr int MT_JUMP_LANES = 320;                     // 313 lanes own two stat
 #endif
 constexpr int MT_JUMP_SLICES = DASP_MT_SLICES;         // slices of 320 lanes share the exponent lists (batch b goes to slice b % SLICES)
 constexpr int MT_JUMP_THREADS = MT_JUMP_SLICES * MT_JUMP_LANES;
-constexpr int MT_GEN_THREADS = 512;                    // one regenerating wave + seven Box-Muller waves
+#ifndef DASP_MT_GEN_WAVES
+#define DASP_MT_GEN_WAVES 8
+#endif
+constexpr int MT_GEN_THREADS = 64 * DASP_MT_GEN_WAVES;   // one regenerating wave + seven Box-Muller waves (16 waves: no faster alone, fewer workgroups per CU)
 constexpr int MT_STEP = 224;                           // new words per regeneration step: a multiple of 16 not above 227
-constexpr int MT_RING = 8192;                          // raw-word ring of a generating workgroup: 36 steps of 224 words
+constexpr int MT_RING = DASP_MT_GEN_WAVES > 8 ? 16384 : 8192;   // raw-word ring of a generating workgroup: 73 (36) steps of 224 words
+#ifndef DASP_MT_PROBE
+#define DASP_MT_PROBE 0                              // timing probes of the generation kernel (scripts/mtprobe_build.sh): 1 no Box-Muller work, 2 no stores, 3 no priority
+#endif
 #ifndef DASP_MT_UNIT
 #define DASP_MT_UNIT 4
 #endif
@@ -58,30 +64,40 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
 }
 __device__ __forceinline__ float mt_uniform(unsigned raw) { return (float)(mt_temper(raw) & 0xFFFFFFu) * 0x1p-24f; }
 
-// chunk 0's state from the kernel argument; the other chunks' states start as zeros (a jump shared by several workgroups is summed
-// into its state with atomic XORs)
-__global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __restrict__ states, int n_chunks) {
+// chunk 0's state from the kernel argument; the other states (chunks, then the giant jumps' targets) start as zeros (a jump shared by
+// several workgroups is summed into its state with atomic XORs)
+__global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __restrict__ states, int n_states) {
     if (blockIdx.x == 0) { if (threadIdx.x < MT_N) states[threadIdx.x] = s.w[threadIdx.x]; return; }
-    for (size_t k = MT_N + (size_t)(blockIdx.x - 1) * 640 + threadIdx.x; k < (size_t)n_chunks * MT_N; k += (size_t)(gridDim.x - 1) * 640) states[k] = 0u;
+    for (size_t k = MT_N + (size_t)(blockIdx.x - 1) * 640 + threadIdx.x; k < (size_t)n_states * MT_N; k += (size_t)(gridDim.x - 1) * 640) states[k] = 0u;
 }
 
-// One jump: states[dst] = g(T) states[src]. giant: src = chunk 0, polynomial N_BABY + blockIdx, dst = 256 (blockIdx + 1);
-// baby: a = blockIdx / 255, b = blockIdx % 255 + 1, src = 256 a, polynomial b - 1, dst = src + b. Word 0 of a jumped state is right in
-// its top bit only - the one bit of it the recurrence reads. `parts` workgroups share a jump when there are fewer jumps than CUs (each
-// takes every parts-th batch of the exponent lists; blockIdx = jump * parts + part).
+// One jump: dst = g(T) src. Chunk ch starts stride * ch = 256 a + b units (of 256 regenerations, J words) behind chunk 0.
+// giant: src = chunk 0, polynomial N_BABY + blockIdx (t^(256 (blockIdx + 1) J)), dst = giants[blockIdx] (behind the chunks' states);
+// baby: chunk blockIdx + 1: src = giants[a - 1] (a = 0: chunk 0), polynomial b - 1 (t^(b J)); b = 0: a copy. Word 0 of a jumped state is
+// right in its top bit only - the one bit of it the recurrence reads. `parts` workgroups share a jump when there are fewer jumps than
+// CUs (each takes every parts-th batch of the exponent lists; blockIdx = jump * parts + part).
 __global__ void __launch_bounds__(MT_JUMP_THREADS)
 mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks, int parts, int stride) {
     extern __shared__ unsigned seq[];
     const int tid = threadIdx.x, job = blockIdx.x / parts, part = blockIdx.x % parts;
-    int src, dst, poly;
-    // (stride 2: chunks of 512 regenerations - a group is 128 chunks, chunk a * 128 + b lies a * 256 J + 2 b J words on: the same giant
-    // polynomials, every other baby polynomial)
-    const int gs = 256 / stride;
-    if (giant) { src = 0; poly = MT_N_BABY + job; dst = gs * (job + 1); }
-    else { const int a = job / (gs - 1), b = job % (gs - 1) + 1; src = gs * a; poly = stride * b - 1; dst = src + b; }
-    if (dst >= n_chunks) return;
+    unsigned* giants = states + (size_t)n_chunks * MT_N;
+    const unsigned* src;
+    unsigned* dst;
+    int poly;
+    if (giant) { src = states; poly = MT_N_BABY + job; dst = giants + (size_t)job * MT_N; }
+    else {
+        const int m = stride * (job + 1), a = m >> 8, b = m & 255;
+        src = a ? giants + (size_t)(a - 1) * MT_N : states;
+        dst = states + (size_t)(job + 1) * MT_N;
+        poly = b - 1;
+        if (b == 0) {                                                          // the chunk starts where a giant jump landed
+            if (part == 0)
+                for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) { if (parts == 1) dst[k] = src[k]; else atomicXor(dst + k, src[k]); }
+            return;
+        }
+    }
 
-    for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) seq[k] = states[(size_t)src * MT_N + k];
+    for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) seq[k] = src[k];
     for (int k = MT_PAD_INDEX + tid; k < MT_SEQ_LDS; k += MT_JUMP_THREADS) seq[k] = 0u;
     __syncthreads();
     // the window: 19,936 more words, 227 at a time
@@ -136,7 +152,7 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
     if (half == 0) seq[t] = o0;
     __syncthreads();
     if (half == 0 && t < MT_N / 2) {
-        unsigned* out = states + (size_t)dst * MT_N + 2 * t;
+        unsigned* out = dst + 2 * t;
         const unsigned w0 = e0 ^ o1, w1 = e1 ^ seq[t + 1];
         if (parts == 1) { out[0] = w0; out[1] = w1; }
         else { atomicXor(out, w0); atomicXor(out + 1, w1); }
@@ -195,16 +211,28 @@ __device__ __forceinline__ void mt_lds_write32(unsigned addr, unsigned w) { asm 
 template <int OUTSTANDING> __device__ __forceinline__ void mt_lds_wait(mt_u32x4& r) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(OUTSTANDING) : "memory");
 }
-// twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first
+// twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first. 17 instructions: every word is shifted once
+// (it is the upper word of one twist and the lower word of the next), one bit-field insert per twist, the matrix row by a sign
+// extension of bit 0 and one three-operand bit operation.
+__device__ __forceinline__ unsigned mt_bfi(unsigned mask, unsigned from_set, unsigned from_clear) {
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(from_set), "v"(from_clear));
+    return r;
+}
 __device__ __forceinline__ mt_u32x4 mt_twist4(mt_u32x4 a) {
     const unsigned a4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane l reads lane l + 1
-    mt_u32x4 t;
-    t.x = mt_twist(a.x, a.y); t.y = mt_twist(a.y, a.z); t.z = mt_twist(a.z, a.w); t.w = mt_twist(a.w, a4);
+    const unsigned s0 = a.x >> 1, s1 = a.y >> 1, s2 = a.z >> 1, s3 = a.w >> 1, s4 = a4 >> 1;
+    mt_u32x4 t;                                        // ((u & 0x80000000 | v & 0x7fffffff) >> 1) ^ (v & 1 ? 0x9908b0df : 0)
+    t.x = mt_bfi(0x3FFFFFFFu, s1, s0) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.y, 0, 1) & 0x9908B0DFu);
+    t.y = mt_bfi(0x3FFFFFFFu, s2, s1) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.z, 0, 1) & 0x9908B0DFu);
+    t.z = mt_bfi(0x3FFFFFFFu, s3, s2) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.w, 0, 1) & 0x9908B0DFu);
+    t.w = mt_bfi(0x3FFFFFFFu, s4, s3) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a4, 0, 1) & 0x9908B0DFu);
     return t;
 }
 
 constexpr int MT_CONSUMERS = MT_GEN_THREADS / 64 - 1;
-constexpr int MT_LEAD = 35;                            // steps the regenerating wave may be ahead of the slowest reader
+constexpr int MT_GEN_LDS = 4 * (MT_RING + 4 + MT_CONSUMERS + 1);          // bytes of LDS of a generating workgroup
+constexpr int MT_LEAD = (MT_RING - 47) / MT_STEP;                          // steps the regenerating wave may be ahead of the slowest reader
 // step v writes words 624 + 224 (v - 1) .. + 255 (all 64 lanes store): slots of words MT_RING below those; the readers of steps > v - MT_LEAD
 // read from 624 + 224 (v - MT_LEAD) - 15 on
 static_assert(MT_RING >= MT_LEAD * MT_STEP + 32 + 15 && MT_RING >= MT_N + MT_STEP + 32 && (MT_RING & (MT_RING - 1)) == 0, "ring size");
@@ -215,11 +243,11 @@ __device__ __forceinline__ int mt_step_end(int v, int q_end) { const int e = MT_
 __global__ void __launch_bounds__(MT_GEN_THREADS)
 mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out, long long n, int rem, long long beta_max,
                    unsigned* __restrict__ final_state, float* __restrict__ tail_u, int bpc) {
-    __shared__ __attribute__((aligned(16))) unsigned ring[MT_RING];
-    __shared__ int avail;                               // words [0, avail) of the chunk exist
-    __shared__ int next_unit;                           // the next unit to claim
-    __shared__ int cur[8];                              // cur[j]: the unit wave 1 + j is at (everything below it of that wave's is read)
-    __shared__ int gave_up;
+    extern __shared__ __attribute__((aligned(16))) unsigned ring[];       // MT_RING words (64 KiB: asked for at the launch) and the words below
+    int& avail = *reinterpret_cast<int*>(ring + MT_RING);                  // words [0, avail) of the chunk exist
+    int& next_unit = *reinterpret_cast<int*>(ring + MT_RING + 1);          // the next unit to claim
+    int& gave_up = *reinterpret_cast<int*>(ring + MT_RING + 2);
+    int* cur = reinterpret_cast<int*>(ring + MT_RING + 4);                 // cur[j]: the unit wave 1 + j is at (everything below it of that wave's is read)
     const int tid = threadIdx.x, c = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long beta0 = (long long)c * bpc;
     const long long left_blocks = beta_max - beta0;
@@ -233,7 +261,7 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
     const int n_units = n_regen > 0 ? n_regen : 1;                             // unit u: steps MT_UNIT u + 1 .. MT_UNIT (u + 1); unit 0 also the start state's groups
 
     for (int k = tid; k < MT_N; k += MT_GEN_THREADS) ring[k] = states[(size_t)c * MT_N + k];
-    if (tid < 8) cur[tid] = tid < MT_CONSUMERS ? 0 : (1 << 28);
+    if (tid < MT_CONSUMERS) cur[tid] = 0;
     if (tid == 0) { avail = MT_N; next_unit = 0; gave_up = 0; }
     __syncthreads();
 
@@ -242,11 +270,18 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
         // slots, overwritten by that step); x[k] = x[k - 227] ^ twist(x[k - 624], x[k - 623]) ----
         // The x[k - 624] side of step v + 1 is complete once step v - 1 is written: it is read behind step v - 1's write and twisted while
         // step v's x[k - 227] words (step v - 1's output) are on their way: a step's own chain is one LDS read, four XORs and the write.
-        __builtin_amdgcn_s_setprio(3);                                         // the chain goes first on the SIMD it shares with a Box-Muller wave
-        const unsigned ring_b = (unsigned)(unsigned long long)ring, mask_b = 4 * MT_RING - 1;
+#if DASP_MT_PROBE != 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        //                                      // the chain goes first on the SIMD it shares with a Box-Muller wave
+        // (the ring is the kernel's only LDS object: its LDS address is 0 - as a constant that is an instruction less per access)
+        if ((unsigned)(unsigned long long)ring != 0u) __builtin_trap();
+        constexpr unsigned ring_b = 0u, mask_b = 4 * MT_RING - 1;
         unsigned q_b = 4u * (MT_N + 4 * lane);                                 // byte offset (unwrapped) of the lane's first word of the step
         mt_u32x4 a = mt_lds_read128(ring_b + ((q_b - 4 * MT_N) & mask_b));    // step 1: x[4 l .. 4 l + 3]
-        mt_lds_wait<0>(a);
+        mt_u32x4 wp = mt_lds_read128(ring_b + ((q_b - 4 * MT_STEP) & mask_b));  // "step 0": the last 224 words of the start state
+        mt_u32x4 fix = mt_lds_read128(ring_b + ((q_b - 4 * MT_STEP - 16) & mask_b));     // lane 0: the three words below those
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(wp), "+v"(fix) :: "memory");
         mt_u32x4 tw = mt_twist4(a);
         mt_u32x4 a_next = mt_lds_read128(ring_b + ((q_b + 4 * MT_STEP - 4 * MT_N) & mask_b));        // step 2's
         int cleared = 0;                                                       // every step <= cleared has been read
@@ -264,21 +299,24 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
             }
 #pragma unroll
             for (int sub = 0; sub < MT_UNIT; ++sub) {
-                mt_u32x4 cw = mt_lds_read128(ring_b + ((q_b - 4 * 228) & mask_b));                   // x[q - 228 .. q - 225]; x[q - 224] is the next lane's first
-                mt_lds_wait<1>(a_next);
-                mt_u32x4 tw_next = mt_twist4(a_next);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw), "+v"(tw_next) :: "memory");         // (the twists in front of the wait, the XORs behind it)
-                const unsigned c4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)cw.x, 0x130, 0xf, 0xf, true);
+                // x[q - 227 + k], k = 0 .. 3, of lane l: words 1, 2, 3 of lane l - 1's previous output and word 0 of its own - registers,
+                // not LDS; lane 0: the last three words of the step before that (`fix`, read from the ring a step ahead)
+                mt_u32x4 fix_next = mt_lds_read128(ring_b + ((q_b - 16) & mask_b));                  // lane 0: x[q0 - 3 .. q0 - 1] for the NEXT step
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a_next), "+v"(fix) :: "memory");
+                const mt_u32x4 tw_next = mt_twist4(a_next);
                 mt_u32x4 w;
-                w.x = tw.x ^ cw.y; w.y = tw.y ^ cw.z; w.z = tw.z ^ cw.w; w.w = tw.w ^ c4;
+                w.x = tw.x ^ (unsigned)__builtin_amdgcn_update_dpp((int)fix.y, (int)wp.y, 0x138, 0xf, 0xf, false);    // wave_shr:1, lane 0 keeps `fix`
+                w.y = tw.y ^ (unsigned)__builtin_amdgcn_update_dpp((int)fix.z, (int)wp.z, 0x138, 0xf, 0xf, false);
+                w.z = tw.z ^ (unsigned)__builtin_amdgcn_update_dpp((int)fix.w, (int)wp.w, 0x138, 0xf, 0xf, false);
+                w.w = tw.w ^ wp.x;
                 mt_lds_write128(ring_b + (q_b & mask_b), w);
                 q_b += 4 * MT_STEP;
                 a_next = mt_lds_read128(ring_b + ((q_b + 4 * MT_STEP - 4 * MT_N) & mask_b));         // step v + 2's: complete with the write above
-                tw = tw_next;
+                tw = tw_next; wp = w; fix = fix_next;
             }
-            if (lane == 0) mt_lds_write32((unsigned)(unsigned long long)&avail, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
+            if (lane == 0) mt_lds_write32(ring_b + 4u * MT_RING, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
         }
-        mt_lds_wait<0>(a_next);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_next), "+v"(fix) :: "memory");
     } else {
         // ---- Box-Muller ----
         const int cj = wave - 1;
@@ -300,6 +338,7 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
             // the groups whose last word lies in this unit (their first may lie up to 15 words back)
             const int qs0 = u == 0 && c == 0 ? MT_N - rem : lo + (phi ? phi - 16 : 0);
             const int pairs = hi >= qs0 + 16 ? ((hi - qs0) >> 4) * 8 : 0;
+#if DASP_MT_PROBE != 1
             for (int p = lane; p < pairs; p += 64) {
                 const int qa = qs0 + 16 * (p >> 3) + (p & 7);
                 const long long i = draw0 + qa;
@@ -308,10 +347,13 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
                     const float rad = mt_radius(ua);
                     float sn, co;
                     mt_sincos(6.283185307179586f * ub, sn, co);
-                    out[i] = rad * co;
-                    out[i + 8] = rad * sn;
+#if DASP_MT_PROBE == 2
+                    if (rad * co + rad * sn == 123.456f)
+#endif
+                    { out[i] = rad * co; out[i + 8] = rad * sn; }
                 }
             }
+#endif
             if ((n & 15) && lane < 16) {                                       // the 16 draws behind the tensor: kept as uniforms for mt_tail_kernel
                 const long long q = n + lane - draw0;
                 if (q >= lo && q < hi) tail_u[lane] = mt_uniform(ring[(int)q & (MT_RING - 1)]);
@@ -344,11 +386,12 @@ MtPlan mt_plan(int left, long long n) {
     const long long last_word = MT_N - rem + p.total - 1;
     p.beta_max = last_word / MT_N;
     p.left_after = (int)(MT_N * (p.beta_max + 1) - last_word);
-    // chunks of 256 regenerations; twice that from 512 chunks on: a jump costs ~170 us of a CU whatever the chunk, the generation of a
-    // chunk ~190 us per 256 regenerations - at (128,2,262144) (327,670 regenerations) 1,279 jumps are five rounds of the device, 639 are three
-    // (measured: jumps 0.89 -> 0.47 ms at an unchanged 0.47 ms of generation, profiles/r06/mtrand_kernel_stats_b128.csv)
-    const long long w256 = (p.beta_max + MT_BLOCKS_PER_CHUNK - 1) / MT_BLOCKS_PER_CHUNK;
-    p.stride = w256 > 512 ? 2 : 1;
+    // One chunk per CU at most: a jump costs ~145 us of a CU whatever the chunk (256 of them, one round of the device, as much as one),
+    // a chunk's generation ~85 us per unit of 256 regenerations when its workgroup has the CU to itself (the regenerating wave's
+    // instruction issue) and no less per unit when several share it. (128,2,262144) (1,280 units): 640 chunks of 2 units were 31 + 436
+    // us of jumps and 322 us of generation, 256 chunks of 5 units: see profiles/r06/README.md.
+    const long long units = (p.beta_max + MT_BLOCKS_PER_CHUNK - 1) / MT_BLOCKS_PER_CHUNK;
+    p.stride = units > 256 ? (int)((units + 255) / 256) : 1;
     const long long bpc = (long long)MT_BLOCKS_PER_CHUNK * p.stride;
     p.n_chunks = p.beta_max == 0 ? 1 : (int)((p.beta_max + bpc - 1) / bpc);
     return p;
@@ -372,12 +415,12 @@ int dasp_mt_layout(int* out8) {
 // Largest n one call takes from any generator position (the loop over pieces is the caller's: pieces are multiples of 16).
 long long dasp_mt_max_values(void) { return (long long)((MT_N_GIANT + 1) * (MT_N_BABY + 1) / 2 - 1) * 2 * MT_BLOCKS_PER_CHUNK * MT_N; }
 
-// 32-bit words of device scratch for n values from a generator with `left`: chunk start states | state afterwards (624) | tail draws (16)
+// 32-bit words of device scratch for n values from a generator with `left`: chunk start states | the giant jumps' seven | state afterwards (624) | tail draws (16)
 long dasp_mt_scratch_words(int left, long long n) {
     if (left < 1 || left > MT_N || n < 16) return -1;
     const MtPlan p = mt_plan(left, n);
-    if (p.n_chunks > (MT_N_GIANT + 1) * (MT_N_BABY + 1) / p.stride) return -1;
-    return (long)p.n_chunks * MT_N + MT_N + 16;
+    if ((long long)p.stride * (p.n_chunks - 1) >= (MT_N_GIANT + 1) * (MT_N_BABY + 1)) return -1;
+    return (long)(p.n_chunks + MT_N_GIANT) * MT_N + MT_N + 16;
 }
 
 // out[0 .. n) <- what `torch.randn(n)` (float32, CPU, n >= 16) returns from the at::mt19937 state (state_host[624], left);
@@ -388,34 +431,38 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
                   int* left_after, int* regenerated, long* final_state_offset_words, void* stream) {
     if (!state_host || !out || !table || !scratch || left < 1 || left > MT_N || n < 16) return DASP_ERR_ARG;
     const MtPlan p = mt_plan(left, n);
-    if (p.n_chunks > (MT_N_GIANT + 1) * (MT_N_BABY + 1) / p.stride) return DASP_ERR_UNSUPPORTED;
+    if ((long long)p.stride * (p.n_chunks - 1) >= (MT_N_GIANT + 1) * (MT_N_BABY + 1)) return DASP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     unsigned* states = scratch;
-    unsigned* final_state = scratch + (size_t)p.n_chunks * MT_N;
+    unsigned* final_state = scratch + (size_t)(p.n_chunks + MT_N_GIANT) * MT_N;
     float* tail_u = reinterpret_cast<float*>(final_state + MT_N);
     MtState s;
     for (int k = 0; k < MT_N; ++k) s.w[k] = state_host[k];
-    hipLaunchKernelGGL(mt_seed_kernel, dim3(p.n_chunks > 1 ? 1 + (p.n_chunks + 63) / 64 : 1), dim3(640), 0, st, s, states, p.n_chunks);
+    hipLaunchKernelGGL(mt_seed_kernel, dim3(p.n_chunks > 1 ? 1 + (p.n_chunks + MT_N_GIANT + 63) / 64 : 1), dim3(640), 0, st, s, states, p.n_chunks + MT_N_GIANT);
     {   // 83 KiB of LDS per workgroup: above the 64 KiB a kernel gets unasked (per device, so every call)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_SEQ_LDS * 4);
         if (e != hipSuccess) return (int)e;
     }
     auto parts_for = [](int jobs) { const int k = 256 / jobs; return k < 1 ? 1 : k > 8 ? 8 : k; };      // fewer jumps than CUs: several workgroups per jump
-    const int gs = 256 / p.stride;                  // chunks per group (one giant jump each)
-    if (p.n_chunks > gs) {
-        const int jobs = (p.n_chunks - 1) / gs, k = parts_for(jobs);
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 1, p.n_chunks, k, p.stride);
+    const int giants = (p.stride * (p.n_chunks - 1)) >> 8;                     // the last chunk starts 256 giants + b units on
+    if (giants > 0) {
+        const int k = parts_for(giants);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(giants * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 1, p.n_chunks, k, p.stride);
     }
     if (p.n_chunks > 1) {
-        const int jobs = p.n_chunks > gs ? ((p.n_chunks + gs - 1) / gs) * (gs - 1) : p.n_chunks - 1, k = parts_for(jobs);
+        const int jobs = p.n_chunks - 1, k = parts_for(jobs);
         hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0, p.n_chunks, k, p.stride);
     }
-    hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), 0, st, states, out, n, left - 1, p.beta_max, final_state, tail_u,
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_generate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_GEN_LDS);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), MT_GEN_LDS, st, states, out, n, left - 1, p.beta_max, final_state, tail_u,
                        MT_BLOCKS_PER_CHUNK * p.stride);
     if (n & 15) hipLaunchKernelGGL(mt_tail_kernel, dim3(1), dim3(64), 0, st, tail_u, out, n);
     if (left_after) *left_after = p.left_after;
     if (regenerated) *regenerated = p.beta_max > 0;
-    if (final_state_offset_words) *final_state_offset_words = (long)p.n_chunks * MT_N;
+    if (final_state_offset_words) *final_state_offset_words = (long)(p.n_chunks + MT_N_GIANT) * MT_N;
     return (int)hipGetLastError();
 }
 

@@ -78,15 +78,28 @@ def test_many_chunks_with_giant_jumps(mt):
     assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref)
 
 
-def test_chunks_of_512_regenerations(mt):
-    """From 512 chunks of 256 regenerations on (82 M values) a chunk is 512 regenerations and the jumps use every other polynomial of the
-    table (mt_plan, stride 2): slices around the chunk and group borders, the whole tensor, and the generator state."""
+def test_chunks_of_several_units(mt):
+    """Beyond 256 units of 256 regenerations (41 M values) a chunk is ceil(units / 256) units, so that no CU gets a second chunk
+    (mt_plan): chunk ch starts stride * ch = 256 a + b units on - giant jump a (kept beside the chunks' states), then baby polynomial b.
+    514 units: stride 3, 172 chunks; slices around chunk borders, the border next to the giant jump (chunks 85 / 86 start at units 255 /
+    258), the whole tensor, and the generator state."""
     n = 513 * 159744 + 77
     ref, s_ref, after_ref, got, s_got, after_got = _both(mt, 3, 5, (n,))
     g = got.cpu()
-    for lo in (0, 2 * 159744 - 100, 128 * 2 * 159744 - 300, 129 * 2 * 159744 + 17, 256 * 2 * 159744 - 50, n - 3000):
+    for lo in (0, 3 * 159744 - 100, 85 * 3 * 159744 - 300, 86 * 3 * 159744 - 1500, 86 * 3 * 159744 + 17, 256 * 159744 - 50, n - 3000):
         assert float((g[lo:lo + 3000] - ref[lo:lo + 3000]).abs().max()) <= 4e-6
     assert float((g - ref).abs().max() / ref.abs().max()) <= 1e-6
+    assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref)
+
+
+def test_one_chunk_per_cu_at_the_largest_reverb_batch(mt):
+    """(256, 12, 66558): the noise of BASELINE config 4 - 1,280 units, stride 5, 256 chunks, five giant jumps; chunks that start on a
+    giant jump's target (b = 0) are copies."""
+    ref, s_ref, after_ref, got, s_got, after_got = _both(mt, 21, 1, (256, 12, 66558))
+    g, r = got.cpu().reshape(-1), ref.reshape(-1)
+    for lo in (0, 5 * 159744 - 700, 51 * 5 * 159744 - 100, 52 * 5 * 159744 - 100, 256 * 159744 - 100, 1024 * 159744 - 100, g.numel() - 3000):
+        assert float((g[lo:lo + 3000] - r[lo:lo + 3000]).abs().max()) <= 4e-6
+    assert float((g - r).abs().max() / r.abs().max()) <= 1e-6
     assert torch.equal(s_got, s_ref) and torch.equal(after_got, after_ref)
 
 
