@@ -19,6 +19,7 @@
 // ~10 k LDS reads of 8 bytes per lane (ds_read_b64: 256 B/clk/CU; lanes own two state words, coefficients split by parity so that
 // every read is 8-byte aligned): LDS-bound, ~50 us on one CU. Then every chunk regenerates its blocks 224 words per step (any 227
 // consecutive new words are independent), and Box-Muller runs on the same wave 448 words at a time. HBM: 4 B written per value.
+#include <atomic>
 #include "common.hpp"
 
 namespace dasp {
@@ -439,11 +440,31 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
     MtState s;
     for (int k = 0; k < MT_N; ++k) s.w[k] = state_host[k];
     hipLaunchKernelGGL(mt_seed_kernel, dim3(p.n_chunks > 1 ? 1 + (p.n_chunks + MT_N_GIANT + 63) / 64 : 1), dim3(640), 0, st, s, states, p.n_chunks + MT_N_GIANT);
-    {   // 83 KiB of LDS per workgroup: above the 64 KiB a kernel gets unasked (per device, so every call)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_SEQ_LDS * 4);
-        if (e != hipSuccess) return (int)e;
+    {   // 83 KiB of LDS per workgroup: above the 64 KiB a kernel gets unasked - asked for once per device (the call costs the host ~10 us)
+        static std::atomic<bool> asked[64];
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !asked[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_SEQ_LDS * 4);
+            if (e != hipSuccess) return (int)e;
+            if (MT_GEN_LDS > 65536) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_generate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_GEN_LDS);
+                if (e != hipSuccess) return (int)e;
+            }
+            if (dev >= 0 && dev < 64) asked[dev].store(true, std::memory_order_release);
+        }
     }
-    auto parts_for = [](int jobs) { const int k = 256 / jobs; return k < 1 ? 1 : k > 8 ? 8 : k; };      // fewer jumps than CUs: several workgroups per jump
+    // Several workgroups per jump where that is fewer rounds x time: a workgroup with 1/k of a jump's exponents takes ~16 + 127 / k us (the
+    // window it regenerates first is the 16), one workgroup per CU at a time (83 KiB of LDS): 79 jumps three ways are one round of 58 us
+    // against 143, 160 jumps three ways two rounds (117 against 143), 255 jumps stay whole.
+    auto parts_for = [](int jobs) {
+        int best = 1;
+        float best_t = 1e30f;
+        for (int k = 1; k <= 8; ++k) {
+            const float t = (float)((jobs * k + 255) / 256) * (16.f + 127.f / (float)k);
+            if (t < best_t - 0.5f) { best_t = t; best = k; }
+        }
+        return best;
+    };
     const int giants = (p.stride * (p.n_chunks - 1)) >> 8;                     // the last chunk starts 256 giants + b units on
     if (giants > 0) {
         const int k = parts_for(giants);
@@ -452,10 +473,6 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
     if (p.n_chunks > 1) {
         const int jobs = p.n_chunks - 1, k = parts_for(jobs);
         hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0, p.n_chunks, k, p.stride);
-    }
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_generate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MT_GEN_LDS);
-        if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), MT_GEN_LDS, st, states, out, n, left - 1, p.beta_max, final_state, tail_u,
                        MT_BLOCKS_PER_CHUNK * p.stride);
