@@ -40,9 +40,9 @@ constexpr int MT_JUMP_THREADS = MT_JUMP_SLICES * MT_JUMP_LANES;
 #ifndef DASP_MT_GEN_WAVES
 #define DASP_MT_GEN_WAVES 8
 #endif
-constexpr int MT_GEN_THREADS = 64 * DASP_MT_GEN_WAVES;   // one regenerating wave + seven Box-Muller waves (16 waves: no faster alone, fewer workgroups per CU)
+constexpr int MT_GEN_THREADS = 64 * DASP_MT_GEN_WAVES;   // one regenerating wave + seven Box-Muller waves (12 / 16 waves: no faster)
 constexpr int MT_STEP = 224;                           // new words per regeneration step: a multiple of 16 not above 227
-constexpr int MT_RING = DASP_MT_GEN_WAVES > 8 ? 16384 : 8192;   // raw-word ring of a generating workgroup: 73 (36) steps of 224 words
+constexpr int MT_RING = 16384;                         // raw-word ring of a generating workgroup: 73 steps of 224 words; 64 KiB: byte offsets wrap as 16-bit sums
 #ifndef DASP_MT_PROBE
 #define DASP_MT_PROBE 0                              // timing probes of the generation kernel (scripts/mtprobe_build.sh): 1 no Box-Muller work, 2 no stores, 3 no priority
 #endif
@@ -191,16 +191,19 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
 // generator state afterwards. word q of the chunk (q = 0 .. 623: the start state) is draw 624 (256 c) + q - (624 - rem).
 //
 // A pipeline inside the workgroup, no barrier in the loop. Wave 0 regenerates: steps of 224 words (any 227 consecutive new words are
-// independent), four consecutive words per lane through 16-byte LDS accesses, into a ring of 8192 words; the steps follow each other
-// in ONE wave's LDS program order (the LDS executes a wave's accesses in issue order), so the serial chain of the chunk is an LDS round
-// trip and a handful of vector instructions per step. After every unit of MT_UNIT steps it publishes how far the sequence reaches
-// (`avail`). Waves 1-7 turn units into normals: each claims the next unit from a counter (the wave that shares its SIMD with the
-// regenerating one simply claims fewer), waits for `avail`, reads the unit's words (two per pair: 448 pairs = seven full passes of the
-// wave), Box-Muller, stores, and publishes the unit it is at (`cur`); the regenerating wave stays at most MT_LEAD steps ahead of the
-// slowest of them. It also runs up to MT_UNIT - 1 steps past the chunk's end: valid words nobody reads.
-// History (profiles/r06/README.md): every wave doing everything between barriers 235 us per chunk of 256 blocks; four regenerating and
-// four Box-Muller waves with two barriers per 448 words 165 us, of which the regeneration chain with its barriers alone was 125 us (733
-// cycles per round); this pipeline with steps dealt out in turn 136 us (the SIMD of the regenerating wave the slowest); claimed units: see there.
+// independent), four consecutive words per lane, into a ring of 16,384 words in the LDS. The serial chain of the chunk never touches
+// the LDS: a step's x[k - 227] words are the previous step's output one lane over (wave shifts), its x[k - 624] side was read from the
+// ring a step ahead. What is left is ONE wave's instruction issue: 33 instructions per step at ~7.7 cycles each (a lone wave issues an
+// independent vector instruction every 5.5 cycles, a dependent one every 8.6, a 16-byte LDS write costs it ~30: tools/ubench6.hip).
+// After every unit of MT_UNIT steps the wave publishes how far the sequence reaches (`avail`). Waves 1-7 turn units into normals: each
+// claims the next unit from a counter (the wave that shares its SIMD with the regenerating one simply claims fewer), waits for `avail`,
+// reads the unit's words (two per pair: 448 pairs = seven full passes of the wave), Box-Muller, stores, and publishes the unit it is at
+// (`cur`); the regenerating wave stays at most MT_LEAD steps ahead of the slowest of them. It also runs up to MT_UNIT - 1 steps past
+// the chunk's end: valid words nobody reads.
+// History (profiles/r06/README.md), per chunk of 256 regenerations: every wave doing everything between barriers 235 us; four
+// regenerating and four Box-Muller waves with two barriers per 448 words 165 us (the regeneration with its barriers alone: 125);
+// this pipeline with the chain through the LDS 136 us dealt out in turn, 88 us with claimed units (the regenerating wave alone: 82, an
+// LDS round trip per step); the chain in registers 85; nothing in the loop waiting for the LDS and 16-bit address sums 78.
 // Every wait is bounded: a wave that polls 2^22 times gives up and the output starts with a NaN (it cannot happen: the eight waves of a
 // workgroup are resident together).
 typedef unsigned mt_u32x4 __attribute__((ext_vector_type(4)));
@@ -211,6 +214,22 @@ __device__ __forceinline__ void mt_lds_write128(unsigned addr, mt_u32x4 w) { asm
 __device__ __forceinline__ void mt_lds_write32(unsigned addr, unsigned w) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
 template <int OUTSTANDING> __device__ __forceinline__ void mt_lds_wait(mt_u32x4& r) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(OUTSTANDING) : "memory");
+}
+// byte offsets into the 64 KiB ring wrap as 16-bit sums: one instruction (a 16-bit add clears the upper half of its result on this chip)
+template <int C> __device__ __forceinline__ unsigned mt_add16(unsigned a) { return (a + (unsigned)C) & 0xFFFFu; }
+// One statement for a step's LDS traffic (between separate asm statements the compiler puts a wait state): write w at a, advance a
+// by ADV, read 16 bytes at the new a + C1 into r1 and at the new a + C2 into r2. r1 and r2 are read-write operands: the registers of
+// values in flight stay the variables' registers from step to step (a copy of one before its wait would copy what was there before).
+template <int ADV, int C1, int C2>
+__device__ __forceinline__ void mt_ring_write_advance_read2(unsigned& a, mt_u32x4 w, mt_u32x4& r1, mt_u32x4& r2) {
+    unsigned t1, t2;
+    asm volatile("ds_write_b128 %4, %5\n\tv_add_u16 %4, %6, %4\n\tv_add_u16 %2, %7, %4\n\tv_add_u16 %3, %8, %4\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                 : "+v"(r1), "+v"(r2), "=&v"(t1), "=&v"(t2), "+v"(a) : "v"(w), "n"(ADV & 0xFFFF), "n"(C1 & 0xFFFF), "n"(C2 & 0xFFFF) : "memory");
+}
+// lanes 1 .. 63: (the lane below's `from_below`) ^ b; lane 0 keeps `lane0` (no source for it: the instruction leaves it alone)
+__device__ __forceinline__ unsigned mt_xor_shr1(unsigned lane0, unsigned from_below, unsigned b) {
+    asm("v_xor_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(lane0) : "v"(from_below), "v"(b));
+    return lane0;
 }
 // twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first. 17 instructions: every word is shifted once
 // (it is the upper word of one twist and the lower word of the next), one bit-field insert per twist, the matrix row by a sign
@@ -269,23 +288,28 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
     if (wave == 0) {
         // ---- regeneration: lane l owns words q0 + 4 l .. q0 + 4 l + 3 of every step (lanes 56-63: the first 32 words of the next step's
         // slots, overwritten by that step); x[k] = x[k - 227] ^ twist(x[k - 624], x[k - 623]) ----
-        // The x[k - 624] side of step v + 1 is complete once step v - 1 is written: it is read behind step v - 1's write and twisted while
-        // step v's x[k - 227] words (step v - 1's output) are on their way: a step's own chain is one LDS read, four XORs and the write.
+        // Step v = tw(v) ^ shift(w(v - 1)): the x[k - 227] words of lane l are words 1, 2, 3 of lane l - 1's previous output and word 0 of
+        // its own - registers and wave shifts, no LDS; lane 0 takes the last three words of step v - 2 (`fix`), read from the ring two steps
+        // ahead. tw(v + 1), the twists of the x[k - 624] side, needs steps <= v - 1 only: its words are read behind step v - 1's write
+        // and twisted at the end of step v, a whole step after they were asked for. Nothing in the loop waits for the LDS.
 #if DASP_MT_PROBE != 3
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);                                         // the chain goes first on the SIMD it shares with a Box-Muller wave
 #endif
-        //                                      // the chain goes first on the SIMD it shares with a Box-Muller wave
-        // (the ring is the kernel's only LDS object: its LDS address is 0 - as a constant that is an instruction less per access)
+        // (the ring is the kernel's only LDS object: its LDS address is 0, and byte offsets into its 64 KiB wrap as 16-bit sums)
         if ((unsigned)(unsigned long long)ring != 0u) __builtin_trap();
-        constexpr unsigned ring_b = 0u, mask_b = 4 * MT_RING - 1;
-        unsigned q_b = 4u * (MT_N + 4 * lane);                                 // byte offset (unwrapped) of the lane's first word of the step
-        mt_u32x4 a = mt_lds_read128(ring_b + ((q_b - 4 * MT_N) & mask_b));    // step 1: x[4 l .. 4 l + 3]
-        mt_u32x4 wp = mt_lds_read128(ring_b + ((q_b - 4 * MT_STEP) & mask_b));  // "step 0": the last 224 words of the start state
-        mt_u32x4 fix = mt_lds_read128(ring_b + ((q_b - 4 * MT_STEP - 16) & mask_b));     // lane 0: the three words below those
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(wp), "+v"(fix) :: "memory");
-        mt_u32x4 tw = mt_twist4(a);
-        mt_u32x4 a_next = mt_lds_read128(ring_b + ((q_b + 4 * MT_STEP - 4 * MT_N) & mask_b));        // step 2's
+        static_assert(4 * MT_RING == 65536, "the regenerating wave's addresses are 16-bit sums");
+        unsigned q_b = 4u * (MT_N + 4 * lane);                                 // byte offset (wrapped) of the lane's first word of the step
+        mt_u32x4 A[2], F[2];                                                   // x[k - 624] side / lane 0's three words of steps of this parity
+        mt_u32x4 a1 = mt_lds_read128(mt_add16<-4 * MT_N>(q_b));                // step 1: x[4 l .. 4 l + 3]
+        mt_u32x4 wp = mt_lds_read128(mt_add16<-4 * MT_STEP>(q_b));             // "step 0": the last 224 words of the start state
+        F[1] = mt_lds_read128(mt_add16<-4 * MT_STEP - 16>(q_b));               // lane 0, step 1: the three words below those
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(wp), "+v"(F[1]) :: "memory");
+        mt_u32x4 tw = mt_twist4(a1);
+        F[0] = mt_lds_read128(mt_add16<-16>(q_b));                             // step 2's (both inside the start state)
+        A[0] = mt_lds_read128(mt_add16<4 * MT_STEP - 4 * MT_N>(q_b));
+        A[1] = A[0];                                                           // (defined; refilled in step 1)
         int cleared = 0;                                                       // every step <= cleared has been read
+        static_assert(MT_UNIT % 2 == 0, "the registers of steps of one parity alternate inside a unit");
         for (int u = 0; u < n_regen; ++u) {
             for (int spin = 0; MT_UNIT * (u + 1) - MT_LEAD > cleared; ++spin) {                      // (asked for once per few units)
                 int lowest = 1 << 28;
@@ -299,25 +323,22 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
                 if (spin > (1 << 22)) { gave_up = 1; break; }
             }
 #pragma unroll
-            for (int sub = 0; sub < MT_UNIT; ++sub) {
-                // x[q - 227 + k], k = 0 .. 3, of lane l: words 1, 2, 3 of lane l - 1's previous output and word 0 of its own - registers,
-                // not LDS; lane 0: the last three words of the step before that (`fix`, read from the ring a step ahead)
-                mt_u32x4 fix_next = mt_lds_read128(ring_b + ((q_b - 16) & mask_b));                  // lane 0: x[q0 - 3 .. q0 - 1] for the NEXT step
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a_next), "+v"(fix) :: "memory");
-                const mt_u32x4 tw_next = mt_twist4(a_next);
-                mt_u32x4 w;
-                w.x = tw.x ^ (unsigned)__builtin_amdgcn_update_dpp((int)fix.y, (int)wp.y, 0x138, 0xf, 0xf, false);    // wave_shr:1, lane 0 keeps `fix`
-                w.y = tw.y ^ (unsigned)__builtin_amdgcn_update_dpp((int)fix.z, (int)wp.z, 0x138, 0xf, 0xf, false);
-                w.z = tw.z ^ (unsigned)__builtin_amdgcn_update_dpp((int)fix.w, (int)wp.w, 0x138, 0xf, 0xf, false);
+            for (int sub = 0; sub < MT_UNIT; ++sub) {                          // step v = MT_UNIT u + sub + 1, parity p
+                const int p = (sub + 1) & 1;
+                mt_u32x4 w;                                                    // lane 0 from F, the others from the lane below (wave_shr:1 leaves lane 0 alone)
+                w.x = mt_xor_shr1(tw.x ^ F[p].y, wp.y, tw.x);
+                w.y = mt_xor_shr1(tw.y ^ F[p].z, wp.z, tw.y);
+                w.z = mt_xor_shr1(tw.z ^ F[p].w, wp.w, tw.z);
                 w.w = tw.w ^ wp.x;
-                mt_lds_write128(ring_b + (q_b & mask_b), w);
-                q_b += 4 * MT_STEP;
-                a_next = mt_lds_read128(ring_b + ((q_b + 4 * MT_STEP - 4 * MT_N) & mask_b));         // step v + 2's: complete with the write above
-                tw = tw_next; wp = w; fix = fix_next;
+                // the write; behind it lane 0's three words for step v + 2 (the end of this step) and step v + 2's x[k - 624] side
+                mt_ring_write_advance_read2<4 * MT_STEP, -16, 4 * MT_STEP - 4 * MT_N>(q_b, w, F[p], A[p]);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(F[p ^ 1]), "+v"(A[p ^ 1]) :: "memory");   // step v + 1's: asked for a step ago
+                tw = mt_twist4(A[p ^ 1]);
+                wp = w;
             }
-            if (lane == 0) mt_lds_write32(ring_b + 4u * MT_RING, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
+            if (lane == 0) mt_lds_write32(4u * MT_RING, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_next), "+v"(fix) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(F[0]), "+v"(F[1]) :: "memory");
     } else {
         // ---- Box-Muller ----
         const int cj = wave - 1;
