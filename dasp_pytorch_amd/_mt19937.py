@@ -38,9 +38,9 @@ BLOCKS_PER_CHUNK = 256                  # a chunk = this many regenerations = 15
 JUMP = N * BLOCKS_PER_CHUNK             # words between the start states of neighbouring chunks
 N_BABY = 255                            # t^(b J), b = 1 .. 255: chunk a*256 + b from chunk a*256
 N_GIANT = 7                             # t^(a 256 J), a = 1 .. 7: chunk a*256 from chunk 0  => at most 2048 chunks (327 M draws) per call
-SLOT = 10112                            # index-list slot per parity class (at most 9969 even / 9968 odd coefficients), a multiple of 128
-STRIDE = 8 + 2 * SLOT                   # uint16 per polynomial: header (two uint32 counts, padded) + even list + odd list
-PAD_INDEX = 20560                       # first word behind the sequence window: the kernel keeps zeros there (list padding reads them)
+GROUP = 16                              # exponents per group: bit s of uint16 g of a row = coefficient of t^(16 g + s)
+ROW = 1280                              # uint16 per polynomial: 1,247 groups, padded with zeros
+PAD_INDEX = 20560                       # first word behind the sequence window of a jump (19937 + 623): the kernel keeps zeros there
 MAX_CHUNKS = (N_GIANT + 1) * (N_BABY + 1)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -122,29 +122,19 @@ def jump_polynomials():
 
 
 def _expand(g):
-    """One polynomial as the kernel reads it: STRIDE uint16 = [n_even (u32), n_odd (u32), 0, 0 | even exponents | odd exponents], each
-    list padded to a multiple of 128 with an exponent whose window is all zeros (PAD_INDEX for the even class, PAD_INDEX + 1 for the odd)."""
-    bits = np.unpackbits(np.frombuffer(g.to_bytes((DEG + 7) // 8 + 1, "little"), dtype=np.uint8), bitorder="little")
-    idx = np.nonzero(bits)[0]
-    row = np.zeros(STRIDE, dtype=np.uint16)
-    head = np.zeros(2, dtype=np.uint32)
-    for k, (cls, pad) in enumerate(((idx[idx % 2 == 0], PAD_INDEX), (idx[idx % 2 == 1], PAD_INDEX + 1))):
-        n8 = (len(cls) + 127) // 128 * 128
-        assert n8 <= SLOT
-        head[k] = n8
-        seg = np.full(SLOT, pad, dtype=np.uint16)
-        seg[:len(cls)] = cls
-        row[8 + k * SLOT: 8 + (k + 1) * SLOT] = seg
-    row[:4] = head.view(np.uint16)
+    """One polynomial as the kernel reads it: ROW uint16, bit s of word k = the coefficient of t^(16 k + s)."""
+    row = np.zeros(ROW, dtype=np.uint16)
+    raw = np.frombuffer(g.to_bytes(2 * ((DEG + 15) // 16), "little"), dtype="<u2")
+    row[:len(raw)] = raw
     return row
 
 
 def build_table(path=TABLE_PATH, force=False):
-    """(N_BABY + N_GIANT, STRIDE) uint16, cached at `path` (a few seconds of integer arithmetic the first time)."""
+    """(N_BABY + N_GIANT, ROW) uint16, cached at `path` (a few seconds of integer arithmetic the first time)."""
     if not force and os.path.exists(path):
         try:
             t = np.load(path)
-            if t.shape == (N_BABY + N_GIANT, STRIDE) and t.dtype == np.uint16:
+            if t.shape == (N_BABY + N_GIANT, ROW) and t.dtype == np.uint16:
                 return t
         except Exception:
             pass
@@ -231,7 +221,7 @@ def _check_layout():
         from . import _lib
         out = (ctypes.c_int * 8)()
         _lib.call("dasp_mt_layout", out)
-        want = [BLOCKS_PER_CHUNK, N_BABY, N_GIANT, SLOT, STRIDE, PAD_INDEX, MAX_CHUNKS, 0]
+        want = [BLOCKS_PER_CHUNK, N_BABY, N_GIANT, GROUP, ROW, PAD_INDEX, MAX_CHUNKS, 0]
         if list(out) != want:
             raise _lib.DaspHipError(f"jump-table layout of libdasp_hip.so {list(out)} != _mt19937.py {want}")
         _layout_checked = True

@@ -28,21 +28,23 @@ namespace {
 constexpr int MT_N = 624, MT_M = 397;
 constexpr int MT_BLOCKS_PER_CHUNK = 256;               // ... or twice that for large draws (mt_plan: `stride` = 2), from the same table
 constexpr int MT_N_BABY = 255, MT_N_GIANT = 7;
-constexpr int MT_SLOT = 10112, MT_STRIDE = 8 + 2 * MT_SLOT;     // list slot per parity class: 79 batches of 128 exponents
+constexpr int MT_GROUP = 16;                           // exponents per group of a jump polynomial: one uint16 of coefficient bits
+constexpr int MT_N_GROUPS = (19937 + MT_GROUP - 1) / MT_GROUP;     // 1,247
+constexpr int MT_ROW = 1280;                           // uint16 per polynomial in the table (the groups, padded with zeros)
 constexpr int MT_PAD_INDEX = 20560;                    // = 19937 + 623: the sequence window of one jump
-constexpr int MT_SEQ_LDS = MT_PAD_INDEX + 648;         // + zeros behind it: list padding reads them (base PAD_INDEX, lanes to 2*319+1)
-constexpr int MT_JUMP_LANES = 320;                     // 313 lanes own two state words each (one more for the odd class's neighbour word)
-#ifndef DASP_MT_SLICES
-#define DASP_MT_SLICES 3
-#endif
-constexpr int MT_JUMP_SLICES = DASP_MT_SLICES;         // slices of 320 lanes share the exponent lists (batch b goes to slice b % SLICES)
-constexpr int MT_JUMP_THREADS = MT_JUMP_SLICES * MT_JUMP_LANES;
+constexpr int MT_SEQ_LDS = MT_PAD_INDEX + 648;         // + zeros behind it (the last lanes' spans reach 20,592)
+constexpr int MT_SPAN_L = 10;                          // state words per lane of a jumping wave: 63 lanes hold the 624
+constexpr int MT_JUMP_THREADS = 1024;                  // 16 waves, each a whole copy of the state for its share of the groups
 #ifndef DASP_MT_GEN_WAVES
 #define DASP_MT_GEN_WAVES 8
 #endif
 constexpr int MT_GEN_THREADS = 64 * DASP_MT_GEN_WAVES;   // one regenerating wave + seven Box-Muller waves (12 / 16 waves: no faster)
 constexpr int MT_STEP = 224;                           // new words per regeneration step: a multiple of 16 not above 227
 constexpr int MT_RING = 16384;                         // raw-word ring of a generating workgroup: 73 steps of 224 words; 64 KiB: byte offsets wrap as 16-bit sums
+#ifndef DASP_MT_CHUNKS_TARGET
+#define DASP_MT_CHUNKS_TARGET 256
+#endif
+constexpr int MT_CHUNKS_TARGET = DASP_MT_CHUNKS_TARGET;   // chunks of a large draw: one per CU (512, two per CU, measured slower: profiles/r06/README.md)
 #ifndef DASP_MT_PROBE
 #define DASP_MT_PROBE 0                              // timing probes of the generation kernel (scripts/mtprobe_build.sh): 1 no Box-Muller work, 2 no stores, 3 no priority
 #endif
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __res
 // CUs (each takes every parts-th batch of the exponent lists; blockIdx = jump * parts + part).
 __global__ void __launch_bounds__(MT_JUMP_THREADS)
 mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks, int parts, int stride) {
-    extern __shared__ unsigned seq[];
+    extern __shared__ __attribute__((aligned(16))) unsigned seq[];
     const int tid = threadIdx.x, job = blockIdx.x / parts, part = blockIdx.x % parts;
     unsigned* giants = states + (size_t)n_chunks * MT_N;
     const unsigned* src;
@@ -108,55 +110,47 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
         __syncthreads();
     }
 
-    // The exponent lists: 128 exponents (64 dwords) per wave and batch, one dword per lane (vector memory: its counter is not the
-    // LDS's - as scalar loads the list put one L2 round trip into every group of eight reads: 187 us per jump), handed to the whole
-    // wave lane by lane (v_readlane). Two halves of 320 lanes take alternate batches: ten waves hide the LDS latency better than five,
-    // the LDS bandwidth is the same. Lanes 313 .. 319 of a half run along on zeros and garbage inside the padded window.
-    const unsigned* row = reinterpret_cast<const unsigned*>(table + (size_t)poly * MT_STRIDE);
-    const int half = __builtin_amdgcn_readfirstlane(tid / MT_JUMP_LANES), t = tid % MT_JUMP_LANES, lane = tid & 63;      // 320 lanes = five whole waves
-    unsigned e0 = 0u, e1 = 0u, o0 = 0u, o1 = 0u;
-    const uint2* win = reinterpret_cast<const uint2*>(seq) + t;                  // words 2 t, 2 t + 1 of the window at exponent 0
-#define MT_ACC(a0, a1, word, sub)                                                              \
-    { const uint2 v0 = win[(((word) & 0xFFFFu) - (sub)) >> 1], v1 = win[(((word) >> 16) - (sub)) >> 1]; \
-      a0 ^= v0.x ^ v1.x; a1 ^= v0.y ^ v1.y; }
-#define MT_CLASS(a0, a1, list, count, sub)                                                     \
-    { const unsigned* lp = (list);                                                             \
-      const int nb = (int)(count) / 128;                                                       \
-      const int first = MT_JUMP_SLICES * part + half, step = MT_JUMP_SLICES * parts;           \
-      if (first < nb) {                                                                        \
-          unsigned nxt = lp[64 * first + lane];                                                \
-          for (int bt = first; bt < nb; bt += step) {                                          \
-              const unsigned cur = nxt;                                                        \
-              nxt = lp[64 * (bt + step < nb ? bt + step : bt) + lane];    /* the next batch, asked for before this batch's reads */ \
-              _Pragma("unroll 8")                                                              \
-              for (int k = 0; k < 64; ++k) {                                                   \
-                  const unsigned w = __builtin_amdgcn_readlane(cur, k);                        \
-                  MT_ACC(a0, a1, w, sub)                                                       \
-              }                                                                                \
-          }                                                                                    \
-      } }
-    MT_CLASS(e0, e1, row + 4, row[0], 0u)
-    MT_CLASS(o0, o1, row + 4 + MT_SLOT / 2, row[1], 1u)                          // odd exponent i: the aligned pair one word below
-#undef MT_CLASS
-#undef MT_ACC
-    // fold the halves, then: word 2 t = even sum + the odd class's UPPER word of this lane; word 2 t + 1 = even sum + the odd class's
-    // LOWER word of lane t + 1
+    // new[k] = XOR over the set coefficients i of x[i + k], k = 0 .. 623. Every wave holds the whole sum for its share of the groups of
+    // 16 exponents: lane l the ten words k = 10 l .. 10 l + 9. For a group 16 g .. 16 g + 15 the lane reads the 26 words from 16 g + 10 l
+    // on ONCE (13 aligned 8-byte reads; lane stride 40 bytes: no bank conflict inside a half wave) and every set exponent 16 g + s is
+    // ten XORs of registers s .. s + 9 - behind a scalar branch on the group's coefficient bits (the polynomial is a bit mask in the
+    // table: 2.5 KB). Per exponent that is ~6.5 bytes of LDS per lane where a read per exponent and two-word lane was 8 for two words,
+    // and no address arithmetic: the jump was 127 us of LDS reads and address instructions, see profiles/r06/README.md.
+    // The groups' bits come by one vector load per lane (lane j: the wave's j-th and (64 + j)-th group) and go round by v_readlane.
+    const int lane = tid & 63, n_waves = (MT_JUMP_THREADS / 64) * parts, wave = part * (MT_JUMP_THREADS / 64) + (tid >> 6);
+    const unsigned short* row = table + (size_t)poly * MT_ROW;
+    const int g_lo = wave + lane * n_waves, g_hi = wave + (64 + lane) * n_waves;
+    const unsigned bits_lo = g_lo < MT_N_GROUPS ? row[g_lo] : 0u, bits_hi = g_hi < MT_N_GROUPS ? row[g_hi] : 0u;
+    unsigned acc[MT_SPAN_L];
+#pragma unroll
+    for (int j = 0; j < MT_SPAN_L; ++j) acc[j] = 0u;
+    const unsigned long long* lane_base = reinterpret_cast<const unsigned long long*>(seq) + (MT_SPAN_L / 2) * lane;
+    for (int k = 0, g = wave; g < MT_N_GROUPS; ++k, g += n_waves) {
+        const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)(k < 64 ? bits_lo : bits_hi), k & 63);
+        if (bits == 0u) continue;
+        const unsigned long long* p = lane_base + (MT_GROUP / 2) * g;
+        unsigned span[MT_GROUP + MT_SPAN_L];
+#pragma unroll
+        for (int r = 0; r < (MT_GROUP + MT_SPAN_L) / 2; ++r) { const unsigned long long v = p[r]; span[2 * r] = (unsigned)v; span[2 * r + 1] = (unsigned)(v >> 32); }
+#pragma unroll
+        for (int e = 0; e < MT_GROUP; ++e)
+            if (bits & (1u << e)) {
+#pragma unroll
+                for (int j = 0; j < MT_SPAN_L; ++j) acc[j] ^= span[e + j];
+            }
+    }
+    // fold the waves' sums through the LDS (the window is done with)
     __syncthreads();
-    if (half > 0) { unsigned* d = seq + 4 * ((half - 1) * MT_JUMP_LANES + t); d[0] = e0; d[1] = e1; d[2] = o0; d[3] = o1; }
+    if (lane < 63) {
+#pragma unroll
+        for (int j = 0; j < MT_SPAN_L; ++j) seq[(tid >> 6) * 640 + MT_SPAN_L * lane + j] = acc[j];
+    }
     __syncthreads();
-    if (half == 0)
-        for (int h = 1; h < MT_JUMP_SLICES; ++h) {
-            const unsigned* d = seq + 4 * ((h - 1) * MT_JUMP_LANES + t);
-            e0 ^= d[0]; e1 ^= d[1]; o0 ^= d[2]; o1 ^= d[3];
-        }
-    __syncthreads();
-    if (half == 0) seq[t] = o0;
-    __syncthreads();
-    if (half == 0 && t < MT_N / 2) {
-        unsigned* out = dst + 2 * t;
-        const unsigned w0 = e0 ^ o1, w1 = e1 ^ seq[t + 1];
-        if (parts == 1) { out[0] = w0; out[1] = w1; }
-        else { atomicXor(out, w0); atomicXor(out + 1, w1); }
+    for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) {
+        unsigned v = 0u;
+#pragma unroll
+        for (int w = 0; w < MT_JUMP_THREADS / 64; ++w) v ^= seq[w * 640 + k];
+        if (parts == 1) dst[k] = v; else atomicXor(dst + k, v);
     }
 }
 
@@ -413,7 +407,7 @@ MtPlan mt_plan(int left, long long n) {
     // instruction issue) and no less per unit when several share it. (128,2,262144) (1,280 units): 640 chunks of 2 units were 31 + 436
     // us of jumps and 322 us of generation, 256 chunks of 5 units: see profiles/r06/README.md.
     const long long units = (p.beta_max + MT_BLOCKS_PER_CHUNK - 1) / MT_BLOCKS_PER_CHUNK;
-    p.stride = units > 256 ? (int)((units + 255) / 256) : 1;
+    p.stride = units > MT_CHUNKS_TARGET ? (int)((units + MT_CHUNKS_TARGET - 1) / MT_CHUNKS_TARGET) : 1;
     const long long bpc = (long long)MT_BLOCKS_PER_CHUNK * p.stride;
     p.n_chunks = p.beta_max == 0 ? 1 : (int)((p.beta_max + bpc - 1) / bpc);
     return p;
@@ -429,7 +423,7 @@ extern "C" {
 // {blocks per chunk, baby polynomials, giant polynomials, list slot, row stride (uint16), pad exponent, max chunks per call, 0}
 int dasp_mt_layout(int* out8) {
     if (!out8) return DASP_ERR_ARG;
-    const int v[8] = {MT_BLOCKS_PER_CHUNK, MT_N_BABY, MT_N_GIANT, MT_SLOT, MT_STRIDE, MT_PAD_INDEX, (MT_N_GIANT + 1) * (MT_N_BABY + 1), 0};
+    const int v[8] = {MT_BLOCKS_PER_CHUNK, MT_N_BABY, MT_N_GIANT, MT_GROUP, MT_ROW, MT_PAD_INDEX, (MT_N_GIANT + 1) * (MT_N_BABY + 1), 0};
     for (int i = 0; i < 8; ++i) out8[i] = v[i];
     return DASP_OK;
 }
@@ -474,14 +468,13 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
             if (dev >= 0 && dev < 64) asked[dev].store(true, std::memory_order_release);
         }
     }
-    // Several workgroups per jump where that is fewer rounds x time: a workgroup with 1/k of a jump's exponents takes ~16 + 127 / k us (the
-    // window it regenerates first is the 16), one workgroup per CU at a time (83 KiB of LDS): 79 jumps three ways are one round of 58 us
-    // against 143, 160 jumps three ways two rounds (117 against 143), 255 jumps stay whole.
+    // Several workgroups per jump where that is fewer rounds x time: a workgroup with 1/k of a jump's groups takes ~14.5 + 67.5 / k us (the
+    // window it regenerates first is the 14.5; measured 82 / 37 / 21 us at k = 1 / 3 / 8), one workgroup per CU at a time (83 KiB of LDS).
     auto parts_for = [](int jobs) {
         int best = 1;
         float best_t = 1e30f;
         for (int k = 1; k <= 8; ++k) {
-            const float t = (float)((jobs * k + 255) / 256) * (16.f + 127.f / (float)k);
+            const float t = (float)((jobs * k + 255) / 256) * (14.5f + 67.5f / (float)k);
             if (t < best_t - 0.5f) { best_t = t; best = k; }
         }
         return best;

@@ -9,14 +9,17 @@ from dasp_pytorch_amd import _mt19937 as mt
 from oracle import mt_stream as ms
 
 
+def _exponents(g_row):
+    """The set coefficients of a table row (bit s of uint16 k = the coefficient of t^(16 k + s))."""
+    bits = np.unpackbits(np.ascontiguousarray(g_row, dtype="<u2").view(np.uint8), bitorder="little")
+    return np.nonzero(bits)[0].astype(np.int64)
+
+
 def _apply(g_row, seq, start):
-    """state[w] = XOR over the listed exponents i of seq[start + i + w], as the kernel sums it (zeros behind the window)."""
-    n_even, n_odd = g_row[:4].view(np.uint32)[:2]
-    idx = np.concatenate([g_row[8:8 + n_even], g_row[8 + mt.SLOT:8 + mt.SLOT + n_odd]]).astype(np.int64)
-    idx = idx[idx < mt.PAD_INDEX]
+    """state[w] = XOR over the set exponents i of seq[start + i + w], as the kernel sums it."""
     win = seq[start:start + mt.DEG + mt.N]
     out = np.zeros(mt.N, np.uint32)
-    for i in idx:
+    for i in _exponents(g_row):
         out ^= win[i:i + mt.N]
     return out
 
@@ -44,13 +47,12 @@ def table():
 
 
 def test_jump_table_layout(table):
-    assert table.shape == (mt.N_BABY + mt.N_GIANT, mt.STRIDE) and table.dtype == np.uint16
-    for row in table[[0, 1, 100, 254, 255, 261]]:
-        n_even, n_odd = row[:4].view(np.uint32)[:2]
-        assert n_even % 128 == 0 and n_odd % 128 == 0 and n_even <= mt.SLOT and n_odd <= mt.SLOT
-        ev, od = row[8:8 + n_even], row[8 + mt.SLOT:8 + mt.SLOT + n_odd]
-        assert (ev % 2 == 0).all() and (od % 2 == 1).all()
-        assert (ev[ev < mt.PAD_INDEX] < mt.DEG).all() and (od[od < mt.PAD_INDEX] < mt.DEG).all()
+    assert table.shape == (mt.N_BABY + mt.N_GIANT, mt.ROW) and table.dtype == np.uint16
+    assert mt.GROUP * mt.ROW >= mt.DEG and mt.PAD_INDEX == mt.DEG + mt.N - 1
+    for row, g in zip(table[[0, 1, 100, 254, 255, 261]], [mt.jump_polynomials()[i] for i in (0, 1, 100, 254, 255, 261)]):
+        ex = _exponents(row)
+        assert ex.max() < mt.DEG and 3000 < len(ex) < 11000
+        assert sum(1 << int(e) for e in ex) == g
 
 
 def test_first_jump_polynomials_equal_stepping(table):
