@@ -12,13 +12,14 @@
 //           element j <- r cos a, element j + 8 <- r sin a; numel % 16 != 0: the LAST 16 elements are recomputed from 16 more draws.
 //
 // How it is made parallel. The twister is linear over GF(2): x[n + J] = XOR over the set coefficients i of g_J(t) = t^J mod p(t) of
-// x[n + i] (p: the characteristic polynomial, degree 19937; host side _mt19937.py). A CHUNK is 256 regenerations (159,744 words) and
-// one workgroup of the generation kernel; the start state of chunk c is the state 256 c regenerations on, which mt_jump_kernel sums
-// out of a 20,560-word window of the sequence held in LDS - from chunk 0's state for the chunks 256 a (7 "giant" polynomials, only
-// above 256 chunks) and from chunk 256 a for the 255 behind it ("baby" polynomials), all workgroups of a phase side by side. A jump is
-// ~10 k LDS reads of 8 bytes per lane (ds_read_b64: 256 B/clk/CU; lanes own two state words, coefficients split by parity so that
-// every read is 8-byte aligned): LDS-bound, ~50 us on one CU. Then every chunk regenerates its blocks 224 words per step (any 227
-// consecutive new words are independent), and Box-Muller runs on the same wave 448 words at a time. HBM: 4 B written per value.
+// x[n + i] (p: the characteristic polynomial, degree 19937; host side _mt19937.py). A UNIT is 256 regenerations (159,744 words); a
+// CHUNK is ceil(units / 256) units - at most 256 chunks, one workgroup of the generation kernel each, no CU a second one. The start
+// state of the chunk 256 a + b units on is summed by mt_jump_kernel out of a 20,560-word window of the sequence held in LDS: from
+// chunk 0's state for the 7 "giant" targets 256 a, from those by the 255 "baby" polynomials t^(b J), all workgroups of a phase side
+// by side. A jump: every wave holds the whole new state (ten words per lane), reads a 26-word span per group of 16 exponents once
+// and XORs registers behind scalar branches on the group's coefficient bits: ~82 us of a CU, fewer jumps than CUs split over up to
+// eight workgroups. Then every chunk regenerates its blocks 224 words per step (any 227 consecutive new words are independent) on ONE
+// wave whose step-to-step chain stays in registers, while seven waves turn the words into normals. HBM: 4 B written per value.
 #include <atomic>
 #include "common.hpp"
 
@@ -26,7 +27,7 @@ namespace dasp {
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
-constexpr int MT_BLOCKS_PER_CHUNK = 256;               // ... or twice that for large draws (mt_plan: `stride` = 2), from the same table
+constexpr int MT_BLOCKS_PER_CHUNK = 256;               // regenerations per unit; a chunk is `stride` units (mt_plan)
 constexpr int MT_N_BABY = 255, MT_N_GIANT = 7;
 constexpr int MT_GROUP = 16;                           // exponents per group of a jump polynomial: one uint16 of coefficient bits
 constexpr int MT_N_GROUPS = (19937 + MT_GROUP - 1) / MT_GROUP;     // 1,247

@@ -468,7 +468,8 @@ int dasp_ew64_backward(int op, const double* x, const double* ctl, const double*
  * (csrc/mtrand.hip; host side - state parsing, jump-ahead table - dasp_pytorch_amd/_mt19937.py).
  *   state_host: the 624 words of the generator (host memory, read during the call);  left: its `left` field (1..624);
  *   out: n >= 16 floats (device);  table: the (262, row stride) uint16 jump table on the device, laid out as dasp_mt_layout says
- *   (out8 = {blocks per chunk, baby polynomials, giant polynomials, list slot, row stride, pad exponent, max chunks per call, 0});
+ *   (out8 = {regenerations per unit, baby polynomials, giant polynomials, exponents per uint16 (bit s of word k of a row = the
+ *   coefficient of t^(16 k + s)), row stride, window length, max units per call, 0});
  *   scratch: dasp_mt_scratch_words(left, n) 32-bit words (device); after the stream has run, words [*final_state_offset_words, + 624)
  *   hold the generator's words after the draw (when *regenerated != 0; else they are unchanged and not written) and *left_after its
  *   `left`. One call takes at most dasp_mt_max_values() values (a caller with more loops over pieces that are multiples of 16).

@@ -12,7 +12,9 @@ for b in 8 128; do
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/scripts/mtrand_time.py $b > /dev/null 2>> $GRAFT_REPO_ROOT/$out/rprof.err )
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/mtrand_kernel_stats_b$b.csv; rm -rf $out/rprof
 done
-timeout 300 python scripts/mtrand_time.py 8 16 64 128 2>/dev/null | tail -4 > $out/mtrand_time.log
+timeout 300 python scripts/mtrand_time.py 8 16 32 64 128 2>/dev/null | tail -5 > $out/mtrand_time.log
+BS="8 16 128" bash scripts/mtrand_trace.sh > $out/mtrand_timeline.log 2>&1
+[ -x tools/ubench6 ] && timeout 60 tools/ubench6 > $out/ubench6.log 2>&1
 ( cd /tmp && DASP_RV_NOISE=generated rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rprof -o p -- python $GRAFT_REPO_ROOT/scripts/reverb_time.py 128 2 262144 > /dev/null 2>> $GRAFT_REPO_ROOT/$out/rprof.err )
 cp $(find $out/rprof -name "*kernel_stats.csv" | head -1) $out/reverb_kernel_stats.csv; rm -rf $out/rprof
 timeout 300 python scripts/seg_gram_ab.py 2>/dev/null | tail -1 > $out/small_batch_steps.log
