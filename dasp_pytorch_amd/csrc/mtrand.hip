@@ -47,7 +47,10 @@ constexpr int MT_RING = 16384;                         // raw-word ring of a gen
 #endif
 constexpr int MT_CHUNKS_TARGET = DASP_MT_CHUNKS_TARGET;   // chunks of a large draw: one per CU (512, two per CU, measured slower: profiles/r06/README.md)
 #ifndef DASP_MT_PROBE
-#define DASP_MT_PROBE 0                              // timing probes of the generation kernel (scripts/mtprobe_build.sh): 1 no Box-Muller work, 2 no stores, 3 no priority
+#define DASP_MT_PROBE 0                              // timing probes of the generation kernel (scripts/mtprobe_build.sh): 1 no Box-Muller work, 2 no stores, 3 no priority, 4 no Box-Muller wave on the regenerating wave's SIMD
+#endif
+#ifndef DASP_MT_SKIP
+#define DASP_MT_SKIP 0                               // timing probes of the regenerating wave: leave out 1 the write, 2 lane 0's read, 4 the x[k-624] read, 8 the twists, 16 the chain
 #endif
 #ifndef DASP_MT_UNIT
 #define DASP_MT_UNIT 4
@@ -59,10 +62,16 @@ struct MtState { unsigned w[MT_N]; };                  // 2,496 bytes: travels a
 __device__ __forceinline__ unsigned mt_twist(unsigned u, unsigned v) {
     return (((u & 0x80000000u) | (v & 0x7FFFFFFFu)) >> 1) ^ ((v & 1u) ? 0x9908B0DFu : 0u);
 }
+// a ^ (b & c) in one instruction (the compiler takes it for register masks only; the tempering masks are literals)
+__device__ __forceinline__ unsigned mt_xor_and(unsigned a, unsigned b, unsigned mask) {
+    unsigned r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x78" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     y ^= y >> 11;
-    y ^= (y << 7) & 0x9D2C5680u;
-    y ^= (y << 15) & 0xEFC60000u;
+    y = mt_xor_and(y, y << 7, 0x9D2C5680u);
+    y = mt_xor_and(y, y << 15, 0xEFC60000u);
     y ^= y >> 18;
     return y;
 }
@@ -175,10 +184,10 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
     const float z = r * r;
     const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
     const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.f));
-    const int q = (int)k;
-    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
+    const unsigned q = (unsigned)(int)k;
+    const float ss = (q & 1u) ? cp : sp, cc = (q & 1u) ? sp : cp;
+    s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ss) ^ ((q << 30) & 0x80000000u));          // quadrants 2, 3: -sin
+    c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cc) ^ (((q + 1u) << 30) & 0x80000000u));   // quadrants 1, 2: -cos
 }
 
 // One chunk: blocks 256 c + 1 .. of the sequence from states[c] (block 256 c), every aligned group of 16 draws whose last word lies
@@ -187,18 +196,20 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
 //
 // A pipeline inside the workgroup, no barrier in the loop. Wave 0 regenerates: steps of 224 words (any 227 consecutive new words are
 // independent), four consecutive words per lane, into a ring of 16,384 words in the LDS. The serial chain of the chunk never touches
-// the LDS: a step's x[k - 227] words are the previous step's output one lane over (wave shifts), its x[k - 624] side was read from the
-// ring a step ahead. What is left is ONE wave's instruction issue: 33 instructions per step at ~7.7 cycles each (a lone wave issues an
-// independent vector instruction every 5.5 cycles, a dependent one every 8.6, a 16-byte LDS write costs it ~30: tools/ubench6.hip).
-// After every unit of MT_UNIT steps the wave publishes how far the sequence reaches (`avail`). Waves 1-7 turn units into normals: each
-// claims the next unit from a counter (the wave that shares its SIMD with the regenerating one simply claims fewer), waits for `avail`,
-// reads the unit's words (two per pair: 448 pairs = seven full passes of the wave), Box-Muller, stores, and publishes the unit it is at
-// (`cur`); the regenerating wave stays at most MT_LEAD steps ahead of the slowest of them. It also runs up to MT_UNIT - 1 steps past
-// the chunk's end: valid words nobody reads.
+// the LDS: a step's x[k - 227] words are the previous step's output one lane over (a rotation of the wave), its x[k - 624] side was
+// read from the ring a step ahead. What is left is ONE wave's instruction issue: 30 instructions per step at ~6.5 cycles each (a lone
+// wave issues an independent vector instruction every 5.5 cycles, a dependent one every 8.6, a 16-byte LDS write costs it 26:
+// tools/ubench6.hip, ubench7.hip). After every unit of MT_UNIT steps the wave publishes how far the sequence reaches (`avail`). Waves
+// 1-7 turn units into normals: each claims the next unit from a counter (the wave that shares its SIMD with the regenerating one
+// simply claims fewer), waits for `avail`, reads the unit's words (two per pair: 448 pairs = seven full passes of the wave),
+// Box-Muller, stores, and publishes the unit it is at (`cur`); the regenerating wave stays at most MT_LEAD steps ahead of the slowest
+// of them. It also runs up to MT_UNIT - 1 steps past the chunk's end: valid words nobody reads.
 // History (profiles/r06/README.md), per chunk of 256 regenerations: every wave doing everything between barriers 235 us; four
 // regenerating and four Box-Muller waves with two barriers per 448 words 165 us (the regeneration with its barriers alone: 125);
 // this pipeline with the chain through the LDS 136 us dealt out in turn, 88 us with claimed units (the regenerating wave alone: 82, an
-// LDS round trip per step); the chain in registers 85; nothing in the loop waiting for the LDS and 16-bit address sums 78.
+// LDS round trip per step); the chain in registers 85; x[k - 624] side asked for a step ahead, 16-bit address sums 78; lane 0's words
+// by the rotation instead of an LDS read and - the larger part - the wait moved in front of the step's write (the LDS counter is in
+// order: behind the write it waited for the write, 64 cycles per step) 71 (the regenerating wave alone 63, without the stores 65).
 // Every wait is bounded: a wave that polls 2^22 times gives up and the output starts with a NaN (it cannot happen: the eight waves of a
 // workgroup are resident together).
 typedef unsigned mt_u32x4 __attribute__((ext_vector_type(4)));
@@ -213,18 +224,31 @@ template <int OUTSTANDING> __device__ __forceinline__ void mt_lds_wait(mt_u32x4&
 // byte offsets into the 64 KiB ring wrap as 16-bit sums: one instruction (a 16-bit add clears the upper half of its result on this chip)
 template <int C> __device__ __forceinline__ unsigned mt_add16(unsigned a) { return (a + (unsigned)C) & 0xFFFFu; }
 // One statement for a step's LDS traffic (between separate asm statements the compiler puts a wait state): write w at a, advance a
-// by ADV, read 16 bytes at the new a + C1 into r1 and at the new a + C2 into r2. r1 and r2 are read-write operands: the registers of
-// values in flight stay the variables' registers from step to step (a copy of one before its wait would copy what was there before).
-template <int ADV, int C1, int C2>
-__device__ __forceinline__ void mt_ring_write_advance_read2(unsigned& a, mt_u32x4 w, mt_u32x4& r1, mt_u32x4& r2) {
-    unsigned t1, t2;
-    asm volatile("ds_write_b128 %4, %5\n\tv_add_u16 %4, %6, %4\n\tv_add_u16 %2, %7, %4\n\tv_add_u16 %3, %8, %4\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
-                 : "+v"(r1), "+v"(r2), "=&v"(t1), "=&v"(t2), "+v"(a) : "v"(w), "n"(ADV & 0xFFFF), "n"(C1 & 0xFFFF), "n"(C2 & 0xFFFF) : "memory");
+// by ADV, read 16 bytes at the new a + C into r. r is a read-write operand: the register of a value in flight stays the variable's
+// register from step to step (a copy of one before its wait would copy what was there before).
+template <int ADV, int C>
+__device__ __forceinline__ void mt_ring_write_advance_read(unsigned& a, mt_u32x4 w, mt_u32x4& r) {
+    unsigned t;
+    asm volatile(
+#if !(DASP_MT_SKIP & 1)
+                 "ds_write_b128 %2, %3\n\t"
+#endif
+                 "v_add_u16 %2, %4, %2\n\tv_add_u16 %1, %5, %2"
+#if !(DASP_MT_SKIP & 4)
+                 "\n\tds_read_b128 %0, %1"
+#endif
+                 : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV & 0xFFFF), "n"(C & 0xFFFF) : "memory");
 }
-// lanes 1 .. 63: (the lane below's `from_below`) ^ b; lane 0 keeps `lane0` (no source for it: the instruction leaves it alone)
-__device__ __forceinline__ unsigned mt_xor_shr1(unsigned lane0, unsigned from_below, unsigned b) {
-    asm("v_xor_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(lane0) : "v"(from_below), "v"(b));
-    return lane0;
+// (lane l - 1's `from_below`) ^ b, lane 0 from lane 63 (a rotation of the whole wave)
+__device__ __forceinline__ unsigned mt_xor_ror1(unsigned from_below, unsigned b) {
+    unsigned r;
+    asm("v_xor_b32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from_below), "v"(b));
+    return r;
+}
+// lanes 60 .. 63 of `now` <- lanes 52 .. 55 of `before` (the other lanes stay)
+__device__ __forceinline__ unsigned mt_keep_tail(unsigned now, unsigned before) {
+    asm("v_mov_b32_dpp %0, %1 row_shr:8 row_mask:0x8 bank_mask:0x8" : "+v"(now) : "v"(before));
+    return now;
 }
 // twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first. 17 instructions: every word is shifted once
 // (it is the upper word of one twist and the lower word of the next), one bit-field insert per twist, the matrix row by a sign
@@ -283,10 +307,12 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
     if (wave == 0) {
         // ---- regeneration: lane l owns words q0 + 4 l .. q0 + 4 l + 3 of every step (lanes 56-63: the first 32 words of the next step's
         // slots, overwritten by that step); x[k] = x[k - 227] ^ twist(x[k - 624], x[k - 623]) ----
-        // Step v = tw(v) ^ shift(w(v - 1)): the x[k - 227] words of lane l are words 1, 2, 3 of lane l - 1's previous output and word 0 of
-        // its own - registers and wave shifts, no LDS; lane 0 takes the last three words of step v - 2 (`fix`), read from the ring two steps
-        // ahead. tw(v + 1), the twists of the x[k - 624] side, needs steps <= v - 1 only: its words are read behind step v - 1's write
-        // and twisted at the end of step v, a whole step after they were asked for. Nothing in the loop waits for the LDS.
+        // Step v = tw(v) ^ rot(z(v - 1)): the x[k - 227] words of lane l are words 1, 2, 3 of lane l - 1's previous output and word 0 of
+        // its own - registers and a rotation of the wave by one lane, no LDS. Lane 0 needs the last three words of step v - 2 (lane 55's):
+        // z(v) is w(v) with lanes 60 .. 63 replaced by lanes 52 .. 55 of z(v - 1), so that lane 63, where the rotation fetches lane 0's
+        // words, holds lane 55's of a step earlier. tw(v + 1), the twists of the x[k - 624] side, needs steps <= v - 1 only: its words are
+        // read behind step v - 1's write and twisted at the end of step v, a whole step after they were asked for. Nothing in the loop
+        // waits for the LDS; per step one 16-byte write and one 16-byte read.
 #if DASP_MT_PROBE != 3
         __builtin_amdgcn_s_setprio(3);                                         // the chain goes first on the SIMD it shares with a Box-Muller wave
 #endif
@@ -294,14 +320,13 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
         if ((unsigned)(unsigned long long)ring != 0u) __builtin_trap();
         static_assert(4 * MT_RING == 65536, "the regenerating wave's addresses are 16-bit sums");
         unsigned q_b = 4u * (MT_N + 4 * lane);                                 // byte offset (wrapped) of the lane's first word of the step
-        mt_u32x4 A[2], F[2];                                                   // x[k - 624] side / lane 0's three words of steps of this parity
+        mt_u32x4 A[2];                                                         // the x[k - 624] side of the steps of either parity
         mt_u32x4 a1 = mt_lds_read128(mt_add16<-4 * MT_N>(q_b));                // step 1: x[4 l .. 4 l + 3]
-        mt_u32x4 wp = mt_lds_read128(mt_add16<-4 * MT_STEP>(q_b));             // "step 0": the last 224 words of the start state
-        F[1] = mt_lds_read128(mt_add16<-4 * MT_STEP - 16>(q_b));               // lane 0, step 1: the three words below those
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(wp), "+v"(F[1]) :: "memory");
+        // "step 0": the last 224 words of the start state; lane 63: the four words below them (lane 0's, as lane 55 of "step -1" would hold them)
+        mt_u32x4 z = mt_lds_read128(lane == 63 ? 4u * (MT_N - MT_STEP - 4) : mt_add16<-4 * MT_STEP>(q_b));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(z) :: "memory");
         mt_u32x4 tw = mt_twist4(a1);
-        F[0] = mt_lds_read128(mt_add16<-16>(q_b));                             // step 2's (both inside the start state)
-        A[0] = mt_lds_read128(mt_add16<4 * MT_STEP - 4 * MT_N>(q_b));
+        A[0] = mt_lds_read128(mt_add16<4 * MT_STEP - 4 * MT_N>(q_b));          // step 2's (inside the start state)
         A[1] = A[0];                                                           // (defined; refilled in step 1)
         int cleared = 0;                                                       // every step <= cleared has been read
         static_assert(MT_UNIT % 2 == 0, "the registers of steps of one parity alternate inside a unit");
@@ -320,23 +345,36 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
 #pragma unroll
             for (int sub = 0; sub < MT_UNIT; ++sub) {                          // step v = MT_UNIT u + sub + 1, parity p
                 const int p = (sub + 1) & 1;
-                mt_u32x4 w;                                                    // lane 0 from F, the others from the lane below (wave_shr:1 leaves lane 0 alone)
-                w.x = mt_xor_shr1(tw.x ^ F[p].y, wp.y, tw.x);
-                w.y = mt_xor_shr1(tw.y ^ F[p].z, wp.z, tw.y);
-                w.z = mt_xor_shr1(tw.z ^ F[p].w, wp.w, tw.z);
-                w.w = tw.w ^ wp.x;
-                // the write; behind it lane 0's three words for step v + 2 (the end of this step) and step v + 2's x[k - 624] side
-                mt_ring_write_advance_read2<4 * MT_STEP, -16, 4 * MT_STEP - 4 * MT_N>(q_b, w, F[p], A[p]);
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(F[p ^ 1]), "+v"(A[p ^ 1]) :: "memory");   // step v + 1's: asked for a step ago
+                mt_u32x4 w;
+#if DASP_MT_SKIP & 16
+                w = tw;
+#else
+                w.x = mt_xor_ror1(z.y, tw.x);
+                w.y = mt_keep_tail(mt_xor_ror1(z.z, tw.y), z.y);
+                w.z = mt_keep_tail(mt_xor_ror1(z.w, tw.z), z.z);
+                w.w = mt_keep_tail(tw.w ^ z.x, z.w);
+#endif
+                // step v + 1's x[k - 624] side: asked for a step ago. (The wait in FRONT of this step's write: the counter is in order, behind
+                // the write it would wait for the write as well - 64 cycles per step, found with probe builds.)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[p ^ 1]) :: "memory");
+                // the write (lanes 56 .. 63 write into the next step's slots, which that step overwrites); behind it step v + 2's x[k - 624] side
+                mt_ring_write_advance_read<4 * MT_STEP, 4 * MT_STEP - 4 * MT_N>(q_b, w, A[p]);
+#if DASP_MT_SKIP & 8
+                tw = A[p ^ 1];
+#else
                 tw = mt_twist4(A[p ^ 1]);
-                wp = w;
+#endif
+                z = w;
             }
             if (lane == 0) mt_lds_write32(4u * MT_RING, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(F[0]), "+v"(F[1]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]) :: "memory");
     } else {
         // ---- Box-Muller ----
         const int cj = wave - 1;
+#if DASP_MT_PROBE == 4
+        if (wave == 4) { if (lane == 0) cur[cj] = 1 << 28; } else
+#endif
         for (;;) {
             int u = 0;
             if (lane == 0) u = __hip_atomic_fetch_add(&next_unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -356,19 +394,19 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
             const int qs0 = u == 0 && c == 0 ? MT_N - rem : lo + (phi ? phi - 16 : 0);
             const int pairs = hi >= qs0 + 16 ? ((hi - qs0) >> 4) * 8 : 0;
 #if DASP_MT_PROBE != 1
-            for (int p = lane; p < pairs; p += 64) {
-                const int qa = qs0 + 16 * (p >> 3) + (p & 7);
-                const long long i = draw0 + qa;
-                if ((i >> 4) < n_groups) {
-                    const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
-                    const float rad = mt_radius(ua);
-                    float sn, co;
-                    mt_sincos(6.283185307179586f * ub, sn, co);
+            // (every unit but the tensor's last lies wholly inside the tensor: no test per pair, and 32-bit offsets from the unit's first draw)
+            float* __restrict__ o = out + (draw0 + qs0);
+            const int pairs_in = (int)((n_groups - ((draw0 + qs0) >> 4) < (long long)(pairs >> 3) ? n_groups - ((draw0 + qs0) >> 4) : (long long)(pairs >> 3)) * 8);
+            for (int p = lane; p < pairs_in; p += 64) {
+                const int rel = 16 * (p >> 3) + (p & 7), qa = qs0 + rel;
+                const float ua = mt_uniform(ring[qa & (MT_RING - 1)]), ub = mt_uniform(ring[(qa + 8) & (MT_RING - 1)]);
+                const float rad = mt_radius(ua);
+                float sn, co;
+                mt_sincos(6.283185307179586f * ub, sn, co);
 #if DASP_MT_PROBE == 2
-                    if (rad * co + rad * sn == 123.456f)
+                if (rad * co + rad * sn == 123.456f)
 #endif
-                    { out[i] = rad * co; out[i + 8] = rad * sn; }
-                }
+                { o[rel] = rad * co; o[rel + 8] = rad * sn; }
             }
 #endif
             if ((n & 15) && lane < 16) {                                       // the 16 draws behind the tensor: kept as uniforms for mt_tail_kernel
