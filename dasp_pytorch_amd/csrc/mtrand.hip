@@ -84,6 +84,106 @@ __global__ void __launch_bounds__(640) mt_seed_kernel(MtState s, unsigned* __res
     for (size_t k = MT_N + (size_t)(blockIdx.x - 1) * 640 + threadIdx.x; k < (size_t)n_states * MT_N; k += (size_t)(gridDim.x - 1) * 640) states[k] = 0u;
 }
 
+// ---- the regeneration chain of one wave (mt_generate_kernel, whose comments explain it, and the window of mt_jump_kernel) ----
+typedef unsigned mt_u32x4 __attribute__((ext_vector_type(4)));
+// LDS accesses of the regenerating wave, written out: their order on the LDS queue and the waits are the algorithm there. (The compiler
+// does not know that a register is in flight between a read and its wait: every use sits behind the wait through the "+v" operands.)
+__device__ __forceinline__ mt_u32x4 mt_lds_read128(unsigned addr) { mt_u32x4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory"); return r; }
+__device__ __forceinline__ void mt_lds_write128(unsigned addr, mt_u32x4 w) { asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
+__device__ __forceinline__ void mt_lds_write32(unsigned addr, unsigned w) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
+template <int OUTSTANDING> __device__ __forceinline__ void mt_lds_wait(mt_u32x4& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(OUTSTANDING) : "memory");
+}
+// byte offsets into the 64 KiB ring wrap as 16-bit sums: one instruction (a 16-bit add clears the upper half of its result on this chip)
+template <int C> __device__ __forceinline__ unsigned mt_add16(unsigned a) { return (a + (unsigned)C) & 0xFFFFu; }
+// One statement for a step's LDS traffic (between separate asm statements the compiler puts a wait state): write w at a, advance a
+// by ADV, read 16 bytes at the new a + C into r. r is a read-write operand: the register of a value in flight stays the variable's
+// register from step to step (a copy of one before its wait would copy what was there before).
+template <int ADV, int C, bool WRAP16>
+__device__ __forceinline__ void mt_ring_write_advance_read(unsigned& a, mt_u32x4 w, mt_u32x4& r) {
+    unsigned t;
+    if (WRAP16)
+        asm volatile(
+#if !(DASP_MT_SKIP & 1)
+                     "ds_write_b128 %2, %3\n\t"
+#endif
+                     "v_add_u16 %2, %4, %2\n\tv_add_u16 %1, %5, %2"
+#if !(DASP_MT_SKIP & 4)
+                     "\n\tds_read_b128 %0, %1"
+#endif
+                     : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV & 0xFFFF), "n"(C & 0xFFFF) : "memory");
+    else
+        asm volatile("ds_write_b128 %2, %3\n\tv_add_u32 %2, %4, %2\n\tv_add_u32 %1, %5, %2\n\tds_read_b128 %0, %1"
+                     : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV), "n"(C) : "memory");
+}
+// (lane l - 1's `from_below`) ^ b, lane 0 from lane 63 (a rotation of the whole wave)
+__device__ __forceinline__ unsigned mt_xor_ror1(unsigned from_below, unsigned b) {
+    unsigned r;
+    asm("v_xor_b32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from_below), "v"(b));
+    return r;
+}
+// lanes 60 .. 63 of `now` <- lanes 52 .. 55 of `before` (the other lanes stay)
+__device__ __forceinline__ unsigned mt_keep_tail(unsigned now, unsigned before) {
+    asm("v_mov_b32_dpp %0, %1 row_shr:8 row_mask:0x8 bank_mask:0x8" : "+v"(now) : "v"(before));
+    return now;
+}
+// twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first. 17 instructions: every word is shifted once
+// (it is the upper word of one twist and the lower word of the next), one bit-field insert per twist, the matrix row by a sign
+// extension of bit 0 and one three-operand bit operation.
+__device__ __forceinline__ unsigned mt_bfi(unsigned mask, unsigned from_set, unsigned from_clear) {
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(from_set), "v"(from_clear));
+    return r;
+}
+__device__ __forceinline__ mt_u32x4 mt_twist4(mt_u32x4 a) {
+    const unsigned a4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane l reads lane l + 1
+    const unsigned s0 = a.x >> 1, s1 = a.y >> 1, s2 = a.z >> 1, s3 = a.w >> 1, s4 = a4 >> 1;
+    mt_u32x4 t;                                        // ((u & 0x80000000 | v & 0x7fffffff) >> 1) ^ (v & 1 ? 0x9908b0df : 0)
+    t.x = mt_bfi(0x3FFFFFFFu, s1, s0) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.y, 0, 1) & 0x9908B0DFu);
+    t.y = mt_bfi(0x3FFFFFFFu, s2, s1) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.z, 0, 1) & 0x9908B0DFu);
+    t.z = mt_bfi(0x3FFFFFFFu, s3, s2) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.w, 0, 1) & 0x9908B0DFu);
+    t.w = mt_bfi(0x3FFFFFFFu, s4, s3) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a4, 0, 1) & 0x9908B0DFu);
+    return t;
+}
+
+// One regeneration step of the wave that owns the chain (mt_generate_kernel's comments): w(v) = tw(v) ^ rot(z(v - 1)) written at q_b,
+// step v + 2's x[k - 624] side asked for into a_refill, tw(v + 1) from a_ready (asked for a step ago). WRAP16: q_b wraps at 64 KiB.
+template <bool WRAP16>
+__device__ __forceinline__ void mt_regen_step(unsigned& q_b, mt_u32x4& z, mt_u32x4& tw, mt_u32x4& a_refill, mt_u32x4& a_ready) {
+    mt_u32x4 w;
+#if DASP_MT_SKIP & 16
+    w = tw;
+#else
+    w.x = mt_xor_ror1(z.y, tw.x);
+    w.y = mt_keep_tail(mt_xor_ror1(z.z, tw.y), z.y);
+    w.z = mt_keep_tail(mt_xor_ror1(z.w, tw.z), z.z);
+    w.w = mt_keep_tail(tw.w ^ z.x, z.w);
+#endif
+    // step v + 1's x[k - 624] side: asked for a step ago. (The wait in FRONT of this step's write: the counter is in order, behind the
+    // write it would wait for the write as well - 64 cycles per step, found with probe builds.)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_ready) :: "memory");
+    // the write (lanes 56 .. 63 write into the next step's slots, which that step overwrites); behind it step v + 2's x[k - 624] side
+    mt_ring_write_advance_read<4 * MT_STEP, 4 * MT_STEP - 4 * MT_N, WRAP16>(q_b, w, a_refill);
+#if DASP_MT_SKIP & 8
+    tw = a_ready;
+#else
+    tw = mt_twist4(a_ready);
+#endif
+    z = w;
+}
+// The start of the chain: q_b = byte address of the lane's first word of step 1 (the 624 words in front of it are the start state)
+template <bool WRAP16>
+__device__ __forceinline__ void mt_regen_start(int lane, unsigned q_b, mt_u32x4& z, mt_u32x4& tw, mt_u32x4& a0, mt_u32x4& a1) {
+    const unsigned m = WRAP16 ? 0xFFFFu : 0xFFFFFFFFu;
+    mt_u32x4 first = mt_lds_read128((q_b - 4u * MT_N) & m);                   // step 1: x[4 l .. 4 l + 3]
+    // "step 0": the last 224 words of the start state; lane 63: the four words below them (lane 0's, as lane 55 of "step -1" would hold them)
+    z = mt_lds_read128(lane == 63 ? (q_b - 4u * 4 * 63 - 4u * MT_STEP - 16u) & m : (q_b - 4u * MT_STEP) & m);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(first), "+v"(z) :: "memory");
+    tw = mt_twist4(first);
+    a0 = mt_lds_read128((q_b + 4u * MT_STEP - 4u * MT_N) & m);                // step 2's (inside the start state)
+    a1 = a0;                                                                   // (defined; refilled in step 1)
+}
+
 // One jump: dst = g(T) src. Chunk ch starts stride * ch = 256 a + b units (of 256 regenerations, J words) behind chunk 0.
 // giant: src = chunk 0, polynomial N_BABY + blockIdx (t^(256 (blockIdx + 1) J)), dst = giants[blockIdx] (behind the chunks' states);
 // baby: chunk blockIdx + 1: src = giants[a - 1] (a = 0: chunk 0), polynomial b - 1 (t^(b J)); b = 0: a copy. Word 0 of a jumped state is
@@ -113,12 +213,21 @@ mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__
     for (int k = tid; k < MT_N; k += MT_JUMP_THREADS) seq[k] = src[k];
     for (int k = MT_PAD_INDEX + tid; k < MT_SEQ_LDS; k += MT_JUMP_THREADS) seq[k] = 0u;
     __syncthreads();
-    // the window: 19,936 more words, 227 at a time
-    for (int q = MT_N; q < MT_PAD_INDEX; q += 227) {
-        const int k = q + tid;
-        if (tid < 227 && k < MT_PAD_INDEX) seq[k] = seq[k - (MT_N - MT_M)] ^ mt_twist(seq[k - MT_N], seq[k - MT_N + 1]);
-        __syncthreads();
+    // the window: 19,936 more words = 89 steps of 224 by one wave, its chain in registers (the generation kernel's; 227 lanes with a
+    // barrier per step took 14.5 us); 90 steps, the overhang and the last lanes' garbage zeroed again
+    if (tid < 64) {
+        if ((unsigned)(unsigned long long)seq != 0u) __builtin_trap();         // (the window is the kernel's only LDS object: address 0)
+        unsigned q_b = 4u * (MT_N + 4 * tid);
+        mt_u32x4 A[2], z, tw;
+        mt_regen_start<false>(tid, q_b, z, tw, A[0], A[1]);
+        for (int v = 0; v < 45; ++v) {
+            mt_regen_step<false>(q_b, z, tw, A[1], A[0]);
+            mt_regen_step<false>(q_b, z, tw, A[0], A[1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]) :: "memory");
+        for (int k = MT_PAD_INDEX + tid; k < MT_SEQ_LDS; k += 64) seq[k] = 0u;
     }
+    __syncthreads();
 
     // new[k] = XOR over the set coefficients i of x[i + k], k = 0 .. 623. Every wave holds the whole sum for its share of the groups of
     // 16 exponents: lane l the ten words k = 10 l .. 10 l + 9. For a group 16 g .. 16 g + 15 the lane reads the 26 words from 16 g + 10 l
@@ -212,63 +321,6 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
 // order: behind the write it waited for the write, 64 cycles per step) 71 (the regenerating wave alone 63, without the stores 65).
 // Every wait is bounded: a wave that polls 2^22 times gives up and the output starts with a NaN (it cannot happen: the eight waves of a
 // workgroup are resident together).
-typedef unsigned mt_u32x4 __attribute__((ext_vector_type(4)));
-// LDS accesses of the regenerating wave, written out: their order on the LDS queue and the waits are the algorithm there. (The compiler
-// does not know that a register is in flight between a read and its wait: every use sits behind the wait through the "+v" operands.)
-__device__ __forceinline__ mt_u32x4 mt_lds_read128(unsigned addr) { mt_u32x4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory"); return r; }
-__device__ __forceinline__ void mt_lds_write128(unsigned addr, mt_u32x4 w) { asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
-__device__ __forceinline__ void mt_lds_write32(unsigned addr, unsigned w) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(w) : "memory"); }
-template <int OUTSTANDING> __device__ __forceinline__ void mt_lds_wait(mt_u32x4& r) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(OUTSTANDING) : "memory");
-}
-// byte offsets into the 64 KiB ring wrap as 16-bit sums: one instruction (a 16-bit add clears the upper half of its result on this chip)
-template <int C> __device__ __forceinline__ unsigned mt_add16(unsigned a) { return (a + (unsigned)C) & 0xFFFFu; }
-// One statement for a step's LDS traffic (between separate asm statements the compiler puts a wait state): write w at a, advance a
-// by ADV, read 16 bytes at the new a + C into r. r is a read-write operand: the register of a value in flight stays the variable's
-// register from step to step (a copy of one before its wait would copy what was there before).
-template <int ADV, int C>
-__device__ __forceinline__ void mt_ring_write_advance_read(unsigned& a, mt_u32x4 w, mt_u32x4& r) {
-    unsigned t;
-    asm volatile(
-#if !(DASP_MT_SKIP & 1)
-                 "ds_write_b128 %2, %3\n\t"
-#endif
-                 "v_add_u16 %2, %4, %2\n\tv_add_u16 %1, %5, %2"
-#if !(DASP_MT_SKIP & 4)
-                 "\n\tds_read_b128 %0, %1"
-#endif
-                 : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV & 0xFFFF), "n"(C & 0xFFFF) : "memory");
-}
-// (lane l - 1's `from_below`) ^ b, lane 0 from lane 63 (a rotation of the whole wave)
-__device__ __forceinline__ unsigned mt_xor_ror1(unsigned from_below, unsigned b) {
-    unsigned r;
-    asm("v_xor_b32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from_below), "v"(b));
-    return r;
-}
-// lanes 60 .. 63 of `now` <- lanes 52 .. 55 of `before` (the other lanes stay)
-__device__ __forceinline__ unsigned mt_keep_tail(unsigned now, unsigned before) {
-    asm("v_mov_b32_dpp %0, %1 row_shr:8 row_mask:0x8 bank_mask:0x8" : "+v"(now) : "v"(before));
-    return now;
-}
-// twist(x[k], x[k + 1]) for the lane's four words; x[k + 4] is the next lane's first. 17 instructions: every word is shifted once
-// (it is the upper word of one twist and the lower word of the next), one bit-field insert per twist, the matrix row by a sign
-// extension of bit 0 and one three-operand bit operation.
-__device__ __forceinline__ unsigned mt_bfi(unsigned mask, unsigned from_set, unsigned from_clear) {
-    unsigned r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(from_set), "v"(from_clear));
-    return r;
-}
-__device__ __forceinline__ mt_u32x4 mt_twist4(mt_u32x4 a) {
-    const unsigned a4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane l reads lane l + 1
-    const unsigned s0 = a.x >> 1, s1 = a.y >> 1, s2 = a.z >> 1, s3 = a.w >> 1, s4 = a4 >> 1;
-    mt_u32x4 t;                                        // ((u & 0x80000000 | v & 0x7fffffff) >> 1) ^ (v & 1 ? 0x9908b0df : 0)
-    t.x = mt_bfi(0x3FFFFFFFu, s1, s0) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.y, 0, 1) & 0x9908B0DFu);
-    t.y = mt_bfi(0x3FFFFFFFu, s2, s1) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.z, 0, 1) & 0x9908B0DFu);
-    t.z = mt_bfi(0x3FFFFFFFu, s3, s2) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a.w, 0, 1) & 0x9908B0DFu);
-    t.w = mt_bfi(0x3FFFFFFFu, s4, s3) ^ ((unsigned)__builtin_amdgcn_sbfe((int)a4, 0, 1) & 0x9908B0DFu);
-    return t;
-}
-
 constexpr int MT_CONSUMERS = MT_GEN_THREADS / 64 - 1;
 constexpr int MT_GEN_LDS = 4 * (MT_RING + 4 + MT_CONSUMERS + 1);          // bytes of LDS of a generating workgroup
 constexpr int MT_LEAD = (MT_RING - 47) / MT_STEP;                          // steps the regenerating wave may be ahead of the slowest reader
@@ -320,14 +372,8 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
         if ((unsigned)(unsigned long long)ring != 0u) __builtin_trap();
         static_assert(4 * MT_RING == 65536, "the regenerating wave's addresses are 16-bit sums");
         unsigned q_b = 4u * (MT_N + 4 * lane);                                 // byte offset (wrapped) of the lane's first word of the step
-        mt_u32x4 A[2];                                                         // the x[k - 624] side of the steps of either parity
-        mt_u32x4 a1 = mt_lds_read128(mt_add16<-4 * MT_N>(q_b));                // step 1: x[4 l .. 4 l + 3]
-        // "step 0": the last 224 words of the start state; lane 63: the four words below them (lane 0's, as lane 55 of "step -1" would hold them)
-        mt_u32x4 z = mt_lds_read128(lane == 63 ? 4u * (MT_N - MT_STEP - 4) : mt_add16<-4 * MT_STEP>(q_b));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(z) :: "memory");
-        mt_u32x4 tw = mt_twist4(a1);
-        A[0] = mt_lds_read128(mt_add16<4 * MT_STEP - 4 * MT_N>(q_b));          // step 2's (inside the start state)
-        A[1] = A[0];                                                           // (defined; refilled in step 1)
+        mt_u32x4 A[2], z, tw;                                                  // A: the x[k - 624] side of the steps of either parity
+        mt_regen_start<true>(lane, q_b, z, tw, A[0], A[1]);
         int cleared = 0;                                                       // every step <= cleared has been read
         static_assert(MT_UNIT % 2 == 0, "the registers of steps of one parity alternate inside a unit");
         for (int u = 0; u < n_regen; ++u) {
@@ -343,29 +389,8 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
                 if (spin > (1 << 22)) { gave_up = 1; break; }
             }
 #pragma unroll
-            for (int sub = 0; sub < MT_UNIT; ++sub) {                          // step v = MT_UNIT u + sub + 1, parity p
-                const int p = (sub + 1) & 1;
-                mt_u32x4 w;
-#if DASP_MT_SKIP & 16
-                w = tw;
-#else
-                w.x = mt_xor_ror1(z.y, tw.x);
-                w.y = mt_keep_tail(mt_xor_ror1(z.z, tw.y), z.y);
-                w.z = mt_keep_tail(mt_xor_ror1(z.w, tw.z), z.z);
-                w.w = mt_keep_tail(tw.w ^ z.x, z.w);
-#endif
-                // step v + 1's x[k - 624] side: asked for a step ago. (The wait in FRONT of this step's write: the counter is in order, behind
-                // the write it would wait for the write as well - 64 cycles per step, found with probe builds.)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[p ^ 1]) :: "memory");
-                // the write (lanes 56 .. 63 write into the next step's slots, which that step overwrites); behind it step v + 2's x[k - 624] side
-                mt_ring_write_advance_read<4 * MT_STEP, 4 * MT_STEP - 4 * MT_N>(q_b, w, A[p]);
-#if DASP_MT_SKIP & 8
-                tw = A[p ^ 1];
-#else
-                tw = mt_twist4(A[p ^ 1]);
-#endif
-                z = w;
-            }
+            for (int sub = 0; sub < MT_UNIT; ++sub)                            // step v = MT_UNIT u + sub + 1: its parity's register is refilled
+                mt_regen_step<true>(q_b, z, tw, A[(sub + 1) & 1], A[sub & 1]);
             if (lane == 0) mt_lds_write32(4u * MT_RING, (unsigned)(MT_N + MT_STEP * MT_UNIT * (u + 1)));   // behind the data in this wave's LDS order
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]) :: "memory");
