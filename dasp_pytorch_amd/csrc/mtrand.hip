@@ -113,8 +113,8 @@ __device__ __forceinline__ void mt_ring_write_advance_read(unsigned& a, mt_u32x4
 #endif
                      : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV & 0xFFFF), "n"(C & 0xFFFF) : "memory");
     else
-        asm volatile("ds_write_b128 %2, %3\n\tv_add_u32 %2, %4, %2\n\tv_add_u32 %1, %5, %2\n\tds_read_b128 %0, %1"
-                     : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV), "n"(C) : "memory");
+        asm volatile("ds_write_b128 %2, %3\n\tv_add_u32 %2, %4, %2\n\tv_subrev_u32 %1, %5, %2\n\tds_read_b128 %0, %1"
+                     : "+v"(r), "=&v"(t), "+v"(a) : "v"(w), "n"(ADV), "n"(-C) : "memory");          // (C < 0)
 }
 // (lane l - 1's `from_below`) ^ b, lane 0 from lane 63 (a rotation of the whole wave)
 __device__ __forceinline__ unsigned mt_xor_ror1(unsigned from_below, unsigned b) {
