@@ -7,7 +7,7 @@ normalised parameters (examples/style_transfer.py:150-154; round 4).
 This module loads the library, registers the fake (meta) implementations that torch.compile / AOTAutograd / torch.library.opcheck need
 (output shapes only; the work-buffer sizes come from the C ABI's own size queries), and answers `enabled()` for the call sites in
 ops.py. The ctypes binding stays: it is the binding for every other op, for float64, for bench.py's per-call HIP events, and the
-fallback when the extension is not built (DASP_TORCH_OPS=0 forces it: A/B of the two bindings)."""
+fallback when the extension is not built (config.plan.torch_ops = False forces it: A/B of the two bindings)."""
 import os
 
 import torch

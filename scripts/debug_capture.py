@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1:
     import torch, numpy as np
     import dasp_pytorch_amd as D
+    from dasp_pytorch_amd import config
     mode = sys.argv[1]
+    config.plan.torch_ops = len(sys.argv) > 2 and sys.argv[2] == "1"           # the binding under test (the probe was written for the ctypes one)
     B, C, N = 8, 2, 131072
     g = torch.Generator(device="cuda:0").manual_seed(5)
     xs = (torch.rand(B, C, N, device="cuda:0", generator=g) * 2 - 1).requires_grad_(True)
@@ -54,6 +56,5 @@ if len(sys.argv) > 1:
     print(mode, "ok", float(ys.abs().sum()))
 else:
     for env, mode in [("0", "bwd-none-retain-del"), ("0", "bwd-none-puretorch"), ("0", "bwd-none-once"), ("0", "bwd-none-nobwd")]:
-        e = dict(os.environ, DASP_TORCH_OPS=env)
-        r = subprocess.run([sys.executable, __file__, mode], env=e, capture_output=True, text=True, timeout=300)
-        print("DASP_TORCH_OPS=" + env, mode, "rc", r.returncode, (r.stdout.strip().splitlines() or [""])[-1], "|", [l for l in r.stderr.splitlines() if "Error" in l or "error" in l][:3])
+        r = subprocess.run([sys.executable, __file__, mode, env], capture_output=True, text=True, timeout=300)
+        print("config.plan.torch_ops=" + env, mode, "rc", r.returncode, (r.stdout.strip().splitlines() or [""])[-1], "|", [l for l in r.stderr.splitlines() if "Error" in l or "error" in l][:3])

@@ -3,7 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dasp_pytorch_amd as D
-from dasp_pytorch_amd import _lib
+from dasp_pytorch_amd import _lib, config
 SR = 44100
 R = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
      (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
@@ -28,13 +28,13 @@ def gpu_ms(fn, B, C, N, ranges):
     return {k.replace("dasp_", ""): round(sum(v) / 30, 4) for k, v in t.items()}
 
 
-for name, fn, ranges, key, shapes, tiles in (("parametric_eq", D.parametric_eq, R, "DASP_SOS_SEGMENT_TILES", ((8, 2, 131072), (16, 2, 131072), (32, 2, 131072)), (8, 16, 32, 64)),
-                                             ("compressor", D.compressor, CR, "DASP_DYN_SEGMENT_TILES", ((8, 2, 262144), (16, 2, 262144), (32, 2, 262144)), (16, 32, 64, 128))):
+for name, fn, ranges, key, shapes, tiles in (("parametric_eq", D.parametric_eq, R, "sos_segment_tiles", ((8, 2, 131072), (16, 2, 131072), (32, 2, 131072)), (8, 16, 32, 64)),
+                                             ("compressor", D.compressor, CR, "dyn_segment_tiles", ((8, 2, 262144), (16, 2, 262144), (32, 2, 262144)), (16, 32, 64, 128))):
     for shp in shapes:
         for t in tiles:
-            os.environ[key] = str(t)
+            setattr(config.plan, key, t)
             r = gpu_ms(fn, *shp, ranges)
             print(name, shp, "tiles per segment", t, "total %.4f ms" % sum(r.values()), r, flush=True)
-        os.environ.pop(key)
+        setattr(config.plan, key, None)
         r = gpu_ms(fn, *shp, ranges)
         print(name, shp, "planner", "total %.4f ms" % sum(r.values()), flush=True)

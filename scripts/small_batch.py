@@ -1,9 +1,10 @@
-"""Developer timing: parametric_eq forward + backward at small batches, plain rows vs segmented rows (DASP_SOS_SEGMENT=0 / 1),
+"""Developer timing: parametric_eq forward + backward at small batches, plain rows vs segmented rows (config.plan.sos_segment False / True),
 plus the difference of the two paths' results."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dasp_pytorch_amd as D
+from dasp_pytorch_amd import config
 SR = 44100
 R = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
      (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
@@ -11,7 +12,7 @@ g = torch.Generator(device="cuda:0").manual_seed(0)
 
 
 def run(B, C, N, force_plain):
-    os.environ["DASP_SOS_SEGMENT"] = "0" if force_plain else "1"
+    config.plan.sos_segment = not force_plain
     x = (torch.rand(B, C, N, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1)) * 2 - 1).requires_grad_(True)
     gg = torch.Generator(device="cuda:0").manual_seed(2)
     cols = [(torch.rand(B, device="cuda:0", generator=gg) * (hi - lo) + lo).requires_grad_(True) for lo, hi in R]
@@ -44,7 +45,7 @@ for B, C, N in ((4, 2, 131072), (16, 2, 131072), (16, 1, 131072), (32, 2, 131072
 # GPU-side times of the entry points (HIP events around every call; the wall times above are launch-bound at these sizes)
 from dasp_pytorch_amd import _lib
 for force_plain in (True, False):
-    os.environ["DASP_SOS_SEGMENT"] = "0" if force_plain else "1"
+    config.plan.sos_segment = not force_plain
     B, C, N = 16, 2, 131072
     x = (torch.rand(B, C, N, device="cuda:0") * 2 - 1).requires_grad_(True)
     cols = [(torch.rand(B, device="cuda:0") * (hi - lo) + lo).requires_grad_(True) for lo, hi in R]

@@ -1,10 +1,10 @@
 """Developer timing (GPU time of the library calls, HIP events): the EQ, the compressor and the reverb at the reference's training batch
-sizes, one workgroup per row / item (DASP_*_SEGMENT=0) against the segmented default, next to the per-sample time of the full batch."""
+sizes, one workgroup per row / item (config.plan.*_segment = False) against the segmented default, next to the per-sample time of the full batch."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dasp_pytorch_amd as D
-from dasp_pytorch_amd import _lib
+from dasp_pytorch_amd import _lib, config
 SR = 44100
 R = [(-20, 20), (20, 2000), (0.1, 6), (-20, 20), (80, 2000), (0.1, 6), (-20, 20), (2000, 8000), (0.1, 6),
      (-20, 20), (8000, 12000), (0.1, 6), (-20, 20), (12000, 21050), (0.1, 6), (-20, 20), (4000, 21050), (0.1, 6)]
@@ -14,8 +14,7 @@ rnd = lambda *s: torch.rand(*s, device="cuda:0", generator=g)
 
 
 def gpu_ms(fn, B, C, N, ranges, env):
-    for k in ("DASP_SOS_SEGMENT", "DASP_DYN_SEGMENT"):
-        os.environ[k] = env
+    config.plan.sos_segment = config.plan.dyn_segment = env != "0"
     x = (rnd(B, C, N) * 2 - 1).requires_grad_(True)
     cols = [(rnd(B) * (hi - lo) + lo).requires_grad_(True) for lo, hi in ranges]
     w = torch.randn(B, C, N, device="cuda:0", generator=g)

@@ -186,7 +186,7 @@ def test_style_transfer_chain_folds_the_gain(D):
 
 def test_chain_controls_in_one_launch_equal_the_torch_ops(D, monkeypatch):
     """The chain de-normalises the compressor's, the reverb's and the gain's parameters and folds the gain in one launch per direction
-    (dasp_chain_controls / ops.ChainControlsFunction); with DASP_CHAIN_FUSED_CONTROLS=0 the same is done by torch ops on the tensors.
+    (dasp_chain_controls / ops.ChainControlsFunction); with config.plan.chain_fused_controls = False the same is done by torch ops on the tensors.
     Mono input (the reference's training shape), outputs and all 50 parameter gradients; the release_ms column gets an exact zero."""
     from dasp_pytorch_amd.chain import StyleTransferChain
     g = torch.Generator(device="cuda:0").manual_seed(9)
