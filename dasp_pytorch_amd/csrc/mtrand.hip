@@ -532,13 +532,13 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
             if (dev >= 0 && dev < 64) asked[dev].store(true, std::memory_order_release);
         }
     }
-    // Several workgroups per jump where that is fewer rounds x time: a workgroup with 1/k of a jump's groups takes ~14.5 + 67.5 / k us (the
-    // window it regenerates first is the 14.5; measured 82 / 37 / 21 us at k = 1 / 3 / 8), one workgroup per CU at a time (83 KiB of LDS).
+    // Several workgroups per jump where that is fewer rounds x time: a workgroup with 1/k of a jump's groups takes ~9.5 + 52.5 / k us (the
+    // window it regenerates first is the 9.5; measured 62 / 27 / 16 us at k = 1 / 3 / 8), one workgroup per CU at a time (83 KiB of LDS).
     auto parts_for = [](int jobs) {
         int best = 1;
         float best_t = 1e30f;
         for (int k = 1; k <= 8; ++k) {
-            const float t = (float)((jobs * k + 255) / 256) * (14.5f + 67.5f / (float)k);
+            const float t = (float)((jobs * k + 255) / 256) * (9.5f + 52.5f / (float)k);
             if (t < best_t - 0.5f) { best_t = t; best = k; }
         }
         return best;
