@@ -158,8 +158,8 @@ def check(status, what):
         for hook in on_failure:
             hook()
         kind = {-1: "invalid argument", -2: "unsupported configuration",
-                -3: "DASP_ERR_DEVICE: a kernel of an EARLIER segmented call on this device gave up waiting for a look-back word and wrote NaN "
-                    f"(family bits {lib().dasp_device_error():#x}: 1 EQ forward, 2 EQ backward, 4 dynamics forward, 8 dynamics backward); results since then "
+                -3: "DASP_ERR_DEVICE: a kernel of an EARLIER call on this device gave up waiting for a word from another workgroup or wave and wrote NaN "
+                    f"(family bits {lib().dasp_device_error():#x}: 1 EQ forward, 2 EQ backward, 4 dynamics forward, 8 dynamics backward, 32 random stream); results since then "
                     "are not to be trusted. dasp_pytorch_amd.config.plan.lookback = False selects the two-launch forms; _lib.lib().dasp_device_error_clear() re-arms"
                 }.get(status, f"hipError {status}")
         raise DaspHipError(f"{what} failed: {kind}")

@@ -315,6 +315,9 @@ def randn_cpu_stream(*size, device, defer=False):
     if not enabled or n < 16 or torch.get_default_dtype() != torch.float32 or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
         return host()
     if _self_check.get(dev) is None:
+        from . import _lib
+        with torch.cuda.device(dev):
+            _lib.check(-3 if _lib.lib().dasp_device_error() else 0, "dasp_mt_randn")       # (a pending device error is not a failed self-check)
         _self_check[dev] = _run_self_check(dev)
         if not _self_check[dev]:
             import warnings

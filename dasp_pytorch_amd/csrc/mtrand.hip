@@ -319,8 +319,8 @@ __device__ __forceinline__ void mt_sincos(float a, float& s, float& c) {
 // LDS round trip per step); the chain in registers 85; x[k - 624] side asked for a step ahead, 16-bit address sums 78; lane 0's words
 // by the rotation instead of an LDS read and - the larger part - the wait moved in front of the step's write (the LDS counter is in
 // order: behind the write it waited for the write, 64 cycles per step) 71 (the regenerating wave alone 63, without the stores 65).
-// Every wait is bounded: a wave that polls 2^22 times gives up and the output starts with a NaN (it cannot happen: the eight waves of a
-// workgroup are resident together).
+// Every wait is bounded: a wave that polls 2^22 times gives up, the output starts with a NaN and the device error word of this family is
+// set - the next call returns DASP_ERR_DEVICE (it cannot happen: the eight waves of a workgroup are resident together).
 constexpr int MT_CONSUMERS = MT_GEN_THREADS / 64 - 1;
 constexpr int MT_GEN_LDS = 4 * (MT_RING + 4 + MT_CONSUMERS + 1);          // bytes of LDS of a generating workgroup
 constexpr int MT_LEAD = (MT_RING - 47) / MT_STEP;                          // steps the regenerating wave may be ahead of the slowest reader
@@ -333,7 +333,7 @@ __device__ __forceinline__ int mt_step_end(int v, int q_end) { const int e = MT_
 
 __global__ void __launch_bounds__(MT_GEN_THREADS)
 mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out, long long n, int rem, long long beta_max,
-                   unsigned* __restrict__ final_state, float* __restrict__ tail_u, int bpc) {
+                   unsigned* __restrict__ final_state, float* __restrict__ tail_u, int bpc, unsigned* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned ring[];       // MT_RING words (64 KiB: asked for at the launch) and the words below
     int& avail = *reinterpret_cast<int*>(ring + MT_RING);                  // words [0, avail) of the chunk exist
     int& next_unit = *reinterpret_cast<int*>(ring + MT_RING + 1);          // the next unit to claim
@@ -442,7 +442,10 @@ mt_generate_kernel(const unsigned* __restrict__ states, float* __restrict__ out,
         }
     }
     __syncthreads();
-    if (gave_up && tid == 0) out[0] = __builtin_nanf("");
+    if (gave_up && tid == 0) {                                                 // (a sticky device error as for the look-back words: common.hpp)
+        out[0] = __builtin_nanf("");
+        if (err) __hip_atomic_store(err + DASP_DEVERR_MT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (c == gridDim.x - 1 && nblk > 0)
         for (int k = tid; k < MT_N; k += MT_GEN_THREADS) final_state[k] = ring[(MT_N * nblk + k) & (MT_RING - 1)];
 }
@@ -512,6 +515,8 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
     if (!state_host || !out || !table || !scratch || left < 1 || left > MT_N || n < 16) return DASP_ERR_ARG;
     const MtPlan p = mt_plan(left, n);
     if ((long long)p.stride * (p.n_chunks - 1) >= (MT_N_GIANT + 1) * (MT_N_BABY + 1)) return DASP_ERR_UNSUPPORTED;
+    if (error_pending()) return DASP_ERR_DEVICE;                               // a wait that gave up in an earlier launch (sticky: dasp_device_error_clear)
+    unsigned* err = error_words_device();
     hipStream_t st = (hipStream_t)stream;
     unsigned* states = scratch;
     unsigned* final_state = scratch + (size_t)(p.n_chunks + MT_N_GIANT) * MT_N;
@@ -553,7 +558,7 @@ int dasp_mt_randn(const unsigned* state_host, int left, float* out, long long n,
         hipLaunchKernelGGL(mt_jump_kernel, dim3(jobs * k), dim3(MT_JUMP_THREADS), MT_SEQ_LDS * 4, st, states, table, 0, p.n_chunks, k, p.stride);
     }
     hipLaunchKernelGGL(mt_generate_kernel, dim3(p.n_chunks), dim3(MT_GEN_THREADS), MT_GEN_LDS, st, states, out, n, left - 1, p.beta_max, final_state, tail_u,
-                       MT_BLOCKS_PER_CHUNK * p.stride);
+                       MT_BLOCKS_PER_CHUNK * p.stride, err);
     if (n & 15) hipLaunchKernelGGL(mt_tail_kernel, dim3(1), dim3(64), 0, st, tail_u, out, n);
     if (left_after) *left_after = p.left_after;
     if (regenerated) *regenerated = p.beta_max > 0;

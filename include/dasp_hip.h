@@ -32,7 +32,8 @@ unsigned long long dasp_abi_hash(void);
  * The words live in 64 bytes of host-mapped memory per device (one allocation, made by the first call of dasp_device_error() or of a
  * segmented entry point on that device - call dasp_device_error() once before capturing a graph); nothing is copied or polled on the
  * fast path. While a bit is set every segmented entry point returns DASP_ERR_DEVICE instead of launching.
- *   dasp_device_error()        bits of the current device: 1 EQ forward, 2 EQ backward, 4 compressor/expander forward, 8 backward, 16 test
+ *   dasp_device_error()        bits of the current device: 1 EQ forward, 2 EQ backward, 4 compressor/expander forward, 8 backward, 16 test,
+ *                              32 the random stream's generation kernel (a wave of its pipeline gave up waiting; dasp_mt_randn checks too)
  *   dasp_device_error_clear()  re-arm
  *   dasp_plan_lookback(on)     1 (default): the one-launch look-back forms where they apply; 0: the two-launch forms (pre-pass + pass) -
  *                              no workgroup ever waits for another; < 0: query. Returns the setting.

@@ -144,6 +144,8 @@ def test_a_word_that_never_arrives_is_an_error_not_a_silent_nan(D, L):
     from dasp_pytorch_amd import _lib
     x, w, ctl = _inputs(8, 2, 262144, DYN_RANGES, 6)
     good = _step(D.compressor, x, w, ctl)
+    from dasp_pytorch_amd import _mt19937
+    _mt19937.randn_cpu_stream(2, 12, 5000, device=DEV)         # (its once-per-device self-check, while the device is healthy)
     zero = torch.zeros(2, dtype=torch.int32, device=DEV)
     out = torch.zeros(1, device=DEV)
     assert L.dasp_device_error() == 0
@@ -157,6 +159,12 @@ def test_a_word_that_never_arrives_is_an_error_not_a_silent_nan(D, L):
             xx, ww, cc = (x, w, ctl) if fn is D.compressor else _inputs(16, 2, 131072, PEQ_RANGES, 7)
             with pytest.raises(RuntimeError, match="DASP_ERR_DEVICE"):
                 fn(xx, SR, *cc)
+        assert _mt19937._self_check.get(torch.device(DEV)) is True           # the random stream's pipeline waits inside a workgroup: same sticky error
+        torch.manual_seed(0)
+        s_before = torch.get_rng_state()
+        with pytest.raises(RuntimeError, match="DASP_ERR_DEVICE"):
+            _mt19937.randn_cpu_stream(2, 12, 5000, device=DEV)
+        assert torch.equal(torch.get_rng_state(), s_before)    # (the generator is left where it was)
         with config.override(lookback=False):                  # the two-launch forms do not look back: they still run
             two = _step(D.compressor, x, w, ctl)
         assert float((two[0] - good[0]).abs().max()) <= 2e-6 * float(good[0].abs().max())
