@@ -324,7 +324,7 @@ __device__ __forceinline__ void mbox_wait(float* lds, int slot, int seq, float& 
 // broken - a scratch buffer overwritten under the launch, a workgroup that died: the reader stores 1 into the device error word of its
 // kernel family (host-mapped memory, csrc/runtime.hip) and carries on with NaN. The next segmented call on that device returns
 // DASP_ERR_DEVICE instead of launching (sticky until dasp_device_error_clear) - loud one call late, never a silent NaN (round 5).
-enum { DASP_DEVERR_SOS_FWD = 0, DASP_DEVERR_SOS_BWD = 1, DASP_DEVERR_DYN_FWD = 2, DASP_DEVERR_DYN_BWD = 3, DASP_DEVERR_TEST = 4, DASP_DEVERR_MT = 5,
+enum { DASP_DEVERR_SOS_FWD = 0, DASP_DEVERR_SOS_BWD = 1, DASP_DEVERR_DYN_FWD = 2, DASP_DEVERR_DYN_BWD = 3, DASP_DEVERR_TEST = 4,
        DASP_DEVERR_TIMEOUT_SLOT = 15, DASP_DEVERR_WORDS = 16 };
 unsigned* error_words_device();      // device view of the current device's 16 words (runtime.hip; allocated on first use, before any capture)
 int error_pending();                 // OR of the error words of the current device as the host sees them

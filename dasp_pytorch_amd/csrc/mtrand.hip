@@ -27,6 +27,7 @@ namespace dasp {
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
+constexpr int DASP_DEVERR_MT = 5;                      // this file's word among the device error words (common.hpp: 0 .. 4 are the look-back families)
 constexpr int MT_BLOCKS_PER_CHUNK = 256;               // regenerations per unit; a chunk is `stride` units (mt_plan)
 constexpr int MT_N_BABY = 255, MT_N_GIANT = 7;
 constexpr int MT_GROUP = 16;                           // exponents per group of a jump polynomial: one uint16 of coefficient bits
