@@ -150,7 +150,7 @@ def lib():
 
 
 
-on_failure = []          # callables run when an entry point fails (ops.py: the cached completion counters may hold a count - drop them)
+on_failure = []          # callables run when an entry point fails (_ctypes_ops.py: the cached completion counters may hold a count - drop them)
 
 
 def check(status, what):

@@ -5,7 +5,7 @@ to be known before anything is imported. Tests set these with `monkeypatch.setat
 
     sos_segment / dyn_segment / chain_segment     False: never cut rows / items into segments (one workgroup per row / item)
     *_segment_tiles                               tiles per segment instead of the library planner's choice (None = the planner)
-    torch_ops                                     False: the ctypes autograd binding (ops.py) instead of torch.ops.dasp.* (csrc/torch_ext)
+    torch_ops                                     False: the ctypes autograd binding (_ctypes_ops.py) instead of torch.ops.dasp.* (csrc/torch_ext)
     chain_fused_controls / chain_fused_forward    False: StyleTransferChain without its fused control launch / fused no-grad EQ + compressor pass
     chain_fused_grad                              the EQ -> compressor forward of the pass WITH gradients as one launch that saves for both
                                                   backward passes: None = from 384 rows (192 stereo items) on, where it wins, True = always, False = never
