@@ -34,10 +34,10 @@ DEG = 19937
 MATRIX_A = 0x9908B0DF
 
 # layout constants shared with csrc/mtrand.hip (dasp_mt_layout() reports the kernel's side; the binding compares)
-BLOCKS_PER_CHUNK = 256                  # a chunk = this many regenerations = 159,744 words, one workgroup of the generation kernel
-JUMP = N * BLOCKS_PER_CHUNK             # words between the start states of neighbouring chunks
-N_BABY = 255                            # t^(b J), b = 1 .. 255: chunk a*256 + b from chunk a*256
-N_GIANT = 7                             # t^(a 256 J), a = 1 .. 7: chunk a*256 from chunk 0  => at most 2048 chunks (327 M draws) per call
+BLOCKS_PER_CHUNK = 256                  # a unit = this many regenerations = 159,744 words; a chunk (one workgroup of the generation kernel) = 1 .. 8 units
+JUMP = N * BLOCKS_PER_CHUNK             # words per unit: the jump polynomials are powers of t^JUMP
+N_BABY = 255                            # t^(b J), b = 1 .. 255: the state 256 a + b units on from the state 256 a units on
+N_GIANT = 7                             # t^(a 256 J), a = 1 .. 7: the state 256 a units on from the start state  => at most 2048 units (327 M draws) per call
 GROUP = 16                              # exponents per group: bit s of uint16 g of a row = coefficient of t^(16 g + s)
 ROW = 1280                              # uint16 per polynomial: 1,247 groups, padded with zeros
 PAD_INDEX = 20560                       # first word behind the sequence window of a jump (19937 + 623): the kernel keeps zeros there

@@ -189,7 +189,7 @@ __device__ __forceinline__ void mt_regen_start(int lane, unsigned q_b, mt_u32x4&
 // giant: src = chunk 0, polynomial N_BABY + blockIdx (t^(256 (blockIdx + 1) J)), dst = giants[blockIdx] (behind the chunks' states);
 // baby: chunk blockIdx + 1: src = giants[a - 1] (a = 0: chunk 0), polynomial b - 1 (t^(b J)); b = 0: a copy. Word 0 of a jumped state is
 // right in its top bit only - the one bit of it the recurrence reads. `parts` workgroups share a jump when there are fewer jumps than
-// CUs (each takes every parts-th batch of the exponent lists; blockIdx = jump * parts + part).
+// CUs (each takes a share of the groups of exponents; blockIdx = jump * parts + part).
 __global__ void __launch_bounds__(MT_JUMP_THREADS)
 mt_jump_kernel(unsigned* __restrict__ states, const unsigned short* __restrict__ table, int giant, int n_chunks, int parts, int stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned seq[];
